@@ -1,0 +1,107 @@
+"""Randomized graphs/reads for differential tests (adversarial: low-complexity sequences, near-identical
+branches, short nodes, N bases, indels)."""
+import random
+
+
+def rand_seq(rng, n, mode=None):
+    mode = mode if mode is not None else rng.choice(["rand", "rand", "period", "homo", "two"])
+    if mode == "rand":
+        return "".join(rng.choice("ACGT") for _ in range(n))
+    if mode == "homo":
+        return rng.choice("ACGT") * n
+    if mode == "two":
+        ab = rng.sample("ACGT", 2)
+        return "".join(rng.choice(ab) for _ in range(n))
+    p = rng.randint(1, 4)
+    unit = "".join(rng.choice("ACGT") for _ in range(p))
+    return (unit * (n // p + 1))[:n]
+
+
+def mutate(rng, s, sub=0.03, indel=0.01, nrate=0.0):
+    out = []
+    for c in s:
+        u = rng.random()
+        if u < indel / 2:
+            continue
+        if u < indel:
+            out.append(rng.choice("ACGT"))
+        if rng.random() < sub:
+            c = rng.choice("ACGT")
+        if nrate and rng.random() < nrate:
+            c = "N"
+        out.append(c)
+    return "".join(out)
+
+
+def rand_graph(rng, max_nodes=7, max_len=40, shape=None):
+    """Returns (node_seqs, edges). Node ids are topologically ordered."""
+    shape = shape or rng.choice(["del", "ins", "bubble", "dag", "dag", "chain", "longdel"])
+    if shape in ("del", "ins"):
+        lens = [rng.randint(1, max_len) for _ in range(3)]
+        seqs = [rand_seq(rng, n) for n in lens]
+        return seqs, [(0, 1), (0, 2), (1, 2)]
+    if shape == "bubble":
+        a = rand_seq(rng, rng.randint(1, max_len))
+        b = mutate(rng, a, sub=0.1, indel=0.05) or "A"
+        return [rand_seq(rng, rng.randint(1, max_len)), a, b, rand_seq(rng, rng.randint(1, max_len))], \
+            [(0, 1), (0, 2), (1, 3), (2, 3)] + ([(0, 3)] if rng.random() < 0.5 else [])
+    if shape == "chain":
+        n = rng.randint(1, max_nodes)
+        return [rand_seq(rng, rng.randint(1, max_len)) for _ in range(n)], [(i, i + 1) for i in range(n - 1)]
+    if shape == "longdel":
+        seqs = ["X"] + [rand_seq(rng, rng.randint(1, max_len)) for _ in range(4)] + ["X"]
+        return seqs, [(0, 1), (0, 3), (1, 4), (1, 2), (3, 4), (3, 5), (4, 5)]
+    n = rng.randint(2, max_nodes)
+    mode = rng.choice([None, None, "homo", "period"])
+    seqs = [rand_seq(rng, rng.randint(1, max_len), mode) for _ in range(n)]
+    edges = set()
+    for t in range(1, n):
+        k = rng.randint(0 if rng.random() < 0.15 else 1, min(t, 3))
+        for f in rng.sample(range(t), k):
+            edges.add((f, t))
+    return seqs, sorted(edges)
+
+
+def rand_path_seq(rng, seqs, edges):
+    succ = {}
+    for f, t in edges:
+        succ.setdefault(f, []).append(t)
+    cur = rng.randrange(len(seqs))
+    out = [seqs[cur]]
+    while cur in succ and rng.random() < 0.9:
+        cur = rng.choice(succ[cur])
+        out.append(seqs[cur])
+    return "".join(out)
+
+
+def rand_read(rng, seqs, edges, min_len=8, max_len=120):
+    kind = rng.random()
+    L = rng.randint(min_len, max_len)
+    if kind < 0.08:
+        r = rand_seq(rng, L)
+    else:
+        p = rand_path_seq(rng, seqs, edges).replace("X", "")
+        if len(p) < 2:
+            p = rand_seq(rng, L)
+        st = rng.randrange(max(1, len(p) - 1))
+        r = p[st:st + L]
+        r = mutate(rng, r, sub=rng.choice([0.0, 0.02, 0.1]), indel=rng.choice([0.0, 0.0, 0.02, 0.08]),
+                   nrate=rng.choice([0.0, 0.0, 0.0, 0.05]))
+        if rng.random() < 0.3:  # soft-clipped ends
+            r = rand_seq(rng, rng.randint(0, 10)) + r + rand_seq(rng, rng.randint(0, 10))
+    if not r:
+        r = "A"
+    if rng.random() < 0.5:
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+        r = "".join(comp.get(c, "N") for c in reversed(r))
+    if rng.random() < 0.02:
+        r = r.lower()
+    return r
+
+
+def cases(seed, n_graphs, reads_per_graph, **kw):
+    rng = random.Random(seed)
+    for _ in range(n_graphs):
+        seqs, edges = rand_graph(rng, **kw)
+        reads = [rand_read(rng, seqs, edges) for _ in range(reads_per_graph)]
+        yield seqs, edges, reads

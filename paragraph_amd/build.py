@@ -1,0 +1,49 @@
+"""Builds the in-tree native artefacts (hipcc cross-compiles gfx950 without a GPU)."""
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+LIB = os.path.join(_HERE, "libparagraph_amd.so")
+HIP_SOURCES = ["pg_api.hip", "pg_fill.hip", "pg_trace.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_hip(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> paragraph_amd/libparagraph_amd.so (the C-ABI library)."""
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("pg_device.h", "pg_kernels.h")] + \
+        [os.path.join(ROOT, "include", "paragraph_amd.h")]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + srcs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+def build_oracle(verbose=False):
+    """Test infrastructure: the plain-C restatement, and (only where /root/reference exists) the
+    reference's own gssw.c behind oracle/ref_harness.c.  Building the checker is not using it."""
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.run(["make", "-C", odir, "port"], check=True, stdout=None if verbose else subprocess.DEVNULL)
+    subprocess.run(["make", "-C", odir, "ref"], check=True, stdout=None if verbose else subprocess.DEVNULL)
+
+
+def build_all(force=False, verbose=False):
+    build_hip(force=force, verbose=verbose)
+    build_oracle(verbose=verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,297 @@
+"""ctypes binding of the C ABI in include/paragraph_amd.h (libparagraph_amd.so, HIP/gfx950).
+
+This module is plumbing only: it never computes an alignment itself and has no CPU fallback --
+if the shared library is missing or no HIP device is usable, it raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libparagraph_amd.so")
+
+AF_CIGAR = 1
+AF_BOTH_STRANDS = 2
+AF_REVERSE_GRAPH = 4
+AF_ALL = 0xFFFFFFFF
+
+PG_OK = 0
+STATUS_NAMES = {0: "PG_OK", 1: "PG_ERR_INVALID", 2: "PG_ERR_NO_DEVICE", 3: "PG_ERR_HIP", 4: "PG_ERR_UNSUPPORTED",
+                5: "PG_ERR_NOMEM", 6: "PG_ERR_OVERFLOW"}
+
+# numpy mirror of struct pg_result (24 bytes)
+RESULT_DTYPE = np.dtype([
+    ("graph_pos", "<i4"), ("score", "<i2"), ("mapq", "u1"), ("is_unique", "u1"), ("returned_reverse", "u1"),
+    ("multi_mask", "u1"), ("n_ops", "<u2"), ("ops_off", "<u4"), ("strand_score", "<i2", (2,)), ("clipped", "<u2"),
+    ("status", "<u2"),
+], align=True)
+assert RESULT_DTYPE.itemsize == 24, RESULT_DTYPE.itemsize
+
+OP_CHARS = "MXNIDS"
+
+EXPORTS = [
+    "pg_ctx_create", "pg_ctx_destroy", "pg_strerror", "pg_last_error", "pg_ctx_set_workspace_bytes", "pg_ctx_sync",
+    "pg_ctx_timing_enable", "pg_ctx_timing_reset", "pg_ctx_timing_get", "pg_graphs_upload", "pg_graphs_destroy",
+    "pg_batch_create", "pg_batch_destroy", "pg_batch_upload", "pg_batch_align", "pg_batch_ops_count",
+    "pg_batch_download", "pg_align_batch", "pg_render_cigar",
+]
+
+
+class Timing(C.Structure):
+    _fields_ = [("fill_ms", C.c_double), ("trace_ms", C.c_double), ("fill_launches", C.c_uint64),
+                ("trace_launches", C.c_uint64), ("fills", C.c_uint64), ("cells", C.c_uint64),
+                ("trace_bytes", C.c_uint64)]
+
+
+class PgError(RuntimeError):
+    def __init__(self, status, msg=""):
+        self.status = status
+        super().__init__("%s (%d)%s" % (STATUS_NAMES.get(status, "?"), status, ": " + msg if msg else ""))
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libparagraph_amd.so (raises if it has not been built: there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    u32p = C.POINTER(C.c_uint32)
+    vp = C.c_void_p
+    L.pg_ctx_create.restype = C.c_int32
+    L.pg_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.pg_ctx_destroy.restype = None
+    L.pg_ctx_destroy.argtypes = [vp]
+    L.pg_strerror.restype = C.c_char_p
+    L.pg_strerror.argtypes = [C.c_int32]
+    L.pg_last_error.restype = C.c_char_p
+    L.pg_last_error.argtypes = [vp]
+    L.pg_ctx_set_workspace_bytes.restype = C.c_int32
+    L.pg_ctx_set_workspace_bytes.argtypes = [vp, C.c_uint64]
+    L.pg_ctx_sync.restype = C.c_int32
+    L.pg_ctx_sync.argtypes = [vp]
+    L.pg_ctx_timing_enable.restype = C.c_int32
+    L.pg_ctx_timing_enable.argtypes = [vp, C.c_int]
+    L.pg_ctx_timing_reset.restype = C.c_int32
+    L.pg_ctx_timing_reset.argtypes = [vp]
+    L.pg_ctx_timing_get.restype = C.c_int32
+    L.pg_ctx_timing_get.argtypes = [vp, C.POINTER(Timing)]
+    L.pg_graphs_upload.restype = C.c_int32
+    L.pg_graphs_upload.argtypes = [vp, C.c_uint32, u32p, u32p, C.c_char_p, u32p, u32p, C.POINTER(vp)]
+    L.pg_graphs_destroy.restype = None
+    L.pg_graphs_destroy.argtypes = [vp, vp]
+    L.pg_batch_create.restype = C.c_int32
+    L.pg_batch_create.argtypes = [vp, C.POINTER(vp)]
+    L.pg_batch_destroy.restype = None
+    L.pg_batch_destroy.argtypes = [vp, vp]
+    L.pg_batch_upload.restype = C.c_int32
+    L.pg_batch_upload.argtypes = [vp, vp, vp, C.c_uint32, u32p, u32p, C.c_char_p]
+    L.pg_batch_align.restype = C.c_int32
+    L.pg_batch_align.argtypes = [vp, vp, C.c_uint32]
+    L.pg_batch_ops_count.restype = C.c_int32
+    L.pg_batch_ops_count.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
+    L.pg_batch_download.restype = C.c_int32
+    L.pg_batch_download.argtypes = [vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.pg_align_batch.restype = C.c_int32
+    L.pg_align_batch.argtypes = [vp, vp, C.c_uint32, u32p, u32p, C.c_char_p, C.c_uint32, vp, vp, C.c_uint64,
+                                 C.POINTER(C.c_uint64)]
+    L.pg_render_cigar.restype = C.c_size_t
+    L.pg_render_cigar.argtypes = [vp, vp, C.c_char_p, C.c_size_t]
+    _lib = L
+    return L
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _p32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def graphs_csr(graphs):
+    """graphs: list of (node_seqs, edges) -> CSR arrays for pg_graphs_upload."""
+    node_off = [0]
+    seq_off = [0]
+    seqs = []
+    pred_off = [0]
+    pred = []
+    for node_seqs, edges in graphs:
+        n = len(node_seqs)
+        preds = [[] for _ in range(n)]
+        for f, t in edges:
+            if not (0 <= f < t < n):
+                raise ValueError("edge (%d,%d) breaks topological order" % (f, t))
+            preds[t].append(f)
+        for i, s in enumerate(node_seqs):
+            seqs.append(s)
+            seq_off.append(seq_off[-1] + len(s))
+            ps = sorted(set(preds[i]))
+            pred.extend(ps)
+            pred_off.append(len(pred))
+        node_off.append(node_off[-1] + n)
+    return (_u32(node_off), _u32(seq_off), "".join(seqs).encode("ascii"), _u32(pred_off),
+            _u32(pred if pred else [0]))
+
+
+def pack_reads(reads):
+    """list[str] or (offsets, bytes) -> (uint32 offsets[n+1], bytes)."""
+    if isinstance(reads, tuple):
+        return _u32(reads[0]), reads[1]
+    lens = np.fromiter((len(r) for r in reads), dtype=np.int64, count=len(reads))
+    off = np.zeros(len(reads) + 1, dtype=np.uint32)
+    np.cumsum(lens, out=off[1:])
+    return off, "".join(reads).encode("ascii")
+
+
+class Context:
+    """One pg_ctx (one device, one stream)."""
+
+    def __init__(self, device=0, workspace_bytes=None):
+        self.L = load_library()
+        h = C.c_void_p()
+        st = self.L.pg_ctx_create(device, C.byref(h))
+        if st != PG_OK:
+            raise PgError(st, "pg_ctx_create(device=%d)" % device)
+        self.h = h
+        if workspace_bytes:
+            self._chk(self.L.pg_ctx_set_workspace_bytes(self.h, workspace_bytes))
+
+    def _chk(self, st):
+        if st != PG_OK:
+            raise PgError(st, (self.L.pg_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if self.h:
+            self.L.pg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._chk(self.L.pg_ctx_sync(self.h))
+
+    def timing_enable(self, on=True):
+        self._chk(self.L.pg_ctx_timing_enable(self.h, 1 if on else 0))
+
+    def timing_reset(self):
+        self._chk(self.L.pg_ctx_timing_reset(self.h))
+
+    def timing(self):
+        t = Timing()
+        self._chk(self.L.pg_ctx_timing_get(self.h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in Timing._fields_}
+
+    def upload_graphs(self, graphs):
+        return Graphs(self, graphs)
+
+    def new_batch(self):
+        return Batch(self)
+
+
+class Graphs:
+    def __init__(self, ctx, graphs):
+        self.ctx = ctx
+        self.n = len(graphs)
+        node_off, seq_off, seq, pred_off, pred = graphs_csr(graphs)
+        h = C.c_void_p()
+        ctx._chk(ctx.L.pg_graphs_upload(ctx.h, self.n, _p32(node_off), _p32(seq_off), seq, _p32(pred_off),
+                                        _p32(pred), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.L.pg_graphs_destroy(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._chk(ctx.L.pg_batch_create(ctx.h, C.byref(h)))
+        self.h = h
+        self.n_reads = 0
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.L.pg_batch_destroy(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, graphs, reads, graph_of_read=None):
+        off, bases = pack_reads(reads)
+        n = len(off) - 1
+        gor = _u32(np.zeros(n, dtype=np.uint32) if graph_of_read is None else graph_of_read)
+        if len(gor) != n:
+            raise ValueError("graph_of_read length mismatch")
+        self._graphs = graphs
+        self.ctx._chk(self.ctx.L.pg_batch_upload(self.ctx.h, self.h, graphs.h, n, _p32(gor), _p32(off), bases))
+        self.n_reads = n
+
+    def align(self, flags=AF_ALL):
+        self.ctx._chk(self.ctx.L.pg_batch_align(self.ctx.h, self.h, flags & 0xFFFFFFFF))
+
+    def download(self):
+        cnt = C.c_uint64()
+        self.ctx._chk(self.ctx.L.pg_batch_ops_count(self.ctx.h, self.h, C.byref(cnt)))
+        res = np.zeros(max(self.n_reads, 1), dtype=RESULT_DTYPE)
+        ops = np.zeros(max(cnt.value, 1), dtype=np.uint32)
+        got = C.c_uint64()
+        self.ctx._chk(self.ctx.L.pg_batch_download(self.ctx.h, self.h, res.ctypes.data, ops.ctypes.data, len(ops),
+                                                   C.byref(got)))
+        return res[:self.n_reads], ops[:got.value]
+
+
+def render_cigar(res_row, ops):
+    """'<node>[<len><op>...]...' exactly as GraphAlignerImpl::extractCigar prints it."""
+    out = []
+    cur = None
+    o0 = int(res_row["ops_off"])
+    for e in range(int(res_row["n_ops"])):
+        o = int(ops[o0 + e])
+        node, code, ln = o >> 20, (o >> 16) & 0xF, o & 0xFFFF
+        if node != cur:
+            if cur is not None:
+                out.append("]")
+            out.append("%d[" % node)
+            cur = node
+        if code < 6:
+            out.append("%d%s" % (ln, OP_CHARS[code]))
+    if cur is not None:
+        out.append("]")
+    return "".join(out)
+
+
+def results_to_dicts(res, ops):
+    out = []
+    for r in res:
+        mm = int(r["multi_mask"])
+        out.append({
+            "graph_pos": int(r["graph_pos"]), "score": int(r["score"]), "mapq": int(r["mapq"]),
+            "unique": bool(r["is_unique"]), "returned_reverse": bool(r["returned_reverse"]),
+            "multi": [(mm >> k) & 1 for k in range(4)],
+            "strand_score": [int(r["strand_score"][0]), int(r["strand_score"][1])],
+            "cigar": render_cigar(r, ops), "clipped": int(r["clipped"]), "status": int(r["status"]),
+        })
+    return out

@@ -1,0 +1,834 @@
+// pg_api.hip -- host side of the C ABI declared in include/paragraph_amd.h.
+//
+// Host responsibilities (everything here is plumbing; all alignment arithmetic runs in the HIP
+// kernels of pg_fill.hip / pg_trace.hip):
+//   * graph upload: builds, for every graph and both graph directions, the linear column layout
+//     (node order = topological id order, as GraphAlignerImpl::initializeGraph does,
+//     GraphAligner.cpp:110-167; reversed graph as graphtools::reverseGraph,
+//     GT!/src/graphcore/GraphOperations.cpp:38-60)
+//   * batch upload: buckets reads by (rows-per-lane variant, graph), packs them 4 per wavefront,
+//     plans chunks so that the traceback workspace of a chunk fits the configured HBM budget
+//   * batch align: per chunk one fill launch (forward + reversed graph wavefronts) and one
+//     pick/traceback launch on the ctx stream
+// There is no CPU fallback: without a HIP device every entry point that needs one fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/paragraph_amd.h"
+#include "pg_device.h"
+#include "pg_kernels.h"
+
+namespace
+{
+struct HostGraph
+{
+    uint32_t n_nodes;
+    uint32_t ncols;
+};
+
+struct Chunk
+{
+    int C;
+    uint32_t pair_begin, pair_end;
+    uint64_t ws_bytes;
+    uint32_t max_nodes;
+    uint64_t fills, cells, trace_bytes;
+};
+
+struct EventPair
+{
+    hipEvent_t a, b;
+    int kind;  // 0 fill, 1 trace
+};
+}  // namespace
+
+struct pg_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint64_t ws_limit = 8ull << 30;
+    uint8_t* workspace = nullptr;
+    uint64_t ws_cap = 0;
+    pg_op* ops_scratch = nullptr;
+    uint64_t ops_scratch_cap = 0;  // entries
+    bool timing = false;
+    std::vector<EventPair> events;
+    std::vector<hipEvent_t> event_pool;
+    pg_timing acc{};
+    std::string err;
+};
+
+struct pg_graphs
+{
+    uint32_t n_graphs = 0;
+    std::vector<HostGraph> host;
+    PgGraphDev* d_graphs = nullptr;
+    PgNode* d_nodes = nullptr;
+    uint32_t* d_preds = nullptr;
+    uint32_t* d_colmeta = nullptr;
+    char* d_seqchars = nullptr;
+};
+
+struct pg_batch
+{
+    const pg_graphs* graphs = nullptr;
+    uint32_t n_reads = 0;
+    uint32_t n_pairs = 0;
+    uint32_t* d_base_off = nullptr;
+    char* d_bases = nullptr;
+    PgWorkItem* d_items = nullptr;
+    PgFillSummary* d_fillsum = nullptr;
+    pg_result* d_results = nullptr;
+    pg_op* d_ops = nullptr;
+    uint64_t ops_cap = 0;
+    unsigned long long* d_ops_counter = nullptr;
+    std::vector<Chunk> chunks;
+    uint64_t max_ws = 0;
+    uint64_t max_scratch = 0;
+    size_t cap_reads = 0, cap_bases = 0, cap_items = 0;
+    std::vector<pg_result> host_template;  // status for reads the device never sees (empty reads)
+    bool has_skipped = false;
+};
+
+static pg_status fail(pg_ctx* ctx, pg_status st, const std::string& msg)
+{
+    if (ctx)
+        ctx->err = msg;
+    return st;
+}
+
+#define HIP_TRY(ctx, call)                                                                                     \
+    do                                                                                                         \
+    {                                                                                                          \
+        hipError_t e__ = (call);                                                                               \
+        if (e__ != hipSuccess)                                                                                 \
+            return fail(ctx, PG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));                  \
+    } while (0)
+
+extern "C" const char* pg_strerror(pg_status st)
+{
+    switch (st)
+    {
+    case PG_OK: return "ok";
+    case PG_ERR_INVALID: return "invalid argument";
+    case PG_ERR_NO_DEVICE: return "no usable HIP device";
+    case PG_ERR_HIP: return "HIP runtime error";
+    case PG_ERR_UNSUPPORTED: return "outside the supported envelope";
+    case PG_ERR_NOMEM: return "out of memory";
+    case PG_ERR_OVERFLOW: return "output buffer too small";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char* pg_last_error(const pg_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
+{
+    if (!out)
+        return PG_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+        return PG_ERR_NO_DEVICE;
+    pg_ctx* ctx = new (std::nothrow) pg_ctx();
+    if (!ctx)
+        return PG_ERR_NOMEM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+    {
+        delete ctx;
+        return PG_ERR_HIP;
+    }
+    *out = ctx;
+    return PG_OK;
+}
+
+extern "C" void pg_ctx_destroy(pg_ctx* ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    for (auto& e : ctx->events)
+    {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    for (auto e : ctx->event_pool)
+        (void)hipEventDestroy(e);
+    if (ctx->workspace)
+        (void)hipFree(ctx->workspace);
+    if (ctx->ops_scratch)
+        (void)hipFree(ctx->ops_scratch);
+    if (ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" pg_status pg_ctx_set_workspace_bytes(pg_ctx* ctx, uint64_t bytes)
+{
+    if (!ctx || bytes < (64ull << 20))
+        return PG_ERR_INVALID;
+    ctx->ws_limit = bytes;
+    return PG_OK;
+}
+
+extern "C" pg_status pg_ctx_sync(pg_ctx* ctx)
+{
+    if (!ctx)
+        return PG_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+
+static pg_status drain_events(pg_ctx* ctx)
+{
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& e : ctx->events)
+    {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, e.a, e.b));
+        if (e.kind == 0)
+        {
+            ctx->acc.fill_ms += ms;
+            ctx->acc.fill_launches++;
+        }
+        else
+        {
+            ctx->acc.trace_ms += ms;
+            ctx->acc.trace_launches++;
+        }
+        ctx->event_pool.push_back(e.a);
+        ctx->event_pool.push_back(e.b);
+    }
+    ctx->events.clear();
+    return PG_OK;
+}
+
+extern "C" pg_status pg_ctx_timing_enable(pg_ctx* ctx, int enable)
+{
+    if (!ctx)
+        return PG_ERR_INVALID;
+    ctx->timing = enable != 0;
+    return PG_OK;
+}
+
+extern "C" pg_status pg_ctx_timing_reset(pg_ctx* ctx)
+{
+    if (!ctx)
+        return PG_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pg_status st = drain_events(ctx);
+    if (st != PG_OK)
+        return st;
+    ctx->acc = pg_timing{};
+    return PG_OK;
+}
+
+extern "C" pg_status pg_ctx_timing_get(pg_ctx* ctx, pg_timing* out)
+{
+    if (!ctx || !out)
+        return PG_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pg_status st = drain_events(ctx);
+    if (st != PG_OK)
+        return st;
+    *out = ctx->acc;
+    return PG_OK;
+}
+
+static hipError_t get_event(pg_ctx* ctx, hipEvent_t* ev)
+{
+    if (!ctx->event_pool.empty())
+    {
+        *ev = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return hipSuccess;
+    }
+    return hipEventCreate(ev);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// graphs
+// ---------------------------------------------------------------------------------------------------
+static char up(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+static uint32_t nt_code_host(char c)
+{
+    switch (c)
+    {
+    case 'A':
+    case 'U':
+        return 0;
+    case 'C':
+        return 1;
+    case 'G':
+        return 2;
+    case 'T':
+        return 3;
+    default:
+        return 4;
+    }
+}
+
+extern "C" pg_status pg_graphs_upload(
+    pg_ctx* ctx, uint32_t n_graphs, const uint32_t* node_off, const uint32_t* seq_off, const char* seq,
+    const uint32_t* pred_off, const uint32_t* pred, pg_graphs** out)
+{
+    if (!ctx || !out || !node_off || !seq_off || !seq || !pred_off || (n_graphs == 0))
+        return fail(ctx, PG_ERR_INVALID, "pg_graphs_upload: null argument or no graphs");
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    std::vector<PgGraphDev> gdev(n_graphs);
+    std::vector<PgNode> nodes;
+    std::vector<uint32_t> preds;
+    std::vector<uint32_t> colmeta;
+    std::vector<char> seqchars;
+    std::vector<HostGraph> host(n_graphs);
+
+    for (uint32_t g = 0; g < n_graphs; ++g)
+    {
+        const uint32_t nb = node_off[g], ne = node_off[g + 1];
+        if (ne <= nb)
+            return fail(ctx, PG_ERR_INVALID, "graph without nodes");
+        const uint32_t n = ne - nb;
+        if (n > PG_MAX_NODES)
+            return fail(ctx, PG_ERR_UNSUPPORTED, "graph with more than 4095 nodes");
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < n; ++i)
+        {
+            const uint32_t len = seq_off[nb + i + 1] - seq_off[nb + i];
+            if (seq_off[nb + i + 1] <= seq_off[nb + i])
+                return fail(ctx, PG_ERR_INVALID, "empty node sequence");
+            total += len;
+            for (uint32_t k = pred_off[nb + i]; k < pred_off[nb + i + 1]; ++k)
+            {
+                if (!pred || pred[k] >= i)
+                    return fail(ctx, PG_ERR_INVALID, "edge breaks topological order");
+                if (k > pred_off[nb + i] && pred[k] <= pred[k - 1])
+                    return fail(ctx, PG_ERR_INVALID, "predecessors must be ascending and unique");
+            }
+        }
+        if (total > 65535 - PG_GROUP_LANES)
+            return fail(ctx, PG_ERR_UNSUPPORTED, "graph longer than 65519 columns");
+        host[g].n_nodes = n;
+        host[g].ncols = (uint32_t)total;
+
+        // successors (forward ids)
+        std::vector<std::vector<uint32_t>> succ(n);
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t k = pred_off[nb + i]; k < pred_off[nb + i + 1]; ++k)
+                succ[pred[k]].push_back(i);
+
+        gdev[g].seq_off = (uint32_t)seqchars.size();
+        gdev[g].pad = 0;
+        for (int dir = 0; dir < 2; ++dir)
+        {
+            PgGraphDir& gd = gdev[g].dir[dir];
+            gd.meta_off = (uint32_t)colmeta.size();
+            gd.ncols = (uint32_t)total;
+            gd.node_off = (uint32_t)nodes.size();
+            gd.n_nodes = n;
+            uint32_t col = 0;
+            for (uint32_t id = 0; id < n; ++id)
+            {
+                const uint32_t src = dir ? n - 1 - id : id;
+                const uint32_t s0 = seq_off[nb + src], len = seq_off[nb + src + 1] - s0;
+                PgNode nd;
+                nd.col_start = col;
+                nd.len = len;
+                nd.pred_off = (uint32_t)preds.size();
+                bool has_succ = false, has_far_succ = false;
+                if (!dir)
+                {
+                    for (uint32_t k = pred_off[nb + id]; k < pred_off[nb + id + 1]; ++k)
+                        preds.push_back(pred[k]);
+                    has_succ = !succ[id].empty();
+                    for (uint32_t s : succ[id])
+                        has_far_succ |= (s != id + 1);
+                }
+                else
+                {
+                    // predecessors in the reversed graph = successors of src in the original, mapped
+                    // s -> n-1-s, ascending
+                    std::vector<uint32_t> ps;
+                    for (uint32_t s : succ[src])
+                        ps.push_back(n - 1 - s);
+                    std::sort(ps.begin(), ps.end());
+                    for (uint32_t p : ps)
+                        preds.push_back(p);
+                    // successors in the reversed graph = predecessors of src in the original
+                    for (uint32_t k = pred_off[nb + src]; k < pred_off[nb + src + 1]; ++k)
+                    {
+                        has_succ = true;
+                        has_far_succ |= ((n - 1 - pred[k]) != id + 1);
+                    }
+                }
+                nd.n_pred = (uint32_t)preds.size() - nd.pred_off;
+                nodes.push_back(nd);
+                // forward direction keeps every seed (the traceback reads them); the reversed
+                // direction only needs seeds that a non-adjacent successor will load
+                const bool save = dir == 0 ? has_succ : has_far_succ;
+                for (uint32_t c = 0; c < len; ++c)
+                {
+                    const char ch = up(dir ? seq[s0 + len - 1 - c] : seq[s0 + c]);
+                    uint32_t m = nt_code_host(ch) | (id << 8);
+                    if (c == 0)
+                        m |= PG_META_FIRST;
+                    if (c == len - 1)
+                        m |= PG_META_LAST | (save ? PG_META_SAVE : 0u);
+                    colmeta.push_back(m);
+                    if (!dir)
+                        seqchars.push_back(ch);
+                }
+                col += len;
+            }
+            for (int c = 0; c < PG_GROUP_LANES; ++c)
+                colmeta.push_back(PG_META_IDLE);
+        }
+    }
+    if (preds.empty())
+        preds.push_back(0);
+
+    pg_graphs* G = new (std::nothrow) pg_graphs();
+    if (!G)
+        return PG_ERR_NOMEM;
+    G->n_graphs = n_graphs;
+    G->host.swap(host);
+    auto up_vec = [&](auto& vec, auto** dptr) -> hipError_t {
+        using T = typename std::remove_reference<decltype(vec)>::type::value_type;
+        hipError_t e = hipMalloc((void**)dptr, vec.size() * sizeof(T));
+        if (e != hipSuccess)
+            return e;
+        return hipMemcpyAsync(*dptr, vec.data(), vec.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+    };
+    hipError_t e = up_vec(gdev, &G->d_graphs);
+    if (e == hipSuccess)
+        e = up_vec(nodes, &G->d_nodes);
+    if (e == hipSuccess)
+        e = up_vec(preds, &G->d_preds);
+    if (e == hipSuccess)
+        e = up_vec(colmeta, &G->d_colmeta);
+    if (e == hipSuccess)
+        e = up_vec(seqchars, &G->d_seqchars);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess)
+    {
+        pg_graphs_destroy(ctx, G);
+        return fail(ctx, PG_ERR_HIP, std::string("graph upload: ") + hipGetErrorString(e));
+    }
+    *out = G;
+    return PG_OK;
+}
+
+extern "C" void pg_graphs_destroy(pg_ctx* ctx, pg_graphs* G)
+{
+    if (!G)
+        return;
+    if (ctx)
+    {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(G->d_graphs);
+    (void)hipFree(G->d_nodes);
+    (void)hipFree(G->d_preds);
+    (void)hipFree(G->d_colmeta);
+    (void)hipFree(G->d_seqchars);
+    delete G;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// batches
+// ---------------------------------------------------------------------------------------------------
+extern "C" pg_status pg_batch_create(pg_ctx* ctx, pg_batch** out)
+{
+    if (!ctx || !out)
+        return PG_ERR_INVALID;
+    *out = new (std::nothrow) pg_batch();
+    return *out ? PG_OK : PG_ERR_NOMEM;
+}
+
+static void batch_free_device(pg_batch* b)
+{
+    (void)hipFree(b->d_base_off);
+    (void)hipFree(b->d_bases);
+    (void)hipFree(b->d_items);
+    (void)hipFree(b->d_fillsum);
+    (void)hipFree(b->d_results);
+    (void)hipFree(b->d_ops);
+    (void)hipFree(b->d_ops_counter);
+    b->d_base_off = nullptr;
+    b->d_bases = nullptr;
+    b->d_items = nullptr;
+    b->d_fillsum = nullptr;
+    b->d_results = nullptr;
+    b->d_ops = nullptr;
+    b->d_ops_counter = nullptr;
+    b->cap_reads = b->cap_bases = b->cap_items = 0;
+    b->ops_cap = 0;
+}
+
+extern "C" void pg_batch_destroy(pg_ctx* ctx, pg_batch* b)
+{
+    if (!b)
+        return;
+    if (ctx)
+    {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    batch_free_device(b);
+    delete b;
+}
+
+static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+extern "C" pg_status pg_batch_upload(
+    pg_ctx* ctx, pg_batch* b, const pg_graphs* G, uint32_t n_reads, const uint32_t* graph_of_read,
+    const uint32_t* base_off, const char* bases)
+{
+    if (!ctx || !b || !G || (n_reads && (!graph_of_read || !base_off || !bases)))
+        return fail(ctx, PG_ERR_INVALID, "pg_batch_upload: null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    b->graphs = G;
+    b->n_reads = n_reads;
+    b->chunks.clear();
+    b->n_pairs = 0;
+    b->has_skipped = false;
+
+    // ---- bucket reads by (variant, graph) -----------------------------------------------------------
+    struct Key
+    {
+        uint32_t c, graph, idx;
+    };
+    std::vector<Key> keys;
+    keys.reserve(n_reads);
+    b->host_template.assign(n_reads, pg_result{});
+    uint64_t ops_total = 0;
+    for (uint32_t i = 0; i < n_reads; ++i)
+    {
+        if (base_off[i + 1] < base_off[i])
+            return fail(ctx, PG_ERR_INVALID, "base_off must be non-decreasing");
+        const uint32_t L = base_off[i + 1] - base_off[i];
+        if (graph_of_read[i] >= G->n_graphs)
+            return fail(ctx, PG_ERR_INVALID, "graph_of_read out of range");
+        if (L > PG_MAX_READ_LEN)
+            return fail(ctx, PG_ERR_UNSUPPORTED, "read longer than 250 bp (gssw word mode is not implemented)");
+        if (L == 0)
+        {
+            // grm::sequentialAlignReads skips reads without bases (Align.cpp:74-77)
+            b->host_template[i].status = 1;
+            b->has_skipped = true;
+            continue;
+        }
+        const uint32_t C = 2 * ((L + 31) / 32);
+        keys.push_back(Key{ C, graph_of_read[i], i });
+        ops_total += pg_ops_cap((int)C);
+    }
+    std::stable_sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) {
+        return x.c != y.c ? x.c < y.c : x.graph < y.graph;
+    });
+
+    // ---- work items (pairs: forward graph, reversed graph) + chunk plan -----------------------------
+    std::vector<PgWorkItem> items;
+    items.reserve(keys.size() / 2 + 16);
+    Chunk cur{};
+    bool open = false;
+    uint64_t cur_scratch = 0;
+    b->max_ws = 0;
+    b->max_scratch = 0;
+    auto close_chunk = [&]() {
+        if (open)
+        {
+            cur.pair_end = (uint32_t)(items.size() / 2);
+            b->chunks.push_back(cur);
+            b->max_ws = std::max(b->max_ws, cur.ws_bytes);
+            b->max_scratch = std::max(b->max_scratch, cur_scratch);
+            open = false;
+        }
+    };
+    size_t p = 0;
+    while (p < keys.size())
+    {
+        size_t q = p;
+        while (q < keys.size() && q - p < PG_GROUPS && keys[q].c == keys[p].c && keys[q].graph == keys[p].graph)
+            ++q;
+        const int C = (int)keys[p].c;
+        const HostGraph& hg = G->host[keys[p].graph];
+        const uint64_t nsteps = (uint64_t)hg.ncols + PG_GROUP_LANES - 1;
+        const uint64_t trace_bytes = align_up(nsteps * 64 * pg_trace_lane_bytes(C), 256);
+        const uint64_t seed_bytes = align_up((uint64_t)hg.n_nodes * 64 * C * 4, 256);
+        const uint64_t need = trace_bytes + 2 * seed_bytes;
+        if (need > ctx->ws_limit)
+            return fail(ctx, PG_ERR_UNSUPPORTED, "workspace limit too small for one wavefront of this graph");
+        if (open && (cur.C != C || cur.ws_bytes + need > ctx->ws_limit))
+            close_chunk();
+        if (!open)
+        {
+            cur = Chunk{};
+            cur.C = C;
+            cur.pair_begin = (uint32_t)(items.size() / 2);
+            cur_scratch = 0;
+            open = true;
+        }
+        PgWorkItem fw{}, rv{};
+        fw.graph = rv.graph = keys[p].graph;
+        fw.dir = 0;
+        rv.dir = 1;
+        for (int gI = 0; gI < PG_GROUPS; ++gI)
+        {
+            const uint32_t r = (p + gI < q) ? keys[p + gI].idx : PG_NONE;
+            fw.read[gI] = rv.read[gI] = r;
+            if (r != PG_NONE)
+            {
+                const uint64_t L = base_off[r + 1] - base_off[r];
+                cur.fills += 4;
+                cur.cells += 4 * L * hg.ncols;
+            }
+        }
+        fw.trace_off = cur.ws_bytes;
+        fw.seed_off = cur.ws_bytes + trace_bytes;
+        rv.trace_off = 0;
+        rv.seed_off = cur.ws_bytes + trace_bytes + seed_bytes;
+        cur.ws_bytes += need;
+        cur.trace_bytes += nsteps * 64 * pg_trace_lane_bytes(C);
+        cur.max_nodes = std::max(cur.max_nodes, hg.n_nodes);
+        cur_scratch += (uint64_t)PG_GROUPS * pg_ops_cap(C);
+        items.push_back(fw);
+        items.push_back(rv);
+        p = q;
+    }
+    close_chunk();
+    b->n_pairs = (uint32_t)(items.size() / 2);
+
+    // ---- device buffers ----------------------------------------------------------------------------
+    const size_t n_bases = n_reads ? base_off[n_reads] : 0;
+    if (n_reads + 1 > b->cap_reads || n_bases > b->cap_bases || items.size() > b->cap_items || ops_total > b->ops_cap)
+    {
+        batch_free_device(b);
+        b->cap_reads = n_reads + 1;
+        b->cap_bases = std::max<size_t>(n_bases, 1);
+        b->cap_items = std::max<size_t>(items.size(), 2);
+        b->ops_cap = std::max<uint64_t>(ops_total, 1);
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_base_off, b->cap_reads * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_bases, b->cap_bases));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_items, b->cap_items * sizeof(PgWorkItem)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_fillsum, b->cap_items * PG_GROUPS * 2 * sizeof(PgFillSummary)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_results, std::max<size_t>(n_reads, 1) * sizeof(pg_result)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_ops, b->ops_cap * sizeof(pg_op)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_ops_counter, sizeof(unsigned long long)));
+    }
+    if (n_reads)
+    {
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_base_off, base_off, (n_reads + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (n_bases)
+            HIP_TRY(ctx, hipMemcpyAsync(b->d_bases, bases, n_bases, hipMemcpyHostToDevice, ctx->stream));
+        if (!items.empty())
+            HIP_TRY(ctx, hipMemcpyAsync(b->d_items, items.data(), items.size() * sizeof(PgWorkItem), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_results, b->host_template.data(), n_reads * sizeof(pg_result), hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
+    // workspace / scratch owned by the ctx (shared by its batches)
+    if (b->max_ws > ctx->ws_cap)
+    {
+        if (ctx->workspace)
+            HIP_TRY(ctx, hipFree(ctx->workspace));
+        ctx->workspace = nullptr;
+        ctx->ws_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->workspace, b->max_ws));
+        ctx->ws_cap = b->max_ws;
+    }
+    if (b->max_scratch > ctx->ops_scratch_cap)
+    {
+        if (ctx->ops_scratch)
+            HIP_TRY(ctx, hipFree(ctx->ops_scratch));
+        ctx->ops_scratch = nullptr;
+        ctx->ops_scratch_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->ops_scratch, b->max_scratch * sizeof(pg_op)));
+        ctx->ops_scratch_cap = b->max_scratch;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+    return PG_OK;
+}
+
+extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
+{
+    if (!ctx || !b || !b->graphs)
+        return fail(ctx, PG_ERR_INVALID, "pg_batch_align: batch not uploaded");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const pg_graphs* G = b->graphs;
+    if (b->max_ws > ctx->ws_cap || b->max_scratch > ctx->ops_scratch_cap)
+        return fail(ctx, PG_ERR_INVALID, "ctx workspace was shrunk after the batch was planned");
+    HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
+    const bool revg = (flags & PG_AF_REVERSE_GRAPH) != 0;
+    for (const Chunk& ch : b->chunks)
+    {
+        const uint32_t n_pairs = ch.pair_end - ch.pair_begin;
+        PgFillArgs fa{};
+        fa.items = b->d_items;
+        fa.item_begin = 2 * ch.pair_begin;
+        fa.item_stride = revg ? 1 : 2;
+        fa.graphs = G->d_graphs;
+        fa.nodes = G->d_nodes;
+        fa.preds = G->d_preds;
+        fa.colmeta = G->d_colmeta;
+        fa.base_off = b->d_base_off;
+        fa.bases = b->d_bases;
+        fa.workspace = ctx->workspace;
+        fa.fillsum = b->d_fillsum;
+        EventPair ev{};
+        if (ctx->timing)
+        {
+            HIP_TRY(ctx, get_event(ctx, &ev.a));
+            HIP_TRY(ctx, get_event(ctx, &ev.b));
+            ev.kind = 0;
+            HIP_TRY(ctx, hipEventRecord(ev.a, ctx->stream));
+        }
+        HIP_TRY(ctx, pg_launch_fill(ch.C, fa, revg ? 2 * n_pairs : n_pairs, ch.max_nodes, ctx->stream));
+        if (ctx->timing)
+        {
+            HIP_TRY(ctx, hipEventRecord(ev.b, ctx->stream));
+            ctx->events.push_back(ev);
+            ctx->acc.fills += revg ? ch.fills : ch.fills / 2;
+            ctx->acc.cells += revg ? ch.cells : ch.cells / 2;
+            ctx->acc.trace_bytes += ch.trace_bytes;
+        }
+        PgTraceArgs ta{};
+        ta.items = b->d_items;
+        ta.pair_begin = ch.pair_begin;
+        ta.n_pairs = n_pairs;
+        ta.C = ch.C;
+        ta.flags = flags;
+        ta.graphs = G->d_graphs;
+        ta.nodes = G->d_nodes;
+        ta.preds = G->d_preds;
+        ta.seqchars = G->d_seqchars;
+        ta.base_off = b->d_base_off;
+        ta.bases = b->d_bases;
+        ta.workspace = ctx->workspace;
+        ta.fillsum = b->d_fillsum;
+        ta.results = b->d_results;
+        ta.ops_scratch = ctx->ops_scratch;
+        ta.ops = b->d_ops;
+        ta.ops_counter = b->d_ops_counter;
+        if (ctx->timing)
+        {
+            HIP_TRY(ctx, get_event(ctx, &ev.a));
+            HIP_TRY(ctx, get_event(ctx, &ev.b));
+            ev.kind = 1;
+            HIP_TRY(ctx, hipEventRecord(ev.a, ctx->stream));
+        }
+        HIP_TRY(ctx, pg_launch_trace(ta, ctx->stream));
+        if (ctx->timing)
+        {
+            HIP_TRY(ctx, hipEventRecord(ev.b, ctx->stream));
+            ctx->events.push_back(ev);
+        }
+    }
+    return PG_OK;
+}
+
+extern "C" pg_status pg_batch_ops_count(pg_ctx* ctx, pg_batch* b, uint64_t* n_ops)
+{
+    if (!ctx || !b || !n_ops)
+        return PG_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long v = 0;
+    if (b->d_ops_counter)
+    {
+        HIP_TRY(ctx, hipMemcpyAsync(&v, b->d_ops_counter, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *n_ops = v;
+    return PG_OK;
+}
+
+extern "C" pg_status pg_batch_download(
+    pg_ctx* ctx, pg_batch* b, pg_result* results, pg_op* ops, uint64_t ops_cap, uint64_t* n_ops)
+{
+    if (!ctx || !b || (b->n_reads && !results))
+        return fail(ctx, PG_ERR_INVALID, "pg_batch_download: null argument");
+    uint64_t cnt = 0;
+    pg_status st = pg_batch_ops_count(ctx, b, &cnt);
+    if (st != PG_OK)
+        return st;
+    if (n_ops)
+        *n_ops = cnt;
+    if (b->n_reads)
+        HIP_TRY(ctx, hipMemcpyAsync(results, b->d_results, b->n_reads * sizeof(pg_result), hipMemcpyDeviceToHost, ctx->stream));
+    if (ops && cnt)
+    {
+        if (cnt > ops_cap)
+        {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            return fail(ctx, PG_ERR_OVERFLOW, "ops buffer too small");
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ops, b->d_ops, cnt * sizeof(pg_op), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+
+extern "C" pg_status pg_align_batch(
+    pg_ctx* ctx, const pg_graphs* graphs, uint32_t n_reads, const uint32_t* graph_of_read, const uint32_t* base_off,
+    const char* bases, uint32_t flags, pg_result* results, pg_op* ops, uint64_t ops_cap, uint64_t* n_ops)
+{
+    pg_batch* b = nullptr;
+    pg_status st = pg_batch_create(ctx, &b);
+    if (st != PG_OK)
+        return st;
+    st = pg_batch_upload(ctx, b, graphs, n_reads, graph_of_read, base_off, bases);
+    if (st == PG_OK)
+        st = pg_batch_align(ctx, b, flags);
+    if (st == PG_OK)
+        st = pg_batch_download(ctx, b, results, ops, ops_cap, n_ops);
+    pg_batch_destroy(ctx, b);
+    return st;
+}
+
+extern "C" size_t pg_render_cigar(const pg_result* r, const pg_op* ops, char* buf, size_t cap)
+{
+    static const char OPC[] = "MXNIDS";
+    size_t len = 0;
+    char tmp[32];
+    auto put = [&](const char* s, size_t n) {
+        for (size_t i = 0; i < n; ++i, ++len)
+            if (buf && len + 1 < cap)
+                buf[len] = s[i];
+    };
+    uint32_t cur = 0xFFFFFFFFu;
+    for (uint32_t e = 0; r && ops && e < r->n_ops; ++e)
+    {
+        const pg_op o = ops[r->ops_off + e];
+        const uint32_t node = PG_OP_NODE(o), code = PG_OP_CODE(o);
+        if (node != cur)
+        {
+            if (cur != 0xFFFFFFFFu)
+                put("]", 1);
+            int k = snprintf(tmp, sizeof tmp, "%u[", node);
+            put(tmp, (size_t)k);
+            cur = node;
+        }
+        if (code <= PG_OPC_S)
+        {
+            int k = snprintf(tmp, sizeof tmp, "%u%c", PG_OP_LEN(o), OPC[code]);
+            put(tmp, (size_t)k);
+        }
+    }
+    if (cur != 0xFFFFFFFFu)
+        put("]", 1);
+    if (buf && cap)
+        buf[len < cap ? len : cap - 1] = 0;
+    return len;
+}

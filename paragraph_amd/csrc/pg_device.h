@@ -1,0 +1,79 @@
+// pg_device.h -- device-side data layout shared by the HIP kernels and the C-ABI host code.
+//
+// HBM layout (see DESIGN.md "Data layout"):
+//   graph set   : PgGraphDev[n_graphs], PgNode[], preds[], colmeta[] (one u32 per graph column, both
+//                 graph directions), seqchars[] (upper-cased node characters, forward direction)
+//   batch       : raw read bases + offsets, PgWorkItem[] (one per wavefront), PgFillSummary[],
+//                 pg_result[], pg_op[]
+//   workspace   : per wavefront a "trace" region (H bytes of every DP cell of the two forward-graph
+//                 fills, stored by pipeline step so each step is one contiguous coalesced store) and a
+//                 "seed" region (last-column H / next-column E of every node)
+#pragma once
+#include <stdint.h>
+
+#define PG_GROUPS 4        // reads per wavefront
+#define PG_GROUP_LANES 16  // lanes per read
+#define PG_NONE 0xFFFFFFFFu
+
+// column meta word: bits 0-2 nt code (0-3 ACGT, 4 other), bit3 FIRST column of node, bit4 LAST column,
+// bit5 SAVE (store the node's last column as a seed), bits 8.. node id
+#define PG_META_CODE(m) ((m)&7u)
+#define PG_META_FIRST 8u
+#define PG_META_LAST 16u
+#define PG_META_SAVE 32u
+#define PG_META_NODE(m) ((m) >> 8)
+#define PG_META_IDLE 4u  // code 4 (scores 0 against everything), no flags
+
+#define PG_GAP_OPEN 6
+#define PG_GAP_EXT 1
+#define PG_PAD_SCORE (-300)
+
+struct PgGraphDir
+{
+    uint32_t meta_off;  // into colmeta[]; ncols + PG_GROUP_LANES entries (tail = PG_META_IDLE)
+    uint32_t ncols;     // total node length
+    uint32_t node_off;  // into nodes[]
+    uint32_t n_nodes;
+};
+
+struct PgGraphDev
+{
+    PgGraphDir dir[2];  // [0] forward graph, [1] reversed graph
+    uint32_t seq_off;   // into seqchars[] (forward direction, by column)
+    uint32_t pad;
+};
+
+struct PgNode
+{
+    uint32_t col_start;  // first column of the node in its direction's linear layout
+    uint32_t len;
+    uint32_t pred_off;  // into preds[] (ids local to the graph direction, ascending)
+    uint32_t n_pred;
+};
+
+// One wavefront of work: up to 4 reads of the same graph, one graph direction, both strands.
+struct PgWorkItem
+{
+    uint32_t graph;
+    uint32_t dir;
+    uint32_t read[PG_GROUPS];
+    uint64_t trace_off;  // byte offset into the workspace (dir 0 only)
+    uint64_t seed_off;   // byte offset into the workspace
+};
+
+// Written by the fill kernel per (work item, group, strand).
+struct PgFillSummary
+{
+    int32_t score;     // best local score of the fill (gssw max_node->score1)
+    int32_t max_node;  // first node (topological) holding it
+    int32_t ref_end;   // node-local column of its first occurrence (ref_end1), -1 if score 0
+    int32_t read_end;  // smallest read index in that column (read_end1)
+    int32_t end_col;   // same column as a graph-global column index
+    int32_t multi;     // alignsEndAtMultNodes
+    int32_t pad[2];
+};
+
+static inline __host__ __device__ uint32_t pg_rows(int C) { return (uint32_t)(PG_GROUP_LANES * C); }
+// bytes of H trace one lane writes per pipeline step: C rows x 2 strands
+static inline __host__ __device__ uint32_t pg_trace_lane_bytes(int C) { return (uint32_t)(2 * C); }
+static inline __host__ __device__ uint32_t pg_ops_cap(int C) { return pg_rows(C) + 32u; }

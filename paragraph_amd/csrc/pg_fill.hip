@@ -1,0 +1,407 @@
+// pg_fill.hip -- the DP fill kernel (gfx950 / CDNA4, hand-written HIP).
+//
+// Replaces, for a whole batch at once, what the reference does per read in
+//   gssw_graph_fill           external/gssw/gssw.c:3963-4044   (topological node loop, max_node rule)
+//   gssw_create_seed_byte     gssw.c:3897-3931                 (lane-wise max over predecessor seeds)
+//   gssw_sw_sse2_byte         gssw.c:153-473                   (affine-gap fill of one node)
+//   gssw_qP_byte              gssw.c:72-98                     (query profile)
+//   alignsEndAtMultNodes      src/c++/lib/grm/GraphAligner.cpp:170-212 (fused: per-node maxima instead of a rescan)
+//
+// Mapping onto CDNA4
+//   * one 64-lane wavefront = 4 reads x 16 lanes; every 16-lane DPP row owns one read.  Lane k of a row
+//     owns read rows [k*C, (k+1)*C) (C = ceil(L/32)*2, template parameter) and sweeps the graph's
+//     columns node by node in topological order, skewed by one column per lane (anti-diagonal
+//     wavefront): at step t lane k works on column t-k.
+//   * both strands of a read (read and its reverse complement) run in the two 16-bit halves of every
+//     VGPR with packed VOP3P integer ops (v_pk_add_u16, v_pk_max_i16/u16, v_pk_sub_u16 clamp), so one
+//     wavefront performs 8 fills at once.  No MFMA: this is integer DP, not a contraction.
+//   * the only cross-lane traffic is (H of the row above on the previous column, running F) handed to
+//     the next lane with two row_shr:1 DPP moves per step; the column's meta word (base code, node
+//     boundary flags) rides the same shift, lane 0 reads it with a scalar load.
+//   * the query profile of the 8 fills lives in LDS ([read][ref code][row] packed dwords); each step
+//     costs C/2 ds_read_b64 per lane.
+//   * H of every cell of the forward-graph fills is written to HBM as bytes, laid out by pipeline
+//     step so that one step of one wavefront is a single contiguous 64*2C-byte store; the traceback
+//     kernel re-derives E/F decisions from H (see pg_trace.hip).
+//   * node boundaries: the last column (H, next-column E) of a node is stored once per lane in a
+//     per-wavefront seed region; a node's first column takes the lane-wise max over its predecessors'
+//     seeds (the predecessor that directly precedes it in the layout stays in registers).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pg_device.h"
+#include "pg_kernels.h"
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u16x2 asU(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
+__device__ __forceinline__ i16x2 asS(uint32_t x) { return __builtin_bit_cast(i16x2, x); }
+__device__ __forceinline__ uint32_t asW(u16x2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t asW(i16x2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return asW(asU(a) + asU(b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return asW(asU(a) - asU(b)); }
+__device__ __forceinline__ uint32_t pk_maxi(uint32_t a, uint32_t b)
+{
+    return asW(__builtin_elementwise_max(asS(a), asS(b)));
+}
+__device__ __forceinline__ uint32_t pk_maxu(uint32_t a, uint32_t b)
+{
+    return asW(__builtin_elementwise_max(asU(a), asU(b)));
+}
+__device__ __forceinline__ uint32_t pk_minu(uint32_t a, uint32_t b)
+{
+    return asW(__builtin_elementwise_min(asU(a), asU(b)));
+}
+__device__ __forceinline__ uint32_t pk_subsat(uint32_t a, uint32_t b)
+{
+    return asW(__builtin_elementwise_sub_sat(asU(a), asU(b)));
+}
+
+// row_shr:1 within each 16-lane DPP row. bound_ctrl=true: lane 0 of a row receives 0.
+__device__ __forceinline__ uint32_t row_shr1_zero(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+}
+// lane 0 of each row keeps `first`.
+__device__ __forceinline__ uint32_t row_shr1_keep(uint32_t first, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x111, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t nt_code(uint32_t c)
+{  // gssw.c:4206-4220
+    switch (c)
+    {
+    case 'A':
+    case 'a':
+    case 'U':
+    case 'u':
+        return 0;
+    case 'C':
+    case 'c':
+        return 1;
+    case 'G':
+    case 'g':
+        return 2;
+    case 'T':
+    case 't':
+        return 3;
+    default:
+        return 4;
+    }
+}
+__device__ __forceinline__ uint32_t upper_c(uint32_t c) { return (c >= 'a' && c <= 'z') ? c - 32u : c; }
+__device__ __forceinline__ uint32_t comp_c(uint32_t c)
+{  // graph-tools SequenceOperations.cpp:66-81: anything but upper-case ACGT becomes 'N'
+    switch (c)
+    {
+    case 'A':
+        return 'T';
+    case 'C':
+        return 'G';
+    case 'G':
+        return 'C';
+    case 'T':
+        return 'A';
+    default:
+        return 'N';
+    }
+}
+__device__ __forceinline__ int sub_score(uint32_t a, uint32_t b)
+{  // gssw.c:4188-4204 (match 1, mismatch 4)
+    return (a == 4u || b == 4u) ? 0 : (a == b ? 1 : -4);
+}
+
+template <int C>
+__global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    constexpr int ROWS = PG_GROUP_LANES * C;
+    uint32_t* prof = lds;                          // [4 reads][5 codes][ROWS] packed (strand A | strand B << 16)
+    uint32_t* nodekey = lds + PG_GROUPS * 5 * ROWS;  // [n_nodes][4 reads][2 strands]
+
+    const int lane = threadIdx.x;
+    const int grp = lane >> 4;
+    const int k = lane & 15;
+
+    const uint32_t item_idx = a.item_begin + blockIdx.x * a.item_stride;
+    const PgWorkItem* itp = a.items + item_idx;
+    const uint32_t graph = itp->graph;
+    const uint32_t dir = itp->dir;
+    const PgGraphDir gd = a.graphs[graph].dir[dir];
+    const uint32_t* __restrict__ smeta = a.colmeta + gd.meta_off;
+    const PgNode* __restrict__ nodes = a.nodes + gd.node_off;
+    const uint32_t n_nodes = gd.n_nodes;
+
+    // ---- query profiles of the 8 fills into LDS (gssw_qP_byte) ------------------------------------
+    for (int e = lane; e < PG_GROUPS * ROWS; e += 64)
+    {
+        const int g = e / ROWS;
+        const int row = e - g * ROWS;
+        const uint32_t ridx = itp->read[g];
+        uint32_t cA = 5u, cB = 5u;  // 5 = padding row
+        if (ridx != PG_NONE)
+        {
+            const uint32_t off = a.base_off[ridx];
+            const uint32_t L = a.base_off[ridx + 1] - off;
+            if ((uint32_t)row < L)
+            {
+                const uint32_t f = (uint8_t)a.bases[off + row];
+                const uint32_t r = (uint8_t)a.bases[off + L - 1 - row];
+                // dir 0: strand A = toUpper(bases), strand B = reverseComplement(bases)
+                // dir 1: strand A = toUpper(reverse(bases)), strand B = reverseComplement(reverse(bases))
+                //        (GraphAligner.cpp:315-337)
+                const uint32_t chA = dir == 0 ? upper_c(f) : upper_c(r);
+                const uint32_t chB = dir == 0 ? comp_c(r) : comp_c(f);
+                cA = nt_code(chA);
+                cB = nt_code(chB);
+            }
+        }
+#pragma unroll
+        for (uint32_t code = 0; code < 5; ++code)
+        {
+            const int sA = cA == 5u ? PG_PAD_SCORE : sub_score(code, cA);
+            const int sB = cB == 5u ? PG_PAD_SCORE : sub_score(code, cB);
+            prof[(g * 5 + code) * ROWS + row] = ((uint32_t)sA & 0xFFFFu) | ((uint32_t)sB << 16);
+        }
+    }
+    for (uint32_t e = lane; e < n_nodes * 8; e += 64)
+        nodekey[e] = 0;
+    __syncthreads();
+
+    uint32_t* __restrict__ seed = (uint32_t*)(a.workspace + itp->seed_off);  // [node][lane][C]
+    uint32_t* __restrict__ trace = (uint32_t*)(a.workspace + itp->trace_off);  // [step][lane][C/2]
+    const bool store_trace = dir == 0;
+
+    uint32_t Hp[C], E[C];
+#pragma unroll
+    for (int r = 0; r < C; ++r)
+    {
+        Hp[r] = 0;
+        E[r] = 0;
+    }
+    uint32_t Hsend = 0, Fsend = 0;
+    uint32_t M = 0, FC = 0;
+    uint32_t meta = PG_META_IDLE;
+    // packed (col | col << 16) of the column this lane works on; col = t - k (wraps for idle lanes)
+    uint32_t colv = (uint32_t)(0x10000 - k) & 0xFFFFu;
+    colv |= colv << 16;
+    const uint32_t GO2 = PG_GAP_OPEN | (PG_GAP_OPEN << 16);
+    const uint32_t GE2 = PG_GAP_EXT | (PG_GAP_EXT << 16);
+    const uint32_t nsteps = gd.ncols + PG_GROUP_LANES - 1;
+    const uint32_t* profl = prof + grp * 5 * ROWS + k * C;
+
+    for (uint32_t t = 0; t < nsteps; ++t)
+    {
+        const uint32_t m0 = smeta[t];
+        meta = row_shr1_keep(m0, meta);
+        const uint32_t dH = row_shr1_zero(Hsend);
+        uint32_t F = row_shr1_zero(Fsend);
+
+        if (meta & PG_META_FIRST)
+        {
+            // seed = lane-wise max over predecessors (gssw_create_seed_byte); the predecessor that
+            // directly precedes this node in the layout is still in Hp/E.
+            const uint32_t node = PG_META_NODE(meta);
+            const PgNode nd = nodes[node];
+            uint32_t sh[C], se[C];
+#pragma unroll
+            for (int r = 0; r < C; ++r)
+            {
+                sh[r] = 0;
+                se[r] = 0;
+            }
+            bool adj = false;
+            for (uint32_t p = 0; p < nd.n_pred; ++p)
+            {
+                const uint32_t pid = a.preds[nd.pred_off + p];
+                if (pid + 1 == node)
+                {
+                    adj = true;
+                    continue;
+                }
+                const uint32_t* sp = seed + ((size_t)pid * 64 + lane) * C;
+#pragma unroll
+                for (int r = 0; r < C; ++r)
+                {
+                    const uint32_t w = sp[r];  // bytes: H_A, H_B, Enext_A, Enext_B
+                    sh[r] = pk_maxu(sh[r], __builtin_amdgcn_perm(0u, w, 0x0c010c00u));
+                    se[r] = pk_maxu(se[r], __builtin_amdgcn_perm(0u, w, 0x0c030c02u));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < C; ++r)
+            {
+                Hp[r] = adj ? pk_maxu(Hp[r], sh[r]) : sh[r];
+                E[r] = adj ? pk_maxu(E[r], se[r]) : se[r];
+            }
+            M = 0;
+            FC = 0;
+        }
+
+        // ---- one column of the affine-gap recurrence for C rows x 2 strands ------------------------
+        const uint32_t* pr = profl + PG_META_CODE(meta) * ROWS;
+        uint32_t s[C];
+#pragma unroll
+        for (int r = 0; r < C; r += 2)
+        {
+            const uint2 v = *(const uint2*)(pr + r);
+            s[r] = v.x;
+            s[r + 1] = v.y;
+        }
+        uint32_t diag = dH;
+        uint32_t colmax = 0;
+#pragma unroll
+        for (int r = 0; r < C; ++r)
+        {
+            uint32_t h = pk_add(diag, s[r]);  // H(i-1,j-1) + s   (may be negative: signed compare next)
+            h = pk_maxi(h, E[r]);             // E >= 0 makes the explicit max(.,0) unnecessary
+            h = pk_maxu(h, F);
+            diag = Hp[r];
+            Hp[r] = h;
+            const uint32_t tt = pk_subsat(h, GO2);
+            E[r] = pk_maxu(pk_subsat(E[r], GE2), tt);
+            F = pk_maxu(pk_subsat(F, GE2), tt);
+            colmax = pk_maxu(colmax, h);
+        }
+        Hsend = diag;
+        Fsend = F;
+
+        // ---- running node maximum + first column reaching it (gssw.c:369-386) -----------------------
+        {
+            const uint32_t Mn = pk_maxu(M, colmax);
+            uint32_t inc = pk_minu(pk_sub(Mn, M), 0x00010001u);  // 1 where the half grew
+            inc = pk_sub(0u, inc);                               // 0xFFFF where it grew
+            FC = (FC & ~inc) | (colv & inc);
+            M = Mn;
+        }
+
+        if (store_trace)
+        {
+            uint32_t* tp = trace + ((size_t)t * 64 + lane) * (C / 2);
+#pragma unroll
+            for (int r = 0; r < C; r += 2)
+                tp[r / 2] = Hp[r] | (Hp[r + 1] << 8);  // bytes A_r, A_r+1, B_r, B_r+1
+        }
+
+        if (meta & PG_META_LAST)
+        {
+            const uint32_t node = PG_META_NODE(meta);
+            if (meta & PG_META_SAVE)
+            {
+                uint32_t* sp = seed + ((size_t)node * 64 + lane) * C;
+#pragma unroll
+                for (int r = 0; r < C; ++r)
+                    sp[r] = __builtin_amdgcn_perm(E[r], Hp[r], 0x06040200u);
+            }
+            // key: max (8 bits) | inverted column (20 bits) | inverted lane (4 bits)
+            const uint32_t kinv = (uint32_t)(15 - k);
+            const uint32_t mA = M & 0xFFFFu, mB = M >> 16;
+            const uint32_t cA = FC & 0xFFFFu, cB = FC >> 16;
+            if (mA)
+                atomicMax(&nodekey[node * 8 + grp * 2 + 0], (mA << 24) | ((0xFFFFFu - cA) << 4) | kinv);
+            if (mB)
+                atomicMax(&nodekey[node * 8 + grp * 2 + 1], (mB << 24) | ((0xFFFFFu - cB) << 4) | kinv);
+        }
+        colv = pk_add(colv, 0x00010001u);
+    }
+
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- per fill: max_node (first node with the strictly largest score, gssw.c:4015-4018), multi
+    //      flag, end position --------------------------------------------------------------------------
+    if (k < 2)
+    {
+        const int strand = k;
+        uint32_t best = 0, bestkey = 0, bestnode = 0, cnt = 0;
+        for (uint32_t n = 0; n < n_nodes; ++n)
+        {
+            const uint32_t key = nodekey[n * 8 + grp * 2 + strand];
+            const uint32_t m = key >> 24;
+            if (m > best)
+            {
+                best = m;
+                bestkey = key;
+                bestnode = n;
+                cnt = 1;
+            }
+            else if (m == best)
+                ++cnt;
+        }
+        PgFillSummary fs;
+        fs.score = (int32_t)best;
+        fs.max_node = (int32_t)bestnode;
+        fs.ref_end = -1;
+        fs.read_end = 0;
+        fs.end_col = -1;
+        fs.multi = cnt > 1 ? 1 : 0;
+        fs.pad[0] = fs.pad[1] = 0;
+        if (best > 0 && store_trace)
+        {
+            const uint32_t col = 0xFFFFFu - ((bestkey >> 4) & 0xFFFFFu);
+            const uint32_t kk = 15u - (bestkey & 15u);
+            const uint32_t* tp = trace + ((size_t)(col + kk) * 64 + (grp * 16 + kk)) * (C / 2);
+            int rr = 0;
+            bool found = false;
+#pragma unroll
+            for (int r = 0; r < C; r += 2)
+            {
+                const uint32_t w = tp[r / 2];
+                const uint32_t b0 = (w >> (strand * 16)) & 0xFFu;
+                const uint32_t b1 = (w >> (strand * 16 + 8)) & 0xFFu;
+                if (!found && b0 == best)
+                {
+                    rr = r;
+                    found = true;
+                }
+                if (!found && b1 == best)
+                {
+                    rr = r + 1;
+                    found = true;
+                }
+            }
+            fs.end_col = (int32_t)col;
+            fs.ref_end = (int32_t)(col - nodes[bestnode].col_start);
+            fs.read_end = (int32_t)(kk * C) + rr;
+        }
+        a.fillsum[((size_t)item_idx * PG_GROUPS + grp) * 2 + strand] = fs;
+    }
+}
+
+#define PG_INST(CC) template __global__ void pg_fill_kernel<CC>(PgFillArgs);
+PG_INST(2) PG_INST(4) PG_INST(6) PG_INST(8) PG_INST(10) PG_INST(12) PG_INST(14) PG_INST(16)
+
+size_t pg_fill_lds_bytes(int C, uint32_t max_nodes)
+{
+    return (size_t)(PG_GROUPS * 5 * PG_GROUP_LANES * C + max_nodes * 8) * sizeof(uint32_t);
+}
+
+hipError_t pg_launch_fill(int C, const PgFillArgs& args, uint32_t n_items, uint32_t max_nodes, hipStream_t stream)
+{
+    if (n_items == 0)
+        return hipSuccess;
+    const size_t lds = pg_fill_lds_bytes(C, max_nodes);
+    void (*fn)(PgFillArgs) = nullptr;
+    switch (C)
+    {
+    case 2: fn = pg_fill_kernel<2>; break;
+    case 4: fn = pg_fill_kernel<4>; break;
+    case 6: fn = pg_fill_kernel<6>; break;
+    case 8: fn = pg_fill_kernel<8>; break;
+    case 10: fn = pg_fill_kernel<10>; break;
+    case 12: fn = pg_fill_kernel<12>; break;
+    case 14: fn = pg_fill_kernel<14>; break;
+    case 16: fn = pg_fill_kernel<16>; break;
+    default: return hipErrorInvalidValue;
+    }
+    if (lds > 48 * 1024)
+    {
+        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
+    hipLaunchKernelGGL(fn, dim3(n_items), dim3(64), lds, stream, args);
+    return hipGetLastError();
+}

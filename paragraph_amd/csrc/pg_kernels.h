@@ -1,0 +1,47 @@
+// pg_kernels.h -- kernel argument blocks + launch wrappers (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/paragraph_amd.h"
+#include "pg_device.h"
+
+struct PgFillArgs
+{
+    const PgWorkItem* items;
+    uint32_t item_begin;
+    uint32_t item_stride;  // 1: every item; 2: forward-graph items only (AF_REVERSE_GRAPH off)
+    const PgGraphDev* graphs;
+    const PgNode* nodes;
+    const uint32_t* preds;
+    const uint32_t* colmeta;
+    const uint32_t* base_off;
+    const char* bases;
+    uint8_t* workspace;
+    PgFillSummary* fillsum;  // [(item * 4 + group) * 2 + strand]
+};
+
+struct PgTraceArgs
+{
+    const PgWorkItem* items;
+    uint32_t pair_begin;  // first (fwd,rev) item pair of this launch; fwd item = 2*pair, rev = 2*pair+1
+    uint32_t n_pairs;
+    int C;
+    uint32_t flags;  // PG_AF_*
+    const PgGraphDev* graphs;
+    const PgNode* nodes;
+    const uint32_t* preds;
+    const char* seqchars;
+    const uint32_t* base_off;
+    const char* bases;
+    const uint8_t* workspace;
+    const PgFillSummary* fillsum;
+    pg_result* results;     // [read]
+    pg_op* ops_scratch;     // [(pair - pair_begin) * 4 + group][pg_ops_cap(C)]
+    pg_op* ops;             // compact output
+    unsigned long long* ops_counter;
+};
+
+size_t pg_fill_lds_bytes(int C, uint32_t max_nodes);
+hipError_t pg_launch_fill(int C, const PgFillArgs& args, uint32_t n_items, uint32_t max_nodes, hipStream_t stream);
+hipError_t pg_launch_trace(const PgTraceArgs& args, hipStream_t stream);

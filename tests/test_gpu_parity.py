@@ -1,0 +1,104 @@
+"""GPU parity: the HIP path (through the C ABI) must be bit-exact with the oracle on graph_pos, CIGAR,
+score, MAPQ, uniqueness, strand and the four multi flags."""
+import pytest
+
+from tests import fuzzgen
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("graph_pos", "score", "mapq", "unique", "returned_reverse", "multi", "cigar")
+
+ALIGNS_GRAPH = (["AAAAAAAAAAA", "TTTTTTTT", "GGGGGGGG", "AAAAAAAAAAA"], [(0, 1), (0, 2), (0, 3), (1, 3), (2, 3)])
+ALIGNS_READS = ["AAAAAAAATTTTCTTTAAAAAAAA", "TTTTTTAAAGAAAATTTTTTT", "AAAAAGCGGGGGGAAAAAA", "AAAAGCGGGGGGAAAAAA",
+                "TTTTTTCCCCCCGCTTTTT", "AAAAAAAAAAAAAAAAAAA"]
+# src/c++/test/test_paragraph_parts.cpp:111-143 (graphPos, graphCigar, score, mapq, reverse strand)
+ALIGNS_EXPECTED = [(3, "0[8M]1[4M1X3M]3[8M]", 19, 60, False), (4, "0[7M]1[4M1X3M]3[6M]", 16, 60, True),
+                   (6, "0[5M]2[1M1X6M]3[6M]", 14, 60, False), (7, "0[4M]2[1M1X6M]3[6M]", 13, 60, False),
+                   (6, "0[5M]2[1M1X6M]3[6M]", 14, 60, True), (0, "0[11M]3[8M]", 19, 60, False)]
+
+
+def gpu_align(ctx, graphs, reads, graph_of_read=None, flags=0xFFFFFFFF):
+    from paragraph_amd import capi
+    G = ctx.upload_graphs(graphs)
+    b = ctx.new_batch()
+    b.upload(G, reads, graph_of_read)
+    b.align(flags)
+    res, ops = b.download()
+    out = capi.results_to_dicts(res, ops)
+    b.close()
+    G.close()
+    return out
+
+
+def compare(got, want, reads, what=""):
+    bad = []
+    for i, (g, w) in enumerate(zip(got, want)):
+        if w["score"] == 0:
+            # degenerate all-zero fill: empty CIGAR at position 0; flagged with status 1
+            ok = g["score"] == 0 and g["cigar"] == "" and g["graph_pos"] == 0 and g["status"] == 1 \
+                and g["multi"] == w["multi"] and g["mapq"] == w["mapq"]
+        else:
+            ok = all(g[k] == w[k] for k in KEYS) and g["status"] == 0
+        if not ok:
+            bad.append((i, reads[i], g, w))
+    assert not bad, "%s: %d/%d mismatches, first: %r" % (what, len(bad), len(reads), bad[:2])
+
+
+def test_reference_unit_vectors(gpu_ctx):
+    got = gpu_align(gpu_ctx, [ALIGNS_GRAPH], ALIGNS_READS)
+    for g, (pos, cigar, score, mapq, rev) in zip(got, ALIGNS_EXPECTED):
+        assert (g["graph_pos"], g["cigar"], g["score"], g["mapq"], g["returned_reverse"]) == (pos, cigar, score, mapq, rev)
+
+
+def test_fuzz_many_graphs(gpu_ctx, checker):
+    graphs, reads, gor = [], [], []
+    want = []
+    for gi, (seqs, edges, rs) in enumerate(fuzzgen.cases(2024, 300, 10)):
+        graphs.append((seqs, edges))
+        reads.extend(rs)
+        gor.extend([gi] * len(rs))
+        want.extend(checker.align_batch(seqs, edges, rs))
+    got = gpu_align(gpu_ctx, graphs, reads, gor)
+    compare(got, want, reads, "fuzz")
+
+
+def test_fuzz_long_reads(gpu_ctx, checker):
+    import random
+    rng = random.Random(5)
+    graphs, reads, gor, want = [], [], [], []
+    for gi in range(60):
+        seqs, edges = fuzzgen.rand_graph(rng, max_len=150, max_nodes=5)
+        rs = [fuzzgen.rand_read(rng, seqs, edges, min_len=100, max_len=250)[:250] for _ in range(8)]
+        graphs.append((seqs, edges))
+        reads.extend(rs)
+        gor.extend([gi] * len(rs))
+        want.extend(checker.align_batch(seqs, edges, rs))
+    got = gpu_align(gpu_ctx, graphs, reads, gor)
+    compare(got, want, reads, "fuzz-long")
+
+
+def test_config2_sample(gpu_ctx, checker):
+    from paragraph_amd import synth
+    site, reads = synth.config2_reads(4096, read_len=150, seed=2)
+    want = checker.align_batch(site.seqs, site.edges, reads, threads=8)
+    got = gpu_align(gpu_ctx, [(site.seqs, site.edges)], reads)
+    compare(got, want, reads, "config2")
+
+
+def test_flags(gpu_ctx, checker):
+    from paragraph_amd import capi
+    seqs, edges = ALIGNS_GRAPH
+    for flags in (capi.AF_CIGAR, capi.AF_CIGAR | capi.AF_BOTH_STRANDS, capi.AF_CIGAR | capi.AF_REVERSE_GRAPH):
+        want = checker.align_batch(seqs, edges, ALIGNS_READS, flags=flags)
+        got = gpu_align(gpu_ctx, [ALIGNS_GRAPH], ALIGNS_READS, flags=flags)
+        compare(got, want, ALIGNS_READS, "flags=%d" % flags)
+
+
+def test_empty_and_ragged(gpu_ctx, checker):
+    seqs, edges = ALIGNS_GRAPH
+    reads = ["", "A", "ACGT" * 60 + "AC", "", "TTTTTTTT"]
+    got = gpu_align(gpu_ctx, [ALIGNS_GRAPH], reads)
+    assert got[0]["status"] == 1 and got[3]["status"] == 1  # skipped like Align.cpp:74-77
+    idx = [1, 2, 4]
+    want = checker.align_batch(seqs, edges, [reads[i] for i in idx])
+    compare([got[i] for i in idx], want, [reads[i] for i in idx], "ragged")

@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the read -> variant-graph realignment path on MI355X.
+
+A "step" is one pass of the hot path (4 graph fills + strand pick + traceback per read, i.e. the default
+grmpy cascade GraphAligner::alignRead(AF_ALL)) over one batch of synthetic reads that is already
+resident in HBM when the timed region starts.
+
+Workload at N=1 = BASELINE.json configs[1]: 1 DEL graph (200 bp flanks, 100 bp deletion; nodes
+201/100/201 bp, G = 502), 1 000 000 synthetic 150 bp reads.  With N GPUs
+every rank runs the same-sized batch on its own GPU (weak scaling, reads/sites are independent; no
+data-path collective; the only collective is the RCCL reduce of a small per-rank tally table at the end
+of each step).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- dominant kernel (pg_fill_kernel): algorithmic bytes of SURVEY.md 8(d)
+                  (B_alg = 6*L*G + L + 64 per read) / HIP-event duration of its launches / 8 TB/s
+  cpu_baseline -- the reference's own gssw.c (oracle/_ref, kind "reference") or the plain-C port, timed
+                  on this host's cores on a bounded sample of the same reads, chunk-per-thread as the
+                  reference parallelises (Align.cpp:114-156)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=1000000, help="reads per GPU per step (config 2: 1M)")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--workspace-gib", type=float, default=16.0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_r01.json"),
+                    help="PMC-derived HBM bytes per fill launch (written by tools/pmc_traffic.py), optional")
+    return ap.parse_args()
+
+
+def cpu_baseline(site, arr, seconds):
+    """Times the CPU checker on a bounded sample of the same reads (rank 0, N=1 only).
+
+    The thread count is chosen by a short probe (gssw allocates and zeroes 11 buffers per node per fill,
+    gssw.c:186-212, so it stops scaling long before a big host runs out of cores); `cores` reports the
+    thread count actually used for the timed sample."""
+    from oracle import oracle as orc
+    if orc.have_ref():
+        chk, kind, label = orc.RefOracle(), "reference", "reference gssw.c (oracle/_ref)"
+    else:
+        chk, kind, label = orc.PortOracle(), "port", "plain-C restatement (oracle/pg_oracle.c)"
+    ncpu = os.cpu_count() or 1
+    reads = [row.tobytes().decode() for row in arr[:min(len(arr), 400000)]]
+    best_t, best_rate, worse = 1, 0.0, 0
+    t = 1
+    chk.align_batch(site.seqs, site.edges, reads[:64], threads=1, want_cigars=True)  # warm-up
+    while t <= ncpu and worse < 2:
+        n = min(len(reads), 256 * t)
+        t0 = time.perf_counter()
+        chk.align_batch(site.seqs, site.edges, reads[:n], threads=t, want_cigars=True)
+        rate = n / max(time.perf_counter() - t0, 1e-6)
+        log("cpu probe: %d threads -> %.0f reads/s" % (t, rate))
+        if rate > best_rate:
+            best_t, best_rate, worse = t, rate, 0
+        else:
+            worse += 1
+        t *= 2
+    done, spent, pos = 0, 0.0, 0
+    slice_n = max(best_t * 16, int(best_rate * 2.0))
+    while spent < seconds and pos < len(reads):
+        n = min(slice_n, len(reads) - pos)
+        t0 = time.perf_counter()
+        chk.align_batch(site.seqs, site.edges, reads[pos:pos + n], threads=best_t, want_cigars=True)
+        spent += time.perf_counter() - t0
+        done += n
+        pos += n
+    return {"value": done / spent, "unit": "reads/s", "cores": best_t, "kind": kind,
+            "sample": "%d of the same config-2 reads, %s, %d threads of %d host CPUs (one aligner per contiguous "
+                      "chunk, Align.cpp:114-156; thread count picked by a throughput probe), %.1f s"
+                      % (done, label, best_t, ncpu, spent)}
+
+
+def log(msg):
+    if os.environ.get("PG_BENCH_VERBOSE"):
+        print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        try:
+            import torch
+        except Exception:  # torch is only plumbing here (barrier + device sync)
+            torch = None
+
+    from paragraph_amd import capi, synth
+
+    # ---- workload: config 2, a different read seed per rank (weak scaling) -------------------------
+    log("generating reads")
+    site, arr = synth.config2_reads_packed(args.reads, read_len=args.read_len, seed=2 + rank)
+    log("reads generated")
+    G = site.total_len
+    L = args.read_len
+    ctx = capi.Context(local_rank, workspace_bytes=int(args.workspace_gib * (1 << 30)))
+    graphs = ctx.upload_graphs([(site.seqs, site.edges)])
+    batch = ctx.new_batch()
+    t0 = time.perf_counter()
+    batch.upload(graphs, synth.packed_to_capi(arr))
+    ctx.sync()
+    t_upload = time.perf_counter() - t0
+    log("uploaded in %.2fs" % t_upload)
+
+    tally = None
+    if world > 1:
+        tally = torch.zeros(8, dtype=torch.int64, device="cuda")
+
+    def barrier():
+        ctx.sync()
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def step():
+        batch.align(capi.AF_ALL)
+        if world > 1:
+            # final read-count reduce (small integer table, RCCL over xGMI)
+            ctx.sync()
+            dist.all_reduce(tally)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    log("warmup done")
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    log("timed region %.3fs" % elapsed)
+    tim = ctx.timing()
+    ctx.timing_enable(False)
+
+    # PCIe-inclusive leg (not the headline value): download of results + ops
+    t0 = time.perf_counter()
+    res, ops = batch.download()
+    t_download = time.perf_counter() - t0
+    log("downloaded in %.2fs" % t_download)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        reads_total = args.reads * world * args.steps
+        value = reads_total / elapsed
+        b_alg = 6 * L * G + L + 64
+        fill_s = tim["fill_ms"] / 1e3
+        reads_per_fill_leg = args.reads * args.steps  # this rank's fill launches
+        achieved_gbs = reads_per_fill_leg * b_alg / fill_s / 1e9 if fill_s > 0 else 0.0
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                with open(args.traffic_json) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "150bp reads aligned/sec (whole node)",
+            "value": value,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u16x2 packed (8-bit scores)",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: 1 DEL graph (200bp flanks, nodes 201/100/201), %d synthetic %dbp reads per GPU, "
+                            "GraphAligner::alignRead(AF_ALL) = 4 fills + strand pick + traceback per read"
+                            % (args.reads, L),
+                "reads_per_gpu": args.reads, "read_len": L, "graph_len": G, "parallelism": "reads x%d" % world,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "pg_fill_kernel<%d>" % (2 * ((L + 31) // 32)),
+                "launches": int(tim["fill_launches"]),
+                "avg_launch_ms": tim["fill_ms"] / max(1, tim["fill_launches"]),
+                "alg_bytes_per_read": b_alg,
+                "alg_bytes_per_launch": b_alg * reads_per_fill_leg / max(1, tim["fill_launches"]),
+                "gcups": tim["cells"] / fill_s / 1e9 if fill_s > 0 else 0.0,
+                "trace_bytes_written_per_read": tim["trace_bytes"] / max(1, reads_per_fill_leg),
+            },
+            "kernel_ms": {"fill": tim["fill_ms"], "trace": tim["trace_ms"]},
+            "pcie_inclusive": {
+                "upload_s": t_upload, "download_s": t_download,
+                "reads_per_s": args.reads / (t_upload + elapsed / args.steps + t_download),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(site, arr, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,13 +123,13 @@ def longdel_site(contig, start, end, flank=150):
                 {"DEL": [1, 4], "REF_L": [1, 2], "REF_R": [3, 4]})
 
 
-def simulate_reads(site, n, read_len, seed, sub_rate=0.01, indel_frac=0.001, random_frac=0.005, n_frac=0.0,
-                   hap_weights=None):
-    """n reads of length read_len sampled from the site's haplotypes.
+def simulate_reads_packed(site, n, read_len, seed, sub_rate=0.01, indel_frac=0.001, random_frac=0.005, n_frac=0.0,
+                          hap_weights=None):
+    """n reads of length read_len sampled from the site's haplotypes, as an (n, read_len) uint8 array.
 
     haplotype ~ hap_weights (uniform default), start uniform such that the read fits, strand 50/50,
     i.i.d. substitutions at sub_rate, indel_frac of reads carry one 1-3 bp indel, random_frac are
-    unrelated random sequence, n_frac of bases become 'N'.  Returns list[str]."""
+    unrelated random sequence, n_frac of bases become 'N'."""
     rng = SplitMix64(seed)
     labels = sorted(site.haplotypes)
     haps = [np.frombuffer(site.haplotype_seq(lab).encode(), dtype=np.uint8) for lab in labels]
@@ -145,28 +145,30 @@ def simulate_reads(site, n, read_len, seed, sub_rate=0.01, indel_frac=0.001, ran
     kind_u = rng.uniform_vector(n)
     out = np.empty((n, read_len), dtype=np.uint8)
     cols = np.arange(read_len)
-    # room for a deletion inside the read: sample a slightly longer window
     for hi, h in enumerate(haps):
         sel = np.nonzero(hap_idx == hi)[0]
         if len(sel) == 0:
             continue
         st = np.floor(start_u[sel] * (len(h) - read_len + 1)).astype(np.int64)
         out[sel] = h[st[:, None] + cols[None, :]]
-    # substitutions: replace by one of the three other bases
-    sub_u = rng.uniform_vector(n * read_len).reshape(n, read_len)
-    sub_b = (rng.vector(n * read_len) % np.uint64(3)).astype(np.int64).reshape(n, read_len)
+    # substitutions: replace by one of the three other bases (chunked to bound memory)
     code = np.zeros(256, dtype=np.int64)
     for k, c in enumerate(b"ACGT"):
         code[c] = k
-    mask = sub_u < sub_rate
-    cur = code[out]
-    out = np.where(mask, _ACGT[(cur + 1 + sub_b) & 3], out)
-    reads = []
-    for i in range(n):
+    step = max(1, (1 << 22) // read_len)
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        m = (hi - lo) * read_len
+        sub_u = rng.uniform_vector(m).reshape(hi - lo, read_len)
+        sub_b = (rng.vector(m) % np.uint64(3)).astype(np.int64).reshape(hi - lo, read_len)
+        blk = out[lo:hi]
+        out[lo:hi] = np.where(sub_u < sub_rate, _ACGT[(code[blk] + 1 + sub_b) & 3], blk)
+    special = np.nonzero(kind_u < random_frac + indel_frac)[0]
+    for i in special:
         r = out[i]
         if kind_u[i] < random_frac:
             r = _ACGT[(rng.vector(read_len) & np.uint64(3)).astype(np.int64)]
-        elif kind_u[i] < random_frac + indel_frac:
+        else:
             k = 1 + rng.below(3)
             p = 10 + rng.below(max(1, read_len - 20 - k))
             if rng.below(2):  # insertion of k random bases (read keeps its length: tail is dropped)
@@ -175,13 +177,27 @@ def simulate_reads(site, n, read_len, seed, sub_rate=0.01, indel_frac=0.001, ran
             else:  # deletion of k bases (pad the tail with random bases)
                 pad = _ACGT[(rng.vector(k) & np.uint64(3)).astype(np.int64)]
                 r = np.concatenate([r[:p], r[p + k:], pad])[:read_len]
-        if n_frac > 0:
-            nu = rng.uniform_vector(read_len)
-            r = np.where(nu < n_frac, np.uint8(ord("N")), r)
-        if strand[i]:
-            r = _COMP[r][::-1]
-        reads.append(r.tobytes().decode())
-    return reads
+        out[i] = r
+    if n_frac > 0:
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
+            nu = rng.uniform_vector((hi - lo) * read_len).reshape(hi - lo, read_len)
+            out[lo:hi] = np.where(nu < n_frac, np.uint8(ord("N")), out[lo:hi])
+    rc = _COMP[out[strand]][:, ::-1]
+    out[strand] = rc
+    return out
+
+
+def packed_to_capi(arr):
+    """(n, L) uint8 array -> (uint32 offsets[n+1], bytes) as capi.pack_reads returns."""
+    n, L = arr.shape
+    return (np.arange(n + 1, dtype=np.uint64) * np.uint64(L)).astype(np.uint32), arr.tobytes()
+
+
+def simulate_reads(site, n, read_len, seed, **kw):
+    """Same data as simulate_reads_packed, as list[str]."""
+    arr = simulate_reads_packed(site, n, read_len, seed, **kw)
+    return [row.tobytes().decode() for row in arr]
 
 
 def config2_site(flank=200, del_len=100, contig_seed=1):
@@ -194,3 +210,8 @@ def config2_site(flank=200, del_len=100, contig_seed=1):
 def config2_reads(n, read_len=150, seed=2):
     site = config2_site()
     return site, simulate_reads(site, n, read_len, seed)
+
+
+def config2_reads_packed(n, read_len=150, seed=2):
+    site = config2_site()
+    return site, simulate_reads_packed(site, n, read_len, seed)

@@ -32,17 +32,8 @@ def build_hip(force=False, verbose=False):
     return LIB
 
 
-def build_oracle(verbose=False):
-    """Test infrastructure: the plain-C restatement, and (only where /root/reference exists) the
-    reference's own gssw.c behind oracle/ref_harness.c.  Building the checker is not using it."""
-    odir = os.path.join(ROOT, "oracle")
-    subprocess.run(["make", "-C", odir, "port"], check=True, stdout=None if verbose else subprocess.DEVNULL)
-    subprocess.run(["make", "-C", odir, "ref"], check=True, stdout=None if verbose else subprocess.DEVNULL)
-
-
 def build_all(force=False, verbose=False):
     build_hip(force=force, verbose=verbose)
-    build_oracle(verbose=verbose)
 
 
 if __name__ == "__main__":

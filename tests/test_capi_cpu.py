@@ -1,0 +1,69 @@
+"""CPU tests of the boundary: the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/paragraph_amd.h declares.  No compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "paragraph_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(pg_[a-z_0-9]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_header_symbols_exported():
+    from paragraph_amd import build, capi
+    build.build_hip()
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), "missing export: " + name
+    assert sorted(capi.EXPORTS) == declared
+
+
+def test_result_struct_layout():
+    from paragraph_amd import capi
+    assert capi.RESULT_DTYPE.itemsize == 24
+    assert capi.RESULT_DTYPE.fields["ops_off"][1] == 12 and capi.RESULT_DTYPE.fields["status"][1] == 22
+
+
+def test_no_device_fails_loudly():
+    """Without a HIP device the product path must fail, not fall back to a CPU implementation."""
+    import pytest
+    from paragraph_amd import capi
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present")
+    except ImportError:
+        pass
+    with pytest.raises(capi.PgError) as ei:
+        capi.Context(0)
+    assert ei.value.status == 2  # PG_ERR_NO_DEVICE
+
+
+def test_render_cigar_helper():
+    import numpy as np
+    from paragraph_amd import capi
+    res = np.zeros(1, dtype=capi.RESULT_DTYPE)
+    ops = np.array([(0 << 20) | (5 << 16) | 3, (0 << 20) | (0 << 16) | 8, (1 << 20) | (1 << 16) | 1,
+                    (3 << 20) | (4 << 16) | 2, (3 << 20) | (0 << 16) | 7], dtype=np.uint32)
+    res[0]["n_ops"] = len(ops)
+    assert capi.render_cigar(res[0], ops) == "0[3S8M]1[1X]3[2D7M]"
+    lib = capi.load_library()
+    buf = ctypes.create_string_buffer(64)
+    n = lib.pg_render_cigar(res.ctypes.data, ops.ctypes.data, buf, 64)
+    assert buf.value.decode() == "0[3S8M]1[1X]3[2D7M]" and n == len(buf.value)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under paragraph_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "paragraph_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".hh")):
+                text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "oracle" not in text.replace("no oracle", ""), os.path.join(dirpath, fn)

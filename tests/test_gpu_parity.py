@@ -102,3 +102,27 @@ def test_empty_and_ragged(gpu_ctx, checker):
     idx = [1, 2, 4]
     want = checker.align_batch(seqs, edges, [reads[i] for i in idx])
     compare([got[i] for i in idx], want, [reads[i] for i in idx], "ragged")
+
+
+def test_golden_fixtures(gpu_ctx):
+    """Committed vectors generated from the reference's gssw.c (tests/golden/make_golden.py)."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.abspath(__file__))
+    n = 0
+    for path in sorted(glob.glob(os.path.join(root, "golden", "*.json"))):
+        with open(path) as f:
+            fx = json.load(f)
+        graphs, reads, gor, want = [], [], [], []
+        for gi, s in enumerate(fx["sets"]):
+            graphs.append((s["nodes"], [tuple(e) for e in s["edges"]]))
+            reads.extend(s["reads"])
+            gor.extend([gi] * len(s["reads"]))
+            want.extend(s["expected"])
+        got = gpu_align(gpu_ctx, graphs, reads, gor)
+        compare(got, want, reads, os.path.basename(path))
+        for g, w in zip(got, want):
+            assert g["strand_score"][0] == w["scores"][0] and g["strand_score"][1] == w["scores"][1]
+        n += len(reads)
+    assert n > 900

@@ -21,6 +21,15 @@
  *   pg_batch_download    the graph_* fields written into common::Read  src/c++/include/common/Read.hh:40-264
  *   pg_align_batch       one-shot convenience = upload + align + download
  *   pg_render_cigar      GraphAlignerImpl::extractCigar         GraphAligner.cpp:88-108
+ *   pg_graphs_set_labels graphtools::Graph::addLabelToEdge as grm::graphFromJson fills it   src/c++/lib/grm/GraphInput.cpp:126-156
+ *   pg_batch_count       read filters (NonUniq, BadAlign) applied by CompositeAligner::alignRead
+ *                                                               src/c++/lib/paragraph/ReadFilter.cpp:43-90, readfilters/*.hh,
+ *                                                               src/c++/lib/grm/CompositeAligner.cpp:152-175
+ *                        + paragraph::disambiguateReads with the production node/edge filters
+ *                                                               src/c++/lib/paragraph/Disambiguation.cpp:82-142, 212-296
+ *                        + paragraph::countReads (fragments, node/edge/sequence counts)
+ *                                                               src/c++/lib/paragraph/ReadCounting.cpp:52-127, 225-244,
+ *                                                               src/c++/lib/common/Fragment.cpp:34-69, 141-181
  *
  * Threading: one pg_ctx per device; calls on one ctx must be serialised by the caller (same rule
  * as one CompositeAligner instance per worker in the reference, Align.cpp:107-110).
@@ -158,6 +167,71 @@ pg_status pg_batch_download(
 pg_status pg_align_batch(
     pg_ctx* ctx, const pg_graphs* graphs, uint32_t n_reads, const uint32_t* graph_of_read, const uint32_t* base_off,
     const char* bases, uint32_t flags, pg_result* results, pg_op* ops, uint64_t ops_cap, uint64_t* n_ops);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Count path: read filters -> node/edge/sequence support per read -> per-fragment union -> per-site
+ * counters {count, :READS, :FWD, :REV} (ReadCounting.cpp:52-69).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct pg_count_params
+{
+    uint32_t remove_nonuniq;      /* paragraph --bad-align-nonuniq (default 1); grmpy has no such filter (0) */
+    uint32_t use_support_filters; /* 1: production nodefilter/edgefilter (Disambiguation.cpp:212-296); 0: none
+                                     (what the reference's unit tests call disambiguateReads with) */
+    double bad_align_frac;        /* --bad-align-frac, default 0.8 */
+} pg_count_params;
+
+/* Per-read outcome of the count path. */
+typedef struct pg_read_support
+{
+    uint64_t label_mask; /* Read::graph_sequences_supported as a bit set over the graph's labels */
+    uint32_t path_off;   /* first entry in the path array */
+    uint16_t n_path;     /* nodes on the read's path */
+    uint8_t status;      /* 0 not aligned / skipped, 1 MAPPED, 2 BAD_ALIGN (filtered), 3 invalid alignment */
+    uint8_t filter;      /* 0 none, 1 nonuniq, 2 bad_align */
+} pg_read_support;
+/* path entry: node id | (node supported) << 30 | (edge from the previous path node supported) << 31 */
+#define PG_PATH_NODE(x) ((uint32_t)(x) & 0xFFFu)
+#define PG_PATH_NODE_OK(x) (((uint32_t)(x) >> 30) & 1u)
+#define PG_PATH_EDGE_OK(x) (((uint32_t)(x) >> 31) & 1u)
+
+enum
+{
+    PG_MAX_LABELS = 64,         /* labels per graph (bit set) */
+    PG_MAX_SEQ_TABLE_LABELS = 8 /* graphs with more labels get no dense sequence-set table (slots = 0) */
+};
+
+/* Layout of the uint32 counter table of a graph set: [nodes*4][edges*4][seq slots*4][tallies*4].
+ * nodes/edges are indexed like the node / predecessor CSR given to pg_graphs_upload (edge k = k-th
+ * predecessor entry); graph g owns seq slots [seq_off[g], seq_off[g] + 2^n_labels(g)) indexed by label
+ * bit set; tallies per graph = {aligned, mapped, bad_align, nonuniq}. */
+typedef struct pg_count_layout
+{
+    uint64_t n_counters; /* total uint32 entries */
+    uint64_t node_base, edge_base, seq_base, tally_base; /* in uint32 entries */
+    uint64_t n_nodes, n_edges, n_seq_slots, n_graphs;
+} pg_count_layout;
+
+/* label_mask_of_pred[k] = bit set of the labels on the edge (pred[k] -> its node), same indexing as the
+ * `pred` array of pg_graphs_upload; n_labels[g] = number of labels of graph g (<= 64). */
+pg_status pg_graphs_set_labels(
+    pg_ctx* ctx, pg_graphs* graphs, const uint64_t* label_mask_of_pred, const uint32_t* n_labels);
+pg_status pg_graphs_count_layout(const pg_graphs* graphs, pg_count_layout* out);
+/* seq_off[g] (n_graphs + 1 entries) of the layout above */
+pg_status pg_graphs_seq_offsets(const pg_graphs* graphs, uint64_t* seq_off);
+
+/* Runs the count path on the device for the batch's last pg_batch_align results.
+ * fragment_of_read: fragment id per read (mates share an id; ids are local to the read's graph);
+ * is_reverse_strand: Read::is_reverse_strand() of the input (BAM flag), may be NULL (all forward);
+ * d_counts: DEVICE pointer to pg_count_layout.n_counters uint32 the kernel ADDS into (caller zeroes it; e.g. a
+ * torch tensor that is then all-reduced with RCCL), or NULL to use a table owned by the batch (zeroed per call). */
+pg_status pg_batch_count(
+    pg_ctx* ctx, pg_batch* batch, const pg_count_params* params, const uint32_t* fragment_of_read,
+    const uint8_t* is_reverse_strand, uint32_t* d_counts);
+/* Copies the count table (if the batch owns it; pass NULL otherwise), per-read supports and path entries
+ * (capacity path_cap entries; *n_path receives the number used) to host memory; synchronises. */
+pg_status pg_batch_download_counts(
+    pg_ctx* ctx, pg_batch* batch, uint32_t* counts, pg_read_support* supports, uint32_t* path, uint64_t path_cap,
+    uint64_t* n_path);
 
 /* Renders "<node>[<len><op>...]..." for one read into buf (NUL-terminated); returns the string length
  * (which may be >= cap, in which case the output was truncated). Host-only helper. */

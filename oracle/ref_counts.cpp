@@ -1,0 +1,359 @@
+/*
+ * oracle/ref_counts.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Count-path checker built on the REFERENCE's own graph-tools library (unpacked from
+ * /root/reference/external/graph-tools.tar.gz into a temporary directory by oracle/Makefile and
+ * compiled as-is): graphtools::Graph, Path (validity rules), PathFamily::containsPath,
+ * decodeGraphAlignment, Alignment/Operation counters are the reference's code.  What is restated here
+ * is only the glue that cannot be compiled in this image (it lives in translation units that pull
+ * Boost/jsoncpp/spdlog):
+ *
+ *   read filters NonUniq / BadAlign + chain     src/c++/lib/paragraph/readfilters/NonUniq.hh:48-52,
+ *                                               BadAlign.hh:62-73, lib/paragraph/ReadFilter.cpp:43-90
+ *   CompositeAligner filter step (gssw stage)   src/c++/lib/grm/CompositeAligner.cpp:152-175
+ *   nodefilter / edgefilter lambdas             src/c++/lib/paragraph/Disambiguation.cpp:212-296
+ *   disambiguateReads                           src/c++/lib/paragraph/Disambiguation.cpp:82-142
+ *   Fragment::addRead / readsToFragments        src/c++/lib/common/Fragment.cpp:34-69, 141-181
+ *   countNodes / countEdges / countPathFamilies src/c++/lib/paragraph/ReadCounting.cpp:52-127
+ *
+ * Interface limits (checker only): <= 64 nodes, <= 64 edges, <= 64 labels per graph.
+ */
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <list>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "graphalign/GraphAlignment.hh"
+#include "graphalign/GraphAlignmentOperations.hh"
+#include "graphcore/Graph.hh"
+#include "graphcore/Path.hh"
+#include "graphcore/PathFamily.hh"
+
+using graphtools::Graph;
+using graphtools::GraphAlignment;
+using graphtools::NodeId;
+using graphtools::decodeGraphAlignment;
+
+struct pgrefc_graph
+{
+    Graph graph;
+    std::vector<std::pair<NodeId, NodeId>> edges;
+    std::map<std::pair<NodeId, NodeId>, uint32_t> edge_index;
+    std::vector<std::string> labels;
+    std::map<std::string, uint32_t> label_index;
+};
+
+struct pgrefc_params
+{
+    int32_t remove_nonuniq;  // paragraph: --bad-align-nonuniq (default true); grmpy: false
+    double bad_align_frac;   // 0.8
+    int32_t use_support_filters;  // 1: production nodefilter/edgefilter lambdas, 0: none (unit-test mode)
+};
+
+extern "C" pgrefc_graph* pgrefc_graph_create(
+    uint32_t n_nodes, const uint32_t* seq_off, const char* seq, uint32_t n_edges, const uint32_t* from,
+    const uint32_t* to, const uint32_t* label_off, const uint32_t* label_ids, uint32_t n_labels,
+    const char* const* label_names)
+{
+    if (n_nodes > 64 || n_edges > 64 || n_labels > 64)
+        return nullptr;
+    auto* g = new pgrefc_graph{ Graph(n_nodes, false), {}, {}, {}, {} };  // expansion off as graphFromJson (GraphInput.cpp:62)
+    for (uint32_t i = 0; i < n_nodes; ++i)
+    {
+        g->graph.setNodeName(i, "n" + std::to_string(i));
+        g->graph.setNodeSeq(i, std::string(seq + seq_off[i], seq + seq_off[i + 1]));
+    }
+    for (uint32_t l = 0; l < n_labels; ++l)
+    {
+        g->labels.emplace_back(label_names[l]);
+        g->label_index[label_names[l]] = l;
+    }
+    try
+    {
+        for (uint32_t e = 0; e < n_edges; ++e)
+        {
+            g->graph.addEdge(from[e], to[e]);
+            g->edges.emplace_back(from[e], to[e]);
+            g->edge_index[{ from[e], to[e] }] = e;
+            for (uint32_t k = label_off[e]; k < label_off[e + 1]; ++k)
+                g->graph.addLabelToEdge(from[e], to[e], g->labels[label_ids[k]]);
+        }
+    }
+    catch (std::exception const&)
+    {
+        delete g;
+        return nullptr;
+    }
+    return g;
+}
+
+extern "C" void pgrefc_graph_destroy(pgrefc_graph* g) { delete g; }
+
+namespace
+{
+struct ReadRec
+{
+    int32_t pos;
+    std::string cigar;
+    size_t read_len;
+    bool unique, graph_reverse;
+    uint32_t fragment;
+    int status;  // 0 not aligned, 1 MAPPED, 2 BAD_ALIGN
+    std::set<NodeId> nodes;
+    std::set<std::pair<NodeId, NodeId>> edges;
+    std::set<std::string> labels;
+};
+
+// Disambiguation.cpp:212-242
+bool node_filter(const Graph& graph, const ReadRec& read, NodeId node_id)
+{
+    try
+    {
+        GraphAlignment alignment = decodeGraphAlignment(read.pos, read.cigar, &graph);
+        const bool is_short_node = graph.nodeSeq(node_id).size() < read.read_len / 2;
+        int32_t index = 0;
+        for (const auto& node_alignment : alignment)
+        {
+            if (node_id == alignment.getNodeIdByIndex(index))
+            {
+                const size_t nonmatch = node_alignment.numMismatched() + node_alignment.numClipped();
+                const size_t indel = node_alignment.numInserted() + node_alignment.numDeleted();
+                if (is_short_node && (nonmatch > 0 || indel > 0))
+                    return false;
+                return nonmatch + indel <= read.read_len / 2;
+            }
+            ++index;
+        }
+    }
+    catch (std::exception const&)
+    {
+    }
+    return false;
+}
+
+// Disambiguation.cpp:244-296
+bool edge_filter(const Graph& graph, const ReadRec& read, NodeId node_id1, NodeId node_id2)
+{
+    try
+    {
+        GraphAlignment alignment = decodeGraphAlignment(read.pos, read.cigar, &graph);
+        const graphtools::Alignment* previous_alignment = nullptr;
+        auto previous_node_id = static_cast<NodeId>(-1);
+        int32_t index = 0;
+        for (const auto& node_alignment : alignment)
+        {
+            const auto node_alignment_node_id = alignment.getNodeIdByIndex(index);
+            if (previous_alignment != nullptr && previous_node_id == node_id1 && node_alignment_node_id == node_id2)
+            {
+                auto const min_node_overlap = static_cast<int32_t>(read.read_len / 10 + 1);
+                bool status
+                    = (previous_alignment->numMatched()
+                           >= (unsigned)std::min(previous_alignment->referenceLength(), (uint32_t)min_node_overlap)
+                       && node_alignment.numMatched()
+                           >= (unsigned)std::min(node_alignment.referenceLength(), (uint32_t)min_node_overlap));
+                if (status)
+                    status = (previous_alignment->queryLength() < previous_alignment->referenceLength() * 2)
+                        && (node_alignment.queryLength() < node_alignment.referenceLength() * 2);
+                if (status)
+                {
+                    const auto node1_length = static_cast<int32_t>(graph.nodeSeq(node_id1).size());
+                    const auto node2_length = static_cast<int32_t>(graph.nodeSeq(node_id2).size());
+                    status = ((int32_t)previous_alignment->numMatched() >= std::min(node1_length, min_node_overlap))
+                        && ((int32_t)node_alignment.numMatched() >= std::min(node2_length, min_node_overlap));
+                }
+                return status;
+            }
+            previous_alignment = &node_alignment;
+            previous_node_id = node_alignment_node_id;
+            ++index;
+        }
+    }
+    catch (std::exception const&)
+    {
+    }
+    return false;
+}
+
+struct Frag
+{
+    uint64_t n_reads = 0, n_fwd = 0, n_rev = 0;
+    std::set<NodeId> nodes;
+    std::set<std::pair<NodeId, NodeId>> edges;
+    std::set<std::string> labels;
+};
+
+void add_count(uint64_t* c, const Frag& f)
+{  // ReadCounting.cpp:52-69
+    c[0] += 1;
+    c[1] += f.n_reads;
+    c[2] += f.n_fwd;
+    c[3] += f.n_rev;
+}
+}  // namespace
+
+/*
+ * Runs filter -> disambiguate -> fragments -> counts for the reads of ONE site.
+ * per-read outputs: status (0 skipped, 1 MAPPED, 2 BAD_ALIGN), node/edge/label support masks
+ * site outputs: node_counts[n_nodes*4], edge_counts[n_edges*4] = {count, READS, FWD, REV};
+ *               seq table: n_seq entries {label mask, 4 counters}
+ * returns 0, or -1 if decodeGraphAlignment threw where the reference would propagate the exception.
+ */
+extern "C" int pgrefc_count_site(
+    pgrefc_graph* g, uint32_t n_reads, const int32_t* pos, const uint32_t* cigar_off, const char* cigars,
+    const uint8_t* aligned, const uint8_t* unique, const uint8_t* graph_reverse, const uint32_t* read_len,
+    const uint32_t* fragment, const pgrefc_params* prm, uint8_t* out_status, uint64_t* out_nodes, uint64_t* out_edges,
+    uint64_t* out_labels, uint64_t* node_counts, uint64_t* edge_counts, uint32_t* n_seq, uint64_t* seq_masks,
+    uint64_t* seq_counts, uint32_t seq_cap)
+{
+    Graph& graph = g->graph;
+    std::vector<ReadRec> reads(n_reads);
+    int rc = 0;
+    for (uint32_t i = 0; i < n_reads; ++i)
+    {
+        ReadRec& r = reads[i];
+        r.pos = pos[i];
+        r.cigar.assign(cigars + cigar_off[i], cigars + cigar_off[i + 1]);
+        r.read_len = read_len[i];
+        r.unique = unique[i] != 0;
+        r.graph_reverse = graph_reverse[i] != 0;
+        r.fragment = fragment[i];
+        r.status = 0;
+        if (!aligned[i])
+            continue;
+        r.status = 1;  // CompositeAligner.cpp:156
+        // filter chain, ReadFilter.cpp:43-90
+        bool bad = false;
+        if (prm->remove_nonuniq && !r.unique)
+            bad = true;
+        if (!bad)
+        {
+            try
+            {
+                const GraphAlignment mapping = decodeGraphAlignment(r.pos, r.cigar, &graph);
+                size_t query_clipped = 0;
+                for (auto const& aln : mapping)
+                    query_clipped += aln.numClipped();
+                const auto query_aligned = mapping.queryLength() - query_clipped;
+                bad = query_aligned < round(prm->bad_align_frac * (mapping.queryLength()));
+            }
+            catch (std::exception const&)
+            {
+                rc = -1;
+                bad = true;
+            }
+        }
+        if (bad)
+            r.status = 2;
+    }
+    // disambiguateReads (only MAPPED reads survive alignReads, Align.cpp:81-84,155)
+    for (auto& r : reads)
+    {
+        if (r.status != 1)
+            continue;
+        bool has_previous = false;
+        NodeId pnode = 0;
+        std::set<std::string> overlapped_pfams;
+        try
+        {
+            GraphAlignment gm = decodeGraphAlignment(r.pos, r.cigar, &graph);
+            auto const& path = gm.path();
+            for (auto node = path.begin(); node != path.end(); ++node)
+            {
+                if (has_previous && (!prm->use_support_filters || edge_filter(graph, r, pnode, *node)))
+                {
+                    r.edges.emplace(pnode, *node);
+                    for (const auto& s : graph.edgeLabels(pnode, *node))
+                        overlapped_pfams.insert(s);
+                }
+                has_previous = true;
+                pnode = *node;
+                if (!prm->use_support_filters || node_filter(graph, r, *node))
+                    r.nodes.emplace(*node);
+            }
+            for (auto const& label : overlapped_pfams)
+            {
+                graphtools::PathFamily pfam(&graph, label);
+                if (pfam.containsPath(path))
+                    r.labels.insert(label);
+            }
+        }
+        catch (std::exception const&)
+        {
+            rc = -1;
+        }
+    }
+    for (uint32_t i = 0; i < n_reads; ++i)
+    {
+        const ReadRec& r = reads[i];
+        out_status[i] = (uint8_t)r.status;
+        uint64_t nm = 0, em = 0, lm = 0;
+        for (auto n : r.nodes)
+            nm |= 1ull << n;
+        for (auto const& e : r.edges)
+            em |= 1ull << g->edge_index.at(e);
+        for (auto const& l : r.labels)
+            lm |= 1ull << g->label_index.at(l);
+        out_nodes[i] = nm;
+        out_edges[i] = em;
+        out_labels[i] = lm;
+    }
+    // readsToFragments over the surviving reads, in read order (Fragment.cpp:165-181)
+    std::list<Frag> frags;
+    std::unordered_map<uint32_t, Frag*> fmap;
+    for (auto const& r : reads)
+    {
+        if (r.status != 1)
+            continue;
+        auto it = fmap.find(r.fragment);
+        if (it == fmap.end())
+        {
+            frags.emplace_back();
+            it = fmap.emplace(r.fragment, &frags.back()).first;
+        }
+        Frag& f = *it->second;
+        ++f.n_reads;
+        if (r.graph_reverse)
+            ++f.n_rev;
+        else
+            ++f.n_fwd;
+        f.nodes.insert(r.nodes.begin(), r.nodes.end());
+        f.edges.insert(r.edges.begin(), r.edges.end());
+        f.labels.insert(r.labels.begin(), r.labels.end());
+    }
+    std::fill(node_counts, node_counts + 4 * graph.numNodes(), 0);
+    std::fill(edge_counts, edge_counts + 4 * g->edges.size(), 0);
+    std::map<uint64_t, std::array<uint64_t, 4>> seqs;
+    for (auto const& f : frags)
+    {
+        for (auto n : f.nodes)
+            add_count(node_counts + 4 * n, f);
+        for (auto const& e : f.edges)
+            add_count(edge_counts + 4 * g->edge_index.at(e), f);
+        if (!f.labels.empty())
+        {
+            uint64_t lm = 0;
+            for (auto const& l : f.labels)
+                lm |= 1ull << g->label_index.at(l);
+            auto& c = seqs[lm];
+            add_count(c.data(), f);
+        }
+    }
+    *n_seq = 0;
+    for (auto const& kv : seqs)
+    {
+        if (*n_seq >= seq_cap)
+            break;
+        seq_masks[*n_seq] = kv.first;
+        std::memcpy(seq_counts + 4 * (*n_seq), kv.second.data(), 4 * sizeof(uint64_t));
+        ++*n_seq;
+    }
+    return rc;
+}

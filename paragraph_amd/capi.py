@@ -30,11 +30,16 @@ assert RESULT_DTYPE.itemsize == 24, RESULT_DTYPE.itemsize
 
 OP_CHARS = "MXNIDS"
 
+SUPPORT_DTYPE = np.dtype([("label_mask", "<u8"), ("path_off", "<u4"), ("n_path", "<u2"), ("status", "u1"),
+                          ("filter", "u1")], align=True)
+assert SUPPORT_DTYPE.itemsize == 16, SUPPORT_DTYPE.itemsize
+
 EXPORTS = [
     "pg_ctx_create", "pg_ctx_destroy", "pg_strerror", "pg_last_error", "pg_ctx_set_workspace_bytes", "pg_ctx_sync",
     "pg_ctx_timing_enable", "pg_ctx_timing_reset", "pg_ctx_timing_get", "pg_graphs_upload", "pg_graphs_destroy",
     "pg_batch_create", "pg_batch_destroy", "pg_batch_upload", "pg_batch_align", "pg_batch_ops_count",
-    "pg_batch_download", "pg_align_batch", "pg_render_cigar",
+    "pg_batch_download", "pg_align_batch", "pg_render_cigar", "pg_graphs_set_labels", "pg_graphs_count_layout",
+    "pg_graphs_seq_offsets", "pg_batch_count", "pg_batch_download_counts",
 ]
 
 
@@ -42,6 +47,15 @@ class Timing(C.Structure):
     _fields_ = [("fill_ms", C.c_double), ("trace_ms", C.c_double), ("fill_launches", C.c_uint64),
                 ("trace_launches", C.c_uint64), ("fills", C.c_uint64), ("cells", C.c_uint64),
                 ("trace_bytes", C.c_uint64)]
+
+
+class CountParams(C.Structure):
+    _fields_ = [("remove_nonuniq", C.c_uint32), ("use_support_filters", C.c_uint32), ("bad_align_frac", C.c_double)]
+
+
+class CountLayout(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_counters", "node_base", "edge_base", "seq_base", "tally_base", "n_nodes",
+                                           "n_edges", "n_seq_slots", "n_graphs")]
 
 
 class PgError(RuntimeError):
@@ -100,6 +114,17 @@ def load_library():
     L.pg_align_batch.restype = C.c_int32
     L.pg_align_batch.argtypes = [vp, vp, C.c_uint32, u32p, u32p, C.c_char_p, C.c_uint32, vp, vp, C.c_uint64,
                                  C.POINTER(C.c_uint64)]
+    u64p = C.POINTER(C.c_uint64)
+    L.pg_graphs_set_labels.restype = C.c_int32
+    L.pg_graphs_set_labels.argtypes = [vp, vp, u64p, u32p]
+    L.pg_graphs_count_layout.restype = C.c_int32
+    L.pg_graphs_count_layout.argtypes = [vp, C.POINTER(CountLayout)]
+    L.pg_graphs_seq_offsets.restype = C.c_int32
+    L.pg_graphs_seq_offsets.argtypes = [vp, u64p]
+    L.pg_batch_count.restype = C.c_int32
+    L.pg_batch_count.argtypes = [vp, vp, C.POINTER(CountParams), u32p, C.POINTER(C.c_uint8), vp]
+    L.pg_batch_download_counts.restype = C.c_int32
+    L.pg_batch_download_counts.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, u64p]
     L.pg_render_cigar.restype = C.c_size_t
     L.pg_render_cigar.argtypes = [vp, vp, C.c_char_p, C.c_size_t]
     _lib = L
@@ -203,10 +228,41 @@ class Graphs:
         self.ctx = ctx
         self.n = len(graphs)
         node_off, seq_off, seq, pred_off, pred = graphs_csr(graphs)
+        self.node_off, self.pred_off, self.pred = node_off, pred_off, pred
+        self.edges = [[(int(pred[k]), t) for t in range(int(node_off[g + 1] - node_off[g]))
+                       for k in range(int(pred_off[node_off[g] + t]), int(pred_off[node_off[g] + t + 1]))]
+                      for g in range(self.n)]
+        self.labels = None
         h = C.c_void_p()
         ctx._chk(ctx.L.pg_graphs_upload(ctx.h, self.n, _p32(node_off), _p32(seq_off), seq, _p32(pred_off),
                                         _p32(pred), C.byref(h)))
         self.h = h
+
+    def set_labels(self, edge_labels, labels=None):
+        """edge_labels: per graph a dict {(from,to): [label,...]}; labels: per graph the ordered label list
+        (default: sorted names).  Counters of edges come back in predecessor-CSR order = self.edges[g]."""
+        if labels is None:
+            labels = [sorted({l for v in el.values() for l in v}) for el in edge_labels]
+        self.labels = [list(l) for l in labels]
+        mask = np.zeros(max(1, len(self.pred)), dtype=np.uint64)
+        k = 0
+        for g in range(self.n):
+            idx = {l: i for i, l in enumerate(self.labels[g])}
+            for e in self.edges[g]:
+                m = 0
+                for l in edge_labels[g].get(e, []):
+                    m |= 1 << idx[l]
+                mask[k] = m
+                k += 1
+        nl = _u32([len(l) for l in self.labels])
+        self.ctx._chk(self.ctx.L.pg_graphs_set_labels(self.ctx.h, self.h, mask.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                      _p32(nl)))
+        lay = CountLayout()
+        self.ctx._chk(self.ctx.L.pg_graphs_count_layout(self.h, C.byref(lay)))
+        self.layout = lay
+        so = np.zeros(self.n + 1, dtype=np.uint64)
+        self.ctx._chk(self.ctx.L.pg_graphs_seq_offsets(self.h, so.ctypes.data_as(C.POINTER(C.c_uint64))))
+        self.seq_off = so
 
     def close(self):
         if self.h and self.ctx.h:
@@ -252,6 +308,31 @@ class Batch:
     def align(self, flags=AF_ALL):
         self.ctx._chk(self.ctx.L.pg_batch_align(self.ctx.h, self.h, flags & 0xFFFFFFFF))
 
+    def count(self, fragment_of_read, is_reverse_strand=None, remove_nonuniq=True, bad_align_frac=0.8,
+              use_support_filters=True, d_counts=None):
+        """Runs the count path; d_counts = device pointer (int) of a caller-owned uint32 table or None."""
+        prm = CountParams(1 if remove_nonuniq else 0, 1 if use_support_filters else 0, bad_align_frac)
+        fr = _u32(fragment_of_read)
+        rv = None
+        if is_reverse_strand is not None:
+            rv = np.ascontiguousarray(is_reverse_strand, dtype=np.uint8)
+        self.ctx._chk(self.ctx.L.pg_batch_count(
+            self.ctx.h, self.h, C.byref(prm), _p32(fr),
+            rv.ctypes.data_as(C.POINTER(C.c_uint8)) if rv is not None else None, d_counts))
+
+    def download_counts(self, want_table=True):
+        """-> (counts table or None, supports (SUPPORT_DTYPE), path entries)."""
+        lay = self._graphs.layout
+        counts = np.zeros(int(lay.n_counters), dtype=np.uint32) if want_table else None
+        sup = np.zeros(max(self.n_reads, 1), dtype=SUPPORT_DTYPE)
+        npath = C.c_uint64()
+        self.ctx._chk(self.ctx.L.pg_batch_download_counts(self.ctx.h, self.h, None, None, None, 0, C.byref(npath)))
+        path = np.zeros(max(int(npath.value), 1), dtype=np.uint32)
+        self.ctx._chk(self.ctx.L.pg_batch_download_counts(
+            self.ctx.h, self.h, counts.ctypes.data if want_table else None, sup.ctypes.data, path.ctypes.data,
+            len(path), C.byref(npath)))
+        return counts, sup[:self.n_reads], path[:int(npath.value)]
+
     def download(self):
         cnt = C.c_uint64()
         self.ctx._chk(self.ctx.L.pg_batch_ops_count(self.ctx.h, self.h, C.byref(cnt)))
@@ -294,4 +375,52 @@ def results_to_dicts(res, ops):
             "strand_score": [int(r["strand_score"][0]), int(r["strand_score"][1])],
             "cigar": render_cigar(r, ops), "clipped": int(r["clipped"]), "status": int(r["status"]),
         })
+    return out
+
+
+def decode_counts(graphs, counts):
+    """counts table -> per graph dict(node_counts[n,4], edge_counts {(from,to): [4]}, seq_counts {"A,B": [4]},
+    tallies {aligned, mapped, bad_align, nonuniq})."""
+    lay = graphs.layout
+    out = []
+    ek = 0
+    for g in range(graphs.n):
+        nb, ne = int(graphs.node_off[g]), int(graphs.node_off[g + 1])
+        nodes = counts[int(lay.node_base) + 4 * nb:int(lay.node_base) + 4 * ne].reshape(-1, 4).astype(np.uint64)
+        edges = {}
+        for e in graphs.edges[g]:
+            edges[e] = [int(x) for x in counts[int(lay.edge_base) + 4 * ek:int(lay.edge_base) + 4 * ek + 4]]
+            ek += 1
+        seqs = {}
+        labs = graphs.labels[g]
+        for m in range(int(graphs.seq_off[g + 1] - graphs.seq_off[g])):
+            o = int(lay.seq_base) + 4 * (int(graphs.seq_off[g]) + m)
+            c = [int(x) for x in counts[o:o + 4]]
+            if c[0]:
+                seqs[",".join(sorted(labs[i] for i in range(len(labs)) if (m >> i) & 1))] = c
+        t = counts[int(lay.tally_base) + 4 * g:int(lay.tally_base) + 4 * g + 4]
+        out.append({"node_counts": nodes, "edge_counts": edges, "seq_counts": seqs,
+                    "tallies": {"aligned": int(t[0]) & 0x7FFFFFFF, "mapped": int(t[1]), "bad_align": int(t[2]),
+                                "nonuniq": int(t[3]), "overflow": bool(int(t[0]) >> 31)}})
+    return out
+
+
+def decode_supports(graphs, graph_of_read, sup, path):
+    """per read: dict(status, filter, nodes {ids}, edges {(from,to)}, labels {names})."""
+    out = []
+    for i, s in enumerate(sup):
+        g = int(graph_of_read[i])
+        nodes, edges = set(), set()
+        prev = None
+        for k in range(int(s["n_path"])):
+            en = int(path[int(s["path_off"]) + k])
+            nd = en & 0xFFF
+            if (en >> 30) & 1:
+                nodes.add(nd)
+            if k > 0 and (en >> 31) & 1:
+                edges.add((prev, nd))
+            prev = nd
+        labs = graphs.labels[g]
+        out.append({"status": int(s["status"]), "filter": int(s["filter"]), "nodes": nodes, "edges": edges,
+                    "labels": {labs[b] for b in range(len(labs)) if (int(s["label_mask"]) >> b) & 1}})
     return out

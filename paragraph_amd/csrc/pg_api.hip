@@ -22,94 +22,16 @@
 
 #include "../../include/paragraph_amd.h"
 #include "pg_device.h"
+#include "pg_internal.h"
 #include "pg_kernels.h"
 
-namespace
-{
-struct HostGraph
-{
-    uint32_t n_nodes;
-    uint32_t ncols;
-};
-
-struct Chunk
-{
-    int C;
-    uint32_t pair_begin, pair_end;
-    uint64_t ws_bytes;
-    uint32_t max_nodes;
-    uint64_t fills, cells, trace_bytes;
-};
-
-struct EventPair
-{
-    hipEvent_t a, b;
-    int kind;  // 0 fill, 1 trace
-};
-}  // namespace
-
-struct pg_ctx
-{
-    int device = 0;
-    hipStream_t stream = nullptr;
-    uint64_t ws_limit = 8ull << 30;
-    uint8_t* workspace = nullptr;
-    uint64_t ws_cap = 0;
-    pg_op* ops_scratch = nullptr;
-    uint64_t ops_scratch_cap = 0;  // entries
-    bool timing = false;
-    std::vector<EventPair> events;
-    std::vector<hipEvent_t> event_pool;
-    pg_timing acc{};
-    std::string err;
-};
-
-struct pg_graphs
-{
-    uint32_t n_graphs = 0;
-    std::vector<HostGraph> host;
-    PgGraphDev* d_graphs = nullptr;
-    PgNode* d_nodes = nullptr;
-    uint32_t* d_preds = nullptr;
-    uint32_t* d_colmeta = nullptr;
-    char* d_seqchars = nullptr;
-};
-
-struct pg_batch
-{
-    const pg_graphs* graphs = nullptr;
-    uint32_t n_reads = 0;
-    uint32_t n_pairs = 0;
-    uint32_t* d_base_off = nullptr;
-    char* d_bases = nullptr;
-    PgWorkItem* d_items = nullptr;
-    PgFillSummary* d_fillsum = nullptr;
-    pg_result* d_results = nullptr;
-    pg_op* d_ops = nullptr;
-    uint64_t ops_cap = 0;
-    unsigned long long* d_ops_counter = nullptr;
-    std::vector<Chunk> chunks;
-    uint64_t max_ws = 0;
-    uint64_t max_scratch = 0;
-    size_t cap_reads = 0, cap_bases = 0, cap_items = 0;
-    std::vector<pg_result> host_template;  // status for reads the device never sees (empty reads)
-    bool has_skipped = false;
-};
-
-static pg_status fail(pg_ctx* ctx, pg_status st, const std::string& msg)
+pg_status pg_fail(pg_ctx* ctx, pg_status st, const std::string& msg)
 {
     if (ctx)
         ctx->err = msg;
     return st;
 }
-
-#define HIP_TRY(ctx, call)                                                                                     \
-    do                                                                                                         \
-    {                                                                                                          \
-        hipError_t e__ = (call);                                                                               \
-        if (e__ != hipSuccess)                                                                                 \
-            return fail(ctx, PG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));                  \
-    } while (0)
+static pg_status fail(pg_ctx* ctx, pg_status st, const std::string& msg) { return pg_fail(ctx, st, msg); }
 
 extern "C" const char* pg_strerror(pg_status st)
 {
@@ -403,6 +325,16 @@ extern "C" pg_status pg_graphs_upload(
         return PG_ERR_NOMEM;
     G->n_graphs = n_graphs;
     G->host.swap(host);
+    {
+        // host CSR copies in the caller's indexing (the count path reports counters in that indexing)
+        const uint32_t total_nodes = node_off[n_graphs];
+        G->h_node_off.assign(node_off, node_off + n_graphs + 1);
+        G->h_pred_off.assign(pred_off, pred_off + total_nodes + 1);
+        G->h_pred.assign(pred, pred + (pred ? pred_off[total_nodes] : 0));
+        G->h_node_len.resize(total_nodes);
+        for (uint32_t i = 0; i < total_nodes; ++i)
+            G->h_node_len[i] = seq_off[i + 1] - seq_off[i];
+    }
     auto up_vec = [&](auto& vec, auto** dptr) -> hipError_t {
         using T = typename std::remove_reference<decltype(vec)>::type::value_type;
         hipError_t e = hipMalloc((void**)dptr, vec.size() * sizeof(T));
@@ -444,6 +376,13 @@ extern "C" void pg_graphs_destroy(pg_ctx* ctx, pg_graphs* G)
     (void)hipFree(G->d_preds);
     (void)hipFree(G->d_colmeta);
     (void)hipFree(G->d_seqchars);
+    (void)hipFree(G->d_cnt_graphs);
+    (void)hipFree(G->d_cnt_pred_off);
+    (void)hipFree(G->d_cnt_pred);
+    (void)hipFree(G->d_cnt_node_len);
+    (void)hipFree(G->d_label_mask);
+    (void)hipFree(G->d_out_mask);
+    (void)hipFree(G->d_in_mask);
     delete G;
 }
 
@@ -467,6 +406,24 @@ static void batch_free_device(pg_batch* b)
     (void)hipFree(b->d_results);
     (void)hipFree(b->d_ops);
     (void)hipFree(b->d_ops_counter);
+    (void)hipFree(b->d_graph_of_read);
+    (void)hipFree(b->d_support);
+    (void)hipFree(b->d_path);
+    (void)hipFree(b->d_path_counter);
+    (void)hipFree(b->d_frag_off);
+    (void)hipFree(b->d_frag_reads);
+    (void)hipFree(b->d_is_rev);
+    (void)hipFree(b->d_counts);
+    b->d_graph_of_read = nullptr;
+    b->d_support = nullptr;
+    b->d_path = nullptr;
+    b->d_path_counter = nullptr;
+    b->d_frag_off = nullptr;
+    b->d_frag_reads = nullptr;
+    b->d_is_rev = nullptr;
+    b->d_counts = nullptr;
+    b->cap_count_reads = b->cap_frags = 0;
+    b->cap_counts = 0;
     b->d_base_off = nullptr;
     b->d_bases = nullptr;
     b->d_items = nullptr;
@@ -628,10 +585,13 @@ extern "C" pg_status pg_batch_upload(
         HIP_TRY(ctx, hipMalloc((void**)&b->d_results, std::max<size_t>(n_reads, 1) * sizeof(pg_result)));
         HIP_TRY(ctx, hipMalloc((void**)&b->d_ops, b->ops_cap * sizeof(pg_op)));
         HIP_TRY(ctx, hipMalloc((void**)&b->d_ops_counter, sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_graph_of_read, b->cap_reads * sizeof(uint32_t)));
     }
+    b->h_graph_of_read.assign(graph_of_read, graph_of_read + n_reads);
     if (n_reads)
     {
         HIP_TRY(ctx, hipMemcpyAsync(b->d_base_off, base_off, (n_reads + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_graph_of_read, graph_of_read, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         if (n_bases)
             HIP_TRY(ctx, hipMemcpyAsync(b->d_bases, bases, n_bases, hipMemcpyHostToDevice, ctx->stream));
         if (!items.empty())

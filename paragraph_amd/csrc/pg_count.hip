@@ -1,0 +1,551 @@
+// pg_count.hip -- the count path on the device: read filters, per-read node/edge/sequence support,
+// per-fragment union and per-site counters.
+//
+// Replaces (per site, per read, with string CIGAR re-parsing and std::set/std::map on the host)
+//   NonUniq / BadAlign filters as applied by CompositeAligner::alignRead
+//        src/c++/lib/paragraph/readfilters/NonUniq.hh:48-52, BadAlign.hh:62-73,
+//        src/c++/lib/paragraph/ReadFilter.cpp:43-90, src/c++/lib/grm/CompositeAligner.cpp:152-175
+//   decodeGraphAlignment + Alignment counters   GT!/src/graphalign/GraphAlignmentOperations.cpp:67-127,
+//                                               GT!/src/graphalign/LinearAlignment.cpp:49-131
+//   nodefilter / edgefilter                     src/c++/lib/paragraph/Disambiguation.cpp:212-296
+//   disambiguateReads + PathFamily::containsPath   Disambiguation.cpp:82-142, GT!/src/graphcore/PathFamily.cpp:89-108
+//   readsToFragments / Fragment::addRead        src/c++/lib/common/Fragment.cpp:34-69, 141-181
+//   countNodes / countEdges / countPathFamilies src/c++/lib/paragraph/ReadCounting.cpp:52-127
+//
+// Two kernels, both pure integer/byte work on data that is already in HBM (pg_result + pg_op from the
+// traceback kernel): one thread per read (support), one thread per fragment (union + atomic counters).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/paragraph_amd.h"
+#include "pg_device.h"
+#include "pg_internal.h"
+
+namespace
+{
+struct CountArgs
+{
+    uint32_t n_reads;
+    pg_count_params prm;
+    const pg_result* results;
+    const pg_op* ops;
+    const uint32_t* base_off;
+    const uint32_t* graph_of_read;
+    const uint8_t* is_rev;
+    const PgCountGraph* graphs;
+    const uint32_t* pred_off;   // set-wide node numbering
+    const uint32_t* pred;
+    const uint32_t* node_len;
+    const uint64_t* label_mask;  // per predecessor entry
+    const uint64_t* out_mask;
+    const uint64_t* in_mask;
+    pg_read_support* support;
+    uint32_t* path;
+    unsigned long long* path_counter;
+    // fragments
+    uint32_t n_frags;
+    const uint32_t* frag_off;
+    const uint32_t* frag_reads;
+    uint32_t* counts;
+    pg_count_layout lay;
+};
+
+struct NodeAln
+{
+    uint32_t node;
+    uint32_t m, x, n, ins, del, s;
+    __device__ uint32_t rlen() const { return m + x + n + del; }
+    __device__ uint32_t qlen() const { return m + x + n + ins + s; }
+};
+
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+__device__ bool node_ok(const NodeAln& a, uint32_t node_len, uint32_t L, bool use)
+{  // Disambiguation.cpp:212-242
+    if (!use)
+        return true;
+    const bool is_short = node_len < L / 2;
+    const uint32_t nonmatch = a.x + a.s;
+    const uint32_t indel = a.ins + a.del;
+    if (is_short && (nonmatch > 0 || indel > 0))
+        return false;
+    return nonmatch + indel <= L / 2;
+}
+
+__device__ bool edge_ok(const NodeAln& p, const NodeAln& c, uint32_t len1, uint32_t len2, uint32_t L, bool use)
+{  // Disambiguation.cpp:244-296
+    if (!use)
+        return true;
+    const uint32_t mno = L / 10 + 1;
+    bool st = p.m >= umin(p.rlen(), mno) && c.m >= umin(c.rlen(), mno);
+    if (st)
+        st = (p.qlen() < p.rlen() * 2) && (c.qlen() < c.rlen() * 2);
+    if (st)
+        st = ((int32_t)p.m >= (int32_t)umin(len1, mno)) && ((int32_t)c.m >= (int32_t)umin(len2, mno));
+    return st;
+}
+
+__global__ __launch_bounds__(64) void pg_support_kernel(CountArgs a)
+{
+    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+    if (r >= a.n_reads)
+        return;
+    const pg_result res = a.results[r];
+    const uint32_t L = a.base_off[r + 1] - a.base_off[r];
+    const PgCountGraph cg = a.graphs[a.graph_of_read[r]];
+    uint32_t* tally = a.counts + a.lay.tally_base + 4ull * a.graph_of_read[r];
+    pg_read_support sup;
+    sup.label_mask = 0;
+    sup.path_off = 0;
+    sup.n_path = 0;
+    sup.status = 0;
+    sup.filter = 0;
+    if (L == 0 || res.status != 0 || res.n_ops == 0)
+    {
+        // skipped (Align.cpp:74-77) or degenerate all-zero alignment (no CIGAR): never counted
+        if (L != 0 && res.status == 2)
+            sup.status = 3;
+        a.support[r] = sup;
+        return;
+    }
+    atomicAdd(&tally[0], 1u);
+    // ---- CompositeAligner.cpp:156-172: MAPPED, then the filter chain may turn it into BAD_ALIGN
+    sup.status = 1;
+    if (a.prm.remove_nonuniq && !res.is_unique)
+    {
+        sup.status = 2;
+        sup.filter = 1;
+    }
+    else
+    {
+        // BadAlign.hh:62-73: queryLength of the whole alignment = read length
+        const double thr = round(a.prm.bad_align_frac * (double)L);
+        if ((double)(L - res.clipped) < thr)
+        {
+            sup.status = 2;
+            sup.filter = 2;
+        }
+    }
+    // decodeGraphAlignment would throw on an invalid path (Path.cpp:86-190): start inside the first node
+    const uint32_t first_node = PG_OP_NODE(a.ops[res.ops_off]);
+    if (res.graph_pos < 0 || (uint32_t)res.graph_pos >= a.node_len[cg.node_base + first_node])
+        sup.status = 3;
+    if (sup.status != 1)
+    {
+        if (sup.filter == 1)
+            atomicAdd(&tally[3], 1u);
+        else if (sup.filter == 2)
+            atomicAdd(&tally[2], 1u);
+        a.support[r] = sup;
+        return;
+    }
+    atomicAdd(&tally[1], 1u);
+
+    // ---- walk the CIGAR node by node (streaming: previous + current node alignment) -----------------
+    uint32_t n_path = 0;
+    {
+        uint32_t cur = 0xFFFFFFFFu;
+        for (uint32_t e = 0; e < res.n_ops; ++e)
+        {
+            const uint32_t nd = PG_OP_NODE(a.ops[res.ops_off + e]);
+            if (nd != cur)
+            {
+                ++n_path;
+                cur = nd;
+            }
+        }
+    }
+    const uint32_t poff = (uint32_t)atomicAdd(a.path_counter, (unsigned long long)n_path);
+    const bool use = a.prm.use_support_filters != 0;
+    NodeAln prev{}, cur{};
+    bool have_prev = false, have_cur = false;
+    uint32_t k = 0;
+    uint64_t overlapped = 0, matched = 0, failed = 0;
+    auto finish_node = [&]() {
+        // edge (prev -> cur) and node cur
+        uint32_t entry = cur.node;
+        const uint32_t gn = cg.node_base + cur.node;
+        if (have_prev)
+        {
+            // predecessor entry of the edge prev.node -> cur.node
+            uint64_t emask = 0;
+            for (uint32_t q = a.pred_off[gn]; q < a.pred_off[gn + 1]; ++q)
+                if (a.pred[q] == prev.node)
+                    emask = a.label_mask[q];
+            const uint64_t touch = a.out_mask[cg.node_base + prev.node] | a.in_mask[gn];
+            matched |= emask;
+            failed |= (~emask) & touch;
+            if (edge_ok(prev, cur, a.node_len[cg.node_base + prev.node], a.node_len[gn], L, use))
+            {
+                entry |= 1u << 31;
+                overlapped |= emask;
+            }
+        }
+        if (node_ok(cur, a.node_len[gn], L, use))
+            entry |= 1u << 30;
+        a.path[poff + k] = entry;
+        ++k;
+    };
+    for (uint32_t e = 0; e < res.n_ops; ++e)
+    {
+        const pg_op o = a.ops[res.ops_off + e];
+        const uint32_t nd = PG_OP_NODE(o), code = PG_OP_CODE(o), len = PG_OP_LEN(o);
+        if (!have_cur || nd != cur.node)
+        {
+            if (have_cur)
+            {
+                finish_node();
+                prev = cur;
+                have_prev = true;
+            }
+            cur = NodeAln{};
+            cur.node = nd;
+            have_cur = true;
+        }
+        switch (code)
+        {
+        case PG_OPC_M: cur.m += len; break;
+        case PG_OPC_X: cur.x += len; break;
+        case PG_OPC_N: cur.n += len; break;
+        case PG_OPC_I: cur.ins += len; break;
+        case PG_OPC_D: cur.del += len; break;
+        case PG_OPC_S: cur.s += len; break;
+        default: break;
+        }
+    }
+    if (have_cur)
+        finish_node();
+    // PathFamily::containsPath for every label overlapped by a supported edge
+    sup.label_mask = overlapped & matched & ~failed;
+    sup.path_off = poff;
+    sup.n_path = (uint16_t)n_path;
+    a.support[r] = sup;
+}
+
+constexpr int FRAG_SET_CAP = 48;
+
+__global__ __launch_bounds__(64) void pg_fragment_kernel(CountArgs a)
+{
+    const uint32_t f = blockIdx.x * 64u + threadIdx.x;
+    if (f >= a.n_frags)
+        return;
+    const uint32_t b = a.frag_off[f], e = a.frag_off[f + 1];
+    uint32_t n = 0, fwd = 0, rev = 0;
+    uint64_t labels = 0;
+    uint32_t nodes[FRAG_SET_CAP], edges[FRAG_SET_CAP];
+    int nn = 0, ne = 0;
+    uint32_t graph = 0;
+    bool overflow = false;
+    for (uint32_t q = b; q < e; ++q)
+    {
+        const uint32_t r = a.frag_reads[q];
+        const pg_read_support sup = a.support[r];
+        if (sup.status != 1)
+            continue;  // only MAPPED reads survive alignReads (Align.cpp:81-84,155)
+        graph = a.graph_of_read[r];
+        const PgCountGraph cg = a.graphs[graph];
+        ++n;
+        const bool read_rev = a.is_rev ? a.is_rev[r] != 0 : false;
+        const bool graph_rev = read_rev != (a.results[r].returned_reverse != 0);  // GraphAligner.cpp:358-359
+        if (graph_rev)
+            ++rev;
+        else
+            ++fwd;
+        labels |= sup.label_mask;
+        uint32_t pnode = 0;
+        for (uint32_t k = 0; k < sup.n_path; ++k)
+        {
+            const uint32_t en = a.path[sup.path_off + k];
+            const uint32_t nd = PG_PATH_NODE(en);
+            if (PG_PATH_NODE_OK(en))
+            {
+                bool seen = false;
+                for (int t = 0; t < nn; ++t)
+                    seen |= nodes[t] == nd;
+                if (!seen)
+                {
+                    if (nn < FRAG_SET_CAP)
+                        nodes[nn++] = nd;
+                    else
+                        overflow = true;
+                }
+            }
+            if (k > 0 && PG_PATH_EDGE_OK(en))
+            {
+                const uint32_t gn = cg.node_base + nd;
+                uint32_t eidx = 0xFFFFFFFFu;
+                for (uint32_t p = a.pred_off[gn]; p < a.pred_off[gn + 1]; ++p)
+                    if (a.pred[p] == pnode)
+                        eidx = p;
+                bool seen = false;
+                for (int t = 0; t < ne; ++t)
+                    seen |= edges[t] == eidx;
+                if (!seen && eidx != 0xFFFFFFFFu)
+                {
+                    if (ne < FRAG_SET_CAP)
+                        edges[ne++] = eidx;
+                    else
+                        overflow = true;
+                }
+            }
+            pnode = nd;
+        }
+    }
+    if (n == 0)
+        return;
+    const PgCountGraph cg = a.graphs[graph];
+    auto add = [&](uint32_t* c) {  // ReadCounting.cpp:52-69
+        atomicAdd(&c[0], 1u);
+        atomicAdd(&c[1], n);
+        atomicAdd(&c[2], fwd);
+        atomicAdd(&c[3], rev);
+    };
+    for (int t = 0; t < nn; ++t)
+        add(a.counts + a.lay.node_base + 4ull * (cg.node_base + nodes[t]));
+    for (int t = 0; t < ne; ++t)
+        add(a.counts + a.lay.edge_base + 4ull * edges[t]);
+    if (labels != 0 && cg.n_labels <= PG_MAX_SEQ_TABLE_LABELS)
+        add(a.counts + a.lay.seq_base + 4ull * (cg.seq_base + labels));
+    if (overflow)
+        atomicAdd(a.counts + a.lay.tally_base + 4ull * graph, 0x80000000u);  // poison: > 48 nodes/edges per fragment
+}
+
+template <typename T> hipError_t dev_upload(const std::vector<T>& v, T** d, hipStream_t s)
+{
+    hipError_t e = hipMalloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (e != hipSuccess || v.empty())
+        return e;
+    return hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+}
+}  // namespace
+
+static void layout_of(const pg_graphs* G, pg_count_layout* lay)
+{
+    lay->n_nodes = G->h_pred_off.size() - 1;
+    lay->n_edges = G->h_pred.size();
+    lay->n_seq_slots = G->h_seq_off.empty() ? 0 : G->h_seq_off.back();
+    lay->n_graphs = G->n_graphs;
+    lay->node_base = 0;
+    lay->edge_base = 4 * lay->n_nodes;
+    lay->seq_base = lay->edge_base + 4 * lay->n_edges;
+    lay->tally_base = lay->seq_base + 4 * lay->n_seq_slots;
+    lay->n_counters = lay->tally_base + 4 * lay->n_graphs;
+}
+
+extern "C" pg_status pg_graphs_set_labels(
+    pg_ctx* ctx, pg_graphs* G, const uint64_t* label_mask_of_pred, const uint32_t* n_labels)
+{
+    if (!ctx || !G)
+        return PG_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n_nodes = G->h_pred_off.size() - 1, n_pred = G->h_pred.size();
+    std::vector<uint64_t> lm(n_pred, 0), outm(n_nodes, 0), inm(n_nodes, 0);
+    G->h_n_labels.assign(G->n_graphs, 0);
+    G->h_seq_off.assign(G->n_graphs + 1, 0);
+    std::vector<PgCountGraph> cg(G->n_graphs);
+    for (uint32_t g = 0; g < G->n_graphs; ++g)
+    {
+        const uint32_t nl = n_labels ? n_labels[g] : 0;
+        if (nl > PG_MAX_LABELS)
+            return pg_fail(ctx, PG_ERR_UNSUPPORTED, "more than 64 labels on a graph");
+        G->h_n_labels[g] = nl;
+        const uint64_t valid = nl >= 64 ? ~0ull : ((1ull << nl) - 1);
+        const uint32_t nb = G->h_node_off[g], ne = G->h_node_off[g + 1];
+        for (uint32_t node = nb; node < ne; ++node)
+            for (uint32_t q = G->h_pred_off[node]; q < G->h_pred_off[node + 1]; ++q)
+            {
+                const uint64_t m = label_mask_of_pred ? label_mask_of_pred[q] : 0;
+                if (m & ~valid)
+                    return pg_fail(ctx, PG_ERR_INVALID, "label bit outside n_labels");
+                lm[q] = m;
+                inm[node] |= m;
+                outm[nb + G->h_pred[q]] |= m;
+            }
+        cg[g].node_base = nb;
+        cg[g].n_nodes = ne - nb;
+        cg[g].n_labels = nl;
+        cg[g].pad = 0;
+        cg[g].seq_base = G->h_seq_off[g];
+        G->h_seq_off[g + 1] = G->h_seq_off[g] + (nl <= PG_MAX_SEQ_TABLE_LABELS ? (1ull << nl) : 0);
+    }
+    (void)hipFree(G->d_cnt_graphs);
+    (void)hipFree(G->d_cnt_pred_off);
+    (void)hipFree(G->d_cnt_pred);
+    (void)hipFree(G->d_cnt_node_len);
+    (void)hipFree(G->d_label_mask);
+    (void)hipFree(G->d_out_mask);
+    (void)hipFree(G->d_in_mask);
+    HIP_TRY(ctx, dev_upload(cg, &G->d_cnt_graphs, ctx->stream));
+    HIP_TRY(ctx, dev_upload(G->h_pred_off, &G->d_cnt_pred_off, ctx->stream));
+    HIP_TRY(ctx, dev_upload(G->h_pred, &G->d_cnt_pred, ctx->stream));
+    HIP_TRY(ctx, dev_upload(G->h_node_len, &G->d_cnt_node_len, ctx->stream));
+    HIP_TRY(ctx, dev_upload(lm, &G->d_label_mask, ctx->stream));
+    HIP_TRY(ctx, dev_upload(outm, &G->d_out_mask, ctx->stream));
+    HIP_TRY(ctx, dev_upload(inm, &G->d_in_mask, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    G->labels_set = true;
+    return PG_OK;
+}
+
+extern "C" pg_status pg_graphs_count_layout(const pg_graphs* G, pg_count_layout* out)
+{
+    if (!G || !out || !G->labels_set)
+        return PG_ERR_INVALID;
+    layout_of(G, out);
+    return PG_OK;
+}
+
+extern "C" pg_status pg_graphs_seq_offsets(const pg_graphs* G, uint64_t* seq_off)
+{
+    if (!G || !seq_off || !G->labels_set)
+        return PG_ERR_INVALID;
+    std::copy(G->h_seq_off.begin(), G->h_seq_off.end(), seq_off);
+    return PG_OK;
+}
+
+extern "C" pg_status pg_batch_count(
+    pg_ctx* ctx, pg_batch* b, const pg_count_params* params, const uint32_t* fragment_of_read,
+    const uint8_t* is_reverse_strand, uint32_t* d_counts)
+{
+    if (!ctx || !b || !b->graphs || !params || (b->n_reads && !fragment_of_read))
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_count: null argument");
+    const pg_graphs* G = b->graphs;
+    if (!G->labels_set)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_count: call pg_graphs_set_labels first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = b->n_reads;
+    pg_count_layout lay;
+    layout_of(G, &lay);
+
+    // ---- fragments: CSR over (graph, fragment id), reads in input order inside a fragment -----------
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    const std::vector<uint32_t>& gor = b->h_graph_of_read;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        return gor[x] != gor[y] ? gor[x] < gor[y] : fragment_of_read[x] < fragment_of_read[y];
+    });
+    std::vector<uint32_t> frag_off;
+    frag_off.reserve(n / 2 + 2);
+    for (uint32_t i = 0; i < n; ++i)
+        if (i == 0 || gor[order[i]] != gor[order[i - 1]] || fragment_of_read[order[i]] != fragment_of_read[order[i - 1]])
+            frag_off.push_back(i);
+    const uint32_t n_frags = (uint32_t)frag_off.size();
+    frag_off.push_back(n);
+    b->n_frags = n_frags;
+
+    if (n > b->cap_count_reads)
+    {
+        (void)hipFree(b->d_support);
+        (void)hipFree(b->d_frag_reads);
+        (void)hipFree(b->d_is_rev);
+        (void)hipFree(b->d_path);
+        b->cap_count_reads = n;
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_support, std::max<size_t>(n, 1) * sizeof(pg_read_support)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_frag_reads, std::max<size_t>(n, 1) * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_is_rev, std::max<size_t>(n, 1)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_path, std::max<uint64_t>(b->ops_cap, 1) * sizeof(uint32_t)));
+    }
+    if (!b->d_path_counter)
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_path_counter, sizeof(unsigned long long)));
+    if (n_frags + 1 > b->cap_frags)
+    {
+        (void)hipFree(b->d_frag_off);
+        b->cap_frags = n_frags + 1;
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_frag_off, b->cap_frags * sizeof(uint32_t)));
+    }
+    uint32_t* counts = d_counts;
+    b->counts_owned_valid = false;
+    if (!counts)
+    {
+        if (lay.n_counters > b->cap_counts)
+        {
+            (void)hipFree(b->d_counts);
+            b->cap_counts = lay.n_counters;
+            HIP_TRY(ctx, hipMalloc((void**)&b->d_counts, lay.n_counters * sizeof(uint32_t)));
+        }
+        counts = b->d_counts;
+        HIP_TRY(ctx, hipMemsetAsync(counts, 0, lay.n_counters * sizeof(uint32_t), ctx->stream));
+        b->counts_owned_valid = true;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(b->d_path_counter, 0, sizeof(unsigned long long), ctx->stream));
+    if (n)
+    {
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_frag_reads, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_frag_off, frag_off.data(), frag_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (is_reverse_strand)
+            HIP_TRY(ctx, hipMemcpyAsync(b->d_is_rev, is_reverse_strand, n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    CountArgs a{};
+    a.n_reads = n;
+    a.prm = *params;
+    a.results = b->d_results;
+    a.ops = b->d_ops;
+    a.base_off = b->d_base_off;
+    a.graph_of_read = b->d_graph_of_read;
+    a.is_rev = is_reverse_strand ? b->d_is_rev : nullptr;
+    a.graphs = G->d_cnt_graphs;
+    a.pred_off = G->d_cnt_pred_off;
+    a.pred = G->d_cnt_pred;
+    a.node_len = G->d_cnt_node_len;
+    a.label_mask = G->d_label_mask;
+    a.out_mask = G->d_out_mask;
+    a.in_mask = G->d_in_mask;
+    a.support = b->d_support;
+    a.path = b->d_path;
+    a.path_counter = b->d_path_counter;
+    a.n_frags = n_frags;
+    a.frag_off = b->d_frag_off;
+    a.frag_reads = b->d_frag_reads;
+    a.counts = counts;
+    a.lay = lay;
+    if (n)
+    {
+        hipLaunchKernelGGL(pg_support_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(pg_fragment_kernel, dim3((n_frags + 63) / 64), dim3(64), 0, ctx->stream, a);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `order` / `frag_off` are host temporaries
+    return PG_OK;
+}
+
+extern "C" pg_status pg_batch_download_counts(
+    pg_ctx* ctx, pg_batch* b, uint32_t* counts, pg_read_support* supports, uint32_t* path, uint64_t path_cap,
+    uint64_t* n_path)
+{
+    if (!ctx || !b || !b->graphs || !b->d_support)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_download_counts: pg_batch_count has not run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long np = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&np, b->d_path_counter, sizeof np, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_path)
+        *n_path = np;
+    if (counts)
+    {
+        if (!b->counts_owned_valid)
+            return pg_fail(ctx, PG_ERR_INVALID, "the count table lives in caller memory (d_counts was given)");
+        pg_count_layout lay;
+        layout_of(b->graphs, &lay);
+        HIP_TRY(ctx, hipMemcpyAsync(counts, b->d_counts, lay.n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (supports && b->n_reads)
+        HIP_TRY(ctx, hipMemcpyAsync(supports, b->d_support, b->n_reads * sizeof(pg_read_support), hipMemcpyDeviceToHost, ctx->stream));
+    if (path && np)
+    {
+        if (np > path_cap)
+        {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            return pg_fail(ctx, PG_ERR_OVERFLOW, "path buffer too small");
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(path, b->d_path, np * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}

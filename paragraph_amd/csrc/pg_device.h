@@ -73,6 +73,16 @@ struct PgFillSummary
     int32_t pad[2];
 };
 
+// Count path: per-graph bases into the caller-indexed tables.
+struct PgCountGraph
+{
+    uint32_t node_base;  // first node of the graph in the set-wide node numbering
+    uint32_t n_nodes;
+    uint32_t n_labels;
+    uint32_t pad;
+    uint64_t seq_base;  // first dense sequence-set slot (valid if n_labels <= PG_MAX_SEQ_TABLE_LABELS)
+};
+
 static inline __host__ __device__ uint32_t pg_rows(int C) { return (uint32_t)(PG_GROUP_LANES * C); }
 // bytes of H trace one lane writes per pipeline step: C rows x 2 strands
 static inline __host__ __device__ uint32_t pg_trace_lane_bytes(int C) { return (uint32_t)(2 * C); }

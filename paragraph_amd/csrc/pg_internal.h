@@ -1,0 +1,119 @@
+// pg_internal.h -- host-side object definitions shared by the C-ABI translation units (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/paragraph_amd.h"
+#include "pg_device.h"
+#include "pg_kernels.h"
+
+struct HostGraph
+{
+    uint32_t n_nodes;
+    uint32_t ncols;
+};
+
+struct Chunk
+{
+    int C;
+    uint32_t pair_begin, pair_end;
+    uint64_t ws_bytes;
+    uint32_t max_nodes;
+    uint64_t fills, cells, trace_bytes;
+};
+
+struct EventPair
+{
+    hipEvent_t a, b;
+    int kind;  // 0 fill, 1 trace
+};
+
+struct pg_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint64_t ws_limit = 8ull << 30;
+    uint8_t* workspace = nullptr;
+    uint64_t ws_cap = 0;
+    pg_op* ops_scratch = nullptr;
+    uint64_t ops_scratch_cap = 0;  // entries
+    bool timing = false;
+    std::vector<EventPair> events;
+    std::vector<hipEvent_t> event_pool;
+    pg_timing acc{};
+    std::string err;
+};
+
+struct pg_graphs
+{
+    uint32_t n_graphs = 0;
+    std::vector<HostGraph> host;
+    PgGraphDev* d_graphs = nullptr;
+    PgNode* d_nodes = nullptr;
+    uint32_t* d_preds = nullptr;
+    uint32_t* d_colmeta = nullptr;
+    char* d_seqchars = nullptr;
+    // ---- count path (pg_count.hip): host CSR copies + device tables in the caller's CSR indexing
+    std::vector<uint32_t> h_node_off;  // n_graphs + 1
+    std::vector<uint32_t> h_pred_off;  // total_nodes + 1
+    std::vector<uint32_t> h_pred;
+    std::vector<uint32_t> h_node_len;
+    std::vector<uint32_t> h_n_labels;  // per graph
+    std::vector<uint64_t> h_seq_off;   // n_graphs + 1 (dense sequence-set slots)
+    bool labels_set = false;
+    PgCountGraph* d_cnt_graphs = nullptr;
+    uint32_t* d_cnt_pred_off = nullptr;
+    uint32_t* d_cnt_pred = nullptr;
+    uint32_t* d_cnt_node_len = nullptr;
+    uint64_t* d_label_mask = nullptr;  // per predecessor entry
+    uint64_t* d_out_mask = nullptr;    // per node: labels on outgoing edges
+    uint64_t* d_in_mask = nullptr;     // per node: labels on incoming edges
+};
+
+struct pg_batch
+{
+    const pg_graphs* graphs = nullptr;
+    uint32_t n_reads = 0;
+    uint32_t n_pairs = 0;
+    uint32_t* d_base_off = nullptr;
+    char* d_bases = nullptr;
+    PgWorkItem* d_items = nullptr;
+    PgFillSummary* d_fillsum = nullptr;
+    pg_result* d_results = nullptr;
+    pg_op* d_ops = nullptr;
+    uint64_t ops_cap = 0;
+    unsigned long long* d_ops_counter = nullptr;
+    std::vector<Chunk> chunks;
+    uint64_t max_ws = 0;
+    uint64_t max_scratch = 0;
+    size_t cap_reads = 0, cap_bases = 0, cap_items = 0;
+    std::vector<pg_result> host_template;  // status for reads the device never sees (empty reads)
+    bool has_skipped = false;
+    // ---- count path
+    std::vector<uint32_t> h_graph_of_read;
+    uint32_t* d_graph_of_read = nullptr;
+    pg_read_support* d_support = nullptr;
+    uint32_t* d_path = nullptr;
+    unsigned long long* d_path_counter = nullptr;
+    uint32_t* d_frag_off = nullptr;
+    uint32_t* d_frag_reads = nullptr;
+    uint8_t* d_is_rev = nullptr;
+    uint32_t* d_counts = nullptr;  // owned table (when the caller passes none)
+    size_t cap_count_reads = 0, cap_frags = 0;
+    uint64_t cap_counts = 0;
+    uint32_t n_frags = 0;
+    bool counts_owned_valid = false;
+};
+
+
+pg_status pg_fail(pg_ctx* ctx, pg_status st, const std::string& msg);
+
+#define HIP_TRY(ctx, call)                                                                                     \
+    do                                                                                                         \
+    {                                                                                                          \
+        hipError_t e__ = (call);                                                                               \
+        if (e__ != hipSuccess)                                                                                 \
+            return pg_fail(ctx, PG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));               \
+    } while (0)

@@ -105,3 +105,28 @@ def cases(seed, n_graphs, reads_per_graph, **kw):
         seqs, edges = rand_graph(rng, **kw)
         reads = [rand_read(rng, seqs, edges) for _ in range(reads_per_graph)]
         yield seqs, edges, reads
+
+
+def rand_labels(rng, edges, max_labels=4):
+    """Random edge labels: {(from,to): [names]} + ordered label list (names chosen so that string order differs
+    from creation order)."""
+    names = rng.sample(["REF", "ALT", "DEL", "INS", "P", "Q", "D", "Z1", "A0"], rng.randint(1, max_labels))
+    out = {}
+    for e in edges:
+        ls = [n for n in names if rng.random() < 0.5]
+        if ls:
+            out[tuple(e)] = ls
+    return out, sorted(names)
+
+
+def rand_fragments(rng, n):
+    """Fragment ids: mostly pairs, some singletons, a few fragments with 3 reads."""
+    ids = []
+    fid = 0
+    while len(ids) < n:
+        k = rng.choice([1, 2, 2, 2, 3])
+        ids.extend([fid] * k)
+        fid += 1
+    ids = ids[:n]
+    rng.shuffle(ids)
+    return ids

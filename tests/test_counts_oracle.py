@@ -1,0 +1,95 @@
+"""CPU tests of the count-path checkers: the pure-Python restatement (oracle/counts.py) against the
+reference's unit-test expectations and -- where oracle/_ref exists -- against the reference's own
+graph-tools code (oracle/_ref/libpg_refcounts.so) on randomized alignments."""
+import random
+
+import pytest
+
+from oracle import counts as oc
+from tests import fuzzgen
+
+ALIGNS_NODES = ["AAAAAAAAAAA", "TTTTTTTT", "GGGGGGGG", "AAAAAAAAAAA"]
+ALIGNS_EDGES = [(0, 1), (0, 2), (0, 3), (1, 3), (2, 3)]
+ALIGNS_LABELS = {(0, 1): ["P"], (1, 3): ["P"], (0, 2): ["Q"], (2, 3): ["Q"], (0, 3): ["D"]}
+# graphPos, graphCigar, reverse strand and the supports of src/c++/test/test_paragraph_parts.cpp:111-143
+ALIGNS = [(3, "0[8M]1[4M1X3M]3[8M]", False, {0, 1, 3}, {(0, 1), (1, 3)}, {"P"}),
+          (4, "0[7M]1[4M1X3M]3[6M]", True, {0, 1, 3}, {(0, 1), (1, 3)}, {"P"}),
+          (6, "0[5M]2[1M1X6M]3[6M]", False, {0, 2, 3}, {(0, 2), (2, 3)}, {"Q"}),
+          (7, "0[4M]2[1M1X6M]3[6M]", False, {0, 2, 3}, {(0, 2), (2, 3)}, {"Q"}),
+          (6, "0[5M]2[1M1X6M]3[6M]", True, {0, 2, 3}, {(0, 2), (2, 3)}, {"Q"}),
+          (0, "0[11M]3[8M]", False, {0, 3}, {(0, 3)}, {"D"})]
+ALIGNS_LENS = [24, 21, 19, 18, 19, 19]
+
+
+def aligns_records():
+    return [{"pos": p, "cigar": c, "aligned": True, "unique": True, "graph_reverse": rev, "read_len": L, "fragment": i}
+            for i, ((p, c, rev, _, _, _), L) in enumerate(zip(ALIGNS, ALIGNS_LENS))]
+
+
+def test_port_supports_match_reference_unit_test():
+    g = oc.CountGraph(ALIGNS_NODES, ALIGNS_EDGES, ALIGNS_LABELS)
+    out = oc.port_count_site(g, aligns_records(), remove_nonuniq=False, use_support_filters=False)
+    for i, (_, _, _, nodes, edges, labels) in enumerate(ALIGNS):
+        assert out["nodes"][i] == nodes and out["edges"][i] == edges and out["labels"][i] == labels
+    assert out["seq_counts"] == {"P": [2, 2, 1, 1], "Q": [3, 3, 2, 1], "D": [1, 1, 1, 0]}
+    assert [int(x) for x in out["node_counts"][0]] == [6, 6, 4, 2]
+
+
+def test_port_disambiguation_unit_test():
+    """src/c++/test/test_disambiguation.cpp:97-105: R / R / none / D."""
+    nodes = ["AAAAAAAAAA", "TTTTTTTTTT", "TTTTTTTTTT", "GGGGGGGGGG", "AAAAAAAAAA"]
+    edges = [(0, 1), (0, 4), (1, 2), (1, 3), (2, 4), (3, 4)]
+    labels = {(0, 1): ["R"], (1, 2): ["R"], (2, 4): ["R"], (0, 4): ["D"]}
+    g = oc.CountGraph(nodes, edges, labels)
+    cig = ["0[10M]1[10M]2[10M]4[10M]", "0[10M]1[10M]2[1M]", "0[10M]1[10M]3[10M]4[10M]", "0[10M]4[10M]"]
+    recs = [{"pos": 0, "cigar": c, "aligned": True, "unique": True, "graph_reverse": False, "read_len": L,
+             "fragment": i} for i, (c, L) in enumerate(zip(cig, [40, 21, 40, 20]))]
+    out = oc.port_count_site(g, recs, remove_nonuniq=False, use_support_filters=False)
+    assert [sorted(s) for s in out["labels"]] == [["R"], ["R"], [], ["D"]]
+
+
+def test_bad_align_rounding():
+    g = oc.CountGraph(["A" * 200], [], {})
+    # L = 150: round(0.8 * 150) = 120 -> 119 aligned is bad, 120 is fine; L = 18: round(14.4) = 14
+    def rec(clip, L):
+        return {"pos": 0, "cigar": "0[%dS%dM]" % (clip, L - clip), "aligned": True, "unique": True,
+                "graph_reverse": False, "read_len": L, "fragment": 0}
+    out = oc.port_count_site(g, [rec(31, 150), rec(30, 150), rec(4, 18), rec(5, 18)], remove_nonuniq=False)
+    assert out["status"] == [2, 1, 1, 2]
+
+
+def make_case(rng, checker):
+    seqs, edges = fuzzgen.rand_graph(rng, max_len=40, max_nodes=6)
+    labels, names = fuzzgen.rand_labels(rng, edges)
+    reads = [fuzzgen.rand_read(rng, seqs, edges, min_len=10, max_len=90) for _ in range(rng.randint(4, 14))]
+    al = checker.align_batch(seqs, edges, reads)
+    frag = fuzzgen.rand_fragments(rng, len(reads))
+    isrev = [rng.random() < 0.5 for _ in reads]
+    recs = [{"pos": a["graph_pos"], "cigar": a["cigar"], "aligned": a["score"] > 0, "unique": a["unique"],
+             "graph_reverse": isrev[i] != a["returned_reverse"], "read_len": len(r), "fragment": frag[i]}
+            for i, (a, r) in enumerate(zip(al, reads))]
+    return oc.CountGraph(seqs, edges, labels, names), recs, reads, frag, isrev
+
+
+def same(x, y):
+    return (x["status"] == y["status"] and x["nodes"] == y["nodes"] and x["edges"] == y["edges"]
+            and x["labels"] == y["labels"] and (x["node_counts"] == y["node_counts"]).all()
+            and (x["edge_counts"] == y["edge_counts"]).all() and x["seq_counts"] == y["seq_counts"])
+
+
+def test_port_vs_reference_graphtools_randomized(checker):
+    if not oc.have_ref():
+        pytest.skip("oracle/_ref/libpg_refcounts.so not built")
+    ref = oc.RefCounts()
+    rng = random.Random(31337)
+    n = 0
+    for _ in range(400):
+        g, recs, _, _, _ = make_case(rng, checker)
+        for kw in (dict(remove_nonuniq=True, use_support_filters=True), dict(remove_nonuniq=False, use_support_filters=True),
+                   dict(remove_nonuniq=False, use_support_filters=False, bad_align_frac=0.5)):
+            x = ref.count_site(g, recs, **kw)
+            y = oc.port_count_site(g, recs, **kw)
+            assert x["rc"] == 0 and y["rc"] == 0
+            assert same(x, y), (g.nodes, g.edges, g.edge_labels, recs, kw)
+            n += 1
+    assert n == 1200

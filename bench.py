@@ -3,7 +3,8 @@
 
 A "step" is one pass of the hot path (4 graph fills + strand pick + traceback per read, i.e. the default
 grmpy cascade GraphAligner::alignRead(AF_ALL)) over one batch of synthetic reads that is already
-resident in HBM when the timed region starts.
+resident in HBM when the timed region starts, followed by the count path (read filters, node/edge/sequence
+support, per-fragment union, per-site counters).
 
 Workload at N=1 = BASELINE.json configs[1]: 1 DEL graph (200 bp flanks, 100 bp deletion; nodes
 201/100/201 bp, G = 502), 1 000 000 synthetic 150 bp reads.  With N GPUs
@@ -125,16 +126,22 @@ def main():
     L = args.read_len
     ctx = capi.Context(local_rank, workspace_bytes=int(args.workspace_gib * (1 << 30)))
     graphs = ctx.upload_graphs([(site.seqs, site.edges)])
+    graphs.set_labels([site.labels])
     batch = ctx.new_batch()
     t0 = time.perf_counter()
     batch.upload(graphs, synth.packed_to_capi(arr))
+    # mates: reads 2k and 2k+1 form fragment k (counts are per fragment, ReadCounting.cpp:52-94)
+    batch.set_fragments(np.arange(args.reads, dtype=np.uint32) // 2)
     ctx.sync()
     t_upload = time.perf_counter() - t0
     log("uploaded in %.2fs" % t_upload)
 
-    tally = None
-    if world > 1:
-        tally = torch.zeros(8, dtype=torch.int64, device="cuda")
+    # per-site counter table {count, READS, FWD, REV} x (nodes, edges, sequence sets) + filter tallies: a torch
+    # tensor so that the final reduce is ONE RCCL all-reduce over xGMI on device memory, no host hop
+    n_counters = int(graphs.layout.n_counters)
+    counts_t = None
+    if torch is not None and torch.cuda.is_available():
+        counts_t = torch.zeros(n_counters, dtype=torch.int32, device="cuda:%d" % local_rank)
 
     def barrier():
         ctx.sync()
@@ -145,10 +152,16 @@ def main():
 
     def step():
         batch.align(capi.AF_ALL)
+        if counts_t is not None:
+            counts_t.zero_()
+            torch.cuda.current_stream().synchronize()
+            batch.count(remove_nonuniq=True, bad_align_frac=0.8, d_counts=counts_t.data_ptr())
+        else:
+            batch.count(remove_nonuniq=True, bad_align_frac=0.8)
         if world > 1:
-            # final read-count reduce (small integer table, RCCL over xGMI)
+            # the only collective of the path: sum of the per-site counters (RCCL over xGMI)
             ctx.sync()
-            dist.all_reduce(tally)
+            dist.all_reduce(counts_t)
 
     for _ in range(args.warmup):
         step()
@@ -169,6 +182,10 @@ def main():
     t0 = time.perf_counter()
     res, ops = batch.download()
     t_download = time.perf_counter() - t0
+    site_counts = None
+    if counts_t is not None:
+        tab = counts_t.cpu().numpy().view(np.uint32)
+        site_counts = capi.decode_counts(graphs, tab)[0]
     log("downloaded in %.2fs" % t_download)
 
     if world > 1:
@@ -226,6 +243,12 @@ def main():
                 "reads_per_s": args.reads / (t_upload + elapsed / args.steps + t_download),
             },
         }
+        if site_counts is not None:
+            out["counts"] = {"edges": {"%s_%s" % (site.names[a], site.names[b]): c[0]
+                                       for (a, b), c in site_counts["edge_counts"].items()},
+                             "sequences": {k: v[0] for k, v in site_counts["seq_counts"].items()},
+                             "tallies": site_counts["tallies"],
+                             "note": "fragment counts of the last step, summed over %d rank(s)" % world}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(site, arr, args.cpu_seconds)
         print(json.dumps(out))

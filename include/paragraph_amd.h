@@ -22,6 +22,7 @@
  *   pg_align_batch       one-shot convenience = upload + align + download
  *   pg_render_cigar      GraphAlignerImpl::extractCigar         GraphAligner.cpp:88-108
  *   pg_graphs_set_labels graphtools::Graph::addLabelToEdge as grm::graphFromJson fills it   src/c++/lib/grm/GraphInput.cpp:126-156
+ *   pg_batch_set_fragments   Read::fragment_id / is_reverse_strand of the input reads   src/c++/include/common/Read.hh:40-120
  *   pg_batch_count       read filters (NonUniq, BadAlign) applied by CompositeAligner::alignRead
  *                                                               src/c++/lib/paragraph/ReadFilter.cpp:43-90, readfilters/*.hh,
  *                                                               src/c++/lib/grm/CompositeAligner.cpp:152-175
@@ -219,14 +220,16 @@ pg_status pg_graphs_count_layout(const pg_graphs* graphs, pg_count_layout* out);
 /* seq_off[g] (n_graphs + 1 entries) of the layout above */
 pg_status pg_graphs_seq_offsets(const pg_graphs* graphs, uint64_t* seq_off);
 
-/* Runs the count path on the device for the batch's last pg_batch_align results.
+/* Fragment membership of the uploaded reads (call once after pg_batch_upload):
  * fragment_of_read: fragment id per read (mates share an id; ids are local to the read's graph);
- * is_reverse_strand: Read::is_reverse_strand() of the input (BAM flag), may be NULL (all forward);
- * d_counts: DEVICE pointer to pg_count_layout.n_counters uint32 the kernel ADDS into (caller zeroes it; e.g. a
- * torch tensor that is then all-reduced with RCCL), or NULL to use a table owned by the batch (zeroed per call). */
-pg_status pg_batch_count(
-    pg_ctx* ctx, pg_batch* batch, const pg_count_params* params, const uint32_t* fragment_of_read,
-    const uint8_t* is_reverse_strand, uint32_t* d_counts);
+ * is_reverse_strand: Read::is_reverse_strand() of the input (BAM flag), may be NULL (all forward). */
+pg_status pg_batch_set_fragments(
+    pg_ctx* ctx, pg_batch* batch, const uint32_t* fragment_of_read, const uint8_t* is_reverse_strand);
+/* Runs the count path on the device for the batch's last pg_batch_align results (asynchronous on the ctx
+ * stream).  d_counts: DEVICE pointer to pg_count_layout.n_counters uint32 the kernels ADD into (caller zeroes
+ * it; e.g. a torch tensor that is then all-reduced with RCCL), or NULL to use a table owned by the batch
+ * (zeroed per call). */
+pg_status pg_batch_count(pg_ctx* ctx, pg_batch* batch, const pg_count_params* params, uint32_t* d_counts);
 /* Copies the count table (if the batch owns it; pass NULL otherwise), per-read supports and path entries
  * (capacity path_cap entries; *n_path receives the number used) to host memory; synchronises. */
 pg_status pg_batch_download_counts(

@@ -39,7 +39,7 @@ EXPORTS = [
     "pg_ctx_timing_enable", "pg_ctx_timing_reset", "pg_ctx_timing_get", "pg_graphs_upload", "pg_graphs_destroy",
     "pg_batch_create", "pg_batch_destroy", "pg_batch_upload", "pg_batch_align", "pg_batch_ops_count",
     "pg_batch_download", "pg_align_batch", "pg_render_cigar", "pg_graphs_set_labels", "pg_graphs_count_layout",
-    "pg_graphs_seq_offsets", "pg_batch_count", "pg_batch_download_counts",
+    "pg_graphs_seq_offsets", "pg_batch_set_fragments", "pg_batch_count", "pg_batch_download_counts",
 ]
 
 
@@ -122,7 +122,9 @@ def load_library():
     L.pg_graphs_seq_offsets.restype = C.c_int32
     L.pg_graphs_seq_offsets.argtypes = [vp, u64p]
     L.pg_batch_count.restype = C.c_int32
-    L.pg_batch_count.argtypes = [vp, vp, C.POINTER(CountParams), u32p, C.POINTER(C.c_uint8), vp]
+    L.pg_batch_count.argtypes = [vp, vp, C.POINTER(CountParams), vp]
+    L.pg_batch_set_fragments.restype = C.c_int32
+    L.pg_batch_set_fragments.argtypes = [vp, vp, u32p, C.POINTER(C.c_uint8)]
     L.pg_batch_download_counts.restype = C.c_int32
     L.pg_batch_download_counts.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, u64p]
     L.pg_render_cigar.restype = C.c_size_t
@@ -308,17 +310,18 @@ class Batch:
     def align(self, flags=AF_ALL):
         self.ctx._chk(self.ctx.L.pg_batch_align(self.ctx.h, self.h, flags & 0xFFFFFFFF))
 
-    def count(self, fragment_of_read, is_reverse_strand=None, remove_nonuniq=True, bad_align_frac=0.8,
-              use_support_filters=True, d_counts=None):
-        """Runs the count path; d_counts = device pointer (int) of a caller-owned uint32 table or None."""
-        prm = CountParams(1 if remove_nonuniq else 0, 1 if use_support_filters else 0, bad_align_frac)
+    def set_fragments(self, fragment_of_read, is_reverse_strand=None):
         fr = _u32(fragment_of_read)
         rv = None
         if is_reverse_strand is not None:
             rv = np.ascontiguousarray(is_reverse_strand, dtype=np.uint8)
-        self.ctx._chk(self.ctx.L.pg_batch_count(
-            self.ctx.h, self.h, C.byref(prm), _p32(fr),
-            rv.ctypes.data_as(C.POINTER(C.c_uint8)) if rv is not None else None, d_counts))
+        self.ctx._chk(self.ctx.L.pg_batch_set_fragments(
+            self.ctx.h, self.h, _p32(fr), rv.ctypes.data_as(C.POINTER(C.c_uint8)) if rv is not None else None))
+
+    def count(self, remove_nonuniq=True, bad_align_frac=0.8, use_support_filters=True, d_counts=None):
+        """Runs the count path (async); d_counts = device pointer (int) of a caller-owned uint32 table or None."""
+        prm = CountParams(1 if remove_nonuniq else 0, 1 if use_support_filters else 0, bad_align_frac)
+        self.ctx._chk(self.ctx.L.pg_batch_count(self.ctx.h, self.h, C.byref(prm), d_counts))
 
     def download_counts(self, want_table=True):
         """-> (counts table or None, supports (SUPPORT_DTYPE), path entries)."""

@@ -463,6 +463,7 @@ extern "C" pg_status pg_batch_upload(
     b->chunks.clear();
     b->n_pairs = 0;
     b->has_skipped = false;
+    b->fragments_set = false;
 
     // ---- bucket reads by (variant, graph) -----------------------------------------------------------
     struct Key

@@ -93,10 +93,14 @@ __device__ bool edge_ok(const NodeAln& p, const NodeAln& c, uint32_t len1, uint3
 
 __global__ __launch_bounds__(64) void pg_support_kernel(CountArgs a)
 {
-    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
-    if (r >= a.n_reads)
-        return;
-    const pg_result res = a.results[r];
+    const uint32_t r0 = blockIdx.x * 64u + threadIdx.x;
+    // out-of-range lanes shadow the last read with every side effect disabled, so that the wave-wide
+    // ballots below always see all 64 lanes
+    const bool live = r0 < a.n_reads;
+    const uint32_t r = live ? r0 : a.n_reads - 1;
+    pg_result res = a.results[r];
+    if (!live)
+        res.status = 0xFFFF;
     const uint32_t L = a.base_off[r + 1] - a.base_off[r];
     const PgCountGraph cg = a.graphs[a.graph_of_read[r]];
     uint32_t* tally = a.counts + a.lay.tally_base + 4ull * a.graph_of_read[r];
@@ -106,15 +110,30 @@ __global__ __launch_bounds__(64) void pg_support_kernel(CountArgs a)
     sup.n_path = 0;
     sup.status = 0;
     sup.filter = 0;
-    if (L == 0 || res.status != 0 || res.n_ops == 0)
+    // tallies: one atomic per wavefront when all its (active) lanes belong to the same graph (the usual case)
+    auto tally_add = [&](int which, bool pred) {
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.graph_of_read[r]);
+        const bool uniform = __all(a.graph_of_read[r] == g0);
+        if (uniform)
+        {
+            const unsigned long long m = __ballot(pred);
+            if (m != 0 && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m))
+                atomicAdd(&tally[which], (uint32_t)__builtin_popcountll(m));
+        }
+        else if (pred)
+            atomicAdd(&tally[which], 1u);
+    };
+    const bool aligned = !(L == 0 || res.status != 0 || res.n_ops == 0);
+    tally_add(0, aligned);
+    if (!aligned)
     {
         // skipped (Align.cpp:74-77) or degenerate all-zero alignment (no CIGAR): never counted
         if (L != 0 && res.status == 2)
             sup.status = 3;
-        a.support[r] = sup;
+        if (live)
+            a.support[r] = sup;
         return;
     }
-    atomicAdd(&tally[0], 1u);
     // ---- CompositeAligner.cpp:156-172: MAPPED, then the filter chain may turn it into BAD_ALIGN
     sup.status = 1;
     if (a.prm.remove_nonuniq && !res.is_unique)
@@ -136,16 +155,14 @@ __global__ __launch_bounds__(64) void pg_support_kernel(CountArgs a)
     const uint32_t first_node = PG_OP_NODE(a.ops[res.ops_off]);
     if (res.graph_pos < 0 || (uint32_t)res.graph_pos >= a.node_len[cg.node_base + first_node])
         sup.status = 3;
+    tally_add(3, sup.status == 2 && sup.filter == 1);
+    tally_add(2, sup.status == 2 && sup.filter == 2);
+    tally_add(1, sup.status == 1);
     if (sup.status != 1)
     {
-        if (sup.filter == 1)
-            atomicAdd(&tally[3], 1u);
-        else if (sup.filter == 2)
-            atomicAdd(&tally[2], 1u);
         a.support[r] = sup;
         return;
     }
-    atomicAdd(&tally[1], 1u);
 
     // ---- walk the CIGAR node by node (streaming: previous + current node alignment) -----------------
     uint32_t n_path = 0;
@@ -229,91 +246,146 @@ __global__ __launch_bounds__(64) void pg_support_kernel(CountArgs a)
 }
 
 constexpr int FRAG_SET_CAP = 48;
+constexpr int FRAG_BLOCK = 256;
+constexpr uint32_t FRAG_LDS_COUNTERS = 4096;
 
-__global__ __launch_bounds__(64) void pg_fragment_kernel(CountArgs a)
+// One thread per fragment.  Fragments are sorted by graph, so a block usually works on ONE graph: its
+// counters are then accumulated in LDS and flushed with one global atomic per touched counter per block
+// (a single hot site would otherwise serialise millions of atomics on a handful of addresses).
+__global__ __launch_bounds__(FRAG_BLOCK) void pg_fragment_kernel(CountArgs a)
 {
-    const uint32_t f = blockIdx.x * 64u + threadIdx.x;
-    if (f >= a.n_frags)
-        return;
-    const uint32_t b = a.frag_off[f], e = a.frag_off[f + 1];
+    __shared__ uint32_t lcnt[FRAG_LDS_COUNTERS];
+    const uint32_t f = blockIdx.x * FRAG_BLOCK + threadIdx.x;
+    const uint32_t f_first = blockIdx.x * FRAG_BLOCK;
+    const uint32_t f_last = min(f_first + FRAG_BLOCK, a.n_frags) - 1;
+    const uint32_t g_first = a.graph_of_read[a.frag_reads[a.frag_off[f_first]]];
+    const uint32_t g_last = a.graph_of_read[a.frag_reads[a.frag_off[f_last]]];
+    const PgCountGraph bg = a.graphs[g_first];
+    const uint32_t e_base = a.pred_off[bg.node_base];
+    const uint32_t n_edges_g = a.pred_off[bg.node_base + bg.n_nodes] - e_base;
+    const uint32_t n_seq_g = bg.n_labels <= PG_MAX_SEQ_TABLE_LABELS ? (1u << bg.n_labels) : 0u;
+    const uint32_t l_edge = 4 * bg.n_nodes, l_seq = l_edge + 4 * n_edges_g, l_total = l_seq + 4 * n_seq_g;
+    const bool use_lds = g_first == g_last && l_total <= FRAG_LDS_COUNTERS;
+    if (use_lds)
+    {
+        for (uint32_t i = threadIdx.x; i < l_total; i += FRAG_BLOCK)
+            lcnt[i] = 0;
+    }
+    __syncthreads();
+
     uint32_t n = 0, fwd = 0, rev = 0;
     uint64_t labels = 0;
     uint32_t nodes[FRAG_SET_CAP], edges[FRAG_SET_CAP];
     int nn = 0, ne = 0;
-    uint32_t graph = 0;
+    uint32_t graph = g_first;
     bool overflow = false;
-    for (uint32_t q = b; q < e; ++q)
+    if (f < a.n_frags)
     {
-        const uint32_t r = a.frag_reads[q];
-        const pg_read_support sup = a.support[r];
-        if (sup.status != 1)
-            continue;  // only MAPPED reads survive alignReads (Align.cpp:81-84,155)
-        graph = a.graph_of_read[r];
-        const PgCountGraph cg = a.graphs[graph];
-        ++n;
-        const bool read_rev = a.is_rev ? a.is_rev[r] != 0 : false;
-        const bool graph_rev = read_rev != (a.results[r].returned_reverse != 0);  // GraphAligner.cpp:358-359
-        if (graph_rev)
-            ++rev;
-        else
-            ++fwd;
-        labels |= sup.label_mask;
-        uint32_t pnode = 0;
-        for (uint32_t k = 0; k < sup.n_path; ++k)
+        const uint32_t b = a.frag_off[f], e = a.frag_off[f + 1];
+        for (uint32_t q = b; q < e; ++q)
         {
-            const uint32_t en = a.path[sup.path_off + k];
-            const uint32_t nd = PG_PATH_NODE(en);
-            if (PG_PATH_NODE_OK(en))
+            const uint32_t r = a.frag_reads[q];
+            const pg_read_support sup = a.support[r];
+            if (sup.status != 1)
+                continue;  // only MAPPED reads survive alignReads (Align.cpp:81-84,155)
+            graph = a.graph_of_read[r];
+            const PgCountGraph cg = a.graphs[graph];
+            ++n;
+            const bool read_rev = a.is_rev[r] != 0;
+            const bool graph_rev = read_rev != (a.results[r].returned_reverse != 0);  // GraphAligner.cpp:358-359
+            if (graph_rev)
+                ++rev;
+            else
+                ++fwd;
+            labels |= sup.label_mask;
+            uint32_t pnode = 0;
+            for (uint32_t k = 0; k < sup.n_path; ++k)
             {
-                bool seen = false;
-                for (int t = 0; t < nn; ++t)
-                    seen |= nodes[t] == nd;
-                if (!seen)
+                const uint32_t en = a.path[sup.path_off + k];
+                const uint32_t nd = PG_PATH_NODE(en);
+                if (PG_PATH_NODE_OK(en))
                 {
-                    if (nn < FRAG_SET_CAP)
-                        nodes[nn++] = nd;
-                    else
-                        overflow = true;
+                    bool seen = false;
+                    for (int t = 0; t < nn; ++t)
+                        seen |= nodes[t] == nd;
+                    if (!seen)
+                    {
+                        if (nn < FRAG_SET_CAP)
+                            nodes[nn++] = nd;
+                        else
+                            overflow = true;
+                    }
                 }
-            }
-            if (k > 0 && PG_PATH_EDGE_OK(en))
-            {
-                const uint32_t gn = cg.node_base + nd;
-                uint32_t eidx = 0xFFFFFFFFu;
-                for (uint32_t p = a.pred_off[gn]; p < a.pred_off[gn + 1]; ++p)
-                    if (a.pred[p] == pnode)
-                        eidx = p;
-                bool seen = false;
-                for (int t = 0; t < ne; ++t)
-                    seen |= edges[t] == eidx;
-                if (!seen && eidx != 0xFFFFFFFFu)
+                if (k > 0 && PG_PATH_EDGE_OK(en))
                 {
-                    if (ne < FRAG_SET_CAP)
-                        edges[ne++] = eidx;
-                    else
-                        overflow = true;
+                    const uint32_t gn = cg.node_base + nd;
+                    uint32_t eidx = 0xFFFFFFFFu;
+                    for (uint32_t p = a.pred_off[gn]; p < a.pred_off[gn + 1]; ++p)
+                        if (a.pred[p] == pnode)
+                            eidx = p;
+                    bool seen = false;
+                    for (int t = 0; t < ne; ++t)
+                        seen |= edges[t] == eidx;
+                    if (!seen && eidx != 0xFFFFFFFFu)
+                    {
+                        if (ne < FRAG_SET_CAP)
+                            edges[ne++] = eidx;
+                        else
+                            overflow = true;
+                    }
                 }
+                pnode = nd;
             }
-            pnode = nd;
         }
     }
-    if (n == 0)
-        return;
-    const PgCountGraph cg = a.graphs[graph];
-    auto add = [&](uint32_t* c) {  // ReadCounting.cpp:52-69
-        atomicAdd(&c[0], 1u);
-        atomicAdd(&c[1], n);
-        atomicAdd(&c[2], fwd);
-        atomicAdd(&c[3], rev);
-    };
-    for (int t = 0; t < nn; ++t)
-        add(a.counts + a.lay.node_base + 4ull * (cg.node_base + nodes[t]));
-    for (int t = 0; t < ne; ++t)
-        add(a.counts + a.lay.edge_base + 4ull * edges[t]);
-    if (labels != 0 && cg.n_labels <= PG_MAX_SEQ_TABLE_LABELS)
-        add(a.counts + a.lay.seq_base + 4ull * (cg.seq_base + labels));
-    if (overflow)
-        atomicAdd(a.counts + a.lay.tally_base + 4ull * graph, 0x80000000u);  // poison: > 48 nodes/edges per fragment
+    if (n != 0)
+    {
+        const PgCountGraph cg = a.graphs[graph];
+        auto add = [&](uint32_t* c) {  // ReadCounting.cpp:52-69
+            atomicAdd(&c[0], 1u);
+            atomicAdd(&c[1], n);
+            atomicAdd(&c[2], fwd);
+            atomicAdd(&c[3], rev);
+        };
+        if (use_lds)
+        {
+            for (int t = 0; t < nn; ++t)
+                add(lcnt + 4 * nodes[t]);
+            for (int t = 0; t < ne; ++t)
+                add(lcnt + l_edge + 4 * (edges[t] - e_base));
+            if (labels != 0 && n_seq_g)
+                add(lcnt + l_seq + 4 * (uint32_t)labels);
+        }
+        else
+        {
+            for (int t = 0; t < nn; ++t)
+                add(a.counts + a.lay.node_base + 4ull * (cg.node_base + nodes[t]));
+            for (int t = 0; t < ne; ++t)
+                add(a.counts + a.lay.edge_base + 4ull * edges[t]);
+            if (labels != 0 && cg.n_labels <= PG_MAX_SEQ_TABLE_LABELS)
+                add(a.counts + a.lay.seq_base + 4ull * (cg.seq_base + labels));
+        }
+        if (overflow)
+            atomicAdd(a.counts + a.lay.tally_base + 4ull * graph, 0x80000000u);  // poison: > 48 nodes/edges per fragment
+    }
+    __syncthreads();
+    if (use_lds)
+    {
+        for (uint32_t i = threadIdx.x; i < l_total; i += FRAG_BLOCK)
+        {
+            const uint32_t v = lcnt[i];
+            if (v == 0)
+                continue;
+            uint32_t* dst;
+            if (i < l_edge)
+                dst = a.counts + a.lay.node_base + 4ull * bg.node_base + i;
+            else if (i < l_seq)
+                dst = a.counts + a.lay.edge_base + 4ull * e_base + (i - l_edge);
+            else
+                dst = a.counts + a.lay.seq_base + 4ull * bg.seq_base + (i - l_seq);
+            atomicAdd(dst, v);
+        }
+    }
 }
 
 template <typename T> hipError_t dev_upload(const std::vector<T>& v, T** d, hipStream_t s)
@@ -409,21 +481,14 @@ extern "C" pg_status pg_graphs_seq_offsets(const pg_graphs* G, uint64_t* seq_off
     return PG_OK;
 }
 
-extern "C" pg_status pg_batch_count(
-    pg_ctx* ctx, pg_batch* b, const pg_count_params* params, const uint32_t* fragment_of_read,
-    const uint8_t* is_reverse_strand, uint32_t* d_counts)
+extern "C" pg_status pg_batch_set_fragments(
+    pg_ctx* ctx, pg_batch* b, const uint32_t* fragment_of_read, const uint8_t* is_reverse_strand)
 {
-    if (!ctx || !b || !b->graphs || !params || (b->n_reads && !fragment_of_read))
-        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_count: null argument");
-    const pg_graphs* G = b->graphs;
-    if (!G->labels_set)
-        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_count: call pg_graphs_set_labels first");
+    if (!ctx || !b || !b->graphs || (b->n_reads && !fragment_of_read))
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_set_fragments: null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t n = b->n_reads;
-    pg_count_layout lay;
-    layout_of(G, &lay);
-
-    // ---- fragments: CSR over (graph, fragment id), reads in input order inside a fragment -----------
+    // fragments: CSR over (graph, fragment id), reads in input order inside a fragment
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
     const std::vector<uint32_t>& gor = b->h_graph_of_read;
@@ -438,7 +503,6 @@ extern "C" pg_status pg_batch_count(
     const uint32_t n_frags = (uint32_t)frag_off.size();
     frag_off.push_back(n);
     b->n_frags = n_frags;
-
     if (n > b->cap_count_reads)
     {
         (void)hipFree(b->d_support);
@@ -459,6 +523,33 @@ extern "C" pg_status pg_batch_count(
         b->cap_frags = n_frags + 1;
         HIP_TRY(ctx, hipMalloc((void**)&b->d_frag_off, b->cap_frags * sizeof(uint32_t)));
     }
+    if (n)
+    {
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_frag_reads, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_frag_off, frag_off.data(), frag_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (is_reverse_strand)
+            HIP_TRY(ctx, hipMemcpyAsync(b->d_is_rev, is_reverse_strand, n, hipMemcpyHostToDevice, ctx->stream));
+        else
+            HIP_TRY(ctx, hipMemsetAsync(b->d_is_rev, 0, n, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `order` / `frag_off` are host temporaries
+    b->fragments_set = true;
+    return PG_OK;
+}
+
+extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_params* params, uint32_t* d_counts)
+{
+    if (!ctx || !b || !b->graphs || !params)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_count: null argument");
+    const pg_graphs* G = b->graphs;
+    if (!G->labels_set)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_count: call pg_graphs_set_labels first");
+    if (!b->fragments_set)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_count: call pg_batch_set_fragments first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = b->n_reads;
+    pg_count_layout lay;
+    layout_of(G, &lay);
     uint32_t* counts = d_counts;
     b->counts_owned_valid = false;
     if (!counts)
@@ -474,13 +565,6 @@ extern "C" pg_status pg_batch_count(
         b->counts_owned_valid = true;
     }
     HIP_TRY(ctx, hipMemsetAsync(b->d_path_counter, 0, sizeof(unsigned long long), ctx->stream));
-    if (n)
-    {
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_frag_reads, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_frag_off, frag_off.data(), frag_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        if (is_reverse_strand)
-            HIP_TRY(ctx, hipMemcpyAsync(b->d_is_rev, is_reverse_strand, n, hipMemcpyHostToDevice, ctx->stream));
-    }
     CountArgs a{};
     a.n_reads = n;
     a.prm = *params;
@@ -488,7 +572,7 @@ extern "C" pg_status pg_batch_count(
     a.ops = b->d_ops;
     a.base_off = b->d_base_off;
     a.graph_of_read = b->d_graph_of_read;
-    a.is_rev = is_reverse_strand ? b->d_is_rev : nullptr;
+    a.is_rev = b->d_is_rev;
     a.graphs = G->d_cnt_graphs;
     a.pred_off = G->d_cnt_pred_off;
     a.pred = G->d_cnt_pred;
@@ -499,7 +583,7 @@ extern "C" pg_status pg_batch_count(
     a.support = b->d_support;
     a.path = b->d_path;
     a.path_counter = b->d_path_counter;
-    a.n_frags = n_frags;
+    a.n_frags = b->n_frags;
     a.frag_off = b->d_frag_off;
     a.frag_reads = b->d_frag_reads;
     a.counts = counts;
@@ -508,10 +592,9 @@ extern "C" pg_status pg_batch_count(
     {
         hipLaunchKernelGGL(pg_support_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a);
         HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(pg_fragment_kernel, dim3((n_frags + 63) / 64), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL(pg_fragment_kernel, dim3((b->n_frags + FRAG_BLOCK - 1) / FRAG_BLOCK), dim3(FRAG_BLOCK), 0, ctx->stream, a);
         HIP_TRY(ctx, hipGetLastError());
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `order` / `frag_off` are host temporaries
     return PG_OK;
 }
 

@@ -105,6 +105,7 @@ struct pg_batch
     uint64_t cap_counts = 0;
     uint32_t n_frags = 0;
     bool counts_owned_valid = false;
+    bool fragments_set = false;
 };
 
 

@@ -30,7 +30,8 @@ def gpu_counts(ctx, graphs, labels, names, reads, gor, frag, isrev, **kw):
     b.upload(G, reads, gor)
     b.align(capi.AF_ALL)
     res, ops = b.download()
-    b.count(frag, isrev, **kw)
+    b.set_fragments(frag, isrev)
+    b.count(**kw)
     table, sup, path = b.download_counts()
     out = (capi.results_to_dicts(res, ops), capi.decode_supports(G, gor, sup, path), capi.decode_counts(G, table))
     b.close()

@@ -32,8 +32,36 @@ def build_hip(force=False, verbose=False):
     return LIB
 
 
+HOST_LIB = os.path.join(_HERE, "libparagraph_host.so")
+HOST_TEST = os.path.join(ROOT, "tests", "host_cpp", "test_host")
+
+
+def build_host(force=False, verbose=False):
+    """g++ -> paragraph_amd/libparagraph_host.so (reference-shaped C++ classes over the C ABI) and the C++ test
+    program tests/host_cpp/test_host."""
+    src = os.path.join(_HERE, "host", "src", "host.cpp")
+    inc = os.path.join(_HERE, "host", "include")
+    hdrs = [os.path.join(dp, f) for dp, _, fs in os.walk(inc) for f in fs]
+    cxx = os.environ.get("CXX", "g++")
+    if force or _stale(HOST_LIB, [src, LIB] + hdrs):
+        cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + inc, "-o", HOST_LIB, src, "-L" + _HERE,
+               "-lparagraph_amd", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    tsrc = os.path.join(ROOT, "tests", "host_cpp", "test_host.cpp")
+    if os.path.exists(tsrc) and (force or _stale(HOST_TEST, [tsrc, HOST_LIB] + hdrs)):
+        cmd = [cxx, "-std=c++17", "-O2", "-I" + inc, "-o", HOST_TEST, tsrc, "-L" + _HERE, "-lparagraph_host",
+               "-lparagraph_amd", "-Wl,-rpath,$ORIGIN/../../paragraph_amd"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return HOST_LIB
+
+
 def build_all(force=False, verbose=False):
     build_hip(force=force, verbose=verbose)
+    build_host(force=force, verbose=verbose)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,61 @@
+// Site-batching replacement of the per-site align -> filter -> disambiguate -> count steps of
+// paragraph::alignAndDisambiguate (src/c++/lib/paragraph/Disambiguation.cpp:152-361).
+//
+// The reference handles ONE site (~130 reads) per call; a GPU needs >= 1e5 reads in flight, so sites are
+// accumulated with addSite() and processed by ONE run(): graphs -> pg_graphs_upload (+labels), all reads ->
+// pg_batch_upload, pg_batch_align, pg_batch_count, then results are fanned back into the common::Read objects
+// (graph_* fields, mapping status after the NonUniq/BadAlign filters, nodes/edges/sequences supported) and into
+// per-site count tables keyed like read_counts_by_node / _by_edge / _by_sequence (ReadCounting.cpp:52-127).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common/Read.hh"
+#include "graphcore/Graph.hh"
+
+namespace paragraph
+{
+struct CountEntry
+{
+    uint64_t count = 0, reads = 0, fwd = 0, rev = 0;  // element, :READS, :FWD, :REV
+    bool operator==(CountEntry const& o) const { return count == o.count && reads == o.reads && fwd == o.fwd && rev == o.rev; }
+};
+
+struct SiteCounts
+{
+    std::map<std::string, CountEntry> by_node;      // node name
+    std::map<std::string, CountEntry> by_edge;      // "<from>_<to>"
+    std::map<std::string, CountEntry> by_sequence;  // sorted, comma-joined label set ("total" of countPathFamilies)
+    uint64_t aligned = 0, mapped = 0, bad_align = 0, nonuniq = 0;
+};
+
+struct BatchParameters
+{
+    bool remove_nonuniq_reads = true;  // paragraph --bad-align-nonuniq
+    double bad_align_frac = 0.8;       // --bad-align-frac
+    bool use_support_filters = true;   // production nodefilter / edgefilter
+    unsigned alignment_flags = (unsigned)-1;
+};
+
+class SiteBatcher
+{
+public:
+    SiteBatcher();
+    ~SiteBatcher();
+    // graph and reads must outlive run(); returns the site index
+    size_t addSite(const graphtools::Graph* graph, std::vector<common::p_Read>* reads);
+    // Aligns and counts every site added so far.  Afterwards each site's read vector holds only the MAPPED
+    // reads (as grm::alignReads leaves it, Align.cpp:155) with their supports filled in.
+    void run(BatchParameters const& parameters = BatchParameters());
+    size_t numSites() const;
+    SiteCounts const& counts(size_t site) const;
+
+private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+};
+}  // namespace paragraph

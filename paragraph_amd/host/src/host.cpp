@@ -1,0 +1,466 @@
+// Host-side mirror of the reference's grm:: / paragraph:: interfaces over the C ABI of libparagraph_amd.so.
+// Everything here is marshalling: graphs -> CSR, reads -> packed bytes, pg_result/pg_op -> common::Read.
+// No alignment arithmetic happens on the host and there is no CPU fallback: without a device every call throws.
+#include <algorithm>
+#include <cctype>
+#include <cstdlib>
+#include <mutex>
+#include <stdexcept>
+#include <unordered_map>
+
+#include "../../../include/paragraph_amd.h"
+#include "grm/Align.hh"
+#include "grm/CompositeAligner.hh"
+#include "grm/GraphAligner.hh"
+#include "paragraph/SiteBatcher.hh"
+
+using common::Read;
+using graphtools::Graph;
+using graphtools::NodeId;
+
+namespace
+{
+void check(pg_ctx* ctx, pg_status st, const char* what)
+{
+    if (st != PG_OK)
+        throw std::runtime_error(std::string(what) + ": " + pg_strerror(st) + " (" + (ctx ? pg_last_error(ctx) : "") + ")");
+}
+
+pg_ctx* deviceContext()
+{
+    static pg_ctx* ctx = nullptr;
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    if (!ctx)
+    {
+        const char* dev = std::getenv("PG_DEVICE");
+        pg_status st = pg_ctx_create(dev ? std::atoi(dev) : 0, &ctx);
+        if (st != PG_OK)
+            throw std::runtime_error(std::string("pg_ctx_create: ") + pg_strerror(st));
+    }
+    return ctx;
+}
+std::mutex& deviceMutex()
+{
+    static std::mutex m;  // calls on one ctx must be serialised (paragraph_amd.h)
+    return m;
+}
+
+struct GraphCsr
+{
+    std::vector<uint32_t> node_off{ 0 }, seq_off{ 0 }, pred_off{ 0 }, pred, n_labels;
+    std::vector<uint64_t> label_mask;
+    std::string seq;
+    std::vector<std::vector<std::string>> label_names;  // per graph, sorted
+    void add(const Graph& g)
+    {
+        std::vector<std::string> names;
+        {
+            auto all = g.allLabels();
+            names.assign(all.begin(), all.end());
+        }
+        if (names.size() > 64)
+            throw std::logic_error("more than 64 sequence labels on one graph");
+        for (NodeId n = 0; n != g.numNodes(); ++n)
+        {
+            const std::string& s = g.nodeSeq(n);
+            for (char c : s)
+            {
+                const char u = (char)std::toupper((unsigned char)c);
+                if (g.isSequenceExpansionRequired() && n != 0 && n != g.numNodes() - 1 && u != 'A' && u != 'C' && u != 'G'
+                    && u != 'T' && u != 'X')
+                    throw std::logic_error("degenerate node sequences need node expansion, which the device path does not do");
+            }
+            seq += s;
+            seq_off.push_back((uint32_t)seq.size());
+            for (NodeId p : g.predecessors(n))
+            {
+                pred.push_back(p);
+                uint64_t m = 0;
+                for (auto const& l : g.edgeLabels(p, n))
+                    m |= 1ull << (std::lower_bound(names.begin(), names.end(), l) - names.begin());
+                label_mask.push_back(m);
+            }
+            pred_off.push_back((uint32_t)pred.size());
+        }
+        node_off.push_back(node_off.back() + (uint32_t)g.numNodes());
+        n_labels.push_back((uint32_t)names.size());
+        label_names.push_back(names);
+    }
+};
+
+std::string reverseComplement(std::string s)
+{  // GT!/src/graphutils/SequenceOperations.cpp:66-88
+    for (char& c : s)
+        c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+    std::reverse(s.begin(), s.end());
+    return s;
+}
+
+// GraphAligner.cpp:358-401
+void applyResult(Read& read, const pg_result& r, const pg_op* ops, bool want_cigar)
+{
+    if (r.returned_reverse)
+    {
+        read.set_bases(reverseComplement(read.bases()));
+        std::string q = read.quals();
+        std::reverse(q.begin(), q.end());
+        read.set_quals(q);
+    }
+    read.set_is_graph_reverse_strand(read.is_reverse_strand() != (r.returned_reverse != 0));
+    read.set_graph_pos(r.graph_pos);
+    read.set_graph_alignment_score(r.score);
+    read.set_is_graph_alignment_unique(r.is_unique != 0);
+    read.set_graph_mapq(r.mapq);
+    if (want_cigar)
+    {
+        std::string buf(16 + 12 * (size_t)r.n_ops, '\0');
+        const size_t n = pg_render_cigar(&r, ops, &buf[0], buf.size());
+        buf.resize(n);
+        read.set_graph_cigar(buf);
+    }
+}
+}  // namespace
+
+namespace grm
+{
+struct GraphAligner::GraphAlignerImpl
+{
+    pg_graphs* graphs = nullptr;
+    const Graph* graph = nullptr;
+    ~GraphAlignerImpl()
+    {
+        if (graphs)
+            pg_graphs_destroy(deviceContext(), graphs);
+    }
+};
+
+GraphAligner::GraphAligner() : _impl(new GraphAlignerImpl()) {}
+GraphAligner::~GraphAligner() = default;
+GraphAligner::GraphAligner(GraphAligner&& rhs) noexcept : _impl(std::move(rhs._impl)) {}
+GraphAligner& GraphAligner::operator=(GraphAligner&& rhs) noexcept
+{
+    _impl = std::move(rhs._impl);
+    return *this;
+}
+
+void GraphAligner::setGraph(Graph const* g)
+{
+    pg_ctx* ctx = deviceContext();
+    std::lock_guard<std::mutex> lock(deviceMutex());
+    if (_impl->graphs)
+        pg_graphs_destroy(ctx, _impl->graphs);
+    _impl->graphs = nullptr;
+    _impl->graph = g;
+    GraphCsr csr;
+    csr.add(*g);
+    check(ctx, pg_graphs_upload(ctx, 1, csr.node_off.data(), csr.seq_off.data(), csr.seq.data(), csr.pred_off.data(),
+                                csr.pred.empty() ? nullptr : csr.pred.data(), &_impl->graphs),
+          "pg_graphs_upload");
+}
+
+void GraphAligner::alignReads(std::vector<Read*> const& reads, unsigned int flags) const
+{
+    if (!_impl->graphs)
+        throw std::logic_error("GraphAligner::setGraph has not been called");
+    pg_ctx* ctx = deviceContext();
+    std::vector<uint32_t> base_off{ 0 }, gor(reads.size(), 0);
+    std::string bases;
+    for (Read* r : reads)
+    {
+        bases += r->bases();
+        base_off.push_back((uint32_t)bases.size());
+    }
+    std::vector<pg_result> res(reads.size());
+    std::vector<pg_op> ops(bases.size() + 48 * reads.size() + 1);
+    uint64_t n_ops = 0;
+    {
+        std::lock_guard<std::mutex> lock(deviceMutex());
+        check(ctx, pg_align_batch(ctx, _impl->graphs, (uint32_t)reads.size(), gor.data(), base_off.data(), bases.data(),
+                                  flags, res.data(), ops.data(), ops.size(), &n_ops),
+              "pg_align_batch");
+    }
+    for (size_t i = 0; i < reads.size(); ++i)
+    {
+        if (reads[i]->bases().empty())
+            continue;
+        if (res[i].status == 2)
+            throw std::runtime_error("device traceback inconsistency (the reference would assert)");
+        applyResult(*reads[i], res[i], ops.data(), (flags & AF_CIGAR) != 0);
+    }
+}
+
+void GraphAligner::alignRead(Read& read, unsigned int flags) const
+{
+    std::vector<Read*> one{ &read };
+    alignReads(one, flags);
+}
+
+std::string GraphAligner::align(const std::string& read, int& mapq, int& position, int& score) const
+{
+    Read tmp;
+    tmp.set_bases(read);
+    alignRead(tmp, AF_CIGAR);  // GraphAligner.cpp:287-296
+    mapq = tmp.graph_mapq();
+    position = tmp.graph_pos();
+    score = tmp.graph_alignment_score();
+    return tmp.graph_cigar();
+}
+
+CompositeAligner::CompositeAligner(bool pathMatching, bool graphMatching, bool klibMatching, bool kmerMatching, unsigned flags)
+    : pathMatching_(pathMatching), graphMatching_(graphMatching), klibMatching_(klibMatching), kmerMatching_(kmerMatching),
+      grapAlignmentflags_(flags)
+{
+    if (pathMatching || klibMatching || kmerMatching)
+        throw std::logic_error("path / klib / kmer sequence matching are not implemented on the device yet "
+                               "(default grmpy cascade = graph sequence matching only)");
+}
+CompositeAligner::~CompositeAligner() = default;
+CompositeAligner::CompositeAligner(CompositeAligner&& rhs) noexcept = default;
+
+void CompositeAligner::setGraph(Graph const* graph, std::list<graphtools::Path> const&)
+{
+    if (graphMatching_)
+        graphAligner_.setGraph(graph);
+}
+
+void CompositeAligner::alignReads(std::vector<Read*> const& reads, ReadFilter filter)
+{
+    attempted_ += (unsigned)reads.size();
+    if (!graphMatching_)
+        return;
+    graphAligner_.alignReads(reads, grapAlignmentflags_);
+    for (Read* read : reads)
+    {
+        // CompositeAligner.cpp:152-175: the gssw stage always produces a mapping
+        read->set_graph_mapping_status(Read::MAPPED);
+        if (filter && filter(*read))
+        {
+            read->set_graph_mapping_status(Read::BAD_ALIGN);
+            ++filtered_;
+        }
+        else
+            ++mappedSw_;
+    }
+}
+
+void CompositeAligner::alignRead(Read& read, ReadFilter filter)
+{
+    std::vector<Read*> one{ &read };
+    alignReads(one, filter);
+}
+
+void alignReads(
+    const Graph* graph, std::list<graphtools::Path> const& paths, std::vector<common::p_Read>& reads, ReadFilter const& filter,
+    bool path_sequence_matching, bool graph_sequence_matching, bool klib_sequence_matching, bool kmer_sequence_matching,
+    bool validate_alignments, uint32_t /*threads*/)
+{
+    if (validate_alignments)
+        throw std::logic_error("--validate-alignments (ValidationAligner) is not part of the device path");
+    CompositeAligner aligner(path_sequence_matching, graph_sequence_matching, klib_sequence_matching, kmer_sequence_matching);
+    aligner.setGraph(graph, paths);
+    std::vector<Read*> todo;
+    for (auto& r : reads)
+    {
+        if (r->bases().empty())
+            continue;  // Align.cpp:74-77
+        r->set_graph_mapping_status(Read::UNMAPPED);
+        todo.push_back(r.get());
+    }
+    aligner.alignReads(todo, filter);
+    std::vector<common::p_Read> kept;
+    for (auto& r : reads)
+        if (!r->bases().empty() && r->graph_mapping_status() == Read::MAPPED)
+            kept.emplace_back(std::move(r));
+    reads.swap(kept);  // Align.cpp:155
+}
+}  // namespace grm
+
+namespace paragraph
+{
+struct SiteBatcher::Impl
+{
+    std::vector<const Graph*> graphs;
+    std::vector<std::vector<common::p_Read>*> reads;
+    std::vector<SiteCounts> counts;
+};
+
+SiteBatcher::SiteBatcher() : impl_(new Impl()) {}
+SiteBatcher::~SiteBatcher() = default;
+size_t SiteBatcher::numSites() const { return impl_->graphs.size(); }
+SiteCounts const& SiteBatcher::counts(size_t site) const { return impl_->counts.at(site); }
+
+size_t SiteBatcher::addSite(const Graph* graph, std::vector<common::p_Read>* reads)
+{
+    impl_->graphs.push_back(graph);
+    impl_->reads.push_back(reads);
+    return impl_->graphs.size() - 1;
+}
+
+void SiteBatcher::run(BatchParameters const& prm)
+{
+    const size_t n_sites = impl_->graphs.size();
+    impl_->counts.assign(n_sites, SiteCounts());
+    if (n_sites == 0)
+        return;
+    pg_ctx* ctx = deviceContext();
+    std::lock_guard<std::mutex> lock(deviceMutex());
+    GraphCsr csr;
+    for (const Graph* g : impl_->graphs)
+        csr.add(*g);
+    pg_graphs* G = nullptr;
+    check(ctx, pg_graphs_upload(ctx, (uint32_t)n_sites, csr.node_off.data(), csr.seq_off.data(), csr.seq.data(),
+                                csr.pred_off.data(), csr.pred.empty() ? nullptr : csr.pred.data(), &G),
+          "pg_graphs_upload");
+    struct Guard
+    {
+        pg_ctx* c;
+        pg_graphs* g;
+        pg_batch* b;
+        ~Guard()
+        {
+            if (b)
+                pg_batch_destroy(c, b);
+            if (g)
+                pg_graphs_destroy(c, g);
+        }
+    } guard{ ctx, G, nullptr };
+    check(ctx, pg_graphs_set_labels(ctx, G, csr.label_mask.empty() ? nullptr : csr.label_mask.data(), csr.n_labels.data()),
+          "pg_graphs_set_labels");
+
+    std::vector<uint32_t> base_off{ 0 }, gor, frag;
+    std::vector<uint8_t> is_rev;
+    std::vector<Read*> flat;
+    std::string bases;
+    for (size_t s = 0; s < n_sites; ++s)
+    {
+        std::unordered_map<std::string, uint32_t> frag_ids;  // fragment ids are local to a site
+        for (auto& r : *impl_->reads[s])
+        {
+            flat.push_back(r.get());
+            bases += r->bases();
+            base_off.push_back((uint32_t)bases.size());
+            gor.push_back((uint32_t)s);
+            auto it = frag_ids.emplace(r->fragment_id(), (uint32_t)frag_ids.size()).first;
+            frag.push_back(it->second);
+            is_rev.push_back(r->is_reverse_strand() ? 1 : 0);
+            r->set_graph_mapping_status(Read::UNMAPPED);
+        }
+    }
+    const uint32_t n = (uint32_t)flat.size();
+    check(ctx, pg_batch_create(ctx, &guard.b), "pg_batch_create");
+    check(ctx, pg_batch_upload(ctx, guard.b, G, n, gor.data(), base_off.data(), bases.data()), "pg_batch_upload");
+    check(ctx, pg_batch_set_fragments(ctx, guard.b, frag.data(), is_rev.data()), "pg_batch_set_fragments");
+    check(ctx, pg_batch_align(ctx, guard.b, prm.alignment_flags), "pg_batch_align");
+    pg_count_params cp{};
+    cp.remove_nonuniq = prm.remove_nonuniq_reads ? 1 : 0;
+    cp.use_support_filters = prm.use_support_filters ? 1 : 0;
+    cp.bad_align_frac = prm.bad_align_frac;
+    check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
+
+    uint64_t n_ops = 0, n_path = 0;
+    check(ctx, pg_batch_ops_count(ctx, guard.b, &n_ops), "pg_batch_ops_count");
+    std::vector<pg_result> res(n);
+    std::vector<pg_op> ops(n_ops + 1);
+    check(ctx, pg_batch_download(ctx, guard.b, res.data(), ops.data(), ops.size(), &n_ops), "pg_batch_download");
+    pg_count_layout lay{};
+    check(ctx, pg_graphs_count_layout(G, &lay), "pg_graphs_count_layout");
+    std::vector<uint64_t> seq_off(n_sites + 1);
+    check(ctx, pg_graphs_seq_offsets(G, seq_off.data()), "pg_graphs_seq_offsets");
+    std::vector<uint32_t> table(lay.n_counters), path;
+    std::vector<pg_read_support> sup(n);
+    check(ctx, pg_batch_download_counts(ctx, guard.b, nullptr, nullptr, nullptr, 0, &n_path), "pg_batch_download_counts");
+    path.resize(n_path + 1);
+    check(ctx, pg_batch_download_counts(ctx, guard.b, table.data(), sup.data(), path.data(), path.size(), &n_path),
+          "pg_batch_download_counts");
+
+    // ---- fan results back into the reads ---------------------------------------------------------------
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        Read& read = *flat[i];
+        if (read.bases().empty() || sup[i].status == 0)
+            continue;
+        if (sup[i].status == 3)
+            throw std::runtime_error("invalid alignment on the device path for fragment " + read.fragment_id());
+        applyResult(read, res[i], ops.data(), true);
+        read.set_graph_mapping_status(sup[i].status == 1 ? Read::MAPPED : Read::BAD_ALIGN);
+        read.clear_graph_nodes_supported();
+        read.clear_graph_edges_supported();
+        read.clear_graph_sequences_supported();
+        if (sup[i].status != 1)
+            continue;
+        const Graph& g = *impl_->graphs[gor[i]];
+        uint32_t prev = 0;
+        std::vector<std::pair<std::string, std::string>> edges;
+        for (uint32_t k = 0; k < sup[i].n_path; ++k)
+        {
+            const uint32_t en = path[sup[i].path_off + k];
+            const uint32_t nd = PG_PATH_NODE(en);
+            if (PG_PATH_NODE_OK(en))
+                read.add_graph_nodes_supported(g.nodeName(nd));
+            if (k > 0 && PG_PATH_EDGE_OK(en))
+                edges.emplace_back(g.nodeName(prev), g.nodeName(nd));
+            prev = nd;
+        }
+        std::sort(edges.begin(), edges.end());  // the reference collects them in a std::set of name pairs
+        for (auto const& e : edges)
+            read.add_graph_edges_supported(e.first + "_" + e.second);
+        const auto& names = csr.label_names[gor[i]];
+        for (size_t b = 0; b < names.size(); ++b)
+            if ((sup[i].label_mask >> b) & 1)
+                read.add_graph_sequences_supported(names[b]);
+    }
+    // ---- per-site tables --------------------------------------------------------------------------------
+    auto entry = [&](uint64_t off) {
+        CountEntry e;
+        e.count = table[off];
+        e.reads = table[off + 1];
+        e.fwd = table[off + 2];
+        e.rev = table[off + 3];
+        return e;
+    };
+    for (size_t s = 0; s < n_sites; ++s)
+    {
+        const Graph& g = *impl_->graphs[s];
+        SiteCounts& sc = impl_->counts[s];
+        const uint32_t nb = csr.node_off[s];
+        for (NodeId nd = 0; nd != g.numNodes(); ++nd)
+        {
+            CountEntry e = entry(lay.node_base + 4ull * (nb + nd));
+            if (e.count)
+                sc.by_node[g.nodeName(nd)] = e;
+            for (uint32_t q = csr.pred_off[nb + nd]; q < csr.pred_off[nb + nd + 1]; ++q)
+            {
+                CountEntry ee = entry(lay.edge_base + 4ull * q);
+                if (ee.count)
+                    sc.by_edge[g.nodeName(csr.pred[q]) + "_" + g.nodeName(nd)] = ee;
+            }
+        }
+        const auto& names = csr.label_names[s];
+        for (uint64_t m = 1; m < seq_off[s + 1] - seq_off[s]; ++m)
+        {
+            CountEntry e = entry(lay.seq_base + 4ull * (seq_off[s] + m));
+            if (!e.count)
+                continue;
+            std::string key;
+            for (size_t b = 0; b < names.size(); ++b)
+                if ((m >> b) & 1)
+                    key += (key.empty() ? "" : ",") + names[b];  // names are sorted -> sorted join
+            sc.by_sequence[key] = e;
+        }
+        const uint64_t t = lay.tally_base + 4ull * s;
+        sc.aligned = table[t] & 0x7FFFFFFFu;
+        sc.mapped = table[t + 1];
+        sc.bad_align = table[t + 2];
+        sc.nonuniq = table[t + 3];
+        if (table[t] >> 31)
+            throw std::runtime_error("a fragment touched more than 48 distinct nodes/edges (device count-table limit)");
+        // only MAPPED reads survive (Align.cpp:155)
+        std::vector<common::p_Read> kept;
+        for (auto& r : *impl_->reads[s])
+            if (!r->bases().empty() && r->graph_mapping_status() == Read::MAPPED)
+                kept.emplace_back(std::move(r));
+        impl_->reads[s]->swap(kept);
+    }
+}
+}  // namespace paragraph

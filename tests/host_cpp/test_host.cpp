@@ -1,0 +1,242 @@
+// C++ tests of the host-side mirror (grm::alignReads / GraphAligner / CompositeAligner / SiteBatcher) on a real
+// GPU.  The fixtures are the reference's own unit tests, re-typed against the same class and method names:
+//   ParagraphTest.Aligns       src/c++/test/test_paragraph_parts.cpp:46-159
+//   DisambiguationTest         src/c++/test/test_disambiguation.cpp:44-105
+// Exit code 0 = all checks passed.
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <list>
+#include <string>
+#include <vector>
+
+#include "grm/Align.hh"
+#include "grm/CompositeAligner.hh"
+#include "grm/GraphAligner.hh"
+#include "paragraph/SiteBatcher.hh"
+
+using namespace common;
+using namespace grm;
+using namespace graphtools;
+
+static int failures = 0;
+#define EXPECT_EQ(a, b)                                                                                              \
+    do                                                                                                               \
+    {                                                                                                                \
+        auto va = (a);                                                                                               \
+        auto vb = (b);                                                                                               \
+        if (!(va == vb))                                                                                             \
+        {                                                                                                            \
+            std::cerr << __FILE__ << ":" << __LINE__ << ": " #a " != " #b " (" << va << " vs " << vb << ")\n";       \
+            ++failures;                                                                                              \
+        }                                                                                                            \
+    } while (0)
+#define EXPECT_TRUE(a) EXPECT_EQ(bool(a), true)
+
+static std::string join(std::vector<std::string> const& v)
+{
+    std::string s;
+    for (auto const& x : v)
+        s += (s.empty() ? "" : ",") + x;
+    return s;
+}
+
+static Graph alignsGraph()
+{
+    Graph graph{ 4 };
+    graph.setNodeName(0, "LF");
+    graph.setNodeSeq(0, "AAAAAAAAAAA");
+    graph.setNodeName(1, "P1");
+    graph.setNodeSeq(1, "TTTTTTTT");
+    graph.setNodeName(2, "Q1");
+    graph.setNodeSeq(2, "GGGGGGGG");
+    graph.setNodeName(3, "RF");
+    graph.setNodeSeq(3, "AAAAAAAAAAA");
+    graph.addEdge(0, 1);
+    graph.addEdge(0, 2);
+    graph.addEdge(0, 3);
+    graph.addEdge(1, 3);
+    graph.addEdge(2, 3);
+    graph.addLabelToEdge(0, 1, "P");
+    graph.addLabelToEdge(1, 3, "P");
+    graph.addLabelToEdge(0, 2, "Q");
+    graph.addLabelToEdge(2, 3, "Q");
+    graph.addLabelToEdge(0, 3, "D");
+    return graph;
+}
+
+static std::vector<p_Read> alignsReads()
+{
+    const char* raw[6][3] = { { "f1", "AAAAAAAATTTTCTTTAAAAAAAA", "########################" },
+                              { "f2", "TTTTTTAAAGAAAATTTTTTT", "#####################" },
+                              { "f3", "AAAAAGCGGGGGGAAAAAA", "###################" },
+                              { "f4", "AAAAGCGGGGGGAAAAAA", "##################" },
+                              { "f5", "TTTTTTCCCCCCGCTTTTT", "###################" },
+                              { "f6", "AAAAAAAAAAAAAAAAAAA", "###################" } };
+    std::vector<p_Read> reads;
+    for (auto& r : raw)
+        reads.emplace_back(new Read(r[0], r[1], r[2]));
+    return reads;
+}
+
+struct Expect
+{
+    const char* bases;
+    int pos;
+    const char* cigar;
+    int mapq, score;
+    bool reverse;
+    const char *nodes, *edges, *seqs;
+};
+static const Expect kAligns[6] = {
+    { "AAAAAAAATTTTCTTTAAAAAAAA", 3, "0[8M]1[4M1X3M]3[8M]", 60, 19, false, "LF,P1,RF", "LF_P1,P1_RF", "P" },
+    { "AAAAAAATTTTCTTTAAAAAA", 4, "0[7M]1[4M1X3M]3[6M]", 60, 16, true, "LF,P1,RF", "LF_P1,P1_RF", "P" },
+    { "AAAAAGCGGGGGGAAAAAA", 6, "0[5M]2[1M1X6M]3[6M]", 60, 14, false, "LF,Q1,RF", "LF_Q1,Q1_RF", "Q" },
+    { "AAAAGCGGGGGGAAAAAA", 7, "0[4M]2[1M1X6M]3[6M]", 60, 13, false, "LF,Q1,RF", "LF_Q1,Q1_RF", "Q" },
+    { "AAAAAGCGGGGGGAAAAAA", 6, "0[5M]2[1M1X6M]3[6M]", 60, 14, true, "LF,Q1,RF", "LF_Q1,Q1_RF", "Q" },
+    { "AAAAAAAAAAAAAAAAAAA", 0, "0[11M]3[8M]", 60, 19, false, "LF,RF", "LF_RF", "D" },
+};
+
+static void testAlignReads()
+{
+    Graph graph = alignsGraph();
+    auto reads = alignsReads();
+    std::list<Path> paths;
+    grm::alignReads(&graph, paths, reads, nullptr, false, true, false, false, false);
+    EXPECT_EQ(reads.size(), size_t(6));
+    for (size_t i = 0; i < reads.size() && i < 6; ++i)
+    {
+        Read const& r = *reads[i];
+        EXPECT_EQ(r.bases(), std::string(kAligns[i].bases));  // reverse-strand reads come back reverse-complemented
+        EXPECT_EQ(r.graph_pos(), kAligns[i].pos);
+        EXPECT_EQ(r.graph_cigar(), std::string(kAligns[i].cigar));
+        EXPECT_EQ(r.graph_mapq(), kAligns[i].mapq);
+        EXPECT_EQ(r.graph_alignment_score(), kAligns[i].score);
+        EXPECT_TRUE(r.is_graph_alignment_unique());
+        EXPECT_EQ(r.is_graph_reverse_strand(), kAligns[i].reverse);
+        EXPECT_EQ(int(r.graph_mapping_status()), int(Read::MAPPED));
+    }
+}
+
+static void testGraphAlignerAlign()
+{
+    Graph graph = alignsGraph();
+    GraphAligner aligner;
+    aligner.setGraph(&graph);
+    int mapq = -1, pos = -1, score = -1;
+    const std::string cigar = aligner.align("AAAAAAAATTTTCTTTAAAAAAAA", mapq, pos, score);
+    EXPECT_EQ(cigar, std::string("0[8M]1[4M1X3M]3[8M]"));
+    EXPECT_EQ(mapq, 60);
+    EXPECT_EQ(pos, 3);
+    EXPECT_EQ(score, 19);
+}
+
+static void testCompositeAlignerFilter()
+{
+    Graph graph = alignsGraph();
+    CompositeAligner aligner(false, true, false, false);
+    std::list<Path> paths;
+    aligner.setGraph(&graph, paths);
+    Read read("f", "AAAAAAAATTTTCTTTAAAAAAAA", "########################");
+    aligner.alignRead(read, [](Read& r) { return r.graph_alignment_score() > 10; });
+    EXPECT_EQ(int(read.graph_mapping_status()), int(Read::BAD_ALIGN));
+    EXPECT_EQ(aligner.attempted(), 1u);
+    EXPECT_EQ(aligner.filtered(), 1u);
+    EXPECT_EQ(aligner.mappedSw(), 0u);
+    bool threw = false;
+    try
+    {
+        CompositeAligner bad(true, true, false, false);
+    }
+    catch (std::logic_error const&)
+    {
+        threw = true;
+    }
+    EXPECT_TRUE(threw);
+}
+
+static void testSiteBatcher()
+{
+    // site 0: ParagraphTest graph; site 1: DisambiguationTest graph
+    Graph g0 = alignsGraph();
+    auto r0 = alignsReads();
+    Graph g1(5);
+    const char* names[5] = { "LF", "R1", "R2", "A1", "RF" };
+    const char* seqs[5] = { "AAAAAAAAAA", "TTTTTTTTTT", "TTTTTTTTTT", "GGGGGGGGGG", "AAAAAAAAAA" };
+    for (NodeId n = 0; n < 5; ++n)
+    {
+        g1.setNodeName(n, names[n]);
+        g1.setNodeSeq(n, seqs[n]);
+    }
+    g1.addEdge(0, 1);
+    g1.addEdge(0, 4);
+    g1.addEdge(1, 2);
+    g1.addEdge(1, 3);
+    g1.addEdge(2, 4);
+    g1.addEdge(3, 4);
+    g1.addLabelToEdge(0, 1, "R");
+    g1.addLabelToEdge(1, 2, "R");
+    g1.addLabelToEdge(2, 4, "R");
+    g1.addLabelToEdge(0, 4, "D");
+    std::vector<p_Read> r1;
+    r1.emplace_back(new Read("f0", "AAAAAAAAAATTTTTTTTTTTTTTTTTTTTAAAAAAAAAA", "AAAAAAAAAATTTTTTTTTTTTTTTTTTTTAAAAAAAAAA"));
+    r1.emplace_back(new Read("f1", "AAAAAAAAAATTTTTTTTTTT", "AAAAAAAAAATTTTTTTTTTT"));
+    r1.emplace_back(new Read("f2", "AAAAAAAAAATTTTTTTTTTGGGGGGGGGGAAAAAAAAAA", "AAAAAAAAAATTTTTTTTTTGGGGGGGGGGAAAAAAAAAA"));
+    r1.emplace_back(new Read("f3", "AAAAAAAAAAAAAAAAAAAA", "AAAAAAAAAAAAAAAAAAAA"));
+
+    paragraph::SiteBatcher batcher;
+    batcher.addSite(&g0, &r0);
+    batcher.addSite(&g1, &r1);
+    paragraph::BatchParameters prm;
+    prm.remove_nonuniq_reads = false;
+    prm.use_support_filters = false;  // what the reference's unit tests call disambiguateReads with
+    batcher.run(prm);
+    EXPECT_EQ(r0.size(), size_t(6));
+    for (size_t i = 0; i < r0.size() && i < 6; ++i)
+    {
+        EXPECT_EQ(r0[i]->graph_cigar(), std::string(kAligns[i].cigar));
+        EXPECT_EQ(join(r0[i]->graph_nodes_supported()), std::string(kAligns[i].nodes));
+        EXPECT_EQ(join(r0[i]->graph_edges_supported()), std::string(kAligns[i].edges));
+        EXPECT_EQ(join(r0[i]->graph_sequences_supported()), std::string(kAligns[i].seqs));
+    }
+    EXPECT_EQ(r1.size(), size_t(4));
+    const char* want1[4] = { "R", "R", "", "D" };  // test_disambiguation.cpp:97-105
+    for (size_t i = 0; i < r1.size() && i < 4; ++i)
+        EXPECT_EQ(join(r1[i]->graph_sequences_supported()), std::string(want1[i]));
+    auto const& c0 = batcher.counts(0);
+    EXPECT_EQ(c0.by_sequence.at("P").count, uint64_t(2));
+    EXPECT_EQ(c0.by_sequence.at("Q").count, uint64_t(3));
+    EXPECT_EQ(c0.by_sequence.at("D").count, uint64_t(1));
+    EXPECT_EQ(c0.by_node.at("LF").count, uint64_t(6));
+    EXPECT_EQ(c0.by_node.at("LF").reads, uint64_t(6));
+    EXPECT_EQ(c0.by_node.at("LF").fwd, uint64_t(4));
+    EXPECT_EQ(c0.by_node.at("LF").rev, uint64_t(2));
+    EXPECT_EQ(c0.by_edge.at("LF_RF").count, uint64_t(1));
+    EXPECT_EQ(c0.mapped, uint64_t(6));
+    auto const& c1 = batcher.counts(1);
+    EXPECT_EQ(c1.by_sequence.at("R").count, uint64_t(2));
+    EXPECT_EQ(c1.by_edge.at("LF_RF").count, uint64_t(1));
+}
+
+int main()
+{
+    try
+    {
+        testAlignReads();
+        testGraphAlignerAlign();
+        testCompositeAlignerFilter();
+        testSiteBatcher();
+    }
+    catch (std::exception const& e)
+    {
+        std::cerr << "exception: " << e.what() << "\n";
+        return 2;
+    }
+    if (failures)
+    {
+        std::cerr << failures << " check(s) failed\n";
+        return 1;
+    }
+    std::cout << "host_cpp: all checks passed\n";
+    return 0;
+}

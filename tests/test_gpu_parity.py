@@ -126,3 +126,16 @@ def test_golden_fixtures(gpu_ctx):
             assert g["strand_score"][0] == w["scores"][0] and g["strand_score"][1] == w["scores"][1]
         n += len(reads)
     assert n > 900
+
+
+def test_host_cpp_mirror():
+    """The reference-shaped C++ host classes (grm::alignReads, GraphAligner, CompositeAligner, SiteBatcher) on
+    the reference's own unit-test fixtures: tests/host_cpp/test_host.cpp."""
+    import os
+    import subprocess
+    from paragraph_amd import build
+    exe = build.HOST_TEST
+    if not os.path.exists(exe):
+        build.build_host()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr

@@ -204,7 +204,10 @@ def main():
         if os.path.exists(args.traffic_json):
             try:
                 with open(args.traffic_json) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
+                    per_read = json.load(f).get("hbm_bytes_per_read")
+                # PMC bytes (rocprofv3 FETCH_SIZE x measured 2.0 + WRITE_SIZE, separate passes, profiles/pmc_r01)
+                # per read x the reads one launch of THIS run processes
+                traffic = per_read * reads_per_fill_leg / max(1, tim["fill_launches"])
             except Exception:
                 traffic = None
         out = {

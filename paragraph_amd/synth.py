@@ -215,3 +215,126 @@ def config2_reads(n, read_len=150, seed=2):
 def config2_reads_packed(n, read_len=150, seed=2):
     site = config2_site()
     return site, simulate_reads_packed(site, n, read_len, seed)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2] / [3]: many mixed DEL/INS sites, 30x paired reads
+# ---------------------------------------------------------------------------------------------------
+def _log_uniform(rng, lo, hi):
+    return int(round(float(np.exp(np.log(lo) + rng.uniform() * (np.log(hi) - np.log(lo))))))
+
+
+class SiteReads:
+    """Reads of one site: packed (n, L) uint8 array, fragment ids (mates share one), BAM-strand flags."""
+
+    def __init__(self, site, reads, fragment, is_reverse, genotype):
+        self.site = site
+        self.reads = reads
+        self.fragment = fragment
+        self.is_reverse = is_reverse
+        self.genotype = genotype
+
+
+def _paired_reads(rng, hap, keep_lo, keep_hi, depth, read_len, sub_rate, frag0):
+    """Paired reads at `depth` over haplotype `hap` (uint8 array); a fragment is kept when at least one mate
+    overlaps [keep_lo, keep_hi) (the target region on this haplotype); mate 1 forward, mate 2 reverse."""
+    n_frag = int(depth * len(hap) / (2.0 * read_len))
+    if n_frag <= 0 or len(hap) < read_len + 2:
+        return np.zeros((0, read_len), np.uint8), np.zeros(0, np.uint32), np.zeros(0, np.uint8)
+    u = rng.uniform_vector(2 * n_frag)
+    # insert ~ N(400, 50) via the sum of 12 uniforms, clipped to [read_len, len(hap)]
+    z = (rng.uniform_vector(12 * n_frag).reshape(n_frag, 12).sum(axis=1) - 6.0)
+    ins = np.clip((400 + 50 * z).astype(np.int64), read_len, len(hap))
+    st = np.floor(u[:n_frag] * (len(hap) - ins + 1)).astype(np.int64)
+    cols = np.arange(read_len)
+    m1 = hap[st[:, None] + cols[None, :]]
+    s2 = st + ins - read_len
+    m2 = _COMP[hap[s2[:, None] + cols[None, :]]][:, ::-1]
+    ov1 = (st < keep_hi) & (st + read_len > keep_lo)
+    ov2 = (s2 < keep_hi) & (s2 + read_len > keep_lo)
+    keep = ov1 | ov2
+    swap = u[n_frag:] < 0.5  # which mate is "first"/forward in the BAM is arbitrary: flip half of the pairs
+    reads = np.empty((2 * n_frag, read_len), np.uint8)
+    reads[0::2] = np.where(swap[:, None], m2, m1)
+    reads[1::2] = np.where(swap[:, None], m1, m2)
+    rev = np.zeros(2 * n_frag, np.uint8)
+    rev[0::2] = swap
+    rev[1::2] = ~swap
+    # the aligner receives reads as stored in the BAM: reverse-strand reads are stored reverse-complemented,
+    # i.e. in reference orientation
+    flip = rev.astype(bool)
+    reads[flip] = _COMP[reads[flip]][:, ::-1]
+    frag = np.repeat(np.arange(n_frag, dtype=np.uint32) + frag0, 2)
+    keep2 = np.repeat(keep, 2)
+    reads, frag, rev = reads[keep2], frag[keep2], rev[keep2]
+    code = np.zeros(256, dtype=np.int64)
+    for k, c in enumerate(b"ACGT"):
+        code[c] = k
+    su = rng.uniform_vector(reads.size).reshape(reads.shape)
+    sb = (rng.vector(reads.size) % np.uint64(3)).astype(np.int64).reshape(reads.shape)
+    reads = np.where(su < sub_rate, _ACGT[(code[reads] + 1 + sb) & 3], reads)
+    return reads, frag, rev
+
+
+def mixed_sites(n_sites, seed=3, contig_len=None, read_len=150, depth=30.0, flank=150, sub_rate=0.01, margin=450):
+    """n_sites DEL/INS sites on one synthetic contig with 30x paired reads from a diploid genotype
+    (0/0 : 0/1 : 1/1 = 1 : 2 : 1).  DEL length log-uniform 50..10000 (> 2*flank -> long-deletion template),
+    INS length log-uniform 50..1000.  Returns list[SiteReads]."""
+    rng = SplitMix64(seed)
+    spacing = 14000
+    contig_len = contig_len or (n_sites * spacing + 20000)
+    contig = np.frombuffer(random_contig(seed * 7919 + 1, contig_len), dtype=np.uint8)
+    cb = contig.tobytes()
+    out = []
+    for s in range(n_sites):
+        center = 10000 + s * spacing
+        is_del = rng.uniform() < 0.5
+        gt = [0, 1, 1, 2][rng.below(4)]  # number of ALT alleles
+        if is_del:
+            dl = _log_uniform(rng, 50, 10000)
+            start, end = center, center + dl - 1
+            site = longdel_site(cb, start, end, flank) if dl > 2 * flank else del_site(cb, start, end, flank)
+            lo, hi = start - flank - 1 - margin, end + flank + 1 + margin
+            ref_hap = contig[lo:hi]
+            alt_hap = np.concatenate([contig[lo:start - 1], contig[end:hi]])
+            # target regions on each haplotype (graph span)
+            if dl > 2 * flank:
+                ref_keep = [(margin, margin + 2 * flank + 2), (len(ref_hap) - margin - 2 * flank - 2, len(ref_hap) - margin)]
+            else:
+                ref_keep = [(margin, len(ref_hap) - margin)]
+            alt_keep = [(margin, len(alt_hap) - margin)]
+        else:
+            il = _log_uniform(rng, 50, 1000)
+            ins = _ACGT[(rng.vector(il) & np.uint64(3)).astype(np.int64)]
+            start = center
+            site = ins_site(cb, start, ins.tobytes(), flank)
+            lo, hi = start - flank - 1 - margin, start + flank + 1 + margin
+            ref_hap = contig[lo:hi]
+            alt_hap = np.concatenate([contig[lo:start], ins, contig[start:hi]])
+            ref_keep = [(margin, len(ref_hap) - margin)]
+            alt_keep = [(margin, len(alt_hap) - margin)]
+        parts = []
+        frag0 = 0
+        for hap, keeps, copies in ((ref_hap, ref_keep, 2 - gt), (alt_hap, alt_keep, gt)):
+            if copies == 0:
+                continue
+            for (klo, khi) in keeps:
+                r, f, v = _paired_reads(rng, hap, klo, khi, depth * copies / 2.0, read_len, sub_rate, frag0)
+                frag0 += len(r) // 2 + 1 + int(depth * len(hap) / (2.0 * read_len))
+                parts.append((r, f, v))
+        reads = np.concatenate([p[0] for p in parts]) if parts else np.zeros((0, read_len), np.uint8)
+        frag = np.concatenate([p[1] for p in parts]) if parts else np.zeros(0, np.uint32)
+        rev = np.concatenate([p[2] for p in parts]) if parts else np.zeros(0, np.uint8)
+        out.append(SiteReads(site, reads, frag, rev, gt))
+    return out
+
+
+def long_node_site(seed, alt_len, flank=300, ref_mid=60):
+    """BASELINE configs[4]-style graph: LF -> {REF (short), ALT (inline, 2-8 kb)} -> RF."""
+    rng = SplitMix64(seed)
+    def rnd(n):
+        return _ACGT[(rng.vector(n) & np.uint64(3)).astype(np.int64)].tobytes()
+    return Site("longalt", ["LF", "REF", "ALT", "RF"], [rnd(flank), rnd(ref_mid), rnd(alt_len), rnd(flank)],
+                [(0, 1), (0, 2), (1, 3), (2, 3)],
+                {(0, 1): ["REF"], (1, 3): ["REF"], (0, 2): ["ALT"], (2, 3): ["ALT"]},
+                {"REF": [0, 1, 3], "ALT": [0, 2, 3]})

@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=1000000, help="reads per GPU per step (config 2: 1M)")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3"],
+                    help="config2 = BASELINE configs[1] (headline); config3 = configs[2]: mixed DEL/INS sites, 30x")
+    ap.add_argument("--sites", type=int, default=2000, help="sites per GPU for --workload config3")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--workspace-gib", type=float, default=16.0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline leg")
@@ -120,18 +123,37 @@ def main():
 
     # ---- workload: config 2, a different read seed per rank (weak scaling) -------------------------
     log("generating reads")
-    site, arr = synth.config2_reads_packed(args.reads, read_len=args.read_len, seed=2 + rank)
-    log("reads generated")
-    G = site.total_len
     L = args.read_len
     ctx = capi.Context(local_rank, workspace_bytes=int(args.workspace_gib * (1 << 30)))
-    graphs = ctx.upload_graphs([(site.seqs, site.edges)])
-    graphs.set_labels([site.labels])
-    batch = ctx.new_batch()
-    t0 = time.perf_counter()
-    batch.upload(graphs, synth.packed_to_capi(arr))
-    # mates: reads 2k and 2k+1 form fragment k (counts are per fragment, ReadCounting.cpp:52-94)
-    batch.set_fragments(np.arange(args.reads, dtype=np.uint32) // 2)
+    if args.workload == "config2":
+        site, arr = synth.config2_reads_packed(args.reads, read_len=args.read_len, seed=2 + rank)
+        log("reads generated")
+        G = site.total_len
+        n_sites = 1
+        b_alg_total = args.reads * (6 * L * G + L + 64)
+        graphs = ctx.upload_graphs([(site.seqs, site.edges)])
+        graphs.set_labels([site.labels])
+        batch = ctx.new_batch()
+        t0 = time.perf_counter()
+        batch.upload(graphs, synth.packed_to_capi(arr))
+        # mates: reads 2k and 2k+1 form fragment k (counts are per fragment, ReadCounting.cpp:52-94)
+        batch.set_fragments(np.arange(args.reads, dtype=np.uint32) // 2)
+    else:
+        sites = synth.mixed_sites(args.sites, seed=3 + rank, read_len=L)
+        log("sites generated")
+        site = sites[0].site
+        arr = np.concatenate([s.reads for s in sites])
+        args.reads = len(arr)
+        n_sites = len(sites)
+        G = float(np.mean([s.site.total_len for s in sites]))
+        b_alg_total = int(sum(len(s.reads) * (6 * L * s.site.total_len + L + 64) for s in sites))
+        graphs = ctx.upload_graphs([(s.site.seqs, s.site.edges) for s in sites])
+        graphs.set_labels([s.site.labels for s in sites])
+        batch = ctx.new_batch()
+        t0 = time.perf_counter()
+        gor = np.concatenate([np.full(len(s.reads), i, dtype=np.uint32) for i, s in enumerate(sites)])
+        batch.upload(graphs, synth.packed_to_capi(arr), gor)
+        batch.set_fragments(np.concatenate([s.fragment for s in sites]), np.concatenate([s.is_reverse for s in sites]))
     ctx.sync()
     t_upload = time.perf_counter() - t0
     log("uploaded in %.2fs" % t_upload)
@@ -196,7 +218,7 @@ def main():
     if rank == 0:
         reads_total = args.reads * world * args.steps
         value = reads_total / elapsed
-        b_alg = 6 * L * G + L + 64
+        b_alg = b_alg_total / args.reads  # 6*L*G + L + 64 per read
         fill_s = tim["fill_ms"] / 1e3
         reads_per_fill_leg = args.reads * args.steps  # this rank's fill launches
         achieved_gbs = reads_per_fill_leg * b_alg / fill_s / 1e9 if fill_s > 0 else 0.0
@@ -224,9 +246,12 @@ def main():
             "dtype": "u16x2 packed (8-bit scores)",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: 1 DEL graph (200bp flanks, nodes 201/100/201), %d synthetic %dbp reads per GPU, "
-                            "GraphAligner::alignRead(AF_ALL) = 4 fills + strand pick + traceback per read"
-                            % (args.reads, L),
+                "workload": ("configs[1]: 1 DEL graph (200bp flanks, nodes 201/100/201), %d synthetic %dbp reads per GPU, "
+                             "GraphAligner::alignRead(AF_ALL) = 4 fills + strand pick + traceback per read, then "
+                             "filters + node/edge/sequence counts" % (args.reads, L)) if args.workload == "config2" else
+                            ("configs[2]: %d mixed DEL/longDEL/INS sites per GPU, 30x paired %dbp reads (%d reads), align + "
+                             "count" % (n_sites, L, args.reads)),
+                "sites_per_gpu": n_sites, "sites_per_s": n_sites * world * args.steps / elapsed,
                 "reads_per_gpu": args.reads, "read_len": L, "graph_len": G, "parallelism": "reads x%d" % world,
             },
             "roofline": {
@@ -246,13 +271,13 @@ def main():
                 "reads_per_s": args.reads / (t_upload + elapsed / args.steps + t_download),
             },
         }
-        if site_counts is not None:
+        if site_counts is not None and args.workload == "config2":
             out["counts"] = {"edges": {"%s_%s" % (site.names[a], site.names[b]): c[0]
                                        for (a, b), c in site_counts["edge_counts"].items()},
                              "sequences": {k: v[0] for k, v in site_counts["seq_counts"].items()},
                              "tallies": site_counts["tallies"],
                              "note": "fragment counts of the last step, summed over %d rank(s)" % world}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "config2":
             out["cpu_baseline"] = cpu_baseline(site, arr, args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:

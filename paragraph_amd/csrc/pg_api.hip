@@ -313,7 +313,7 @@ extern "C" pg_status pg_graphs_upload(
                 }
                 col += len;
             }
-            for (int c = 0; c < PG_GROUP_LANES; ++c)
+            for (int c = 0; c < PG_META_PAD; ++c)
                 colmeta.push_back(PG_META_IDLE);
         }
     }
@@ -639,7 +639,6 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         PgFillArgs fa{};
         fa.items = b->d_items;
         fa.item_begin = 2 * ch.pair_begin;
-        fa.item_stride = revg ? 1 : 2;
         fa.graphs = G->d_graphs;
         fa.nodes = G->d_nodes;
         fa.preds = G->d_preds;
@@ -656,7 +655,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             ev.kind = 0;
             HIP_TRY(ctx, hipEventRecord(ev.a, ctx->stream));
         }
-        HIP_TRY(ctx, pg_launch_fill(ch.C, fa, revg ? 2 * n_pairs : n_pairs, ch.max_nodes, ctx->stream));
+        HIP_TRY(ctx, pg_launch_fill(ch.C, fa, n_pairs, revg, ch.max_nodes, ctx->stream));
         if (ctx->timing)
         {
             HIP_TRY(ctx, hipEventRecord(ev.b, ctx->stream));

@@ -23,6 +23,7 @@
 #define PG_META_SAVE 32u
 #define PG_META_NODE(m) ((m) >> 8)
 #define PG_META_IDLE 4u  // code 4 (scores 0 against everything), no flags
+#define PG_META_PAD 160   // idle words appended to every direction's column array (64-wide block prefetch)
 
 #define PG_GAP_OPEN 6
 #define PG_GAP_EXT 1
@@ -30,7 +31,7 @@
 
 struct PgGraphDir
 {
-    uint32_t meta_off;  // into colmeta[]; ncols + PG_GROUP_LANES entries (tail = PG_META_IDLE)
+    uint32_t meta_off;  // into colmeta[]; ncols + PG_META_PAD entries (tail = PG_META_IDLE)
     uint32_t ncols;     // total node length
     uint32_t node_off;  // into nodes[]
     uint32_t n_nodes;

@@ -113,23 +113,22 @@ __device__ __forceinline__ int sub_score(uint32_t a, uint32_t b)
     return (a == 4u || b == 4u) ? 0 : (a == b ? 1 : -4);
 }
 
-template <int C>
-__global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
+template <int C, int DIR>
+__device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair, uint32_t* lds)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr int ROWS = PG_GROUP_LANES * C;
-    uint32_t* prof = lds;                          // [4 reads][5 codes][ROWS] packed (strand A | strand B << 16)
+    uint32_t* prof = lds;                            // [4 reads][5 codes][ROWS] packed (strand A | strand B << 16)
     uint32_t* nodekey = lds + PG_GROUPS * 5 * ROWS;  // [n_nodes][4 reads][2 strands]
 
     const int lane = threadIdx.x;
     const int grp = lane >> 4;
     const int k = lane & 15;
 
-    const uint32_t item_idx = a.item_begin + blockIdx.x * a.item_stride;
+    // items come in (forward graph, reversed graph) pairs: this instantiation takes the DIR member
+    const uint32_t item_idx = a.item_begin + 2 * pair + DIR;
     const PgWorkItem* itp = a.items + item_idx;
     const uint32_t graph = itp->graph;
-    const uint32_t dir = itp->dir;
-    const PgGraphDir gd = a.graphs[graph].dir[dir];
+    const PgGraphDir gd = a.graphs[graph].dir[DIR];
     const uint32_t* __restrict__ smeta = a.colmeta + gd.meta_off;
     const PgNode* __restrict__ nodes = a.nodes + gd.node_off;
     const uint32_t n_nodes = gd.n_nodes;
@@ -149,11 +148,11 @@ __global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
             {
                 const uint32_t f = (uint8_t)a.bases[off + row];
                 const uint32_t r = (uint8_t)a.bases[off + L - 1 - row];
-                // dir 0: strand A = toUpper(bases), strand B = reverseComplement(bases)
-                // dir 1: strand A = toUpper(reverse(bases)), strand B = reverseComplement(reverse(bases))
+                // DIR 0: strand A = toUpper(bases), strand B = reverseComplement(bases)
+                // DIR 1: strand A = toUpper(reverse(bases)), strand B = reverseComplement(reverse(bases))
                 //        (GraphAligner.cpp:315-337)
-                const uint32_t chA = dir == 0 ? upper_c(f) : upper_c(r);
-                const uint32_t chB = dir == 0 ? comp_c(r) : comp_c(f);
+                const uint32_t chA = DIR == 0 ? upper_c(f) : upper_c(r);
+                const uint32_t chB = DIR == 0 ? comp_c(r) : comp_c(f);
                 cA = nt_code(chA);
                 cB = nt_code(chB);
             }
@@ -170,9 +169,8 @@ __global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
         nodekey[e] = 0;
     __syncthreads();
 
-    uint32_t* __restrict__ seed = (uint32_t*)(a.workspace + itp->seed_off);  // [node][lane][C]
+    uint32_t* __restrict__ seed = (uint32_t*)(a.workspace + itp->seed_off);    // [node][lane][C]
     uint32_t* __restrict__ trace = (uint32_t*)(a.workspace + itp->trace_off);  // [step][lane][C/2]
-    const bool store_trace = dir == 0;
 
     uint32_t Hp[C], E[C];
 #pragma unroll
@@ -183,7 +181,6 @@ __global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
     }
     uint32_t Hsend = 0, Fsend = 0;
     uint32_t M = 0, FC = 0;
-    uint32_t meta = PG_META_IDLE;
     // packed (col | col << 16) of the column this lane works on; col = t - k (wraps for idle lanes)
     uint32_t colv = (uint32_t)(0x10000 - k) & 0xFFFFu;
     colv |= colv << 16;
@@ -192,18 +189,56 @@ __global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
     const uint32_t nsteps = gd.ncols + PG_GROUP_LANES - 1;
     const uint32_t* profl = prof + grp * 5 * ROWS + k * C;
 
+    // Column meta words: one coalesced vector load per 64 steps (lane l holds the word of step t0 + l),
+    // handed out with v_readlane -- no memory latency inside the step loop.  The array is padded with
+    // PG_META_PAD idle words on the host.
+    uint32_t mblock = smeta[lane];
+    uint32_t mblock_next = smeta[64 + lane];
+    // software pipeline: `meta` / `s[]` always belong to the step about to be computed
+    uint32_t meta = row_shr1_keep((uint32_t)__builtin_amdgcn_readlane((int)mblock, 0), PG_META_IDLE);
+    uint32_t s[C];
+    {
+        const uint32_t* pr = profl + PG_META_CODE(meta) * ROWS;
+#pragma unroll
+        for (int r = 0; r < C; r += 2)
+        {
+            const uint2 v = *(const uint2*)(pr + r);
+            s[r] = v.x;
+            s[r + 1] = v.y;
+        }
+    }
+
     for (uint32_t t = 0; t < nsteps; ++t)
     {
-        const uint32_t m0 = smeta[t];
-        meta = row_shr1_keep(m0, meta);
+        const uint32_t meta_cur = meta;
         const uint32_t dH = row_shr1_zero(Hsend);
         uint32_t F = row_shr1_zero(Fsend);
 
-        if (meta & PG_META_FIRST)
+        // ---- prefetch the next step's meta word and profile rows -----------------------------------
+        const uint32_t tn = t + 1;
+        if ((tn & 63u) == 0)
+        {
+            mblock = mblock_next;
+            mblock_next = smeta[tn + 64 + lane];
+        }
+        meta = row_shr1_keep((uint32_t)__builtin_amdgcn_readlane((int)mblock, (int)(tn & 63u)), meta_cur);
+        uint32_t sn[C];
+        {
+            const uint32_t* pr = profl + PG_META_CODE(meta) * ROWS;
+#pragma unroll
+            for (int r = 0; r < C; r += 2)
+            {
+                const uint2 v = *(const uint2*)(pr + r);
+                sn[r] = v.x;
+                sn[r + 1] = v.y;
+            }
+        }
+
+        if (meta_cur & PG_META_FIRST)
         {
             // seed = lane-wise max over predecessors (gssw_create_seed_byte); the predecessor that
             // directly precedes this node in the layout is still in Hp/E.
-            const uint32_t node = PG_META_NODE(meta);
+            const uint32_t node = PG_META_NODE(meta_cur);
             const PgNode nd = nodes[node];
             uint32_t sh[C], se[C];
 #pragma unroll
@@ -241,17 +276,8 @@ __global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
         }
 
         // ---- one column of the affine-gap recurrence for C rows x 2 strands ------------------------
-        const uint32_t* pr = profl + PG_META_CODE(meta) * ROWS;
-        uint32_t s[C];
-#pragma unroll
-        for (int r = 0; r < C; r += 2)
-        {
-            const uint2 v = *(const uint2*)(pr + r);
-            s[r] = v.x;
-            s[r + 1] = v.y;
-        }
         uint32_t diag = dH;
-        uint32_t colmax = 0;
+        uint32_t hs[C];
 #pragma unroll
         for (int r = 0; r < C; ++r)
         {
@@ -260,24 +286,33 @@ __global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
             h = pk_maxu(h, F);
             diag = Hp[r];
             Hp[r] = h;
+            hs[r] = h;
             const uint32_t tt = pk_subsat(h, GO2);
             E[r] = pk_maxu(pk_subsat(E[r], GE2), tt);
             F = pk_maxu(pk_subsat(F, GE2), tt);
-            colmax = pk_maxu(colmax, h);
         }
         Hsend = diag;
         Fsend = F;
 
         // ---- running node maximum + first column reaching it (gssw.c:369-386) -----------------------
         {
-            const uint32_t Mn = pk_maxu(M, colmax);
-            uint32_t inc = pk_minu(pk_sub(Mn, M), 0x00010001u);  // 1 where the half grew
-            inc = pk_sub(0u, inc);                               // 0xFFFF where it grew
-            FC = (FC & ~inc) | (colv & inc);
+            // tree reduction (a chain would serialise 2C dependent packed ops)
+#pragma unroll
+            for (int w = 1; w < C; w *= 2)
+#pragma unroll
+                for (int r = 0; r + w < C; r += 2 * w)
+                    hs[r] = pk_maxu(hs[r], hs[r + w]);
+            const uint32_t Mn = pk_maxu(M, hs[0]);
+            if (DIR == 0)
+            {
+                uint32_t inc = pk_minu(pk_sub(Mn, M), 0x00010001u);  // 1 where the half grew
+                inc = pk_sub(0u, inc);                               // 0xFFFF where it grew
+                FC = (FC & ~inc) | (colv & inc);
+            }
             M = Mn;
         }
 
-        if (store_trace)
+        if (DIR == 0)
         {
             uint32_t* tp = trace + ((size_t)t * 64 + lane) * (C / 2);
 #pragma unroll
@@ -285,10 +320,10 @@ __global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
                 tp[r / 2] = Hp[r] | (Hp[r + 1] << 8);  // bytes A_r, A_r+1, B_r, B_r+1
         }
 
-        if (meta & PG_META_LAST)
+        if (meta_cur & PG_META_LAST)
         {
-            const uint32_t node = PG_META_NODE(meta);
-            if (meta & PG_META_SAVE)
+            const uint32_t node = PG_META_NODE(meta_cur);
+            if (meta_cur & PG_META_SAVE)
             {
                 uint32_t* sp = seed + ((size_t)node * 64 + lane) * C;
 #pragma unroll
@@ -305,6 +340,9 @@ __global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
                 atomicMax(&nodekey[node * 8 + grp * 2 + 1], (mB << 24) | ((0xFFFFFu - cB) << 4) | kinv);
         }
         colv = pk_add(colv, 0x00010001u);
+#pragma unroll
+        for (int r = 0; r < C; ++r)
+            s[r] = sn[r];
     }
 
     __threadfence_block();
@@ -338,7 +376,7 @@ __global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
         fs.end_col = -1;
         fs.multi = cnt > 1 ? 1 : 0;
         fs.pad[0] = fs.pad[1] = 0;
-        if (best > 0 && store_trace)
+        if (best > 0 && DIR == 0)
         {
             const uint32_t col = 0xFFFFFu - ((bestkey >> 4) & 0xFFFFFu);
             const uint32_t kk = 15u - (bestkey & 15u);
@@ -370,38 +408,59 @@ __global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
     }
 }
 
-#define PG_INST(CC) template __global__ void pg_fill_kernel<CC>(PgFillArgs);
-PG_INST(2) PG_INST(4) PG_INST(6) PG_INST(8) PG_INST(10) PG_INST(12) PG_INST(14) PG_INST(16)
+// One launch covers both graph directions: even workgroups run the forward-graph body (stores the H trace),
+// odd ones the reversed-graph body (scores + multi flags only).  With AF_REVERSE_GRAPH off (both_dirs == 0)
+// every workgroup is a forward-graph one.
+template <int C>
+__global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if (a.both_dirs)
+    {
+        if (blockIdx.x & 1u)
+            pg_fill_body<C, 1>(a, blockIdx.x >> 1, lds);
+        else
+            pg_fill_body<C, 0>(a, blockIdx.x >> 1, lds);
+    }
+    else
+        pg_fill_body<C, 0>(a, blockIdx.x, lds);
+}
 
 size_t pg_fill_lds_bytes(int C, uint32_t max_nodes)
 {
     return (size_t)(PG_GROUPS * 5 * PG_GROUP_LANES * C + max_nodes * 8) * sizeof(uint32_t);
 }
 
-hipError_t pg_launch_fill(int C, const PgFillArgs& args, uint32_t n_items, uint32_t max_nodes, hipStream_t stream)
+template <int C> static hipError_t launch_c(PgFillArgs args, uint32_t n_pairs, bool revg, size_t lds, hipStream_t stream)
 {
-    if (n_items == 0)
-        return hipSuccess;
-    const size_t lds = pg_fill_lds_bytes(C, max_nodes);
-    void (*fn)(PgFillArgs) = nullptr;
-    switch (C)
-    {
-    case 2: fn = pg_fill_kernel<2>; break;
-    case 4: fn = pg_fill_kernel<4>; break;
-    case 6: fn = pg_fill_kernel<6>; break;
-    case 8: fn = pg_fill_kernel<8>; break;
-    case 10: fn = pg_fill_kernel<10>; break;
-    case 12: fn = pg_fill_kernel<12>; break;
-    case 14: fn = pg_fill_kernel<14>; break;
-    case 16: fn = pg_fill_kernel<16>; break;
-    default: return hipErrorInvalidValue;
-    }
+    void (*fn)(PgFillArgs) = pg_fill_kernel<C>;
     if (lds > 48 * 1024)
     {
         hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
     }
-    hipLaunchKernelGGL(fn, dim3(n_items), dim3(64), lds, stream, args);
+    args.both_dirs = revg ? 1u : 0u;
+    hipLaunchKernelGGL(fn, dim3(revg ? 2 * n_pairs : n_pairs), dim3(64), lds, stream, args);
     return hipGetLastError();
+}
+
+// Launches the forward-graph fills of n_pairs item pairs and (revg) their reversed-graph fills.
+hipError_t pg_launch_fill(int C, const PgFillArgs& args, uint32_t n_pairs, bool revg, uint32_t max_nodes, hipStream_t stream)
+{
+    if (n_pairs == 0)
+        return hipSuccess;
+    const size_t lds = pg_fill_lds_bytes(C, max_nodes);
+    switch (C)
+    {
+    case 2: return launch_c<2>(args, n_pairs, revg, lds, stream);
+    case 4: return launch_c<4>(args, n_pairs, revg, lds, stream);
+    case 6: return launch_c<6>(args, n_pairs, revg, lds, stream);
+    case 8: return launch_c<8>(args, n_pairs, revg, lds, stream);
+    case 10: return launch_c<10>(args, n_pairs, revg, lds, stream);
+    case 12: return launch_c<12>(args, n_pairs, revg, lds, stream);
+    case 14: return launch_c<14>(args, n_pairs, revg, lds, stream);
+    case 16: return launch_c<16>(args, n_pairs, revg, lds, stream);
+    default: return hipErrorInvalidValue;
+    }
 }

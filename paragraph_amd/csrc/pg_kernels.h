@@ -10,7 +10,7 @@ struct PgFillArgs
 {
     const PgWorkItem* items;
     uint32_t item_begin;
-    uint32_t item_stride;  // 1: every item; 2: forward-graph items only (AF_REVERSE_GRAPH off)
+    uint32_t both_dirs;  // 1: even workgroups = forward graph, odd = reversed graph; 0: forward graph only
     const PgGraphDev* graphs;
     const PgNode* nodes;
     const uint32_t* preds;
@@ -43,5 +43,5 @@ struct PgTraceArgs
 };
 
 size_t pg_fill_lds_bytes(int C, uint32_t max_nodes);
-hipError_t pg_launch_fill(int C, const PgFillArgs& args, uint32_t n_items, uint32_t max_nodes, hipStream_t stream);
+hipError_t pg_launch_fill(int C, const PgFillArgs& args, uint32_t n_pairs, bool revg, uint32_t max_nodes, hipStream_t stream);
 hipError_t pg_launch_trace(const PgTraceArgs& args, hipStream_t stream);

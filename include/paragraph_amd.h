@@ -22,9 +22,11 @@
  *   pg_align_batch       one-shot convenience = upload + align + download
  *   pg_render_cigar      GraphAlignerImpl::extractCigar         GraphAligner.cpp:88-108
  *   pg_graphs_set_labels graphtools::Graph::addLabelToEdge as grm::graphFromJson fills it   src/c++/lib/grm/GraphInput.cpp:126-156
+ *   pg_graphs_build_path_index / pg_batch_path_align   grm::PathAligner::{setGraph,alignRead}   src/c++/lib/grm/PathAligner.cpp:70-164
+ *   pg_batch_set_active  the `status != MAPPED` hand-over between cascade stages   src/c++/lib/grm/CompositeAligner.cpp:78-176
  *   pg_batch_set_fragments   Read::fragment_id / is_reverse_strand of the input reads   src/c++/include/common/Read.hh:40-120
  *   pg_batch_count       read filters (NonUniq, BadAlign) applied by CompositeAligner::alignRead
- *                                                               src/c++/lib/paragraph/ReadFilter.cpp:43-90, readfilters/*.hh,
+ *                                                               src/c++/lib/paragraph/ReadFilter.cpp:43-90, readfilters/{NonUniq,BadAlign}.hh,
  *                                                               src/c++/lib/grm/CompositeAligner.cpp:152-175
  *                        + paragraph::disambiguateReads with the production node/edge filters
  *                                                               src/c++/lib/paragraph/Disambiguation.cpp:82-142, 212-296
@@ -65,7 +67,10 @@ enum
     PG_AF_CIGAR = 1u,
     PG_AF_BOTH_STRANDS = 2u,
     PG_AF_REVERSE_GRAPH = 4u,
-    PG_AF_ALL = 0xFFFFFFFFu
+    PG_AF_ALL = 0xFFFFFFFFu,
+    /* library extension (ignored when flags == PG_AF_ALL): keep the results / ops already produced for reads
+     * that are not active in this call (stage 2 of the cascade after pg_batch_path_align) */
+    PG_AF_KEEP_RESULTS = 0x100u
 };
 
 enum
@@ -93,9 +98,11 @@ typedef struct pg_result
     uint32_t ops_off;         /* first entry in the ops array */
     int16_t strand_score[2];  /* best score of the forward / reverse-complement strand fill */
     uint16_t clipped;         /* soft-clipped bases (both ends) of the chosen alignment: what BadAlign needs */
-    uint16_t status;          /* 0 ok; 1 = degenerate (score 0, empty CIGAR: the reference's behaviour is
-                                 undefined downstream); 2 = internal traceback inconsistency */
+    uint16_t status;          /* low byte: 0 ok; 1 = degenerate (score 0, empty CIGAR: the reference's behaviour is
+                                 undefined downstream); 2 = internal traceback inconsistency.
+                                 PG_STATUS_PATH_ALIGNER is or-ed in when the PathAligner stage produced the record */
 } pg_result;
+#define PG_STATUS_PATH_ALIGNER 0x100u
 
 /* One run-length CIGAR element inside a node: node id (12 bits) | op (4 bits) | length (16 bits). */
 typedef uint32_t pg_op;
@@ -235,6 +242,21 @@ pg_status pg_batch_count(pg_ctx* ctx, pg_batch* batch, const pg_count_params* pa
 pg_status pg_batch_download_counts(
     pg_ctx* ctx, pg_batch* batch, uint32_t* counts, pg_read_support* supports, uint32_t* path, uint64_t path_cap,
     uint64_t* n_path);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Exact path matching stage (grm::PathAligner, --path-sequence-matching; default ON in `paragraph`, OFF in grmpy)
+ * ------------------------------------------------------------------------------------------------- */
+/* KmerIndex of every graph (all length-k paths; the reference uses k = 32, PathAligner.hh) */
+pg_status pg_graphs_build_path_index(pg_ctx* ctx, pg_graphs* graphs, uint32_t kmer_len);
+/* PathAligner::alignRead for every read of the batch: reads whose whole length matches a path exactly get their
+ * pg_result (status has PG_STATUS_PATH_ALIGNER set; is_graph_reverse_strand = returned_reverse, NOT xor-ed with the
+ * BAM strand, PathAligner.cpp:121-129) and ops.  Resets the batch's results/ops.  Asynchronous. */
+pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* batch);
+/* flags[i]: bit0 = MAPPED by the path stage, bit1 = anchored (a unique k-mer was found); synchronises */
+pg_status pg_batch_download_path_flags(pg_ctx* ctx, pg_batch* batch, uint8_t* flags);
+/* Restricts the following pg_batch_align calls to reads with active[i] != 0 (NULL = every read): the next
+ * stage of the cascade runs only on reads the previous stage left unmapped / filtered. */
+pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* batch, const uint8_t* active);
 
 /* Renders "<node>[<len><op>...]..." for one read into buf (NUL-terminated); returns the string length
  * (which may be >= cap, in which case the output was truncated). Host-only helper. */

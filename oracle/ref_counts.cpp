@@ -357,3 +357,116 @@ extern "C" int pgrefc_count_site(
     }
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------------
+ * PathAligner checker (src/c++/lib/grm/PathAligner.cpp:70-164).  The reference's own
+ * graphtools::extendPath / extendPathMatching / projectAlignmentOntoGraph / Alignment / generateCigar run
+ * as compiled from the tarball; restated are (a) the KmerIndex constructor (GT!/src/graphalign/KmerIndex.cpp:
+ * 76-116 -- that file includes a Boost header and cannot be compiled here): every length-k path from every
+ * node position via extendPath, keyed by its sequence, and (b) PathAligner::alignRead's control flow.
+ * ---------------------------------------------------------------------------------------------------- */
+#include "graphcore/PathOperations.hh"
+
+namespace
+{
+std::string rc_graphtools(std::string s)
+{  // GT!/src/graphutils/SequenceOperations.cpp:66-88
+    for (char& c : s)
+        c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+    std::reverse(s.begin(), s.end());
+    return s;
+}
+}  // namespace
+
+struct pgrefc_path_result
+{
+    int32_t status;  /* 0 unmapped, 1 MAPPED */
+    int32_t graph_pos, score, mapq, unique, is_graph_reverse, anchored;
+    int32_t cigar_len;
+};
+
+extern "C" int pgrefc_path_align(
+    pgrefc_graph* g, int32_t kmer_len, uint32_t n_reads, const uint32_t* base_off, const char* bases,
+    pgrefc_path_result* out, char* cigars, int cigar_stride)
+{
+    using graphtools::Path;
+    const Graph& graph = g->graph;
+    std::unordered_map<std::string, std::list<Path>> index;
+    for (NodeId node_id = 0; node_id != graph.numNodes(); ++node_id)
+    {
+        const std::string node_seq = graph.nodeSeq(node_id);
+        std::vector<NodeId> node_list{ node_id };
+        for (size_t pos = 0; pos != node_seq.length(); ++pos)
+        {
+            Path path(&graph, static_cast<int32_t>(pos), node_list, static_cast<int32_t>(pos));
+            for (const Path& kp : graphtools::extendPath(path, 0, kmer_len - 1))
+                index[kp.seq()].push_back(kp);
+        }
+    }
+    struct ExactMatch
+    {
+        size_t qpos;
+        Path path;
+        bool isReverse;
+    };
+    for (uint32_t r = 0; r < n_reads; ++r)
+    {
+        pgrefc_path_result& o = out[r];
+        std::memset(&o, 0, sizeof o);
+        if (cigars)
+            cigars[(size_t)r * cigar_stride] = 0;
+        const std::string read_fwd(bases + base_off[r], bases + base_off[r + 1]);
+        const size_t read_length = read_fwd.size();
+        if (read_length < (size_t)kmer_len)
+            continue;
+        std::list<ExactMatch> matches;
+        for (int strand = 0; strand < 2; ++strand)
+        {
+            const bool is_reverse_strand = strand != 0;
+            const std::string read_bases = is_reverse_strand ? rc_graphtools(read_fwd) : read_fwd;
+            for (size_t pos = 0; pos + kmer_len <= read_bases.size(); ++pos)
+            {
+                const std::string kmer = read_bases.substr(pos, kmer_len);
+                auto it = index.find(kmer);
+                if (it != index.end() && it->second.size() == 1)
+                {
+                    size_t qpos = pos;
+                    const auto extended = graphtools::extendPathMatching(it->second.front(), read_bases, qpos);
+                    matches.push_back(ExactMatch{ qpos, extended, is_reverse_strand });
+                    pos = matches.back().qpos + matches.back().path.length();
+                }
+            }
+        }
+        o.anchored = matches.empty() ? 0 : 1;
+        const ExactMatch* first = nullptr;
+        int n_full = 0;
+        for (auto const& m : matches)
+            if (m.path.length() == read_length)
+            {
+                if (!first)
+                    first = &m;
+                ++n_full;
+            }
+        if (!first)
+            continue;
+        std::string cigar;
+        if (first->qpos > 0)
+            cigar += std::to_string(first->qpos) + "S";
+        cigar += std::to_string(first->path.length()) + "M";
+        if (first->qpos + first->path.length() < read_length)
+            cigar += std::to_string(read_length - first->qpos - first->path.length()) + "S";
+        graphtools::Alignment linearAlignment(0, cigar);
+        graphtools::GraphAlignment graphAlignment = graphtools::projectAlignmentOntoGraph(linearAlignment, first->path);
+        const std::string gc = graphAlignment.generateCigar();
+        o.status = 1;
+        o.graph_pos = first->path.startPosition();
+        o.score = (int32_t)first->path.length();
+        o.is_graph_reverse = first->isReverse ? 1 : 0;
+        o.unique = n_full == 1 ? 1 : 0;
+        o.mapq = n_full == 1 ? 60 : 0;
+        o.cigar_len = (int32_t)gc.size();
+        if (cigars && (int)gc.size() < cigar_stride)
+            std::memcpy(cigars + (size_t)r * cigar_stride, gc.c_str(), gc.size() + 1);
+    }
+    return 0;
+}

@@ -15,6 +15,8 @@ AF_CIGAR = 1
 AF_BOTH_STRANDS = 2
 AF_REVERSE_GRAPH = 4
 AF_ALL = 0xFFFFFFFF
+AF_KEEP_RESULTS = 0x100
+STATUS_PATH_ALIGNER = 0x100
 
 PG_OK = 0
 STATUS_NAMES = {0: "PG_OK", 1: "PG_ERR_INVALID", 2: "PG_ERR_NO_DEVICE", 3: "PG_ERR_HIP", 4: "PG_ERR_UNSUPPORTED",
@@ -39,7 +41,8 @@ EXPORTS = [
     "pg_ctx_timing_enable", "pg_ctx_timing_reset", "pg_ctx_timing_get", "pg_graphs_upload", "pg_graphs_destroy",
     "pg_batch_create", "pg_batch_destroy", "pg_batch_upload", "pg_batch_align", "pg_batch_ops_count",
     "pg_batch_download", "pg_align_batch", "pg_render_cigar", "pg_graphs_set_labels", "pg_graphs_count_layout",
-    "pg_graphs_seq_offsets", "pg_batch_set_fragments", "pg_batch_count", "pg_batch_download_counts",
+    "pg_graphs_seq_offsets", "pg_batch_set_fragments", "pg_batch_count", "pg_batch_download_counts", "pg_graphs_build_path_index",
+    "pg_batch_path_align", "pg_batch_download_path_flags", "pg_batch_set_active",
 ]
 
 
@@ -127,6 +130,14 @@ def load_library():
     L.pg_batch_set_fragments.argtypes = [vp, vp, u32p, C.POINTER(C.c_uint8)]
     L.pg_batch_download_counts.restype = C.c_int32
     L.pg_batch_download_counts.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, u64p]
+    L.pg_graphs_build_path_index.restype = C.c_int32
+    L.pg_graphs_build_path_index.argtypes = [vp, vp, C.c_uint32]
+    L.pg_batch_path_align.restype = C.c_int32
+    L.pg_batch_path_align.argtypes = [vp, vp]
+    L.pg_batch_download_path_flags.restype = C.c_int32
+    L.pg_batch_download_path_flags.argtypes = [vp, vp, vp]
+    L.pg_batch_set_active.restype = C.c_int32
+    L.pg_batch_set_active.argtypes = [vp, vp, vp]
     L.pg_render_cigar.restype = C.c_size_t
     L.pg_render_cigar.argtypes = [vp, vp, C.c_char_p, C.c_size_t]
     _lib = L
@@ -240,6 +251,9 @@ class Graphs:
                                         _p32(pred), C.byref(h)))
         self.h = h
 
+    def build_path_index(self, kmer_len=32):
+        self.ctx._chk(self.ctx.L.pg_graphs_build_path_index(self.ctx.h, self.h, kmer_len))
+
     def set_labels(self, edge_labels, labels=None):
         """edge_labels: per graph a dict {(from,to): [label,...]}; labels: per graph the ordered label list
         (default: sorted names).  Counters of edges come back in predecessor-CSR order = self.edges[g]."""
@@ -306,6 +320,22 @@ class Batch:
         self._graphs = graphs
         self.ctx._chk(self.ctx.L.pg_batch_upload(self.ctx.h, self.h, graphs.h, n, _p32(gor), _p32(off), bases))
         self.n_reads = n
+
+    def path_align(self):
+        """PathAligner stage for every read; returns flags (bit0 mapped, bit1 anchored)."""
+        self.ctx._chk(self.ctx.L.pg_batch_path_align(self.ctx.h, self.h))
+        fl = np.zeros(max(self.n_reads, 1), dtype=np.uint8)
+        self.ctx._chk(self.ctx.L.pg_batch_download_path_flags(self.ctx.h, self.h, fl.ctypes.data))
+        return fl[:self.n_reads]
+
+    def set_active(self, active):
+        if active is None:
+            self.ctx._chk(self.ctx.L.pg_batch_set_active(self.ctx.h, self.h, None))
+        else:
+            a = np.ascontiguousarray(active, dtype=np.uint8)
+            if len(a) != self.n_reads:
+                raise ValueError("active length mismatch")
+            self.ctx._chk(self.ctx.L.pg_batch_set_active(self.ctx.h, self.h, a.ctypes.data))
 
     def align(self, flags=AF_ALL):
         self.ctx._chk(self.ctx.L.pg_batch_align(self.ctx.h, self.h, flags & 0xFFFFFFFF))
@@ -376,7 +406,8 @@ def results_to_dicts(res, ops):
             "unique": bool(r["is_unique"]), "returned_reverse": bool(r["returned_reverse"]),
             "multi": [(mm >> k) & 1 for k in range(4)],
             "strand_score": [int(r["strand_score"][0]), int(r["strand_score"][1])],
-            "cigar": render_cigar(r, ops), "clipped": int(r["clipped"]), "status": int(r["status"]),
+            "cigar": render_cigar(r, ops), "clipped": int(r["clipped"]), "status": int(r["status"]) & 0xFF,
+            "by_path_aligner": bool(int(r["status"]) & STATUS_PATH_ALIGNER),
         })
     return out
 

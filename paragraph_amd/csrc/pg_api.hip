@@ -331,6 +331,8 @@ extern "C" pg_status pg_graphs_upload(
         G->h_node_off.assign(node_off, node_off + n_graphs + 1);
         G->h_pred_off.assign(pred_off, pred_off + total_nodes + 1);
         G->h_pred.assign(pred, pred + (pred ? pred_off[total_nodes] : 0));
+        G->h_nodeseq_off.assign(seq_off, seq_off + total_nodes + 1);
+        G->h_seq_raw.assign(seq, seq + seq_off[total_nodes]);
         G->h_node_len.resize(total_nodes);
         for (uint32_t i = 0; i < total_nodes; ++i)
             G->h_node_len[i] = seq_off[i + 1] - seq_off[i];
@@ -383,6 +385,7 @@ extern "C" void pg_graphs_destroy(pg_ctx* ctx, pg_graphs* G)
     (void)hipFree(G->d_label_mask);
     (void)hipFree(G->d_out_mask);
     (void)hipFree(G->d_in_mask);
+    pg_path_index_free(G->path_index);
     delete G;
 }
 
@@ -407,6 +410,8 @@ static void batch_free_device(pg_batch* b)
     (void)hipFree(b->d_ops);
     (void)hipFree(b->d_ops_counter);
     (void)hipFree(b->d_graph_of_read);
+    (void)hipFree(b->d_path_flags);
+    b->d_path_flags = nullptr;
     (void)hipFree(b->d_support);
     (void)hipFree(b->d_path);
     (void)hipFree(b->d_path_counter);
@@ -450,21 +455,16 @@ extern "C" void pg_batch_destroy(pg_ctx* ctx, pg_batch* b)
 
 static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
-extern "C" pg_status pg_batch_upload(
-    pg_ctx* ctx, pg_batch* b, const pg_graphs* G, uint32_t n_reads, const uint32_t* graph_of_read,
-    const uint32_t* base_off, const char* bases)
+// Builds the wavefront work items + chunk plan for the reads with active[i] != 0 (all reads when active is
+// NULL) and uploads them.  Items/fill summaries never need more room than the all-reads plan.
+static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active)
 {
-    if (!ctx || !b || !G || (n_reads && (!graph_of_read || !base_off || !bases)))
-        return fail(ctx, PG_ERR_INVALID, "pg_batch_upload: null argument");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    b->graphs = G;
-    b->n_reads = n_reads;
+    const pg_graphs* G = b->graphs;
+    const uint32_t n_reads = b->n_reads;
+    const uint32_t* base_off = b->h_base_off.data();
+    const uint32_t* graph_of_read = b->h_graph_of_read.data();
     b->chunks.clear();
     b->n_pairs = 0;
-    b->has_skipped = false;
-    b->fragments_set = false;
-
     // ---- bucket reads by (variant, graph) -----------------------------------------------------------
     struct Key
     {
@@ -472,27 +472,13 @@ extern "C" pg_status pg_batch_upload(
     };
     std::vector<Key> keys;
     keys.reserve(n_reads);
-    b->host_template.assign(n_reads, pg_result{});
-    uint64_t ops_total = 0;
     for (uint32_t i = 0; i < n_reads; ++i)
     {
-        if (base_off[i + 1] < base_off[i])
-            return fail(ctx, PG_ERR_INVALID, "base_off must be non-decreasing");
         const uint32_t L = base_off[i + 1] - base_off[i];
-        if (graph_of_read[i] >= G->n_graphs)
-            return fail(ctx, PG_ERR_INVALID, "graph_of_read out of range");
-        if (L > PG_MAX_READ_LEN)
-            return fail(ctx, PG_ERR_UNSUPPORTED, "read longer than 250 bp (gssw word mode is not implemented)");
-        if (L == 0)
-        {
-            // grm::sequentialAlignReads skips reads without bases (Align.cpp:74-77)
-            b->host_template[i].status = 1;
-            b->has_skipped = true;
+        if (L == 0 || (active && !active[i]))
             continue;
-        }
         const uint32_t C = 2 * ((L + 31) / 32);
         keys.push_back(Key{ C, graph_of_read[i], i });
-        ops_total += pg_ops_cap((int)C);
     }
     std::stable_sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) {
         return x.c != y.c ? x.c < y.c : x.graph < y.graph;
@@ -569,37 +555,16 @@ extern "C" pg_status pg_batch_upload(
     }
     close_chunk();
     b->n_pairs = (uint32_t)(items.size() / 2);
-
-    // ---- device buffers ----------------------------------------------------------------------------
-    const size_t n_bases = n_reads ? base_off[n_reads] : 0;
-    if (n_reads + 1 > b->cap_reads || n_bases > b->cap_bases || items.size() > b->cap_items || ops_total > b->ops_cap)
+    if (items.size() > b->cap_items)
     {
-        batch_free_device(b);
-        b->cap_reads = n_reads + 1;
-        b->cap_bases = std::max<size_t>(n_bases, 1);
+        (void)hipFree(b->d_items);
+        (void)hipFree(b->d_fillsum);
         b->cap_items = std::max<size_t>(items.size(), 2);
-        b->ops_cap = std::max<uint64_t>(ops_total, 1);
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_base_off, b->cap_reads * sizeof(uint32_t)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_bases, b->cap_bases));
         HIP_TRY(ctx, hipMalloc((void**)&b->d_items, b->cap_items * sizeof(PgWorkItem)));
         HIP_TRY(ctx, hipMalloc((void**)&b->d_fillsum, b->cap_items * PG_GROUPS * 2 * sizeof(PgFillSummary)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_results, std::max<size_t>(n_reads, 1) * sizeof(pg_result)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_ops, b->ops_cap * sizeof(pg_op)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_ops_counter, sizeof(unsigned long long)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_graph_of_read, b->cap_reads * sizeof(uint32_t)));
     }
-    b->h_graph_of_read.assign(graph_of_read, graph_of_read + n_reads);
-    if (n_reads)
-    {
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_base_off, base_off, (n_reads + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_graph_of_read, graph_of_read, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        if (n_bases)
-            HIP_TRY(ctx, hipMemcpyAsync(b->d_bases, bases, n_bases, hipMemcpyHostToDevice, ctx->stream));
-        if (!items.empty())
-            HIP_TRY(ctx, hipMemcpyAsync(b->d_items, items.data(), items.size() * sizeof(PgWorkItem), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_results, b->host_template.data(), n_reads * sizeof(pg_result), hipMemcpyHostToDevice, ctx->stream));
-    }
-    HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
+    if (!items.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_items, items.data(), items.size() * sizeof(PgWorkItem), hipMemcpyHostToDevice, ctx->stream));
     // workspace / scratch owned by the ctx (shared by its batches)
     if (b->max_ws > ctx->ws_cap)
     {
@@ -619,8 +584,83 @@ extern "C" pg_status pg_batch_upload(
         HIP_TRY(ctx, hipMalloc((void**)&ctx->ops_scratch, b->max_scratch * sizeof(pg_op)));
         ctx->ops_scratch_cap = b->max_scratch;
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `items` goes out of scope
     return PG_OK;
+}
+
+extern "C" pg_status pg_batch_upload(
+    pg_ctx* ctx, pg_batch* b, const pg_graphs* G, uint32_t n_reads, const uint32_t* graph_of_read,
+    const uint32_t* base_off, const char* bases)
+{
+    if (!ctx || !b || !G || (n_reads && (!graph_of_read || !base_off || !bases)))
+        return fail(ctx, PG_ERR_INVALID, "pg_batch_upload: null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    b->graphs = G;
+    b->n_reads = n_reads;
+    b->has_skipped = false;
+    b->fragments_set = false;
+    b->host_template.assign(n_reads, pg_result{});
+    uint64_t ops_total = 0;
+    for (uint32_t i = 0; i < n_reads; ++i)
+    {
+        if (base_off[i + 1] < base_off[i])
+            return fail(ctx, PG_ERR_INVALID, "base_off must be non-decreasing");
+        const uint32_t L = base_off[i + 1] - base_off[i];
+        if (graph_of_read[i] >= G->n_graphs)
+            return fail(ctx, PG_ERR_INVALID, "graph_of_read out of range");
+        if (L > PG_MAX_READ_LEN)
+            return fail(ctx, PG_ERR_UNSUPPORTED, "read longer than 250 bp (gssw word mode is not implemented)");
+        if (L == 0)
+        {
+            // grm::sequentialAlignReads skips reads without bases (Align.cpp:74-77)
+            b->host_template[i].status = 1;
+            b->has_skipped = true;
+            continue;
+        }
+        ops_total += pg_ops_cap((int)(2 * ((L + 31) / 32)));
+    }
+    b->h_graph_of_read.assign(graph_of_read, graph_of_read + n_reads);
+    b->h_base_off.assign(base_off, base_off + (n_reads ? n_reads + 1 : 0));
+    if (!n_reads)
+        b->h_base_off.assign(1, 0);
+
+    // ---- device buffers ----------------------------------------------------------------------------
+    const size_t n_bases = n_reads ? base_off[n_reads] : 0;
+    if (n_reads + 1 > b->cap_reads || n_bases > b->cap_bases || ops_total > b->ops_cap)
+    {
+        batch_free_device(b);
+        b->cap_reads = n_reads + 1;
+        b->cap_bases = std::max<size_t>(n_bases, 1);
+        b->ops_cap = std::max<uint64_t>(ops_total, 1);
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_base_off, b->cap_reads * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_bases, b->cap_bases));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_results, std::max<size_t>(n_reads, 1) * sizeof(pg_result)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_ops, b->ops_cap * sizeof(pg_op)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_ops_counter, sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_graph_of_read, b->cap_reads * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_path_flags, b->cap_reads));
+    }
+    if (n_reads)
+    {
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_base_off, base_off, (n_reads + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_graph_of_read, graph_of_read, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (n_bases)
+            HIP_TRY(ctx, hipMemcpyAsync(b->d_bases, bases, n_bases, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_results, b->host_template.data(), n_reads * sizeof(pg_result), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(b->d_path_flags, 0, n_reads, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
+    return plan_items(ctx, b, nullptr);
+}
+
+extern "C" pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* b, const uint8_t* active)
+{
+    if (!ctx || !b || !b->graphs)
+        return fail(ctx, PG_ERR_INVALID, "pg_batch_set_active: batch not uploaded");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return plan_items(ctx, b, active);
 }
 
 extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
@@ -631,7 +671,8 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     const pg_graphs* G = b->graphs;
     if (b->max_ws > ctx->ws_cap || b->max_scratch > ctx->ops_scratch_cap)
         return fail(ctx, PG_ERR_INVALID, "ctx workspace was shrunk after the batch was planned");
-    HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
+    if (!(flags & PG_AF_KEEP_RESULTS) || (flags == PG_AF_ALL))
+        HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
     const bool revg = (flags & PG_AF_REVERSE_GRAPH) != 0;
     for (const Chunk& ch : b->chunks)
     {

@@ -123,12 +123,12 @@ __global__ __launch_bounds__(64) void pg_support_kernel(CountArgs a)
         else if (pred)
             atomicAdd(&tally[which], 1u);
     };
-    const bool aligned = !(L == 0 || res.status != 0 || res.n_ops == 0);
+    const bool aligned = !(L == 0 || (res.status & 0xFFu) != 0 || res.n_ops == 0);
     tally_add(0, aligned);
     if (!aligned)
     {
         // skipped (Align.cpp:74-77) or degenerate all-zero alignment (no CIGAR): never counted
-        if (L != 0 && res.status == 2)
+        if (L != 0 && (res.status & 0xFFu) == 2)
             sup.status = 3;
         if (live)
             a.support[r] = sup;
@@ -292,7 +292,11 @@ __global__ __launch_bounds__(FRAG_BLOCK) void pg_fragment_kernel(CountArgs a)
             const PgCountGraph cg = a.graphs[graph];
             ++n;
             const bool read_rev = a.is_rev[r] != 0;
-            const bool graph_rev = read_rev != (a.results[r].returned_reverse != 0);  // GraphAligner.cpp:358-359
+            const pg_result rr = a.results[r];
+            // gssw stage: is_reverse_strand() != return_reverse (GraphAligner.cpp:358-359); path stage: the match's
+            // own strand (PathAligner.cpp:121-129)
+            const bool graph_rev = (rr.status & PG_STATUS_PATH_ALIGNER) ? rr.returned_reverse != 0
+                                                                        : read_rev != (rr.returned_reverse != 0);
             if (graph_rev)
                 ++rev;
             else

@@ -46,6 +46,9 @@ struct pg_ctx
     std::string err;
 };
 
+struct pg_path_index;
+void pg_path_index_free(pg_path_index* ix);
+
 struct pg_graphs
 {
     uint32_t n_graphs = 0;
@@ -60,6 +63,9 @@ struct pg_graphs
     std::vector<uint32_t> h_pred_off;  // total_nodes + 1
     std::vector<uint32_t> h_pred;
     std::vector<uint32_t> h_node_len;
+    std::vector<uint32_t> h_nodeseq_off;  // total_nodes + 1, into h_seq_raw
+    std::string h_seq_raw;            // node sequences exactly as given (the path stage compares raw characters)
+    pg_path_index* path_index = nullptr;
     std::vector<uint32_t> h_n_labels;  // per graph
     std::vector<uint64_t> h_seq_off;   // n_graphs + 1 (dense sequence-set slots)
     bool labels_set = false;
@@ -93,6 +99,8 @@ struct pg_batch
     bool has_skipped = false;
     // ---- count path
     std::vector<uint32_t> h_graph_of_read;
+    std::vector<uint32_t> h_base_off;
+    uint8_t* d_path_flags = nullptr;  // per read: bit0 mapped by the path stage, bit1 anchored
     uint32_t* d_graph_of_read = nullptr;
     pg_read_support* d_support = nullptr;
     uint32_t* d_path = nullptr;

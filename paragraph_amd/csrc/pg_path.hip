@@ -1,0 +1,620 @@
+// pg_path.hip -- exact path matching stage of the aligner cascade on the device.
+//
+// Replaces
+//   grm::PathAligner::{setGraph,alignRead}            src/c++/lib/grm/PathAligner.cpp:70-164
+//   graphtools::KmerIndex (construction + numPaths)   GT!/src/graphalign/KmerIndex.cpp:76-116, 209-223
+//   graphtools::extendPathMatching                    GT!/src/graphcore/PathOperations.cpp:117-271
+//   projectAlignmentOntoGraph for an all-match alignment + GraphAlignment::generateCigar
+//                                                     GT!/src/graphalign/GraphAlignmentOperations.cpp:130-164
+//
+// Host: enumerates every length-k path of every graph (depth-first over successors in ascending id, as
+// extendPathEnd does), groups them by sequence and builds one open-addressing hash table per graph:
+// key = 64-bit polynomial hash of the k raw characters, value = (number of paths with that sequence, first path).
+// Device: one thread per read; both strands; rolling hash over the read; for k-mers with exactly one path the
+// reference's greedy exact extension (right, then left; at a node end the neighbour with the UNIQUE longest
+// common prefix over the shortest neighbour's length) is replayed character by character on the raw node
+// sequences.  A read is MAPPED when a match covers the whole read; more than one such match makes it
+// non-unique (MAPQ 0).  HBM-bound byte work: no LDS staging is needed (a read touches <= 2L graph bytes).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/paragraph_amd.h"
+#include "pg_device.h"
+#include "pg_internal.h"
+
+namespace
+{
+constexpr uint64_t HASH_B = 0x9E3779B97F4A7C15ull | 1ull;
+
+struct PathGraphDev
+{
+    uint32_t node_base;  // set-wide node numbering (caller CSR)
+    uint32_t n_nodes;
+    uint64_t tab_off;    // into the entry table
+    uint32_t tab_mask;   // capacity - 1 (capacity is a power of two), 0xFFFFFFFF = graph has no k-mers
+    uint32_t pad;
+};
+
+struct KmerEntry
+{
+    uint64_t hash;  // 0 = empty
+    uint32_t count;
+    uint32_t start_pos;
+    uint32_t end_pos;
+    uint32_t n_nodes;
+    uint32_t pool_off;  // node ids (graph-local) of the first path with this sequence
+    uint32_t pad;
+};
+
+struct PathArgs
+{
+    uint32_t n_reads;
+    uint32_t k;
+    uint64_t pow_k1;  // HASH_B^(k-1)
+    const uint32_t* base_off;
+    const char* bases;
+    const uint32_t* graph_of_read;
+    const PathGraphDev* graphs;
+    const KmerEntry* table;
+    const uint32_t* pool;
+    const uint32_t* node_off;  // raw char offsets per (set-wide) node, n_total + 1
+    const char* raw;
+    const uint32_t* succ_off;  // per set-wide node
+    const uint32_t* succ;
+    const uint32_t* pred_off;
+    const uint32_t* pred;
+    pg_result* results;
+    pg_op* ops;
+    unsigned long long* ops_counter;
+    uint8_t* flags;
+};
+
+__device__ __forceinline__ uint32_t comp_raw(uint32_t c)
+{  // GT!/src/graphutils/SequenceOperations.cpp:66-81 (case-sensitive: anything else becomes 'N')
+    switch (c)
+    {
+    case 'A': return 'T';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    case 'T': return 'A';
+    default: return 'N';
+    }
+}
+
+struct Walker
+{
+    const PathArgs& a;
+    const PathGraphDev g;
+    const char* bases;
+    int L;
+    int strand;
+
+    __device__ uint32_t q(int j) const { return strand == 0 ? (uint8_t)bases[j] : comp_raw((uint8_t)bases[L - 1 - j]); }
+    __device__ uint32_t nlen(uint32_t node) const { return a.node_off[g.node_base + node + 1] - a.node_off[g.node_base + node]; }
+    __device__ uint32_t nch(uint32_t node, uint32_t pos) const { return (uint8_t)a.raw[a.node_off[g.node_base + node] + pos]; }
+
+    // Extends the seed path `e` anchored at read position qpos (extendPathMatching).  Outputs the final path as
+    // (first node, start_pos, last node, end_pos, length, #nodes prepended, #nodes appended) and the new qpos.
+    // With REC, prepended / appended node ids are written to rec_l[0..] (closest first) / rec_r[0..].
+    template <bool REC>
+    __device__ void extend(const KmerEntry& e, int& qpos, uint32_t& first_node, uint32_t& start_pos, uint32_t& end_pos,
+                           int& length, uint32_t& n_left, uint32_t& n_right, uint32_t* rec_l, uint32_t* rec_r) const
+    {
+        // ---- extendPathEndMatching (PathOperations.cpp:117-189)
+        uint32_t node = a.pool[e.pool_off + e.n_nodes - 1];
+        uint32_t pos_in_node = e.end_pos + 1;
+        int pos_in_query = qpos + (int)a.k;
+        n_right = 0;
+        bool moved = true;
+        while (moved)
+        {
+            moved = false;
+            const uint32_t len = nlen(node);
+            while (pos_in_query < L && pos_in_node < len && q(pos_in_query) == nch(node, pos_in_node))
+            {
+                moved = true;
+                ++pos_in_node;
+                ++pos_in_query;
+            }
+            if (pos_in_node >= len)
+            {
+                const uint32_t sb = a.succ_off[g.node_base + node], se = a.succ_off[g.node_base + node + 1];
+                uint32_t min_size = 0xFFFFFFFFu;
+                for (uint32_t s = sb; s < se; ++s)
+                    min_size = min(min_size, nlen(a.succ[s]));
+                uint32_t n_longest = 0, longest = 0, cur = 0;
+                for (uint32_t s = sb; s < se; ++s)
+                {
+                    const uint32_t sn = a.succ[s];
+                    uint32_t p = 0;
+                    while (p < min_size && pos_in_query + (int)p < L && nch(sn, p) == q(pos_in_query + (int)p))
+                        ++p;
+                    if (p > longest)
+                    {
+                        longest = p;
+                        cur = sn;
+                        n_longest = 1;
+                    }
+                    else if (p == longest)
+                        ++n_longest;
+                }
+                if (longest == 0 || n_longest != 1)
+                    break;
+                if (REC)
+                    rec_r[n_right] = cur;
+                ++n_right;
+                pos_in_query += (int)longest;
+                pos_in_node = longest;
+                node = cur;
+                moved = true;
+            }
+        }
+        end_pos = pos_in_node - 1;
+        const int end_query = pos_in_query;
+        // ---- extendPathStartMatching (PathOperations.cpp:191-266)
+        node = a.pool[e.pool_off];
+        pos_in_node = e.start_pos;
+        pos_in_query = qpos;
+        n_left = 0;
+        moved = true;
+        while (moved)
+        {
+            moved = false;
+            while (pos_in_query > 0 && pos_in_node > 0 && q(pos_in_query - 1) == nch(node, pos_in_node - 1))
+            {
+                moved = true;
+                --pos_in_node;
+                --pos_in_query;
+            }
+            if (pos_in_node == 0)
+            {
+                const uint32_t pb = a.pred_off[g.node_base + node], pe = a.pred_off[g.node_base + node + 1];
+                uint32_t min_size = 0xFFFFFFFFu;
+                for (uint32_t s = pb; s < pe; ++s)
+                    min_size = min(min_size, nlen(a.pred[s]));
+                uint32_t n_longest = 0, longest = 0, cur = 0;
+                for (uint32_t s = pb; s < pe; ++s)
+                {
+                    const uint32_t pn = a.pred[s];
+                    const uint32_t plen = nlen(pn);
+                    uint32_t pp = plen, ml = 0;
+                    while (pp > plen - min_size && pos_in_query - (int)ml > 0 && nch(pn, pp - 1) == q(pos_in_query - (int)ml - 1))
+                    {
+                        --pp;
+                        ++ml;
+                    }
+                    if (ml > longest)
+                    {
+                        longest = ml;
+                        cur = pn;
+                        n_longest = 1;
+                    }
+                    else if (ml == longest)
+                        ++n_longest;
+                }
+                if (longest == 0 || n_longest != 1)
+                    break;
+                if (REC)
+                    rec_l[n_left] = cur;
+                ++n_left;
+                pos_in_query -= (int)longest;
+                node = cur;
+                pos_in_node = nlen(node) - longest;
+                moved = true;
+            }
+        }
+        first_node = node;
+        start_pos = pos_in_node;
+        qpos = pos_in_query;
+        length = end_query - pos_in_query;
+    }
+
+    __device__ bool lookup(uint64_t h, int pos, KmerEntry& out) const
+    {
+        if (g.tab_mask == 0xFFFFFFFFu)
+            return false;
+        if (h == 0)
+            h = 1;
+        uint32_t slot = (uint32_t)(h >> 20) & g.tab_mask;
+        for (;;)
+        {
+            const KmerEntry e = a.table[g.tab_off + slot];
+            if (e.hash == 0)
+                return false;
+            if (e.hash == h)
+            {
+                if (e.count != 1)
+                    return false;
+                // verify the characters against the path (a 64-bit collision would otherwise fake an anchor)
+                uint32_t ni = 0, node = a.pool[e.pool_off], p = e.start_pos;
+                for (uint32_t c = 0; c < a.k; ++c)
+                {
+                    if (p >= nlen(node))
+                    {
+                        ++ni;
+                        node = a.pool[e.pool_off + ni];
+                        p = 0;
+                    }
+                    if (nch(node, p) != q(pos + (int)c))
+                        return false;
+                    ++p;
+                }
+                out = e;
+                return true;
+            }
+            slot = (slot + 1) & g.tab_mask;
+        }
+    }
+};
+
+__global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
+{
+    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+    if (r >= a.n_reads)
+        return;
+    const uint32_t off = a.base_off[r];
+    const int L = (int)(a.base_off[r + 1] - off);
+    uint8_t flags = 0;
+    if (L < (int)a.k || L == 0)
+    {
+        a.flags[r] = 0;
+        return;
+    }
+    const PathGraphDev g = a.graphs[a.graph_of_read[r]];
+    int n_full = 0, n_matches = 0;
+    int first_strand = 0, first_pos = 0;
+    for (int strand = 0; strand < 2; ++strand)
+    {
+        Walker w{ a, g, a.bases + off, L, strand };
+        uint64_t h = 0;
+        for (uint32_t c = 0; c < a.k; ++c)
+            h = h * HASH_B + (uint64_t)w.q((int)c) + 1;
+        int pos = 0;
+        for (;;)
+        {
+            KmerEntry e;
+            int next = pos + 1;
+            if (w.lookup(h, pos, e))
+            {
+                int qpos = pos;
+                uint32_t fn, sp, ep, nl, nr;
+                int len;
+                w.extend<false>(e, qpos, fn, sp, ep, len, nl, nr, nullptr, nullptr);
+                ++n_matches;
+                if (len == L)
+                {
+                    if (n_full == 0)
+                    {
+                        first_strand = strand;
+                        first_pos = pos;
+                    }
+                    ++n_full;
+                }
+                next = qpos + len + 1;  // PathAligner.cpp:104 + the loop increment
+            }
+            if (next + (int)a.k > L)
+                break;
+            if (next == pos + 1)
+                h = (h - ((uint64_t)w.q(pos) + 1) * a.pow_k1) * HASH_B + (uint64_t)w.q(pos + (int)a.k) + 1;
+            else
+            {
+                h = 0;
+                for (uint32_t c = 0; c < a.k; ++c)
+                    h = h * HASH_B + (uint64_t)w.q(next + (int)c) + 1;
+            }
+            pos = next;
+        }
+    }
+    if (n_matches)
+        flags |= 2;
+    if (n_full == 0)
+    {
+        a.flags[r] = flags;
+        return;
+    }
+    // ---- second pass over the first full-length match: count nodes, allocate ops, record, emit ----------
+    Walker w{ a, g, a.bases + off, L, first_strand };
+    uint64_t h = 0;
+    for (uint32_t c = 0; c < a.k; ++c)
+        h = h * HASH_B + (uint64_t)w.q(first_pos + (int)c) + 1;
+    KmerEntry e;
+    w.lookup(h, first_pos, e);
+    int qpos = first_pos;
+    uint32_t fn, sp, ep, nl, nr;
+    int len;
+    w.extend<false>(e, qpos, fn, sp, ep, len, nl, nr, nullptr, nullptr);
+    const uint32_t n_nodes = nl + e.n_nodes + nr;
+    const unsigned long long base = atomicAdd(a.ops_counter, (unsigned long long)n_nodes);
+    pg_op* ops = a.ops + base;
+    // prepended nodes are produced closest-first: write them at nl-1-j; seed nodes at nl+i; appended at nl+n_seed+j
+    {
+        // record into the ops area itself (node ids first, converted to op words below)
+        uint32_t* ids = (uint32_t*)ops;
+        // use the tail of the region for the "left" list so that nothing overlaps: left[j] -> ids[nl-1-j]
+        // implemented by recording into temporaries placed at the final positions via reversed pointer maths
+        qpos = first_pos;
+        // rec_l must map j -> ids[nl-1-j]; do it with a small adaptor: record to ids+0.. then reverse
+        w.extend<true>(e, qpos, fn, sp, ep, len, nl, nr, ids, ids + nl + e.n_nodes);
+        for (uint32_t i = 0, j = nl ? nl - 1 : 0; i < j; ++i, --j)
+        {
+            const uint32_t t = ids[i];
+            ids[i] = ids[j];
+            ids[j] = t;
+        }
+        for (uint32_t i = 0; i < e.n_nodes; ++i)
+            ids[nl + i] = a.pool[e.pool_off + i];
+        for (uint32_t i = 0; i < n_nodes; ++i)
+        {
+            const uint32_t node = ids[i];
+            const uint32_t lo = i == 0 ? sp : 0u;
+            const uint32_t hi = i == n_nodes - 1 ? ep : w.nlen(node) - 1;
+            ops[i] = (node << 20) | ((uint32_t)PG_OPC_M << 16) | ((hi - lo + 1) & 0xFFFFu);
+        }
+    }
+    pg_result res;
+    res.graph_pos = (int32_t)sp;
+    res.score = (int16_t)L;
+    res.mapq = n_full == 1 ? 60 : 0;
+    res.is_unique = n_full == 1 ? 1 : 0;
+    res.returned_reverse = first_strand ? 1 : 0;
+    res.multi_mask = 0;
+    res.n_ops = (uint16_t)n_nodes;
+    res.ops_off = (uint32_t)base;
+    res.strand_score[0] = first_strand ? -1 : (int16_t)L;
+    res.strand_score[1] = first_strand ? (int16_t)L : -1;
+    res.clipped = 0;
+    res.status = PG_STATUS_PATH_ALIGNER;
+    a.results[r] = res;
+    a.flags[r] = flags | 1;
+}
+
+uint64_t hash_str(const char* s, uint32_t k)
+{
+    uint64_t h = 0;
+    for (uint32_t c = 0; c < k; ++c)
+        h = h * HASH_B + (uint64_t)(uint8_t)s[c] + 1;
+    return h ? h : 1;
+}
+}  // namespace
+
+struct pg_path_index
+{
+    uint32_t k = 0;
+    uint64_t pow_k1 = 1;
+    PathGraphDev* d_graphs = nullptr;
+    KmerEntry* d_table = nullptr;
+    uint32_t* d_pool = nullptr;
+    uint32_t* d_node_off = nullptr;
+    char* d_raw = nullptr;
+    uint32_t* d_succ_off = nullptr;
+    uint32_t* d_succ = nullptr;
+};
+
+void pg_path_index_free(pg_path_index* ix)
+{
+    if (!ix)
+        return;
+    (void)hipFree(ix->d_graphs);
+    (void)hipFree(ix->d_table);
+    (void)hipFree(ix->d_pool);
+    (void)hipFree(ix->d_node_off);
+    (void)hipFree(ix->d_raw);
+    (void)hipFree(ix->d_succ_off);
+    (void)hipFree(ix->d_succ);
+    delete ix;
+}
+
+template <typename T> static hipError_t up(const std::vector<T>& v, T** d, hipStream_t s)
+{
+    hipError_t e = hipMalloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (e != hipSuccess || v.empty())
+        return e;
+    return hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+}
+
+extern "C" pg_status pg_graphs_build_path_index(pg_ctx* ctx, pg_graphs* G, uint32_t kmer_len)
+{
+    if (!ctx || !G || kmer_len == 0 || kmer_len > 250)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_graphs_build_path_index: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n_total = (uint32_t)G->h_node_len.size();
+    // successor CSR (set-wide node numbering, graph-local ids as values, ascending)
+    std::vector<uint32_t> succ_off(n_total + 1, 0), succ;
+    {
+        std::vector<std::vector<uint32_t>> sl(n_total);
+        for (uint32_t g = 0; g < G->n_graphs; ++g)
+        {
+            const uint32_t nb = G->h_node_off[g], ne = G->h_node_off[g + 1];
+            for (uint32_t node = nb; node < ne; ++node)
+                for (uint32_t q = G->h_pred_off[node]; q < G->h_pred_off[node + 1]; ++q)
+                    sl[nb + G->h_pred[q]].push_back(node - nb);
+        }
+        for (uint32_t i = 0; i < n_total; ++i)
+        {
+            std::sort(sl[i].begin(), sl[i].end());
+            succ.insert(succ.end(), sl[i].begin(), sl[i].end());
+            succ_off[i + 1] = (uint32_t)succ.size();
+        }
+    }
+    std::vector<PathGraphDev> gd(G->n_graphs);
+    std::vector<KmerEntry> table;
+    std::vector<uint32_t> pool;
+    const std::string& raw = G->h_seq_raw;
+    const std::vector<uint32_t>& noff = G->h_nodeseq_off;
+    struct PathRec
+    {
+        uint32_t start, end;
+        std::vector<uint32_t> nodes;
+    };
+    for (uint32_t g = 0; g < G->n_graphs; ++g)
+    {
+        const uint32_t nb = G->h_node_off[g], ne = G->h_node_off[g + 1];
+        std::unordered_map<std::string, std::pair<uint32_t, PathRec>> idx;  // sequence -> (count, first path)
+        std::vector<uint32_t> nl;
+        std::string seq;
+        // depth-first enumeration = extendPathEnd (PathOperations.cpp:70-101)
+        struct Rec
+        {
+            static void go(const pg_graphs* G, const std::vector<uint32_t>& succ_off, const std::vector<uint32_t>& succ,
+                           const std::string& raw, const std::vector<uint32_t>& noff, uint32_t nb, uint32_t k,
+                           std::vector<uint32_t>& nl, std::string& seq, uint32_t start, uint32_t pos,
+                           std::unordered_map<std::string, std::pair<uint32_t, PathRec>>& idx)
+            {
+                const uint32_t node = nl.back();
+                const uint32_t len = G->h_node_len[nb + node];
+                const uint32_t need = k - (uint32_t)seq.size();
+                const uint32_t room = len - pos;
+                if (need <= room)
+                {
+                    const size_t before = seq.size();
+                    seq.append(raw, noff[nb + node] + pos, need);
+                    auto it = idx.find(seq);
+                    if (it == idx.end())
+                        idx.emplace(seq, std::make_pair(1u, PathRec{ start, pos + need - 1, nl }));
+                    else
+                        it->second.first++;
+                    seq.resize(before);
+                    return;
+                }
+                const size_t before = seq.size();
+                seq.append(raw, noff[nb + node] + pos, room);
+                for (uint32_t s = succ_off[nb + node]; s < succ_off[nb + node + 1]; ++s)
+                {
+                    nl.push_back(succ[s]);
+                    go(G, succ_off, succ, raw, noff, nb, k, nl, seq, start, 0, idx);
+                    nl.pop_back();
+                }
+                seq.resize(before);
+            }
+        };
+        for (uint32_t node = 0; node < ne - nb; ++node)
+            for (uint32_t pos = 0; pos < G->h_node_len[nb + node]; ++pos)
+            {
+                nl.assign(1, node);
+                seq.clear();
+                Rec::go(G, succ_off, succ, raw, noff, nb, kmer_len, nl, seq, pos, pos, idx);
+            }
+        gd[g].node_base = nb;
+        gd[g].n_nodes = ne - nb;
+        gd[g].pad = 0;
+        gd[g].tab_off = table.size();
+        if (idx.empty())
+        {
+            gd[g].tab_mask = 0xFFFFFFFFu;
+            continue;
+        }
+        uint32_t cap = 4;
+        while (cap < 2 * idx.size())
+            cap *= 2;
+        gd[g].tab_mask = cap - 1;
+        table.resize(table.size() + cap, KmerEntry{});
+        for (auto const& kv : idx)
+        {
+            const uint64_t h = hash_str(kv.first.data(), kmer_len);
+            uint32_t slot = (uint32_t)(h >> 20) & (cap - 1);
+            for (;;)
+            {
+                KmerEntry& e = table[gd[g].tab_off + slot];
+                if (e.hash == 0)
+                {
+                    e.hash = h;
+                    e.count = kv.second.first;
+                    e.start_pos = kv.second.second.start;
+                    e.end_pos = kv.second.second.end;
+                    e.n_nodes = (uint32_t)kv.second.second.nodes.size();
+                    e.pool_off = (uint32_t)pool.size();
+                    pool.insert(pool.end(), kv.second.second.nodes.begin(), kv.second.second.nodes.end());
+                    break;
+                }
+                if (e.hash == h)
+                    return pg_fail(ctx, PG_ERR_UNSUPPORTED, "64-bit k-mer hash collision inside one graph");
+                slot = (slot + 1) & (cap - 1);
+            }
+        }
+    }
+    pg_path_index* ix = new pg_path_index();
+    ix->k = kmer_len;
+    ix->pow_k1 = 1;
+    for (uint32_t i = 1; i < kmer_len; ++i)
+        ix->pow_k1 *= HASH_B;
+    std::vector<uint32_t> node_off(noff.begin(), noff.end());
+    std::vector<char> rawv(raw.begin(), raw.end());
+    hipError_t e = up(gd, &ix->d_graphs, ctx->stream);
+    if (e == hipSuccess) e = up(table, &ix->d_table, ctx->stream);
+    if (e == hipSuccess) e = up(pool, &ix->d_pool, ctx->stream);
+    if (e == hipSuccess) e = up(node_off, &ix->d_node_off, ctx->stream);
+    if (e == hipSuccess) e = up(rawv, &ix->d_raw, ctx->stream);
+    if (e == hipSuccess) e = up(succ_off, &ix->d_succ_off, ctx->stream);
+    if (e == hipSuccess) e = up(succ, &ix->d_succ, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess)
+    {
+        pg_path_index_free(ix);
+        return pg_fail(ctx, PG_ERR_HIP, std::string("path index upload: ") + hipGetErrorString(e));
+    }
+    pg_path_index_free(G->path_index);
+    G->path_index = ix;
+    // the extension walks predecessors too: reuse / create the caller-indexed predecessor tables
+    if (!G->d_cnt_pred_off)
+    {
+        HIP_TRY(ctx, up(G->h_pred_off, &G->d_cnt_pred_off, ctx->stream));
+        HIP_TRY(ctx, up(G->h_pred, &G->d_cnt_pred, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PG_OK;
+}
+
+extern "C" pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* b)
+{
+    if (!ctx || !b || !b->graphs)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_path_align: batch not uploaded");
+    const pg_graphs* G = b->graphs;
+    if (!G->path_index)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_path_align: call pg_graphs_build_path_index first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const pg_path_index* ix = G->path_index;
+    HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
+    if (b->n_reads)
+        HIP_TRY(ctx, hipMemsetAsync(b->d_path_flags, 0, b->n_reads, ctx->stream));
+    PathArgs a{};
+    a.n_reads = b->n_reads;
+    a.k = ix->k;
+    a.pow_k1 = ix->pow_k1;
+    a.base_off = b->d_base_off;
+    a.bases = b->d_bases;
+    a.graph_of_read = b->d_graph_of_read;
+    a.graphs = ix->d_graphs;
+    a.table = ix->d_table;
+    a.pool = ix->d_pool;
+    a.node_off = ix->d_node_off;
+    a.raw = ix->d_raw;
+    a.succ_off = ix->d_succ_off;
+    a.succ = ix->d_succ;
+    a.pred_off = G->d_cnt_pred_off;
+    a.pred = G->d_cnt_pred;
+    a.results = b->d_results;
+    a.ops = b->d_ops;
+    a.ops_counter = b->d_ops_counter;
+    a.flags = b->d_path_flags;
+    if (b->n_reads)
+    {
+        hipLaunchKernelGGL(pg_path_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return PG_OK;
+}
+
+extern "C" pg_status pg_batch_download_path_flags(pg_ctx* ctx, pg_batch* b, uint8_t* flags)
+{
+    if (!ctx || !b || (b->n_reads && !flags))
+        return PG_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (b->n_reads)
+        HIP_TRY(ctx, hipMemcpyAsync(flags, b->d_path_flags, b->n_reads, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}

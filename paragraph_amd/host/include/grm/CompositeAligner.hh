@@ -1,12 +1,13 @@
 // grm::CompositeAligner (src/c++/include/grm/CompositeAligner.hh:44-91): the aligner cascade
-// path -> kmer -> klib -> gssw with a filter after each stage.  On the device build only the gssw stage
-// exists so far; asking for path / kmer / klib matching throws std::logic_error.
+// path -> kmer -> klib -> gssw with a filter after each stage.  On the device build the path and gssw stages
+// exist; asking for kmer / klib matching throws std::logic_error.
 #pragma once
 #include <list>
 #include <vector>
 
 #include "grm/Filter.hh"
 #include "grm/GraphAligner.hh"
+#include "grm/PathAligner.hh"
 
 namespace grm
 {
@@ -36,6 +37,7 @@ public:
 private:
     const bool pathMatching_, graphMatching_, klibMatching_, kmerMatching_;
     const unsigned int grapAlignmentflags_;
+    PathAligner pathAligner_;
     GraphAligner graphAligner_;
     unsigned attempted_ = 0, filtered_ = 0, mappedKlib_ = 0, mappedPath_ = 0, anchoredPath_ = 0, mappedKmers_ = 0,
              mappedSw_ = 0;

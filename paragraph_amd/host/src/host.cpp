@@ -12,6 +12,7 @@
 #include "grm/Align.hh"
 #include "grm/CompositeAligner.hh"
 #include "grm/GraphAligner.hh"
+#include "grm/PathAligner.hh"
 #include "paragraph/SiteBatcher.hh"
 
 using common::Read;
@@ -207,27 +208,144 @@ std::string GraphAligner::align(const std::string& read, int& mapq, int& positio
     return tmp.graph_cigar();
 }
 
+struct PathAligner::Impl
+{
+    int32_t kmer_size = 32;
+    pg_graphs* graphs = nullptr;
+    ~Impl()
+    {
+        if (graphs)
+            pg_graphs_destroy(deviceContext(), graphs);
+    }
+};
+
+PathAligner::PathAligner(int32_t kmer_size) : impl_(new Impl()) { impl_->kmer_size = kmer_size; }
+PathAligner::~PathAligner() = default;
+PathAligner::PathAligner(PathAligner&& rhs) noexcept = default;
+PathAligner& PathAligner::operator=(PathAligner&& rhs) noexcept = default;
+
+void PathAligner::setGraph(Graph const* g, std::list<graphtools::Path> const&)
+{
+    pg_ctx* ctx = deviceContext();
+    std::lock_guard<std::mutex> lock(deviceMutex());
+    if (impl_->graphs)
+        pg_graphs_destroy(ctx, impl_->graphs);
+    impl_->graphs = nullptr;
+    GraphCsr csr;
+    csr.add(*g);
+    check(ctx, pg_graphs_upload(ctx, 1, csr.node_off.data(), csr.seq_off.data(), csr.seq.data(), csr.pred_off.data(),
+                                csr.pred.empty() ? nullptr : csr.pred.data(), &impl_->graphs),
+          "pg_graphs_upload");
+    check(ctx, pg_graphs_build_path_index(ctx, impl_->graphs, (uint32_t)impl_->kmer_size), "pg_graphs_build_path_index");
+}
+
+void PathAligner::alignReads(std::vector<Read*> const& reads)
+{
+    if (!impl_->graphs)
+        throw std::logic_error("PathAligner::setGraph has not been called");
+    attempted_ += (unsigned)reads.size();
+    if (reads.empty())
+        return;
+    pg_ctx* ctx = deviceContext();
+    std::vector<uint32_t> base_off{ 0 }, gor(reads.size(), 0);
+    std::string bases;
+    for (Read* r : reads)
+    {
+        bases += r->bases();
+        base_off.push_back((uint32_t)bases.size());
+    }
+    std::vector<pg_result> res(reads.size());
+    std::vector<pg_op> ops(bases.size() + 48 * reads.size() + 1);
+    std::vector<uint8_t> flags(reads.size());
+    uint64_t n_ops = 0;
+    {
+        std::lock_guard<std::mutex> lock(deviceMutex());
+        pg_batch* b = nullptr;
+        check(ctx, pg_batch_create(ctx, &b), "pg_batch_create");
+        pg_status st = pg_batch_upload(ctx, b, impl_->graphs, (uint32_t)reads.size(), gor.data(), base_off.data(), bases.data());
+        if (st == PG_OK)
+            st = pg_batch_path_align(ctx, b);
+        if (st == PG_OK)
+            st = pg_batch_download_path_flags(ctx, b, flags.data());
+        if (st == PG_OK)
+            st = pg_batch_download(ctx, b, res.data(), ops.data(), ops.size(), &n_ops);
+        pg_batch_destroy(ctx, b);
+        check(ctx, st, "path stage");
+    }
+    for (size_t i = 0; i < reads.size(); ++i)
+    {
+        if (flags[i] & 2)
+            ++anchored_;
+        if (!(flags[i] & 1))
+            continue;
+        Read& read = *reads[i];
+        const pg_result& r = res[i];
+        // PathAligner.cpp:121-161
+        if (r.returned_reverse)
+            read.set_bases(reverseComplement(read.bases()));
+        read.set_is_graph_reverse_strand(r.returned_reverse != 0);
+        std::string buf(16 + 12 * (size_t)r.n_ops, '\0');
+        buf.resize(pg_render_cigar(&r, ops.data(), &buf[0], buf.size()));
+        read.set_graph_alignment_score(r.score);
+        read.set_graph_cigar(buf);
+        read.set_graph_pos(r.graph_pos);
+        read.set_graph_mapping_status(Read::MAPPED);
+        read.set_is_graph_alignment_unique(r.is_unique != 0);
+        read.set_graph_mapq(r.mapq);
+        ++mapped_;
+    }
+}
+
+void PathAligner::alignRead(Read& read)
+{
+    std::vector<Read*> one{ &read };
+    alignReads(one);
+}
+
 CompositeAligner::CompositeAligner(bool pathMatching, bool graphMatching, bool klibMatching, bool kmerMatching, unsigned flags)
     : pathMatching_(pathMatching), graphMatching_(graphMatching), klibMatching_(klibMatching), kmerMatching_(kmerMatching),
       grapAlignmentflags_(flags)
 {
-    if (pathMatching || klibMatching || kmerMatching)
-        throw std::logic_error("path / klib / kmer sequence matching are not implemented on the device yet "
-                               "(default grmpy cascade = graph sequence matching only)");
+    if (klibMatching || kmerMatching)
+        throw std::logic_error("klib / kmer sequence matching are not implemented on the device yet "
+                               "(available stages: path sequence matching, graph sequence matching)");
 }
 CompositeAligner::~CompositeAligner() = default;
 CompositeAligner::CompositeAligner(CompositeAligner&& rhs) noexcept = default;
 
-void CompositeAligner::setGraph(Graph const* graph, std::list<graphtools::Path> const&)
+void CompositeAligner::setGraph(Graph const* graph, std::list<graphtools::Path> const& paths)
 {
+    if (pathMatching_)
+        pathAligner_.setGraph(graph, paths);
     if (graphMatching_)
         graphAligner_.setGraph(graph);
 }
 
-void CompositeAligner::alignReads(std::vector<Read*> const& reads, ReadFilter filter)
+void CompositeAligner::alignReads(std::vector<Read*> const& all_reads, ReadFilter filter)
 {
-    attempted_ += (unsigned)reads.size();
-    if (!graphMatching_)
+    attempted_ += (unsigned)all_reads.size();
+    std::vector<Read*> reads = all_reads;
+    if (pathMatching_)
+    {
+        // CompositeAligner.cpp:82-103
+        const unsigned before = pathAligner_.mapped();
+        pathAligner_.alignReads(reads);
+        mappedPath_ += pathAligner_.mapped() - before;
+        anchoredPath_ = pathAligner_.anchored();
+        std::vector<Read*> rest;
+        for (Read* read : reads)
+        {
+            if (read->graph_mapping_status() == Read::MAPPED && filter && filter(*read))
+            {
+                read->set_graph_mapping_status(Read::BAD_ALIGN);
+                filtered_ += !kmerMatching_ && !klibMatching_ && !graphMatching_;
+            }
+            if (read->graph_mapping_status() != Read::MAPPED)
+                rest.push_back(read);
+        }
+        reads.swap(rest);
+    }
+    if (!graphMatching_ || reads.empty())
         return;
     graphAligner_.alignReads(reads, grapAlignmentflags_);
     for (Read* read : reads)

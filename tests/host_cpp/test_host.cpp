@@ -146,7 +146,7 @@ static void testCompositeAlignerFilter()
     bool threw = false;
     try
     {
-        CompositeAligner bad(true, true, false, false);
+        CompositeAligner bad(false, true, true, false);
     }
     catch (std::logic_error const&)
     {
@@ -218,10 +218,83 @@ static void testSiteBatcher()
     EXPECT_EQ(c1.by_edge.at("LF_RF").count, uint64_t(1));
 }
 
+static Graph deletionGraph(const char* l, const char* d, const char* r)
+{
+    // graphtools::makeDeletionGraph (GT!/src/graphcore/GraphBuilders.cpp): left -> {deletion, right}, deletion -> right
+    Graph g(3);
+    g.setNodeSeq(0, l);
+    g.setNodeSeq(1, d);
+    g.setNodeSeq(2, r);
+    g.addEdge(0, 1);
+    g.addEdge(0, 2);
+    g.addEdge(1, 2);
+    return g;
+}
+
+// PathAligner.Aligns_ExactMatch / Aligns_ExactMatchLongMEM / Aligns_MultipleMatches, src/c++/test/test_pathaligner.cpp:37-144
+static void testPathAligner()
+{
+    Graph g = deletionGraph("AAAAAAAAA", "CCCC", "GGGGGGGGG");
+    std::list<Path> paths;
+    PathAligner aligner(16);
+    aligner.setGraph(&g, paths);
+    struct Case
+    {
+        const char* bases;
+        bool bam_reverse;
+        int pos;
+        const char* cigar;
+        int score;
+        bool reverse;
+    } cases[] = { { "AAAAAAAAGGGGGGGG", false, 1, "0[8M]2[8M]", 16, false },
+                  { "CCCCCCCCTTTTTTTT", false, 1, "0[8M]2[8M]", 16, true },
+                  { "AAAAAAAACCCCGGGG", false, 1, "0[8M]1[4M]2[4M]", 16, false },
+                  { "CCCCGGGGTTTTTTTT", true, 1, "0[8M]1[4M]2[4M]", 16, true },
+                  { "AAAAAAAAGGGGGGGGG", false, 1, "0[8M]2[9M]", 17, false },
+                  { "CCCCCCCCCTTTTTTTTT", false, 0, "0[9M]2[9M]", 18, true } };
+    for (auto const& c : cases)
+    {
+        Read read;
+        read.setCoreInfo("f1", c.bases, "################");
+        read.set_is_reverse_strand(c.bam_reverse);
+        aligner.alignRead(read);
+        EXPECT_EQ(int(read.graph_mapping_status()), int(Read::MAPPED));
+        EXPECT_EQ(read.graph_pos(), c.pos);
+        EXPECT_EQ(read.graph_cigar(), std::string(c.cigar));
+        EXPECT_EQ(read.graph_alignment_score(), c.score);
+        EXPECT_EQ(read.is_graph_reverse_strand(), c.reverse);
+    }
+    Graph g2 = deletionGraph("GGGGGGGGGGGG", "CCCCCCCCCCCCCCCC", "GGGGGGGGGGGGGTGGG");
+    PathAligner aligner2(16);
+    aligner2.setGraph(&g2, paths);
+    Read read;
+    read.setCoreInfo("f1", "CCCCCCCCCCCCGGGGGGGGGGGG", "#####################################");
+    aligner2.alignRead(read);
+    EXPECT_EQ(int(read.graph_mapping_status()), int(Read::MAPPED));
+    EXPECT_EQ(read.graph_pos(), 4);
+    EXPECT_EQ(read.graph_cigar(), std::string("1[12M]2[12M]"));
+    EXPECT_EQ(read.graph_alignment_score(), 24);
+    EXPECT_EQ(read.is_graph_reverse_strand(), false);
+    EXPECT_EQ(read.is_graph_alignment_unique(), false);
+    EXPECT_EQ(read.graph_mapq(), 0);
+    // cascade: the exact read goes through the path stage, the mismatching one through gssw
+    Graph g3 = alignsGraph();
+    CompositeAligner comp(true, true, false, false);
+    comp.setGraph(&g3, paths);
+    Read exact("e", "AAAAAAAAAAATTTTTTTTAAAAAAAAAAA", ""), inexact("i", "AAAAAAAATTTTCTTTAAAAAAAA", "");
+    std::vector<Read*> both{ &exact, &inexact };
+    comp.alignReads(both, nullptr);
+    EXPECT_EQ(comp.mappedPath(), 0u);  // 30 bp read is shorter than the 32-mer index: falls through to gssw
+    EXPECT_EQ(comp.mappedSw(), 2u);
+    EXPECT_EQ(exact.graph_cigar(), std::string("0[11M]1[8M]3[11M]"));
+    EXPECT_EQ(inexact.graph_cigar(), std::string("0[8M]1[4M1X3M]3[8M]"));
+}
+
 int main()
 {
     try
     {
+        testPathAligner();
         testAlignReads();
         testGraphAlignerAlign();
         testCompositeAlignerFilter();

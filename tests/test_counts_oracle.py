@@ -93,3 +93,41 @@ def test_port_vs_reference_graphtools_randomized(checker):
             assert same(x, y), (g.nodes, g.edges, g.edge_labels, recs, kw)
             n += 1
     assert n == 1200
+
+
+def test_path_checker_unit_vectors_and_port_vs_ref():
+    """PathAligner checkers: reference unit tests (src/c++/test/test_pathaligner.cpp:37-144, k = 16) and the
+    pure-Python port against the harness built on the reference's graph-tools."""
+    from oracle import pathalign as pa
+    g1 = (["AAAAAAAAA", "CCCC", "GGGGGGGGG"], [(0, 1), (0, 2), (1, 2)])
+    reads = ["AAAAAAAAGGGGGGGG", "CCCCCCCCTTTTTTTT", "AAAAAAAACCCCGGGG", "CCCCGGGGTTTTTTTT", "AAAAAAAAGGGGGGGGG",
+             "CCCCCCCCCTTTTTTTTT"]
+    want = [(1, "0[8M]2[8M]", 16, False), (1, "0[8M]2[8M]", 16, True), (1, "0[8M]1[4M]2[4M]", 16, False),
+            (1, "0[8M]1[4M]2[4M]", 16, True), (1, "0[8M]2[9M]", 17, False), (0, "0[9M]2[9M]", 18, True)]
+    got = pa.port_path_align(*g1, reads, 16)
+    for g, (pos, cigar, score, rev) in zip(got, want):
+        assert (g["status"], g["graph_pos"], g["cigar"], g["score"], g["is_graph_reverse"], g["mapq"]) == \
+            (1, pos, cigar, score, rev, 60)
+    g2 = (["GGGGGGGGGGGG", "CCCCCCCCCCCCCCCC", "GGGGGGGGGGGGGTGGG"], [(0, 1), (0, 2), (1, 2)])
+    m = pa.port_path_align(*g2, ["CCCCCCCCCCCCGGGGGGGGGGGG"], 16)[0]
+    assert (m["graph_pos"], m["cigar"], m["score"], m["unique"], m["mapq"]) == (4, "1[12M]2[12M]", 24, False, 0)
+    if not pa.have_ref():
+        return
+    rng = random.Random(5)
+    n = 0
+    for _ in range(300):
+        seqs, edges = fuzzgen.rand_graph(rng, max_len=60, max_nodes=6)
+        k = rng.choice([8, 12, 16, 32])
+        rs = []
+        for _ in range(8):
+            p = fuzzgen.rand_path_seq(rng, seqs, edges)
+            st = rng.randrange(max(1, len(p)))
+            r = p[st:st + rng.randint(k, 80)]
+            if rng.random() < 0.3:
+                r = fuzzgen.mutate(rng, r, sub=0.02, indel=0.0)
+            if rng.random() < 0.4:
+                r = pa._rc(r)
+            rs.append(r or "A")
+        assert pa.ref_path_align(seqs, edges, rs, k) == pa.port_path_align(seqs, edges, rs, k), (seqs, edges, rs, k)
+        n += len(rs)
+    assert n == 2400

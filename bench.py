@@ -43,7 +43,8 @@ def parse_args():
                     help="config2 = BASELINE configs[1] (headline); config3 = configs[2]: mixed DEL/INS sites, 30x")
     ap.add_argument("--sites", type=int, default=2000, help="sites per GPU for --workload config3")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--workspace-gib", type=float, default=16.0)
+    ap.add_argument("--workspace-gib", type=float, default=64.0,
+                    help="HBM budget for traceback state (two halves: trace of chunk i overlaps fill of chunk i+1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_r01.json"),

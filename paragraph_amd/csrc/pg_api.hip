@@ -32,6 +32,7 @@ pg_status pg_fail(pg_ctx* ctx, pg_status st, const std::string& msg)
     return st;
 }
 static pg_status fail(pg_ctx* ctx, pg_status st, const std::string& msg) { return pg_fail(ctx, st, msg); }
+static void recycle_sync_events(pg_ctx* ctx);
 
 extern "C" const char* pg_strerror(pg_status st)
 {
@@ -62,7 +63,8 @@ extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
     if (!ctx)
         return PG_ERR_NOMEM;
     ctx->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess
+        || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess)
     {
         delete ctx;
         return PG_ERR_HIP;
@@ -78,6 +80,11 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2)
+        (void)hipStreamSynchronize(ctx->stream2);
+    recycle_sync_events(ctx);
+    for (auto e : ctx->sync_event_pool)
+        (void)hipEventDestroy(e);
     for (auto& e : ctx->events)
     {
         (void)hipEventDestroy(e.a);
@@ -91,6 +98,8 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
         (void)hipFree(ctx->ops_scratch);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2)
+        (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
 }
 
@@ -108,12 +117,15 @@ extern "C" pg_status pg_ctx_sync(pg_ctx* ctx)
         return PG_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
+    recycle_sync_events(ctx);
     return PG_OK;
 }
 
 static pg_status drain_events(pg_ctx* ctx)
 {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     for (auto& e : ctx->events)
     {
         float ms = 0.f;
@@ -165,6 +177,26 @@ extern "C" pg_status pg_ctx_timing_get(pg_ctx* ctx, pg_timing* out)
         return st;
     *out = ctx->acc;
     return PG_OK;
+}
+
+// ordering-only events (no timing) for the two-stream chunk pipeline; recycled whenever the ctx is synchronised
+static hipError_t get_sync_event(pg_ctx* ctx, hipEvent_t* ev)
+{
+    if (!ev)
+        return hipSuccess;
+    if (!ctx->sync_event_pool.empty())
+    {
+        *ev = ctx->sync_event_pool.back();
+        ctx->sync_event_pool.pop_back();
+        return hipSuccess;
+    }
+    return hipEventCreateWithFlags(ev, hipEventDisableTiming);
+}
+static void recycle_sync_events(pg_ctx* ctx)
+{
+    for (auto e : ctx->sync_events_in_flight)
+        ctx->sync_event_pool.push_back(e);
+    ctx->sync_events_in_flight.clear();
 }
 
 static hipError_t get_event(pg_ctx* ctx, hipEvent_t* ev)
@@ -514,9 +546,9 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active)
         const uint64_t trace_bytes = align_up(nsteps * 64 * pg_trace_lane_bytes(C), 256);
         const uint64_t seed_bytes = align_up((uint64_t)hg.n_nodes * 64 * C * 4, 256);
         const uint64_t need = trace_bytes + 2 * seed_bytes;
-        if (need > ctx->ws_limit)
+        if (need > ctx->ws_limit / 2)
             return fail(ctx, PG_ERR_UNSUPPORTED, "workspace limit too small for one wavefront of this graph");
-        if (open && (cur.C != C || cur.ws_bytes + need > ctx->ws_limit))
+        if (open && (cur.C != C || cur.ws_bytes + need > ctx->ws_limit / 2))
             close_chunk();
         if (!open)
         {
@@ -566,14 +598,16 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active)
     if (!items.empty())
         HIP_TRY(ctx, hipMemcpyAsync(b->d_items, items.data(), items.size() * sizeof(PgWorkItem), hipMemcpyHostToDevice, ctx->stream));
     // workspace / scratch owned by the ctx (shared by its batches)
-    if (b->max_ws > ctx->ws_cap)
+    if (2 * b->max_ws > ctx->ws_cap)
     {
+        // two halves: chunk i uses half (i & 1) so that trace(i) can overlap fill(i + 1)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
         if (ctx->workspace)
             HIP_TRY(ctx, hipFree(ctx->workspace));
         ctx->workspace = nullptr;
         ctx->ws_cap = 0;
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->workspace, b->max_ws));
-        ctx->ws_cap = b->max_ws;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->workspace, 2 * b->max_ws));
+        ctx->ws_cap = 2 * b->max_ws;
     }
     if (b->max_scratch > ctx->ops_scratch_cap)
     {
@@ -669,14 +703,30 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         return fail(ctx, PG_ERR_INVALID, "pg_batch_align: batch not uploaded");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const pg_graphs* G = b->graphs;
-    if (b->max_ws > ctx->ws_cap || b->max_scratch > ctx->ops_scratch_cap)
+    if (2 * b->max_ws > ctx->ws_cap || b->max_scratch > ctx->ops_scratch_cap)
         return fail(ctx, PG_ERR_INVALID, "ctx workspace was shrunk after the batch was planned");
     if (!(flags & PG_AF_KEEP_RESULTS) || (flags == PG_AF_ALL))
         HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
     const bool revg = (flags & PG_AF_REVERSE_GRAPH) != 0;
+    // Chunk pipeline on two streams: fill(i) runs on `stream`, pick+trace(i) on `stream2`; chunk i uses workspace
+    // half (i & 1), so the latency-bound traceback of chunk i overlaps the VALU-bound fill of chunk i+1.
+    const uint64_t half = ctx->ws_cap / 2;
+    std::vector<hipEvent_t> trace_done;
+    {
+        // the trace stream must see everything queued on the main stream so far (memsets, uploads, path stage)
+        hipEvent_t e0;
+        HIP_TRY(ctx, get_sync_event(ctx, &e0));
+        HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, e0, 0));
+        ctx->sync_events_in_flight.push_back(e0);
+    }
+    size_t ci = 0;
     for (const Chunk& ch : b->chunks)
     {
         const uint32_t n_pairs = ch.pair_end - ch.pair_begin;
+        uint8_t* ws = ctx->workspace + (ci & 1) * half;
+        if (ci >= 2)
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, trace_done[ci - 2], 0));  // workspace half is free again
         PgFillArgs fa{};
         fa.items = b->d_items;
         fa.item_begin = 2 * ch.pair_begin;
@@ -686,7 +736,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         fa.colmeta = G->d_colmeta;
         fa.base_off = b->d_base_off;
         fa.bases = b->d_bases;
-        fa.workspace = ctx->workspace;
+        fa.workspace = ws;
         fa.fillsum = b->d_fillsum;
         EventPair ev{};
         if (ctx->timing)
@@ -705,6 +755,11 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             ctx->acc.cells += revg ? ch.cells : ch.cells / 2;
             ctx->acc.trace_bytes += ch.trace_bytes;
         }
+        hipEvent_t fill_done;
+        HIP_TRY(ctx, get_sync_event(ctx, &fill_done));
+        HIP_TRY(ctx, hipEventRecord(fill_done, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, fill_done, 0));
+        ctx->sync_events_in_flight.push_back(fill_done);
         PgTraceArgs ta{};
         ta.items = b->d_items;
         ta.pair_begin = ch.pair_begin;
@@ -717,7 +772,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         ta.seqchars = G->d_seqchars;
         ta.base_off = b->d_base_off;
         ta.bases = b->d_bases;
-        ta.workspace = ctx->workspace;
+        ta.workspace = ws;
         ta.fillsum = b->d_fillsum;
         ta.results = b->d_results;
         ta.ops_scratch = ctx->ops_scratch;
@@ -728,15 +783,24 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             HIP_TRY(ctx, get_event(ctx, &ev.a));
             HIP_TRY(ctx, get_event(ctx, &ev.b));
             ev.kind = 1;
-            HIP_TRY(ctx, hipEventRecord(ev.a, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ev.a, ctx->stream2));
         }
-        HIP_TRY(ctx, pg_launch_trace(ta, ctx->stream));
+        HIP_TRY(ctx, pg_launch_trace(ta, ctx->stream2));
         if (ctx->timing)
         {
-            HIP_TRY(ctx, hipEventRecord(ev.b, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ev.b, ctx->stream2));
             ctx->events.push_back(ev);
         }
+        hipEvent_t td;
+        HIP_TRY(ctx, get_sync_event(ctx, &td));
+        HIP_TRY(ctx, hipEventRecord(td, ctx->stream2));
+        trace_done.push_back(td);
+        ctx->sync_events_in_flight.push_back(td);
+        ++ci;
     }
+    // everything later on the main stream (count path, downloads) sees the finished tracebacks
+    for (size_t k = trace_done.size() >= 2 ? trace_done.size() - 2 : 0; k < trace_done.size(); ++k)
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, trace_done[k], 0));
     return PG_OK;
 }
 

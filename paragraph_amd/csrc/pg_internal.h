@@ -34,6 +34,8 @@ struct pg_ctx
 {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // pick + traceback of chunk i overlaps the fill of chunk i + 1
+    std::vector<hipEvent_t> sync_event_pool, sync_events_in_flight;
     uint64_t ws_limit = 8ull << 30;
     uint8_t* workspace = nullptr;
     uint64_t ws_cap = 0;

@@ -139,3 +139,26 @@ def test_host_cpp_mirror():
         build.build_host()
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_many_tiny_nodes(gpu_ctx, checker):
+    """Graphs with hundreds of 1-4 bp nodes: single-column nodes (FIRST and LAST on the same column), long
+    predecessor lists, seeds on every column, node-key table far larger than the profile."""
+    import random
+    rng = random.Random(4321)
+    graphs, reads, gor, want = [], [], [], []
+    for gi in range(6):
+        n = rng.choice([60, 150, 300])
+        seqs = [fuzzgen.rand_seq(rng, rng.randint(1, 4), "rand") for _ in range(n)]
+        edges = set()
+        for t in range(1, n):
+            for f in rng.sample(range(max(0, t - 6), t), min(t, rng.randint(1, 3))):
+                edges.add((f, t))
+        edges = sorted(edges)
+        rs = [fuzzgen.rand_read(rng, seqs, edges, min_len=20, max_len=140) for _ in range(12)]
+        graphs.append((seqs, edges))
+        reads.extend(rs)
+        gor.extend([gi] * len(rs))
+        want.extend(checker.align_batch(seqs, edges, rs))
+    got = gpu_align(gpu_ctx, graphs, reads, gor)
+    compare(got, want, reads, "tiny-nodes")

@@ -80,7 +80,8 @@ def cpu_baseline(site, arr, seconds):
             worse += 1
         t *= 2
     done, spent, pos = 0, 0.0, 0
-    slice_n = max(best_t * 16, int(best_rate * 2.0))
+    # short slices: gssw's per-fill malloc/free churn degrades long single calls on glibc (heap growth per thread)
+    slice_n = 512 * best_t
     while spent < seconds and pos < len(reads):
         n = min(slice_n, len(reads) - pos)
         t0 = time.perf_counter()

@@ -23,6 +23,7 @@
  *   pg_render_cigar      GraphAlignerImpl::extractCigar         GraphAligner.cpp:88-108
  *   pg_graphs_set_labels graphtools::Graph::addLabelToEdge as grm::graphFromJson fills it   src/c++/lib/grm/GraphInput.cpp:126-156
  *   pg_graphs_build_path_index / pg_batch_path_align   grm::PathAligner::{setGraph,alignRead}   src/c++/lib/grm/PathAligner.cpp:70-164
+ *   pg_graphs_build_kmer_index / pg_batch_kmer_align   grm::KmerAligner<16>::{setGraph,alignRead}   src/c++/lib/grm/KmerAligner.cpp:305-538
  *   pg_batch_set_active  the `status != MAPPED` hand-over between cascade stages   src/c++/lib/grm/CompositeAligner.cpp:78-176
  *   pg_batch_set_fragments   Read::fragment_id / is_reverse_strand of the input reads   src/c++/include/common/Read.hh:40-120
  *   pg_batch_count       read filters (NonUniq, BadAlign) applied by CompositeAligner::alignRead
@@ -103,6 +104,7 @@ typedef struct pg_result
                                  PG_STATUS_PATH_ALIGNER is or-ed in when the PathAligner stage produced the record */
 } pg_result;
 #define PG_STATUS_PATH_ALIGNER 0x100u
+#define PG_STATUS_KMER_ALIGNER 0x200u
 
 /* One run-length CIGAR element inside a node: node id (12 bits) | op (4 bits) | length (16 bits). */
 typedef uint32_t pg_op;
@@ -252,9 +254,24 @@ pg_status pg_graphs_build_path_index(pg_ctx* ctx, pg_graphs* graphs, uint32_t km
  * pg_result (status has PG_STATUS_PATH_ALIGNER set; is_graph_reverse_strand = returned_reverse, NOT xor-ed with the
  * BAM strand, PathAligner.cpp:121-129) and ops.  Resets the batch's results/ops.  Asynchronous. */
 pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* batch);
-/* flags[i]: bit0 = MAPPED by the path stage, bit1 = anchored (a unique k-mer was found); synchronises */
+/* flags[i] of the LAST seed stage run: bit0 = MAPPED, bit1 = anchored (path stage: a unique k-mer was found),
+ * bit2 = BAD_ALIGN (k-mer stage); synchronises */
 pg_status pg_batch_download_path_flags(pg_ctx* ctx, pg_batch* batch, uint8_t* flags);
-/* Restricts the following pg_batch_align calls to reads with active[i] != 0 (NULL = every read): the next
+/* ---------------------------------------------------------------------------------------------------
+ * k-mer seed stage (grm::KmerAligner<16>, --kmer-sequence-matching; default OFF in both CLIs)
+ * ------------------------------------------------------------------------------------------------- */
+/* Paths of every graph (grm::pathsFromJson, GraphInput.cpp:163-196): graph g owns paths [path_off[g], path_off[g+1]),
+ * path p = node ids path_nodes[path_node_off[p] .. path_node_off[p+1]) (whole nodes, first to last).  Builds the
+ * per-path sorted (k-mer, position) tables; kmer_len <= 16 (the reference instantiates 16; its unit test 10). */
+pg_status pg_graphs_build_kmer_index(
+    pg_ctx* ctx, pg_graphs* graphs, uint32_t kmer_len, const uint32_t* path_off, const uint32_t* path_node_off,
+    const uint32_t* path_nodes);
+/* KmerAligner::alignRead for every ACTIVE read: results get PG_STATUS_KMER_ALIGNER; stage flags (see
+ * pg_batch_download_path_flags): bit0 MAPPED, bit2 BAD_ALIGN (several equally good, different alignments).
+ * flags: PG_AF_KEEP_RESULTS keeps earlier stages' results/ops.  Asynchronous. */
+pg_status pg_batch_kmer_align(pg_ctx* ctx, pg_batch* batch, uint32_t flags);
+
+/* Restricts the following stage calls (pg_batch_path_align / pg_batch_kmer_align / pg_batch_align) to reads with active[i] != 0 (NULL = every read): the next
  * stage of the cascade runs only on reads the previous stage left unmapped / filtered. */
 pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* batch, const uint8_t* active);
 

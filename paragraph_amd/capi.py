@@ -17,6 +17,7 @@ AF_REVERSE_GRAPH = 4
 AF_ALL = 0xFFFFFFFF
 AF_KEEP_RESULTS = 0x100
 STATUS_PATH_ALIGNER = 0x100
+STATUS_KMER_ALIGNER = 0x200
 
 PG_OK = 0
 STATUS_NAMES = {0: "PG_OK", 1: "PG_ERR_INVALID", 2: "PG_ERR_NO_DEVICE", 3: "PG_ERR_HIP", 4: "PG_ERR_UNSUPPORTED",
@@ -42,7 +43,8 @@ EXPORTS = [
     "pg_batch_create", "pg_batch_destroy", "pg_batch_upload", "pg_batch_align", "pg_batch_ops_count",
     "pg_batch_download", "pg_align_batch", "pg_render_cigar", "pg_graphs_set_labels", "pg_graphs_count_layout",
     "pg_graphs_seq_offsets", "pg_batch_set_fragments", "pg_batch_count", "pg_batch_download_counts", "pg_graphs_build_path_index",
-    "pg_batch_path_align", "pg_batch_download_path_flags", "pg_batch_set_active",
+    "pg_batch_path_align", "pg_batch_download_path_flags", "pg_batch_set_active", "pg_graphs_build_kmer_index",
+    "pg_batch_kmer_align",
 ]
 
 
@@ -138,6 +140,10 @@ def load_library():
     L.pg_batch_download_path_flags.argtypes = [vp, vp, vp]
     L.pg_batch_set_active.restype = C.c_int32
     L.pg_batch_set_active.argtypes = [vp, vp, vp]
+    L.pg_graphs_build_kmer_index.restype = C.c_int32
+    L.pg_graphs_build_kmer_index.argtypes = [vp, vp, C.c_uint32, u32p, u32p, u32p]
+    L.pg_batch_kmer_align.restype = C.c_int32
+    L.pg_batch_kmer_align.argtypes = [vp, vp, C.c_uint32]
     L.pg_render_cigar.restype = C.c_size_t
     L.pg_render_cigar.argtypes = [vp, vp, C.c_char_p, C.c_size_t]
     _lib = L
@@ -254,6 +260,17 @@ class Graphs:
     def build_path_index(self, kmer_len=32):
         self.ctx._chk(self.ctx.L.pg_graphs_build_path_index(self.ctx.h, self.h, kmer_len))
 
+    def build_kmer_index(self, paths, kmer_len=16):
+        """paths: per graph a list of node-id lists (whole-node paths as grm::pathsFromJson builds them)."""
+        poff, noff, nodes = [0], [0], []
+        for gp in paths:
+            for p in gp:
+                nodes.extend(p)
+                noff.append(len(nodes))
+            poff.append(len(noff) - 1)
+        poff, noff, nodes = _u32(poff), _u32(noff), _u32(nodes if nodes else [0])
+        self.ctx._chk(self.ctx.L.pg_graphs_build_kmer_index(self.ctx.h, self.h, kmer_len, _p32(poff), _p32(noff), _p32(nodes)))
+
     def set_labels(self, edge_labels, labels=None):
         """edge_labels: per graph a dict {(from,to): [label,...]}; labels: per graph the ordered label list
         (default: sorted names).  Counters of edges come back in predecessor-CSR order = self.edges[g]."""
@@ -324,6 +341,13 @@ class Batch:
     def path_align(self):
         """PathAligner stage for every read; returns flags (bit0 mapped, bit1 anchored)."""
         self.ctx._chk(self.ctx.L.pg_batch_path_align(self.ctx.h, self.h))
+        fl = np.zeros(max(self.n_reads, 1), dtype=np.uint8)
+        self.ctx._chk(self.ctx.L.pg_batch_download_path_flags(self.ctx.h, self.h, fl.ctypes.data))
+        return fl[:self.n_reads]
+
+    def kmer_align(self, flags=AF_ALL):
+        """KmerAligner stage for every active read; returns flags (bit0 mapped, bit2 BAD_ALIGN)."""
+        self.ctx._chk(self.ctx.L.pg_batch_kmer_align(self.ctx.h, self.h, flags & 0xFFFFFFFF))
         fl = np.zeros(max(self.n_reads, 1), dtype=np.uint8)
         self.ctx._chk(self.ctx.L.pg_batch_download_path_flags(self.ctx.h, self.h, fl.ctypes.data))
         return fl[:self.n_reads]

@@ -418,6 +418,7 @@ extern "C" void pg_graphs_destroy(pg_ctx* ctx, pg_graphs* G)
     (void)hipFree(G->d_out_mask);
     (void)hipFree(G->d_in_mask);
     pg_path_index_free(G->path_index);
+    pg_kmer_index_free(G->kmer_index);
     delete G;
 }
 
@@ -444,6 +445,9 @@ static void batch_free_device(pg_batch* b)
     (void)hipFree(b->d_graph_of_read);
     (void)hipFree(b->d_path_flags);
     b->d_path_flags = nullptr;
+    (void)hipFree(b->d_active);
+    b->d_active = nullptr;
+    b->has_active = false;
     (void)hipFree(b->d_support);
     (void)hipFree(b->d_path);
     (void)hipFree(b->d_path_counter);
@@ -634,6 +638,7 @@ extern "C" pg_status pg_batch_upload(
     b->n_reads = n_reads;
     b->has_skipped = false;
     b->fragments_set = false;
+    b->has_active = false;
     b->host_template.assign(n_reads, pg_result{});
     uint64_t ops_total = 0;
     for (uint32_t i = 0; i < n_reads; ++i)
@@ -674,6 +679,7 @@ extern "C" pg_status pg_batch_upload(
         HIP_TRY(ctx, hipMalloc((void**)&b->d_ops_counter, sizeof(unsigned long long)));
         HIP_TRY(ctx, hipMalloc((void**)&b->d_graph_of_read, b->cap_reads * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMalloc((void**)&b->d_path_flags, b->cap_reads));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_active, b->cap_reads));
     }
     if (n_reads)
     {
@@ -694,6 +700,9 @@ extern "C" pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* b, const uint8_t
         return fail(ctx, PG_ERR_INVALID, "pg_batch_set_active: batch not uploaded");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    b->has_active = active != nullptr;
+    if (active && b->n_reads)
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_active, active, b->n_reads, hipMemcpyHostToDevice, ctx->stream));
     return plan_items(ctx, b, active);
 }
 

@@ -50,6 +50,8 @@ struct pg_ctx
 
 struct pg_path_index;
 void pg_path_index_free(pg_path_index* ix);
+struct pg_kmer_index;
+void pg_kmer_index_free(pg_kmer_index* ix);
 
 struct pg_graphs
 {
@@ -68,6 +70,7 @@ struct pg_graphs
     std::vector<uint32_t> h_nodeseq_off;  // total_nodes + 1, into h_seq_raw
     std::string h_seq_raw;            // node sequences exactly as given (the path stage compares raw characters)
     pg_path_index* path_index = nullptr;
+    pg_kmer_index* kmer_index = nullptr;
     std::vector<uint32_t> h_n_labels;  // per graph
     std::vector<uint64_t> h_seq_off;   // n_graphs + 1 (dense sequence-set slots)
     bool labels_set = false;
@@ -102,7 +105,9 @@ struct pg_batch
     // ---- count path
     std::vector<uint32_t> h_graph_of_read;
     std::vector<uint32_t> h_base_off;
-    uint8_t* d_path_flags = nullptr;  // per read: bit0 mapped by the path stage, bit1 anchored
+    uint8_t* d_path_flags = nullptr;  // per read: bit0 mapped by the last seed stage, bit1 anchored, bit2 BAD_ALIGN
+    uint8_t* d_active = nullptr;      // per read: 0 = skipped by the stage kernels (NULL semantics via has_active)
+    bool has_active = false;
     uint32_t* d_graph_of_read = nullptr;
     pg_read_support* d_support = nullptr;
     uint32_t* d_path = nullptr;

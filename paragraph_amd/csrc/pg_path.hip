@@ -71,6 +71,7 @@ struct PathArgs
     pg_op* ops;
     unsigned long long* ops_counter;
     uint8_t* flags;
+    const uint8_t* active;  // nullptr = every read
 };
 
 __device__ __forceinline__ uint32_t comp_raw(uint32_t c)
@@ -254,7 +255,7 @@ struct Walker
 __global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
 {
     const uint32_t r = blockIdx.x * 64u + threadIdx.x;
-    if (r >= a.n_reads)
+    if (r >= a.n_reads || (a.active && !a.active[r]))
         return;
     const uint32_t off = a.base_off[r];
     const int L = (int)(a.base_off[r + 1] - off);
@@ -600,6 +601,7 @@ extern "C" pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* b)
     a.ops = b->d_ops;
     a.ops_counter = b->d_ops_counter;
     a.flags = b->d_path_flags;
+    a.active = b->has_active ? b->d_active : nullptr;
     if (b->n_reads)
     {
         hipLaunchKernelGGL(pg_path_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);

@@ -1,12 +1,13 @@
 // grm::CompositeAligner (src/c++/include/grm/CompositeAligner.hh:44-91): the aligner cascade
 // path -> kmer -> klib -> gssw with a filter after each stage.  On the device build the path and gssw stages
-// exist; asking for kmer / klib matching throws std::logic_error.
+// and the k-mer stage exist; asking for klib matching throws std::logic_error.
 #pragma once
 #include <list>
 #include <vector>
 
 #include "grm/Filter.hh"
 #include "grm/GraphAligner.hh"
+#include "grm/KmerAligner.hh"
 #include "grm/PathAligner.hh"
 
 namespace grm
@@ -39,6 +40,7 @@ private:
     const unsigned int grapAlignmentflags_;
     PathAligner pathAligner_;
     GraphAligner graphAligner_;
+    KmerAligner<16> kmerAligner_;
     unsigned attempted_ = 0, filtered_ = 0, mappedKlib_ = 0, mappedPath_ = 0, anchoredPath_ = 0, mappedKmers_ = 0,
              mappedSw_ = 0;
 };

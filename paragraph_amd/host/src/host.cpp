@@ -12,6 +12,7 @@
 #include "grm/Align.hh"
 #include "grm/CompositeAligner.hh"
 #include "grm/GraphAligner.hh"
+#include "grm/KmerAligner.hh"
 #include "grm/PathAligner.hh"
 #include "paragraph/SiteBatcher.hh"
 
@@ -302,13 +303,107 @@ void PathAligner::alignRead(Read& read)
     alignReads(one);
 }
 
+struct KmerAlignerBase::Impl
+{
+    unsigned k = 16;
+    pg_graphs* graphs = nullptr;
+    ~Impl()
+    {
+        if (graphs)
+            pg_graphs_destroy(deviceContext(), graphs);
+    }
+};
+
+KmerAlignerBase::KmerAlignerBase(unsigned kmer_length) : impl_(new Impl()) { impl_->k = kmer_length; }
+KmerAlignerBase::~KmerAlignerBase() = default;
+KmerAlignerBase::KmerAlignerBase(KmerAlignerBase&& rhs) noexcept = default;
+KmerAlignerBase& KmerAlignerBase::operator=(KmerAlignerBase&& rhs) noexcept = default;
+
+void KmerAlignerBase::setGraph(Graph const* g, std::list<graphtools::Path> const& paths)
+{
+    pg_ctx* ctx = deviceContext();
+    std::lock_guard<std::mutex> lock(deviceMutex());
+    if (impl_->graphs)
+        pg_graphs_destroy(ctx, impl_->graphs);
+    impl_->graphs = nullptr;
+    GraphCsr csr;
+    csr.add(*g);
+    check(ctx, pg_graphs_upload(ctx, 1, csr.node_off.data(), csr.seq_off.data(), csr.seq.data(), csr.pred_off.data(),
+                                csr.pred.empty() ? nullptr : csr.pred.data(), &impl_->graphs),
+          "pg_graphs_upload");
+    std::vector<uint32_t> path_off{ 0, (uint32_t)paths.size() }, node_off{ 0 }, nodes;
+    for (auto const& p : paths)
+    {
+        nodes.insert(nodes.end(), p.nodes.begin(), p.nodes.end());
+        node_off.push_back((uint32_t)nodes.size());
+    }
+    if (nodes.empty())
+        nodes.push_back(0);
+    check(ctx, pg_graphs_build_kmer_index(ctx, impl_->graphs, impl_->k, path_off.data(), node_off.data(), nodes.data()),
+          "pg_graphs_build_kmer_index");
+}
+
+void KmerAlignerBase::alignReads(std::vector<Read*> const& reads)
+{
+    if (!impl_->graphs)
+        throw std::logic_error("KmerAligner::setGraph has not been called");
+    attempted_ += (unsigned)reads.size();
+    if (reads.empty())
+        return;
+    pg_ctx* ctx = deviceContext();
+    std::vector<uint32_t> base_off{ 0 }, gor(reads.size(), 0);
+    std::string bases;
+    for (Read* r : reads)
+    {
+        bases += r->bases();
+        base_off.push_back((uint32_t)bases.size());
+        r->set_graph_mapping_status(Read::UNMAPPED);  // KmerAligner.cpp:519
+    }
+    std::vector<pg_result> res(reads.size());
+    std::vector<pg_op> ops(bases.size() + 48 * reads.size() + 1);
+    std::vector<uint8_t> flags(reads.size());
+    uint64_t n_ops = 0;
+    {
+        std::lock_guard<std::mutex> lock(deviceMutex());
+        pg_batch* b = nullptr;
+        check(ctx, pg_batch_create(ctx, &b), "pg_batch_create");
+        pg_status st = pg_batch_upload(ctx, b, impl_->graphs, (uint32_t)reads.size(), gor.data(), base_off.data(), bases.data());
+        if (st == PG_OK)
+            st = pg_batch_kmer_align(ctx, b, PG_AF_ALL);
+        if (st == PG_OK)
+            st = pg_batch_download_path_flags(ctx, b, flags.data());
+        if (st == PG_OK)
+            st = pg_batch_download(ctx, b, res.data(), ops.data(), ops.size(), &n_ops);
+        pg_batch_destroy(ctx, b);
+        check(ctx, st, "k-mer stage");
+    }
+    for (size_t i = 0; i < reads.size(); ++i)
+    {
+        if (!(flags[i] & 5))
+            continue;
+        Read& read = *reads[i];
+        // KmerAligner.cpp:424-472 (updateAlignment) + 497-505
+        applyResult(read, res[i], ops.data(), true);
+        read.set_graph_mapq(res[i].mapq);
+        read.set_is_graph_alignment_unique(res[i].is_unique != 0);
+        read.set_graph_mapping_status((flags[i] & 1) ? Read::MAPPED : Read::BAD_ALIGN);
+        mapped_ += (flags[i] & 1) != 0;
+    }
+}
+
+void KmerAlignerBase::alignRead(Read& read)
+{
+    std::vector<Read*> one{ &read };
+    alignReads(one);
+}
+
 CompositeAligner::CompositeAligner(bool pathMatching, bool graphMatching, bool klibMatching, bool kmerMatching, unsigned flags)
     : pathMatching_(pathMatching), graphMatching_(graphMatching), klibMatching_(klibMatching), kmerMatching_(kmerMatching),
       grapAlignmentflags_(flags)
 {
-    if (klibMatching || kmerMatching)
-        throw std::logic_error("klib / kmer sequence matching are not implemented on the device yet "
-                               "(available stages: path sequence matching, graph sequence matching)");
+    if (klibMatching)
+        throw std::logic_error("klib sequence matching is not implemented on the device yet "
+                               "(available stages: path, kmer and graph sequence matching)");
 }
 CompositeAligner::~CompositeAligner() = default;
 CompositeAligner::CompositeAligner(CompositeAligner&& rhs) noexcept = default;
@@ -319,6 +414,8 @@ void CompositeAligner::setGraph(Graph const* graph, std::list<graphtools::Path> 
         pathAligner_.setGraph(graph, paths);
     if (graphMatching_)
         graphAligner_.setGraph(graph);
+    if (kmerMatching_)
+        kmerAligner_.setGraph(graph, paths);
 }
 
 void CompositeAligner::alignReads(std::vector<Read*> const& all_reads, ReadFilter filter)
@@ -339,6 +436,28 @@ void CompositeAligner::alignReads(std::vector<Read*> const& all_reads, ReadFilte
             {
                 read->set_graph_mapping_status(Read::BAD_ALIGN);
                 filtered_ += !kmerMatching_ && !klibMatching_ && !graphMatching_;
+            }
+            if (read->graph_mapping_status() != Read::MAPPED)
+                rest.push_back(read);
+        }
+        reads.swap(rest);
+    }
+    if (kmerMatching_ && !reads.empty())
+    {
+        // CompositeAligner.cpp:105-126
+        kmerAligner_.alignReads(reads);
+        std::vector<Read*> rest;
+        for (Read* read : reads)
+        {
+            if (read->graph_mapping_status() == Read::MAPPED)
+            {
+                if (filter && filter(*read))
+                {
+                    read->set_graph_mapping_status(Read::BAD_ALIGN);
+                    filtered_ += !klibMatching_ && !graphMatching_;
+                }
+                else
+                    ++mappedKmers_;
             }
             if (read->graph_mapping_status() != Read::MAPPED)
                 rest.push_back(read);

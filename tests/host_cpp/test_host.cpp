@@ -290,10 +290,52 @@ static void testPathAligner()
     EXPECT_EQ(inexact.graph_cigar(), std::string("0[8M]1[4M1X3M]3[8M]"));
 }
 
+// KmerAlignerTest.Aligns, src/c++/test/test_kmeraligner.cpp:44-193 (KmerAligner<10>, paths P / Q / D)
+static void testKmerAligner()
+{
+    Graph graph = alignsGraph();
+    std::list<Path> paths;
+    for (auto const& nodes : std::vector<std::vector<NodeId>>{ { 0, 1, 3 }, { 0, 2, 3 }, { 0, 3 } })
+    {
+        Path p;
+        p.graph = &graph;
+        p.nodes = nodes;
+        p.end_position = (int32_t)graph.nodeSeq(nodes.back()).size() - 1;
+        paths.push_back(p);
+    }
+    KmerAligner<10> aligner;
+    aligner.setGraph(&graph, paths);
+    struct Case
+    {
+        const char* bases;
+        int status, pos;
+        const char* cigar;
+        int score;
+        bool reverse;
+    } cases[] = { { "AAAAAAAATTTTTTTTAAAAAAAA", Read::MAPPED, 3, "0[8M]1[8M]3[8M]", 24, false },
+                  { "TTTTTTAAAAAAAATTTTTTT", Read::MAPPED, 4, "0[7M]1[8M]3[6M]", 21, true },
+                  { "AAAAAGGGGGGGGAAAAAA", Read::MAPPED, 6, "0[5M]2[8M]3[6M]", 19, false },
+                  { "AAAAGGGGGGGGAAAAAA", Read::MAPPED, 7, "0[4M]2[8M]3[6M]", 18, false },
+                  { "TTTTTTCCCCCCCCTTTTT", Read::MAPPED, 6, "0[5M]2[8M]3[6M]", 19, true },
+                  { "AAAAAAAAAAAAAAAAAAA", Read::BAD_ALIGN, 0, "0[11M]3[8M]", 19, false } };
+    for (auto const& c : cases)
+    {
+        Read read("f", c.bases, "");
+        aligner.alignRead(read);
+        EXPECT_EQ(int(read.graph_mapping_status()), c.status);
+        EXPECT_EQ(read.graph_pos(), c.pos);
+        EXPECT_EQ(read.graph_cigar(), std::string(c.cigar));
+        EXPECT_EQ(read.graph_alignment_score(), c.score);
+        EXPECT_EQ(read.is_graph_reverse_strand(), c.reverse);
+        EXPECT_EQ(read.graph_mapq(), c.status == Read::MAPPED ? 60 : 0);
+    }
+}
+
 int main()
 {
     try
     {
+        testKmerAligner();
         testPathAligner();
         testAlignReads();
         testGraphAlignerAlign();

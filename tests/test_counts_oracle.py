@@ -131,3 +131,19 @@ def test_path_checker_unit_vectors_and_port_vs_ref():
         assert pa.ref_path_align(seqs, edges, rs, k) == pa.port_path_align(seqs, edges, rs, k), (seqs, edges, rs, k)
         n += len(rs)
     assert n == 2400
+
+
+def test_kmer_checker_unit_vectors():
+    """KmerAlignerTest.Aligns, src/c++/test/test_kmeraligner.cpp:149-193 (KmerAligner<10>)."""
+    from oracle import kmeralign as ka
+    nodes = ["AAAAAAAAAAA", "TTTTTTTT", "GGGGGGGG", "AAAAAAAAAAA"]
+    paths = [[0, 1, 3], [0, 2, 3], [0, 3]]
+    reads = ["AAAAAAAATTTTTTTTAAAAAAAA", "TTTTTTAAAAAAAATTTTTTT", "AAAAAGGGGGGGGAAAAAA", "AAAAGGGGGGGGAAAAAA",
+             "TTTTTTCCCCCCCCTTTTT", "AAAAAAAAAAAAAAAAAAA"]
+    want = [(1, 3, "0[8M]1[8M]3[8M]", 24, False, 60), (1, 4, "0[7M]1[8M]3[6M]", 21, True, 60),
+            (1, 6, "0[5M]2[8M]3[6M]", 19, False, 60), (1, 7, "0[4M]2[8M]3[6M]", 18, False, 60),
+            (1, 6, "0[5M]2[8M]3[6M]", 19, True, 60), (2, 0, "0[11M]3[8M]", 19, False, 0)]
+    got = ka.port_kmer_align(nodes, paths, reads, 10)
+    for g, (st, pos, cigar, score, rev, mapq) in zip(got, want):
+        assert (g["status"], g["graph_pos"], g["cigar"], g["score"], g["is_graph_reverse"], g["mapq"]) == \
+            (st, pos, cigar, score, rev, mapq)

@@ -1,0 +1,107 @@
+"""GPU parity of the k-mer seed stage (grm::KmerAligner) against the Python restatement (oracle/kmeralign.py,
+pinned on the reference's unit test src/c++/test/test_kmeraligner.cpp:149-193)."""
+import random
+
+import pytest
+
+from tests import fuzzgen
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("graph_pos", "score", "cigar")
+
+
+def gpu_kmer(ctx, graphs, paths, reads, gor, k):
+    from paragraph_amd import capi
+    G = ctx.upload_graphs(graphs)
+    G.build_kmer_index(paths, k)
+    b = ctx.new_batch()
+    b.upload(G, reads, gor)
+    flags = b.kmer_align()
+    res, ops = b.download()
+    out = capi.results_to_dicts(res, ops)
+    b.close()
+    G.close()
+    return flags, out
+
+
+def check(flags, got, want, reads, what):
+    n = 0
+    for i, (f, g, w) in enumerate(zip(flags, got, want)):
+        st = 1 if f & 1 else (2 if f & 4 else 0)
+        assert st == w["status"], (what, i, reads[i], f, g, w)
+        if st:
+            n += 1
+            assert all(g[key] == w[key] for key in KEYS) and g["returned_reverse"] == w["used_reverse"], (what, i, reads[i], g, w)
+            assert g["mapq"] == w["mapq"] and g["unique"] == w["unique"]
+    return n
+
+
+def test_reference_unit_vectors(gpu_ctx):
+    from oracle import kmeralign as ka
+    nodes = ["AAAAAAAAAAA", "TTTTTTTT", "GGGGGGGG", "AAAAAAAAAAA"]
+    edges = [(0, 1), (0, 2), (0, 3), (1, 3), (2, 3)]
+    paths = [[0, 1, 3], [0, 2, 3], [0, 3]]
+    reads = ["AAAAAAAATTTTTTTTAAAAAAAA", "TTTTTTAAAAAAAATTTTTTT", "AAAAAGGGGGGGGAAAAAA", "AAAAGGGGGGGGAAAAAA",
+             "TTTTTTCCCCCCCCTTTTT", "AAAAAAAAAAAAAAAAAAA"]
+    want = [(1, 3, "0[8M]1[8M]3[8M]", 24, False), (1, 4, "0[7M]1[8M]3[6M]", 21, True), (1, 6, "0[5M]2[8M]3[6M]", 19, False),
+            (1, 7, "0[4M]2[8M]3[6M]", 18, False), (1, 6, "0[5M]2[8M]3[6M]", 19, True), (2, 0, "0[11M]3[8M]", 19, False)]
+    flags, got = gpu_kmer(gpu_ctx, [(nodes, edges)], [paths], reads, None, 10)
+    for f, g, (st, pos, cigar, score, rev) in zip(flags, got, want):
+        assert (1 if f & 1 else (2 if f & 4 else 0)) == st
+        assert (g["graph_pos"], g["cigar"], g["score"], g["returned_reverse"]) == (pos, cigar, score, rev)
+    assert ka.port_kmer_align(nodes, paths, reads, 10)[5]["status"] == 2
+
+
+def _rand_paths(rng, n_nodes, edges):
+    succ = {}
+    for f, t in edges:
+        succ.setdefault(f, []).append(t)
+    roots = [i for i in range(n_nodes) if not any(t == i for _, t in edges)] or [0]
+    paths = []
+    for _ in range(rng.randint(1, 4)):
+        cur = rng.choice(roots)
+        p = [cur]
+        while cur in succ:
+            cur = rng.choice(succ[cur])
+            p.append(cur)
+        if p not in paths:
+            paths.append(p)
+    return paths
+
+
+@pytest.mark.parametrize("k", [10, 16])
+def test_kmer_stage_fuzz(gpu_ctx, k):
+    from oracle import kmeralign as ka
+    from oracle.pathalign import _rc
+    rng = random.Random(77 + k)
+    graphs, paths, reads, gor, want = [], [], [], [], []
+    for gi in range(150):
+        seqs, edges = fuzzgen.rand_graph(rng, max_len=50, max_nodes=6, shape=rng.choice(["del", "bubble", "dag", "longdel"]))
+        seqs = [s.replace("X", "N") if rng.random() < 0.5 else s for s in seqs]
+        ps = _rand_paths(rng, len(seqs), edges)
+        rs = []
+        for _ in range(8):
+            p = rng.choice(ps)
+            pseq = "".join(seqs[n] for n in p)
+            L = rng.randint(k, 70)
+            st = rng.randrange(max(1, len(pseq) - L + 1))
+            r = pseq[st:st + L]
+            kind = rng.random()
+            if kind < 0.4:
+                r = fuzzgen.mutate(rng, r, sub=0.03, indel=0.0)
+            elif kind < 0.5:
+                r = fuzzgen.mutate(rng, r, sub=0.0, indel=0.03)
+            if rng.random() < 0.4:
+                r = _rc(r)
+            if rng.random() < 0.05:
+                r = r.lower()
+            rs.append(r or "A")
+        graphs.append((seqs, edges))
+        paths.append(ps)
+        reads.extend(rs)
+        gor.extend([gi] * len(rs))
+        want.extend(ka.port_kmer_align(seqs, ps, rs, k))
+    flags, got = gpu_kmer(gpu_ctx, graphs, paths, reads, gor, k)
+    n = check(flags, got, want, reads, "kmer-fuzz-%d" % k)
+    assert n > 300

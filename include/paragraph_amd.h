@@ -105,6 +105,7 @@ typedef struct pg_result
 } pg_result;
 #define PG_STATUS_PATH_ALIGNER 0x100u
 #define PG_STATUS_KMER_ALIGNER 0x200u
+#define PG_STATUS_KLIB_ALIGNER 0x400u
 
 /* One run-length CIGAR element inside a node: node id (12 bits) | op (4 bits) | length (16 bits). */
 typedef uint32_t pg_op;
@@ -271,7 +272,26 @@ pg_status pg_graphs_build_kmer_index(
  * flags: PG_AF_KEEP_RESULTS keeps earlier stages' results/ops.  Asynchronous. */
 pg_status pg_batch_kmer_align(pg_ctx* ctx, pg_batch* batch, uint32_t flags);
 
-/* Restricts the following stage calls (pg_batch_path_align / pg_batch_kmer_align / pg_batch_align) to reads with active[i] != 0 (NULL = every read): the next
+/* ---------------------------------------------------------------------------------------------------
+ * klib (ksw) stage (grm::KlibAligner, --klib-sequence-matching; default OFF in both CLIs)
+ *   replaces KlibAligner::{setGraph,alignRead}  src/c++/lib/grm/KlibAligner.cpp:186-205, 388-442 and, underneath,
+ *   common::KlibAlignment::update (src/c++/lib/common/Klib.cpp:144-164) = ksw_align(KSW_XSTART) + ksw_global
+ *   (external/klib/ksw.c:223-355, 457-531) with match 1, mismatch -4, gap open 5 (+1 for its first base), extend 1.
+ * ------------------------------------------------------------------------------------------------- */
+/* Paths as for pg_graphs_build_kmer_index (<= 30 per graph, whole nodes, no empty node). */
+pg_status pg_graphs_build_klib_index(
+    pg_ctx* ctx, pg_graphs* graphs, const uint32_t* path_off, const uint32_t* path_node_off, const uint32_t* path_nodes);
+/* KlibAligner::alignRead for every ACTIVE read (reads <= 256 bases): per path and strand one local alignment with start
+ * recovery and a global re-alignment of the local window; best score wins, an equally good candidate with a different
+ * (CIGAR, position) makes the read BAD_ALIGN.  results get PG_STATUS_KLIB_ALIGNER, score = number of matched bases
+ * (KlibAligner.cpp:207-308), strand_score[] = the ksw score; stage flags as for the k-mer stage (bit0 MAPPED, bit2
+ * BAD_ALIGN).  flags: PG_AF_KEEP_RESULTS keeps earlier stages' results/ops.  Asynchronous. */
+pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* batch, uint32_t flags);
+/* Device-side overflow word of the klib stage since the last call (0 = none; bit0 the batch's op buffer was too small
+ * for a read's CIGAR, bit1 a path CIGAR exceeded 2 * L + 4 runs: those reads stay unmapped).  Synchronises, clears. */
+pg_status pg_graphs_klib_error(pg_ctx* ctx, pg_graphs* graphs, uint32_t* error);
+
+/* Restricts the following stage calls (pg_batch_path_align / pg_batch_kmer_align / pg_batch_klib_align / pg_batch_align) to reads with active[i] != 0 (NULL = every read): the next
  * stage of the cascade runs only on reads the previous stage left unmapped / filtered. */
 pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* batch, const uint8_t* active);
 

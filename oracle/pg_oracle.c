@@ -846,3 +846,267 @@ int pgo_align_batch(
     free(ch);
     return status;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * KlibAligner stage -- scalar restatement of klib's ksw_align(KSW_XSTART) + ksw_global, under klib_glue.h.
+ *
+ *   ksw_qinit (16-bit profile, slen = ceil(qlen/8))   external/klib/ksw.c:58-104
+ *   ksw_i16                                           external/klib/ksw.c:223-321
+ *   ksw_align (reverse pass with KSW_XSTOP)           external/klib/ksw.c:330-355
+ *   ksw_global (+ push_cigar run merging)             external/klib/ksw.c:441-455, 457-531
+ *
+ * ksw_i16 is Farrar's striped kernel.  Written cell by cell it is the textbook affine recurrence EXCEPT for one
+ * thing this restatement keeps: E of the next column is taken from the H of the FIRST pass over the column, i.e. with
+ * the vertical gap F restarted at every stripe segment (rows that are multiples of slen); the lazy-F loop later raises
+ * H but never E (ksw.c:262-288).  The column maximum / end-row rule is the memory order of the striped vector
+ * (ksw.c:304-306): smallest row % slen first, then smallest row / slen.  Padding rows (>= qlen) can never hold a new
+ * maximum and are not modelled.
+ * ---------------------------------------------------------------------------------------------- */
+#include "klib_glue.h"
+
+static inline int pgo_sat0(int v) { return v < 0 ? 0 : v; }
+
+/* target accessor of ksw_align's second pass: the first te+1 columns are reversed in place, the rest are not */
+static inline uint8_t pgo_tcol(const uint8_t* t, int i, int rev_te) { return (rev_te >= 0 && i <= rev_te) ? t[rev_te - i] : t[i]; }
+
+/* one ksw_i16 call: q[0..qlen) (already in the orientation of the pass), endsc = 0x10000 for "no KSW_XSTOP" */
+static void pgo_ksw_i16(
+    int qlen, const uint8_t* q, int tlen, const uint8_t* t, int rev_te, const int8_t* mat, int gapo, int gape, int endsc, int* score,
+    int* te_out, int* qe_out)
+{
+    const int slen = (qlen + 7) / 8, gapoe = gapo + gape;
+    int* H0 = (int*)calloc((size_t)qlen + 1, sizeof(int));
+    int* H1 = (int*)calloc((size_t)qlen + 1, sizeof(int));
+    int* E = (int*)calloc((size_t)qlen + 1, sizeof(int));
+    int* Hmax = (int*)calloc((size_t)qlen + 1, sizeof(int));
+    int gmax = 0, te = -1;
+    for (int i = 0; i < tlen; ++i)
+    {
+        const int8_t* row = mat + 5 * pgo_tcol(t, i, rev_te);
+        int f_loc = 0, f_full = 0, diag = 0, imax = 0;
+        for (int j = 0; j < qlen; ++j)
+        {
+            if (j % slen == 0)
+                f_loc = 0;
+            int base = diag + row[q[j]];
+            if (base < E[j])
+                base = E[j];
+            const int hp = base > f_loc ? base : f_loc;
+            const int h = base > f_full ? base : f_full;
+            diag = H0[j];
+            H1[j] = h;
+            if (h > imax)
+                imax = h;
+            int e = pgo_sat0(E[j] - gape), o = pgo_sat0(hp - gapoe);
+            E[j] = e > o ? e : o;
+            f_loc = pgo_sat0(f_loc - gape);
+            if (f_loc < o)
+                f_loc = o;
+            f_full = pgo_sat0(f_full - gape);
+            const int of = pgo_sat0(h - gapoe);
+            if (f_full < of)
+                f_full = of;
+        }
+        if (imax > gmax)
+        {
+            gmax = imax;
+            te = i;
+            memcpy(Hmax, H1, (size_t)qlen * sizeof(int));
+            if (gmax >= endsc)
+                break;
+        }
+        int* s = H1;
+        H1 = H0;
+        H0 = s;
+    }
+    int best = -1, qe = -1;
+    long best_key = 0;
+    for (int j = 0; j < qlen; ++j)
+    {
+        const long key = (long)(j % slen) * 8 + j / slen;
+        if (Hmax[j] > best || (Hmax[j] == best && key < best_key))
+        {
+            best = Hmax[j];
+            best_key = key;
+            qe = j;
+        }
+    }
+    *score = gmax;
+    *te_out = te;
+    *qe_out = qe;
+    free(H0);
+    free(H1);
+    free(E);
+    free(Hmax);
+}
+
+#define PGO_MINUS_INF (-0x40000000)
+
+static uint32_t* pgo_push_cigar(int* n, int* m, uint32_t* c, int op, int len)
+{
+    if (*n == 0 || (uint32_t)op != (c[*n - 1] & 0xf))
+    {
+        if (*n == *m)
+        {
+            *m = *m ? *m << 1 : 4;
+            c = (uint32_t*)realloc(c, (size_t)*m * 4);
+        }
+        c[(*n)++] = (uint32_t)len << 4 | (uint32_t)op;
+    }
+    else
+        c[*n - 1] += (uint32_t)len << 4;
+    return c;
+}
+
+static void pgo_ksw_global(int qlen, const uint8_t* q, int tlen, const uint8_t* t, const int8_t* mat, int gapo, int gape, int w, int* n_cigar_, uint32_t** cigar_)
+{
+    const int gapoe = gapo + gape;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    uint8_t* z = (uint8_t*)malloc((size_t)(n_col > 0 ? n_col : 1) * (size_t)(tlen > 0 ? tlen : 1));
+    int* eh_h = (int*)calloc((size_t)qlen + 2, sizeof(int));
+    int* eh_e = (int*)calloc((size_t)qlen + 2, sizeof(int));
+    eh_h[0] = 0;
+    eh_e[0] = PGO_MINUS_INF;
+    int j;
+    for (j = 1; j <= qlen && j <= w; ++j)
+    {
+        eh_h[j] = -(gapo + gape * j);
+        eh_e[j] = PGO_MINUS_INF;
+    }
+    for (; j <= qlen; ++j)
+        eh_h[j] = eh_e[j] = PGO_MINUS_INF;
+    for (int i = 0; i < tlen; ++i)
+    {
+        int f = PGO_MINUS_INF, h1;
+        const int8_t* row = mat + 5 * t[i];
+        uint8_t* zi = z + (size_t)i * (size_t)n_col;
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        h1 = beg == 0 ? -(gapo + gape * (i + 1)) : PGO_MINUS_INF;
+        for (j = beg; j < end; ++j)
+        {
+            int h = eh_h[j], e = eh_e[j];
+            uint8_t d;
+            eh_h[j] = h1;
+            h += row[q[j]];
+            d = h > e ? 0 : 1;
+            h = h > e ? h : e;
+            d = h > f ? d : 2;
+            h = h > f ? h : f;
+            h1 = h;
+            h -= gapoe;
+            e -= gape;
+            d |= e > h ? 1 << 2 : 0;
+            e = e > h ? e : h;
+            eh_e[j] = e;
+            f -= gape;
+            d |= f > h ? 2 << 4 : 0;
+            f = f > h ? f : h;
+            zi[j - beg] = d;
+        }
+        eh_h[end] = h1;
+        eh_e[end] = PGO_MINUS_INF;
+    }
+    int n = 0, m = 0, which = 0;
+    uint32_t* cigar = 0;
+    int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+    while (i >= 0 && k >= 0)
+    {
+        which = z[(size_t)i * (size_t)n_col + (size_t)(k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+        if (which == 0)
+        {
+            cigar = pgo_push_cigar(&n, &m, cigar, 0, 1);
+            --i;
+            --k;
+        }
+        else if (which == 1)
+        {
+            cigar = pgo_push_cigar(&n, &m, cigar, 2, 1);
+            --i;
+        }
+        else
+        {
+            cigar = pgo_push_cigar(&n, &m, cigar, 1, 1);
+            --k;
+        }
+    }
+    if (i >= 0)
+        cigar = pgo_push_cigar(&n, &m, cigar, 2, i + 1);
+    if (k >= 0)
+        cigar = pgo_push_cigar(&n, &m, cigar, 1, k + 1);
+    for (i = 0; i < n >> 1; ++i)
+    {
+        uint32_t tmp = cigar[i];
+        cigar[i] = cigar[n - 1 - i];
+        cigar[n - 1 - i] = tmp;
+    }
+    *n_cigar_ = n;
+    *cigar_ = cigar;
+    free(eh_h);
+    free(eh_e);
+    free(z);
+}
+
+static void pgo_klib_engine(int qlen, uint8_t* query, int tlen, uint8_t* target, const int8_t* mat, int gapo, int gape, klib_pair* out)
+{
+    int score, te, qe;
+    pgo_ksw_i16(qlen, query, tlen, target, -1, mat, gapo, gape, 0x10000, &score, &te, &qe);
+    /* second pass: query[0..qe] reversed against target with its first te+1 columns reversed, stop at >= score */
+    uint8_t* rq = (uint8_t*)malloc((size_t)qe + 2);
+    for (int j = 0; j <= qe; ++j)
+        rq[j] = query[qe - j];
+    int rscore, rte, rqe;
+    pgo_ksw_i16(qe + 1, rq, tlen, target, te, mat, gapo, gape, score, &rscore, &rte, &rqe);
+    free(rq);
+    out->score = score;
+    out->te = te;
+    out->qe = qe;
+    out->tb = out->qb = -1;
+    if (rscore == score)
+    {
+        out->tb = te - rte;
+        out->qb = qe - rqe;
+    }
+    out->n_cigar = 0;
+    out->cigar = 0;
+    out->ub = (out->tb < 0 || out->qb < 0);
+    if (out->ub)
+        return;
+    pgo_ksw_global(qe - out->qb + 1, query + out->qb, te - out->tb + 1, target + out->tb, mat, gapo, gape, tlen, &out->n_cigar, &out->cigar);
+}
+
+int pgo_klib_pair(const char* ref, const char* query, int match, int mismatch, int gapo, int gape, int32_t* out5, uint32_t* cigar, int cap)
+{
+    const int tl = (int)strlen(ref), ql = (int)strlen(query);
+    uint8_t* t = (uint8_t*)malloc((size_t)tl + 1);
+    uint8_t* q = (uint8_t*)malloc((size_t)ql + 1);
+    klib_translate(ref, t, tl);
+    klib_translate(query, q, ql);
+    int8_t mat[25];
+    klib_matrix(mat, match, mismatch);
+    klib_pair pr;
+    memset(&pr, 0, sizeof pr);
+    pgo_klib_engine(ql, q, tl, t, mat, gapo, gape, &pr);
+    out5[0] = pr.score;
+    out5[1] = pr.tb;
+    out5[2] = pr.te;
+    out5[3] = pr.qb;
+    out5[4] = pr.qe;
+    for (int i = 0; i < pr.n_cigar && i < cap; ++i)
+        cigar[i] = pr.cigar[i];
+    const int n = pr.ub ? -1 : pr.n_cigar;
+    free(pr.cigar);
+    free(t);
+    free(q);
+    return n;
+}
+
+int pgo_klib_align(
+    int n_nodes, const uint32_t* node_off, const char* node_seq, int n_paths, const uint32_t* path_node_off, const uint32_t* path_nodes,
+    uint32_t n_reads, const uint32_t* read_off, const char* read_bases, const uint8_t* bam_reverse, int match, int mismatch, int gapo,
+    int gape, klib_result* results, char* cigars, int stride)
+{
+    return klib_align_batch(
+        pgo_klib_engine, n_nodes, node_off, node_seq, n_paths, path_node_off, path_nodes, n_reads, read_off, read_bases, bam_reverse,
+        match, mismatch, gapo, gape, results, cigars, stride);
+}

@@ -399,3 +399,65 @@ int pgref_align_batch(
     free(ch);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * KlibAligner stage: the reference's ksw.c (ksw_align + ksw_global, compiled in place) under the restated
+ * wrapper of klib_glue.h.  KlibAlignment::update  src/c++/lib/common/Klib.cpp:144-164.
+ * ---------------------------------------------------------------------------------------------- */
+#include "ksw.h"
+#include "klib_glue.h"
+
+static void pgref_klib_engine(int qlen, uint8_t* query, int tlen, uint8_t* target, const int8_t* mat, int gapo, int gape, klib_pair* out)
+{
+    kswq_t* qp = 0;
+    kswr_t r = ksw_align(qlen, query, tlen, target, 5, mat, gapo, gape, KSW_XSTART, &qp);
+    free(qp);
+    out->score = r.score;
+    out->tb = r.tb;
+    out->te = r.te;
+    out->qb = r.qb;
+    out->qe = r.qe;
+    out->n_cigar = 0;
+    out->cigar = 0;
+    out->ub = (r.tb < 0 || r.qb < 0);
+    if (out->ub)
+        return;
+    ksw_global(r.qe - r.qb + 1, query + r.qb, r.te - r.tb + 1, target + r.tb, 5, mat, gapo, gape, tlen, &out->n_cigar, &out->cigar);
+}
+
+/* one KlibAlignment (setRef / setQuery / getCigar); returns n_cigar (cigar: up to cap entries), out5 = score,r0,r1,a0,a1 */
+int pgref_klib_pair(const char* ref, const char* query, int match, int mismatch, int gapo, int gape, int32_t* out5, uint32_t* cigar, int cap)
+{
+    const int tl = (int)strlen(ref), ql = (int)strlen(query);
+    uint8_t* t = (uint8_t*)malloc((size_t)tl + 1);
+    uint8_t* q = (uint8_t*)malloc((size_t)ql + 1);
+    klib_translate(ref, t, tl);
+    klib_translate(query, q, ql);
+    int8_t mat[25];
+    klib_matrix(mat, match, mismatch);
+    klib_pair pr;
+    memset(&pr, 0, sizeof pr);
+    pgref_klib_engine(ql, q, tl, t, mat, gapo, gape, &pr);
+    out5[0] = pr.score;
+    out5[1] = pr.tb;
+    out5[2] = pr.te;
+    out5[3] = pr.qb;
+    out5[4] = pr.qe;
+    for (int i = 0; i < pr.n_cigar && i < cap; ++i)
+        cigar[i] = pr.cigar[i];
+    const int n = pr.ub ? -1 : pr.n_cigar;
+    free(pr.cigar);
+    free(t);
+    free(q);
+    return n;
+}
+
+int pgref_klib_align(
+    int n_nodes, const uint32_t* node_off, const char* node_seq, int n_paths, const uint32_t* path_node_off, const uint32_t* path_nodes,
+    uint32_t n_reads, const uint32_t* read_off, const char* read_bases, const uint8_t* bam_reverse, int match, int mismatch, int gapo,
+    int gape, klib_result* results, char* cigars, int stride)
+{
+    return klib_align_batch(
+        pgref_klib_engine, n_nodes, node_off, node_seq, n_paths, path_node_off, path_nodes, n_reads, read_off, read_bases, bam_reverse,
+        match, mismatch, gapo, gape, results, cigars, stride);
+}

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libparagraph_amd.so")
-HIP_SOURCES = ["pg_api.hip", "pg_fill.hip", "pg_trace.hip", "pg_count.hip", "pg_path.hip", "pg_kmer.hip"]
+HIP_SOURCES = ["pg_api.hip", "pg_fill.hip", "pg_trace.hip", "pg_count.hip", "pg_path.hip", "pg_kmer.hip", "pg_klib.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 

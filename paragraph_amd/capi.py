@@ -18,6 +18,7 @@ AF_ALL = 0xFFFFFFFF
 AF_KEEP_RESULTS = 0x100
 STATUS_PATH_ALIGNER = 0x100
 STATUS_KMER_ALIGNER = 0x200
+STATUS_KLIB_ALIGNER = 0x400
 
 PG_OK = 0
 STATUS_NAMES = {0: "PG_OK", 1: "PG_ERR_INVALID", 2: "PG_ERR_NO_DEVICE", 3: "PG_ERR_HIP", 4: "PG_ERR_UNSUPPORTED",
@@ -44,7 +45,7 @@ EXPORTS = [
     "pg_batch_download", "pg_align_batch", "pg_render_cigar", "pg_graphs_set_labels", "pg_graphs_count_layout",
     "pg_graphs_seq_offsets", "pg_batch_set_fragments", "pg_batch_count", "pg_batch_download_counts", "pg_graphs_build_path_index",
     "pg_batch_path_align", "pg_batch_download_path_flags", "pg_batch_set_active", "pg_graphs_build_kmer_index",
-    "pg_batch_kmer_align",
+    "pg_batch_kmer_align", "pg_graphs_build_klib_index", "pg_batch_klib_align", "pg_graphs_klib_error",
 ]
 
 
@@ -144,6 +145,12 @@ def load_library():
     L.pg_graphs_build_kmer_index.argtypes = [vp, vp, C.c_uint32, u32p, u32p, u32p]
     L.pg_batch_kmer_align.restype = C.c_int32
     L.pg_batch_kmer_align.argtypes = [vp, vp, C.c_uint32]
+    L.pg_graphs_build_klib_index.restype = C.c_int32
+    L.pg_graphs_build_klib_index.argtypes = [vp, vp, u32p, u32p, u32p]
+    L.pg_batch_klib_align.restype = C.c_int32
+    L.pg_batch_klib_align.argtypes = [vp, vp, C.c_uint32]
+    L.pg_graphs_klib_error.restype = C.c_int32
+    L.pg_graphs_klib_error.argtypes = [vp, vp, u32p]
     L.pg_render_cigar.restype = C.c_size_t
     L.pg_render_cigar.argtypes = [vp, vp, C.c_char_p, C.c_size_t]
     _lib = L
@@ -271,6 +278,22 @@ class Graphs:
         poff, noff, nodes = _u32(poff), _u32(noff), _u32(nodes if nodes else [0])
         self.ctx._chk(self.ctx.L.pg_graphs_build_kmer_index(self.ctx.h, self.h, kmer_len, _p32(poff), _p32(noff), _p32(nodes)))
 
+    def build_klib_index(self, paths):
+        """paths: per graph a list of node-id lists (as for build_kmer_index)."""
+        poff, noff, nodes = [0], [0], []
+        for gp in paths:
+            for p in gp:
+                nodes.extend(p)
+                noff.append(len(nodes))
+            poff.append(len(noff) - 1)
+        poff, noff, nodes = _u32(poff), _u32(noff), _u32(nodes if nodes else [0])
+        self.ctx._chk(self.ctx.L.pg_graphs_build_klib_index(self.ctx.h, self.h, _p32(poff), _p32(noff), _p32(nodes)))
+
+    def klib_error(self):
+        e = np.zeros(1, dtype=np.uint32)
+        self.ctx._chk(self.ctx.L.pg_graphs_klib_error(self.ctx.h, self.h, _p32(e)))
+        return int(e[0])
+
     def set_labels(self, edge_labels, labels=None):
         """edge_labels: per graph a dict {(from,to): [label,...]}; labels: per graph the ordered label list
         (default: sorted names).  Counters of edges come back in predecessor-CSR order = self.edges[g]."""
@@ -341,6 +364,13 @@ class Batch:
     def path_align(self):
         """PathAligner stage for every read; returns flags (bit0 mapped, bit1 anchored)."""
         self.ctx._chk(self.ctx.L.pg_batch_path_align(self.ctx.h, self.h))
+        fl = np.zeros(max(self.n_reads, 1), dtype=np.uint8)
+        self.ctx._chk(self.ctx.L.pg_batch_download_path_flags(self.ctx.h, self.h, fl.ctypes.data))
+        return fl[:self.n_reads]
+
+    def klib_align(self, flags=AF_ALL):
+        """KlibAligner stage for every active read; returns flags (bit0 mapped, bit2 BAD_ALIGN)."""
+        self.ctx._chk(self.ctx.L.pg_batch_klib_align(self.ctx.h, self.h, flags & 0xFFFFFFFF))
         fl = np.zeros(max(self.n_reads, 1), dtype=np.uint8)
         self.ctx._chk(self.ctx.L.pg_batch_download_path_flags(self.ctx.h, self.h, fl.ctypes.data))
         return fl[:self.n_reads]

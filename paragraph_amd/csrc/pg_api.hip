@@ -419,6 +419,7 @@ extern "C" void pg_graphs_destroy(pg_ctx* ctx, pg_graphs* G)
     (void)hipFree(G->d_in_mask);
     pg_path_index_free(G->path_index);
     pg_kmer_index_free(G->kmer_index);
+    pg_klib_index_free(G->klib_index);
     delete G;
 }
 

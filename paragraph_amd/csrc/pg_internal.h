@@ -52,6 +52,8 @@ struct pg_path_index;
 void pg_path_index_free(pg_path_index* ix);
 struct pg_kmer_index;
 void pg_kmer_index_free(pg_kmer_index* ix);
+struct pg_klib_index;
+void pg_klib_index_free(pg_klib_index* ix);
 
 struct pg_graphs
 {
@@ -71,6 +73,7 @@ struct pg_graphs
     std::string h_seq_raw;            // node sequences exactly as given (the path stage compares raw characters)
     pg_path_index* path_index = nullptr;
     pg_kmer_index* kmer_index = nullptr;
+    pg_klib_index* klib_index = nullptr;
     std::vector<uint32_t> h_n_labels;  // per graph
     std::vector<uint64_t> h_seq_off;   // n_graphs + 1 (dense sequence-set slots)
     bool labels_set = false;

@@ -1,0 +1,178 @@
+"""GPU parity of the klib stage (grm::KlibAligner) against the reference's own ksw.c under the restated wrapper
+(oracle/_ref) -- or the scalar ksw restatement when _ref is absent; both pinned by tests/test_klib_oracle.py on
+src/c++/test/test_klibaligner.cpp:149-193 and src/c++/test/test_align.cpp:38-147."""
+import random
+
+import pytest
+
+from tests import fuzzgen
+from tests.test_klib_oracle import KA_EXPECT, KA_NODES, KA_PATHS, KA_READS, random_case
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("graph_pos", "score", "cigar")
+
+
+def checker():
+    from oracle import klibalign as ok
+    return ok.ref_klib() if ok.have_ref() else ok.port_klib()
+
+
+def gpu_klib(ctx, graphs, paths, reads, gor):
+    from paragraph_amd import capi
+    G = ctx.upload_graphs(graphs)
+    G.build_klib_index(paths)
+    b = ctx.new_batch()
+    b.upload(G, reads, gor)
+    flags = b.klib_align()
+    res, ops = b.download()
+    out = capi.results_to_dicts(res, ops)
+    assert G.klib_error() == 0
+    b.close()
+    G.close()
+    return flags, out
+
+
+def check(flags, got, want, reads, what):
+    n = 0
+    for i, (f, g, w) in enumerate(zip(flags, got, want)):
+        assert not w["ub"]
+        st = 1 if f & 1 else (2 if f & 4 else 0)
+        assert st == w["status"], (what, i, reads[i], f, g, w)
+        if st:
+            n += 1
+            assert all(g[key] == w[key] for key in KEYS) and g["returned_reverse"] == w["used_reverse"], (what, i, reads[i], g, w)
+            assert g["mapq"] == w["mapq"] and g["unique"] == w["unique"]
+    return n
+
+
+def edges_of(paths):
+    return sorted({(p[i], p[i + 1]) for p in paths for i in range(len(p) - 1)})
+
+
+def test_reference_unit_vectors(gpu_ctx):
+    flags, got = gpu_klib(gpu_ctx, [(KA_NODES, edges_of(KA_PATHS))], [KA_PATHS], KA_READS, None)
+    for f, g, (pos, cigar, score, rev) in zip(flags, got, KA_EXPECT):
+        assert f & 1 and g["mapq"] == 60 and g["unique"]
+        assert (g["graph_pos"], g["cigar"], g["score"], g["returned_reverse"]) == (pos, cigar, score, rev)
+
+
+def test_klib_stage_fuzz_bubbles(gpu_ctx):
+    chk = checker()
+    rng = random.Random(4242)
+    graphs, paths, reads, gor, want = [], [], [], [], []
+    for gi in range(120):
+        nodes, ps, rs = random_case(rng, 10)
+        graphs.append((nodes, edges_of(ps) or [(0, len(nodes) - 1)]))
+        paths.append(ps)
+        reads.extend(rs)
+        gor.extend([gi] * len(rs))
+        want.extend(chk.align(nodes, ps, rs))
+    flags, got = gpu_klib(gpu_ctx, graphs, paths, reads, gor)
+    n = check(flags, got, want, reads, "klib-bubbles")
+    assert n > 800
+    assert sum(1 for w in want if w["status"] == 2) > 5
+
+
+def _rand_paths(rng, n_nodes, edges):
+    succ = {}
+    for f, t in edges:
+        succ.setdefault(f, []).append(t)
+    roots = [i for i in range(n_nodes) if not any(t == i for _, t in edges)] or [0]
+    paths = []
+    for _ in range(rng.randint(1, 5)):
+        cur = rng.choice(roots)
+        p = [cur]
+        while cur in succ:
+            cur = rng.choice(succ[cur])
+            p.append(cur)
+        if p not in paths:
+            paths.append(p)
+    return paths
+
+
+def test_klib_stage_fuzz_dags(gpu_ctx):
+    from oracle.pathalign import _rc
+    chk = checker()
+    rng = random.Random(99)
+    graphs, paths, reads, gor, want = [], [], [], [], []
+    for gi in range(100):
+        seqs, edges = fuzzgen.rand_graph(rng, max_len=60, max_nodes=7, shape=rng.choice(["del", "bubble", "dag", "longdel"]))
+        seqs = [s.replace("X", "N") if rng.random() < 0.5 else s for s in seqs]
+        ps = _rand_paths(rng, len(seqs), edges)
+        rs = []
+        for _ in range(8):
+            p = rng.choice(ps)
+            pseq = "".join(seqs[n] for n in p)
+            L = rng.randint(5, 200)
+            st = rng.randrange(max(1, len(pseq) - 10))
+            r = fuzzgen.mutate(rng, pseq[st:st + L], sub=rng.choice([0.0, 0.03, 0.1]), indel=rng.choice([0.0, 0.02, 0.06])) or "A"
+            if rng.random() < 0.4:
+                r = _rc(r)
+            if rng.random() < 0.05:
+                r = r.lower()
+            rs.append(r[:250])
+        graphs.append((seqs, edges))
+        paths.append(ps)
+        reads.extend(rs)
+        gor.extend([gi] * len(rs))
+        want.extend(chk.align(seqs, ps, rs))
+    flags, got = gpu_klib(gpu_ctx, graphs, paths, reads, gor)
+    n = check(flags, got, want, reads, "klib-dags")
+    assert n > 500
+
+
+def test_klib_stage_150bp_site(gpu_ctx):
+    """Reads of the bench's shape (150 bp, ~500 bp of paths) incl. indel-bearing ones: R = 3 rows per lane."""
+    chk = checker()
+    rng = random.Random(7)
+    lf = "".join(rng.choice("ACGT") for _ in range(200))
+    rf = "".join(rng.choice("ACGT") for _ in range(200))
+    alt = "".join(rng.choice("ACGT") for _ in range(60))
+    nodes = [lf, alt, alt[:20] + "".join(rng.choice("ACGT") for _ in range(30)), rf]
+    ps = [[0, 1, 3], [0, 2, 3], [0, 3]]
+    reads = []
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    for _ in range(300):
+        p = rng.choice(ps)
+        seq = "".join(nodes[x] for x in p)
+        st = rng.randrange(len(seq) - 150)
+        r = fuzzgen.mutate(rng, seq[st:st + 150], sub=rng.choice([0.0, 0.01, 0.05]), indel=rng.choice([0.0, 0.01, 0.03]))[:250] or "A"
+        if rng.random() < 0.5:
+            r = "".join(comp[c] for c in reversed(r))
+        reads.append(r)
+    want = chk.align(nodes, ps, reads)
+    flags, got = gpu_klib(gpu_ctx, [(nodes, edges_of(ps))], [ps], reads, None)
+    n = check(flags, got, want, reads, "klib-150")
+    assert n >= 290
+
+
+def test_klib_after_kmer_keeps_results(gpu_ctx):
+    """Cascade use: k-mer stage first, klib only on what it left unmapped, earlier results kept."""
+    import numpy as np
+    from paragraph_amd import capi
+    chk = checker()
+    from oracle import kmeralign as ka
+    reads = KA_READS + ["AAAAAAAATTTTCTTTAAAAAAAA", "AAAAAGGGGGAAAAAA"]
+    G = gpu_ctx.upload_graphs([(KA_NODES, edges_of(KA_PATHS))])
+    G.build_kmer_index([KA_PATHS], 10)
+    G.build_klib_index([KA_PATHS])
+    b = gpu_ctx.new_batch()
+    b.upload(G, reads, None)
+    f1 = b.kmer_align()
+    active = np.array([0 if f & 1 else 1 for f in f1], dtype=np.uint8)
+    b.set_active(active)
+    f2 = b.klib_align(capi.AF_KEEP_RESULTS)
+    res, ops = b.download()
+    out = capi.results_to_dicts(res, ops)
+    wk = ka.port_kmer_align(KA_NODES, KA_PATHS, reads, 10)
+    wl = chk.align(KA_NODES, KA_PATHS, reads)
+    assert active.sum() >= 1
+    for i in range(len(reads)):
+        w = wl[i] if active[i] else wk[i]
+        if active[i]:
+            assert (1 if f2[i] & 1 else (2 if f2[i] & 4 else 0)) == w["status"]
+        if w["status"]:
+            assert all(out[i][k] == w[k] for k in KEYS), (i, out[i], w)
+    b.close()
+    G.close()

@@ -1,12 +1,12 @@
 // grm::CompositeAligner (src/c++/include/grm/CompositeAligner.hh:44-91): the aligner cascade
-// path -> kmer -> klib -> gssw with a filter after each stage.  On the device build the path and gssw stages
-// and the k-mer stage exist; asking for klib matching throws std::logic_error.
+// path -> kmer -> klib -> gssw with a filter after each stage; every stage runs on the device.
 #pragma once
 #include <list>
 #include <vector>
 
 #include "grm/Filter.hh"
 #include "grm/GraphAligner.hh"
+#include "grm/KlibAligner.hh"
 #include "grm/KmerAligner.hh"
 #include "grm/PathAligner.hh"
 
@@ -41,6 +41,7 @@ private:
     PathAligner pathAligner_;
     GraphAligner graphAligner_;
     KmerAligner<16> kmerAligner_;
+    KlibAligner klibAligner_;
     unsigned attempted_ = 0, filtered_ = 0, mappedKlib_ = 0, mappedPath_ = 0, anchoredPath_ = 0, mappedKmers_ = 0,
              mappedSw_ = 0;
 };

@@ -100,14 +100,19 @@ std::string reverseComplement(std::string s)
 }
 
 // GraphAligner.cpp:358-401
-void applyResult(Read& read, const pg_result& r, const pg_op* ops, bool want_cigar)
+// reverse_quals: only GraphAligner reverses the qualities with the bases (GraphAligner.cpp:375-378); the k-mer and klib
+// stages replace the bases alone (KmerAligner.cpp:457, KlibAligner.cpp:328)
+void applyResult(Read& read, const pg_result& r, const pg_op* ops, bool want_cigar, bool reverse_quals = true)
 {
     if (r.returned_reverse)
     {
         read.set_bases(reverseComplement(read.bases()));
-        std::string q = read.quals();
-        std::reverse(q.begin(), q.end());
-        read.set_quals(q);
+        if (reverse_quals)
+        {
+            std::string q = read.quals();
+            std::reverse(q.begin(), q.end());
+            read.set_quals(q);
+        }
     }
     read.set_is_graph_reverse_strand(read.is_reverse_strand() != (r.returned_reverse != 0));
     read.set_graph_pos(r.graph_pos);
@@ -383,7 +388,7 @@ void KmerAlignerBase::alignReads(std::vector<Read*> const& reads)
             continue;
         Read& read = *reads[i];
         // KmerAligner.cpp:424-472 (updateAlignment) + 497-505
-        applyResult(read, res[i], ops.data(), true);
+        applyResult(read, res[i], ops.data(), true, false);
         read.set_graph_mapq(res[i].mapq);
         read.set_is_graph_alignment_unique(res[i].is_unique != 0);
         read.set_graph_mapping_status((flags[i] & 1) ? Read::MAPPED : Read::BAD_ALIGN);
@@ -397,13 +402,108 @@ void KmerAlignerBase::alignRead(Read& read)
     alignReads(one);
 }
 
+struct KlibAligner::Impl
+{
+    pg_graphs* graphs = nullptr;
+    ~Impl()
+    {
+        if (graphs)
+            pg_graphs_destroy(deviceContext(), graphs);
+    }
+};
+
+KlibAligner::KlibAligner() : impl_(new Impl()) {}
+KlibAligner::~KlibAligner() = default;
+KlibAligner::KlibAligner(KlibAligner&& rhs) noexcept = default;
+KlibAligner& KlibAligner::operator=(KlibAligner&& rhs) noexcept = default;
+
+void KlibAligner::setGraph(Graph const* g, std::list<graphtools::Path> const& paths)
+{
+    pg_ctx* ctx = deviceContext();
+    std::lock_guard<std::mutex> lock(deviceMutex());
+    if (impl_->graphs)
+        pg_graphs_destroy(ctx, impl_->graphs);
+    impl_->graphs = nullptr;
+    GraphCsr csr;
+    csr.add(*g);
+    check(ctx, pg_graphs_upload(ctx, 1, csr.node_off.data(), csr.seq_off.data(), csr.seq.data(), csr.pred_off.data(),
+                                csr.pred.empty() ? nullptr : csr.pred.data(), &impl_->graphs),
+          "pg_graphs_upload");
+    std::vector<uint32_t> path_off{ 0, (uint32_t)paths.size() }, node_off{ 0 }, nodes;
+    for (auto const& p : paths)
+    {
+        nodes.insert(nodes.end(), p.nodes.begin(), p.nodes.end());
+        node_off.push_back((uint32_t)nodes.size());
+    }
+    if (nodes.empty())
+        nodes.push_back(0);
+    check(ctx, pg_graphs_build_klib_index(ctx, impl_->graphs, path_off.data(), node_off.data(), nodes.data()),
+          "pg_graphs_build_klib_index");
+}
+
+void KlibAligner::alignReads(std::vector<Read*> const& reads)
+{
+    if (!impl_->graphs)
+        throw std::logic_error("KlibAligner::setGraph has not been called");
+    attempted_ += (unsigned)reads.size();
+    if (reads.empty())
+        return;
+    pg_ctx* ctx = deviceContext();
+    std::vector<uint32_t> base_off{ 0 }, gor(reads.size(), 0);
+    std::string bases;
+    for (Read* r : reads)
+    {
+        bases += r->bases();
+        base_off.push_back((uint32_t)bases.size());
+        r->set_graph_mapping_status(Read::UNMAPPED);  // KlibAligner.cpp:415
+    }
+    std::vector<pg_result> res(reads.size());
+    std::vector<pg_op> ops(2 * bases.size() + 64 * reads.size() + 1);
+    std::vector<uint8_t> flags(reads.size());
+    uint64_t n_ops = 0;
+    uint32_t overflow = 0;
+    {
+        std::lock_guard<std::mutex> lock(deviceMutex());
+        pg_batch* b = nullptr;
+        check(ctx, pg_batch_create(ctx, &b), "pg_batch_create");
+        pg_status st = pg_batch_upload(ctx, b, impl_->graphs, (uint32_t)reads.size(), gor.data(), base_off.data(), bases.data());
+        if (st == PG_OK)
+            st = pg_batch_klib_align(ctx, b, PG_AF_ALL);
+        if (st == PG_OK)
+            st = pg_batch_download_path_flags(ctx, b, flags.data());
+        if (st == PG_OK)
+            st = pg_batch_download(ctx, b, res.data(), ops.data(), ops.size(), &n_ops);
+        if (st == PG_OK)
+            st = pg_graphs_klib_error(ctx, impl_->graphs, &overflow);
+        pg_batch_destroy(ctx, b);
+        check(ctx, st, "klib stage");
+    }
+    if (overflow)
+        throw std::runtime_error("klib stage: CIGAR buffer overflow on the device");
+    for (size_t i = 0; i < reads.size(); ++i)
+    {
+        if (!(flags[i] & 5))
+            continue;
+        Read& read = *reads[i];
+        // KlibAligner.cpp:310-343 (updateAlignment) + 349-386 (pickBest)
+        applyResult(read, res[i], ops.data(), true, false);
+        read.set_graph_mapq(res[i].mapq);
+        read.set_is_graph_alignment_unique(res[i].is_unique != 0);
+        read.set_graph_mapping_status((flags[i] & 1) ? Read::MAPPED : Read::BAD_ALIGN);
+        mapped_ += (flags[i] & 1) != 0;
+    }
+}
+
+void KlibAligner::alignRead(Read& read)
+{
+    std::vector<Read*> one{ &read };
+    alignReads(one);
+}
+
 CompositeAligner::CompositeAligner(bool pathMatching, bool graphMatching, bool klibMatching, bool kmerMatching, unsigned flags)
     : pathMatching_(pathMatching), graphMatching_(graphMatching), klibMatching_(klibMatching), kmerMatching_(kmerMatching),
       grapAlignmentflags_(flags)
 {
-    if (klibMatching)
-        throw std::logic_error("klib sequence matching is not implemented on the device yet "
-                               "(available stages: path, kmer and graph sequence matching)");
 }
 CompositeAligner::~CompositeAligner() = default;
 CompositeAligner::CompositeAligner(CompositeAligner&& rhs) noexcept = default;
@@ -416,6 +516,8 @@ void CompositeAligner::setGraph(Graph const* graph, std::list<graphtools::Path> 
         graphAligner_.setGraph(graph);
     if (kmerMatching_)
         kmerAligner_.setGraph(graph, paths);
+    if (klibMatching_)
+        klibAligner_.setGraph(graph, paths);
 }
 
 void CompositeAligner::alignReads(std::vector<Read*> const& all_reads, ReadFilter filter)
@@ -458,6 +560,28 @@ void CompositeAligner::alignReads(std::vector<Read*> const& all_reads, ReadFilte
                 }
                 else
                     ++mappedKmers_;
+            }
+            if (read->graph_mapping_status() != Read::MAPPED)
+                rest.push_back(read);
+        }
+        reads.swap(rest);
+    }
+    if (klibMatching_ && !reads.empty())
+    {
+        // CompositeAligner.cpp:128-150
+        klibAligner_.alignReads(reads);
+        std::vector<Read*> rest;
+        for (Read* read : reads)
+        {
+            if (read->graph_mapping_status() == Read::MAPPED)
+            {
+                if (filter && filter(*read))
+                {
+                    read->set_graph_mapping_status(Read::BAD_ALIGN);
+                    filtered_ += !graphMatching_;
+                }
+                else
+                    ++mappedKlib_;
             }
             if (read->graph_mapping_status() != Read::MAPPED)
                 rest.push_back(read);

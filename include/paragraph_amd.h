@@ -189,6 +189,9 @@ typedef struct pg_count_params
     uint32_t use_support_filters; /* 1: production nodefilter/edgefilter (Disambiguation.cpp:212-296); 0: none
                                      (what the reference's unit tests call disambiguateReads with) */
     double bad_align_frac;        /* --bad-align-frac, default 0.8 */
+    uint32_t use_kmer_filter;     /* 1: KmerFilter after BadAlign (--bad-align-uniq-kmer-len != 0, default off); needs
+                                     pg_graphs_build_filter_index */
+    uint32_t reserved;
 } pg_count_params;
 
 /* Per-read outcome of the count path. */
@@ -198,7 +201,7 @@ typedef struct pg_read_support
     uint32_t path_off;   /* first entry in the path array */
     uint16_t n_path;     /* nodes on the read's path */
     uint8_t status;      /* 0 not aligned / skipped, 1 MAPPED, 2 BAD_ALIGN (filtered), 3 invalid alignment */
-    uint8_t filter;      /* 0 none, 1 nonuniq, 2 bad_align */
+    uint8_t filter;      /* 0 none, 1 nonuniq, 2 bad_align, 3 kmer_tooshort, 4 kmer_uncov (KmerFilter.cpp:88-139) */
 } pg_read_support;
 /* path entry: node id | (node supported) << 30 | (edge from the previous path node supported) << 31 */
 #define PG_PATH_NODE(x) ((uint32_t)(x) & 0xFFFu)
@@ -229,6 +232,12 @@ pg_status pg_graphs_set_labels(
 pg_status pg_graphs_count_layout(const pg_graphs* graphs, pg_count_layout* out);
 /* seq_off[g] (n_graphs + 1 entries) of the layout above */
 pg_status pg_graphs_seq_offsets(const pg_graphs* graphs, uint64_t* seq_off);
+
+/* KmerFilter's graphtools::KmerIndex (src/c++/lib/paragraph/readfilters/KmerFilter.cpp:52-76): kmer_len > 0 = that
+ * length on every graph; kmer_len < 0 = per graph the smallest length in 10..63 at which every node and edge is
+ * overlapped by at least -kmer_len unique k-mers (graphtools::findMinCoveringKmerLength; PG_ERR_UNSUPPORTED when
+ * there is none).  kmer_len_of_graph (n_graphs entries, may be NULL) receives the lengths used. */
+pg_status pg_graphs_build_filter_index(pg_ctx* ctx, pg_graphs* graphs, int32_t kmer_len, uint32_t* kmer_len_of_graph);
 
 /* Fragment membership of the uploaded reads (call once after pg_batch_upload):
  * fragment_of_read: fragment id per read (mates share an id; ids are local to the read's graph);

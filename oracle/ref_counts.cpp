@@ -470,3 +470,160 @@ extern "C" int pgrefc_path_align(
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------
+ * KmerFilter checker (src/c++/lib/paragraph/readfilters/KmerFilter.cpp:52-139).  The reference's own
+ * graphtools::decodeGraphAlignment / Alignment::numClipped / extendPath run as compiled from the tarball; restated
+ * are the KmerIndex (constructor + updateKmerCounts, GT!/src/graphalign/KmerIndex.cpp:76-141 -- Boost include),
+ * findMinCoveringKmerLength (GT!/src/graphalign/KmerIndexOperations.cpp:77-113) and filterRead's control flow.
+ * Returns the k-mer length used (-1: auto-detection found none).
+ * ---------------------------------------------------------------------------------------------------- */
+#include <unordered_set>
+
+namespace
+{
+struct RestatedKmerIndex
+{
+    std::unordered_map<std::string, std::list<graphtools::Path>> map;
+    std::unordered_map<NodeId, size_t> node_counts;
+    std::map<std::pair<NodeId, NodeId>, size_t> edge_counts;
+    RestatedKmerIndex(const Graph& graph, int32_t k)
+    {
+        for (NodeId node_id = 0; node_id != graph.numNodes(); ++node_id)
+        {
+            const std::string node_seq = graph.nodeSeq(node_id);
+            std::vector<NodeId> node_list{ node_id };
+            for (size_t pos = 0; pos != node_seq.length(); ++pos)
+            {
+                graphtools::Path path(&graph, static_cast<int32_t>(pos), node_list, static_cast<int32_t>(pos));
+                for (const graphtools::Path& kp : graphtools::extendPath(path, 0, k - 1))
+                    map[kp.seq()].push_back(kp);
+            }
+        }
+        for (auto const& kv : map)
+        {
+            if (kv.second.size() != 1)
+                continue;
+            bool has_previous = false;
+            NodeId previous = 0;
+            for (auto const& n : kv.second.front().nodeIds())
+            {
+                node_counts[n] += 1;
+                if (has_previous)
+                    edge_counts[std::make_pair(previous, n)] += 1;
+                has_previous = true;
+                previous = n;
+            }
+        }
+    }
+    size_t nodeCount(NodeId n) const
+    {
+        auto it = node_counts.find(n);
+        return it == node_counts.end() ? 0 : it->second;
+    }
+    size_t edgeCount(NodeId a, NodeId b) const
+    {
+        auto it = edge_counts.find(std::make_pair(a, b));
+        return it == edge_counts.end() ? 0 : it->second;
+    }
+};
+}  // namespace
+
+extern "C" int pgrefc_kmer_filter(
+    pgrefc_graph* g, int32_t kmer_len, uint32_t n_reads, const int32_t* pos, const uint32_t* cigar_off, const char* cigars,
+    const uint32_t* base_off, const char* bases, uint8_t* out_filtered, char* msgs, int msg_stride)
+{
+    const Graph& graph = g->graph;
+    if (kmer_len < 0)
+    {
+        const size_t need = (size_t)(-kmer_len);
+        kmer_len = -1;
+        for (int32_t k = 10; k < 64 && kmer_len < 0; ++k)
+        {
+            RestatedKmerIndex index(graph, k);
+            bool any_below = false;
+            for (NodeId node_id = 0; node_id != graph.numNodes() && !any_below; ++node_id)
+            {
+                if (index.nodeCount(node_id) < need)
+                    any_below = true;
+                for (const auto succ : graph.successors(node_id))
+                    if (!any_below && index.edgeCount(node_id, succ) < need)
+                        any_below = true;
+            }
+            if (!any_below)
+                kmer_len = k;
+        }
+        if (kmer_len < 0)
+            return -1;
+    }
+    RestatedKmerIndex index(graph, kmer_len);
+    for (uint32_t r = 0; r < n_reads; ++r)
+    {
+        const std::string cigar(cigars + cigar_off[r], cigars + cigar_off[r + 1]);
+        const std::string rb(bases + base_off[r], bases + base_off[r + 1]);
+        std::pair<bool, std::string> result{ false, "" };
+        try
+        {
+            const graphtools::GraphAlignment alignment = graphtools::decodeGraphAlignment(pos[r], cigar, &graph);
+            const auto sc_left = alignment[0].numClipped();
+            const auto sc_right = alignment[alignment.size() - 1].numClipped();
+            if ((signed)(rb.size() - sc_left - sc_right) < kmer_len)
+                result = { true, "kmer_tooshort" };
+            else
+            {
+                std::unordered_set<std::string> kmers;
+                for (size_t p = sc_left; p <= rb.size() - sc_right - kmer_len; ++p)
+                    kmers.insert(rb.substr(p, (size_t)kmer_len));
+                std::unordered_set<NodeId> nodes_not_covered;
+                std::list<NodeId> nodes_supported;
+                for (int32_t ni = 0; ni != (int32_t)alignment.size(); ++ni)
+                {
+                    const NodeId node_id = (NodeId)alignment.getNodeIdByIndex(ni);
+                    if (index.nodeCount(node_id) > 0)
+                    {
+                        nodes_not_covered.insert(node_id);
+                        nodes_supported.push_back(node_id);
+                    }
+                }
+                bool pass = false;
+                for (auto const& kmer : kmers)
+                {
+                    auto it = index.map.find(kmer);
+                    if (it != index.map.end() && it->second.size() == 1)
+                    {
+                        for (const auto& node_id : it->second.front().nodeIds())
+                        {
+                            nodes_not_covered.erase(node_id);
+                            if (nodes_not_covered.empty())
+                            {
+                                pass = true;
+                                break;
+                            }
+                        }
+                    }
+                    if (pass)
+                        break;
+                }
+                if (!pass)
+                {
+                    std::string msg = "kmer_uncov";
+                    for (auto const& node : nodes_supported)
+                        if (nodes_not_covered.count(node) != 0)
+                            msg += "_" + std::to_string(node);
+                    result = { true, msg };
+                }
+            }
+        }
+        catch (std::exception const&)
+        {
+            result = { true, "kmer_nomapping" };
+        }
+        out_filtered[r] = result.first ? 1 : 0;
+        if (msgs)
+        {
+            std::strncpy(msgs + (size_t)r * msg_stride, result.second.c_str(), (size_t)msg_stride - 1);
+            msgs[(size_t)r * msg_stride + msg_stride - 1] = 0;
+        }
+    }
+    return kmer_len;
+}

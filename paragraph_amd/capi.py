@@ -45,7 +45,7 @@ EXPORTS = [
     "pg_batch_download", "pg_align_batch", "pg_render_cigar", "pg_graphs_set_labels", "pg_graphs_count_layout",
     "pg_graphs_seq_offsets", "pg_batch_set_fragments", "pg_batch_count", "pg_batch_download_counts", "pg_graphs_build_path_index",
     "pg_batch_path_align", "pg_batch_download_path_flags", "pg_batch_set_active", "pg_graphs_build_kmer_index",
-    "pg_batch_kmer_align", "pg_graphs_build_klib_index", "pg_batch_klib_align", "pg_graphs_klib_error",
+    "pg_batch_kmer_align", "pg_graphs_build_klib_index", "pg_batch_klib_align", "pg_graphs_klib_error", "pg_graphs_build_filter_index",
 ]
 
 
@@ -56,7 +56,8 @@ class Timing(C.Structure):
 
 
 class CountParams(C.Structure):
-    _fields_ = [("remove_nonuniq", C.c_uint32), ("use_support_filters", C.c_uint32), ("bad_align_frac", C.c_double)]
+    _fields_ = [("remove_nonuniq", C.c_uint32), ("use_support_filters", C.c_uint32), ("bad_align_frac", C.c_double),
+                ("use_kmer_filter", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class CountLayout(C.Structure):
@@ -145,6 +146,8 @@ def load_library():
     L.pg_graphs_build_kmer_index.argtypes = [vp, vp, C.c_uint32, u32p, u32p, u32p]
     L.pg_batch_kmer_align.restype = C.c_int32
     L.pg_batch_kmer_align.argtypes = [vp, vp, C.c_uint32]
+    L.pg_graphs_build_filter_index.restype = C.c_int32
+    L.pg_graphs_build_filter_index.argtypes = [vp, vp, C.c_int32, u32p]
     L.pg_graphs_build_klib_index.restype = C.c_int32
     L.pg_graphs_build_klib_index.argtypes = [vp, vp, u32p, u32p, u32p]
     L.pg_batch_klib_align.restype = C.c_int32
@@ -278,6 +281,12 @@ class Graphs:
         poff, noff, nodes = _u32(poff), _u32(noff), _u32(nodes if nodes else [0])
         self.ctx._chk(self.ctx.L.pg_graphs_build_kmer_index(self.ctx.h, self.h, kmer_len, _p32(poff), _p32(noff), _p32(nodes)))
 
+    def build_filter_index(self, kmer_len):
+        """KmerFilter index; kmer_len < 0 = auto-detect per graph. Returns the lengths used."""
+        out = np.zeros(max(self.n, 1), dtype=np.uint32)
+        self.ctx._chk(self.ctx.L.pg_graphs_build_filter_index(self.ctx.h, self.h, int(kmer_len), _p32(out)))
+        return [int(x) for x in out[:self.n]]
+
     def build_klib_index(self, paths):
         """paths: per graph a list of node-id lists (as for build_kmer_index)."""
         poff, noff, nodes = [0], [0], []
@@ -402,9 +411,10 @@ class Batch:
         self.ctx._chk(self.ctx.L.pg_batch_set_fragments(
             self.ctx.h, self.h, _p32(fr), rv.ctypes.data_as(C.POINTER(C.c_uint8)) if rv is not None else None))
 
-    def count(self, remove_nonuniq=True, bad_align_frac=0.8, use_support_filters=True, d_counts=None):
+    def count(self, remove_nonuniq=True, bad_align_frac=0.8, use_support_filters=True, d_counts=None, use_kmer_filter=False):
         """Runs the count path (async); d_counts = device pointer (int) of a caller-owned uint32 table or None."""
-        prm = CountParams(1 if remove_nonuniq else 0, 1 if use_support_filters else 0, bad_align_frac)
+        prm = CountParams(1 if remove_nonuniq else 0, 1 if use_support_filters else 0, bad_align_frac,
+                          1 if use_kmer_filter else 0, 0)
         self.ctx._chk(self.ctx.L.pg_batch_count(self.ctx.h, self.h, C.byref(prm), d_counts))
 
     def download_counts(self, want_table=True):

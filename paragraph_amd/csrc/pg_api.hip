@@ -418,6 +418,7 @@ extern "C" void pg_graphs_destroy(pg_ctx* ctx, pg_graphs* G)
     (void)hipFree(G->d_out_mask);
     (void)hipFree(G->d_in_mask);
     pg_path_index_free(G->path_index);
+    pg_path_index_free(G->filter_index);
     pg_kmer_index_free(G->kmer_index);
     pg_klib_index_free(G->klib_index);
     delete G;

@@ -26,6 +26,7 @@
 #include "../../include/paragraph_amd.h"
 #include "pg_device.h"
 #include "pg_internal.h"
+#include "pg_kmerindex.h"
 
 namespace
 {
@@ -54,7 +55,88 @@ struct CountArgs
     const uint32_t* frag_reads;
     uint32_t* counts;
     pg_count_layout lay;
+    // KmerFilter (prm.use_kmer_filter)
+    const char* bases;
+    const PathGraphDev* kf_graphs;
+    const KmerEntry* kf_table;
+    const uint32_t* kf_pool;
+    const uint32_t* kf_node_off;
+    const char* kf_raw;
+    const uint8_t* kf_node_uniq;
 };
+
+__device__ __forceinline__ uint32_t kf_comp(uint32_t c)
+{  // GT!/src/graphutils/SequenceOperations.cpp:66-81
+    switch (c)
+    {
+    case 'A': return 'T';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    case 'T': return 'A';
+    default: return 'N';
+    }
+}
+
+// readfilters::KmerFilter::filterRead (src/c++/lib/paragraph/readfilters/KmerFilter.cpp:78-139) on the read as the
+// aligner left it (bases reverse-complemented when the alignment is to the reverse strand).  Returns 0 = keep,
+// 3 = kmer_tooshort, 4 = kmer_uncov.  The read's unique k-mers are looked up once per alignment node that has unique
+// k-mers (no per-thread node set: a read crosses a handful of nodes).
+__device__ uint32_t kmer_filter(const CountArgs& a, const pg_result& res, uint32_t r, uint32_t graph, int L)
+{
+    const PathGraphDev g = a.kf_graphs[graph];
+    const int k = (int)g.k;
+    const pg_op* ops = a.ops + res.ops_off;
+    // numClipped of the first / last node alignment (all of that node's soft clips, on either side)
+    const uint32_t first = PG_OP_NODE(ops[0]), last = PG_OP_NODE(ops[res.n_ops - 1]);
+    int sc_left = 0, sc_right = 0;
+    for (uint32_t e = 0; e < res.n_ops && PG_OP_NODE(ops[e]) == first; ++e)
+        if (PG_OP_CODE(ops[e]) == PG_OPC_S)
+            sc_left += (int)PG_OP_LEN(ops[e]);
+    for (uint32_t e = res.n_ops; e > 0 && PG_OP_NODE(ops[e - 1]) == last; --e)
+        if (PG_OP_CODE(ops[e - 1]) == PG_OPC_S)
+            sc_right += (int)PG_OP_LEN(ops[e - 1]);
+    if (L - sc_left - sc_right < k)
+        return 3;
+    const char* b = a.bases + a.base_off[r];
+    const bool rev = res.returned_reverse != 0;
+    auto q = [&](int j) -> uint32_t { return rev ? kf_comp((uint8_t)b[L - 1 - j]) : (uint32_t)(uint8_t)b[j]; };
+    const int p_first = sc_left, p_last = L - sc_right - k;  // inclusive
+    // scan(node): does a unique read k-mer exist whose path contains `node` (node < 0: any unique k-mer at all)
+    auto scan = [&](int node) -> bool {
+        uint64_t h = 0;
+        for (int c = 0; c < k; ++c)
+            h = h * PG_HASH_B + (uint64_t)q(p_first + c) + 1;
+        for (int pos = p_first;; ++pos)
+        {
+            KmerEntry e;
+            if (pg_kmer_lookup_unique(g, a.kf_table, a.kf_pool, a.kf_node_off, a.kf_raw, h, pos, q, e))
+            {
+                if (node < 0)
+                    return true;
+                for (uint32_t i = 0; i < e.n_nodes; ++i)
+                    if (a.kf_pool[e.pool_off + i] == (uint32_t)node)
+                        return true;
+            }
+            if (pos == p_last)
+                return false;
+            h = (h - ((uint64_t)q(pos) + 1) * g.pow_k1) * PG_HASH_B + (uint64_t)q(pos + k) + 1;
+        }
+    };
+    // with no unique k-mer in the read the reference reports "kmer_uncov" even when no node needs covering
+    if (!scan(-1))
+        return 4;
+    uint32_t cur = 0xFFFFFFFFu;
+    for (uint32_t e = 0; e < res.n_ops; ++e)
+    {
+        const uint32_t nd = PG_OP_NODE(ops[e]);
+        if (nd == cur)
+            continue;
+        cur = nd;
+        if (a.kf_node_uniq[g.node_base + nd] && !scan((int)nd))
+            return 4;
+    }
+    return 0;
+}
 
 struct NodeAln
 {
@@ -155,6 +237,15 @@ __global__ __launch_bounds__(64) void pg_support_kernel(CountArgs a)
     const uint32_t first_node = PG_OP_NODE(a.ops[res.ops_off]);
     if (res.graph_pos < 0 || (uint32_t)res.graph_pos >= a.node_len[cg.node_base + first_node])
         sup.status = 3;
+    if (sup.status == 1 && a.prm.use_kmer_filter)
+    {
+        const uint32_t kf = kmer_filter(a, res, r, a.graph_of_read[r], (int)L);
+        if (kf)
+        {
+            sup.status = 2;
+            sup.filter = (uint8_t)kf;
+        }
+    }
     tally_add(3, sup.status == 2 && sup.filter == 1);
     tally_add(2, sup.status == 2 && sup.filter == 2);
     tally_add(1, sup.status == 1);
@@ -592,6 +683,19 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     a.frag_reads = b->d_frag_reads;
     a.counts = counts;
     a.lay = lay;
+    if (params->use_kmer_filter)
+    {
+        const pg_path_index* fx = G->filter_index;
+        if (!fx)
+            return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_count: use_kmer_filter needs pg_graphs_build_filter_index");
+        a.bases = b->d_bases;
+        a.kf_graphs = fx->d_graphs;
+        a.kf_table = fx->d_table;
+        a.kf_pool = fx->d_pool;
+        a.kf_node_off = fx->d_node_off;
+        a.kf_raw = fx->d_raw;
+        a.kf_node_uniq = fx->d_node_uniq;
+    }
     if (n)
     {
         hipLaunchKernelGGL(pg_support_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a);

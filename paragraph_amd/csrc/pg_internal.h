@@ -72,6 +72,7 @@ struct pg_graphs
     std::vector<uint32_t> h_nodeseq_off;  // total_nodes + 1, into h_seq_raw
     std::string h_seq_raw;            // node sequences exactly as given (the path stage compares raw characters)
     pg_path_index* path_index = nullptr;
+    pg_path_index* filter_index = nullptr;  // KmerFilter (count path)
     pg_kmer_index* kmer_index = nullptr;
     pg_klib_index* klib_index = nullptr;
     std::vector<uint32_t> h_n_labels;  // per graph

@@ -1,0 +1,99 @@
+// pg_kmerindex.h -- graphtools::KmerIndex on the device: shared by the exact path matching stage (pg_path.hip) and the
+// KmerFilter of the count path (pg_count.hip).
+//   graphtools::KmerIndex (construction, numPaths, getPaths, numUniqueKmersOverlappingNode / Edge)
+//       GT!/src/graphalign/KmerIndex.cpp:76-135, 209-260
+// One open-addressing hash table per graph: key = 64-bit polynomial hash of the k raw characters, value = (number of
+// paths with that sequence, the FIRST such path in the reference's enumeration order).  k may differ per graph (the
+// KmerFilter's auto-detected length is per graph).
+#ifndef PG_KMERINDEX_H
+#define PG_KMERINDEX_H
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "pg_internal.h"
+
+constexpr uint64_t PG_HASH_B = 0x9E3779B97F4A7C15ull | 1ull;
+
+struct PathGraphDev
+{
+    uint32_t node_base;  // set-wide node numbering (caller CSR)
+    uint32_t n_nodes;
+    uint64_t tab_off;    // into the entry table
+    uint32_t tab_mask;   // capacity - 1 (capacity is a power of two), 0xFFFFFFFF = graph has no k-mers
+    uint32_t k;          // k-mer length of this graph's table
+    uint64_t pow_k1;     // PG_HASH_B^(k-1)
+};
+
+struct KmerEntry
+{
+    uint64_t hash;  // 0 = empty
+    uint32_t count;
+    uint32_t start_pos;
+    uint32_t end_pos;
+    uint32_t n_nodes;
+    uint32_t pool_off;  // node ids (graph-local) of the first path with this sequence
+    uint32_t pad;
+};
+
+struct pg_path_index
+{
+    uint32_t k = 0;  // common k (0 when the graphs differ)
+    uint64_t pow_k1 = 1;
+    PathGraphDev* d_graphs = nullptr;
+    KmerEntry* d_table = nullptr;
+    uint32_t* d_pool = nullptr;
+    uint32_t* d_node_off = nullptr;
+    char* d_raw = nullptr;
+    uint32_t* d_succ_off = nullptr;
+    uint32_t* d_succ = nullptr;
+    uint8_t* d_node_uniq = nullptr;  // per set-wide node: numUniqueKmersOverlappingNode(node) > 0
+    std::vector<uint32_t> h_k;       // per graph
+};
+
+// k_per_graph[g] > 0: that length; < 0: graphtools::findMinCoveringKmerLength(graph, -k, -k)
+// (GT!/src/graphalign/KmerIndexOperations.cpp:77-113; fails with PG_ERR_UNSUPPORTED when no length 10..63 covers).
+pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32_t>& k_per_graph, pg_path_index** out);
+
+// Looks the k characters q(pos..pos+k-1) up; true only for a k-mer with EXACTLY ONE path (characters verified, so a
+// 64-bit hash collision cannot fake a hit).  Q: callable int -> uint32_t raw character.
+template <typename Q>
+__device__ __forceinline__ bool pg_kmer_lookup_unique(
+    const PathGraphDev& g, const KmerEntry* __restrict__ table, const uint32_t* __restrict__ pool, const uint32_t* __restrict__ node_off,
+    const char* __restrict__ raw, uint64_t h, int pos, Q q, KmerEntry& out)
+{
+    if (g.tab_mask == 0xFFFFFFFFu)
+        return false;
+    if (h == 0)
+        h = 1;
+    uint32_t slot = (uint32_t)(h >> 20) & g.tab_mask;
+    for (;;)
+    {
+        const KmerEntry e = table[g.tab_off + slot];
+        if (e.hash == 0)
+            return false;
+        if (e.hash == h)
+        {
+            if (e.count != 1)
+                return false;
+            uint32_t ni = 0, node = pool[e.pool_off], p = e.start_pos;
+            for (uint32_t c = 0; c < g.k; ++c)
+            {
+                if (p >= node_off[g.node_base + node + 1] - node_off[g.node_base + node])
+                {
+                    ++ni;
+                    node = pool[e.pool_off + ni];
+                    p = 0;
+                }
+                if ((uint32_t)(uint8_t)raw[node_off[g.node_base + node] + p] != q(pos + (int)c))
+                    return false;
+                ++p;
+            }
+            out = e;
+            return true;
+        }
+        slot = (slot + 1) & g.tab_mask;
+    }
+}
+#endif

@@ -25,30 +25,11 @@
 #include "../../include/paragraph_amd.h"
 #include "pg_device.h"
 #include "pg_internal.h"
+#include "pg_kmerindex.h"
 
 namespace
 {
-constexpr uint64_t HASH_B = 0x9E3779B97F4A7C15ull | 1ull;
-
-struct PathGraphDev
-{
-    uint32_t node_base;  // set-wide node numbering (caller CSR)
-    uint32_t n_nodes;
-    uint64_t tab_off;    // into the entry table
-    uint32_t tab_mask;   // capacity - 1 (capacity is a power of two), 0xFFFFFFFF = graph has no k-mers
-    uint32_t pad;
-};
-
-struct KmerEntry
-{
-    uint64_t hash;  // 0 = empty
-    uint32_t count;
-    uint32_t start_pos;
-    uint32_t end_pos;
-    uint32_t n_nodes;
-    uint32_t pool_off;  // node ids (graph-local) of the first path with this sequence
-    uint32_t pad;
-};
+constexpr uint64_t HASH_B = PG_HASH_B;
 
 struct PathArgs
 {
@@ -216,39 +197,7 @@ struct Walker
 
     __device__ bool lookup(uint64_t h, int pos, KmerEntry& out) const
     {
-        if (g.tab_mask == 0xFFFFFFFFu)
-            return false;
-        if (h == 0)
-            h = 1;
-        uint32_t slot = (uint32_t)(h >> 20) & g.tab_mask;
-        for (;;)
-        {
-            const KmerEntry e = a.table[g.tab_off + slot];
-            if (e.hash == 0)
-                return false;
-            if (e.hash == h)
-            {
-                if (e.count != 1)
-                    return false;
-                // verify the characters against the path (a 64-bit collision would otherwise fake an anchor)
-                uint32_t ni = 0, node = a.pool[e.pool_off], p = e.start_pos;
-                for (uint32_t c = 0; c < a.k; ++c)
-                {
-                    if (p >= nlen(node))
-                    {
-                        ++ni;
-                        node = a.pool[e.pool_off + ni];
-                        p = 0;
-                    }
-                    if (nch(node, p) != q(pos + (int)c))
-                        return false;
-                    ++p;
-                }
-                out = e;
-                return true;
-            }
-            slot = (slot + 1) & g.tab_mask;
-        }
+        return pg_kmer_lookup_unique(g, a.table, a.pool, a.node_off, a.raw, h, pos, [&](int j) { return q(j); }, out);
     }
 };
 
@@ -382,19 +331,6 @@ uint64_t hash_str(const char* s, uint32_t k)
 }
 }  // namespace
 
-struct pg_path_index
-{
-    uint32_t k = 0;
-    uint64_t pow_k1 = 1;
-    PathGraphDev* d_graphs = nullptr;
-    KmerEntry* d_table = nullptr;
-    uint32_t* d_pool = nullptr;
-    uint32_t* d_node_off = nullptr;
-    char* d_raw = nullptr;
-    uint32_t* d_succ_off = nullptr;
-    uint32_t* d_succ = nullptr;
-};
-
 void pg_path_index_free(pg_path_index* ix)
 {
     if (!ix)
@@ -406,6 +342,7 @@ void pg_path_index_free(pg_path_index* ix)
     (void)hipFree(ix->d_raw);
     (void)hipFree(ix->d_succ_off);
     (void)hipFree(ix->d_succ);
+    (void)hipFree(ix->d_node_uniq);
     delete ix;
 }
 
@@ -417,10 +354,88 @@ template <typename T> static hipError_t up(const std::vector<T>& v, T** d, hipSt
     return hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
 }
 
-extern "C" pg_status pg_graphs_build_path_index(pg_ctx* ctx, pg_graphs* G, uint32_t kmer_len)
+namespace
 {
-    if (!ctx || !G || kmer_len == 0 || kmer_len > 250)
-        return pg_fail(ctx, PG_ERR_INVALID, "pg_graphs_build_path_index: bad argument");
+struct PathRec
+{
+    uint32_t start, end;
+    std::vector<uint32_t> nodes;
+};
+typedef std::unordered_map<std::string, std::pair<uint32_t, PathRec>> KmerMap;  // sequence -> (count, first path)
+
+// every length-k path of graph g, depth-first = extendPathEnd (PathOperations.cpp:70-101), KmerIndex.cpp:76-99
+void enumerate_kmers(const pg_graphs* G, const std::vector<uint32_t>& succ_off, const std::vector<uint32_t>& succ, uint32_t g, uint32_t k,
+                     KmerMap& idx)
+{
+    const std::string& raw = G->h_seq_raw;
+    const std::vector<uint32_t>& noff = G->h_nodeseq_off;
+    const uint32_t nb = G->h_node_off[g], ne = G->h_node_off[g + 1];
+    std::vector<uint32_t> nl;
+    std::string seq;
+    struct Rec
+    {
+        static void go(const pg_graphs* G, const std::vector<uint32_t>& succ_off, const std::vector<uint32_t>& succ,
+                       const std::string& raw, const std::vector<uint32_t>& noff, uint32_t nb, uint32_t k,
+                       std::vector<uint32_t>& nl, std::string& seq, uint32_t start, uint32_t pos, KmerMap& idx)
+        {
+            const uint32_t node = nl.back();
+            const uint32_t len = G->h_node_len[nb + node];
+            const uint32_t need = k - (uint32_t)seq.size();
+            const uint32_t room = len - pos;
+            if (need <= room)
+            {
+                const size_t before = seq.size();
+                seq.append(raw, noff[nb + node] + pos, need);
+                auto it = idx.find(seq);
+                if (it == idx.end())
+                    idx.emplace(seq, std::make_pair(1u, PathRec{ start, pos + need - 1, nl }));
+                else
+                    it->second.first++;
+                seq.resize(before);
+                return;
+            }
+            const size_t before = seq.size();
+            seq.append(raw, noff[nb + node] + pos, room);
+            for (uint32_t s = succ_off[nb + node]; s < succ_off[nb + node + 1]; ++s)
+            {
+                nl.push_back(succ[s]);
+                go(G, succ_off, succ, raw, noff, nb, k, nl, seq, start, 0, idx);
+                nl.pop_back();
+            }
+            seq.resize(before);
+        }
+    };
+    for (uint32_t node = 0; node < ne - nb; ++node)
+        for (uint32_t pos = 0; pos < G->h_node_len[nb + node]; ++pos)
+        {
+            nl.assign(1, node);
+            seq.clear();
+            Rec::go(G, succ_off, succ, raw, noff, nb, k, nl, seq, pos, pos, idx);
+        }
+}
+
+// KmerIndex::Impl::updateKmerCounts (KmerIndex.cpp:118-141): unique k-mers per node / per edge of graph g
+void unique_counts(const KmerMap& idx, uint32_t n_nodes, std::vector<uint32_t>& node_cnt, std::unordered_map<uint64_t, uint32_t>& edge_cnt)
+{
+    node_cnt.assign(n_nodes, 0);
+    edge_cnt.clear();
+    for (auto const& kv : idx)
+    {
+        if (kv.second.first != 1)
+            continue;
+        const std::vector<uint32_t>& nodes = kv.second.second.nodes;
+        for (size_t i = 0; i < nodes.size(); ++i)
+        {
+            node_cnt[nodes[i]] += 1;
+            if (i)
+                edge_cnt[((uint64_t)nodes[i - 1] << 32) | nodes[i]] += 1;
+        }
+    }
+}
+}  // namespace
+
+pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32_t>& k_per_graph, pg_path_index** out)
+{
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t n_total = (uint32_t)G->h_node_len.size();
     // successor CSR (set-wide node numbering, graph-local ids as values, ascending)
@@ -444,64 +459,60 @@ extern "C" pg_status pg_graphs_build_path_index(pg_ctx* ctx, pg_graphs* G, uint3
     std::vector<PathGraphDev> gd(G->n_graphs);
     std::vector<KmerEntry> table;
     std::vector<uint32_t> pool;
+    std::vector<uint8_t> node_uniq(n_total, 0);
+    std::vector<uint32_t> h_k(G->n_graphs, 0);
     const std::string& raw = G->h_seq_raw;
     const std::vector<uint32_t>& noff = G->h_nodeseq_off;
-    struct PathRec
-    {
-        uint32_t start, end;
-        std::vector<uint32_t> nodes;
-    };
     for (uint32_t g = 0; g < G->n_graphs; ++g)
     {
         const uint32_t nb = G->h_node_off[g], ne = G->h_node_off[g + 1];
-        std::unordered_map<std::string, std::pair<uint32_t, PathRec>> idx;  // sequence -> (count, first path)
-        std::vector<uint32_t> nl;
-        std::string seq;
-        // depth-first enumeration = extendPathEnd (PathOperations.cpp:70-101)
-        struct Rec
+        KmerMap idx;
+        std::vector<uint32_t> node_cnt;
+        std::unordered_map<uint64_t, uint32_t> edge_cnt;
+        int32_t k = k_per_graph[g];
+        if (k > 0)
         {
-            static void go(const pg_graphs* G, const std::vector<uint32_t>& succ_off, const std::vector<uint32_t>& succ,
-                           const std::string& raw, const std::vector<uint32_t>& noff, uint32_t nb, uint32_t k,
-                           std::vector<uint32_t>& nl, std::string& seq, uint32_t start, uint32_t pos,
-                           std::unordered_map<std::string, std::pair<uint32_t, PathRec>>& idx)
+            enumerate_kmers(G, succ_off, succ, g, (uint32_t)k, idx);
+            unique_counts(idx, ne - nb, node_cnt, edge_cnt);
+        }
+        else
+        {
+            // findMinCoveringKmerLength(graph, -k, -k): the first length 10..63 at which every node and every edge is
+            // overlapped by at least -k unique k-mers
+            const uint32_t need = (uint32_t)(-k);
+            k = -1;
+            for (int32_t kk = 10; kk < 64 && k < 0; ++kk)
             {
-                const uint32_t node = nl.back();
-                const uint32_t len = G->h_node_len[nb + node];
-                const uint32_t need = k - (uint32_t)seq.size();
-                const uint32_t room = len - pos;
-                if (need <= room)
+                idx.clear();
+                enumerate_kmers(G, succ_off, succ, g, (uint32_t)kk, idx);
+                unique_counts(idx, ne - nb, node_cnt, edge_cnt);
+                bool any_below = false;
+                for (uint32_t node = 0; node < ne - nb && !any_below; ++node)
                 {
-                    const size_t before = seq.size();
-                    seq.append(raw, noff[nb + node] + pos, need);
-                    auto it = idx.find(seq);
-                    if (it == idx.end())
-                        idx.emplace(seq, std::make_pair(1u, PathRec{ start, pos + need - 1, nl }));
-                    else
-                        it->second.first++;
-                    seq.resize(before);
-                    return;
+                    if (node_cnt[node] < need)
+                        any_below = true;
+                    for (uint32_t s = succ_off[nb + node]; s < succ_off[nb + node + 1] && !any_below; ++s)
+                    {
+                        auto it = edge_cnt.find(((uint64_t)node << 32) | succ[s]);
+                        if ((it == edge_cnt.end() ? 0u : it->second) < need)
+                            any_below = true;
+                    }
                 }
-                const size_t before = seq.size();
-                seq.append(raw, noff[nb + node] + pos, room);
-                for (uint32_t s = succ_off[nb + node]; s < succ_off[nb + node + 1]; ++s)
-                {
-                    nl.push_back(succ[s]);
-                    go(G, succ_off, succ, raw, noff, nb, k, nl, seq, start, 0, idx);
-                    nl.pop_back();
-                }
-                seq.resize(before);
+                if (!any_below)
+                    k = kk;
             }
-        };
+            if (k < 0)
+                return pg_fail(ctx, PG_ERR_UNSUPPORTED, "no k-mer length in 10..63 covers every node and edge with unique k-mers");
+        }
+        h_k[g] = (uint32_t)k;
         for (uint32_t node = 0; node < ne - nb; ++node)
-            for (uint32_t pos = 0; pos < G->h_node_len[nb + node]; ++pos)
-            {
-                nl.assign(1, node);
-                seq.clear();
-                Rec::go(G, succ_off, succ, raw, noff, nb, kmer_len, nl, seq, pos, pos, idx);
-            }
+            node_uniq[nb + node] = node_cnt[node] > 0;
         gd[g].node_base = nb;
         gd[g].n_nodes = ne - nb;
-        gd[g].pad = 0;
+        gd[g].k = (uint32_t)k;
+        gd[g].pow_k1 = 1;
+        for (int32_t i = 1; i < k; ++i)
+            gd[g].pow_k1 *= HASH_B;
         gd[g].tab_off = table.size();
         if (idx.empty())
         {
@@ -515,7 +526,7 @@ extern "C" pg_status pg_graphs_build_path_index(pg_ctx* ctx, pg_graphs* G, uint3
         table.resize(table.size() + cap, KmerEntry{});
         for (auto const& kv : idx)
         {
-            const uint64_t h = hash_str(kv.first.data(), kmer_len);
+            const uint64_t h = hash_str(kv.first.data(), (uint32_t)k);
             uint32_t slot = (uint32_t)(h >> 20) & (cap - 1);
             for (;;)
             {
@@ -538,9 +549,17 @@ extern "C" pg_status pg_graphs_build_path_index(pg_ctx* ctx, pg_graphs* G, uint3
         }
     }
     pg_path_index* ix = new pg_path_index();
-    ix->k = kmer_len;
+    ix->h_k = h_k;
+    ix->k = 0;
+    if (G->n_graphs)
+    {
+        ix->k = h_k[0];
+        for (uint32_t g = 1; g < G->n_graphs; ++g)
+            if (h_k[g] != h_k[0])
+                ix->k = 0;
+    }
     ix->pow_k1 = 1;
-    for (uint32_t i = 1; i < kmer_len; ++i)
+    for (uint32_t i = 1; i < ix->k; ++i)
         ix->pow_k1 *= HASH_B;
     std::vector<uint32_t> node_off(noff.begin(), noff.end());
     std::vector<char> rawv(raw.begin(), raw.end());
@@ -551,12 +570,29 @@ extern "C" pg_status pg_graphs_build_path_index(pg_ctx* ctx, pg_graphs* G, uint3
     if (e == hipSuccess) e = up(rawv, &ix->d_raw, ctx->stream);
     if (e == hipSuccess) e = up(succ_off, &ix->d_succ_off, ctx->stream);
     if (e == hipSuccess) e = up(succ, &ix->d_succ, ctx->stream);
+    if (e == hipSuccess) e = up(node_uniq, &ix->d_node_uniq, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess)
     {
         pg_path_index_free(ix);
-        return pg_fail(ctx, PG_ERR_HIP, std::string("path index upload: ") + hipGetErrorString(e));
+        return pg_fail(ctx, PG_ERR_HIP, std::string("k-mer index upload: ") + hipGetErrorString(e));
     }
+    *out = ix;
+    return PG_OK;
+}
+
+extern "C" pg_status pg_graphs_build_path_index(pg_ctx* ctx, pg_graphs* G, uint32_t kmer_len)
+{
+    if (!ctx || !G || kmer_len == 0 || kmer_len > 250)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_graphs_build_path_index: bad argument");
+    pg_path_index* ix = nullptr;
+    const pg_status st = pg_build_kmer_index(ctx, G, std::vector<int32_t>(G->n_graphs, (int32_t)kmer_len), &ix);
+    if (st != PG_OK)
+        return st;
+    ix->k = kmer_len;
+    ix->pow_k1 = 1;
+    for (uint32_t i = 1; i < kmer_len; ++i)
+        ix->pow_k1 *= HASH_B;
     pg_path_index_free(G->path_index);
     G->path_index = ix;
     // the extension walks predecessors too: reuse / create the caller-indexed predecessor tables
@@ -566,6 +602,23 @@ extern "C" pg_status pg_graphs_build_path_index(pg_ctx* ctx, pg_graphs* G, uint3
         HIP_TRY(ctx, up(G->h_pred, &G->d_cnt_pred, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return PG_OK;
+}
+
+/* KmerFilter's index (KmerFilter.cpp:52-76): kmer_len > 0 for every graph, or < 0 = auto-detected per graph */
+extern "C" pg_status pg_graphs_build_filter_index(pg_ctx* ctx, pg_graphs* G, int32_t kmer_len, uint32_t* kmer_len_of_graph)
+{
+    if (!ctx || !G || kmer_len == 0 || kmer_len > 250)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_graphs_build_filter_index: bad argument");
+    pg_path_index* ix = nullptr;
+    const pg_status st = pg_build_kmer_index(ctx, G, std::vector<int32_t>(G->n_graphs, kmer_len), &ix);
+    if (st != PG_OK)
+        return st;
+    if (kmer_len_of_graph)
+        for (uint32_t g = 0; g < G->n_graphs; ++g)
+            kmer_len_of_graph[g] = ix->h_k[g];
+    pg_path_index_free(G->filter_index);
+    G->filter_index = ix;
     return PG_OK;
 }
 

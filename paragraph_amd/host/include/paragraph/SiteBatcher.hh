@@ -38,6 +38,7 @@ struct BatchParameters
     bool remove_nonuniq_reads = true;  // paragraph --bad-align-nonuniq
     double bad_align_frac = 0.8;       // --bad-align-frac
     bool use_support_filters = true;   // production nodefilter / edgefilter
+    int32_t kmer_len = 0;              // --bad-align-uniq-kmer-len: 0 = no KmerFilter, < 0 = auto-detect per graph
     unsigned alignment_flags = (unsigned)-1;
 };
 

@@ -717,6 +717,12 @@ void SiteBatcher::run(BatchParameters const& prm)
     cp.remove_nonuniq = prm.remove_nonuniq_reads ? 1 : 0;
     cp.use_support_filters = prm.use_support_filters ? 1 : 0;
     cp.bad_align_frac = prm.bad_align_frac;
+    if (prm.kmer_len != 0)
+    {
+        // createReadFilter(graph, nonuniq, frac, kmer_len): NonUniq -> BadAlign -> KmerFilter (ReadFilter.cpp:74-90)
+        check(ctx, pg_graphs_build_filter_index(ctx, G, prm.kmer_len, nullptr), "pg_graphs_build_filter_index");
+        cp.use_kmer_filter = 1;
+    }
     check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
 
     uint64_t n_ops = 0, n_path = 0;

@@ -22,10 +22,13 @@ def count_checker():
     return oc.port_count_site
 
 
-def gpu_counts(ctx, graphs, labels, names, reads, gor, frag, isrev, **kw):
+def gpu_counts(ctx, graphs, labels, names, reads, gor, frag, isrev, filter_k=0, **kw):
     from paragraph_amd import capi
     G = ctx.upload_graphs(graphs)
     G.set_labels(labels, names)
+    if filter_k:
+        gpu_counts.filter_lengths = G.build_filter_index(filter_k)
+        kw = dict(kw, use_kmer_filter=True)
     b = ctx.new_batch()
     b.upload(G, reads, gor)
     b.align(capi.AF_ALL)
@@ -94,3 +97,71 @@ def test_counts_fuzz(gpu_ctx, checker):
             for ei, e in enumerate(cg_edges):
                 assert c["edge_counts"][e] == [int(x) for x in w["edge_counts"][ei]], (gi, e)
             assert c["seq_counts"] == w["seq_counts"], (gi, c["seq_counts"], w["seq_counts"])
+
+
+def _rc(s):
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    return "".join(comp.get(c, "N") for c in reversed(s))
+
+
+@pytest.mark.parametrize("filter_k", [4, 8, -1])
+def test_kmer_filter_fuzz(gpu_ctx, filter_k):
+    """KmerFilter as the third filter of the chain: per-read outcome and the resulting counters."""
+    from oracle import counts as oc
+    from oracle import kmerfilter as kf
+    check = count_checker()
+    fcheck = kf.ref_kmer_filter if oc.have_ref() else kf.port_kmer_filter
+    rng = random.Random(4040 + filter_k)
+    graphs, labels, names, reads, gor, frag, isrev = [], [], [], [], [], [], []
+    while len(graphs) < 80:
+        seqs, edges = fuzzgen.rand_graph(rng, max_len=40, max_nodes=6)
+        if filter_k < 0:
+            seqs = [s + "".join(rng.choice("ACGT") for _ in range(14)) for s in seqs]
+            if kf.port_kmer_filter(seqs, edges, filter_k, [])[0] < 0:
+                continue
+        lab, nm = fuzzgen.rand_labels(rng, edges)
+        rs = [fuzzgen.rand_read(rng, seqs, edges, min_len=10, max_len=90) for _ in range(rng.randint(4, 14))]
+        gi = len(graphs)
+        graphs.append((seqs, edges))
+        labels.append(lab)
+        names.append(nm)
+        reads.extend(rs)
+        gor.extend([gi] * len(rs))
+        frag.extend(fuzzgen.rand_fragments(rng, len(rs)))
+        isrev.extend([rng.random() < 0.5 for _ in rs])
+    kw = dict(remove_nonuniq=True, use_support_filters=True)
+    al, sup0, _ = gpu_counts(gpu_ctx, graphs, labels, names, reads, gor, frag, isrev, **kw)
+    al2, sup, cnt = gpu_counts(gpu_ctx, graphs, labels, names, reads, gor, frag, isrev, filter_k=filter_k, **kw)
+    lengths = gpu_counts.filter_lengths
+    n3 = n4 = nkeep = 0
+    k0 = 0
+    for gi, (seqs, edges) in enumerate(graphs):
+        idx = [i for i in range(len(reads)) if gor[i] == gi]
+        cand = [i for i in idx if sup0[i]["status"] == 1]
+        recs = [(al[i]["graph_pos"], al[i]["cigar"], _rc(reads[i]) if al[i]["returned_reverse"] else reads[i]) for i in cand]
+        kk, want = fcheck(seqs, edges, filter_k, recs)
+        assert kk == lengths[gi]
+        wmap = dict(zip(cand, want))
+        recs2 = []
+        for i in idx:
+            assert al2[i]["cigar"] == al[i]["cigar"]
+            if i in wmap:
+                filtered, msg = wmap[i]
+                exp = (1, 0) if not filtered else (2, 3 if msg == "kmer_tooshort" else 4)
+                assert (sup[i]["status"], sup[i]["filter"]) == exp, (graphs[gi], reads[i], al[i], sup[i], wmap[i])
+                n3 += exp[1] == 3
+                n4 += exp[1] == 4
+                nkeep += exp[1] == 0
+            else:
+                assert (sup[i]["status"], sup[i]["filter"]) == (sup0[i]["status"], sup0[i]["filter"])
+            keep = sup[i]["status"] == 1
+            recs2.append({"pos": al[i]["graph_pos"], "cigar": al[i]["cigar"], "aligned": al[i]["score"] > 0 and keep,
+                          "unique": al[i]["unique"], "graph_reverse": isrev[i] != al[i]["returned_reverse"],
+                          "read_len": len(reads[i]), "fragment": frag[i]})
+        w = check(oc.CountGraph(seqs, edges, labels[gi], names[gi]), recs2, **kw)
+        c = cnt[gi]
+        assert (c["node_counts"] == w["node_counts"]).all(), (gi, c["node_counts"], w["node_counts"])
+        assert c["seq_counts"] == w["seq_counts"]
+    assert n4 > 20 and nkeep > 20
+    if filter_k == 8:
+        assert n3 > 0

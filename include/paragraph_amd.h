@@ -24,6 +24,9 @@
  *   pg_graphs_set_labels graphtools::Graph::addLabelToEdge as grm::graphFromJson fills it   src/c++/lib/grm/GraphInput.cpp:126-156
  *   pg_graphs_build_path_index / pg_batch_path_align   grm::PathAligner::{setGraph,alignRead}   src/c++/lib/grm/PathAligner.cpp:70-164
  *   pg_graphs_build_kmer_index / pg_batch_kmer_align   grm::KmerAligner<16>::{setGraph,alignRead}   src/c++/lib/grm/KmerAligner.cpp:305-538
+ *   pg_graphs_build_klib_index / pg_batch_klib_align   grm::KlibAligner::{setGraph,alignRead}     src/c++/lib/grm/KlibAligner.cpp:186-442
+ *                        (+ common::KlibAlignment::update = ksw_align + ksw_global   src/c++/lib/common/Klib.cpp:144-164, external/klib/ksw.c)
+ *   pg_graphs_build_filter_index   readfilters::KmerFilter's graphtools::KmerIndex   src/c++/lib/paragraph/readfilters/KmerFilter.cpp:52-76
  *   pg_batch_set_active  the `status != MAPPED` hand-over between cascade stages   src/c++/lib/grm/CompositeAligner.cpp:78-176
  *   pg_batch_set_fragments   Read::fragment_id / is_reverse_strand of the input reads   src/c++/include/common/Read.hh:40-120
  *   pg_batch_count       read filters (NonUniq, BadAlign) applied by CompositeAligner::alignRead

@@ -79,7 +79,7 @@ enum
 
 enum
 {
-    PG_MAX_READ_LEN = 250, /* byte-mode gssw never overflows up to here (gssw.c:380) */
+    PG_MAX_READ_LEN = 512, /* <= 250: gssw's byte mode (never overflows, gssw.c:380); 251..512: its 16-bit word mode */
     PG_MAX_NODES = 4095
 };
 

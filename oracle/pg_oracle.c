@@ -22,8 +22,10 @@
  * tests/golden/ holds vectors generated from the real gssw.c.
  *
  * Scores are held in int32, i.e. no 8-bit saturation: identical to gssw for reads <= 250 bp
- * (250 + bias 4 < 255, gssw.c:380); longer reads take gssw's 16-bit restart path, which this file
- * models as plain arithmetic ("word mode", unpinned beyond the randomized comparison).
+ * (250 + bias 4 < 255, gssw.c:380); longer reads take gssw's 16-bit restart path ("word mode") once a score
+ * reaches 251, which is the same arithmetic -- except that GraphAligner's alignsEndAtMultNodes then reads the 16-bit
+ * matrix through a byte pointer, which aligns_end_at_mult_nodes() below reproduces.  Pinned against the real gssw.c
+ * by tests/test_oracle.py::test_port_vs_reference_gssw_word_mode.
  */
 #include <ctype.h>
 #include <pthread.h>
@@ -610,12 +612,29 @@ static int aligns_end_at_mult_nodes(pgo_graph* g, int dir, int32_t max_node, int
         const pgo_node* n = &nodes[id];
         int found = 0;
         size_t cells = (size_t)n->len * (size_t)L;
-        for (size_t c = 0; c < cells; ++c)
-            if (n->H[c] == top)
+        if (top >= 251)
+        {
+            /* The fill overflowed gssw's byte mode (score + bias >= 255, gssw.c:380, 4100-4104) and was redone in the
+             * 16-bit word mode, but alignsEndAtMultNodes still scans the matrix through a uint8_t* for len * readLen
+             * BYTES (GraphAligner.cpp:180-187): it sees the low/high bytes of the first half of the uint16 cells. */
+            for (size_t b = 0; b < cells; ++b)
             {
-                found = 1;
-                break;
+                const int32_t v = n->H[b / 2];
+                const int32_t byte = (b & 1) ? ((v >> 8) & 0xFF) : (v & 0xFF);
+                if (byte == top)
+                {
+                    found = 1;
+                    break;
+                }
             }
+        }
+        else
+            for (size_t c = 0; c < cells; ++c)
+                if (n->H[c] == top)
+                {
+                    found = 1;
+                    break;
+                }
         hits += found;
         if (hits > 1)
             return 1;

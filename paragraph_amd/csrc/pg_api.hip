@@ -515,8 +515,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active)
         const uint32_t L = base_off[i + 1] - base_off[i];
         if (L == 0 || (active && !active[i]))
             continue;
-        const uint32_t C = 2 * ((L + 31) / 32);
-        keys.push_back(Key{ C, graph_of_read[i], i });
+        keys.push_back(Key{ (uint32_t)pg_variant_of(L), graph_of_read[i], i });
     }
     std::stable_sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) {
         return x.c != y.c ? x.c < y.c : x.graph < y.graph;
@@ -550,7 +549,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active)
         const HostGraph& hg = G->host[keys[p].graph];
         const uint64_t nsteps = (uint64_t)hg.ncols + PG_GROUP_LANES - 1;
         const uint64_t trace_bytes = align_up(nsteps * 64 * pg_trace_lane_bytes(C), 256);
-        const uint64_t seed_bytes = align_up((uint64_t)hg.n_nodes * 64 * C * 4, 256);
+        const uint64_t seed_bytes = align_up((uint64_t)hg.n_nodes * 64 * pg_seed_lane_bytes(C), 256);
         const uint64_t need = trace_bytes + 2 * seed_bytes;
         if (need > ctx->ws_limit / 2)
             return fail(ctx, PG_ERR_UNSUPPORTED, "workspace limit too small for one wavefront of this graph");
@@ -651,7 +650,7 @@ extern "C" pg_status pg_batch_upload(
         if (graph_of_read[i] >= G->n_graphs)
             return fail(ctx, PG_ERR_INVALID, "graph_of_read out of range");
         if (L > PG_MAX_READ_LEN)
-            return fail(ctx, PG_ERR_UNSUPPORTED, "read longer than 250 bp (gssw word mode is not implemented)");
+            return fail(ctx, PG_ERR_UNSUPPORTED, "read longer than 512 bp");
         if (L == 0)
         {
             // grm::sequentialAlignReads skips reads without bases (Align.cpp:74-77)
@@ -659,7 +658,7 @@ extern "C" pg_status pg_batch_upload(
             b->has_skipped = true;
             continue;
         }
-        ops_total += pg_ops_cap((int)(2 * ((L + 31) / 32)));
+        ops_total += pg_ops_cap(pg_variant_of(L));
     }
     b->h_graph_of_read.assign(graph_of_read, graph_of_read + n_reads);
     b->h_base_off.assign(base_off, base_off + (n_reads ? n_reads + 1 : 0));

@@ -27,7 +27,8 @@
 
 #define PG_GAP_OPEN 6
 #define PG_GAP_EXT 1
-#define PG_PAD_SCORE (-300)
+#define PG_PAD_SCORE (-300)        // byte variants (scores <= 250)
+#define PG_PAD_SCORE_WIDE (-1000)  // wide variants (scores <= 512)
 
 struct PgGraphDir
 {
@@ -84,7 +85,19 @@ struct PgCountGraph
     uint64_t seq_base;  // first dense sequence-set slot (valid if n_labels <= PG_MAX_SEQ_TABLE_LABELS)
 };
 
-static inline __host__ __device__ uint32_t pg_rows(int C) { return (uint32_t)(PG_GROUP_LANES * C); }
-// bytes of H trace one lane writes per pipeline step: C rows x 2 strands
-static inline __host__ __device__ uint32_t pg_trace_lane_bytes(int C) { return (uint32_t)(2 * C); }
-static inline __host__ __device__ uint32_t pg_ops_cap(int C) { return pg_rows(C) + 32u; }
+// Kernel variants.  A variant code V is the rows-per-lane count C for the byte variants (reads <= 250 bp: one byte
+// of H per cell, C = 2 * ceil(L / 32) in 2..16) and 64 + C for the WIDE variants (reads of 251..512 bp, gssw's
+// 16-bit "word mode", gssw.c:527-786: two bytes of H per cell, C = 4 * ceil(L / 64) in 16..32).
+#define PG_VAR_WIDE 64
+static inline __host__ __device__ int pg_var_c(int V) { return V & 63; }
+static inline __host__ __device__ bool pg_var_wide(int V) { return V >= PG_VAR_WIDE; }
+static inline __host__ __device__ int pg_variant_of(uint32_t L)
+{
+    return L <= 250u ? (int)(2u * ((L + 31u) / 32u)) : PG_VAR_WIDE + (int)(4u * ((L + 63u) / 64u));
+}
+static inline __host__ __device__ uint32_t pg_rows(int V) { return (uint32_t)(PG_GROUP_LANES * pg_var_c(V)); }
+// bytes of H trace one lane writes per pipeline step: C rows x 2 strands (x 2 bytes when wide)
+static inline __host__ __device__ uint32_t pg_trace_lane_bytes(int V) { return (uint32_t)((pg_var_wide(V) ? 4 : 2) * pg_var_c(V)); }
+// bytes of seed (H, next-column E of both strands) one lane keeps per node
+static inline __host__ __device__ uint32_t pg_seed_lane_bytes(int V) { return (uint32_t)((pg_var_wide(V) ? 8 : 4) * pg_var_c(V)); }
+static inline __host__ __device__ uint32_t pg_ops_cap(int V) { return pg_rows(V) + 32u; }

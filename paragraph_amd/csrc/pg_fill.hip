@@ -113,12 +113,16 @@ __device__ __forceinline__ int sub_score(uint32_t a, uint32_t b)
     return (a == 4u || b == 4u) ? 0 : (a == b ? 1 : -4);
 }
 
-template <int C, int DIR>
+template <int C, int DIR, bool WIDE>
 __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair, uint32_t* lds)
 {
+    constexpr int PAD = WIDE ? PG_PAD_SCORE_WIDE : PG_PAD_SCORE;
+    constexpr int TRACE_DW = WIDE ? C : C / 2;  // dwords of H trace per lane per step
+    constexpr int SEED_DW = WIDE ? 2 * C : C;   // dwords of seed per lane per node
     constexpr int ROWS = PG_GROUP_LANES * C;
     uint32_t* prof = lds;                            // [4 reads][5 codes][ROWS] packed (strand A | strand B << 16)
-    uint32_t* nodekey = lds + PG_GROUPS * 5 * ROWS;  // [n_nodes][4 reads][2 strands]
+    uint32_t* nodekey = lds + PG_GROUPS * 5 * ROWS;  // [n_nodes][4 reads][2 strands]; u64 entries when WIDE
+    unsigned long long* nodekey64 = (unsigned long long*)nodekey;
 
     const int lane = threadIdx.x;
     const int grp = lane >> 4;
@@ -160,17 +164,17 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 #pragma unroll
         for (uint32_t code = 0; code < 5; ++code)
         {
-            const int sA = cA == 5u ? PG_PAD_SCORE : sub_score(code, cA);
-            const int sB = cB == 5u ? PG_PAD_SCORE : sub_score(code, cB);
+            const int sA = cA == 5u ? PAD : sub_score(code, cA);
+            const int sB = cB == 5u ? PAD : sub_score(code, cB);
             prof[(g * 5 + code) * ROWS + row] = ((uint32_t)sA & 0xFFFFu) | ((uint32_t)sB << 16);
         }
     }
-    for (uint32_t e = lane; e < n_nodes * 8; e += 64)
+    for (uint32_t e = lane; e < n_nodes * 8 * (WIDE ? 2u : 1u); e += 64)
         nodekey[e] = 0;
     __syncthreads();
 
-    uint32_t* __restrict__ seed = (uint32_t*)(a.workspace + itp->seed_off);    // [node][lane][C]
-    uint32_t* __restrict__ trace = (uint32_t*)(a.workspace + itp->trace_off);  // [step][lane][C/2]
+    uint32_t* __restrict__ seed = (uint32_t*)(a.workspace + itp->seed_off);    // [node][lane][SEED_DW]
+    uint32_t* __restrict__ trace = (uint32_t*)(a.workspace + itp->trace_off);  // [step][lane][TRACE_DW]
 
     uint32_t Hp[C], E[C];
 #pragma unroll
@@ -181,6 +185,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     }
     uint32_t Hsend = 0, Fsend = 0;
     uint32_t M = 0, FC = 0;
+    uint32_t FR = 0;  // WIDE: smallest row (within the lane) holding the lane's maximum in column FC, per strand
     // packed (col | col << 16) of the column this lane works on; col = t - k (wraps for idle lanes)
     uint32_t colv = (uint32_t)(0x10000 - k) & 0xFFFFu;
     colv |= colv << 16;
@@ -256,13 +261,21 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                     adj = true;
                     continue;
                 }
-                const uint32_t* sp = seed + ((size_t)pid * 64 + lane) * C;
+                const uint32_t* sp = seed + ((size_t)pid * 64 + lane) * SEED_DW;
 #pragma unroll
                 for (int r = 0; r < C; ++r)
                 {
-                    const uint32_t w = sp[r];  // bytes: H_A, H_B, Enext_A, Enext_B
-                    sh[r] = pk_maxu(sh[r], __builtin_amdgcn_perm(0u, w, 0x0c010c00u));
-                    se[r] = pk_maxu(se[r], __builtin_amdgcn_perm(0u, w, 0x0c030c02u));
+                    if (WIDE)
+                    {  // dwords: (H_A | H_B << 16), (Enext_A | Enext_B << 16)
+                        sh[r] = pk_maxu(sh[r], sp[2 * r]);
+                        se[r] = pk_maxu(se[r], sp[2 * r + 1]);
+                    }
+                    else
+                    {
+                        const uint32_t w = sp[r];  // bytes: H_A, H_B, Enext_A, Enext_B
+                        sh[r] = pk_maxu(sh[r], __builtin_amdgcn_perm(0u, w, 0x0c010c00u));
+                        se[r] = pk_maxu(se[r], __builtin_amdgcn_perm(0u, w, 0x0c030c02u));
+                    }
                 }
             }
 #pragma unroll
@@ -273,6 +286,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             }
             M = 0;
             FC = 0;
+            FR = 0;
         }
 
         // ---- one column of the affine-gap recurrence for C rows x 2 strands ------------------------
@@ -295,6 +309,35 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         Fsend = F;
 
         // ---- running node maximum + first column reaching it (gssw.c:369-386) -----------------------
+        if (WIDE)
+        {
+            // also the smallest row holding it: the reference's alignsEndAtMultNodes reads word-mode matrices through a
+            // byte pointer and so only sees the first half of every node's cells (epilogue)
+            uint32_t cm = hs[0];
+#pragma unroll
+            for (int r = 1; r < C; ++r)
+                cm = pk_maxu(cm, hs[r]);
+            const uint32_t Mn = pk_maxu(M, cm);
+            uint32_t inc = pk_minu(pk_sub(Mn, M), 0x00010001u);
+            inc = pk_sub(0u, inc);
+            FC = (FC & ~inc) | (colv & inc);
+            if (inc)
+            {
+                uint32_t frA = FR & 0xFFFFu, frB = FR >> 16;
+                const uint32_t mnA = Mn & 0xFFFFu, mnB = Mn >> 16;
+#pragma unroll
+                for (int r = C - 1; r >= 0; --r)
+                {
+                    if ((inc & 0xFFFFu) && (hs[r] & 0xFFFFu) == mnA)
+                        frA = (uint32_t)r;
+                    if ((inc >> 16) && (hs[r] >> 16) == mnB)
+                        frB = (uint32_t)r;
+                }
+                FR = frA | (frB << 16);
+            }
+            M = Mn;
+        }
+        else
         {
             // tree reduction (a chain would serialise 2C dependent packed ops)
 #pragma unroll
@@ -314,10 +357,19 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 
         if (DIR == 0)
         {
-            uint32_t* tp = trace + ((size_t)t * 64 + lane) * (C / 2);
+            uint32_t* tp = trace + ((size_t)t * 64 + lane) * TRACE_DW;
+            if (WIDE)
+            {
 #pragma unroll
-            for (int r = 0; r < C; r += 2)
-                tp[r / 2] = Hp[r] | (Hp[r + 1] << 8);  // bytes A_r, A_r+1, B_r, B_r+1
+                for (int r = 0; r < C; ++r)
+                    tp[r] = Hp[r];  // halves A_r, B_r
+            }
+            else
+            {
+#pragma unroll
+                for (int r = 0; r < C; r += 2)
+                    tp[r / 2] = Hp[r] | (Hp[r + 1] << 8);  // bytes A_r, A_r+1, B_r, B_r+1
+            }
         }
 
         if (meta_cur & PG_META_LAST)
@@ -325,19 +377,41 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             const uint32_t node = PG_META_NODE(meta_cur);
             if (meta_cur & PG_META_SAVE)
             {
-                uint32_t* sp = seed + ((size_t)node * 64 + lane) * C;
+                uint32_t* sp = seed + ((size_t)node * 64 + lane) * SEED_DW;
 #pragma unroll
                 for (int r = 0; r < C; ++r)
-                    sp[r] = __builtin_amdgcn_perm(E[r], Hp[r], 0x06040200u);
+                {
+                    if (WIDE)
+                    {
+                        sp[2 * r] = Hp[r];
+                        sp[2 * r + 1] = E[r];
+                    }
+                    else
+                        sp[r] = __builtin_amdgcn_perm(E[r], Hp[r], 0x06040200u);
+                }
             }
-            // key: max (8 bits) | inverted column (20 bits) | inverted lane (4 bits)
+            // key: max (12 bits) | inverted column (16 bits; a direction has <= 65519 columns) | inverted lane (4 bits)
             const uint32_t kinv = (uint32_t)(15 - k);
             const uint32_t mA = M & 0xFFFFu, mB = M >> 16;
             const uint32_t cA = FC & 0xFFFFu, cB = FC >> 16;
-            if (mA)
-                atomicMax(&nodekey[node * 8 + grp * 2 + 0], (mA << 24) | ((0xFFFFFu - cA) << 4) | kinv);
-            if (mB)
-                atomicMax(&nodekey[node * 8 + grp * 2 + 1], (mB << 24) | ((0xFFFFFu - cB) << 4) | kinv);
+            if (WIDE)
+            {
+                // key: max | inverted column (16 bits) | inverted row (16 bits)
+                const uint32_t rA = (uint32_t)(k * C) + (FR & 0xFFFFu), rB = (uint32_t)(k * C) + (FR >> 16);
+                if (mA)
+                    atomicMax(&nodekey64[node * 8 + grp * 2 + 0],
+                              ((unsigned long long)mA << 32) | ((unsigned long long)(0xFFFFu - cA) << 16) | (0xFFFFu - rA));
+                if (mB)
+                    atomicMax(&nodekey64[node * 8 + grp * 2 + 1],
+                              ((unsigned long long)mB << 32) | ((unsigned long long)(0xFFFFu - cB) << 16) | (0xFFFFu - rB));
+            }
+            else
+            {
+                if (mA)
+                    atomicMax(&nodekey[node * 8 + grp * 2 + 0], (mA << 20) | ((0xFFFFu - cA) << 4) | kinv);
+                if (mB)
+                    atomicMax(&nodekey[node * 8 + grp * 2 + 1], (mB << 20) | ((0xFFFFu - cB) << 4) | kinv);
+            }
         }
         colv = pk_add(colv, 0x00010001u);
 #pragma unroll
@@ -350,14 +424,74 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 
     // ---- per fill: max_node (first node with the strictly largest score, gssw.c:4015-4018), multi
     //      flag, end position --------------------------------------------------------------------------
-    if (k < 2)
+    if (k < 2 && WIDE)
+    {
+        const int strand = k;
+        unsigned long long bestkey = 0;
+        uint32_t best = 0, bestnode = 0, cnt = 0;
+        for (uint32_t n = 0; n < n_nodes; ++n)
+        {
+            const unsigned long long key = nodekey64[n * 8 + grp * 2 + strand];
+            const uint32_t m = (uint32_t)(key >> 32);
+            if (m > best)
+            {
+                best = m;
+                bestkey = key;
+                bestnode = n;
+                cnt = 1;
+            }
+            else if (m == best)
+                ++cnt;
+        }
+        if (best >= 251u)
+        {
+            // gssw redid this fill in its 16-bit word mode (score + bias >= 255, gssw.c:380, 4100-4104), but
+            // alignsEndAtMultNodes scans len * readLen BYTES of each node's matrix through a uint8_t*
+            // (GraphAligner.cpp:180-187): a node only counts if the top score (<= 255) sits in the low byte of one of its
+            // first ceil(len * readLen / 2) cells, in (reference position, read position) order.
+            cnt = 0;
+            if (best <= 255u)
+            {
+                const uint32_t ridx = itp->read[grp];
+                const uint32_t L = ridx == PG_NONE ? 0u : a.base_off[ridx + 1] - a.base_off[ridx];
+                for (uint32_t n = 0; n < n_nodes; ++n)
+                {
+                    const unsigned long long key = nodekey64[n * 8 + grp * 2 + strand];
+                    if ((uint32_t)(key >> 32) != best)
+                        continue;
+                    const uint32_t col = 0xFFFFu - (uint32_t)((key >> 16) & 0xFFFFu);
+                    const uint32_t row = 0xFFFFu - (uint32_t)(key & 0xFFFFu);
+                    const uint64_t cell = (uint64_t)(col - nodes[n].col_start) * L + row;
+                    if (cell < ((uint64_t)nodes[n].len * L + 1) / 2)
+                        ++cnt;
+                }
+            }
+        }
+        PgFillSummary fs;
+        fs.score = (int32_t)best;
+        fs.max_node = (int32_t)bestnode;
+        fs.ref_end = -1;
+        fs.read_end = 0;
+        fs.end_col = -1;
+        fs.multi = cnt > 1 ? 1 : 0;
+        fs.pad[0] = fs.pad[1] = 0;
+        if (best > 0 && DIR == 0)
+        {
+            const uint32_t col = 0xFFFFu - (uint32_t)((bestkey >> 16) & 0xFFFFu);
+            fs.end_col = (int32_t)col;
+            fs.ref_end = (int32_t)(col - nodes[bestnode].col_start);
+            fs.read_end = (int32_t)(0xFFFFu - (uint32_t)(bestkey & 0xFFFFu));
+        }
+        a.fillsum[((size_t)item_idx * PG_GROUPS + grp) * 2 + strand] = fs;
+    }
+    if (k < 2 && !WIDE)
     {
         const int strand = k;
         uint32_t best = 0, bestkey = 0, bestnode = 0, cnt = 0;
         for (uint32_t n = 0; n < n_nodes; ++n)
         {
             const uint32_t key = nodekey[n * 8 + grp * 2 + strand];
-            const uint32_t m = key >> 24;
+            const uint32_t m = key >> 20;
             if (m > best)
             {
                 best = m;
@@ -378,9 +512,9 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         fs.pad[0] = fs.pad[1] = 0;
         if (best > 0 && DIR == 0)
         {
-            const uint32_t col = 0xFFFFFu - ((bestkey >> 4) & 0xFFFFFu);
+            const uint32_t col = 0xFFFFu - ((bestkey >> 4) & 0xFFFFu);
             const uint32_t kk = 15u - (bestkey & 15u);
-            const uint32_t* tp = trace + ((size_t)(col + kk) * 64 + (grp * 16 + kk)) * (C / 2);
+            const uint32_t* tp = trace + ((size_t)(col + kk) * 64 + (grp * 16 + kk)) * TRACE_DW;
             int rr = 0;
             bool found = false;
 #pragma unroll
@@ -411,29 +545,30 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 // One launch covers both graph directions: even workgroups run the forward-graph body (stores the H trace),
 // odd ones the reversed-graph body (scores + multi flags only).  With AF_REVERSE_GRAPH off (both_dirs == 0)
 // every workgroup is a forward-graph one.
-template <int C>
+template <int C, bool WIDE>
 __global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if (a.both_dirs)
     {
         if (blockIdx.x & 1u)
-            pg_fill_body<C, 1>(a, blockIdx.x >> 1, lds);
+            pg_fill_body<C, 1, WIDE>(a, blockIdx.x >> 1, lds);
         else
-            pg_fill_body<C, 0>(a, blockIdx.x >> 1, lds);
+            pg_fill_body<C, 0, WIDE>(a, blockIdx.x >> 1, lds);
     }
     else
-        pg_fill_body<C, 0>(a, blockIdx.x, lds);
+        pg_fill_body<C, 0, WIDE>(a, blockIdx.x, lds);
 }
 
-size_t pg_fill_lds_bytes(int C, uint32_t max_nodes)
+size_t pg_fill_lds_bytes(int V, uint32_t max_nodes)
 {
-    return (size_t)(PG_GROUPS * 5 * PG_GROUP_LANES * C + max_nodes * 8) * sizeof(uint32_t);
+    return (size_t)(PG_GROUPS * 5 * PG_GROUP_LANES * pg_var_c(V) + max_nodes * 8 * (pg_var_wide(V) ? 2 : 1)) * sizeof(uint32_t);
 }
 
-template <int C> static hipError_t launch_c(PgFillArgs args, uint32_t n_pairs, bool revg, size_t lds, hipStream_t stream)
+template <int C, bool WIDE = false>
+static hipError_t launch_c(PgFillArgs args, uint32_t n_pairs, bool revg, size_t lds, hipStream_t stream)
 {
-    void (*fn)(PgFillArgs) = pg_fill_kernel<C>;
+    void (*fn)(PgFillArgs) = pg_fill_kernel<C, WIDE>;
     if (lds > 48 * 1024)
     {
         hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -461,6 +596,11 @@ hipError_t pg_launch_fill(int C, const PgFillArgs& args, uint32_t n_pairs, bool 
     case 12: return launch_c<12>(args, n_pairs, revg, lds, stream);
     case 14: return launch_c<14>(args, n_pairs, revg, lds, stream);
     case 16: return launch_c<16>(args, n_pairs, revg, lds, stream);
+    case PG_VAR_WIDE + 16: return launch_c<16, true>(args, n_pairs, revg, lds, stream);
+    case PG_VAR_WIDE + 20: return launch_c<20, true>(args, n_pairs, revg, lds, stream);
+    case PG_VAR_WIDE + 24: return launch_c<24, true>(args, n_pairs, revg, lds, stream);
+    case PG_VAR_WIDE + 28: return launch_c<28, true>(args, n_pairs, revg, lds, stream);
+    case PG_VAR_WIDE + 32: return launch_c<32, true>(args, n_pairs, revg, lds, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -112,7 +112,7 @@ struct Emitter
 };
 }  // namespace
 
-template <int C>
+template <int C, bool WIDE>
 __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
 {
     const uint32_t tid = blockIdx.x * 64u + threadIdx.x;
@@ -182,18 +182,34 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
     auto qchar = [&](int j) -> uint32_t {
         return s == 0 ? upper_c((uint8_t)bases[j]) : comp_c((uint8_t)bases[L - 1 - j]);
     };
+    // byte variants: trace [step][lane][C/2] dwords of bytes (A_r, A_r+1, B_r, B_r+1), seed [node][lane][C] dwords of
+    // bytes (H_A, H_B, Enext_A, Enext_B); wide variants: trace [step][lane][C] dwords (A_r | B_r << 16), seed
+    // [node][lane][2C] dwords (H_A | H_B << 16), (Enext_A | Enext_B << 16)
     auto Hcell = [&](uint32_t col, int j) -> int {
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
+        if (WIDE)
+        {
+            const size_t dw = ((size_t)(col + kq) * 64 + (grp * 16 + kq)) * C + r;
+            return (int)((const uint16_t*)trace)[dw * 2 + (uint32_t)s];
+        }
         const size_t dw = ((size_t)(col + kq) * 64 + (grp * 16 + kq)) * (C / 2) + r / 2;
         return (int)trace[dw * 4 + (r & 1u) + 2u * (uint32_t)s];
     };
-    auto seedw = [&](uint32_t node, int j) -> uint32_t {
+    auto seedH = [&](uint32_t node, int j) -> int {
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
-        return seed[((size_t)node * 64 + (grp * 16 + kq)) * C + r];
+        if (WIDE)
+            return (int)((seed[((size_t)node * 64 + (grp * 16 + kq)) * (2 * C) + 2 * r] >> (16 * s)) & 0xFFFFu);
+        return (int)((seed[((size_t)node * 64 + (grp * 16 + kq)) * C + r] >> (8 * s)) & 0xFFu);
+    };
+    auto seedE = [&](uint32_t node, int j) -> int {
+        const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
+        if (WIDE)
+            return (int)((seed[((size_t)node * 64 + (grp * 16 + kq)) * (2 * C) + 2 * r + 1] >> (16 * s)) & 0xFFFFu);
+        return (int)((seed[((size_t)node * 64 + (grp * 16 + kq)) * C + r] >> (16 + 8 * s)) & 0xFFu);
     };
 
     Emitter em;
-    em.cap = pg_ops_cap(C);
+    em.cap = pg_ops_cap(WIDE ? PG_VAR_WIDE + C : C);
     em.slot = a.ops_scratch + (size_t)tid * em.cap;
     em.n = 0;
     em.last_op = 0xFFu;
@@ -317,8 +333,7 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
                 int se = 0;
                 for (uint32_t p = 0; p < nd.n_pred; ++p)
                 {
-                    const uint32_t w = seedw(a.preds[nd.pred_off + p], j);
-                    const int en = (int)((w >> (16 + 8 * s)) & 0xFFu);
+                    const int en = seedE(a.preds[nd.pred_off + p], j);
                     se = en > se ? en : se;
                 }
                 if (sc == se)
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
                 const uint32_t rch = (uint8_t)refc[c0 + i];
                 const uint32_t qch = qchar(j);
                 const int sub = sub_score(nt_code(rch), nt_code(qch));
-                const int hp = (int)((seedw(pid, j - 1) >> (8 * s)) & 0xFFu);
+                const int hp = seedH(pid, j - 1);
                 if (sc == hp + sub)
                 {
                     const uint32_t op = (rch == 'N' || qch == 'N') ? PG_OPC_N : (rch == qch ? PG_OPC_M : PG_OPC_X);
@@ -372,9 +387,8 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
             }
             else
             {
-                const uint32_t w = seedw(pid, j);
-                const int hp = (int)((w >> (8 * s)) & 0xFFu);
-                const int en = (int)((w >> (16 + 8 * s)) & 0xFFu);
+                const int hp = seedH(pid, j);
+                const int en = seedE(pid, j);
                 if (sc == hp - PG_GAP_OPEN)
                 {
                     em.emit(n, PG_OPC_D, 1);
@@ -428,14 +442,19 @@ hipError_t pg_launch_trace(const PgTraceArgs& args, hipStream_t stream)
     const dim3 grid((threads + 63) / 64), block(64);
     switch (args.C)
     {
-    case 2: hipLaunchKernelGGL(pg_trace_kernel<2>, grid, block, 0, stream, args); break;
-    case 4: hipLaunchKernelGGL(pg_trace_kernel<4>, grid, block, 0, stream, args); break;
-    case 6: hipLaunchKernelGGL(pg_trace_kernel<6>, grid, block, 0, stream, args); break;
-    case 8: hipLaunchKernelGGL(pg_trace_kernel<8>, grid, block, 0, stream, args); break;
-    case 10: hipLaunchKernelGGL(pg_trace_kernel<10>, grid, block, 0, stream, args); break;
-    case 12: hipLaunchKernelGGL(pg_trace_kernel<12>, grid, block, 0, stream, args); break;
-    case 14: hipLaunchKernelGGL(pg_trace_kernel<14>, grid, block, 0, stream, args); break;
-    case 16: hipLaunchKernelGGL(pg_trace_kernel<16>, grid, block, 0, stream, args); break;
+    case 2: hipLaunchKernelGGL((pg_trace_kernel<2, false>), grid, block, 0, stream, args); break;
+    case 4: hipLaunchKernelGGL((pg_trace_kernel<4, false>), grid, block, 0, stream, args); break;
+    case 6: hipLaunchKernelGGL((pg_trace_kernel<6, false>), grid, block, 0, stream, args); break;
+    case 8: hipLaunchKernelGGL((pg_trace_kernel<8, false>), grid, block, 0, stream, args); break;
+    case 10: hipLaunchKernelGGL((pg_trace_kernel<10, false>), grid, block, 0, stream, args); break;
+    case 12: hipLaunchKernelGGL((pg_trace_kernel<12, false>), grid, block, 0, stream, args); break;
+    case 14: hipLaunchKernelGGL((pg_trace_kernel<14, false>), grid, block, 0, stream, args); break;
+    case 16: hipLaunchKernelGGL((pg_trace_kernel<16, false>), grid, block, 0, stream, args); break;
+    case PG_VAR_WIDE + 16: hipLaunchKernelGGL((pg_trace_kernel<16, true>), grid, block, 0, stream, args); break;
+    case PG_VAR_WIDE + 20: hipLaunchKernelGGL((pg_trace_kernel<20, true>), grid, block, 0, stream, args); break;
+    case PG_VAR_WIDE + 24: hipLaunchKernelGGL((pg_trace_kernel<24, true>), grid, block, 0, stream, args); break;
+    case PG_VAR_WIDE + 28: hipLaunchKernelGGL((pg_trace_kernel<28, true>), grid, block, 0, stream, args); break;
+    case PG_VAR_WIDE + 32: hipLaunchKernelGGL((pg_trace_kernel<32, true>), grid, block, 0, stream, args); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

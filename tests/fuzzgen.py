@@ -130,3 +130,33 @@ def rand_fragments(rng, n):
     ids = ids[:n]
     rng.shuffle(ids)
     return ids
+
+
+def long_read_case(rng, n_reads=6):
+    """Graphs whose paths are long enough for 251..512 bp reads that overflow gssw's byte mode (score >= 251), incl.
+    scores right at the 251..255 boundary and repeated flanks (ties between nodes)."""
+    n_mid = rng.randint(1, 3)
+    lf = rand_seq(rng, rng.randint(150, 300))
+    rf = lf if rng.random() < 0.25 else rand_seq(rng, rng.randint(150, 300))
+    mids = []
+    for _ in range(n_mid):
+        mids.append(mids[0] if mids and rng.random() < 0.3 else rand_seq(rng, rng.randint(1, 120)))
+    seqs = [lf] + mids + [rf]
+    last = len(seqs) - 1
+    edges = [(0, i + 1) for i in range(n_mid)] + [(i + 1, last) for i in range(n_mid)]
+    if rng.random() < 0.5:
+        edges.append((0, last))
+    edges = sorted(set(edges))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    reads = []
+    for _ in range(n_reads):
+        mid = rng.choice(range(n_mid + 1))
+        path = lf + (mids[mid] if mid < n_mid else "") + rf if (mid < n_mid or (0, last) in edges) else lf + mids[0] + rf
+        L = rng.choice([rng.randint(251, 262), rng.randint(251, 512)])
+        st = rng.randrange(max(1, len(path) - L + 1))
+        r = path[st:st + L]
+        r = mutate(rng, r, sub=rng.choice([0.0, 0.0, 0.005, 0.03]), indel=rng.choice([0.0, 0.0, 0.004]))[:512] or "A"
+        if rng.random() < 0.5:
+            r = "".join(comp.get(c, "N") for c in reversed(r))
+        reads.append(r)
+    return seqs, edges, reads

@@ -77,6 +77,30 @@ def test_fuzz_long_reads(gpu_ctx, checker):
     compare(got, want, reads, "fuzz-long")
 
 
+def test_fuzz_word_mode_reads(gpu_ctx, checker):
+    """251..512 bp reads: the wide kernel variants (two bytes of H per cell) = gssw's 16-bit word mode, incl. the
+    reference's byte-pointer scan of word matrices in alignsEndAtMultNodes (scores 251..255 / >= 256)."""
+    import random
+    rng = random.Random(512)
+    graphs, reads, gor, want = [], [], [], []
+    for gi in range(120):
+        if gi % 3 == 0:
+            seqs, edges = fuzzgen.rand_graph(rng, max_len=260, max_nodes=5)
+            rs = [fuzzgen.rand_read(rng, seqs, edges, min_len=240, max_len=512)[:512] for _ in range(8)]
+        else:
+            seqs, edges, rs = fuzzgen.long_read_case(rng, 8)
+        graphs.append((seqs, edges))
+        reads.extend(rs)
+        gor.extend([gi] * len(rs))
+        want.extend(checker.align_batch(seqs, edges, rs, cigar_stride=2048))
+    got = gpu_align(gpu_ctx, graphs, reads, gor)
+    compare(got, want, reads, "fuzz-word")
+    assert sum(1 for w in want if w["score"] >= 251) > 300
+    assert sum(1 for w in want if 251 <= max(w["scores"]) <= 255) > 15
+    assert sum(1 for w in want if max(w["scores"]) >= 251 and any(w["multi"])) > 0
+    assert max(len(r) for r in reads) > 480
+
+
 def test_config2_sample(gpu_ctx, checker):
     from paragraph_amd import synth
     site, reads = synth.config2_reads(4096, read_len=150, seed=2)

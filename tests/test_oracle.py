@@ -75,6 +75,34 @@ def test_port_vs_reference_gssw_randomized(port):
     assert n == 6000
 
 
+def test_port_vs_reference_gssw_word_mode(port):
+    """Reads of 251..512 bp: gssw restarts the fill in its 16-bit word mode once a score reaches 255 - bias
+    (gssw.c:380, 527-786); the port models that as plain arithmetic.  Pinned here against the real gssw.c,
+    with reads close enough to the graph that most of them do overflow the byte mode."""
+    import random
+    from oracle import oracle as orc
+    if not orc.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    ref = orc.RefOracle()
+    rng = random.Random(2511)
+    n = n_over = 0
+    n_edge = n_multi = 0
+    for it in range(150):
+        if it % 3 == 0:
+            seqs, edges = fuzzgen.rand_graph(rng, max_len=260, max_nodes=5)
+            reads = [fuzzgen.rand_read(rng, seqs, edges, min_len=251, max_len=512)[:512] for _ in range(6)]
+        else:
+            seqs, edges, reads = fuzzgen.long_read_case(rng)
+        a = ref.align_batch(seqs, edges, reads)
+        b = port.align_batch(seqs, edges, reads)
+        assert a == b, (seqs, edges)
+        n += len(reads)
+        n_over += sum(1 for x in a if x["score"] >= 251)
+        n_edge += sum(1 for x in a if 251 <= max(x["scores"]) <= 255)
+        n_multi += sum(1 for x in a if max(x["scores"]) >= 251 and any(x["multi"]))
+    assert n == 900 and n_over > 300 and n_edge > 20 and n_multi > 0
+
+
 def test_fill_level_outputs_vs_reference(port):
     from oracle import oracle as orc
     if not orc.have_ref():

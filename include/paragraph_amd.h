@@ -293,7 +293,7 @@ pg_status pg_batch_kmer_align(pg_ctx* ctx, pg_batch* batch, uint32_t flags);
 /* Paths as for pg_graphs_build_kmer_index (<= 30 per graph, whole nodes, no empty node). */
 pg_status pg_graphs_build_klib_index(
     pg_ctx* ctx, pg_graphs* graphs, const uint32_t* path_off, const uint32_t* path_node_off, const uint32_t* path_nodes);
-/* KlibAligner::alignRead for every ACTIVE read (reads <= 256 bases): per path and strand one local alignment with start
+/* KlibAligner::alignRead for every ACTIVE read (reads <= 512 bases): per path and strand one local alignment with start
  * recovery and a global re-alignment of the local window; best score wins, an equally good candidate with a different
  * (CIGAR, position) makes the read BAD_ALIGN.  results get PG_STATUS_KLIB_ALIGNER, score = number of matched bases
  * (KlibAligner.cpp:207-308), strand_score[] = the ksw score; stage flags as for the k-mer stage (bit0 MAPPED, bit2

@@ -38,7 +38,8 @@ constexpr int HEAP_CAP = MAX_PATHS + 2;
 // KlibAlignerImpl's scoring (KlibAligner.cpp:134-142): ksw charges gapo + gape for the first gap base
 constexpr int K_MATCH = 1, K_MISMATCH = -4, K_GAPO = 5, K_GAPE = 1, K_GAPOE = K_GAPO + K_GAPE;
 constexpr int K_MINUS_INF = -0x40000000;
-constexpr int Z_LANE_BYTES = 4;  // direction bytes per lane per step (R <= 4)
+// direction bytes per lane per step: one per row, padded to a dword (R <= 4) or two (R <= 8)
+constexpr int z_lane_bytes(int R) { return R <= 4 ? 4 : 8; }
 
 struct LPathDev
 {
@@ -222,7 +223,7 @@ __device__ __forceinline__ void klib_local(
 }
 
 // ksw_global sweep over the window: rows q[0..nrows), columns tcode[t0 + i], band w.  Writes one direction byte per
-// cell to z[((i + lane) * 64 + lane) * Z_LANE_BYTES + r].
+// cell to z[((i + lane) * 64 + lane) * z_lane_bytes(R) + r].
 template <int R>
 __device__ __forceinline__ void klib_global(
     const uint8_t* __restrict__ tcode, int t0, int ncols, const int (&q)[R], int nrows, int w, int lane, uint8_t* __restrict__ z)
@@ -260,7 +261,7 @@ __device__ __forceinline__ void klib_global(
         if (lane_on && i >= 0 && i < ncols)
         {
             int d = diag0, f = up_f;
-            uint32_t zw = 0;
+            uint64_t zw = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r)
             {
@@ -283,7 +284,7 @@ __device__ __forceinline__ void klib_global(
                     f -= K_GAPE;
                     dir |= f > h ? 32u : 0u;
                     f = f > h ? f : h;
-                    zw |= dir << (8 * r);
+                    zw |= (uint64_t)dir << (8 * r);
                 }
                 else
                 {
@@ -292,7 +293,10 @@ __device__ __forceinline__ void klib_global(
                     E[r] = K_MINUS_INF;
                 }
             }
-            *(uint32_t*)(z + ((size_t)t * 64 + (size_t)lane) * Z_LANE_BYTES) = zw;
+            if (R <= 4)
+                *(uint32_t*)(z + ((size_t)t * 64 + (size_t)lane) * 4) = (uint32_t)zw;
+            else
+                *(uint64_t*)(z + ((size_t)t * 64 + (size_t)lane) * 8) = zw;
             my_hlast = Hp[R - 1];
             my_f = f;
             diag0 = up_h;
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(64) void pg_klib_pair_kernel(KlibArgs a)
             while (i >= 0 && k >= 0)
             {
                 const int ln = k / R, rr = k % R;
-                const uint32_t zb = z[((size_t)(i + ln) * 64 + (size_t)ln) * Z_LANE_BYTES + (size_t)rr];
+                const uint32_t zb = z[((size_t)(i + ln) * 64 + (size_t)ln) * z_lane_bytes(R) + (size_t)rr];
                 which = (zb >> (which << 1)) & 3u;
                 if (which == 0)
                 {
@@ -908,8 +912,8 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     uint32_t max_len = 0;
     for (uint32_t r = 0; r < b->n_reads; ++r)
         max_len = std::max(max_len, b->h_base_off[r + 1] - b->h_base_off[r]);
-    if (max_len > 256)
-        return pg_fail(ctx, PG_ERR_UNSUPPORTED, "pg_batch_klib_align: reads longer than 256 bases are not supported");
+    if (max_len > 512)
+        return pg_fail(ctx, PG_ERR_UNSUPPORTED, "pg_batch_klib_align: reads longer than 512 bases are not supported");
     const int R = std::max(1, (int)((max_len + 63) / 64));
     const uint64_t n_items = (uint64_t)b->n_reads * 2u * ix->max_paths;
     if (!(flags & PG_AF_KEEP_RESULTS) || flags == PG_AF_ALL)
@@ -922,7 +926,7 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     // direction bytes: the window has at most 2 * L target columns (a local alignment with positive score cannot
     // delete more bases than it matches) and never more than the path; + 64 steps of skew
     const uint64_t z_steps = std::min<uint64_t>(2ull * max_len, ix->max_path_len) + 64 + 1;
-    const uint64_t z_bytes = z_steps * 64 * Z_LANE_BYTES;
+    const uint64_t z_bytes = z_steps * 64 * z_lane_bytes(R);
     const uint32_t cig_cap = 2 * max_len + 4;
     pg_status st = grow(ctx, &ix->d_items, &ix->items_cap, (size_t)n_items);
     if (st == PG_OK) st = grow(ctx, &ix->d_cigars, &ix->cigars_cap, (size_t)n_items * cig_cap);
@@ -957,7 +961,11 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     case 1: hipLaunchKernelGGL(pg_klib_pair_kernel<1>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
     case 2: hipLaunchKernelGGL(pg_klib_pair_kernel<2>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
     case 3: hipLaunchKernelGGL(pg_klib_pair_kernel<3>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
-    default: hipLaunchKernelGGL(pg_klib_pair_kernel<4>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+    case 4: hipLaunchKernelGGL(pg_klib_pair_kernel<4>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+    case 5: hipLaunchKernelGGL(pg_klib_pair_kernel<5>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+    case 6: hipLaunchKernelGGL(pg_klib_pair_kernel<6>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+    case 7: hipLaunchKernelGGL(pg_klib_pair_kernel<7>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+    default: hipLaunchKernelGGL(pg_klib_pair_kernel<8>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
     }
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(pg_klib_pick_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);

@@ -147,6 +147,26 @@ def test_klib_stage_150bp_site(gpu_ctx):
     assert n >= 290
 
 
+def test_klib_stage_long_reads(gpu_ctx):
+    """300..512 bp reads: R = 5..8 rows per lane, 8 direction bytes per lane per step."""
+    chk = checker()
+    rng = random.Random(11)
+    graphs, paths, reads, gor, want = [], [], [], [], []
+    for gi in range(12):
+        seqs, edges, rs = fuzzgen.long_read_case(rng, 6)
+        last = len(seqs) - 1
+        ps = [[0, i, last] for i in range(1, last)] + ([[0, last]] if (0, last) in edges else [])
+        rs = [r for r in rs] + [fuzzgen.mutate(rng, (seqs[0] + seqs[1] + seqs[last])[:rng.randint(300, 512)], sub=0.02, indel=0.01)[:512]]
+        graphs.append((seqs, edges))
+        paths.append(ps)
+        reads.extend(rs)
+        gor.extend([gi] * len(rs))
+        want.extend(chk.align(seqs, ps, rs))
+    flags, got = gpu_klib(gpu_ctx, graphs, paths, reads, gor)
+    n = check(flags, got, want, reads, "klib-long")
+    assert n > 60 and max(len(r) for r in reads) > 450
+
+
 def test_klib_after_kmer_keeps_results(gpu_ctx):
     """Cascade use: k-mer stage first, klib only on what it left unmapped, earlier results kept."""
     import numpy as np

@@ -47,6 +47,8 @@ def parse_args():
                     help="HBM budget for traceback state (two halves: trace of chunk i overlaps fill of chunk i+1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stream-batches", type=int, default=4,
+                    help="batches of the PCIe-inclusive streaming leg (0 = skip; reported beside the headline value)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_r01.json"),
                     help="PMC-derived HBM bytes per fill launch (written by tools/pmc_traffic.py), optional")
     return ap.parse_args()
@@ -212,6 +214,37 @@ def main():
         site_counts = capi.decode_counts(graphs, tab)[0]
     log("downloaded in %.2fs" % t_download)
 
+    # PCIe-inclusive leg, streaming form: host buffers -> device -> results on the host, two batch objects; the
+    # upload of batch i+1 and the download of batch i-1 run on the copy stream under the kernels of batch i
+    t_stream = None
+    if world == 1 and args.workload == "config2" and args.stream_batches > 0:
+        packed = synth.packed_to_capi(arr)
+        frag = np.arange(args.reads, dtype=np.uint32) // 2
+        bb = [ctx.new_batch(), ctx.new_batch()]
+        for b in bb:  # allocate once (steady state)
+            b.upload(graphs, packed)
+            b.set_fragments(frag)
+        ctx.sync()
+        t0 = time.perf_counter()
+        pending = None
+        for i in range(args.stream_batches):
+            b = bb[i & 1]
+            b.upload(graphs, packed)
+            b.set_fragments(frag)
+            b.align(capi.AF_ALL)
+            b.count(remove_nonuniq=True, bad_align_frac=0.8)
+            if pending is not None:
+                pending.download()
+                pending.download_counts()
+            pending = b
+        pending.download()
+        pending.download_counts()
+        ctx.sync()
+        t_stream = (time.perf_counter() - t0) / args.stream_batches
+        log("streaming leg: %.3fs per batch" % t_stream)
+        for b in bb:
+            b.close()
+
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -271,6 +304,10 @@ def main():
             "pcie_inclusive": {
                 "upload_s": t_upload, "download_s": t_download,
                 "reads_per_s": args.reads / (t_upload + elapsed / args.steps + t_download),
+                "streaming_s_per_batch": t_stream,
+                "streaming_reads_per_s": (args.reads / t_stream) if t_stream else None,
+                "note": "upload_s is the FIRST upload (allocations included); streaming = double-buffered steady state, "
+                        "host arrays in, results + ops + supports + counts out",
             },
         }
         if site_counts is not None and args.workload == "config2":

@@ -64,7 +64,8 @@ extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
         return PG_ERR_NOMEM;
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess
-        || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess)
+        || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess
+        || hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking) != hipSuccess)
     {
         delete ctx;
         return PG_ERR_HIP;
@@ -82,6 +83,8 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
         (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2)
         (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream_copy)
+        (void)hipStreamSynchronize(ctx->stream_copy);
     recycle_sync_events(ctx);
     for (auto e : ctx->sync_event_pool)
         (void)hipEventDestroy(e);
@@ -100,6 +103,8 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
         (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2)
         (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream_copy)
+        (void)hipStreamDestroy(ctx->stream_copy);
     delete ctx;
 }
 
@@ -116,10 +121,37 @@ extern "C" pg_status pg_ctx_sync(pg_ctx* ctx)
     if (!ctx)
         return PG_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     recycle_sync_events(ctx);
     return PG_OK;
+}
+
+hipError_t pg_stage_begin(pg_ctx* ctx, pg_batch* b)
+{
+    if (b->upload_recorded)
+        return hipStreamWaitEvent(ctx->stream, b->ev_upload, 0);
+    return hipSuccess;
+}
+
+hipError_t pg_stage_end(pg_ctx* ctx, pg_batch* b)
+{
+    if (!b->ev_busy)
+        return hipSuccess;
+    b->busy_recorded = true;
+    return hipEventRecord(b->ev_busy, ctx->stream);
+}
+
+hipError_t pg_batch_wait(pg_ctx* ctx, pg_batch* b)
+{
+    (void)ctx;
+    hipError_t e = hipSuccess;
+    if (b->upload_recorded)
+        e = hipEventSynchronize(b->ev_upload);
+    if (e == hipSuccess && b->busy_recorded)
+        e = hipEventSynchronize(b->ev_busy);
+    return e;
 }
 
 static pg_status drain_events(pg_ctx* ctx)
@@ -432,7 +464,16 @@ extern "C" pg_status pg_batch_create(pg_ctx* ctx, pg_batch** out)
     if (!ctx || !out)
         return PG_ERR_INVALID;
     *out = new (std::nothrow) pg_batch();
-    return *out ? PG_OK : PG_ERR_NOMEM;
+    if (!*out)
+        return PG_ERR_NOMEM;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipEventCreateWithFlags(&(*out)->ev_upload, hipEventDisableTiming) != hipSuccess
+        || hipEventCreateWithFlags(&(*out)->ev_busy, hipEventDisableTiming) != hipSuccess)
+    {
+        delete *out;
+        *out = nullptr;
+        return PG_ERR_HIP;
+    }
+    return PG_OK;
 }
 
 static void batch_free_device(pg_batch* b)
@@ -485,9 +526,15 @@ extern "C" void pg_batch_destroy(pg_ctx* ctx, pg_batch* b)
     if (ctx)
     {
         (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream_copy);
         (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream2);
     }
     batch_free_device(b);
+    if (b->ev_upload)
+        (void)hipEventDestroy(b->ev_upload);
+    if (b->ev_busy)
+        (void)hipEventDestroy(b->ev_busy);
     delete b;
 }
 
@@ -495,7 +542,7 @@ static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a
 
 // Builds the wavefront work items + chunk plan for the reads with active[i] != 0 (all reads when active is
 // NULL) and uploads them.  Items/fill summaries never need more room than the all-reads plan.
-static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active)
+static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hipStream_t cs)
 {
     const pg_graphs* G = b->graphs;
     const uint32_t n_reads = b->n_reads;
@@ -594,6 +641,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active)
     b->n_pairs = (uint32_t)(items.size() / 2);
     if (items.size() > b->cap_items)
     {
+        HIP_TRY(ctx, pg_batch_wait(ctx, b));  // kernels of an earlier use of this batch may still read them
         (void)hipFree(b->d_items);
         (void)hipFree(b->d_fillsum);
         b->cap_items = std::max<size_t>(items.size(), 2);
@@ -601,11 +649,12 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active)
         HIP_TRY(ctx, hipMalloc((void**)&b->d_fillsum, b->cap_items * PG_GROUPS * 2 * sizeof(PgFillSummary)));
     }
     if (!items.empty())
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_items, items.data(), items.size() * sizeof(PgWorkItem), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_items, items.data(), items.size() * sizeof(PgWorkItem), hipMemcpyHostToDevice, cs));
     // workspace / scratch owned by the ctx (shared by its batches)
     if (2 * b->max_ws > ctx->ws_cap)
     {
         // two halves: chunk i uses half (i & 1) so that trace(i) can overlap fill(i + 1)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
         if (ctx->workspace)
             HIP_TRY(ctx, hipFree(ctx->workspace));
@@ -616,6 +665,8 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active)
     }
     if (b->max_scratch > ctx->ops_scratch_cap)
     {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
         if (ctx->ops_scratch)
             HIP_TRY(ctx, hipFree(ctx->ops_scratch));
         ctx->ops_scratch = nullptr;
@@ -623,7 +674,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active)
         HIP_TRY(ctx, hipMalloc((void**)&ctx->ops_scratch, b->max_scratch * sizeof(pg_op)));
         ctx->ops_scratch_cap = b->max_scratch;
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `items` goes out of scope
+    HIP_TRY(ctx, hipStreamSynchronize(cs));  // `items` goes out of scope
     return PG_OK;
 }
 
@@ -634,7 +685,11 @@ extern "C" pg_status pg_batch_upload(
     if (!ctx || !b || !G || (n_reads && (!graph_of_read || !base_off || !bases)))
         return fail(ctx, PG_ERR_INVALID, "pg_batch_upload: null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // Uploads run on the copy stream: the upload of the NEXT batch overlaps the kernels of the current one.  Only an
+    // earlier use of THIS batch object has to be finished before its buffers are overwritten.
+    hipStream_t cs = ctx->stream_copy;
+    if (b->busy_recorded)
+        HIP_TRY(ctx, hipStreamWaitEvent(cs, b->ev_busy, 0));
     b->graphs = G;
     b->n_reads = n_reads;
     b->has_skipped = false;
@@ -669,6 +724,8 @@ extern "C" pg_status pg_batch_upload(
     const size_t n_bases = n_reads ? base_off[n_reads] : 0;
     if (n_reads + 1 > b->cap_reads || n_bases > b->cap_bases || ops_total > b->ops_cap)
     {
+        HIP_TRY(ctx, pg_batch_wait(ctx, b));
+        HIP_TRY(ctx, hipStreamSynchronize(cs));
         batch_free_device(b);
         b->cap_reads = n_reads + 1;
         b->cap_bases = std::max<size_t>(n_bases, 1);
@@ -684,15 +741,20 @@ extern "C" pg_status pg_batch_upload(
     }
     if (n_reads)
     {
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_base_off, base_off, (n_reads + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_graph_of_read, graph_of_read, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_base_off, base_off, (n_reads + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_graph_of_read, graph_of_read, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
         if (n_bases)
-            HIP_TRY(ctx, hipMemcpyAsync(b->d_bases, bases, n_bases, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_results, b->host_template.data(), n_reads * sizeof(pg_result), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(b->d_path_flags, 0, n_reads, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(b->d_bases, bases, n_bases, hipMemcpyHostToDevice, cs));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_results, b->host_template.data(), n_reads * sizeof(pg_result), hipMemcpyHostToDevice, cs));
+        HIP_TRY(ctx, hipMemsetAsync(b->d_path_flags, 0, n_reads, cs));
     }
-    HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
-    return plan_items(ctx, b, nullptr);
+    HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), cs));
+    const pg_status st = plan_items(ctx, b, nullptr, cs);
+    if (st != PG_OK)
+        return st;
+    HIP_TRY(ctx, hipEventRecord(b->ev_upload, cs));
+    b->upload_recorded = true;
+    return PG_OK;
 }
 
 extern "C" pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* b, const uint8_t* active)
@@ -700,11 +762,12 @@ extern "C" pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* b, const uint8_t
     if (!ctx || !b || !b->graphs)
         return fail(ctx, PG_ERR_INVALID, "pg_batch_set_active: batch not uploaded");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, pg_batch_wait(ctx, b));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     b->has_active = active != nullptr;
     if (active && b->n_reads)
         HIP_TRY(ctx, hipMemcpyAsync(b->d_active, active, b->n_reads, hipMemcpyHostToDevice, ctx->stream));
-    return plan_items(ctx, b, active);
+    return plan_items(ctx, b, active, ctx->stream);
 }
 
 extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
@@ -715,6 +778,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     const pg_graphs* G = b->graphs;
     if (2 * b->max_ws > ctx->ws_cap || b->max_scratch > ctx->ops_scratch_cap)
         return fail(ctx, PG_ERR_INVALID, "ctx workspace was shrunk after the batch was planned");
+    HIP_TRY(ctx, pg_stage_begin(ctx, b));
     if (!(flags & PG_AF_KEEP_RESULTS) || (flags == PG_AF_ALL))
         HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
     const bool revg = (flags & PG_AF_REVERSE_GRAPH) != 0;
@@ -811,6 +875,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     // everything later on the main stream (count path, downloads) sees the finished tracebacks
     for (size_t k = trace_done.size() >= 2 ? trace_done.size() - 2 : 0; k < trace_done.size(); ++k)
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, trace_done[k], 0));
+    HIP_TRY(ctx, pg_stage_end(ctx, b));
     return PG_OK;
 }
 
@@ -822,8 +887,9 @@ extern "C" pg_status pg_batch_ops_count(pg_ctx* ctx, pg_batch* b, uint64_t* n_op
     unsigned long long v = 0;
     if (b->d_ops_counter)
     {
-        HIP_TRY(ctx, hipMemcpyAsync(&v, b->d_ops_counter, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, pg_batch_wait(ctx, b));
+        HIP_TRY(ctx, hipMemcpyAsync(&v, b->d_ops_counter, sizeof v, hipMemcpyDeviceToHost, ctx->stream_copy));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
     }
     *n_ops = v;
     return PG_OK;
@@ -841,17 +907,17 @@ extern "C" pg_status pg_batch_download(
     if (n_ops)
         *n_ops = cnt;
     if (b->n_reads)
-        HIP_TRY(ctx, hipMemcpyAsync(results, b->d_results, b->n_reads * sizeof(pg_result), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(results, b->d_results, b->n_reads * sizeof(pg_result), hipMemcpyDeviceToHost, ctx->stream_copy));
     if (ops && cnt)
     {
         if (cnt > ops_cap)
         {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
             return fail(ctx, PG_ERR_OVERFLOW, "ops buffer too small");
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ops, b->d_ops, cnt * sizeof(pg_op), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ops, b->d_ops, cnt * sizeof(pg_op), hipMemcpyDeviceToHost, ctx->stream_copy));
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
     return PG_OK;
 }
 

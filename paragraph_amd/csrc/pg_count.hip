@@ -620,14 +620,19 @@ extern "C" pg_status pg_batch_set_fragments(
     }
     if (n)
     {
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_frag_reads, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_frag_off, frag_off.data(), frag_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_frag_reads, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream_copy));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_frag_off, frag_off.data(), frag_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream_copy));
         if (is_reverse_strand)
-            HIP_TRY(ctx, hipMemcpyAsync(b->d_is_rev, is_reverse_strand, n, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(b->d_is_rev, is_reverse_strand, n, hipMemcpyHostToDevice, ctx->stream_copy));
         else
-            HIP_TRY(ctx, hipMemsetAsync(b->d_is_rev, 0, n, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(b->d_is_rev, 0, n, ctx->stream_copy));
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `order` / `frag_off` are host temporaries
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));  // `order` / `frag_off` are host temporaries
+    if (b->ev_upload)
+    {
+        HIP_TRY(ctx, hipEventRecord(b->ev_upload, ctx->stream_copy));
+        b->upload_recorded = true;
+    }
     b->fragments_set = true;
     return PG_OK;
 }
@@ -642,6 +647,7 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     if (!b->fragments_set)
         return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_count: call pg_batch_set_fragments first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, pg_stage_begin(ctx, b));
     const uint32_t n = b->n_reads;
     pg_count_layout lay;
     layout_of(G, &lay);
@@ -703,6 +709,7 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
         hipLaunchKernelGGL(pg_fragment_kernel, dim3((b->n_frags + FRAG_BLOCK - 1) / FRAG_BLOCK), dim3(FRAG_BLOCK), 0, ctx->stream, a);
         HIP_TRY(ctx, hipGetLastError());
     }
+    HIP_TRY(ctx, pg_stage_end(ctx, b));
     return PG_OK;
 }
 
@@ -713,9 +720,10 @@ extern "C" pg_status pg_batch_download_counts(
     if (!ctx || !b || !b->graphs || !b->d_support)
         return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_download_counts: pg_batch_count has not run");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, pg_batch_wait(ctx, b));
     unsigned long long np = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&np, b->d_path_counter, sizeof np, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&np, b->d_path_counter, sizeof np, hipMemcpyDeviceToHost, ctx->stream_copy));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
     if (n_path)
         *n_path = np;
     if (counts)
@@ -724,19 +732,19 @@ extern "C" pg_status pg_batch_download_counts(
             return pg_fail(ctx, PG_ERR_INVALID, "the count table lives in caller memory (d_counts was given)");
         pg_count_layout lay;
         layout_of(b->graphs, &lay);
-        HIP_TRY(ctx, hipMemcpyAsync(counts, b->d_counts, lay.n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(counts, b->d_counts, lay.n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream_copy));
     }
     if (supports && b->n_reads)
-        HIP_TRY(ctx, hipMemcpyAsync(supports, b->d_support, b->n_reads * sizeof(pg_read_support), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(supports, b->d_support, b->n_reads * sizeof(pg_read_support), hipMemcpyDeviceToHost, ctx->stream_copy));
     if (path && np)
     {
         if (np > path_cap)
         {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
             return pg_fail(ctx, PG_ERR_OVERFLOW, "path buffer too small");
         }
-        HIP_TRY(ctx, hipMemcpyAsync(path, b->d_path, np * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(path, b->d_path, np * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream_copy));
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
     return PG_OK;
 }

@@ -35,6 +35,7 @@ struct pg_ctx
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // pick + traceback of chunk i overlaps the fill of chunk i + 1
+    hipStream_t stream_copy = nullptr;  // uploads of the NEXT batch / downloads of the PREVIOUS one overlap the kernels
     std::vector<hipEvent_t> sync_event_pool, sync_events_in_flight;
     uint64_t ws_limit = 8ull << 30;
     uint8_t* workspace = nullptr;
@@ -125,7 +126,18 @@ struct pg_batch
     uint32_t n_frags = 0;
     bool counts_owned_valid = false;
     bool fragments_set = false;
+    // ---- batch pipelining: uploads run on ctx->stream_copy, kernels on ctx->stream
+    hipEvent_t ev_upload = nullptr;  // recorded on stream_copy when the batch's inputs are resident
+    hipEvent_t ev_busy = nullptr;    // recorded on stream after the last stage queued for this batch
+    bool upload_recorded = false, busy_recorded = false;
 };
+
+// Every function that queues work on a batch's buffers on ctx->stream calls pg_stage_begin first (the main stream waits for
+// the batch's upload) and pg_stage_end last (marks the batch busy until here).  pg_batch_wait blocks the host until the
+// batch's queued stages and uploads are complete -- without waiting for other batches' work.
+hipError_t pg_stage_begin(pg_ctx* ctx, pg_batch* b);
+hipError_t pg_stage_end(pg_ctx* ctx, pg_batch* b);
+hipError_t pg_batch_wait(pg_ctx* ctx, pg_batch* b);
 
 
 pg_status pg_fail(pg_ctx* ctx, pg_status st, const std::string& msg);

@@ -916,6 +916,7 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
         return pg_fail(ctx, PG_ERR_UNSUPPORTED, "pg_batch_klib_align: reads longer than 512 bases are not supported");
     const int R = std::max(1, (int)((max_len + 63) / 64));
     const uint64_t n_items = (uint64_t)b->n_reads * 2u * ix->max_paths;
+    HIP_TRY(ctx, pg_stage_begin(ctx, b));
     if (!(flags & PG_AF_KEEP_RESULTS) || flags == PG_AF_ALL)
         HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
     if (b->n_reads == 0 || n_items == 0)
@@ -970,6 +971,7 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(pg_klib_pick_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, pg_stage_end(ctx, b));
     return PG_OK;
 }
 

@@ -599,6 +599,7 @@ extern "C" pg_status pg_batch_kmer_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
         HIP_TRY(ctx, hipMalloc((void**)&ix->d_bitmap, need * sizeof(uint32_t)));
         ix->bitmap_cap = need;
     }
+    HIP_TRY(ctx, pg_stage_begin(ctx, b));
     if (!(flags & PG_AF_KEEP_RESULTS) || flags == PG_AF_ALL)
         HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
     KmerArgs a{};
@@ -626,5 +627,6 @@ extern "C" pg_status pg_batch_kmer_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
         hipLaunchKernelGGL(pg_kmer_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
         HIP_TRY(ctx, hipGetLastError());
     }
+    HIP_TRY(ctx, pg_stage_end(ctx, b));
     return PG_OK;
 }

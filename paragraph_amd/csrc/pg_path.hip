@@ -631,6 +631,7 @@ extern "C" pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* b)
         return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_path_align: call pg_graphs_build_path_index first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const pg_path_index* ix = G->path_index;
+    HIP_TRY(ctx, pg_stage_begin(ctx, b));
     HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
     if (b->n_reads)
         HIP_TRY(ctx, hipMemsetAsync(b->d_path_flags, 0, b->n_reads, ctx->stream));
@@ -660,6 +661,7 @@ extern "C" pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* b)
         hipLaunchKernelGGL(pg_path_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
         HIP_TRY(ctx, hipGetLastError());
     }
+    HIP_TRY(ctx, pg_stage_end(ctx, b));
     return PG_OK;
 }
 
@@ -668,8 +670,9 @@ extern "C" pg_status pg_batch_download_path_flags(pg_ctx* ctx, pg_batch* b, uint
     if (!ctx || !b || (b->n_reads && !flags))
         return PG_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, pg_batch_wait(ctx, b));
     if (b->n_reads)
-        HIP_TRY(ctx, hipMemcpyAsync(flags, b->d_path_flags, b->n_reads, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(flags, b->d_path_flags, b->n_reads, hipMemcpyDeviceToHost, ctx->stream_copy));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
     return PG_OK;
 }

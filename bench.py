@@ -292,7 +292,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "pg_fill_kernel<%d>" % (2 * ((L + 31) // 32)),
+                "kernel": "pg_fill_kernel<%d, false>" % (2 * ((L + 31) // 32)),
                 "launches": int(tim["fill_launches"]),
                 "avg_launch_ms": tim["fill_ms"] / max(1, tim["fill_launches"]),
                 "alg_bytes_per_read": b_alg,

@@ -40,11 +40,12 @@ def build_host(force=False, verbose=False):
     """g++ -> paragraph_amd/libparagraph_host.so (reference-shaped C++ classes over the C ABI) and the C++ test
     program tests/host_cpp/test_host."""
     src = os.path.join(_HERE, "host", "src", "host.cpp")
+    gsrc = os.path.join(_HERE, "host", "src", "genotyping.cpp")
     inc = os.path.join(_HERE, "host", "include")
     hdrs = [os.path.join(dp, f) for dp, _, fs in os.walk(inc) for f in fs]
     cxx = os.environ.get("CXX", "g++")
-    if force or _stale(HOST_LIB, [src, LIB] + hdrs):
-        cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + inc, "-o", HOST_LIB, src, "-L" + _HERE,
+    if force or _stale(HOST_LIB, [src, gsrc, LIB] + hdrs):
+        cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + inc, "-o", HOST_LIB, src, gsrc, "-L" + _HERE,
                "-lparagraph_amd", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
@@ -59,9 +60,25 @@ def build_host(force=False, verbose=False):
     return HOST_LIB
 
 
+def build_genotyping_test(force=False, verbose=False):
+    """CPU-only: the host genotyping module + its test program (no HIP, runs in the "not gpu" suite)."""
+    gsrc = os.path.join(_HERE, "host", "src", "genotyping.cpp")
+    inc = os.path.join(_HERE, "host", "include")
+    tsrc = os.path.join(ROOT, "tests", "host_cpp", "test_genotyping.cpp")
+    exe = os.path.join(ROOT, "tests", "host_cpp", "test_genotyping")
+    hdrs = [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(inc, "genotyping")) for f in fs]
+    if force or _stale(exe, [tsrc, gsrc] + hdrs):
+        cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-I" + inc, "-o", exe, tsrc, gsrc]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return exe
+
+
 def build_all(force=False, verbose=False):
     build_hip(force=force, verbose=verbose)
     build_host(force=force, verbose=verbose)
+    build_genotyping_test(force=force, verbose=verbose)
 
 
 if __name__ == "__main__":

@@ -33,6 +33,16 @@ struct SiteCounts
     uint64_t aligned = 0, mapped = 0, bad_align = 0, nonuniq = 0;
 };
 
+// read_counts_by_edge as genotyping::BreakpointStatistics::addCounts reads it (BreakpointStatistics.cpp:108-143): fragment
+// counts keyed "<from>_<to>"
+inline std::map<std::string, int32_t> readCountsByEdge(SiteCounts const& c)
+{
+    std::map<std::string, int32_t> out;
+    for (auto const& kv : c.by_edge)
+        out[kv.first] = (int32_t)kv.second.count;
+    return out;
+}
+
 struct BatchParameters
 {
     bool remove_nonuniq_reads = true;  // paragraph --bad-align-nonuniq

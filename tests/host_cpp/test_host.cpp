@@ -7,12 +7,14 @@
 #include <cstdlib>
 #include <iostream>
 #include <list>
+#include <random>
 #include <string>
 #include <vector>
 
 #include "grm/Align.hh"
 #include "grm/CompositeAligner.hh"
 #include "grm/GraphAligner.hh"
+#include "genotyping/GraphBreakpointGenotyper.hh"
 #include "paragraph/SiteBatcher.hh"
 
 using namespace common;
@@ -387,10 +389,76 @@ static void testKlibAligner()
     EXPECT_EQ(c2.graph_cigar(), std::string("0[5M]2[8M]3[6M]"));
 }
 
+// align + count on the device, genotype on the host (lib/grmpy/CountAndGenotype.cpp:46-88): a 60 bp deletion, three
+// samples simulated as REF/REF, REF/ALT and ALT/ALT at ~30x
+static void testSiteToGenotype()
+{
+    std::mt19937_64 rng(11);
+    auto rnd = [&](size_t n) {
+        std::string s(n, 'A');
+        for (auto& c : s)
+            c = "ACGT"[rng() % 4];
+        return s;
+    };
+    Graph g(5, false);
+    const char* names[5] = { "source", "LF", "MID", "RF", "sink" };
+    const std::string seqs[5] = { "X", rnd(200), rnd(60), rnd(200), "X" };
+    for (NodeId n = 0; n < 5; ++n)
+    {
+        g.setNodeName(n, names[n]);
+        g.setNodeSeq(n, seqs[n]);
+    }
+    g.addEdge(0, 1);
+    g.addEdge(1, 2);
+    g.addEdge(1, 3);
+    g.addEdge(2, 3);
+    g.addEdge(3, 4);
+    g.addLabelToEdge(1, 2, "REF");
+    g.addLabelToEdge(2, 3, "REF");
+    g.addLabelToEdge(1, 3, "ALT");
+    const std::string hap[2] = { seqs[1] + seqs[2] + seqs[3], seqs[1] + seqs[3] };
+    const int alt_copies[3] = { 0, 1, 2 };
+    const char* want[3] = { "REF/REF", "ALT/REF", "ALT/ALT" };
+    genotyping::GraphBreakpointGenotyper genotyper;
+    genotyper.reset(&g);
+    std::vector<std::vector<p_Read>> reads(3);
+    paragraph::SiteBatcher batcher;
+    const int L = 100;
+    for (int s = 0; s < 3; ++s)
+    {
+        for (int copy = 0; copy < 2; ++copy)
+        {
+            const std::string& h = hap[copy < alt_copies[s] ? 1 : 0];
+            const int n_reads = (int)(15.0 * h.size() / L);  // 15x per haplotype
+            for (int i = 0; i < n_reads; ++i)
+            {
+                const size_t st = rng() % (h.size() - L + 1);
+                std::string r = h.substr(st, L);
+                if (rng() % 50 == 0)
+                    r[rng() % L] = "ACGT"[rng() % 4];
+                reads[s].emplace_back(new Read("s" + std::to_string(s) + "c" + std::to_string(copy) + "r" + std::to_string(i), r, std::string(L, '#')));
+            }
+        }
+        batcher.addSite(&g, &reads[s]);
+    }
+    batcher.run();
+    for (int s = 0; s < 3; ++s)
+        genotyper.addSample("sample" + std::to_string(s), paragraph::readCountsByEdge(batcher.counts(s)), 30.0, L, 8.0);
+    genotyper.runGenotyping();
+    const std::vector<std::string>& an = genotyper.alleleNames();
+    for (int s = 0; s < 3; ++s)
+    {
+        const genotyping::Genotype gt = genotyper.getGenotype("sample" + std::to_string(s), "");
+        EXPECT_EQ(gt.toString(&an), std::string(want[s]));
+        EXPECT_EQ(gt.filterString(), std::string("PASS"));
+    }
+}
+
 int main()
 {
     try
     {
+        testSiteToGenotype();
         testKlibAligner();
         testKmerAligner();
         testPathAligner();

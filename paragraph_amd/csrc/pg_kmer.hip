@@ -6,11 +6,12 @@
 //
 // Host: for every path of every graph the path sequence, its node starts and the (k-mer, position) table sorted
 // by (k-mer, position) (windows of k consecutive ACGT/acgt bases, 2 bits per base, first base most significant).
-// Device: one thread per read.  Per (path, strand): the reference's merge-join of the read's sorted k-mers against
-// the path table (including its quirk: a k-mer that occurs twice in the read only joins through its first
-// occurrence) produces candidate diagonals; they are visited in ascending offset through a bitmap, scored by
-// Hamming distance over the raw characters and kept in a bounded max-heap that replays libstdc++'s
-// push_heap/pop_heap element order (capacity = paths + 2).  pickBest: fewest mismatches (<= 2) wins; any equally
+// Device: one WAVEFRONT per read.  Per strand the read's k-mers are sorted in LDS; per (path, strand) the reference's
+// merge-join of the sorted read k-mers against the path table (including its quirk: a k-mer that occurs twice in the read
+// only joins through its first occurrence) runs lane-parallel and produces candidate diagonals; they are visited in
+// ascending offset through a bitmap, scored by a wave-wide Hamming distance over the raw characters and kept in a bounded
+// max-heap that replays libstdc++'s push_heap/pop_heap element order (capacity = paths + 2).  CIGARs: the wave writes one
+// (node, op) label per read position into LDS; candidates are compared label by label, the best one is run-length encoded.  pickBest: fewest mismatches (<= 2) wins; any equally
 // good candidate with a different (CIGAR, position) makes the read BAD_ALIGN.  CIGARs are never materialised as
 // strings: two candidates are compared by streaming their run-length elements side by side.
 #include <hip/hip_runtime.h>
@@ -57,13 +58,16 @@ struct KmerArgs
     const uint32_t* starts;
     const uint32_t* kmers;
     const uint32_t* kpos;
-    uint32_t* bitmap;  // [n_reads][bitmap_words]
-    uint32_t bitmap_words;
     pg_result* results;
     pg_op* ops;
     unsigned long long* ops_counter;
     uint8_t* flags;
     const uint8_t* active;  // nullptr = every read
+    // dynamic LDS layout (sized by the batch's longest read and the index's longest path)
+    uint32_t n_sort;    // k-mer windows per strand, padded to a power of two
+    uint32_t l_max;     // longest read, padded to a multiple of 4
+    uint32_t bm_words;  // candidate-offset bitmap
+    uint32_t cache_n;   // path-table entries cached in LDS (paths with more k-mers are searched in global memory)
 };
 
 __device__ __forceinline__ uint32_t comp_raw(uint32_t c)
@@ -98,131 +102,82 @@ struct Cand
 };
 
 struct ReadView
-{
-    const char* bases;
+{  // both strands of the read as raw characters (forward: as given; reverse: reverseComplement), staged in LDS
+    const uint8_t* fwd;
+    const uint8_t* rev;
     int L;
-    __device__ uint32_t at(int j, bool reverse) const { return reverse ? comp_raw((uint8_t)bases[L - 1 - j]) : (uint8_t)bases[j]; }
+    __device__ uint32_t at(int j, bool reverse) const { return reverse ? rev[j] : fwd[j]; }
 };
 
-// Streams the run-length CIGAR elements of one candidate alignment (KmerAligner.cpp:321-472).
-struct OpGen
+// Per-position labels of one candidate alignment (KmerAligner.cpp:321-472), written by the whole wavefront into `lab`
+// (LDS): label = node id << 4 | op for every read position; the graph CIGAR is the run-length encoding of that array.
+// Reference positions that are 'N' at the ends of the window are soft-clipped (:326-329); the clip belongs to the first /
+// last aligned node.  Returns false (uniformly) when nothing is left to align (no CIGAR at all).
+struct CandLabels
 {
-    const KmerArgs& a;
-    const KPathDev p;
-    ReadView rv;
-    bool reverse;
-    // alignment geometry
-    uint32_t pos;  // path position of the first non-clipped base
-    int left, right;
-    uint32_t node_idx, this_start;
-    int length_left, it;
-    bool left_pending;
-    // per-node state
-    int node_remaining;  // bases of the current node still to emit (0 = need a new node)
-    uint32_t cur_node;
-    bool right_pending;
     int32_t graph_pos;
-
-    __device__ uint32_t ref(uint32_t i) const { return (uint8_t)a.pathseq[p.seq_off + i]; }
-    __device__ uint32_t start_of(uint32_t i) const { return a.starts[p.start_off + 2 * i]; }
-    __device__ uint32_t node_of(uint32_t i) const { return a.starts[p.start_off + 2 * i + 1]; }
-
-    __device__ void init(uint32_t cand_pos)
-    {
-        const int L = rv.L;
-        left = 0;
-        while (left < L && ref(cand_pos + left) == 'N')
-            ++left;
-        right = 0;
-        while (right < L - left && ref(cand_pos + L - 1 - right) == 'N')
-            ++right;
-        pos = cand_pos + left;
-        node_idx = 0;
-        for (uint32_t i = 0; i < p.n_nodes; ++i)
-            if (start_of(i) <= pos)
-                node_idx = i;
-        this_start = pos - start_of(node_idx);
-        graph_pos = (int32_t)this_start;
-        length_left = L - left - right;
-        it = left;
-        left_pending = left > 0;
-        right_pending = false;
-        node_remaining = 0;
-        cur_node = 0;
-    }
-
-    // next element: returns false at the end; (node, op, len)
-    __device__ bool next(uint32_t& node, uint32_t& op, uint32_t& len)
-    {
-        for (;;)
-        {
-            if (node_remaining > 0)
-            {
-                if (left_pending)
-                {
-                    left_pending = false;
-                    node = cur_node;
-                    op = PG_OPC_S;
-                    len = (uint32_t)left;
-                    return true;
-                }
-                // one run of equal ops inside the node
-                const uint32_t r0 = this_start + start_of(node_idx);
-                auto opat = [&](int j) -> uint32_t {
-                    const uint32_t rc = ref(r0 + (uint32_t)j), qc = rv.at(it + j, reverse);
-                    return rc == qc ? PG_OPC_M : ((rc == 'N' || qc == 'N') ? PG_OPC_N : PG_OPC_X);
-                };
-                const uint32_t o = opat(0);
-                int run = 1;
-                while (run < node_remaining && opat(run) == o)
-                    ++run;
-                node = cur_node;
-                op = o;
-                len = (uint32_t)run;
-                it += run;
-                this_start += (uint32_t)run;
-                node_remaining -= run;
-                if (node_remaining == 0 && !(right > 0 && length_left == 0))
-                {
-                    ++node_idx;
-                    this_start = 0;
-                }
-                else if (node_remaining == 0)
-                    right_pending = true;
-                return true;
-            }
-            if (right_pending)
-            {
-                right_pending = false;
-                node = cur_node;
-                op = PG_OPC_S;
-                len = (uint32_t)right;
-                ++node_idx;
-                this_start = 0;
-                return true;
-            }
-            if (node_idx >= p.n_nodes || length_left <= 0)
-                return false;
-            int this_length = length_left;
-            if (node_idx + 1 < p.n_nodes)
-            {
-                const int room = (int)(start_of(node_idx + 1) - start_of(node_idx) - this_start);
-                this_length = room < length_left ? room : length_left;
-            }
-            if (this_length > 0)
-            {
-                cur_node = node_of(node_idx);
-                node_remaining = this_length;
-                length_left -= this_length;
-            }
-            else
-            {
-                ++node_idx;
-                this_start = 0;
-            }
-        }
-    }
+    int left, right;
+    uint32_t matches;
 };
+
+__device__ bool label_candidate(
+    const KmerArgs& a, const KPathDev& p, const ReadView& rv, bool reverse, uint32_t cand_pos, int lane, uint32_t* lab, CandLabels& out)
+{
+    const int L = rv.L;
+    auto ref = [&](uint32_t i) -> uint32_t { return (uint8_t)a.pathseq[p.seq_off + i]; };
+    auto start_of = [&](uint32_t i) -> uint32_t { return a.starts[p.start_off + 2 * i]; };
+    auto node_of = [&](uint32_t i) -> uint32_t { return a.starts[p.start_off + 2 * i + 1]; };
+    int left = 0;
+    while (left < L && ref(cand_pos + left) == 'N')
+        ++left;
+    int right = 0;
+    while (right < L - left && ref(cand_pos + L - 1 - right) == 'N')
+        ++right;
+    const uint32_t pos = cand_pos + (uint32_t)left;
+    uint32_t node_idx = 0;
+    for (uint32_t i = 0; i < p.n_nodes; ++i)
+        if (start_of(i) <= pos)
+            node_idx = i;
+    out.graph_pos = (int32_t)(pos - start_of(node_idx));
+    out.left = left;
+    out.right = right;
+    out.matches = 0;
+    const int aligned = L - left - right;
+    if (aligned <= 0)
+        return false;
+    // node of the last aligned base (the right clip is printed inside its bracket)
+    const uint32_t last_pp = cand_pos + (uint32_t)(L - right - 1);
+    uint32_t last_idx = node_idx;
+    for (uint32_t i = node_idx; i < p.n_nodes; ++i)
+        if (start_of(i) <= last_pp)
+            last_idx = i;
+    uint32_t m = 0;
+    for (int j = lane; j < L; j += 64)
+    {
+        uint32_t label;
+        if (j < left)
+            label = (node_of(node_idx) << 4) | PG_OPC_S;
+        else if (j >= L - right)
+            label = (node_of(last_idx) << 4) | PG_OPC_S | 8u;  // | 8: a right clip never merges with a left one
+        else
+        {
+            const uint32_t pp = cand_pos + (uint32_t)j;
+            uint32_t ni = node_idx;
+            while (ni + 1 < p.n_nodes && start_of(ni + 1) <= pp)
+                ++ni;
+            const uint32_t rc = ref(pp), qc = rv.at(j, reverse);
+            const uint32_t op = rc == qc ? PG_OPC_M : ((rc == 'N' || qc == 'N') ? PG_OPC_N : PG_OPC_X);
+            m += op == PG_OPC_M;
+            label = (node_of(ni) << 4) | op;
+        }
+        lab[j] = label;
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1)
+        m += __shfl_xor(m, k);
+    out.matches = m;
+    return true;
+}
 
 __device__ void heap_push(Cand* h, int& n, const Cand& v)
 {  // std::push_heap with Candidate::lessMismatches (max-heap on mismatches)
@@ -269,26 +224,100 @@ __device__ void heap_pop(Cand* h, int& n)
     n = len;
 }
 
+constexpr int KMER_SORT_MAX = 512;  // windows per strand (reads <= 512 bp)
+
+// One WAVEFRONT per read.  The read and its reverse complement are staged in LDS; per strand the (k-mer, position) pairs are
+// produced by the 64 lanes and sorted in LDS (bitonic, 64-bit keys, both strands in the same passes); each path's sorted
+// table is cached in LDS and joined in parallel: lane j takes sorted entry j, and -- this is the reference's single-cursor
+// merge (KmerAligner.cpp:246-276) -- only the FIRST read occurrence of a k-mer value joins, with every path entry of that
+// value.  Candidate diagonals go into an LDS bitmap, are visited in ascending offset, scored by a wave-wide Hamming
+// distance and pushed into the bounded heap by lane 0 (libstdc++ element order).
 __global__ __launch_bounds__(64) void pg_kmer_kernel(KmerArgs a)
 {
-    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char kmer_lds[];
+    unsigned long long* skey0 = (unsigned long long*)kmer_lds;       // [2][n_sort] sorted (k-mer << 32 | position)
+    uint32_t* slab0 = (uint32_t*)(skey0 + 2 * a.n_sort);            // [2][l_max] per-position labels (best / rival)
+    uint32_t* sbm = slab0 + 2 * a.l_max;                            // [bm_words]
+    uint32_t* spk = sbm + a.bm_words;                               // [cache_n] path k-mers
+    uint32_t* spp = spk + a.cache_n;                                // [cache_n] path positions
+    Cand* sheap = (Cand*)(spp + a.cache_n);                         // [HEAP_CAP]
+    int* shn_p = (int*)(sheap + HEAP_CAP);
+    uint8_t* sread = (uint8_t*)(shn_p + 4);                         // [2][l_max]
+    uint32_t* slab[2] = { slab0, slab0 + a.l_max };
+    const uint32_t r = blockIdx.x;
+    const int lane = (int)threadIdx.x;
     if (r >= a.n_reads || (a.active && !a.active[r]))
         return;
     const uint32_t off = a.base_off[r];
     const int L = (int)(a.base_off[r + 1] - off);
-    a.flags[r] = 0;
-    if (L == 0)
+    if (lane == 0)
+        a.flags[r] = 0;
+    if (L == 0 || L > (int)a.l_max)
         return;
     const KGraphDev g = a.graphs[a.graph_of_read[r]];
     if (g.n_paths == 0 || g.n_paths > MAX_PATHS)
         return;
-    ReadView rv{ a.bases + off, L };
+    for (int j = lane; j < L; j += 64)
+    {
+        sread[j] = (uint8_t)a.bases[off + j];
+        sread[a.l_max + j] = (uint8_t)comp_raw((uint8_t)a.bases[off + L - 1 - j]);
+    }
+    ReadView rv{ sread, sread + a.l_max, L };
     const int K = (int)a.k;
-    Cand heap[HEAP_CAP];
-    int hn = 0;
     const int cap = (int)g.n_paths + 2;
-    uint32_t* bm = a.bitmap + (size_t)r * a.bitmap_words;
+    uint32_t* bm = sbm;
+    int& shn = *shn_p;
+    if (lane == 0)
+        shn = 0;
+    __syncthreads();
 
+    const int n_win = L >= K ? L - K + 1 : 0;
+    int N = 64;
+    while (N < n_win)
+        N <<= 1;
+    // ---- sorted (k-mer, position) pairs of both strands (KmerAligner.cpp:120-133) ------------------------------------
+    for (int i2 = lane; i2 < 2 * N; i2 += 64)
+    {
+        const int strand = i2 >= N ? 1 : 0, i = i2 - strand * N;
+        unsigned long long key = ~0ull;
+        if (i < n_win)
+        {
+            uint32_t val = 0;
+            bool ok = true;
+            for (int c = 0; c < K; ++c)
+            {
+                const uint32_t bb = base2(rv.at(i + c, strand != 0));
+                ok = ok && bb <= 3;
+                val = (val << 2) | (bb & 3u);
+            }
+            if (ok)
+                key = ((unsigned long long)val << 32) | (uint32_t)i;
+        }
+        skey0[strand * a.n_sort + i] = key;
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= N; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1)
+        {
+            for (int i2 = lane; i2 < 2 * N; i2 += 64)
+            {
+                const int strand = i2 >= N ? 1 : 0, i = i2 - strand * N;
+                unsigned long long* skey = skey0 + strand * a.n_sort;
+                const int ixj = i ^ j;
+                if (ixj > i)
+                {
+                    const unsigned long long x = skey[i], y = skey[ixj];
+                    const bool asc = (i & k2) == 0;
+                    if ((x > y) == asc)
+                    {
+                        skey[i] = y;
+                        skey[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    // candidates are pushed path by path, forward strand first (KmerAligner.cpp:524-531): the heap's element order depends on it
     for (uint32_t pi = 0; pi < g.n_paths; ++pi)
     {
         const KPathDev p = a.paths[g.path_off + pi];
@@ -296,59 +325,52 @@ __global__ __launch_bounds__(64) void pg_kmer_kernel(KmerArgs a)
             continue;  // every candidate would overhang the path
         const uint32_t n_off = p.len - (uint32_t)L + 1;
         const uint32_t words = (n_off + 31) / 32;
+        if (words > a.bm_words)
+            continue;  // cannot happen (bm_words is sized by the longest path)
+        // the path's sorted (k-mer, position) table: LDS copy when it fits
+        const bool cached = p.n_kmers <= a.cache_n;
+        if (cached)
+            for (uint32_t e = lane; e < p.n_kmers; e += 64)
+            {
+                spk[e] = a.kmers[p.kmer_off + e];
+                spp[e] = a.kpos[p.kmer_off + e];
+            }
+        const uint32_t* pk = cached ? spk : a.kmers + p.kmer_off;
+        const uint32_t* pp = cached ? spp : a.kpos + p.kmer_off;
         for (int strand = 0; strand < 2; ++strand)
         {
             const bool reverse = strand != 0;
-            for (uint32_t w = 0; w < words; ++w)
+            const unsigned long long* skey = skey0 + strand * a.n_sort;
+            for (uint32_t w = lane; w < words; w += 64)
                 bm[w] = 0;
-            // merge-join (KmerAligner.cpp:246-276).  The read's k-mers must be visited in (k-mer, position) order
-            // with ONE forward cursor over the path table: process the read's k-mers in sorted order by repeatedly
-            // extracting the next smallest (k-mer, position) -- O(n^2) over <= L windows, no per-thread arrays.
-            uint32_t cursor = 0;
-            uint64_t last_key = 0;
-            bool have_last = false;
-            for (;;)
+            __syncthreads();
+            // ---- merge-join ---------------------------------------------------------------------------------------
+            for (int j = lane; j < N; j += 64)
             {
-                // next smallest (kmer, pos) strictly greater than last_key
-                uint64_t best_key = ~0ull;
-                uint32_t val = 0;
-                int run = 0;
-                for (int i = 0; i < L; ++i)
+                const unsigned long long key = skey[j];
+                if (key == ~0ull)
+                    continue;
+                const uint32_t km = (uint32_t)(key >> 32), sp = (uint32_t)key;
+                if (j > 0 && (uint32_t)(skey[j - 1] >> 32) == km)
+                    continue;  // a later read occurrence of the same k-mer: the reference's cursor is already past it
+                uint32_t lo = 0, hi = p.n_kmers;
+                while (lo < hi)
                 {
-                    const uint32_t b = base2(rv.at(i, reverse));
-                    if (b > 3)
-                    {
-                        run = 0;
-                        val = 0;
-                        continue;
-                    }
-                    val = (val << 2) | b;
-                    if (K < 16)
-                        val &= (1u << (2 * K)) - 1u;
-                    ++run;
-                    if (run >= K)
-                    {
-                        const uint64_t key = ((uint64_t)val << 32) | (uint32_t)(i - K + 1);
-                        if ((!have_last || key > last_key) && key < best_key)
-                            best_key = key;
-                    }
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (pk[mid] < km)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
                 }
-                if (best_key == ~0ull)
-                    break;
-                last_key = best_key;
-                have_last = true;
-                const uint32_t km = (uint32_t)(best_key >> 32), sp = (uint32_t)best_key;
-                while (cursor < p.n_kmers && a.kmers[p.kmer_off + cursor] < km)
-                    ++cursor;
-                while (cursor < p.n_kmers && a.kmers[p.kmer_off + cursor] == km)
+                for (; lo < p.n_kmers && pk[lo] == km; ++lo)
                 {
-                    const int offset = (int)a.kpos[p.kmer_off + cursor] - (int)sp;
+                    const int offset = (int)pp[lo] - (int)sp;
                     if (offset >= 0 && p.len >= (uint32_t)offset + (uint32_t)L)
-                        bm[offset >> 5] |= 1u << (offset & 31);
-                    ++cursor;
+                        atomicOr(&bm[offset >> 5], 1u << (offset & 31));
                 }
             }
-            // candidates in ascending offset (std::sort + std::unique), Hamming distance, bounded heap
+            __syncthreads();
+            // ---- candidates in ascending offset (std::sort + std::unique), Hamming distance, bounded heap --------------
             for (uint32_t w = 0; w < words; ++w)
             {
                 uint32_t bits = bm[w];
@@ -358,18 +380,29 @@ __global__ __launch_bounds__(64) void pg_kmer_kernel(KmerArgs a)
                     bits &= bits - 1;
                     const uint32_t offset = w * 32 + bit;
                     uint32_t mm = 0;
-                    for (int j = 0; j < L; ++j)
+                    for (int j = lane; j < L; j += 64)
                         mm += rv.at(j, reverse) != (uint8_t)a.pathseq[p.seq_off + offset + (uint32_t)j];
-                    heap_push(heap, hn, Cand{ pi, offset, (uint32_t)reverse, mm });
-                    if (hn == cap)
-                        heap_pop(heap, hn);
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1)
+                        mm += __shfl_xor(mm, m);
+                    if (lane == 0)
+                    {
+                        int hn = shn;
+                        heap_push(sheap, hn, Cand{ pi, offset, (uint32_t)reverse, mm });
+                        if (hn == cap)
+                            heap_pop(sheap, hn);
+                        shn = hn;
+                    }
                 }
             }
+            __syncthreads();
         }
     }
+    Cand* heap = sheap;
+    const int hn = shn;
     if (hn == 0)
         return;
-    // ---- pickBest (KmerAligner.cpp:478-516)
+    // ---- pickBest (KmerAligner.cpp:478-516): every lane evaluates the same (uniform) selection
     int bi = 0;
     for (int i = 1; i < hn; ++i)
         if (heap[i].mm < heap[bi].mm)
@@ -377,6 +410,10 @@ __global__ __launch_bounds__(64) void pg_kmer_kernel(KmerArgs a)
     const Cand best = heap[bi];
     if (best.mm > 2)
         return;
+    const KPathDev pbest = a.paths[g.path_off + best.path];
+    CandLabels lb;
+    const bool has_ops = label_candidate(a, pbest, rv, best.reverse != 0, best.pos, lane, slab[0], lb);
+    __syncthreads();
     bool bad = false;
     {
         int i = bi + 1;
@@ -389,22 +426,19 @@ __global__ __launch_bounds__(64) void pg_kmer_kernel(KmerArgs a)
             const Cand sb = heap[si];
             if (sb.mm != best.mm)
                 break;
-            OpGen g1{ a, a.paths[g.path_off + best.path], rv, best.reverse != 0 };
-            OpGen g2{ a, a.paths[g.path_off + sb.path], rv, sb.reverse != 0 };
-            g1.init(best.pos);
-            g2.init(sb.pos);
-            bool differ = g1.graph_pos != g2.graph_pos;
-            while (!differ)
+            // "different CIGAR or position" (:497-505): the CIGAR strings are equal iff the per-position labels are
+            CandLabels l2;
+            const bool has2 = label_candidate(a, a.paths[g.path_off + sb.path], rv, sb.reverse != 0, sb.pos, lane, slab[1], l2);
+            __syncthreads();
+            bool differ = l2.graph_pos != lb.graph_pos || has2 != has_ops;
+            if (!differ && has_ops)
             {
-                uint32_t n1, o1, l1, n2, o2, l2;
-                const bool h1 = g1.next(n1, o1, l1), h2 = g2.next(n2, o2, l2);
-                if (h1 != h2)
-                    differ = true;
-                else if (!h1)
-                    break;
-                else if (n1 != n2 || o1 != o2 || l1 != l2)
-                    differ = true;
+                bool d = false;
+                for (int j = lane; j < L; j += 64)
+                    d = d || slab[0][j] != slab[1][j];
+                differ = __any(d);
             }
+            __syncthreads();
             if (differ)
             {
                 bad = true;
@@ -413,40 +447,45 @@ __global__ __launch_bounds__(64) void pg_kmer_kernel(KmerArgs a)
             i = si + 1;
         }
     }
-    // ---- emit the best alignment
-    OpGen gen{ a, a.paths[g.path_off + best.path], rv, best.reverse != 0 };
-    gen.init(best.pos);
-    uint32_t n_ops = 0, score = 0, clipped = 0;
+    if (lane != 0)
+        return;
+    // ---- emit the best alignment: run-length encode the labels (two passes over LDS: count, write)
+    uint32_t n_ops = 0;
+    if (has_ops)
     {
-        uint32_t nd, op, len;
-        while (gen.next(nd, op, len))
-            ++n_ops;
+        n_ops = 1;
+        for (int j = 1; j < L; ++j)
+            n_ops += slab[0][j] != slab[0][j - 1];
     }
     const unsigned long long base = atomicAdd(a.ops_counter, (unsigned long long)n_ops);
-    gen.init(best.pos);
+    if (has_ops)
     {
-        uint32_t nd, op, len, e = 0;
-        while (gen.next(nd, op, len))
+        uint32_t e = 0, run = 1, cur = slab[0][0];
+        for (int j = 1; j <= L; ++j)
         {
-            a.ops[base + e++] = (nd << 20) | (op << 16) | (len & 0xFFFFu);
-            if (op == PG_OPC_M)
-                score += len;
-            if (op == PG_OPC_S)
-                clipped += len;
+            const uint32_t nxt = j < L ? slab[0][j] : 0xFFFFFFFFu;
+            if (nxt == cur)
+            {
+                ++run;
+                continue;
+            }
+            a.ops[base + e++] = ((cur >> 4) << 20) | ((cur & 7u) << 16) | (run & 0xFFFFu);
+            cur = nxt;
+            run = 1;
         }
     }
     pg_result res;
-    res.graph_pos = gen.graph_pos;
-    res.score = (int16_t)score;
+    res.graph_pos = lb.graph_pos;
+    res.score = (int16_t)lb.matches;
     res.mapq = bad ? 0 : 60;
     res.is_unique = bad ? 0 : 1;
     res.returned_reverse = (uint8_t)best.reverse;
     res.multi_mask = 0;
     res.n_ops = (uint16_t)n_ops;
     res.ops_off = (uint32_t)base;
-    res.strand_score[0] = best.reverse ? -1 : (int16_t)score;
-    res.strand_score[1] = best.reverse ? (int16_t)score : -1;
-    res.clipped = (uint16_t)clipped;
+    res.strand_score[0] = best.reverse ? -1 : (int16_t)lb.matches;
+    res.strand_score[1] = best.reverse ? (int16_t)lb.matches : -1;
+    res.clipped = (uint16_t)(has_ops ? lb.left + lb.right : 0);
     res.status = PG_STATUS_KMER_ALIGNER;
     a.results[r] = res;
     a.flags[r] = bad ? 4 : 1;  // bit0 MAPPED, bit2 BAD_ALIGN (ambiguous best)
@@ -457,14 +496,13 @@ struct pg_kmer_index
 {
     uint32_t k = 0;
     uint32_t max_path_len = 0;
+    uint32_t max_path_kmers = 0;
     KGraphDev* d_graphs = nullptr;
     KPathDev* d_paths = nullptr;
     char* d_pathseq = nullptr;
     uint32_t* d_starts = nullptr;
     uint32_t* d_kmers = nullptr;
     uint32_t* d_kpos = nullptr;
-    uint32_t* d_bitmap = nullptr;
-    size_t bitmap_cap = 0;
 };
 
 void pg_kmer_index_free(pg_kmer_index* ix)
@@ -477,7 +515,6 @@ void pg_kmer_index_free(pg_kmer_index* ix)
     (void)hipFree(ix->d_starts);
     (void)hipFree(ix->d_kmers);
     (void)hipFree(ix->d_kpos);
-    (void)hipFree(ix->d_bitmap);
     delete ix;
 }
 
@@ -500,7 +537,7 @@ extern "C" pg_status pg_graphs_build_kmer_index(
     std::vector<KPathDev> pd;
     std::vector<char> pathseq;
     std::vector<uint32_t> starts, kmers, kpos;
-    uint32_t max_len = 0;
+    uint32_t max_len = 0, max_kmers = 0;
     for (uint32_t g = 0; g < G->n_graphs; ++g)
     {
         const uint32_t nb = G->h_node_off[g], n_nodes = G->h_node_off[g + 1] - nb;
@@ -551,6 +588,7 @@ extern "C" pg_status pg_graphs_build_kmer_index(
             std::sort(ks.begin(), ks.end());
             kp.kmer_off = (uint32_t)kmers.size();
             kp.n_kmers = (uint32_t)ks.size();
+            max_kmers = std::max(max_kmers, kp.n_kmers);
             for (auto const& e : ks)
             {
                 kmers.push_back(e.first);
@@ -562,6 +600,7 @@ extern "C" pg_status pg_graphs_build_kmer_index(
     pg_kmer_index* ix = new pg_kmer_index();
     ix->k = kmer_len;
     ix->max_path_len = max_len;
+    ix->max_path_kmers = max_kmers;
     hipError_t e = upk(gd, &ix->d_graphs, ctx->stream);
     if (e == hipSuccess) e = upk(pd, &ix->d_paths, ctx->stream);
     if (e == hipSuccess) e = upk(pathseq, &ix->d_pathseq, ctx->stream);
@@ -589,16 +628,6 @@ extern "C" pg_status pg_batch_kmer_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     pg_kmer_index* ix = G->kmer_index;
     const uint32_t words = (ix->max_path_len + 31) / 32 + 1;
-    const size_t need = (size_t)std::max<uint32_t>(b->n_reads, 1) * words;
-    if (need > ix->bitmap_cap)
-    {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ix->d_bitmap);
-        ix->d_bitmap = nullptr;
-        ix->bitmap_cap = 0;
-        HIP_TRY(ctx, hipMalloc((void**)&ix->d_bitmap, need * sizeof(uint32_t)));
-        ix->bitmap_cap = need;
-    }
     HIP_TRY(ctx, pg_stage_begin(ctx, b));
     if (!(flags & PG_AF_KEEP_RESULTS) || flags == PG_AF_ALL)
         HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
@@ -615,16 +644,29 @@ extern "C" pg_status pg_batch_kmer_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     a.starts = ix->d_starts;
     a.kmers = ix->d_kmers;
     a.kpos = ix->d_kpos;
-    a.bitmap = ix->d_bitmap;
-    a.bitmap_words = words;
     a.results = b->d_results;
     a.ops = b->d_ops;
     a.ops_counter = b->d_ops_counter;
     a.flags = b->d_path_flags;
     a.active = b->has_active ? b->d_active : nullptr;
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < b->n_reads; ++i)
+        max_len = std::max(max_len, b->h_base_off[i + 1] - b->h_base_off[i]);
+    if (max_len > (uint32_t)KMER_SORT_MAX)
+        return pg_fail(ctx, PG_ERR_UNSUPPORTED, "pg_batch_kmer_align: reads longer than 512 bases are not supported");
+    a.l_max = (max_len + 3u) & ~3u;
+    a.n_sort = 64;
+    while (a.n_sort < max_len)
+        a.n_sort <<= 1;
+    a.bm_words = words;
+    a.cache_n = std::min<uint32_t>(ix->max_path_kmers, 2048u);
+    const size_t lds = (size_t)2 * a.n_sort * 8 + (size_t)2 * a.l_max * 4 + (size_t)a.bm_words * 4 + (size_t)2 * a.cache_n * 4
+        + HEAP_CAP * sizeof(Cand) + 16 + (size_t)2 * a.l_max;
     if (b->n_reads)
     {
-        hipLaunchKernelGGL(pg_kmer_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
+        if (lds > 48 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)pg_kmer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(pg_kmer_kernel, dim3(b->n_reads), dim3(64), lds, ctx->stream, a);
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, pg_stage_end(ctx, b));

@@ -120,6 +120,10 @@ struct ReadView
     __device__ uint32_t at(int j, bool reverse) const { return reverse ? comp_raw((uint8_t)bases[L - 1 - j]) : (uint8_t)bases[j]; }
 };
 
+// value of lane - 1 (lane 0 gets `lane0`): one DPP move (wave_shr:1 works across the four 16-lane rows on gfx950;
+// tools/ubench/dpp_wave_shr.hip), not a ds_bpermute round trip -- it sits on the step-to-step critical path
+__device__ __forceinline__ int lane_up(int v, int lane0) { return __builtin_amdgcn_update_dpp(lane0, v, 0x138, 0xf, 0xf, false); }
+
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 {
 #pragma unroll
@@ -156,13 +160,8 @@ __device__ __forceinline__ void klib_local(
     int tc_next = (lane_on && lane == 0 && ncols > 0) ? (int)tcode[t0] : 4;
     for (int t = 0; t < steps; ++t)
     {
-        int up_h = __shfl_up(my_hlast, 1);
-        int up_f = __shfl_up(my_f, 1);
-        if (lane == 0)
-        {
-            up_h = 0;
-            up_f = 0;
-        }
+        const int up_h = lane_up(my_hlast, 0);
+        const int up_f = lane_up(my_f, 0);
         const int i = t - lane;
         const int tc = tc_next;
         {  // prefetch the next step's target code
@@ -245,14 +244,10 @@ __device__ __forceinline__ void klib_global(
     int tc_next = (lane_on && lane == 0 && ncols > 0) ? (int)tcode[t0] : 4;
     for (int t = 0; t < steps; ++t)
     {
-        int up_h = __shfl_up(my_hlast, 1);
-        int up_f = __shfl_up(my_f, 1);
         const int i = t - lane;
-        if (lane == 0)
-        {
-            up_h = -(K_GAPO + K_GAPE * (i + 1));  // H[i][-1] (ksw.c:486, beg == 0)
-            up_f = K_MINUS_INF;
-        }
+        // lane 0: H[i][-1] = -(gapo + gape * (i + 1)) (ksw.c:486, beg == 0; here i == t), F = -inf
+        const int up_h = lane_up(my_hlast, -(K_GAPO + K_GAPE * (t + 1)));
+        const int up_f = lane_up(my_f, K_MINUS_INF);
         const int tc = tc_next;
         {
             const int in = i + 1;
@@ -923,7 +918,7 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
         return PG_OK;
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(n_items, (uint64_t)n_cu * 16u);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(n_items, (uint64_t)n_cu * 32u);
     // direction bytes: the window has at most 2 * L target columns (a local alignment with positive score cannot
     // delete more bases than it matches) and never more than the path; + 64 steps of skew
     const uint64_t z_steps = std::min<uint64_t>(2ull * max_len, ix->max_path_len) + 64 + 1;

@@ -60,6 +60,67 @@ def main():
         sets.append({"nodes": s.seqs, "edges": s.edges, "reads": reads,
                      "expected": R.align_batch(s.seqs, s.edges, reads)})
     dump("templates_ins_longdel.json", sets, "ins_site / longdel_site on random_contig(11,4000), 96 reads each")
+    # 5. reads of 251..512 bp: gssw's 16-bit word mode (incl. GraphAligner's byte-pointer multi-node scan)
+    rng = random.Random(251)
+    sets = []
+    for _ in range(10):
+        seqs, edges, reads = fuzzgen.long_read_case(rng, 6)
+        sets.append({"nodes": seqs, "edges": edges, "reads": reads,
+                     "expected": R.align_batch(seqs, edges, reads, cigar_stride=2048)})
+    dump("fuzz_word.json", sets, "fuzzgen.long_read_case(Random(251), 6) x10: reads 251-512 bp")
+    stage_fixtures()
+
+
+def dump_stage(name, source, note, sets):
+    os.makedirs(os.path.join(HERE, "stages"), exist_ok=True)
+    path = os.path.join(HERE, "stages", name)
+    with open(path, "w") as f:
+        json.dump({"generator": "tests/golden/make_golden.py", "source": source, "note": note, "sets": sets}, f, separators=(",", ":"))
+    print(path, os.path.getsize(path), "bytes")
+
+
+def stage_fixtures():
+    """Fixtures of the optional cascade stages and the KmerFilter, from the reference-backed checkers (oracle/_ref)."""
+    from oracle import klibalign, kmerfilter, pathalign
+    from tests.test_klib_oracle import random_case
+    from tests.test_kmerfilter_oracle import rand_case as filter_case
+    # klib stage: the reference's ksw.c under the restated KlibAligner wrapper
+    rng = random.Random(606)
+    K = klibalign.ref_klib()
+    sets = []
+    for _ in range(25):
+        nodes, paths, reads = random_case(rng, 8)
+        sets.append({"nodes": nodes, "paths": paths, "reads": reads, "expected": K.align(nodes, paths, reads)})
+    dump_stage("klib.json", "reference ksw.c via oracle/ref_harness.c + klib_glue.h", "test_klib_oracle.random_case(Random(606), 8) x25", sets)
+    # path stage: graph-tools extendPathMatching etc. via oracle/ref_counts.cpp
+    rng = random.Random(707)
+    sets = []
+    for _ in range(25):
+        seqs, edges = fuzzgen.rand_graph(rng, max_len=80, max_nodes=6)
+        seqs = [s.replace("X", "A") for s in seqs]
+        reads = []
+        for _ in range(8):
+            p = fuzzgen.rand_path_seq(rng, seqs, edges)
+            L = rng.randint(20, 90)
+            st = rng.randrange(max(1, len(p) - 10))
+            r = p[st:st + L] or "A"
+            if rng.random() < 0.3:
+                r = fuzzgen.mutate(rng, r, sub=0.02, indel=0.0) or "A"
+            if rng.random() < 0.4:
+                r = pathalign._rc(r)
+            reads.append(r)
+        k = rng.choice([12, 16, 32])
+        sets.append({"nodes": seqs, "edges": edges, "k": k, "reads": reads, "expected": pathalign.ref_path_align(seqs, edges, reads, k)})
+    dump_stage("path.json", "reference graph-tools via oracle/ref_counts.cpp", "rand_graph(Random(707)) x25, 8 reads each, k in {12,16,32}", sets)
+    # KmerFilter
+    rng = random.Random(808)
+    sets = []
+    for _ in range(40):
+        seqs, edges, reads = filter_case(rng)
+        k = rng.choice([3, 4, 5, 8, 12])
+        kk, out = kmerfilter.ref_kmer_filter(seqs, edges, k, reads)
+        sets.append({"nodes": seqs, "edges": edges, "k": k, "reads": [list(r) for r in reads], "expected": [[bool(f), m] for f, m in out]})
+    dump_stage("kmerfilter.json", "reference graph-tools via oracle/ref_counts.cpp", "test_kmerfilter_oracle.rand_case(Random(808)) x40", sets)
 
 
 if __name__ == "__main__":

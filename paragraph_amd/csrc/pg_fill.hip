@@ -193,14 +193,17 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     const uint32_t GE2 = PG_GAP_EXT | (PG_GAP_EXT << 16);
     const uint32_t nsteps = gd.ncols + PG_GROUP_LANES - 1;
     const uint32_t* profl = prof + grp * 5 * ROWS + k * C;
+    const uint32_t trace_lane_off = (uint32_t)lane * TRACE_DW * 4u;
 
-    // Column meta words: one coalesced vector load per 64 steps (lane l holds the word of step t0 + l),
-    // handed out with v_readlane -- no memory latency inside the step loop.  The array is padded with
+    // Column meta words: the word of step t is the same for the whole wavefront, so it is read with SCALAR loads through
+    // the constant address space (the graph tables are never written by a kernel), two steps ahead.  Scalar loads count
+    // on lgkmcnt: the step loop never has to wait on vmcnt, i.e. on its own trace stores.  The array is padded with
     // PG_META_PAD idle words on the host.
-    uint32_t mblock = smeta[lane];
-    uint32_t mblock_next = smeta[64 + lane];
+    typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
+    const const_u32_ptr cmeta = (const_u32_ptr)(uintptr_t)smeta;
+    uint32_t mw1 = cmeta[1], mw2 = cmeta[2];
     // software pipeline: `meta` / `s[]` always belong to the step about to be computed
-    uint32_t meta = row_shr1_keep((uint32_t)__builtin_amdgcn_readlane((int)mblock, 0), PG_META_IDLE);
+    uint32_t meta = row_shr1_keep(cmeta[0], PG_META_IDLE);
     uint32_t s[C];
     {
         const uint32_t* pr = profl + PG_META_CODE(meta) * ROWS;
@@ -220,13 +223,9 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         uint32_t F = row_shr1_zero(Fsend);
 
         // ---- prefetch the next step's meta word and profile rows -----------------------------------
-        const uint32_t tn = t + 1;
-        if ((tn & 63u) == 0)
-        {
-            mblock = mblock_next;
-            mblock_next = smeta[tn + 64 + lane];
-        }
-        meta = row_shr1_keep((uint32_t)__builtin_amdgcn_readlane((int)mblock, (int)(tn & 63u)), meta_cur);
+        meta = row_shr1_keep(mw1, meta_cur);
+        mw1 = mw2;
+        mw2 = cmeta[t + 3];
         uint32_t sn[C];
         {
             const uint32_t* pr = profl + PG_META_CODE(meta) * ROWS;
@@ -350,6 +349,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             {
                 uint32_t inc = pk_minu(pk_sub(Mn, M), 0x00010001u);  // 1 where the half grew
                 inc = pk_sub(0u, inc);                               // 0xFFFF where it grew
+                asm volatile("" : "+v"(inc));                        // keep it a mask: one v_bfi_b32, not compare + select per half
                 FC = (FC & ~inc) | (colv & inc);
             }
             M = Mn;
@@ -357,7 +357,9 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 
         if (DIR == 0)
         {
-            uint32_t* tp = trace + ((size_t)t * 64 + lane) * TRACE_DW;
+            // uniform step base + 32-bit lane offset: the store takes the scalar-base addressing form, no per-step VALU
+            // address arithmetic
+            uint32_t* tp = (uint32_t*)((char*)(trace + (size_t)t * 64 * TRACE_DW) + trace_lane_off);
             if (WIDE)
             {
 #pragma unroll
@@ -368,7 +370,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             {
 #pragma unroll
                 for (int r = 0; r < C; r += 2)
-                    tp[r / 2] = Hp[r] | (Hp[r + 1] << 8);  // bytes A_r, A_r+1, B_r, B_r+1
+                    tp[r / 2] = __builtin_amdgcn_perm(Hp[r + 1], Hp[r], 0x06020400u);  // bytes A_r, A_r+1, B_r, B_r+1 (one v_perm)
             }
         }
 

@@ -100,4 +100,11 @@ static inline __host__ __device__ uint32_t pg_rows(int V) { return (uint32_t)(PG
 static inline __host__ __device__ uint32_t pg_trace_lane_bytes(int V) { return (uint32_t)((pg_var_wide(V) ? 4 : 2) * pg_var_c(V)); }
 // bytes of seed (H, next-column E of both strands) one lane keeps per node
 static inline __host__ __device__ uint32_t pg_seed_lane_bytes(int V) { return (uint32_t)((pg_var_wide(V) ? 8 : 4) * pg_var_c(V)); }
+// seed region of one work item: [node][lane][seed dwords], 256-byte aligned; behind it the per-node maxima keys
+// [node][4 reads][2 strands] as 64-bit slots
+static inline __host__ __device__ uint64_t pg_seed_region_bytes(int V, uint32_t n_nodes)
+{
+    return ((uint64_t)n_nodes * 64u * pg_seed_lane_bytes(V) + 255u) & ~(uint64_t)255u;
+}
+static inline __host__ __device__ uint64_t pg_key_region_bytes(uint32_t n_nodes) { return ((uint64_t)n_nodes * 64u + 255u) & ~(uint64_t)255u; }
 static inline __host__ __device__ uint32_t pg_ops_cap(int V) { return pg_rows(V) + 32u; }

@@ -120,9 +120,12 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     constexpr int TRACE_DW = WIDE ? C : C / 2;  // dwords of H trace per lane per step
     constexpr int SEED_DW = WIDE ? 2 * C : C;   // dwords of seed per lane per node
     constexpr int ROWS = PG_GROUP_LANES * C;
-    uint32_t* prof = lds;                            // [4 reads][5 codes][ROWS] packed (strand A | strand B << 16)
-    uint32_t* nodekey = lds + PG_GROUPS * 5 * ROWS;  // [n_nodes][4 reads][2 strands]; u64 entries when WIDE
-    unsigned long long* nodekey64 = (unsigned long long*)nodekey;
+    // LDS holds the profiles of the four real reference codes only: [4 reads][4 codes][ROWS] packed (strand A | strand B << 16)
+    // = 10 240 B at C = 10, i.e. 16 wavefronts per CU (the kernel is latency-sensitive: 12 -> 16 waves is worth ~8 %).  Code 4
+    // (N / idle column) scores 0 on real rows and PAD on padding rows: synthesised in registers on the rare columns that
+    // carry it.  The per-node maxima keys live in the workspace behind this item's seed region (global atomics, 3 per lane
+    // per sweep) for the same reason.
+    uint32_t* prof = lds;
 
     const int lane = threadIdx.x;
     const int grp = lane >> 4;
@@ -136,6 +139,8 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     const uint32_t* __restrict__ smeta = a.colmeta + gd.meta_off;
     const PgNode* __restrict__ nodes = a.nodes + gd.node_off;
     const uint32_t n_nodes = gd.n_nodes;
+    uint32_t* nodekey = (uint32_t*)(a.workspace + itp->seed_off + pg_seed_region_bytes(WIDE ? PG_VAR_WIDE + C : C, n_nodes));
+    unsigned long long* nodekey64 = (unsigned long long*)nodekey;  // [n_nodes][4 reads][2 strands] 64-bit slots
 
     // ---- query profiles of the 8 fills into LDS (gssw_qP_byte) ------------------------------------
     for (int e = lane; e < PG_GROUPS * ROWS; e += 64)
@@ -162,16 +167,27 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             }
         }
 #pragma unroll
-        for (uint32_t code = 0; code < 5; ++code)
+        for (uint32_t code = 0; code < 4; ++code)
         {
             const int sA = cA == 5u ? PAD : sub_score(code, cA);
             const int sB = cB == 5u ? PAD : sub_score(code, cB);
-            prof[(g * 5 + code) * ROWS + row] = ((uint32_t)sA & 0xFFFFu) | ((uint32_t)sB << 16);
+            prof[(g * 4 + code) * ROWS + row] = ((uint32_t)sA & 0xFFFFu) | ((uint32_t)sB << 16);
         }
     }
-    for (uint32_t e = lane; e < n_nodes * 8 * (WIDE ? 2u : 1u); e += 64)
-        nodekey[e] = 0;
+    // (device-scope stores / loads on the keys, but only a workgroup-scope fence: an agent-scope fence would write the
+    // whole L2 back, trace stores included)
+    for (uint32_t e = lane; e < n_nodes * 16; e += 64)
+        __hip_atomic_store(&nodekey[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_block();
     __syncthreads();
+    // rows of this lane that exist in its read (the others are padding rows)
+    uint32_t real_rows = 0;
+    {
+        const uint32_t ridx = itp->read[grp];
+        const uint32_t Lg = ridx == PG_NONE ? 0u : a.base_off[ridx + 1] - a.base_off[ridx];
+        real_rows = Lg > (uint32_t)(k * C) ? Lg - (uint32_t)(k * C) : 0u;
+    }
+    const uint32_t PADPK = ((uint32_t)PAD & 0xFFFFu) | ((uint32_t)PAD << 16);
 
     uint32_t* __restrict__ seed = (uint32_t*)(a.workspace + itp->seed_off);    // [node][lane][SEED_DW]
     uint32_t* __restrict__ trace = (uint32_t*)(a.workspace + itp->trace_off);  // [step][lane][TRACE_DW]
@@ -192,7 +208,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     const uint32_t GO2 = PG_GAP_OPEN | (PG_GAP_OPEN << 16);
     const uint32_t GE2 = PG_GAP_EXT | (PG_GAP_EXT << 16);
     const uint32_t nsteps = gd.ncols + PG_GROUP_LANES - 1;
-    const uint32_t* profl = prof + grp * 5 * ROWS + k * C;
+    const uint32_t* profl = prof + grp * 4 * ROWS + k * C;
     const uint32_t trace_lane_off = (uint32_t)lane * TRACE_DW * 4u;
 
     // Column meta words: the word of step t is the same for the whole wavefront, so it is read with SCALAR loads through
@@ -206,13 +222,20 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     uint32_t meta = row_shr1_keep(cmeta[0], PG_META_IDLE);
     uint32_t s[C];
     {
-        const uint32_t* pr = profl + PG_META_CODE(meta) * ROWS;
+        const uint32_t code = PG_META_CODE(meta);
+        const uint32_t* pr = profl + (code < 3u ? code : 3u) * ROWS;
 #pragma unroll
         for (int r = 0; r < C; r += 2)
         {
             const uint2 v = *(const uint2*)(pr + r);
             s[r] = v.x;
             s[r + 1] = v.y;
+        }
+        if (code >= 4u)
+        {
+#pragma unroll
+            for (int r = 0; r < C; ++r)
+                s[r] = (uint32_t)r < real_rows ? 0u : PADPK;
         }
     }
 
@@ -228,13 +251,20 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         mw2 = cmeta[t + 3];
         uint32_t sn[C];
         {
-            const uint32_t* pr = profl + PG_META_CODE(meta) * ROWS;
+            const uint32_t code = PG_META_CODE(meta);
+            const uint32_t* pr = profl + (code < 3u ? code : 3u) * ROWS;
 #pragma unroll
             for (int r = 0; r < C; r += 2)
             {
                 const uint2 v = *(const uint2*)(pr + r);
                 sn[r] = v.x;
                 sn[r + 1] = v.y;
+            }
+            if (code >= 4u)
+            {  // rare: N in the graph, or the idle columns behind its end
+#pragma unroll
+                for (int r = 0; r < C; ++r)
+                    sn[r] = (uint32_t)r < real_rows ? 0u : PADPK;
             }
         }
 
@@ -410,9 +440,9 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             else
             {
                 if (mA)
-                    atomicMax(&nodekey[node * 8 + grp * 2 + 0], (mA << 20) | ((0xFFFFu - cA) << 4) | kinv);
+                    atomicMax(&nodekey[(node * 8 + grp * 2 + 0) * 2], (mA << 20) | ((0xFFFFu - cA) << 4) | kinv);
                 if (mB)
-                    atomicMax(&nodekey[node * 8 + grp * 2 + 1], (mB << 20) | ((0xFFFFu - cB) << 4) | kinv);
+                    atomicMax(&nodekey[(node * 8 + grp * 2 + 1) * 2], (mB << 20) | ((0xFFFFu - cB) << 4) | kinv);
             }
         }
         colv = pk_add(colv, 0x00010001u);
@@ -433,7 +463,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         uint32_t best = 0, bestnode = 0, cnt = 0;
         for (uint32_t n = 0; n < n_nodes; ++n)
         {
-            const unsigned long long key = nodekey64[n * 8 + grp * 2 + strand];
+            const unsigned long long key = __hip_atomic_load(&nodekey64[n * 8 + grp * 2 + strand], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t m = (uint32_t)(key >> 32);
             if (m > best)
             {
@@ -458,7 +488,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 const uint32_t L = ridx == PG_NONE ? 0u : a.base_off[ridx + 1] - a.base_off[ridx];
                 for (uint32_t n = 0; n < n_nodes; ++n)
                 {
-                    const unsigned long long key = nodekey64[n * 8 + grp * 2 + strand];
+                    const unsigned long long key = __hip_atomic_load(&nodekey64[n * 8 + grp * 2 + strand], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((uint32_t)(key >> 32) != best)
                         continue;
                     const uint32_t col = 0xFFFFu - (uint32_t)((key >> 16) & 0xFFFFu);
@@ -492,7 +522,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         uint32_t best = 0, bestkey = 0, bestnode = 0, cnt = 0;
         for (uint32_t n = 0; n < n_nodes; ++n)
         {
-            const uint32_t key = nodekey[n * 8 + grp * 2 + strand];
+            const uint32_t key = __hip_atomic_load(&nodekey[(n * 8 + grp * 2 + strand) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t m = key >> 20;
             if (m > best)
             {
@@ -564,7 +594,8 @@ __global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
 
 size_t pg_fill_lds_bytes(int V, uint32_t max_nodes)
 {
-    return (size_t)(PG_GROUPS * 5 * PG_GROUP_LANES * pg_var_c(V) + max_nodes * 8 * (pg_var_wide(V) ? 2 : 1)) * sizeof(uint32_t);
+    (void)max_nodes;
+    return (size_t)(PG_GROUPS * 4 * PG_GROUP_LANES * pg_var_c(V)) * sizeof(uint32_t);
 }
 
 template <int C, bool WIDE = false>

@@ -143,16 +143,21 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     unsigned long long* nodekey64 = (unsigned long long*)nodekey;  // [n_nodes][4 reads][2 strands] 64-bit slots
 
     // ---- query profiles of the 8 fills into LDS (gssw_qP_byte) ------------------------------------
-    for (int e = lane; e < PG_GROUPS * ROWS; e += 64)
+    // (read index, offset and length are uniform per read: loaded once, not per profile entry)
+#pragma unroll
+    for (int g = 0; g < PG_GROUPS; ++g)
     {
-        const int g = e / ROWS;
-        const int row = e - g * ROWS;
         const uint32_t ridx = itp->read[g];
-        uint32_t cA = 5u, cB = 5u;  // 5 = padding row
+        uint32_t off = 0, L = 0;
         if (ridx != PG_NONE)
         {
-            const uint32_t off = a.base_off[ridx];
-            const uint32_t L = a.base_off[ridx + 1] - off;
+            off = a.base_off[ridx];
+            L = a.base_off[ridx + 1] - off;
+        }
+        for (int row = lane; row < ROWS; row += 64)
+        {
+        uint32_t cA = 5u, cB = 5u;  // 5 = padding row
+        {
             if ((uint32_t)row < L)
             {
                 const uint32_t f = (uint8_t)a.bases[off + row];
@@ -172,6 +177,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             const int sA = cA == 5u ? PAD : sub_score(code, cA);
             const int sB = cB == 5u ? PAD : sub_score(code, cB);
             prof[(g * 4 + code) * ROWS + row] = ((uint32_t)sA & 0xFFFFu) | ((uint32_t)sB << 16);
+        }
         }
     }
     // (device-scope stores / loads on the keys, but only a workgroup-scope fence: an agent-scope fence would write the

@@ -229,7 +229,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     uint32_t s[C];
     {
         const uint32_t code = PG_META_CODE(meta);
-        const uint32_t* pr = profl + (code < 3u ? code : 3u) * ROWS;
+        const uint32_t* pr = profl + (code & 3u) * ROWS;
 #pragma unroll
         for (int r = 0; r < C; r += 2)
         {
@@ -258,7 +258,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         uint32_t sn[C];
         {
             const uint32_t code = PG_META_CODE(meta);
-            const uint32_t* pr = profl + (code < 3u ? code : 3u) * ROWS;
+            const uint32_t* pr = profl + (code & 3u) * ROWS;
 #pragma unroll
             for (int r = 0; r < C; r += 2)
             {

@@ -363,12 +363,32 @@ extern "C" pg_status pg_graphs_upload(
                 // forward direction keeps every seed (the traceback reads them); the reversed
                 // direction only needs seeds that a non-adjacent successor will load
                 const bool save = dir == 0 ? has_succ : has_far_succ;
+                // predecessor summary of the node, carried by its first column's meta word (no table loads on the device
+                // in the common cases): adjacent predecessor?, and none / exactly one far predecessor with id < 512 / general
+                uint32_t pred_bits = 0;
+                {
+                    uint32_t n_far = 0, far = 0;
+                    for (uint32_t k = nd.pred_off; k < nd.pred_off + nd.n_pred; ++k)
+                    {
+                        if (preds[k] + 1 == id)
+                            pred_bits |= PG_META_PRED_ADJ;
+                        else
+                        {
+                            ++n_far;
+                            far = preds[k];
+                        }
+                    }
+                    if (n_far == 1 && far < 512)
+                        pred_bits |= PG_META_PRED_ONE | (far << PG_META_PRED_SHIFT);
+                    else if (n_far != 0)
+                        pred_bits |= PG_META_PRED_MANY;
+                }
                 for (uint32_t c = 0; c < len; ++c)
                 {
                     const char ch = up(dir ? seq[s0 + len - 1 - c] : seq[s0 + c]);
                     uint32_t m = nt_code_host(ch) | (id << 8);
                     if (c == 0)
-                        m |= PG_META_FIRST;
+                        m |= PG_META_FIRST | pred_bits;
                     if (c == len - 1)
                         m |= PG_META_LAST | (save ? PG_META_SAVE : 0u);
                     colmeta.push_back(m);

@@ -21,7 +21,12 @@
 #define PG_META_FIRST 8u
 #define PG_META_LAST 16u
 #define PG_META_SAVE 32u
-#define PG_META_NODE(m) ((m) >> 8)
+#define PG_META_NODE(m) (((m) >> 8) & 0xFFFu)
+// first column of a node only: summary of its predecessors (bits 20..31)
+#define PG_META_PRED_ADJ (1u << 20)   // the node directly before it in the layout is a predecessor (its state is still in registers)
+#define PG_META_PRED_ONE (1u << 21)   // exactly one other predecessor, id (< 512) in bits 23..31
+#define PG_META_PRED_MANY (2u << 21)  // anything else: read the predecessor table
+#define PG_META_PRED_SHIFT 23
 #define PG_META_IDLE 4u  // code 4 (scores 0 against everything), no flags
 #define PG_META_PAD 160   // idle words appended to every direction's column array (64-wide block prefetch)
 

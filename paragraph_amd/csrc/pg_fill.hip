@@ -206,6 +206,10 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         E[r] = 0;
     }
     uint32_t Hsend = 0, Fsend = 0;
+    // one-entry seed cache (byte variants): the seed this lane stored last stays in registers, so the usual bubble
+    // (LF -> {ALT, RF}: RF's far predecessor is LF) needs no memory round trip -- a load there stalls the whole wavefront
+    uint32_t cseed[WIDE ? 1 : C];
+    uint32_t cnode = 0xFFFFFFFFu;
     uint32_t M = 0, FC = 0;
     uint32_t FR = 0;  // WIDE: smallest row (within the lane) holding the lane's maximum in column FC, per strand
     // packed (col | col << 16) of the column this lane works on; col = t - k (wraps for idle lanes)
@@ -279,7 +283,6 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             // seed = lane-wise max over predecessors (gssw_create_seed_byte); the predecessor that
             // directly precedes this node in the layout is still in Hp/E.
             const uint32_t node = PG_META_NODE(meta_cur);
-            const PgNode nd = nodes[node];
             uint32_t sh[C], se[C];
 #pragma unroll
             for (int r = 0; r < C; ++r)
@@ -287,7 +290,39 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 sh[r] = 0;
                 se[r] = 0;
             }
-            bool adj = false;
+            bool adj = (meta_cur & PG_META_PRED_ADJ) != 0;
+            if (!WIDE && !(meta_cur & PG_META_PRED_MANY))
+            {
+                // predecessor summary in the meta word: no table loads
+                if (meta_cur & PG_META_PRED_ONE)
+                {
+                    const uint32_t pid = meta_cur >> PG_META_PRED_SHIFT;
+                    uint32_t w[C];
+                    if (pid == cnode)
+                    {
+#pragma unroll
+                        for (int r = 0; r < C; ++r)
+                            w[r] = cseed[WIDE ? 0 : r];
+                    }
+                    else
+                    {
+                        const uint32_t* sp = seed + ((size_t)pid * 64 + lane) * SEED_DW;
+#pragma unroll
+                        for (int r = 0; r < C; ++r)
+                            w[r] = sp[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < C; ++r)
+                    {
+                        sh[r] = __builtin_amdgcn_perm(0u, w[r], 0x0c010c00u);
+                        se[r] = __builtin_amdgcn_perm(0u, w[r], 0x0c030c02u);
+                    }
+                }
+            }
+            else
+            {
+            adj = false;
+            const PgNode nd = nodes[node];
             for (uint32_t p = 0; p < nd.n_pred; ++p)
             {
                 const uint32_t pid = a.preds[nd.pred_off + p];
@@ -312,6 +347,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                         se[r] = pk_maxu(se[r], __builtin_amdgcn_perm(0u, w, 0x0c030c02u));
                     }
                 }
+            }
             }
 #pragma unroll
             for (int r = 0; r < C; ++r)
@@ -425,8 +461,13 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                         sp[2 * r + 1] = E[r];
                     }
                     else
-                        sp[r] = __builtin_amdgcn_perm(E[r], Hp[r], 0x06040200u);
+                    {
+                        const uint32_t w = __builtin_amdgcn_perm(E[r], Hp[r], 0x06040200u);
+                        sp[r] = w;
+                        cseed[r] = w;
+                    }
                 }
+                cnode = node;
             }
             // key: max (12 bits) | inverted column (16 bits; a direction has <= 65519 columns) | inverted lane (4 bits)
             const uint32_t kinv = (uint32_t)(15 - k);

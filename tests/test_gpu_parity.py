@@ -128,6 +128,28 @@ def test_empty_and_ragged(gpu_ctx, checker):
     compare([got[i] for i in idx], want, [reads[i] for i in idx], "ragged")
 
 
+def test_length_boundaries(gpu_ctx, checker):
+    """Every variant boundary: rows-per-lane steps (multiples of 32 / 64), byte vs wide (250 / 251), the 512 limit."""
+    import random
+    rng = random.Random(1234)
+    seqs, edges, _ = fuzzgen.long_read_case(rng, 1)
+    path = seqs[0] + seqs[1] + seqs[-1]
+    lens = [1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 159, 160, 161, 191, 192, 193, 223, 224,
+            225, 249, 250, 251, 252, 255, 256, 257, 319, 320, 321, 383, 384, 385, 447, 448, 449, 479, 480, 481, 511, 512]
+    reads = []
+    for L in lens:
+        st = rng.randrange(max(1, len(path) - L))
+        r = (path[st:st + L] + fuzzgen.rand_seq(rng, L))[:L]
+        reads.append(fuzzgen.mutate(rng, r, sub=0.01, indel=0.0)[:L] or "A")
+        reads.append(r)
+    want = checker.align_batch(seqs, edges, reads, cigar_stride=4096)
+    got = gpu_align(gpu_ctx, [(seqs, edges)], reads)
+    compare(got, want, reads, "length-boundaries")
+    from paragraph_amd import capi
+    with pytest.raises(Exception):
+        gpu_align(gpu_ctx, [(seqs, edges)], ["A" * 513])
+
+
 def test_golden_fixtures(gpu_ctx):
     """Committed vectors generated from the reference's gssw.c (tests/golden/make_golden.py)."""
     import glob

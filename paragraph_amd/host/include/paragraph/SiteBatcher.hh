@@ -49,6 +49,9 @@ struct BatchParameters
     double bad_align_frac = 0.8;       // --bad-align-frac
     bool use_support_filters = true;   // production nodefilter / edgefilter
     int32_t kmer_len = 0;              // --bad-align-uniq-kmer-len: 0 = no KmerFilter, < 0 = auto-detect per graph
+    // --path-sequence-matching (default ON in `paragraph`, OFF in grmpy): exact 32-mer-anchored path matching first; reads
+    // it leaves unmapped -- or that the filter chain rejects -- go on to the gssw stage (CompositeAligner.cpp:78-103, 152)
+    bool path_sequence_matching = false;
     unsigned alignment_flags = (unsigned)-1;
 };
 

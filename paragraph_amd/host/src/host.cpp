@@ -712,7 +712,6 @@ void SiteBatcher::run(BatchParameters const& prm)
     check(ctx, pg_batch_create(ctx, &guard.b), "pg_batch_create");
     check(ctx, pg_batch_upload(ctx, guard.b, G, n, gor.data(), base_off.data(), bases.data()), "pg_batch_upload");
     check(ctx, pg_batch_set_fragments(ctx, guard.b, frag.data(), is_rev.data()), "pg_batch_set_fragments");
-    check(ctx, pg_batch_align(ctx, guard.b, prm.alignment_flags), "pg_batch_align");
     pg_count_params cp{};
     cp.remove_nonuniq = prm.remove_nonuniq_reads ? 1 : 0;
     cp.use_support_filters = prm.use_support_filters ? 1 : 0;
@@ -723,6 +722,26 @@ void SiteBatcher::run(BatchParameters const& prm)
         check(ctx, pg_graphs_build_filter_index(ctx, G, prm.kmer_len, nullptr), "pg_graphs_build_filter_index");
         cp.use_kmer_filter = 1;
     }
+    uint32_t align_flags = prm.alignment_flags;
+    if (prm.path_sequence_matching && n)
+    {
+        // stage 1: PathAligner on every read; the filter chain runs on the device (count pass) and decides who goes on
+        check(ctx, pg_graphs_build_path_index(ctx, G, 32), "pg_graphs_build_path_index");
+        check(ctx, pg_batch_path_align(ctx, guard.b), "pg_batch_path_align");
+        check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
+        std::vector<uint8_t> stage_flags(n), active(n, 1);
+        std::vector<pg_read_support> stage_sup(n);
+        uint64_t np = 0;
+        check(ctx, pg_batch_download_path_flags(ctx, guard.b, stage_flags.data()), "pg_batch_download_path_flags");
+        check(ctx, pg_batch_download_counts(ctx, guard.b, nullptr, stage_sup.data(), nullptr, 0, &np), "pg_batch_download_counts");
+        for (uint32_t i = 0; i < n; ++i)
+            if ((stage_flags[i] & 1) && stage_sup[i].status == 1)
+                active[i] = 0;  // MAPPED by the path stage and accepted by the filters: done
+        check(ctx, pg_batch_set_active(ctx, guard.b, active.data()), "pg_batch_set_active");
+        // keep the path-stage records of the finished reads (the extension flag is ignored when flags == PG_AF_ALL)
+        align_flags = (align_flags & (PG_AF_CIGAR | PG_AF_BOTH_STRANDS | PG_AF_REVERSE_GRAPH)) | PG_AF_KEEP_RESULTS;
+    }
+    check(ctx, pg_batch_align(ctx, guard.b, align_flags), "pg_batch_align");
     check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
 
     uint64_t n_ops = 0, n_path = 0;
@@ -749,7 +768,22 @@ void SiteBatcher::run(BatchParameters const& prm)
             continue;
         if (sup[i].status == 3)
             throw std::runtime_error("invalid alignment on the device path for fragment " + read.fragment_id());
-        applyResult(read, res[i], ops.data(), true);
+        if (res[i].status & PG_STATUS_PATH_ALIGNER)
+        {
+            // PathAligner.cpp:121-161: the match's own strand, bases replaced, qualities untouched
+            if (res[i].returned_reverse)
+                read.set_bases(reverseComplement(read.bases()));
+            read.set_is_graph_reverse_strand(res[i].returned_reverse != 0);
+            std::string buf(16 + 12 * (size_t)res[i].n_ops, '\0');
+            buf.resize(pg_render_cigar(&res[i], ops.data(), &buf[0], buf.size()));
+            read.set_graph_cigar(buf);
+            read.set_graph_pos(res[i].graph_pos);
+            read.set_graph_alignment_score(res[i].score);
+            read.set_is_graph_alignment_unique(res[i].is_unique != 0);
+            read.set_graph_mapq(res[i].mapq);
+        }
+        else
+            applyResult(read, res[i], ops.data(), true);
         read.set_graph_mapping_status(sup[i].status == 1 ? Read::MAPPED : Read::BAD_ALIGN);
         read.clear_graph_nodes_supported();
         read.clear_graph_edges_supported();

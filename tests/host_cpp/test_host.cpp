@@ -3,6 +3,7 @@
 //   ParagraphTest.Aligns       src/c++/test/test_paragraph_parts.cpp:46-159
 //   DisambiguationTest         src/c++/test/test_disambiguation.cpp:44-105
 // Exit code 0 = all checks passed.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -389,6 +390,82 @@ static void testKlibAligner()
     EXPECT_EQ(c2.graph_cigar(), std::string("0[5M]2[8M]3[6M]"));
 }
 
+static std::string revComp(std::string s)
+{
+    for (char& c : s)
+        c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+    std::reverse(s.begin(), s.end());
+    return s;
+}
+
+// paragraph's default cascade in the batcher (path -> gssw) must give every read what CompositeAligner gives it
+static void testSiteBatcherPathStage()
+{
+    std::mt19937_64 rng(5);
+    auto rnd = [&](size_t n) {
+        std::string s(n, 'A');
+        for (auto& c : s)
+            c = "ACGT"[rng() % 4];
+        return s;
+    };
+    Graph g(3, false);
+    const std::string seqs[3] = { rnd(120), rnd(40), rnd(120) };
+    const char* names[3] = { "LF", "MID", "RF" };
+    for (NodeId n = 0; n < 3; ++n)
+    {
+        g.setNodeName(n, names[n]);
+        g.setNodeSeq(n, seqs[n]);
+    }
+    g.addEdge(0, 1);
+    g.addEdge(0, 2);
+    g.addEdge(1, 2);
+    g.addLabelToEdge(0, 1, "REF");
+    g.addLabelToEdge(1, 2, "REF");
+    g.addLabelToEdge(0, 2, "ALT");
+    const std::string hap[2] = { seqs[0] + seqs[1] + seqs[2], seqs[0] + seqs[2] };
+    std::vector<p_Read> a, b;
+    for (int i = 0; i < 60; ++i)
+    {
+        const std::string& h = hap[i & 1];
+        std::string r = h.substr(rng() % (h.size() - 70), 70);
+        if (i % 3 == 0)
+            r[rng() % r.size()] = "ACGT"[rng() % 4];  // not an exact match any more: falls through to gssw
+        if (i % 4 == 0)
+            r = revComp(r);
+        a.emplace_back(new Read("f" + std::to_string(i), r, std::string(r.size(), '#')));
+        b.emplace_back(new Read("f" + std::to_string(i), r, std::string(r.size(), '#')));
+    }
+    paragraph::SiteBatcher batcher;
+    batcher.addSite(&g, &a);
+    paragraph::BatchParameters prm;
+    prm.path_sequence_matching = true;
+    batcher.run(prm);
+    std::list<Path> no_paths;
+    CompositeAligner comp(true, true, false, false);
+    comp.setGraph(&g, no_paths);
+    std::vector<Read*> ptrs;
+    for (auto& r : b)
+        ptrs.push_back(r.get());
+    comp.alignReads(ptrs, nullptr);
+    EXPECT_TRUE(comp.mappedPath() > 10u);
+    EXPECT_TRUE(comp.mappedSw() > 10u);
+    size_t k = 0;
+    for (auto& r : b)
+    {
+        // the batcher drops nothing here (no BAD_ALIGN expected for these reads) and keeps the input order
+        if (k >= a.size())
+            break;
+        EXPECT_EQ(a[k]->fragment_id(), r->fragment_id());
+        EXPECT_EQ(a[k]->graph_cigar(), r->graph_cigar());
+        EXPECT_EQ(a[k]->graph_pos(), r->graph_pos());
+        EXPECT_EQ(a[k]->graph_mapq(), r->graph_mapq());
+        EXPECT_EQ(a[k]->is_graph_reverse_strand(), r->is_graph_reverse_strand());
+        EXPECT_EQ(a[k]->bases(), r->bases());
+        ++k;
+    }
+    EXPECT_EQ(k, b.size());
+}
+
 // align + count on the device, genotype on the host (lib/grmpy/CountAndGenotype.cpp:46-88): a 60 bp deletion, three
 // samples simulated as REF/REF, REF/ALT and ALT/ALT at ~30x
 static void testSiteToGenotype()
@@ -459,6 +536,7 @@ int main()
     try
     {
         testSiteToGenotype();
+        testSiteBatcherPathStage();
         testKlibAligner();
         testKmerAligner();
         testPathAligner();

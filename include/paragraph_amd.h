@@ -60,7 +60,7 @@ enum
     PG_ERR_INVALID = 1,     /* bad argument (NULL, non-topological edge, empty node, ...) */
     PG_ERR_NO_DEVICE = 2,   /* no usable HIP device */
     PG_ERR_HIP = 3,         /* a HIP runtime call failed (see pg_last_error) */
-    PG_ERR_UNSUPPORTED = 4, /* outside the supported envelope (read > 250 bp, > 4095 nodes, ...) */
+    PG_ERR_UNSUPPORTED = 4, /* outside the supported envelope (read > 512 bp, > 4095 nodes, ...) */
     PG_ERR_NOMEM = 5,
     PG_ERR_OVERFLOW = 6     /* an output buffer supplied by the caller is too small */
 };

@@ -147,5 +147,6 @@ pg_status pg_fail(pg_ctx* ctx, pg_status st, const std::string& msg);
     {                                                                                                          \
         hipError_t e__ = (call);                                                                               \
         if (e__ != hipSuccess)                                                                                 \
-            return pg_fail(ctx, PG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));               \
+            return pg_fail(ctx, e__ == hipErrorOutOfMemory ? PG_ERR_NOMEM : PG_ERR_HIP,                          \
+                           std::string(#call) + ": " + hipGetErrorString(e__));                                \
     } while (0)

@@ -89,40 +89,36 @@ string Genotype::filterString() const
 
 void Genotype::relabel(vector<uint64_t> const& new_labels)
 {
-    for (auto& g : gt)
-        g = new_labels.at(g);
-    std::sort(gt.begin(), gt.end());
-    for (auto& l : gl_name)
-    {
-        for (auto& g : l)
-            g = new_labels.at(g);
-        std::sort(l.begin(), l.end());
-    }
-    vector<double> new_allele_fractions(new_labels.size(), 0.0);
-    for (size_t g = 0; g < allele_fractions.size(); ++g)
-        new_allele_fractions[new_labels.at(g)] = allele_fractions[g];
-    allele_fractions = new_allele_fractions;
+    auto remap = [&](GenotypeVector& v) {
+        for (uint64_t& allele : v)
+            allele = new_labels.at(allele);
+        std::sort(v.begin(), v.end());
+    };
+    remap(gt);
+    for (GenotypeVector& name : gl_name)
+        remap(name);
+    vector<double> moved(new_labels.size(), 0.0);
+    for (size_t old = 0; old < allele_fractions.size(); ++old)
+        moved[new_labels.at(old)] = allele_fractions[old];
+    allele_fractions.swap(moved);
 }
 
 size_t GenotypeSet::add(vector<string> const& allele_names, Genotype const& gt)
 {
-    genotypes.push_back(gt);
-    Genotype& remapped_gt = genotypes.back();
-    vector<uint64_t> gt_remapping(allele_names.size());
-    size_t j = 0;
-    for (auto const& a : allele_names)
+    // index of every incoming allele in the merged list (appending the ones not seen before)
+    vector<uint64_t> to_merged;
+    to_merged.reserve(allele_names.size());
+    for (const string& name : allele_names)
     {
-        auto a_it = std::find(merged_allele_names.begin(), merged_allele_names.end(), a);
-        if (a_it == merged_allele_names.end())
-        {
-            gt_remapping[j] = merged_allele_names.size();
-            merged_allele_names.push_back(a);
-        }
-        else
-            gt_remapping[j] = (uint64_t)(a_it - merged_allele_names.begin());
-        ++j;
+        size_t at = 0;
+        while (at < merged_allele_names.size() && merged_allele_names[at] != name)
+            ++at;
+        if (at == merged_allele_names.size())
+            merged_allele_names.push_back(name);
+        to_merged.push_back(at);
     }
-    remapped_gt.relabel(gt_remapping);
+    genotypes.push_back(gt);
+    genotypes.back().relabel(to_merged);
     return genotypes.size() - 1;
 }
 
@@ -135,26 +131,28 @@ GenotypingParameters::GenotypingParameters(const vector<string>& _allele_names, 
     setPossibleGenotypes();
 }
 
+// All unordered genotypes (non-decreasing allele tuples) of the given ploidy, in the order the likelihood loop visits them:
+// colexicographic -- 0/0, 0/1, 1/1, 0/2, 1/2, 2/2, ... (the first best likelihood wins a tie, so the order matters).
+static void enumerateGenotypes(unsigned slots_left, unsigned max_allele, GenotypeVector& tail, vector<GenotypeVector>& out)
+{
+    for (unsigned allele = 0; allele <= max_allele; ++allele)
+    {
+        tail.insert(tail.begin(), allele);
+        if (slots_left == 1)
+            out.push_back(tail);
+        else
+            enumerateGenotypes(slots_left - 1, allele, tail, out);
+        tail.erase(tail.begin());
+    }
+}
+
 void GenotypingParameters::setPossibleGenotypes()
 {
-    vector<GenotypeVector> gts;
-    if (num_alleles)
-    {
-        const std::function<void(unsigned int, unsigned int, vector<uint64_t>)> makeGenotypes
-            = [&makeGenotypes, &gts](unsigned int p, unsigned int n, vector<uint64_t> suffix) {
-                  for (unsigned int a = 0; a <= n; ++a)
-                  {
-                      auto new_suffix = suffix;
-                      new_suffix.insert(new_suffix.begin(), a);
-                      if (p == 1)
-                          gts.push_back(new_suffix);
-                      else if (p > 1)
-                          makeGenotypes(p - 1, a, new_suffix);
-                  }
-              };
-        makeGenotypes(ploidy_, num_alleles - 1, {});
-    }
-    possible_genotypes = std::move(gts);
+    possible_genotypes.clear();
+    if (num_alleles == 0 || ploidy_ == 0)
+        return;
+    GenotypeVector tail;
+    enumerateGenotypes(ploidy_, num_alleles - 1, tail, possible_genotypes);
 }
 
 vector<int> GenotypingParameters::alleleNameConversionIndex(const vector<string>& names) const
@@ -254,285 +252,278 @@ BreakpointGenotyper::BreakpointGenotyper(std::unique_ptr<GenotypingParameters> c
     }
 }
 
+// One breakpoint, one sample.  Model: the reads supporting allele a are Poisson with mean lambda * (copies of a in the genotype)
+// * het fraction, or lambda * error rate when the genotype has no copy of a; lambda = depth scaled by the fraction of read
+// start positions that give at least min_overlap_bases across the breakpoint.
 Genotype BreakpointGenotyper::genotype(const BreakpointGenotyperParameter& param, const vector<int32_t>& read_counts_per_allele) const
 {
     if (read_counts_per_allele.size() != n_alleles_)
         error("Error: number of read counts and alleles mismatches. " + std::to_string(read_counts_per_allele.size()) + " != "
               + std::to_string(n_alleles_) + ".");
-    Genotype result;
-    // adjusted depth: reads must overlap the breakpoint by min_overlap_bases
-    const double multiplier = (param.read_length - (int32_t)min_overlap_bases_) / (double)param.read_length;
-    const double lambda = param.read_depth * multiplier;
-    const int32_t total_num_reads = std::accumulate(read_counts_per_allele.begin(), read_counts_per_allele.end(), 0);
-    if (total_num_reads == 0)
+    Genotype call;
+    const double lambda = param.read_depth * ((param.read_length - (int32_t)min_overlap_bases_) / (double)param.read_length);
+    int32_t n_reads = 0;
+    for (int32_t c : read_counts_per_allele)
+        n_reads += c;
+    if (n_reads == 0)
     {
-        result.filters.insert("NO_READS");
-        return result;
+        call.filters.insert("NO_READS");
+        return call;
     }
-    result.num_reads = total_num_reads;
+    call.num_reads = n_reads;
 
-    double best_gl = -std::numeric_limits<double>::max();
-    for (const auto& igt : possible_genotypes)
+    // likelihood of every candidate genotype; the first maximum is the call
+    double top = -std::numeric_limits<double>::max(), likelihood_mass = 0;
+    for (const GenotypeVector& candidate : possible_genotypes)
     {
-        const double gl = genotypeLikelihood(lambda, igt, read_counts_per_allele);
-        result.gl_name.push_back(igt);
-        result.gl.push_back(gl);
-        if (gl > best_gl)
+        const double gl = genotypeLikelihood(lambda, candidate, read_counts_per_allele);
+        call.gl_name.push_back(candidate);
+        call.gl.push_back(gl);
+        likelihood_mass += std::exp(gl);
+        if (gl > top)
         {
-            best_gl = gl;
-            result.gt = igt;
+            top = gl;
+            call.gt = candidate;
         }
     }
-
-    double sum_gl = 0;
-    for (auto l : result.gl)
-        sum_gl += std::exp(l);
-    const double pr_gt_error = 1.0 - std::exp(best_gl) / sum_gl;
-    if (pr_gt_error == 0)
-        result.gq = 100;
-    else
+    // GQ = phred of the posterior error under a flat prior over the candidates, truncated, capped at 100
+    const double p_wrong = 1.0 - std::exp(top) / likelihood_mass;
+    call.gq = 100;
+    if (p_wrong != 0)
     {
-        const double gq_log10 = std::log10(pr_gt_error);
-        result.gq = gq_log10 < -10 ? 100 : (int)(-10 * gq_log10);
+        const double lg = std::log10(p_wrong);
+        if (lg >= -10)
+            call.gq = (int)(-10 * lg);
     }
-    if (result.gq < min_pass_gq_)
-        result.filters.insert("GQ");
+    if (call.gq < min_pass_gq_)
+        call.filters.insert("GQ");
 
-    result.allele_fractions.assign(n_alleles_, 0.0);
-    for (unsigned int al = 0; al < n_alleles_; ++al)
-        result.allele_fractions[al] = ((double)read_counts_per_allele[al]) / total_num_reads;
+    for (int32_t c : read_counts_per_allele)
+        call.allele_fractions.push_back((double)c / n_reads);
 
-    double coverage_test_pvalue = param.use_poisson_depth ? poissonCdf(lambda, total_num_reads)
-                                                          : normalCdf(lambda, param.depth_sd, total_num_reads);
-    if (coverage_test_pvalue > 0.5)
-    {
-        coverage_test_pvalue = 1 - coverage_test_pvalue;
-        if (coverage_test_pvalue < coverage_test_cutoff_.first)
-            result.filters.insert("BP_DEPTH");
-    }
-    else if (coverage_test_pvalue < coverage_test_cutoff_.second)
-        result.filters.insert("BP_DEPTH");
-    result.coverage_test_pvalue = coverage_test_pvalue;
-    return result;
+    // two-sided depth test: is the total read count plausible for this depth?
+    double tail = param.use_poisson_depth ? poissonCdf(lambda, n_reads) : normalCdf(lambda, param.depth_sd, n_reads);
+    const bool upper = tail > 0.5;
+    if (upper)
+        tail = 1 - tail;
+    if (tail < (upper ? coverage_test_cutoff_.first : coverage_test_cutoff_.second))
+        call.filters.insert("BP_DEPTH");
+    call.coverage_test_pvalue = tail;
+    return call;
 }
 
 double BreakpointGenotyper::genotypeLikelihood(double lambda, const GenotypeVector& gv, const vector<int32_t>& read_counts) const
 {
-    auto it = genotype_prior_.find(gv);
-    const double log_phi = it == genotype_prior_.end() ? 0 : it->second;
-    vector<int> allele_ploidy(n_alleles_, 0);
-    for (unsigned int al = 0; al < n_alleles_; ++al)
-        for (const auto g : gv)
-            if (al == g)
-                ++allele_ploidy[al];
-    double gl = log_phi;
+    auto prior = genotype_prior_.find(gv);
+    double gl = prior == genotype_prior_.end() ? 0.0 : prior->second;
     for (unsigned int al = 0; al < n_alleles_; ++al)
     {
-        double mean;
-        if (allele_ploidy[al] == 0)  // no copies -> all reads supporting this allele are errors
-            mean = lambda * (allele_error_rate_.size() == 1 ? allele_error_rate_[0] : allele_error_rate_[al]);
-        else
-            mean = lambda * allele_ploidy[al] * (haplotype_read_fraction_.size() == 1 ? haplotype_read_fraction_[0] : haplotype_read_fraction_[al]);
-        const double lp = logPoissonPdf(mean, read_counts[al]);
-        if (std::exp(lp) == 0)  // the reference takes log(pdf): an underflowing pdf ends the sum
+        const int copies = (int)std::count(gv.begin(), gv.end(), (uint64_t)al);
+        const double rate = copies == 0 ? (allele_error_rate_.size() == 1 ? allele_error_rate_[0] : allele_error_rate_[al])
+                                        : copies * (haplotype_read_fraction_.size() == 1 ? haplotype_read_fraction_[0] : haplotype_read_fraction_[al]);
+        const double lp = logPoissonPdf(lambda * rate, read_counts[al]);
+        // the reference takes log(pdf): a pdf that underflows to zero (or an infinite sum) ends the evaluation
+        if (std::exp(lp) == 0 || std::isinf(gl + lp))
             return -std::numeric_limits<double>::max();
         gl += lp;
-        if (std::isinf(gl))
-            return -std::numeric_limits<double>::max();
     }
     return gl;
 }
 
 // -------------------------------------------------------------------------------------------------- BreakpointStatistics
+// A breakpoint = one node and the edges leaving it (forward) or entering it (backward).  Alleles are the labels on those
+// edges; two alleles that use exactly the same edges cannot be told apart here and are merged into one "canonical" allele
+// (named REF when REF is among them, otherwise after the alphabetically first member).
 BreakpointStatistics::BreakpointStatistics(graphtools::Graph const& graph, graphtools::NodeId node_id, bool forward)
 {
-    const auto& node_name = graph.nodeName(node_id);
-    const auto allele_nodes = forward ? graph.successors(node_id) : graph.predecessors(node_id);
-    std::map<string, std::set<string>> allele_edge_sets;
-    for (auto const& an : allele_nodes)
+    const string& here = graph.nodeName(node_id);
+    std::map<string, std::set<string>> edges_of_allele;  // ordered by allele name
+    for (graphtools::NodeId other : (forward ? graph.successors(node_id) : graph.predecessors(node_id)))
     {
-        const auto& an_name = graph.nodeName(an);
-        const string edge_name = forward ? (node_name + "_" + an_name) : (an_name + "_" + node_name);
-        edge_names.push_back(edge_name);
-        edge_name_to_index[edge_name] = edge_names.size() - 1;
-        const auto& edge_labels = forward ? graph.edgeLabels(node_id, an) : graph.edgeLabels(an, node_id);
-        for (const auto& allele_name : edge_labels)
+        const string& there = graph.nodeName(other);
+        const string edge = forward ? here + "_" + there : there + "_" + here;
+        edge_name_to_index[edge] = edge_names.size();
+        edge_names.push_back(edge);
+        for (const string& label : (forward ? graph.edgeLabels(node_id, other) : graph.edgeLabels(other, node_id)))
         {
-            allele_edge_sets[allele_name].insert(edge_name);
-            if (std::find(all_allele_names.begin(), all_allele_names.end(), allele_name) == all_allele_names.end())
-                all_allele_names.push_back(allele_name);
+            edges_of_allele[label].insert(edge);
+            if (std::find(all_allele_names.begin(), all_allele_names.end(), label) == all_allele_names.end())
+                all_allele_names.push_back(label);
         }
     }
-    // canonical alleles: alleles with the same edge set are one equivalence class, named REF if it contains REF, else by
-    // its first member
-    std::map<string, std::list<string>> canonical_allele_to_allele;
-    for (const auto& allele : allele_edge_sets)
-        canonical_allele_to_allele[joinWith(allele.second.begin(), allele.second.end(), ";", [](const string& s) { return s; })]
-            .push_back(allele.first);
-    for (const auto& canonical_allele : canonical_allele_to_allele)
+    // group alleles by their edge set; groups come out ordered by the ";"-joined edge names
+    std::map<string, vector<string>> groups;
+    for (auto const& ae : edges_of_allele)
     {
-        const bool has_ref = std::find(canonical_allele.second.begin(), canonical_allele.second.end(), "REF") != canonical_allele.second.end();
-        const string canonical_allele_name = has_ref ? string("REF") : canonical_allele.second.front();
-        canonical_allele_names.push_back(canonical_allele_name);
-        const size_t this_allele_index = canonical_allele_names.size() - 1;
-        for (const auto& edge : allele_edge_sets[canonical_allele_name])
-            edgename_to_alleles[edge].push_back(this_allele_index);
-        for (auto const& noncanonical_allele : canonical_allele.second)
+        string key;
+        for (const string& e : ae.second)
+            key += (key.empty() ? "" : ";") + e;
+        groups[key].push_back(ae.first);
+    }
+    for (auto const& grp : groups)
+    {
+        const vector<string>& members = grp.second;
+        const bool holds_ref = std::find(members.begin(), members.end(), "REF") != members.end();
+        const string name = holds_ref ? "REF" : members.front();
+        const size_t index = canonical_allele_names.size();
+        canonical_allele_names.push_back(name);
+        for (const string& e : edges_of_allele[name])
+            edgename_to_alleles[e].push_back(index);
+        for (const string& m : members)
         {
-            allele_name_to_index[noncanonical_allele] = this_allele_index;
-            allele_name_to_canonical_allele_name[noncanonical_allele] = canonical_allele_name;
+            allele_name_to_index[m] = index;
+            allele_name_to_canonical_allele_name[m] = name;
         }
     }
 }
 
 void BreakpointStatistics::addCounts(std::map<string, int32_t> const& read_counts_by_edge)
 {
-    for (auto const& edge_name : edge_names)
+    for (size_t e = 0; e < edge_names.size(); ++e)
     {
-        const size_t e_index = edge_name_to_index.at(edge_name);
-        auto c_it = read_counts_by_edge.find(edge_name);
-        const int this_edge_count = c_it == read_counts_by_edge.end() ? 0 : c_it->second;
-        if (this_edge_count == 0)
+        auto hit = read_counts_by_edge.find(edge_names[e]);
+        if (hit == read_counts_by_edge.end() || hit->second == 0)
             continue;
-        if (edge_counts.size() <= e_index)
-            edge_counts.resize(edge_names.size(), 0);
-        edge_counts[e_index] += this_edge_count;
-        for (const auto& allele : edgename_to_alleles[edge_name])
+        // (the count vectors stay empty until the first non-zero count arrives, as in the reference)
+        if (edge_counts.empty())
+            edge_counts.assign(edge_names.size(), 0);
+        edge_counts[e] += hit->second;
+        for (size_t allele : edgename_to_alleles[edge_names[e]])
         {
-            if (allele_counts.size() <= allele)
-                allele_counts.resize(canonical_allele_names.size(), 0);
-            allele_counts[allele] += this_edge_count;
+            if (allele_counts.empty())
+                allele_counts.assign(canonical_allele_names.size(), 0);
+            allele_counts[allele] += hit->second;
         }
     }
 }
 
-int32_t BreakpointStatistics::getCount(string const& edge_or_allele_name) const
+int32_t BreakpointStatistics::getCount(string const& name) const
 {
-    const auto e_it = edge_name_to_index.find(edge_or_allele_name);
-    const auto a_it = allele_name_to_index.find(edge_or_allele_name);
-    if (e_it != edge_name_to_index.end() && a_it != allele_name_to_index.end())
-        error("Allele / sequence name " + edge_or_allele_name + " is ambiguous with an edge name.");
-    if (e_it != edge_name_to_index.end())
-        return e_it->second >= edge_counts.size() ? 0 : edge_counts[e_it->second];
-    if (a_it != allele_name_to_index.end())
-        return a_it->second >= allele_counts.size() ? 0 : allele_counts[a_it->second];
-    return 0;  // unknown edge or allele: not every allele is seen at every breakpoint of a complex site
+    const auto as_edge = edge_name_to_index.find(name);
+    const auto as_allele = allele_name_to_index.find(name);
+    const bool is_edge = as_edge != edge_name_to_index.end(), is_allele = as_allele != allele_name_to_index.end();
+    if (is_edge && is_allele)
+        error("Allele / sequence name " + name + " is ambiguous with an edge name.");
+    if (is_edge)
+        return as_edge->second < edge_counts.size() ? edge_counts[as_edge->second] : 0;
+    if (is_allele)
+        return as_allele->second < allele_counts.size() ? allele_counts[as_allele->second] : 0;
+    return 0;  // not every allele of a complex site is seen at every breakpoint
 }
 
-BreakpointMap createBreakpointMap(graphtools::Graph const& wgraph)
+BreakpointMap createBreakpointMap(graphtools::Graph const& graph)
 {
-    BreakpointMap breakpoint_map;
-    if (wgraph.numNodes() == 0)
-        return breakpoint_map;
-    const graphtools::NodeId source_node = 0, sink_node = (graphtools::NodeId)(wgraph.numNodes() - 1);
-    const bool has_source_and_sink = wgraph.nodeName(source_node) == "source" && wgraph.nodeName(sink_node) == "sink";
-    for (graphtools::NodeId node = source_node; node <= sink_node; ++node)
+    BreakpointMap out;
+    const size_t n = graph.numNodes();
+    if (n == 0)
+        return out;
+    // the artificial "source" / "sink" nodes of converted graphs are not breakpoints
+    const bool framed = graph.nodeName(0) == "source" && graph.nodeName((graphtools::NodeId)(n - 1)) == "sink";
+    for (size_t i = 0; i < n; ++i)
     {
-        if (has_source_and_sink && (node == source_node || node == sink_node))
+        if (framed && (i == 0 || i + 1 == n))
             continue;
-        const string& node_name = wgraph.nodeName(node);
-        if (wgraph.successors(node).size() > 1)
-            breakpoint_map.emplace(node_name + "_", BreakpointStatistics(wgraph, node, true));
-        if (wgraph.predecessors(node).size() > 1)
-            breakpoint_map.emplace(string("_") + node_name, BreakpointStatistics(wgraph, node, false));
+        const graphtools::NodeId node = (graphtools::NodeId)i;
+        if (graph.successors(node).size() > 1)
+            out.emplace(graph.nodeName(node) + "_", BreakpointStatistics(graph, node, true));
+        if (graph.predecessors(node).size() > 1)
+            out.emplace("_" + graph.nodeName(node), BreakpointStatistics(graph, node, false));
     }
-    return breakpoint_map;
+    return out;
 }
 
 // ------------------------------------------------------------------------------------------------------ CombinedGenotype
-Genotype combinedGenotype(GenotypeSet const& genotypes, const BreakpointGenotyperParameter* b_param, const BreakpointGenotyper* p_genotyper)
+namespace
 {
-    Genotype result;
-    const size_t num_pass_genotypes = countUniqGenotypes(genotypes, true);
-    if (num_pass_genotypes == 0)
-    {
-        const auto num_fail_genotypes = (int)countUniqGenotypes(genotypes, false);
-        if (num_fail_genotypes == 0)
-            result.filters.insert("NO_VALID_GT");
-        else if (num_fail_genotypes == 1)
-            result = reportConsensusGenotypes(genotypes, false);
-        else
-            result = genotypeByTotalCounts(genotypes, false, p_genotyper, b_param);
-    }
-    else if (num_pass_genotypes == 1)
-        result = reportConsensusGenotypes(genotypes, true);
-    else
-        result = genotypeByTotalCounts(genotypes, true, p_genotyper, b_param);
-    if (result.filters.empty())
-        result.filters.insert("PASS");
-    return result;
+GenotypeVector sortedCopy(GenotypeVector v)
+{
+    std::sort(v.begin(), v.end());
+    return v;
 }
+
+bool usable(const Genotype& bp, bool pass_only) { return !bp.gt.empty() && !(pass_only && !bp.filters.empty()); }
+}  // namespace
 
 size_t countUniqGenotypes(GenotypeSet const& genotypes, bool pass_only)
 {
-    std::set<GenotypeVector> voted_gts;
-    for (auto& bp : genotypes)
+    std::set<GenotypeVector> distinct;
+    for (const Genotype& bp : genotypes)
+        if (usable(bp, pass_only))
+            distinct.insert(sortedCopy(bp.gt));
+    return distinct.size();
+}
+
+// Site genotype from the breakpoint genotypes: when the (passing, else all) breakpoints agree, report that genotype with the
+// pooled evidence; when they disagree, genotype the mean allele counts again and flag CONFLICT.
+Genotype combinedGenotype(GenotypeSet const& genotypes, const BreakpointGenotyperParameter* b_param, const BreakpointGenotyper* p_genotyper)
+{
+    Genotype site;
+    bool pass_only = true;
+    size_t distinct = countUniqGenotypes(genotypes, true);
+    if (distinct == 0)
     {
-        if (bp.gt.empty())
-            continue;
-        if (pass_only && !bp.filters.empty())
-            continue;
-        GenotypeVector sorted_gt = bp.gt;
-        std::sort(sorted_gt.begin(), sorted_gt.end());
-        voted_gts.insert(sorted_gt);
+        pass_only = false;
+        distinct = countUniqGenotypes(genotypes, false);
     }
-    return voted_gts.size();
+    if (distinct == 0)
+        site.filters.insert("NO_VALID_GT");
+    else if (distinct == 1)
+        site = reportConsensusGenotypes(genotypes, pass_only);
+    else
+        site = genotypeByTotalCounts(genotypes, pass_only, p_genotyper, b_param);
+    if (site.filters.empty())
+        site.filters.insert("PASS");
+    return site;
 }
 
 Genotype reportConsensusGenotypes(GenotypeSet const& genotypes, bool pass_only)
 {
-    Genotype result;
-    // the reference keys an unordered_map by the "a|b" string of the sorted genotype; the order of the resulting GL list
-    // is that container's iteration order there and sorted-by-key here (GL lookups are by name)
-    std::map<string, std::pair<GenotypeVector, double>> GLs;
-    result.num_reads = 0;
-    vector<int> gqs;
-    for (auto& bp : genotypes)
+    Genotype site;
+    // best likelihood seen for every (sorted) genotype; the reference keeps them in an unordered_map keyed by "a|b", so the
+    // order of the resulting GL list is unspecified there -- here it is sorted by genotype
+    std::map<GenotypeVector, double> best_gl;
+    bool any = false;
+    int lowest_gq = 0;
+    for (const Genotype& bp : genotypes)
     {
         if (bp.gt.empty())
         {
-            result.filters.insert("BP_NO_GT");
+            site.filters.insert("BP_NO_GT");
             continue;
         }
         if (pass_only && !bp.filters.empty())
         {
-            result.filters.insert(bp.filters.begin(), bp.filters.end());
+            site.filters.insert(bp.filters.begin(), bp.filters.end());
             continue;
         }
-        if (result.gt.empty())
-        {
-            GenotypeVector sorted_bp = bp.gt;
-            std::sort(sorted_bp.begin(), sorted_bp.end());
-            result.gt = sorted_bp;
-        }
-        result.num_reads += bp.num_reads;
-        if (!result.gt.empty())
-            gqs.emplace_back(bp.gq);
-        if (bp.allele_fractions.size() > result.allele_fractions.size())
-            result.allele_fractions.resize(bp.allele_fractions.size(), 0);
-        for (size_t i = 0; i < bp.allele_fractions.size(); ++i)
-            result.allele_fractions[i] += bp.num_reads * bp.allele_fractions[i];
+        if (site.gt.empty())
+            site.gt = sortedCopy(bp.gt);
+        lowest_gq = any ? std::min(lowest_gq, bp.gq) : bp.gq;
+        any = true;
+        site.num_reads += bp.num_reads;
+        if (site.allele_fractions.size() < bp.allele_fractions.size())
+            site.allele_fractions.resize(bp.allele_fractions.size(), 0.0);
+        for (size_t al = 0; al < bp.allele_fractions.size(); ++al)
+            site.allele_fractions[al] += bp.num_reads * bp.allele_fractions[al];  // read-weighted mean, divided below
         for (size_t i = 0; i < bp.gl.size(); ++i)
         {
-            auto sorted_gl_name = bp.gl_name[i];
-            std::sort(sorted_gl_name.begin(), sorted_gl_name.end());
-            const string key = joinWith(sorted_gl_name.begin(), sorted_gl_name.end(), "|", [](uint64_t g) { return std::to_string(g); });
-            auto gl_it = GLs.find(key);
-            if (gl_it == GLs.end())
-                GLs.emplace(key, std::make_pair(sorted_gl_name, bp.gl[i]));
-            else
-                gl_it->second.second = std::max(gl_it->second.second, bp.gl[i]);
+            const GenotypeVector key = sortedCopy(bp.gl_name[i]);
+            auto slot = best_gl.find(key);
+            if (slot == best_gl.end())
+                best_gl.emplace(key, bp.gl[i]);
+            else if (bp.gl[i] > slot->second)
+                slot->second = bp.gl[i];
         }
     }
-    for (auto& af : result.allele_fractions)
-        af /= result.num_reads;
-    for (auto const& gl : GLs)
+    for (double& af : site.allele_fractions)
+        af /= site.num_reads;
+    for (auto const& kv : best_gl)
     {
-        result.gl.push_back(gl.second.second);
-        result.gl_name.push_back(gl.second.first);
+        site.gl_name.push_back(kv.first);
+        site.gl.push_back(kv.second);
     }
-    result.gq = gqs.empty() ? 0 : *std::min_element(gqs.begin(), gqs.end());
-    return result;
+    site.gq = any ? lowest_gq : 0;
+    return site;
 }
 
 Genotype genotypeByTotalCounts(
@@ -540,37 +531,33 @@ Genotype genotypeByTotalCounts(
 {
     if (!p_genotyper || !b_param || !(b_param->read_depth > 0) || b_param->read_length <= 0)
         error("genotypeByTotalCounts needs a genotyper and positive depth / read length");
-    std::set<string> filters;
-    filters.insert("CONFLICT");
-    vector<int> sum_counts;
-    int num_bp = 0;
-    for (auto const& bp : genotypes)
+    std::set<string> flags{ "CONFLICT" };
+    vector<int> total;
+    int n_used = 0;
+    for (const Genotype& bp : genotypes)
     {
         if (use_pass_only && !bp.filters.empty())
         {
-            filters.insert(bp.filters.begin(), bp.filters.end());
+            flags.insert(bp.filters.begin(), bp.filters.end());
             continue;
         }
         if (bp.num_reads == 0)
         {
-            filters.insert("BP_NO_GT");
+            flags.insert("BP_NO_GT");
             continue;
         }
-        if (sum_counts.empty())
-            sum_counts.resize(bp.allele_fractions.size(), 0);
-        size_t allele_index = 0;
-        for (auto& af : bp.allele_fractions)
-        {
-            sum_counts.at(allele_index) += (int)std::round(af * bp.num_reads);
-            allele_index++;
-        }
-        num_bp++;
+        if (total.empty())
+            total.assign(bp.allele_fractions.size(), 0);
+        for (size_t al = 0; al < bp.allele_fractions.size(); ++al)
+            total.at(al) += (int)std::round(bp.allele_fractions[al] * bp.num_reads);  // back to per-allele read counts
+        ++n_used;
     }
-    for (auto& s : sum_counts)
-        s = (int)std::round((double)s / num_bp);
-    Genotype result = p_genotyper->genotype(*b_param, vector<int32_t>(sum_counts.begin(), sum_counts.end()));
-    result.filters = filters;
-    return result;
+    vector<int32_t> mean_counts;
+    for (int t : total)
+        mean_counts.push_back((int32_t)std::round((double)t / n_used));
+    Genotype site = p_genotyper->genotype(*b_param, mean_counts);
+    site.filters = flags;
+    return site;
 }
 
 // ------------------------------------------------------------------------------------------------ GraphBreakpointGenotyper

@@ -501,8 +501,7 @@ void KlibAligner::alignRead(Read& read)
 }
 
 CompositeAligner::CompositeAligner(bool pathMatching, bool graphMatching, bool klibMatching, bool kmerMatching, unsigned flags)
-    : pathMatching_(pathMatching), graphMatching_(graphMatching), klibMatching_(klibMatching), kmerMatching_(kmerMatching),
-      grapAlignmentflags_(flags)
+    : on_{ pathMatching, graphMatching, klibMatching, kmerMatching }, gssw_flags_(flags)
 {
 }
 CompositeAligner::~CompositeAligner() = default;
@@ -510,44 +509,44 @@ CompositeAligner::CompositeAligner(CompositeAligner&& rhs) noexcept = default;
 
 void CompositeAligner::setGraph(Graph const* graph, std::list<graphtools::Path> const& paths)
 {
-    if (pathMatching_)
-        pathAligner_.setGraph(graph, paths);
-    if (graphMatching_)
-        graphAligner_.setGraph(graph);
-    if (kmerMatching_)
-        kmerAligner_.setGraph(graph, paths);
-    if (klibMatching_)
-        klibAligner_.setGraph(graph, paths);
+    if (on_.path)
+        path_stage_.setGraph(graph, paths);
+    if (on_.graph)
+        gssw_stage_.setGraph(graph);
+    if (on_.kmer)
+        kmer_stage_.setGraph(graph, paths);
+    if (on_.klib)
+        klib_stage_.setGraph(graph, paths);
 }
 
 void CompositeAligner::alignReads(std::vector<Read*> const& all_reads, ReadFilter filter)
 {
-    attempted_ += (unsigned)all_reads.size();
+    tally_.attempted += (unsigned)all_reads.size();
     std::vector<Read*> reads = all_reads;
-    if (pathMatching_)
+    if (on_.path)
     {
         // CompositeAligner.cpp:82-103
-        const unsigned before = pathAligner_.mapped();
-        pathAligner_.alignReads(reads);
-        mappedPath_ += pathAligner_.mapped() - before;
-        anchoredPath_ = pathAligner_.anchored();
+        const unsigned before = path_stage_.mapped();
+        path_stage_.alignReads(reads);
+        tally_.path += path_stage_.mapped() - before;
+        tally_.anchored = path_stage_.anchored();
         std::vector<Read*> rest;
         for (Read* read : reads)
         {
             if (read->graph_mapping_status() == Read::MAPPED && filter && filter(*read))
             {
                 read->set_graph_mapping_status(Read::BAD_ALIGN);
-                filtered_ += !kmerMatching_ && !klibMatching_ && !graphMatching_;
+                tally_.filtered += !on_.kmer && !on_.klib && !on_.graph;
             }
             if (read->graph_mapping_status() != Read::MAPPED)
                 rest.push_back(read);
         }
         reads.swap(rest);
     }
-    if (kmerMatching_ && !reads.empty())
+    if (on_.kmer && !reads.empty())
     {
         // CompositeAligner.cpp:105-126
-        kmerAligner_.alignReads(reads);
+        kmer_stage_.alignReads(reads);
         std::vector<Read*> rest;
         for (Read* read : reads)
         {
@@ -556,20 +555,20 @@ void CompositeAligner::alignReads(std::vector<Read*> const& all_reads, ReadFilte
                 if (filter && filter(*read))
                 {
                     read->set_graph_mapping_status(Read::BAD_ALIGN);
-                    filtered_ += !klibMatching_ && !graphMatching_;
+                    tally_.filtered += !on_.klib && !on_.graph;
                 }
                 else
-                    ++mappedKmers_;
+                    ++tally_.kmers;
             }
             if (read->graph_mapping_status() != Read::MAPPED)
                 rest.push_back(read);
         }
         reads.swap(rest);
     }
-    if (klibMatching_ && !reads.empty())
+    if (on_.klib && !reads.empty())
     {
         // CompositeAligner.cpp:128-150
-        klibAligner_.alignReads(reads);
+        klib_stage_.alignReads(reads);
         std::vector<Read*> rest;
         for (Read* read : reads)
         {
@@ -578,19 +577,19 @@ void CompositeAligner::alignReads(std::vector<Read*> const& all_reads, ReadFilte
                 if (filter && filter(*read))
                 {
                     read->set_graph_mapping_status(Read::BAD_ALIGN);
-                    filtered_ += !graphMatching_;
+                    tally_.filtered += !on_.graph;
                 }
                 else
-                    ++mappedKlib_;
+                    ++tally_.klib;
             }
             if (read->graph_mapping_status() != Read::MAPPED)
                 rest.push_back(read);
         }
         reads.swap(rest);
     }
-    if (!graphMatching_ || reads.empty())
+    if (!on_.graph || reads.empty())
         return;
-    graphAligner_.alignReads(reads, grapAlignmentflags_);
+    gssw_stage_.alignReads(reads, gssw_flags_);
     for (Read* read : reads)
     {
         // CompositeAligner.cpp:152-175: the gssw stage always produces a mapping
@@ -598,10 +597,10 @@ void CompositeAligner::alignReads(std::vector<Read*> const& all_reads, ReadFilte
         if (filter && filter(*read))
         {
             read->set_graph_mapping_status(Read::BAD_ALIGN);
-            ++filtered_;
+            ++tally_.filtered;
         }
         else
-            ++mappedSw_;
+            ++tally_.sw;
     }
 }
 

@@ -36,43 +36,52 @@ HOST_LIB = os.path.join(_HERE, "libparagraph_host.so")
 HOST_TEST = os.path.join(ROOT, "tests", "host_cpp", "test_host")
 
 
-def build_host(force=False, verbose=False):
-    """g++ -> paragraph_amd/libparagraph_host.so (reference-shaped C++ classes over the C ABI) and the C++ test
-    program tests/host_cpp/test_host."""
-    src = os.path.join(_HERE, "host", "src", "host.cpp")
-    gsrc = os.path.join(_HERE, "host", "src", "genotyping.cpp")
+HOST_CPU_SOURCES = ["genotyping.cpp", "json.cpp", "io.cpp", "graphio.cpp"]  # no device calls: also built into the CPU test programs
+HOST_GPU_SOURCES = ["host.cpp", "workflow.cpp"]
+
+
+def _host_paths():
     inc = os.path.join(_HERE, "host", "include")
     hdrs = [os.path.join(dp, f) for dp, _, fs in os.walk(inc) for f in fs]
+    src = lambda names: [os.path.join(_HERE, "host", "src", n) for n in names]
+    return inc, hdrs, src(HOST_CPU_SOURCES), src(HOST_GPU_SOURCES)
+
+
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+
+
+def build_host(force=False, verbose=False):
+    """g++ -> paragraph_amd/libparagraph_host.so (reference-shaped C++ classes over the C ABI, BAM/FASTA/JSON input, the
+    batched site workflow) and the C++ test program tests/host_cpp/test_host."""
+    inc, hdrs, cpu_src, gpu_src = _host_paths()
     cxx = os.environ.get("CXX", "g++")
-    if force or _stale(HOST_LIB, [src, gsrc, LIB] + hdrs):
-        cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + inc, "-o", HOST_LIB, src, gsrc, "-L" + _HERE,
-               "-lparagraph_amd", "-Wl,-rpath,$ORIGIN"]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.run(cmd, check=True)
-    tsrc = os.path.join(ROOT, "tests", "host_cpp", "test_host.cpp")
-    if os.path.exists(tsrc) and (force or _stale(HOST_TEST, [tsrc, HOST_LIB] + hdrs)):
-        cmd = [cxx, "-std=c++17", "-O2", "-I" + inc, "-o", HOST_TEST, tsrc, "-L" + _HERE, "-lparagraph_host",
-               "-lparagraph_amd", "-Wl,-rpath,$ORIGIN/../../paragraph_amd"]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.run(cmd, check=True)
+    if force or _stale(HOST_LIB, cpu_src + gpu_src + [LIB] + hdrs):
+        _run([cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-I" + inc, "-o", HOST_LIB] + gpu_src + cpu_src
+             + ["-L" + _HERE, "-lparagraph_amd", "-lz", "-Wl,-rpath,$ORIGIN"], verbose)
+    for name in ("test_host", "test_workflow"):
+        tsrc = os.path.join(ROOT, "tests", "host_cpp", name + ".cpp")
+        exe = os.path.join(ROOT, "tests", "host_cpp", name)
+        if os.path.exists(tsrc) and (force or _stale(exe, [tsrc, HOST_LIB] + hdrs)):
+            _run([cxx, "-std=c++17", "-O2", "-pthread", "-I" + inc, "-o", exe, tsrc, "-L" + _HERE, "-lparagraph_host",
+                  "-lparagraph_amd", "-Wl,-rpath,$ORIGIN/../../paragraph_amd"], verbose)
     return HOST_LIB
 
 
 def build_genotyping_test(force=False, verbose=False):
-    """CPU-only: the host genotyping module + its test program (no HIP, runs in the "not gpu" suite)."""
-    gsrc = os.path.join(_HERE, "host", "src", "genotyping.cpp")
-    inc = os.path.join(_HERE, "host", "include")
-    tsrc = os.path.join(ROOT, "tests", "host_cpp", "test_genotyping.cpp")
-    exe = os.path.join(ROOT, "tests", "host_cpp", "test_genotyping")
-    hdrs = [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(inc, "genotyping")) for f in fs]
-    if force or _stale(exe, [tsrc, gsrc] + hdrs):
-        cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-I" + inc, "-o", exe, tsrc, gsrc]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.run(cmd, check=True)
-    return exe
+    """CPU-only programs of the "not gpu" suite: the genotyping module test and the input / statistics test (no HIP)."""
+    inc, hdrs, cpu_src, _ = _host_paths()
+    cxx = os.environ.get("CXX", "g++")
+    exes = []
+    for name in ("test_genotyping", "test_hostio"):
+        tsrc = os.path.join(ROOT, "tests", "host_cpp", name + ".cpp")
+        exe = os.path.join(ROOT, "tests", "host_cpp", name)
+        if os.path.exists(tsrc) and (force or _stale(exe, [tsrc] + cpu_src + hdrs)):
+            _run([cxx, "-std=c++17", "-O2", "-I" + inc, "-o", exe, tsrc] + cpu_src + ["-lz"], verbose)
+        exes.append(exe)
+    return exes[0]
 
 
 def build_all(force=False, verbose=False):

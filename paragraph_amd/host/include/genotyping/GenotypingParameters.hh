@@ -7,6 +7,7 @@
 #include <utility>
 #include <vector>
 
+#include "common/Json.hh"
 #include "genotyping/Genotype.hh"
 
 namespace genotyping
@@ -29,6 +30,10 @@ public:
     const std::map<GenotypeVector, double>& genotypeFractions() const { return genotype_fractions; }
     const std::vector<GenotypeVector>& possibleGenotypes() const { return possible_genotypes; }
 
+    // the genotyping-parameter document of grmpy -G (GenotypingParameters::setFromJson, GenotypingParameters.cpp:83-187).
+    // Quirks kept: both values of "coverage_test_cutoff" land in the LOWER cutoff, "use_poisson_depth" must be the STRING
+    // "true" / "false", "ploidy" does not re-enumerate the possible genotypes, "min_pass_gq" is not read at all.
+    void setFromJson(common::Json const& param_json);
     // setFromJson's keys
     void setMinOverlapBases(unsigned int v) { min_overlap_bases = v; }
     void setReferenceAllele(const std::string& v) { reference_allele = v; }

@@ -1,0 +1,46 @@
+// Post-hoc numbers of the count document: "fragment_statistics" (alignmentStats, lib/paragraph/ReadCounting.cpp:129-223, over
+// common::Fragment lengths, lib/common/Fragment.cpp:33-152) and "alignment_statistics" (summarizeAlignments,
+// lib/paragraph/GraphSummaryStatistics.cpp:47-185 with AlignmentStatistics.cpp:41-144).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "common/Json.hh"
+#include "common/Read.hh"
+#include "graphcore/Graph.hh"
+
+namespace paragraph
+{
+// per-node pieces of a "<id>[<ops>]..." graph CIGAR
+struct NodeAlignment
+{
+    graphtools::NodeId node = 0;
+    uint32_t matched = 0, mismatched = 0, clipped = 0, inserted = 0, deleted = 0, missing = 0;
+    uint32_t referenceLength() const { return matched + mismatched + deleted + missing; }
+    uint32_t queryLength() const { return matched + mismatched + inserted + clipped + missing; }
+};
+// throws std::runtime_error on malformed text or node ids outside the graph
+std::vector<NodeAlignment> decodeGraphCigar(std::string const& graph_cigar, graphtools::Graph const& graph);
+
+// The running estimators the fragment statistics are defined by (boost::accumulators 1.6x: tag::mean = sum / n,
+// tag::variance = the iterative update, tag::median = the P-square estimator of Jain & Chlamtac 1985, markers seeded
+// with the first five samples; fewer than five samples report the third slot of the unsorted seed array).
+class RunningStats
+{
+public:
+    void add(double x);
+    double mean() const;      // NaN when empty (written as null)
+    double variance() const;  // 0 when fewer than two samples
+    double median() const;    // 0 when empty
+    size_t count() const { return n_; }
+
+private:
+    size_t n_ = 0;
+    double sum_ = 0, imm_mean_ = 0, var_ = 0;
+    double heights_[5] = { 0, 0, 0, 0, 0 }, actual_[5] = { 1, 2, 3, 4, 5 }, desired_[5] = { 1, 2, 3, 4, 5 };
+};
+
+common::Json fragmentStatistics(graphtools::Graph const& graph, std::vector<common::Read const*> const& reads);
+common::Json alignmentStatistics(graphtools::Graph const& graph, std::vector<common::Read const*> const& reads);
+}  // namespace paragraph

@@ -1,0 +1,102 @@
+// Many-site version of the `paragraph` / `grmpy` per-site loop.
+//
+// The reference handles one (graph, sample) pair at a time: paragraph::Parameters::load -> common::extractReads ->
+// paragraph::alignAndDisambiguate (lib/paragraph/Disambiguation.cpp:152-361), driven per sample and graph by
+// grmpy::alignSingleSample (lib/grmpy/AlignSamples.cpp:115-172) and grmpy::Workflow::alignSamples (Workflow.cpp:108-146),
+// then grmpy::countAndGenotype (CountAndGenotype.cpp:46-88) per graph.  Here read extraction for ALL pairs runs first on
+// host threads (one BamReader per thread), all pairs go through ONE SiteBatcher::run() on the device, and the count
+// documents and genotypes are assembled from the batch results.
+#pragma once
+#include <list>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common/Json.hh"
+#include "common/Read.hh"
+#include "common/ReadReader.hh"
+#include "common/Region.hh"
+#include "genotyping/SampleInfo.hh"
+#include "graphcore/Graph.hh"
+
+namespace paragraph
+{
+// paragraph::Parameters (include/paragraph/Parameters.hh:44-126): what to compute and emit for a site
+struct Parameters
+{
+    enum output_options
+    {
+        ALIGNMENTS = 0x01,
+        FILTERED_ALIGNMENTS = 0x02,  // accepted; filtered reads are tallied, their records are not re-emitted
+        NODE_READ_COUNTS = 0x08,
+        EDGE_READ_COUNTS = 0x10,
+        PATH_READ_COUNTS = 0x20,
+        DETAILED_READ_COUNTS = 0x40,
+        // VARIANTS 0x04, PATH_COVERAGE 0x80, NODE_COVERAGE 0x100, HAPLOTYPES 0x200 are not produced
+    };
+    int max_reads = 10000;
+    float bad_align_frac = 0.8f;
+    int output_options_ = NODE_READ_COUNTS | EDGE_READ_COUNTS | PATH_READ_COUNTS;  // the `paragraph` tool's default
+    bool path_sequence_matching = true;    // `paragraph` default; grmpy turns it off
+    bool graph_sequence_matching = true;
+    bool remove_nonuniq_reads = true;
+    int kmer_len = 0;
+    int threads = 1;  // host threads for read extraction and document assembly
+    bool output_enabled(output_options o) const { return (output_options_ & o) != 0; }
+};
+
+// A loaded graph description (Parameters::load, lib/paragraph/Parameters.cpp:39-90): the document with a "graph" wrapper
+// flattened, its target regions, "max_reads" override and the longest explicit node sequence.
+struct GraphDescription
+{
+    static GraphDescription load(std::string const& graph_path, std::string const& reference_path, std::string const& override_target_regions = "");
+    static GraphDescription fromJson(common::Json root, std::string const& reference_path, std::string const& override_target_regions = "");
+    common::Json description;
+    std::string reference_path;
+    std::list<common::Region> target_regions;
+    size_t longest_alt_insertion = 0;
+    int64_t max_reads = -1;  // < 0: not given
+    std::shared_ptr<graphtools::Graph> graph;
+    std::list<graphtools::Path> paths;
+};
+
+struct SiteInput
+{
+    GraphDescription const* description = nullptr;
+    common::ReadBuffer* reads = nullptr;  // in: extracted reads; out: the reads the document was built from
+};
+
+// One device batch over all sites; returns one count document per site: the description plus "reference",
+// "read_counts_by_node" / "_by_edge" / "_by_sequence", "fragment_statistics", "alignment_statistics" and optionally "alignments".
+std::vector<common::Json> alignAndDisambiguateBatch(Parameters const& parameters, std::vector<SiteInput> const& sites);
+// single-site convenience with the reference's shape
+common::Json alignAndDisambiguate(Parameters const& parameters, GraphDescription const& description, common::ReadBuffer& all_reads);
+}  // namespace paragraph
+
+namespace grmpy
+{
+// grmpy::Parameters (include/grmpy/Parameters.hh:30-74)
+struct Parameters
+{
+    int threads = 1;
+    int max_reads = 10000;
+    float bad_align_frac = 0.8f;
+    bool path_sequence_matching = false;
+    bool graph_sequence_matching = true;
+    int bad_align_uniq_kmer_len = 0;
+    bool output_alignments = false;  // keep "alignments" in the per-sample documents (the original writes them to a folder)
+};
+
+// extraction + alignment + counting of ONE sample against ONE graph; stores the count document in the sample
+void alignSingleSample(
+    Parameters const& parameters, std::string const& graph_path, std::string const& reference_path, common::ReadReader& reader,
+    genotyping::SampleInfo& sample);
+// genotypes of one graph from the samples' count documents (graph_path "" = take the graph from the first sample's document)
+common::Json countAndGenotype(
+    std::string const& graph_path, std::string const& reference_path, std::string const& genotyping_parameter_path,
+    genotyping::Samples const& samples);
+// every graph x every sample in ONE device batch; returns one genotype document per graph, in the order given
+std::vector<common::Json> genotypeGraphs(
+    Parameters const& parameters, std::vector<std::string> const& graph_paths, std::string const& reference_path,
+    genotyping::Samples const& samples, std::string const& genotyping_parameter_path);
+}  // namespace grmpy

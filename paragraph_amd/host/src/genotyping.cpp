@@ -225,6 +225,68 @@ void GenotypingParameters::setGenotypeFractions(const vector<string>& names, con
             genotype_fractions[gt] = other_genotype_fraction;
 }
 
+void GenotypingParameters::setFromJson(common::Json const& doc)
+{
+    if (doc.isMember("min_overlap_bases"))
+        min_overlap_bases = (unsigned)doc["min_overlap_bases"].asUInt64();
+    if (doc.isMember("reference_allele"))
+        reference_allele = doc["reference_allele"].asString();
+    if (doc.isMember("reference_allele_error_rate"))
+        reference_allele_error_rate = doc["reference_allele_error_rate"].asDouble();
+    if (doc.isMember("other_allele_error_rate"))
+        other_allele_error_rate = doc["other_allele_error_rate"].asDouble();
+    if (doc.isMember("other_genotype_fraction"))
+        other_genotype_fraction = doc["other_genotype_fraction"].asDouble();
+    if (doc.isMember("ploidy"))
+        ploidy_ = (unsigned)doc["ploidy"].asInt64();
+    // "het_haplotype_fraction" (singular) only acts when its text form starts with '[', which no JSON number does
+    if (doc.isMember("coverage_test_cutoff"))
+    {
+        common::Json const& cut = doc["coverage_test_cutoff"];
+        if (!cut.isArray() || cut.size() != 2)
+            error("Error: coverage_test_cutoff needs to be a list of 2 values: lower end, upper end.");
+        coverage_test_cutoff.first = cut[(size_t)0].asDouble();
+        coverage_test_cutoff.first = cut[(size_t)1].asDouble();
+    }
+    const bool per_allele = doc.isMember("allele_error_rates") || doc.isMember("het_haplotype_fractions") || doc.isMember("genotype_fractions");
+    if (per_allele)
+    {
+        if (!doc.isMember("allele_names"))
+            error("Error: with allele_error_rates/het_haplotype_fractions/genotype_fractions specified in JSON, allele_names must be "
+                  "specified as well.");
+        vector<string> names;
+        for (auto const& n : doc["allele_names"].elements())
+            names.push_back(n.asString());
+        auto reals = [](common::Json const& arr) {
+            vector<double> out;
+            for (auto const& v : arr.elements())
+                out.push_back(v.asDouble());
+            return out;
+        };
+        if (doc.isMember("allele_error_rates"))
+            setAlleleErrorRates(names, reals(doc["allele_error_rates"]));
+        if (doc.isMember("het_haplotype_fractions"))
+            setHetHaplotypeFractions(names, reals(doc["het_haplotype_fractions"]));
+        if (doc.isMember("genotype_fractions"))
+        {
+            std::map<string, double> fractions;
+            for (auto const& kv : doc["genotype_fractions"].members())
+                fractions[kv.first] = kv.second.asDouble();
+            setGenotypeFractions(names, fractions);
+        }
+    }
+    if (doc.isMember("use_poisson_depth"))
+    {
+        common::Json const& flag = doc["use_poisson_depth"];
+        if (flag.isString() && flag.asString() == "true")
+            use_poisson_depth = true;
+        else if (flag.isString() && flag.asString() == "false")
+            use_poisson_depth = false;
+        else
+            error("In genotyping parameter JSON use_poisson_depth only allows true or false.");
+    }
+}
+
 // --------------------------------------------------------------------------------------------------- BreakpointGenotyper
 BreakpointGenotyper::BreakpointGenotyper(std::unique_ptr<GenotypingParameters> const& param)
     : n_alleles_(param->numAlleles()), ploidy_(param->ploidy()), coverage_test_cutoff_(param->coverageTestCutoff()),

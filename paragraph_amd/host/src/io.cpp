@@ -1,0 +1,953 @@
+// Sample-side input of the host workflow: coordinates, FASTA, BGZF/BAM/BAI, read-pair bookkeeping and per-site read
+// extraction.  Headers under include/common cite the reference interfaces each class mirrors.
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <unordered_map>
+
+#include "common/BamReader.hh"
+#include "common/Fasta.hh"
+#include "common/ReadExtraction.hh"
+#include "common/ReadPairs.hh"
+#include "common/Region.hh"
+
+namespace common
+{
+// ------------------------------------------------------------------------------------------------------------------
+// coordinates
+// ------------------------------------------------------------------------------------------------------------------
+void parsePos(std::string const& text, std::string& chrom, int64_t& start, int64_t& end)
+{
+    // fields are separated by any of " :-"; empty fields are dropped (stringutil::split)
+    std::vector<std::string> fields;
+    std::string cur;
+    for (char c : text)
+    {
+        if (c == ' ' || c == ':' || c == '-')
+        {
+            if (!cur.empty())
+                fields.push_back(cur);
+            cur.clear();
+        }
+        else
+            cur += c;
+    }
+    if (!cur.empty())
+        fields.push_back(cur);
+    auto number = [](std::string s) {
+        s.erase(std::remove(s.begin(), s.end(), ','), s.end());
+        return (int64_t)std::stoll(s);
+    };
+    if (fields.size() >= 1)
+        chrom = fields[0];
+    if (fields.size() >= 2)
+        start = number(fields[1]) - 1;
+    if (fields.size() >= 3)
+        end = number(fields[2]) - 1;
+}
+
+std::string formatPos(std::string const& chrom, int64_t start, int64_t end)
+{
+    std::string out = chrom;
+    if (start >= 0)
+    {
+        out += ":" + std::to_string(start + 1);
+        if (end >= 0)
+            out += "-" + std::to_string(end + 1);
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// FASTA
+// ------------------------------------------------------------------------------------------------------------------
+struct FastaFile::Impl
+{
+    struct Contig
+    {
+        size_t length, offset, line_bases, line_bytes;
+    };
+    std::string filename;
+    mutable std::ifstream in;
+    std::unordered_map<std::string, Contig> contigs;
+    std::vector<std::string> order;
+};
+
+FastaFile::FastaFile(std::string const& path) : impl_(new Impl)
+{
+    impl_->filename = path;
+    impl_->in.open(path, std::ios::binary);
+    if (!impl_->in.good())
+        throw std::runtime_error("Cannot open FASTA file " + path);
+    std::ifstream fai(path + ".fai");
+    if (!fai.good())
+    {
+        // no samtools index next to the file: derive one by scanning (the original indexes on the fly as well)
+        std::string line, name;
+        Impl::Contig c{};
+        bool open = false;
+        size_t at = 0;
+        auto close = [&] {
+            if (open)
+            {
+                impl_->contigs[name] = c;
+                impl_->order.push_back(name);
+            }
+        };
+        while (std::getline(impl_->in, line))
+        {
+            const size_t bytes = line.size() + 1;
+            if (!line.empty() && line.back() == '\r')
+                line.pop_back();
+            if (!line.empty() && line[0] == '>')
+            {
+                close();
+                name = line.substr(1, line.find_first_of(" \t") == std::string::npos ? std::string::npos : line.find_first_of(" \t") - 1);
+                c = Impl::Contig{ 0, at + bytes, 0, 0 };
+                open = true;
+            }
+            else if (open)
+            {
+                if (c.line_bases == 0 && !line.empty())
+                {
+                    c.line_bases = line.size();
+                    c.line_bytes = bytes;
+                }
+                c.length += line.size();
+            }
+            at += bytes;
+        }
+        close();
+        for (auto& kv : impl_->contigs)
+            if (kv.second.line_bases == 0)
+                kv.second.line_bases = kv.second.line_bytes = 1;
+        impl_->in.clear();
+        return;
+    }
+    std::string line;
+    while (std::getline(fai, line))
+    {
+        if (line.empty())
+            continue;
+        std::stringstream ss(line);
+        std::string name;
+        Impl::Contig c{};
+        std::getline(ss, name, '\t');
+        ss >> c.length >> c.offset >> c.line_bases >> c.line_bytes;
+        if (ss.fail() || c.line_bases == 0 || c.line_bytes < c.line_bases)
+            throw std::runtime_error("Malformed FASTA index line: " + line);
+        impl_->contigs[name] = c;
+        impl_->order.push_back(name);
+    }
+}
+
+FastaFile::~FastaFile() = default;
+std::string const& FastaFile::getFilename() const { return impl_->filename; }
+std::vector<std::string> FastaFile::getContigNames() const { return impl_->order; }
+
+size_t FastaFile::contigSize(std::string const& contig) const
+{
+    if (contig.empty())
+    {
+        size_t all = 0;
+        for (auto const& kv : impl_->contigs)
+            all += kv.second.length;
+        return all;
+    }
+    auto it = impl_->contigs.find(contig);
+    if (it == impl_->contigs.end())
+        throw std::runtime_error("Contig " + contig + " is not known");
+    return it->second.length;
+}
+
+std::string FastaFile::query(std::string const& location) const
+{
+    std::string chrom;
+    int64_t start = -1, end = -1;
+    parsePos(location, chrom, start, end);
+    return query(chrom, start, end);
+}
+
+std::string FastaFile::query(std::string const& chrom, int64_t start, int64_t end) const
+{
+    if (end < start)
+        return "";
+    start = std::max<int64_t>(start, 0);
+    auto it = impl_->contigs.find(chrom);
+    if (it == impl_->contigs.end())
+        throw std::runtime_error("Contig " + chrom + " is not known");
+    Impl::Contig const& c = it->second;
+    if ((size_t)start >= c.length)
+        return "";
+    const size_t last = std::min<size_t>((size_t)end, c.length - 1);
+    // bytes [first_byte, last_byte] of the file cover the bases plus the line ends between them
+    const size_t first_byte = c.offset + ((size_t)start / c.line_bases) * c.line_bytes + (size_t)start % c.line_bases;
+    const size_t last_byte = c.offset + (last / c.line_bases) * c.line_bytes + last % c.line_bases;
+    std::string raw(last_byte - first_byte + 1, '\0');
+    impl_->in.clear();
+    impl_->in.seekg((std::streamoff)first_byte);
+    impl_->in.read(&raw[0], (std::streamsize)raw.size());
+    if ((size_t)impl_->in.gcount() != raw.size())
+        throw std::runtime_error("Short read from FASTA file " + impl_->filename);
+    std::string out;
+    out.reserve(last - (size_t)start + 1);
+    for (char ch : raw)
+    {
+        if (ch == '\n' || ch == '\r')
+            continue;
+        char u = (char)toupper((unsigned char)ch);
+        out += (u == 'A' || u == 'C' || u == 'G' || u == 'T') ? u : 'N';
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BGZF: a series of gzip members of <= 64 KiB each; a virtual offset is (file offset of the member << 16) | offset
+// inside its inflated payload (SAM spec 4.1)
+// ------------------------------------------------------------------------------------------------------------------
+namespace
+{
+class Bgzf
+{
+public:
+    explicit Bgzf(std::string const& path) : path_(path)
+    {
+        fp_ = fopen(path.c_str(), "rb");
+        if (!fp_)
+            throw std::runtime_error("ERROR: Failed to open " + path);
+    }
+    ~Bgzf()
+    {
+        if (fp_)
+            fclose(fp_);
+    }
+    Bgzf(Bgzf const&) = delete;
+    Bgzf& operator=(Bgzf const&) = delete;
+
+    void seek(uint64_t voffset)
+    {
+        const uint64_t coff = voffset >> 16;
+        if (!(have_block_ && coff == block_start_))
+            loadBlock(coff);
+        within_ = (size_t)(voffset & 0xFFFF);
+        if (within_ > data_.size())
+            throw std::runtime_error("BGZF: virtual offset beyond block in " + path_);
+    }
+    uint64_t tell()
+    {
+        // a position at the very end of a block is the start of the next one (as bgzf_tell reports after a read)
+        if (have_block_ && within_ == data_.size() && !eof_)
+        {
+            loadBlock(block_start_ + block_csize_);
+            within_ = 0;
+        }
+        return (block_start_ << 16) | (uint64_t)within_;
+    }
+    // returns the number of bytes read (< n only at end of file)
+    size_t read(void* dst, size_t n)
+    {
+        size_t done = 0;
+        while (done < n)
+        {
+            if (!have_block_)
+                loadBlock(0);
+            if (within_ == data_.size())
+            {
+                if (eof_)
+                    break;
+                loadBlock(block_start_ + block_csize_);
+                within_ = 0;
+                continue;
+            }
+            const size_t take = std::min(n - done, data_.size() - within_);
+            memcpy((char*)dst + done, data_.data() + within_, take);
+            within_ += take;
+            done += take;
+        }
+        return done;
+    }
+    void readExact(void* dst, size_t n, const char* what)
+    {
+        if (read(dst, n) != n)
+            throw std::runtime_error(std::string("Truncated BAM (") + what + ") in " + path_);
+    }
+
+private:
+    void loadBlock(uint64_t coff)
+    {
+        have_block_ = true;
+        block_start_ = coff;
+        block_csize_ = 0;
+        data_.clear();
+        within_ = 0;
+        if (fseeko(fp_, (off_t)coff, SEEK_SET) != 0)
+            throw std::runtime_error("BGZF: seek failed in " + path_);
+        unsigned char hdr[12];
+        const size_t got = fread(hdr, 1, sizeof hdr, fp_);
+        if (got == 0)
+        {
+            eof_ = true;
+            return;
+        }
+        if (got != sizeof hdr || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4))
+            throw std::runtime_error("BGZF: bad block header in " + path_);
+        const unsigned xlen = hdr[10] | (hdr[11] << 8);
+        std::vector<unsigned char> extra(xlen);
+        if (fread(extra.data(), 1, xlen, fp_) != xlen)
+            throw std::runtime_error("BGZF: truncated block header in " + path_);
+        int bsize = -1;
+        for (size_t i = 0; i + 4 <= xlen;)
+        {
+            const unsigned slen = extra[i + 2] | (extra[i + 3] << 8);
+            if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2 && i + 6 <= xlen)
+                bsize = extra[i + 4] | (extra[i + 5] << 8);
+            i += 4 + slen;
+        }
+        if (bsize < 0)
+            throw std::runtime_error("BGZF: block without BC field in " + path_);
+        block_csize_ = (uint64_t)bsize + 1;
+        const size_t cdata_len = block_csize_ - 12 - xlen - 8;
+        std::vector<unsigned char> cdata(cdata_len + 8);
+        if (fread(cdata.data(), 1, cdata.size(), fp_) != cdata.size())
+            throw std::runtime_error("BGZF: truncated block in " + path_);
+        const unsigned char* tail = cdata.data() + cdata_len;
+        const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        data_.resize(isize);
+        if (isize)
+        {
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK)
+                throw std::runtime_error("BGZF: inflateInit2 failed");
+            zs.next_in = cdata.data();
+            zs.avail_in = (uInt)cdata_len;
+            zs.next_out = data_.data();
+            zs.avail_out = (uInt)isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.avail_out != 0)
+                throw std::runtime_error("BGZF: inflate failed in " + path_);
+            const uint32_t want_crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
+            if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), data_.data(), (uInt)isize) != want_crc)
+                throw std::runtime_error("BGZF: CRC mismatch in " + path_);
+        }
+        eof_ = false;
+    }
+
+    std::string path_;
+    FILE* fp_ = nullptr;
+    bool have_block_ = false, eof_ = false;
+    uint64_t block_start_ = 0, block_csize_ = 0;
+    std::vector<unsigned char> data_;
+    size_t within_ = 0;
+};
+
+inline uint32_t le32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint64_t le64(const unsigned char* p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
+
+struct Chunk
+{
+    uint64_t beg, end;
+};
+
+struct RefIndex
+{
+    std::unordered_map<uint32_t, std::vector<Chunk>> bins;
+    std::vector<uint64_t> linear;  // smallest virtual offset of a record overlapping each 16 kbp window
+};
+
+// the UCSC binning scheme of the BAI (SAM spec 5.3): all bins a query [beg, end) can have records in
+void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t>& bins)
+{
+    --end;
+    bins.push_back(0);
+    for (int level = 1, shift = 26, first = 1; level <= 5; ++level, shift -= 3)
+    {
+        for (int64_t k = first + (beg >> shift); k <= first + (end >> shift); ++k)
+            bins.push_back((uint32_t)k);
+        first += 1 << (3 * level);
+    }
+}
+
+struct BamRecord
+{
+    int32_t tid = -1, pos = -1, mtid = -1, mpos = -1;
+    uint16_t flag = 0;
+    uint8_t mapq = 0;
+    int64_t end_pos = 0;  // pos + reference span of the CIGAR, at least pos + 1 (bam_endpos)
+    std::string name, bases, quals;
+};
+
+struct RegionCursor
+{
+    bool valid = false;
+    int32_t tid = -1;
+    int64_t beg = 0, end = 0;
+    std::vector<Chunk> chunks;
+    size_t chunk = 0;
+    uint64_t at = 0;  // virtual offset of the next record to look at
+    bool started = false, finished = true;
+};
+}  // namespace
+
+struct BamReader::Impl
+{
+    std::string path, index_path, reference;
+    std::unique_ptr<Bgzf> bgzf;
+    std::string header_text;
+    std::vector<std::string> names;
+    std::vector<int64_t> lengths;
+    std::unordered_map<std::string, int> tid_of;
+    std::vector<RefIndex> index;
+    RegionCursor cursor;
+    std::vector<unsigned char> scratch;
+
+    void open();
+    void loadIndex();
+    bool readRecord(BamRecord& rec);
+    RegionCursor query(int32_t tid, int64_t beg, int64_t end) const;
+    bool next(RegionCursor& cur, BamRecord& rec);
+};
+
+namespace
+{
+bool fileExists(std::string const& p)
+{
+    std::ifstream f(p);
+    return f.good();
+}
+
+void toRead(BamRecord const& rec, Read& read)
+{
+    read.set_fragment_id(rec.name);
+    read.set_bases(rec.bases);
+    read.set_quals(rec.quals);
+    read.set_is_mapped((rec.flag & BamReader::kIsMapped) == 0);
+    read.set_is_first_mate((rec.flag & BamReader::kIsFirstMate) != 0);
+    read.set_is_mate_mapped((rec.flag & BamReader::kIsMateMapped) == 0);
+    read.set_is_reverse_strand((rec.flag & 0x10) != 0);
+    read.set_is_mate_reverse_strand((rec.flag & 0x20) != 0);
+    read.set_chrom_id(rec.tid);
+    read.set_pos(rec.pos);
+    read.set_mapq(rec.mapq);
+    read.set_mate_chrom_id(rec.mtid);
+    read.set_mate_pos(rec.mpos);
+}
+}  // namespace
+
+void BamReader::Impl::open()
+{
+    bgzf.reset(new Bgzf(path));
+    unsigned char b[8];
+    bgzf->readExact(b, 4, "magic");
+    if (memcmp(b, "BAM\1", 4) != 0)
+    {
+        if (memcmp(b, "CRAM", 4) == 0)
+            throw std::runtime_error("ERROR: CRAM input is not supported by this reader: " + path);
+        throw std::runtime_error("ERROR: Unknown alignment file format.");
+    }
+    bgzf->readExact(b, 4, "header length");
+    header_text.resize(le32(b));
+    if (!header_text.empty())
+        bgzf->readExact(&header_text[0], header_text.size(), "header text");
+    bgzf->readExact(b, 4, "reference count");
+    const uint32_t n_ref = le32(b);
+    for (uint32_t i = 0; i < n_ref; ++i)
+    {
+        bgzf->readExact(b, 4, "reference name length");
+        std::string name(le32(b), '\0');
+        if (!name.empty())
+            bgzf->readExact(&name[0], name.size(), "reference name");
+        while (!name.empty() && name.back() == '\0')
+            name.pop_back();
+        bgzf->readExact(b, 4, "reference length");
+        tid_of[name] = (int)i;
+        names.push_back(name);
+        lengths.push_back((int64_t)le32(b));
+    }
+    loadIndex();
+}
+
+void BamReader::Impl::loadIndex()
+{
+    std::string use = index_path;
+    if (use.empty())
+    {
+        use = path + ".bai";
+        if (!fileExists(use) && path.size() > 4 && path.compare(path.size() - 4, 4, ".bam") == 0)
+            use = path.substr(0, path.size() - 4) + ".bai";
+    }
+    std::ifstream in(use, std::ios::binary);
+    if (!in.good())
+        throw std::runtime_error("ERROR: Failed to read index of " + path);
+    std::vector<unsigned char> buf((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    size_t at = 0;
+    auto need = [&](size_t n) {
+        if (at + n > buf.size())
+            throw std::runtime_error("ERROR: Truncated index " + use);
+    };
+    need(8);
+    if (memcmp(buf.data(), "BAI\1", 4) != 0)
+        throw std::runtime_error("ERROR: " + use + " is not a BAI index");
+    const uint32_t n_ref = le32(buf.data() + 4);
+    at = 8;
+    index.resize(n_ref);
+    for (uint32_t r = 0; r < n_ref; ++r)
+    {
+        need(4);
+        const uint32_t n_bin = le32(buf.data() + at);
+        at += 4;
+        for (uint32_t bi = 0; bi < n_bin; ++bi)
+        {
+            need(8);
+            const uint32_t bin = le32(buf.data() + at);
+            const uint32_t n_chunk = le32(buf.data() + at + 4);
+            at += 8;
+            need((size_t)n_chunk * 16);
+            if (bin != 37450)  // the pseudo-bin holds statistics, not chunks
+            {
+                auto& chunks = index[r].bins[bin];
+                for (uint32_t c = 0; c < n_chunk; ++c)
+                    chunks.push_back(Chunk{ le64(buf.data() + at + c * 16), le64(buf.data() + at + c * 16 + 8) });
+            }
+            at += (size_t)n_chunk * 16;
+        }
+        need(4);
+        const uint32_t n_intv = le32(buf.data() + at);
+        at += 4;
+        need((size_t)n_intv * 8);
+        index[r].linear.resize(n_intv);
+        for (uint32_t i = 0; i < n_intv; ++i)
+            index[r].linear[i] = le64(buf.data() + at + (size_t)i * 8);
+        at += (size_t)n_intv * 8;
+    }
+}
+
+bool BamReader::Impl::readRecord(BamRecord& rec)
+{
+    unsigned char b4[4];
+    const size_t got = bgzf->read(b4, 4);
+    if (got == 0)
+        return false;
+    if (got != 4)
+        throw std::runtime_error("Truncated BAM (record length) in " + path);
+    const uint32_t block_size = le32(b4);
+    if (block_size < 32)
+        throw std::runtime_error("Corrupt BAM record in " + path);
+    scratch.resize(block_size);
+    bgzf->readExact(scratch.data(), block_size, "record");
+    const unsigned char* p = scratch.data();
+    rec.tid = (int32_t)le32(p);
+    rec.pos = (int32_t)le32(p + 4);
+    const uint32_t l_name = p[8];
+    rec.mapq = p[9];
+    const uint32_t n_cigar = p[12] | (p[13] << 8);
+    rec.flag = (uint16_t)(p[14] | (p[15] << 8));
+    const uint32_t l_seq = le32(p + 16);
+    rec.mtid = (int32_t)le32(p + 20);
+    rec.mpos = (int32_t)le32(p + 24);
+    size_t at = 32;
+    if (at + l_name + (size_t)n_cigar * 4 + (l_seq + 1) / 2 + l_seq > block_size)
+        throw std::runtime_error("Corrupt BAM record in " + path);
+    rec.name.assign((const char*)p + at, l_name ? l_name - 1 : 0);
+    at += l_name;
+    int64_t ref_span = 0;
+    for (uint32_t c = 0; c < n_cigar; ++c)
+    {
+        const uint32_t op = le32(p + at + (size_t)c * 4);
+        const uint32_t kind = op & 0xF;
+        if (kind == 0 || kind == 2 || kind == 3 || kind == 7 || kind == 8)  // M D N = X consume the reference
+            ref_span += op >> 4;
+    }
+    if ((rec.flag & 4) || n_cigar == 0)
+        ref_span = 0;
+    rec.end_pos = (int64_t)rec.pos + (ref_span > 0 ? ref_span : 1);
+    at += (size_t)n_cigar * 4;
+    static const char kBases[] = "=ACMGRSVTWYHKDBN";
+    rec.bases.resize(l_seq);
+    for (uint32_t i = 0; i < l_seq; ++i)
+    {
+        const unsigned char packed = p[at + i / 2];
+        rec.bases[i] = kBases[(i & 1) ? (packed & 0xF) : (packed >> 4)];
+    }
+    at += (l_seq + 1) / 2;
+    rec.quals.resize(l_seq);
+    for (uint32_t i = 0; i < l_seq; ++i)
+        rec.quals[i] = (char)(33 + p[at + i]);  // 0xFF ("no qualities") wraps like the uint8 -> char cast it mirrors
+    return true;
+}
+
+RegionCursor BamReader::Impl::query(int32_t tid, int64_t beg, int64_t end) const
+{
+    RegionCursor cur;
+    if (tid < 0 || (size_t)tid >= names.size())
+        return cur;
+    cur.valid = true;
+    cur.tid = tid;
+    cur.beg = std::max<int64_t>(beg, 0);
+    cur.end = std::max(end, cur.beg);
+    cur.finished = false;
+    if ((size_t)tid >= index.size() || cur.end <= cur.beg)
+    {
+        cur.finished = true;
+        return cur;
+    }
+    RefIndex const& ri = index[(size_t)tid];
+    // records overlapping window beg >> 14 start at or after this offset; a 0 entry (empty window) just disables the cut
+    uint64_t min_off = 0;
+    if (!ri.linear.empty())
+        min_off = ri.linear[std::min((size_t)(cur.beg >> 14), ri.linear.size() - 1)];
+    const int64_t end_clamped = std::min<int64_t>(cur.end, (int64_t)1 << 29);
+    std::vector<uint32_t> bins;
+    reg2bins(std::min<int64_t>(cur.beg, ((int64_t)1 << 29) - 1), std::max<int64_t>(end_clamped, 1), bins);
+    for (uint32_t bin : bins)
+    {
+        auto it = ri.bins.find(bin);
+        if (it == ri.bins.end())
+            continue;
+        for (Chunk const& c : it->second)
+        {
+            if (c.end > min_off)
+                cur.chunks.push_back(c);
+        }
+    }
+    std::sort(cur.chunks.begin(), cur.chunks.end(), [](Chunk const& a, Chunk const& b) { return a.beg < b.beg; });
+    std::vector<Chunk> merged;
+    for (Chunk const& c : cur.chunks)
+    {
+        if (!merged.empty() && c.beg <= merged.back().end)
+            merged.back().end = std::max(merged.back().end, c.end);
+        else
+            merged.push_back(c);
+    }
+    cur.chunks.swap(merged);
+    if (cur.chunks.empty())
+        cur.finished = true;
+    return cur;
+}
+
+bool BamReader::Impl::next(RegionCursor& cur, BamRecord& rec)
+{
+    while (!cur.finished)
+    {
+        if (!cur.started)
+        {
+            cur.at = cur.chunks[cur.chunk].beg;
+            cur.started = true;
+        }
+        if (cur.at >= cur.chunks[cur.chunk].end)
+        {
+            if (++cur.chunk == cur.chunks.size())
+            {
+                cur.finished = true;
+                break;
+            }
+            cur.at = std::max(cur.at, cur.chunks[cur.chunk].beg);
+            continue;
+        }
+        bgzf->seek(cur.at);
+        if (!readRecord(rec))
+        {
+            cur.finished = true;
+            break;
+        }
+        cur.at = bgzf->tell();
+        if (rec.tid != cur.tid || (int64_t)rec.pos >= cur.end)
+        {
+            cur.finished = true;  // coordinate-sorted: nothing further can overlap
+            break;
+        }
+        if (rec.end_pos > cur.beg)
+            return true;
+    }
+    return false;
+}
+
+BamReader::BamReader(const std::string& path, const std::string& index_path, const std::string& reference) : impl_(new Impl)
+{
+    auto must_exist = [](std::string const& p) {
+        if (!fileExists(p))
+            throw std::runtime_error("ERROR: File " + p + " does not exist");
+    };
+    must_exist(path);
+    if (!index_path.empty())
+        must_exist(index_path);
+    if (!reference.empty())
+    {
+        must_exist(reference);
+        must_exist(reference + ".fai");
+    }
+    impl_->path = path;
+    impl_->index_path = index_path;
+    impl_->reference = reference;
+    impl_->open();
+}
+
+BamReader::~BamReader() = default;
+BamReader::BamReader(BamReader&&) noexcept = default;
+BamReader& BamReader::operator=(BamReader&&) noexcept = default;
+std::vector<std::string> const& BamReader::contigNames() const { return impl_->names; }
+std::vector<int64_t> const& BamReader::contigLengths() const { return impl_->lengths; }
+std::string const& BamReader::headerText() const { return impl_->header_text; }
+
+void BamReader::setRegion(const std::string& region_encoding)
+{
+    // hts_parse_reg: the text after the last ':' is "beg[-end]" with thousands separators allowed; a name that matches a
+    // contig as a whole wins (contig names may hold ':')
+    std::string name = region_encoding;
+    int64_t beg = 0, end = (int64_t)1 << 29;
+    auto whole = impl_->tid_of.find(region_encoding);
+    if (whole == impl_->tid_of.end())
+    {
+        const size_t colon = region_encoding.rfind(':');
+        if (colon != std::string::npos)
+        {
+            name = region_encoding.substr(0, colon);
+            std::string range = region_encoding.substr(colon + 1);
+            range.erase(std::remove(range.begin(), range.end(), ','), range.end());
+            char* e = nullptr;
+            const long long b = strtoll(range.c_str(), &e, 10);
+            beg = b > 0 ? b - 1 : 0;
+            if (*e == '-')
+            {
+                const long long en = strtoll(e + 1, &e, 10);
+                end = en;
+            }
+            if (end < beg)
+                end = beg;  // empty interval
+        }
+    }
+    auto it = impl_->tid_of.find(name);
+    if (it == impl_->tid_of.end())
+        throw std::runtime_error("Failed to jump to " + region_encoding + " in " + impl_->path);
+    impl_->cursor = impl_->query(it->second, beg, end);
+}
+
+bool BamReader::getAlign(Read& read)
+{
+    if (!impl_->cursor.valid)
+        throw std::logic_error("Error: no region has been set on " + impl_->path);
+    BamRecord rec;
+    while (impl_->next(impl_->cursor, rec))
+    {
+        if (rec.flag & (kSupplementaryAlign | kSecondaryAlign))
+            continue;
+        toRead(rec, read);
+        return true;
+    }
+    return false;
+}
+
+bool BamReader::getAlignedMate(const Read& read, Read& mate)
+{
+    const int32_t tid = read.is_mate_mapped() ? read.mate_chrom_id() : read.chrom_id();
+    const int32_t beg = read.is_mate_mapped() ? read.mate_pos() : read.pos();
+    RegionCursor cur = impl_->query(tid, beg, (int64_t)beg + 1);
+    if (!cur.valid)
+        return false;
+    BamRecord rec;
+    // like the original, `mate` is overwritten by every candidate looked at, also when none matches
+    while (impl_->next(cur, rec))
+    {
+        toRead(rec, mate);
+        if (mate.fragment_id() == read.fragment_id() && mate.is_first_mate() != read.is_first_mate())
+            return true;
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// read pairs and extraction
+// ------------------------------------------------------------------------------------------------------------------
+void ReadPairs::add(const Read& read)
+{
+    ReadPair& mates = pairs_[read.fragment_id()];
+    const int before = mates.numInitialized();
+    mates.add(read);
+    num_reads_ += mates.numInitialized() - before;
+}
+
+const ReadPair& ReadPairs::operator[](const std::string& fragment_id) const
+{
+    auto it = pairs_.find(fragment_id);
+    if (it == pairs_.end())
+        throw std::runtime_error("Fragment " + fragment_id + " does not exist");
+    return it->second;
+}
+
+void ReadPairs::getReads(std::vector<Read>& reads) const
+{
+    for (auto const& kv : pairs_)
+    {
+        if (kv.second.first_mate().is_initialized())
+            reads.push_back(kv.second.first_mate());
+        if (kv.second.second_mate().is_initialized())
+            reads.push_back(kv.second.second_mate());
+    }
+}
+
+void ReadPairs::getReads(std::vector<p_Read>& reads) const
+{
+    for (auto const& kv : pairs_)
+    {
+        if (kv.second.first_mate().is_initialized())
+            reads.emplace_back(new Read(kv.second.first_mate()));
+        if (kv.second.second_mate().is_initialized())
+            reads.emplace_back(new Read(kv.second.second_mate()));
+    }
+}
+
+void ReadPairs::clear()
+{
+    pairs_.clear();
+    num_reads_ = 0;
+}
+
+bool isReadOrItsMateInRegion(Read& read, const Region& region)
+{
+    // the mate's extent is not known from this record; the read's own length stands in for it
+    const int64_t len = (int64_t)read.bases().length();
+    auto touches = [&](int64_t pos) { return !(pos > region.end || pos + len < region.start); };
+    if (touches(read.pos()))
+        return true;
+    return read.chrom_id() == read.mate_chrom_id() && touches(read.mate_pos());
+}
+
+int extractMappedReadsFromRegion(ReadPairs& read_pairs, int max_num_reads, ReadReader& reader, const Region& region)
+{
+    Read read;
+    unsigned total_length = 0, counted = 0;
+    while (read_pairs.num_reads() != max_num_reads && reader.getAlign(read))
+    {
+        if (!read.bases().empty())
+        {
+            total_length += (unsigned)read.bases().length();
+            ++counted;
+        }
+        if (isReadOrItsMateInRegion(read, region))
+            read_pairs.add(read);
+    }
+    return counted ? (int)(total_length / counted) : 0;
+}
+
+void recoverMissingMates(ReadReader& reader, ReadPairs& read_pairs)
+{
+    // collected first: adding to the map while walking it is only safe because a recovered mate lands in an existing
+    // entry, but collecting keeps that assumption out of the loop
+    std::vector<Read> lonely;
+    for (auto const& kv : read_pairs)
+    {
+        ReadPair const& pair = kv.second;
+        if (pair.first_mate().is_initialized() && pair.second_mate().is_initialized())
+            continue;
+        Read const& have = pair.first_mate().is_initialized() ? pair.first_mate() : pair.second_mate();
+        const int kMaxNormalDistanceBetweenMates = 1000;
+        if (have.chrom_id() == have.mate_chrom_id() && std::abs(have.pos() - have.mate_pos()) < kMaxNormalDistanceBetweenMates)
+            continue;  // the scan window would have held a mate this close
+        lonely.push_back(have);
+    }
+    for (Read const& have : lonely)
+    {
+        Read mate;
+        reader.getAlignedMate(have, mate);
+        if (mate.is_initialized())
+            read_pairs.add(mate);
+    }
+}
+
+std::pair<int, int> extractReadsFromRegion(
+    std::vector<p_Read>& all_reads, int max_num_reads, ReadReader& reader, const Region& region, unsigned longest_alt_insertion,
+    int avr_fragment_length)
+{
+    reader.setRegion(region.getExtendedRegion((int64_t)avr_fragment_length * 3));
+    ReadPairs read_pairs;
+    const unsigned read_length = (unsigned)extractMappedReadsFromRegion(read_pairs, max_num_reads, reader, region);
+    std::pair<int, int> extracted(read_pairs.num_reads(), 0);
+    if (max_num_reads != read_pairs.num_reads() && read_length <= longest_alt_insertion * 2)
+    {
+        recoverMissingMates(reader, read_pairs);
+        extracted.second = read_pairs.num_reads() - extracted.first;
+    }
+    read_pairs.getReads(all_reads);
+    return extracted;
+}
+
+void extractReads(
+    ReadReader& reader, std::list<Region> const& target_regions, int max_num_reads, unsigned longest_alt_insertion,
+    std::vector<p_Read>& all_reads, int avr_fragment_length)
+{
+    for (Region const& region : target_regions)
+        extractReadsFromRegion(all_reads, max_num_reads, reader, region, longest_alt_insertion, avr_fragment_length);
+}
+
+void extractReads(
+    const std::string& bam_path, const std::string& bam_index_path, const std::string& reference_path,
+    std::list<Region> const& target_regions, int max_num_reads, unsigned longest_alt_insertion, std::vector<p_Read>& all_reads,
+    int avr_fragment_length)
+{
+    BamReader reader(bam_path, bam_index_path, reference_path);
+    extractReads(reader, target_regions, max_num_reads, longest_alt_insertion, all_reads, avr_fragment_length);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Read -> "alignments" entry
+// ------------------------------------------------------------------------------------------------------------------
+Json Read::toJson() const
+{
+    Json v = Json::object();
+    auto text = [&](const char* key, std::string const& s) {
+        if (!s.empty())
+            v[key] = s;
+    };
+    auto number = [&](const char* key, int64_t n) {
+        if (n)
+            v[key] = n;
+    };
+    auto flag = [&](const char* key, bool b) {
+        if (b)
+            v[key] = true;
+    };
+    auto list = [&](const char* key, std::vector<std::string> const& items) {
+        if (items.empty())
+            return;
+        Json arr = Json::array();
+        for (auto const& s : items)
+            arr.append(s);
+        v[key] = arr;
+    };
+    text("fragmentId", fragment_id_);
+    text("bases", bases_);
+    text("quals", quals_);
+    number("chromId", chrom_id_);
+    number("pos", pos_);
+    number("mapq", mapq_);
+    flag("isReverseStrand", is_reverse_strand_);
+    flag("isMateReverseStrand", is_mate_reverse_strand_);
+    flag("isMapped", is_mapped_);
+    flag("isFirstMate", is_first_mate_);
+    flag("isMateMapped", is_mate_mapped_);
+    number("mateChromId", mate_chrom_id_);
+    number("matePos", mate_pos_);
+    number("graphPos", graph_pos_);
+    text("graphCigar", graph_cigar_);
+    number("graphMapq", graph_mapq_);
+    number("graphAlignmentScore", graph_alignment_score_);
+    flag("isGraphAlignmentUnique", is_graph_alignment_unique_);
+    flag("isGraphReverseStrand", is_graph_reverse_strand_);
+    list("graphNodesSupported", nodes_);
+    list("graphEdgesSupported", edges_);
+    list("graphSequencesSupported", sequences_);
+    if (status_ == BAD_ALIGN)
+        v["graphMappingStatus"] = "BAD_ALIGN";
+    else if (status_ == MAPPED)
+        v["graphMappingStatus"] = "MAPPED";
+    return v;
+}
+}  // namespace common

@@ -1,0 +1,558 @@
+// paragraph::alignAndDisambiguateBatch / grmpy::genotypeGraphs -- see include/paragraph/Workflow.hh.
+#include "paragraph/Workflow.hh"
+
+#include <algorithm>
+#include <atomic>
+#include <map>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+#include <thread>
+#include <unordered_map>
+
+#include "common/BamReader.hh"
+#include "common/ReadExtraction.hh"
+#include "genotyping/BreakpointStatistics.hh"
+#include "genotyping/GraphBreakpointGenotyper.hh"
+#include "grm/GraphInput.hh"
+#include "paragraph/SiteBatcher.hh"
+#include "paragraph/Statistics.hh"
+
+using common::Json;
+
+namespace
+{
+// run fn(i) for i in [0, n) on up to `threads` host threads; the first exception is rethrown on the caller
+template <typename Fn> void parallelFor(size_t n, int threads, Fn fn)
+{
+    const size_t workers = std::max<size_t>(1, std::min<size_t>((size_t)std::max(threads, 1), n));
+    if (workers == 1)
+    {
+        for (size_t i = 0; i < n; ++i)
+            fn(i);
+        return;
+    }
+    std::atomic<size_t> next(0);
+    std::exception_ptr failure;
+    std::atomic<bool> failed(false);
+    std::vector<std::thread> pool;
+    for (size_t w = 0; w < workers; ++w)
+        pool.emplace_back([&] {
+            for (;;)
+            {
+                const size_t i = next.fetch_add(1);
+                if (i >= n || failed.load())
+                    return;
+                try
+                {
+                    fn(i);
+                }
+                catch (...)
+                {
+                    if (!failed.exchange(true))
+                        failure = std::current_exception();
+                    return;
+                }
+            }
+        });
+    for (auto& t : pool)
+        t.join();
+    if (failure)
+        std::rethrow_exception(failure);
+}
+}  // namespace
+
+namespace paragraph
+{
+GraphDescription GraphDescription::load(std::string const& graph_path, std::string const& reference_path, std::string const& override_target_regions)
+{
+    return fromJson(Json::parseFile(graph_path), reference_path, override_target_regions);
+}
+
+GraphDescription GraphDescription::fromJson(Json root, std::string const& reference_path, std::string const& override_target_regions)
+{
+    GraphDescription d;
+    d.reference_path = reference_path;
+    if (root.isMember("graph"))
+    {
+        const Json inner = root["graph"];
+        for (auto const& kv : inner.members())
+            root[kv.first] = kv.second;
+        root.removeMember("graph");
+    }
+    if (!override_target_regions.empty())
+    {
+        std::stringstream ss(override_target_regions);
+        std::string piece;
+        while (std::getline(ss, piece, ','))  // stringutil::split's default separators: space and comma
+        {
+            std::stringstream words(piece);
+            std::string word;
+            while (words >> word)
+                d.target_regions.emplace_back(word);
+        }
+    }
+    else
+    {
+        if (!root["target_regions"].isArray())
+            throw std::runtime_error("Graph description is missing \"target_regions\" key.");
+        for (Json const& r : root["target_regions"].elements())
+            d.target_regions.emplace_back(r.asString());
+    }
+    if (root.isMember("max_reads"))
+        d.max_reads = (int64_t)root["max_reads"].asUInt64();
+    for (Json const& node : root["nodes"].elements())
+        if (node.isMember("sequence"))
+            d.longest_alt_insertion = std::max(d.longest_alt_insertion, node["sequence"].asString().size());
+    d.graph = std::make_shared<graphtools::Graph>(grm::graphFromJson(root, reference_path));
+    d.paths = grm::pathsFromJson(d.graph.get(), root["paths"]);
+    d.description = std::move(root);
+    return d;
+}
+
+namespace
+{
+Json countsToJson(std::map<std::string, CountEntry> const& table)
+{
+    Json out = Json::object();
+    for (auto const& kv : table)
+    {
+        out[kv.first] = kv.second.count;
+        out[kv.first + ":READS"] = kv.second.reads;
+        out[kv.first + ":FWD"] = kv.second.fwd;
+        out[kv.first + ":REV"] = kv.second.rev;
+    }
+    return out;
+}
+
+// per-fragment support sets, needed for the per-family node / edge breakdown (countPathFamilies with `detailed`,
+// ReadCounting.cpp:96-127); the family totals themselves come from the device tables
+struct FragmentSupport
+{
+    uint64_t reads = 0, fwd = 0, rev = 0;
+    std::set<std::string> nodes, edges, sequences;
+};
+
+void addDetailedCounts(Json& by_sequence, common::ReadBuffer const& reads)
+{
+    std::vector<std::string> order;
+    std::unordered_map<std::string, FragmentSupport> fragments;
+    for (auto const& read : reads)
+    {
+        auto it = fragments.find(read->fragment_id());
+        if (it == fragments.end())
+        {
+            it = fragments.emplace(read->fragment_id(), FragmentSupport()).first;
+            order.push_back(read->fragment_id());
+        }
+        FragmentSupport& f = it->second;
+        ++f.reads;
+        if (read->graph_mapping_status() == common::Read::MAPPED)
+            ++(read->is_graph_reverse_strand() ? f.rev : f.fwd);
+        f.nodes.insert(read->graph_nodes_supported().begin(), read->graph_nodes_supported().end());
+        f.edges.insert(read->graph_edges_supported().begin(), read->graph_edges_supported().end());
+        f.sequences.insert(read->graph_sequences_supported().begin(), read->graph_sequences_supported().end());
+    }
+    auto bump = [](Json& table, std::string const& key, FragmentSupport const& f) {
+        table[key] = table[key].asUInt64() + 1;
+        table[key + ":READS"] = table[key + ":READS"].asUInt64() + f.reads;
+        table[key + ":FWD"] = table[key + ":FWD"].asUInt64() + f.fwd;
+        table[key + ":REV"] = table[key + ":REV"].asUInt64() + f.rev;
+    };
+    for (auto const& id : order)
+    {
+        FragmentSupport const& f = fragments[id];
+        if (f.sequences.empty())
+            continue;
+        std::string family;
+        for (auto const& s : f.sequences)
+            family += (family.empty() ? "" : ",") + s;
+        Json& table = by_sequence[family];
+        for (auto const& n : f.nodes)
+            bump(table, n, f);
+        for (auto const& e : f.edges)
+            bump(table, e, f);
+    }
+}
+}  // namespace
+
+std::vector<Json> alignAndDisambiguateBatch(Parameters const& parameters, std::vector<SiteInput> const& sites)
+{
+    if (!parameters.graph_sequence_matching)
+        throw std::runtime_error("alignAndDisambiguateBatch: the gssw stage cannot be switched off in the batched workflow");
+    SiteBatcher batcher;
+    std::vector<size_t> reads_in(sites.size());
+    for (size_t s = 0; s < sites.size(); ++s)
+    {
+        if (!sites[s].description || !sites[s].reads)
+            throw std::runtime_error("alignAndDisambiguateBatch: site without description or reads");
+        reads_in[s] = sites[s].reads->size();
+        batcher.addSite(sites[s].description->graph.get(), sites[s].reads);
+    }
+    BatchParameters bp;
+    bp.remove_nonuniq_reads = parameters.remove_nonuniq_reads;
+    bp.bad_align_frac = parameters.bad_align_frac;
+    bp.kmer_len = parameters.kmer_len;
+    bp.path_sequence_matching = parameters.path_sequence_matching;
+    if (!sites.empty())
+        batcher.run(bp);
+
+    std::vector<Json> documents(sites.size());
+    parallelFor(sites.size(), parameters.threads, [&](size_t s) {
+        GraphDescription const& d = *sites[s].description;
+        common::ReadBuffer const& reads = *sites[s].reads;
+        SiteCounts const& counts = batcher.counts(s);
+        Json out = d.description;
+        out["reference"] = d.reference_path;
+        std::vector<common::Read const*> view;
+        view.reserve(reads.size());
+        for (auto const& r : reads)
+            view.push_back(r.get());
+        out["fragment_statistics"] = fragmentStatistics(*d.graph, view);
+        if (parameters.output_enabled(Parameters::NODE_READ_COUNTS))
+            out["read_counts_by_node"] = countsToJson(counts.by_node);
+        if (parameters.output_enabled(Parameters::EDGE_READ_COUNTS))
+            out["read_counts_by_edge"] = countsToJson(counts.by_edge);
+        if (parameters.output_enabled(Parameters::PATH_READ_COUNTS))
+        {
+            Json families = Json::object();
+            for (auto const& kv : counts.by_sequence)
+            {
+                Json total = Json::object();
+                total["total"] = kv.second.count;
+                total["total:READS"] = kv.second.reads;
+                total["total:FWD"] = kv.second.fwd;
+                total["total:REV"] = kv.second.rev;
+                families[kv.first] = total;
+            }
+            if (parameters.output_enabled(Parameters::DETAILED_READ_COUNTS))
+                addDetailedCounts(families, reads);
+            out["read_counts_by_sequence"] = families;
+        }
+        Json stats = alignmentStatistics(*d.graph, view);
+        // the filter tallies only exist when filtered alignments are asked for (Disambiguation.cpp:177-199, 333-346)
+        const bool tally = parameters.output_enabled(Parameters::FILTERED_ALIGNMENTS);
+        stats["bad_alignment_pct"] = (tally && reads_in[s]) ? (double)counts.bad_align / (double)reads_in[s] : 0.0;
+        if (tally && counts.bad_align)
+            stats["read_filter_bad_align"] = counts.bad_align;
+        if (tally && counts.nonuniq)
+            stats["read_filter_nonuniq"] = counts.nonuniq;
+        out["alignment_statistics"] = stats;
+        if (parameters.output_enabled(Parameters::ALIGNMENTS))
+        {
+            Json alignments = Json::array();
+            for (auto const& r : reads)
+                alignments.append(r->toJson());
+            out["alignments"] = alignments;
+        }
+        documents[s] = std::move(out);
+    });
+    return documents;
+}
+
+Json alignAndDisambiguate(Parameters const& parameters, GraphDescription const& description, common::ReadBuffer& all_reads)
+{
+    std::vector<SiteInput> one(1);
+    one[0].description = &description;
+    one[0].reads = &all_reads;
+    return alignAndDisambiguateBatch(parameters, one)[0];
+}
+}  // namespace paragraph
+
+namespace grmpy
+{
+namespace
+{
+paragraph::Parameters siteParameters(Parameters const& p)
+{
+    paragraph::Parameters sp;
+    sp.max_reads = p.max_reads;
+    sp.bad_align_frac = p.bad_align_frac;
+    sp.path_sequence_matching = p.path_sequence_matching;
+    sp.graph_sequence_matching = p.graph_sequence_matching;
+    sp.kmer_len = p.bad_align_uniq_kmer_len;
+    sp.threads = p.threads;
+    sp.output_options_ = paragraph::Parameters::NODE_READ_COUNTS | paragraph::Parameters::EDGE_READ_COUNTS
+        | paragraph::Parameters::PATH_READ_COUNTS | paragraph::Parameters::DETAILED_READ_COUNTS;
+    if (p.output_alignments)
+        sp.output_options_ |= paragraph::Parameters::ALIGNMENTS;
+    return sp;
+}
+
+// what alignSingleSample keeps of a count document (AlignSamples.cpp:160-171)
+void finishSampleDocument(Json& doc, std::string const& bam, bool keep_alignments)
+{
+    doc["bam"] = bam;
+    if (!keep_alignments)
+        doc.removeMember("alignments");
+}
+
+Json genotypeToJson(genotyping::Genotype const& g, std::vector<std::string> const& allele_names)
+{
+    Json out = Json::object();
+    out["GT"] = g.toString(&allele_names);
+    if (!g.gl.empty())
+    {
+        Json gl = Json::object();
+        for (size_t i = 0; i < g.gl.size(); ++i)
+        {
+            std::string name;
+            for (size_t j = 0; j < g.gl_name[i].size(); ++j)
+                name += (j ? "/" : "") + allele_names[g.gl_name[i][j]];
+            gl[name] = g.gl[i];
+        }
+        out["GL"] = gl;
+    }
+    if (g.gq != -1)
+        out["GQ"] = g.gq;
+    if (!g.allele_fractions.empty())
+    {
+        Json fractions = Json::object();
+        for (size_t a = 0; a < g.allele_fractions.size() && a < allele_names.size(); ++a)
+            fractions[allele_names[a]] = g.allele_fractions[a];
+        out["allele_fractions"] = fractions;
+    }
+    if (!g.filters.empty())
+    {
+        Json filters = Json::array();
+        for (auto const& f : g.filters)
+            filters.append(f);
+        out["filters"] = filters;
+    }
+    if (!g.gt.empty())
+    {
+        out["num_reads"] = g.num_reads;
+        if (g.coverage_test_pvalue != -1)
+            out["coverage_test_pvalue"] = g.coverage_test_pvalue;
+    }
+    return out;
+}
+
+std::map<std::string, int32_t> edgeCounts(Json const& doc)
+{
+    if (!doc.isMember("read_counts_by_edge"))
+        throw std::runtime_error("Cannot find key read_counts_by_edge in JSON");
+    std::map<std::string, int32_t> out;
+    for (auto const& kv : doc["read_counts_by_edge"].members())
+        if (kv.second.isNumber())
+            out[kv.first] = (int32_t)kv.second.asInt64();
+    return out;
+}
+
+// GraphGenotyper::addAlignment + getGenotypes (lib/genotyping/GraphGenotyper.cpp:88-330) without the "population" block
+Json genotypeDocument(
+    graphtools::Graph const& graph, Json const& root, std::string const& genotyping_parameter_path,
+    std::vector<genotyping::SampleInfo const*> const& samples, std::vector<Json const*> const& documents)
+{
+    std::vector<std::string> regions;
+    for (Json const& r : root["target_regions"].elements())
+        regions.push_back(r.asString());
+    const auto ploidies = genotyping::GraphBreakpointGenotyper::ploidiesForTargetRegions(regions);
+    genotyping::GraphBreakpointGenotyper genotyper(ploidies.first, ploidies.second);
+    genotyper.reset(&graph);
+    if (!genotyping_parameter_path.empty())
+        genotyper.parameters().setFromJson(Json::parseFile(genotyping_parameter_path));
+
+    Json result = Json::object();
+    const genotyping::BreakpointMap breakpoints = genotyping::createBreakpointMap(graph);
+    for (size_t i = 0; i < samples.size(); ++i)
+    {
+        genotyping::SampleInfo const& sample = *samples[i];
+        Json const& doc = *documents[i];
+        genotyper.addSample(
+            sample.sample_name(), edgeCounts(doc), sample.autosome_depth(), (int)sample.read_length(), sample.depth_sd(), sample.sex());
+        if (doc.isMember("eventinfo"))
+        {
+            if (result.isMember("eventinfo") && result["eventinfo"] != doc["eventinfo"])
+                throw std::runtime_error("Samples disagree on eventinfo");
+            result["eventinfo"] = doc["eventinfo"];
+        }
+        if (!result.isMember("graphinfo"))
+        {
+            Json info = Json::object();
+            if (doc.isMember("ID"))
+                info["ID"] = doc["ID"];
+            else if (doc.isMember("vcf_records"))
+            {
+                std::string ids;
+                for (Json const& rec : doc["vcf_records"].elements())
+                    if (rec.isMember("id"))
+                        ids += (ids.empty() ? "" : ",") + rec["id"].asString();
+                info["ID"] = ids;
+            }
+            Json bp_info = Json::array();
+            for (auto const& bp : breakpoints)
+            {
+                Json entry = Json::object();
+                entry["name"] = bp.first;
+                entry["mapped_alleles"] = Json::object();
+                for (auto const& allele : bp.second.allAlleleNames())
+                {
+                    auto const& canonical = bp.second.getCanonicalAlleleName(allele);
+                    if (canonical != allele)
+                        entry["mapped_alleles"][allele] = canonical;
+                }
+                bp_info.append(entry);
+            }
+            result["breakpointinfo"] = bp_info;
+            info["target_regions"] = doc["target_regions"];
+            info["sequencenames"] = doc["sequencenames"];
+            info["nodes"] = Json::array();
+            for (Json const& n : doc["nodes"].elements())
+            {
+                Json node = Json::object();
+                node["name"] = n["name"];
+                if (n.isMember("sequences"))
+                    node["sequences"] = n["sequences"];
+                info["nodes"].append(node);
+            }
+            info["edges"] = Json::array();
+            for (Json const& e : doc["edges"].elements())
+            {
+                Json edge = Json::object();
+                edge["name"] = e["from"].asString() + "_" + e["to"].asString();
+                if (e.isMember("sequences"))
+                    edge["sequences"] = e["sequences"];
+                info["edges"].append(edge);
+            }
+            result["graphinfo"] = info;
+        }
+        Json per_sample = doc["alignment_statistics"];
+        for (auto const& kv : doc["fragment_statistics"].members())
+            if (kv.first != "linear_histogram" && kv.first != "graph_histogram")
+                per_sample[kv.first] = kv.second;
+        result["samples"][sample.sample_name()] = per_sample;
+    }
+    genotyper.runGenotyping();
+    auto const& allele_names = genotyper.alleleNames();
+    for (size_t i = 0; i < samples.size(); ++i)
+    {
+        const std::string name = samples[i]->sample_name();
+        Json& entry = result["samples"][name];
+        entry["breakpoints"] = Json::object();
+        for (auto const& bp : breakpoints)
+        {
+            Json bj = Json::object();
+            bj["gt"] = genotypeToJson(genotyper.getGenotype(name, bp.first), allele_names);
+            Json counts = Json::object();
+            counts["edges"] = Json::object();
+            counts["alleles"] = Json::object();
+            for (auto const& edge : bp.second.edgeNames())
+                counts["edges"][edge] = genotyper.getCount(i, bp.first, edge);
+            for (auto const& allele : bp.second.canonicalAlleleNames())
+                counts["alleles"][allele] = genotyper.getCount(i, bp.first, allele);
+            bj["counts"] = counts;
+            entry["breakpoints"][bp.first] = bj;
+        }
+        entry["gt"] = genotypeToJson(genotyper.getGenotype(name, ""), allele_names);
+    }
+    return result;
+}
+}  // namespace
+
+void alignSingleSample(
+    Parameters const& parameters, std::string const& graph_path, std::string const& reference_path, common::ReadReader& reader,
+    genotyping::SampleInfo& sample)
+{
+    const paragraph::GraphDescription d = paragraph::GraphDescription::load(graph_path, reference_path);
+    common::ReadBuffer reads;
+    common::extractReads(reader, d.target_regions, parameters.max_reads, (unsigned)d.longest_alt_insertion, reads);
+    Json doc = paragraph::alignAndDisambiguate(siteParameters(parameters), d, reads);
+    finishSampleDocument(doc, sample.filename(), parameters.output_alignments);
+    sample.set_alignment_data(doc);
+}
+
+Json countAndGenotype(
+    std::string const& graph_path, std::string const& reference_path, std::string const& genotyping_parameter_path,
+    genotyping::Samples const& samples)
+{
+    if (samples.empty())
+        throw std::runtime_error("countAndGenotype: no samples");
+    const Json root = graph_path.empty() ? samples.front().get_alignment_data() : Json::parseFile(graph_path);
+    const graphtools::Graph graph = grm::graphFromJson(root, reference_path, true);
+    std::vector<genotyping::SampleInfo const*> sample_ptrs;
+    std::vector<Json const*> docs;
+    for (auto const& s : samples)
+    {
+        sample_ptrs.push_back(&s);
+        docs.push_back(&s.get_alignment_data());
+    }
+    Json const& flat = root.isMember("graph") ? root["graph"] : root;
+    return genotypeDocument(graph, flat, genotyping_parameter_path, sample_ptrs, docs);
+}
+
+std::vector<Json> genotypeGraphs(
+    Parameters const& parameters, std::vector<std::string> const& graph_paths, std::string const& reference_path,
+    genotyping::Samples const& samples, std::string const& genotyping_parameter_path)
+{
+    const size_t n_graphs = graph_paths.size(), n_samples = samples.size();
+    std::vector<paragraph::GraphDescription> graphs(n_graphs);
+    parallelFor(n_graphs, parameters.threads, [&](size_t g) { graphs[g] = paragraph::GraphDescription::load(graph_paths[g], reference_path); });
+
+    // extraction: tasks in sample-major order so a worker mostly stays on one BAM; every worker owns its readers
+    std::vector<common::ReadBuffer> reads(n_graphs * n_samples);
+    {
+        const size_t workers = std::max<size_t>(1, std::min<size_t>((size_t)std::max(parameters.threads, 1), n_graphs * n_samples));
+        std::atomic<size_t> next(0);
+        std::exception_ptr failure;
+        std::atomic<bool> failed(false);
+        auto work = [&] {
+            std::map<size_t, std::unique_ptr<common::BamReader>> readers;
+            try
+            {
+                for (;;)
+                {
+                    const size_t task = next.fetch_add(1);
+                    if (task >= n_graphs * n_samples || failed.load())
+                        return;
+                    const size_t s = task / n_graphs, g = task % n_graphs;
+                    auto& reader = readers[s];
+                    if (!reader)
+                        reader.reset(new common::BamReader(samples[s].filename(), samples[s].index_filename(), reference_path));
+                    const int max_reads = graphs[g].max_reads >= 0 ? (int)graphs[g].max_reads : parameters.max_reads;
+                    common::extractReads(
+                        *reader, graphs[g].target_regions, max_reads, (unsigned)graphs[g].longest_alt_insertion, reads[g * n_samples + s]);
+                }
+            }
+            catch (...)
+            {
+                if (!failed.exchange(true))
+                    failure = std::current_exception();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (size_t w = 1; w < workers; ++w)
+            pool.emplace_back(work);
+        work();
+        for (auto& t : pool)
+            t.join();
+        if (failure)
+            std::rethrow_exception(failure);
+    }
+
+    std::vector<paragraph::SiteInput> sites(n_graphs * n_samples);
+    for (size_t g = 0; g < n_graphs; ++g)
+        for (size_t s = 0; s < n_samples; ++s)
+        {
+            sites[g * n_samples + s].description = &graphs[g];
+            sites[g * n_samples + s].reads = &reads[g * n_samples + s];
+        }
+    std::vector<Json> documents = paragraph::alignAndDisambiguateBatch(siteParameters(parameters), sites);
+    for (size_t g = 0; g < n_graphs; ++g)
+        for (size_t s = 0; s < n_samples; ++s)
+            finishSampleDocument(documents[g * n_samples + s], samples[s].filename(), parameters.output_alignments);
+
+    std::vector<Json> genotypes(n_graphs);
+    parallelFor(n_graphs, parameters.threads, [&](size_t g) {
+        std::vector<genotyping::SampleInfo const*> sample_ptrs;
+        std::vector<Json const*> docs;
+        for (size_t s = 0; s < n_samples; ++s)
+        {
+            sample_ptrs.push_back(&samples[s]);
+            docs.push_back(&documents[g * n_samples + s]);
+        }
+        genotypes[g] = genotypeDocument(*graphs[g].graph, graphs[g].description, genotyping_parameter_path, sample_ptrs, docs);
+    });
+    return genotypes;
+}
+}  // namespace grmpy

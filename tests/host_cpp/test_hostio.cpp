@@ -1,0 +1,632 @@
+// CPU-only checks of the host input layer (JSON, coordinates, FASTA, BAM/BAI, read extraction, graph descriptions,
+// manifests, graph coordinates, statistics).  Expectations come from the reference's own unit tests and data files:
+//   src/c++/test/test_stringutil.cpp:86-118, test_readextraction.cpp:105-199, test_graph_input.cpp:46-155,
+//   GT!/tests/GraphCoordinatesTest.cpp:72-140, share/test-data/multiparagraph/reads.sam (text of reads.bam).
+// Usage: test_hostio <tests/golden/sites directory>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <random>
+#include <sstream>
+
+#include "common/BamReader.hh"
+#include "common/Fasta.hh"
+#include "common/Json.hh"
+#include "common/ReadExtraction.hh"
+#include "common/Region.hh"
+#include "genotyping/GenotypingParameters.hh"
+#include "genotyping/SampleInfo.hh"
+#include "graphcore/GraphCoordinates.hh"
+#include "grm/GraphInput.hh"
+#include "paragraph/Statistics.hh"
+
+using namespace common;
+
+static int g_failures = 0;
+#define CHECK(cond)                                                                  \
+    do                                                                               \
+    {                                                                                \
+        if (!(cond))                                                                 \
+        {                                                                            \
+            std::cerr << __FILE__ << ":" << __LINE__ << ": CHECK failed: " #cond "\n"; \
+            ++g_failures;                                                            \
+        }                                                                            \
+    } while (0)
+#define CHECK_THROWS(expr)                                                           \
+    do                                                                               \
+    {                                                                                \
+        bool threw = false;                                                          \
+        try                                                                          \
+        {                                                                            \
+            (void)(expr);                                                            \
+        }                                                                            \
+        catch (std::exception const&)                                                \
+        {                                                                            \
+            threw = true;                                                            \
+        }                                                                            \
+        if (!threw)                                                                  \
+        {                                                                            \
+            std::cerr << __FILE__ << ":" << __LINE__ << ": expected an exception: " #expr "\n"; \
+            ++g_failures;                                                            \
+        }                                                                            \
+    } while (0)
+
+static void testJson()
+{
+    const Json v = Json::parse(R"({"b": [1, -2, 3.5, 1e3, true, false, null], "a": {"s": "x\"\\\né😀", "big": 18446744073709551615}})");
+    CHECK(v.isObject() && v["b"].isArray() && v["b"].size() == 7);
+    CHECK(v["b"][0].asInt64() == 1 && v["b"][1].asInt64() == -2 && v["b"][2].asDouble() == 3.5 && v["b"][3].asDouble() == 1000.0);
+    CHECK(v["b"][4].asBool() && !v["b"][5].asBool() && v["b"][6].isNull());
+    CHECK(v["a"]["s"].asString() == "x\"\\\n\xc3\xa9\xf0\x9f\x98\x80");
+    CHECK(v["a"]["big"].asUInt64() == 18446744073709551615ull);
+    CHECK(v["missing"].isNull() && !v.isMember("missing") && v.isMember("a"));
+    CHECK(v.getMemberNames() == (std::vector<std::string>{ "a", "b" }));  // sorted like Json::Value
+    CHECK(Json::parse(v.dump()) == v);
+    CHECK(Json::parse(v.dump(4)) == v);
+    Json w = Json::object();
+    w["nan"] = std::nan("");
+    w["x"] = 0.1;
+    w["i"] = 3.0;
+    CHECK(w.dump() == R"({"i":3.0,"nan":null,"x":0.1})");
+    Json arr;
+    arr.append(1);
+    arr.append("two");
+    CHECK(arr.isArray() && arr.size() == 2 && arr.dump() == "[1,\"two\"]");
+    CHECK(Json(1) == Json(1.0) && Json(1) != Json(2) && Json((uint64_t)5) == Json(5));
+    CHECK_THROWS(Json::parse("{\"a\": }"));
+    CHECK_THROWS(Json::parse("[1, 2"));
+    CHECK_THROWS(Json::parse("{} x"));
+    CHECK_THROWS(Json::parse("\"abc"));
+    CHECK_THROWS(v["b"].asString());
+    CHECK_THROWS(Json::parseFile("/nonexistent/file.json"));
+}
+
+static void testCoordinates()
+{
+    std::string chr;
+    int64_t start = -1, end = -1;
+    parsePos("chr1", chr, start, end);
+    CHECK(chr == "chr1" && start == -1 && end == -1);
+    parsePos("chr1:1,000", chr, start, end);
+    CHECK(chr == "chr1" && start == 999 && end == -1);
+    parsePos("chr1:1,000-2000", chr, start, end);
+    CHECK(chr == "chr1" && start == 999 && end == 1999);
+    CHECK(formatPos("chr2", 9, 19) == "chr2:10-20" && formatPos("chr2", 9) == "chr2:10" && formatPos("chr2") == "chr2");
+    const Region r("chrX:850-1149");
+    CHECK(r.chrom == "chrX" && r.start == 849 && r.end == 1148 && r.length() == 300);
+    CHECK((std::string)r.getExtendedRegion(999) == "chrX:1-2148");
+    CHECK((std::string)r.getExtendedRegion(100) == "chrX:750-1249");
+    CHECK((std::string)r.getLeftFlank(10) == "chrX:839-849" && (std::string)r.getRightFlank(10) == "chrX:1150-1160");
+}
+
+static void testFasta(std::string const& dir)
+{
+    FastaFile fa(dir + "/multiparagraph/dummy.fa");
+    CHECK(fa.contigSize("chr") == 440 && fa.contigSize("") == 440);
+    CHECK(fa.query("chr:1-40") == std::string(40, 'A'));
+    CHECK(fa.query("chr:41-80") == std::string(40, 'C'));
+    CHECK(fa.query("chr:39-42") == "AACC");
+    CHECK(fa.query("chr:81-231").size() == 151);
+    CHECK(fa.query("chr:431-600") == std::string(10, 'C'));  // clipped at the contig end
+    CHECK(fa.query("chr:441-450").empty() && fa.query("chr", 10, 5).empty());
+    CHECK(fa.query("chr", -5, 2) == "AAA");
+    CHECK_THROWS(fa.query("nochr:1-2"));
+    // no .fai next to this one: indexed by scanning
+    FastaFile plain(dir + "/basic/dummy.fa");
+    CHECK(plain.getContigNames().size() == 2);
+    CHECK(plain.query("SimpleDeletion:1-25") == "CGTCGACGTCGAACGATCGTCAGTA");
+    CHECK(plain.query("SimpleDeletion:19-22") == "GTCA");
+    // a lower-case / IUPAC base comes back as upper case / N
+    {
+        const std::string path = "/tmp/pg_hostio_test.fa";
+        std::ofstream(path) << ">c1 description\nacgtRYn\nACG\n>c2\nTT\n";
+        FastaFile mixed(path);
+        CHECK(mixed.query("c1:1-10") == "ACGTNNNACG" && mixed.query("c2:1-2") == "TT" && mixed.contigSize("c1") == 10);
+        std::remove(path.c_str());
+    }
+}
+
+struct SamLine
+{
+    std::string name, rname, rnext, seq, qual;
+    int flag = 0, pos = 0, mapq = 0, pnext = 0;
+};
+
+static std::vector<SamLine> readSam(std::string const& path)
+{
+    std::vector<SamLine> out;
+    std::ifstream in(path);
+    std::string line;
+    while (std::getline(in, line))
+    {
+        if (line.empty() || line[0] == '@')
+            continue;
+        std::stringstream ss(line);
+        SamLine s;
+        std::string cigar, tlen;
+        ss >> s.name >> s.flag >> s.rname >> s.pos >> s.mapq >> cigar >> s.rnext >> s.pnext >> tlen >> s.seq >> s.qual;
+        out.push_back(s);
+    }
+    return out;
+}
+
+static void testBamAgainstSam(std::string const& dir)
+{
+    const auto sam = readSam(dir + "/multiparagraph/reads.sam");
+    CHECK(sam.size() == 6);
+    BamReader reader(dir + "/multiparagraph/reads.bam", "", dir + "/multiparagraph/dummy.fa");
+    CHECK(reader.contigNames() == std::vector<std::string>{ "chr" } && reader.contigLengths()[0] == 160);
+    CHECK(reader.headerText().find("@SQ\tSN:chr\tLN:160") != std::string::npos);
+    for (const char* region : { "chr", "chr:1-160", "chr:40", "chr:40-40", "chr:89-200" })
+    {
+        reader.setRegion(region);
+        Read r;
+        size_t n = 0;
+        while (reader.getAlign(r))
+        {
+            CHECK(n < sam.size());
+            SamLine const& s = sam[std::min(n, sam.size() - 1)];
+            CHECK(r.fragment_id() == s.name && r.bases() == s.seq && r.quals() == s.qual);
+            CHECK(r.pos() == s.pos - 1 && r.mapq() == s.mapq && r.chrom_id() == 0);
+            CHECK(r.is_first_mate() == ((s.flag & 0x40) != 0) && r.is_mapped() == !(s.flag & 4) && r.is_mate_mapped() == !(s.flag & 8));
+            CHECK(r.is_reverse_strand() == ((s.flag & 0x10) != 0) && r.is_mate_reverse_strand() == ((s.flag & 0x20) != 0));
+            CHECK(r.mate_chrom_id() == (s.rnext == "=" ? 0 : -1) && r.mate_pos() == s.pnext - 1);
+            ++n;
+        }
+        CHECK(n == sam.size());
+        CHECK(!reader.getAlign(r));  // stays exhausted
+    }
+    // reads span 40..89 (1-based): windows before / after see nothing
+    Read r;
+    reader.setRegion("chr:1-39");
+    CHECK(!reader.getAlign(r));
+    reader.setRegion("chr:90-160");
+    CHECK(!reader.getAlign(r));
+    CHECK_THROWS(reader.setRegion("nochr:1-10"));
+    CHECK_THROWS(BamReader(dir + "/multiparagraph/missing.bam", "", ""));
+}
+
+// region queries through the index must equal a filter over the full scan, in the same order
+static void testBamIndexConsistency(std::string const& dir)
+{
+    BamReader reader(dir + "/chrX/chrX_graph_typing.bam", "", dir + "/chrX/chrX_graph_typing.fa");
+    CHECK(reader.contigNames().size() == 25);
+    const size_t tid = (size_t)(std::find(reader.contigNames().begin(), reader.contigNames().end(), "chrX") - reader.contigNames().begin());
+    CHECK(tid < reader.contigNames().size());
+    std::vector<Read> all;
+    reader.setRegion("chrX");
+    Read r;
+    while (reader.getAlign(r))
+        all.push_back(r);
+    CHECK(all.size() > 50);
+    for (size_t i = 1; i < all.size(); ++i)
+        CHECK(all[i - 1].pos() <= all[i].pos());
+    std::mt19937 rng(5);
+    const int64_t len = 10000;  // the reads of this file sit in the first 10 kbp of chrX
+    size_t nonempty = 0;
+    for (int iter = 0; iter < 200; ++iter)
+    {
+        const int64_t beg = (int64_t)(rng() % (uint64_t)len), span = 1 + (int64_t)(rng() % 600);
+        reader.setRegion(formatPos("chrX", beg, beg + span - 1));
+        std::vector<Read> got;
+        while (reader.getAlign(r))
+            got.push_back(r);
+        // every returned record starts before the window end; every full-scan record starting inside is returned
+        size_t k = 0;
+        for (auto const& g : got)
+        {
+            CHECK(g.pos() < beg + span);
+            while (k < all.size() && !(all[k] == g))
+                ++k;
+            CHECK(k < all.size());  // subsequence of the full scan, same order
+        }
+        for (auto const& a : all)
+        {
+            if (a.pos() >= beg && a.pos() < beg + span)
+                CHECK(std::find(got.begin(), got.end(), a) != got.end());
+            if (a.pos() + (int64_t)a.bases().size() + 600 < beg || a.pos() >= beg + span)
+                CHECK(std::find(got.begin(), got.end(), a) == got.end());
+        }
+        nonempty += !got.empty();
+    }
+    CHECK(nonempty > 5);
+    // mates: for paired records whose mate is in the file, getAlignedMate finds the other end
+    size_t found = 0, tried = 0;
+    for (auto const& a : all)
+    {
+        if (!a.is_mate_mapped() || a.mate_chrom_id() != a.chrom_id() || tried >= 40)
+            continue;
+        ++tried;
+        Read mate;
+        if (reader.getAlignedMate(a, mate))
+        {
+            ++found;
+            CHECK(mate.fragment_id() == a.fragment_id() && mate.is_first_mate() != a.is_first_mate() && mate.pos() == a.mate_pos());
+        }
+    }
+    CHECK(tried > 0 && found > 0);
+}
+
+class ScriptedReader : public ReadReader
+{
+public:
+    std::deque<Read> aligns;
+    std::map<std::string, Read> mates;
+    std::vector<std::string> regions, mate_calls;
+    void setRegion(const std::string& region) override { regions.push_back(region); }
+    bool getAlign(Read& align) override
+    {
+        if (aligns.empty())
+            return false;
+        align = aligns.front();
+        aligns.pop_front();
+        return true;
+    }
+    bool getAlignedMate(const Read& read, Read& mate) override
+    {
+        mate_calls.push_back(read.fragment_id());
+        auto it = mates.find(read.fragment_id());
+        if (it == mates.end())
+            return false;
+        mate = it->second;
+        return true;
+    }
+};
+
+static Read makeRead(const char* id, const char* bases, bool first, int chrom, int pos, int mchrom = -1, int mpos = -1)
+{
+    Read r;
+    r.setCoreInfo(id, bases, std::string(strlen(bases), '#'));
+    r.set_is_first_mate(first);
+    r.set_chrom_id(chrom);
+    r.set_pos(pos);
+    r.set_mate_chrom_id(mchrom);
+    r.set_mate_pos(mpos);
+    return r;
+}
+
+static void testExtraction()
+{
+    const Read read1 = makeRead("Fragment_1", "AAAA", true, 1, 100), read2 = makeRead("Fragment_2", "AAAA", true, 1, 100);
+    {  // ExtractsAllReadsFromReader
+        ScriptedReader reader;
+        reader.aligns = { read1, read2 };
+        ReadPairs pairs;
+        const int mean_len = extractMappedReadsFromRegion(pairs, 10, reader, Region("1", 0, 1800));
+        std::vector<Read> got;
+        pairs.getReads(got);
+        CHECK(got == (std::vector<Read>{ read1, read2 }) && mean_len == 4 && pairs.num_reads() == 2);
+    }
+    {  // ExtractsMaxAllowedReadsFromReader
+        ScriptedReader reader;
+        reader.aligns = { read1, read2 };
+        ReadPairs pairs;
+        extractMappedReadsFromRegion(pairs, 1, reader, Region("1", 0, 1800));
+        std::vector<Read> got;
+        pairs.getReads(got);
+        CHECK(got == std::vector<Read>{ read1 } && reader.aligns.size() == 1);
+    }
+    {  // RecoversAnomalousMates
+        const Read a = makeRead("Fragment_1", "AAAA", true, 1, 100, 1, 1600), b = makeRead("Fragment_2", "CCCC", true, 3, 500, 3, 800),
+                   c = makeRead("Fragment_3", "AAAA", false, 5, 500, 3, 500);
+        Read mate_a, mate_c;
+        mate_a.setCoreInfo("Fragment_1", "TTTT", "####");
+        mate_a.set_is_first_mate(false);
+        mate_c.setCoreInfo("Fragment_3", "GGGG", "####");
+        mate_c.set_is_first_mate(true);
+        ScriptedReader reader;
+        reader.mates["Fragment_1"] = mate_a;
+        reader.mates["Fragment_3"] = mate_c;
+        ReadPairs pairs;
+        pairs.add(a);
+        pairs.add(b);
+        pairs.add(c);
+        recoverMissingMates(reader, pairs);
+        std::vector<Read> got;
+        pairs.getReads(got);
+        CHECK(got == (std::vector<Read>{ a, mate_a, b, mate_c, c }));
+        CHECK(reader.mate_calls == (std::vector<std::string>{ "Fragment_1", "Fragment_3" }));  // the nearby mate of b is not looked up
+        CHECK(pairs.num_reads() == 5 && pairs["Fragment_1"].second_mate() == mate_a);
+        CHECK_THROWS(pairs["nope"]);
+    }
+    {  // isReadOrItsMateInRegion
+        Read r = read1;
+        CHECK(!isReadOrItsMateInRegion(r, Region("1", 0, 50)));
+        CHECK(isReadOrItsMateInRegion(r, Region("1", 101, 103)));
+        CHECK(!isReadOrItsMateInRegion(r, Region("1", 110, 200)));
+        r.set_mate_chrom_id(1);
+        r.set_mate_pos(1600);
+        CHECK(isReadOrItsMateInRegion(r, Region("1", 1550, 1650)));
+    }
+    {  // extractReadsFromRegion: the scan window is region +- 3 x fragment length; mates only when reads are short enough
+        const Read far = makeRead("F", "ACGTACGTAC", true, 0, 1000, 0, 9000);
+        Read mate = makeRead("F", "TTTTTTTTTT", false, 0, 9000, 0, 1000);
+        for (unsigned longest_insertion : { 0u, 5u, 6u })
+        {
+            ScriptedReader reader;
+            reader.aligns = { far };
+            reader.mates["F"] = mate;
+            std::vector<p_Read> out;
+            const auto n = extractReadsFromRegion(out, 100, reader, Region("chr", 990, 1100), longest_insertion, 333);
+            CHECK(reader.regions == std::vector<std::string>{ "chr:1-2100" });
+            const bool expect_mate = 10 <= longest_insertion * 2;
+            CHECK(n.first == 1 && n.second == (expect_mate ? 1 : 0) && out.size() == (expect_mate ? 2u : 1u));
+        }
+        // a replaced mate slot does not count twice
+        ReadPairs pairs;
+        pairs.add(far);
+        pairs.add(far);
+        CHECK(pairs.num_reads() == 1);
+    }
+}
+
+static void testGraphInput(std::string const& dir)
+{
+    const std::string fa = dir + "/basic/dummy.fa";
+    auto load = [&](const char* name, bool store = true) { return grm::graphFromJson(Json::parseFile(dir + "/basic/" + name), fa, store); };
+    {
+        const auto g = load("del-with-edges-nodes.json");
+        CHECK(g.numEdges() == 5 && g.numNodes() == 5);
+        for (graphtools::NodeId n = 0; n < g.numNodes(); ++n)
+            CHECK(!g.nodeSeq(n).empty());
+        CHECK(g.nodeSeq(0) == "X" && g.nodeSeq(4) == "X" && g.nodeName(0) == "source");
+        CHECK(g.nodeSeq(1) == "CGTCGACGTCGAACGATCGTCAGTACGACTACGTCGACAT");
+        CHECK(g.edgeLabels(1, 2).count("REF") == 1 && g.edgeLabels(1, 3).count("ALT") == 1);
+        const Json doc = Json::parseFile(dir + "/basic/del-with-edges-nodes.json");
+        const auto paths = grm::pathsFromJson(&g, doc["paths"]);
+        CHECK(paths.size() == 2 && paths.front().nodes.size() == 5 && paths.front().start_position == 0 && paths.front().end_position == 0);
+    }
+    {
+        const auto g = load("del-with-edges-nodes.json", false);
+        for (graphtools::NodeId n = 0; n < g.numNodes(); ++n)
+            if (g.nodeName(n) != "source" && g.nodeName(n) != "sink")
+                CHECK(g.nodeSeq(n).empty());
+    }
+    {
+        const auto g = load("del-with-nodes-only.json");
+        CHECK(g.numEdges() == 0 && g.numNodes() == 3);
+    }
+    {
+        const auto g = load("del-with-ref-node-array.json");
+        CHECK(g.numEdges() == 0 && g.numNodes() == 4);
+        for (graphtools::NodeId n = 0; n < g.numNodes(); ++n)
+            CHECK(!g.nodeSeq(n).empty());
+    }
+    CHECK_THROWS(load("del-with-no-ref-or-seq-node-key.json"));
+    CHECK_THROWS(load("del-with-edges-only.json"));
+    CHECK_THROWS(load("del-with-bad-edges-value.json"));
+    CHECK_THROWS(load("del-with-bad-node-seq-ids.json"));
+    CHECK_THROWS(load("del-with-duplicate-node-names.json"));
+    // the chrX swap graph: explicit N-runs on source / sink become "X", the rest comes from the FASTA
+    {
+        const auto g = grm::graphFromJson(Json::parseFile(dir + "/chrX/chrX_graph_typing.2sample.json"), dir + "/chrX/chrX_graph_typing.fa");
+        CHECK(g.numNodes() == 6 && g.numEdges() == 7 && g.nodeSeq(0) == "X" && g.nodeSeq(5) == "X");
+        CHECK(g.nodeSeq(2).size() == 150 && g.nodeSeq(3).size() == 149 && g.nodeSeq(4).size() == 150 && g.nodeSeq(1).size() == 150);
+        // the node-level "sequences": ["REF"] of LF and RF labels every edge in and out of them
+        CHECK(g.edgeLabels(2, 3) == (std::set<std::string>{ "ALT", "REF" }) && g.edgeLabels(2, 4) == std::set<std::string>{ "REF" });
+        CHECK(g.edgeLabels(0, 2) == std::set<std::string>{ "REF" } && g.edgeLabels(0, 1).empty() && g.edgeLabels(4, 5).empty());
+    }
+}
+
+static void testGraphCoordinates()
+{
+    graphtools::Graph graph(4);
+    const char* names[] = { "LF", "P1", "Q1", "RF" };
+    const char* seqs[] = { "AAAAAAAAAAA", "TTTTTT", "GGGGGGGG", "AAAAAAAAAAA" };
+    for (graphtools::NodeId n = 0; n < 4; ++n)
+    {
+        graph.setNodeName(n, names[n]);
+        graph.setNodeSeq(n, seqs[n]);
+    }
+    graph.addEdge(0, 1);
+    graph.addEdge(0, 2);
+    graph.addEdge(1, 3);
+    graph.addEdge(2, 3);
+    graphtools::GraphCoordinates c(&graph);
+    CHECK(c.canonicalPos(0, 6) == 6 && c.canonicalPos(1, 4) == 15 && c.canonicalPos(2, 3) == 20 && c.canonicalPos(3, 2) == 27);
+    const uint64_t starts[] = { 0, 11, 17, 25 };
+    for (graphtools::NodeId n = 0; n < 4; ++n)
+        for (uint64_t j = 0; j < strlen(seqs[n]); ++j)
+        {
+            graphtools::NodeId node;
+            uint64_t off;
+            c.nodeAndOffset(starts[n] + j, node, off);
+            CHECK(node == n && off == j);
+        }
+    CHECK(c.distance(10, 5) == 5 && c.distance(5, 10) == 5);
+    CHECK(c.distance(14, 6) == 8 && c.distance(20, 6) == 8);
+    CHECK(c.distance(2, 11 + 6 + 8 + 4) == 9 + 6 + 4);  // LF -> RF goes through the shorter P1
+    CHECK(c.distance(12, 18) == graphtools::GraphCoordinates::kNoPath);  // P1 and Q1 are alternatives
+    graphtools::Path p;
+    p.graph = &graph;
+    p.nodes = { 0, 1 };
+    p.start_position = 3;
+    p.end_position = 4;
+    CHECK(c.canonicalStartAndEnd(p) == (std::pair<uint64_t, uint64_t>(3, 15)));
+}
+
+static void testStatistics()
+{
+    using paragraph::RunningStats;
+    RunningStats empty;
+    CHECK(std::isnan(empty.mean()) && empty.variance() == 0 && empty.median() == 0);
+    RunningStats few;
+    few.add(7);
+    few.add(3);
+    CHECK(few.mean() == 5 && few.median() == 0);  // fewer than five samples: the third seed slot, still unset
+    CHECK(std::fabs(few.variance() - 4.0) < 1e-12);  // iterative update: 0 * 1/2 + (3 - 5)^2 / 1
+    RunningStats many;
+    for (int i = 1; i <= 1001; ++i)
+        many.add((double)((i * 37) % 1001));
+    CHECK(std::fabs(many.mean() - 500.0) < 1e-9);
+    CHECK(std::fabs(many.median() - 500.0) < 25.0);
+    CHECK(std::fabs(many.variance() - (1001.0 * 1001.0 - 1.0) / 12.0) / 83500.0 < 0.01);
+
+    graphtools::Graph g(4);
+    const char* names[] = { "source", "A", "B", "sink" };
+    const char* seqs[] = { "X", "ACGTACGTAC", "TTTTTTTTTTTTTTTTTTTT", "X" };
+    for (graphtools::NodeId n = 0; n < 4; ++n)
+    {
+        g.setNodeName(n, names[n]);
+        g.setNodeSeq(n, seqs[n]);
+    }
+    g.addEdge(0, 1);
+    g.addEdge(1, 2);
+    g.addEdge(2, 3);
+    g.addLabelToEdge(0, 1, "REF");
+    g.addLabelToEdge(1, 2, "REF");
+    g.addLabelToEdge(2, 3, "REF");
+    const auto pieces = paragraph::decodeGraphCigar("1[2S3M1X4M]2[5M1I2M1D3M4S]", g);
+    CHECK(pieces.size() == 2 && pieces[0].node == 1 && pieces[0].matched == 7 && pieces[0].mismatched == 1 && pieces[0].clipped == 2);
+    CHECK(pieces[1].referenceLength() == 11 && pieces[1].queryLength() == 15 && pieces[0].queryLength() == 10);
+    CHECK_THROWS(paragraph::decodeGraphCigar("9[3M]", g));
+    CHECK_THROWS(paragraph::decodeGraphCigar("1[3M", g));
+    CHECK_THROWS(paragraph::decodeGraphCigar("1[3Q]", g));
+
+    Read r1("f1", std::string(25, 'A'), std::string(25, '#')), r2("f1", std::string(10, 'T'), std::string(10, '#'));
+    r1.set_graph_mapping_status(Read::MAPPED);
+    r1.set_graph_pos(0);
+    r1.set_graph_cigar("1[2S3M1X4M]2[5M1I2M1D3M4S]");
+    r1.set_graph_alignment_score(11);
+    r1.add_graph_sequences_supported("REF");
+    r1.set_is_mapped(true);
+    r1.set_is_mate_mapped(true);
+    r1.set_chrom_id(0);
+    r1.set_mate_chrom_id(0);
+    r1.set_pos(100);
+    r1.set_mate_pos(300);
+    r1.set_is_mate_reverse_strand(true);
+    r2.set_is_first_mate(false);
+    r2.set_graph_mapping_status(Read::MAPPED);
+    r2.set_graph_pos(12);
+    r2.set_graph_cigar("2[8M]");
+    r2.set_is_graph_reverse_strand(true);
+    r2.set_is_mapped(true);
+    r2.set_is_mate_mapped(true);
+    r2.set_chrom_id(0);
+    r2.set_mate_chrom_id(0);
+    r2.set_pos(300);
+    r2.set_mate_pos(100);
+    r2.set_is_reverse_strand(true);
+    Read lone("f2", "ACGT", "####");
+    lone.set_graph_mapping_status(Read::MAPPED);
+    lone.set_graph_pos(1);
+    lone.set_graph_cigar("1[4M]");
+    const std::vector<Read const*> reads = { &r1, &r2, &lone };
+    const Json fs = paragraph::fragmentStatistics(g, reads);
+    CHECK(fs["paired_read"].asUInt64() == 1 && fs["single_read"].asUInt64() == 1 && fs["multi_read"].asUInt64() == 0);
+    CHECK(fs["problematic_linear"].asUInt64() == 1 && fs["problematic_graph"].asUInt64() == 0);
+    CHECK(fs["mean_linear"].asDouble() == 210.0);  // |300 - 100| + 10 bases of the read added last
+    // r1 spans canonical [1+0, 11+11), r2 [11+12, 11+20): gap from 22 to 23 is 1 -> 25 + 8 + 1
+    CHECK(fs["mean_graph"].asDouble() == 34.0);
+    CHECK(fs["median_graph"].asDouble() == 0.0 && fs["variance_graph"].asDouble() == 0.0);
+    const Json as = paragraph::alignmentStatistics(g, reads);
+    CHECK(as["nodes"]["A"]["num_fwd_reads"].asInt64() == 2 && as["nodes"]["B"]["num_rev_reads"].asInt64() == 1);
+    CHECK(as["nodes"]["A"]["contig_length"].asInt64() == 10 && as["edges"]["A_B"]["contig_length"].asInt64() == 30);
+    CHECK(std::fabs(as["nodes"]["A"]["mismatch_rate"].asDouble() - 1.0 / 12.0) < 1e-12);  // (7 + 4) M + 1 X
+    CHECK(std::fabs(as["nodes"]["A"]["clip_rate"].asDouble() - 2.0 / 12.0) < 1e-12);
+    CHECK(as["edges"]["A_B"]["clip_rate"].asDouble() == 0.0);  // clips on an edge only count next to the terminals
+    CHECK(as["alleles"]["REF"]["avr_score"].asDouble() == 11.0 && as["alleles"]["REF"]["contig_length"].asInt64() == 30);
+}
+
+static void testManifestAndParameters(std::string const& dir)
+{
+    const std::string path = "/tmp/pg_hostio_manifest.txt";
+    {
+        std::ofstream out(path);
+        out << "#id\tpath\tdepth\tread length\tdepth sd\tsex\n";
+        out << "SAMPLE1\t" << dir << "/chrX/chrX_graph_typing.bam\t44.2\t150\t20\tmale\n\n";
+        out << "SAMPLE2\t" << dir << "/chrX/chrX_graph_typing.bam\t30\t100\t5.5\tFemale\n";
+    }
+    const auto samples = genotyping::loadManifest(path);
+    CHECK(samples.size() == 2 && samples[0].sample_name() == "SAMPLE1" && samples[0].autosome_depth() == 44.2);
+    CHECK(samples[0].read_length() == 150 && samples[0].depth_sd() == 20 && samples[0].sex() == genotyping::Sex::MALE);
+    CHECK(samples[1].sex() == genotyping::Sex::FEMALE && samples[1].depth_sd() == 5.5 && samples[1].index_filename().empty());
+    {
+        std::ofstream out(path);
+        out << "id,path,depth,read length\nS," << dir << "/chrX/chrX_graph_typing.bam,20,100\n";
+    }
+    const auto plain = genotyping::loadManifest(path);
+    CHECK(plain.size() == 1 && plain[0].depth_sd() == std::sqrt(100.0) && plain[0].sex() == genotyping::Sex::UNKNOWN);
+    {
+        std::ofstream out(path);
+        out << "id\tpath\tcolour\nS\tx\tred\n";
+    }
+    CHECK_THROWS(genotyping::loadManifest(path));
+    {
+        std::ofstream out(path);
+        out << "id\tpath\tdepth\tread length\nS\t/no/such.bam\t20\t100\n";
+    }
+    CHECK_THROWS(genotyping::loadManifest(path));
+    {
+        std::ofstream out(path);
+        out << "id\tpath\tdepth\n";
+    }
+    CHECK_THROWS(genotyping::loadManifest(path));
+    std::remove(path.c_str());
+
+    genotyping::GenotypingParameters p({ "ALT", "REF" }, 2);
+    p.setFromJson(Json::parseFile(dir + "/chrX/param.json"));
+    CHECK(p.minOverlapBases() == 16 && p.ploidy() == 2 && p.otherAlleleErrorRate() == 0.05);
+    CHECK(p.alleleErrorRates() == (std::vector<double>{ 0.04, 0.04 }));       // given as REF, ALT -> stored as ALT, REF
+    CHECK(p.hetHaplotypeFractions() == (std::vector<double>{ 0.45, 0.5 }));
+    CHECK(p.coverageTestCutoff().first == 0.0001);  // both values land in the lower cutoff
+    CHECK_THROWS(p.setFromJson(Json::parse(R"({"use_poisson_depth": true})")));
+    p.setFromJson(Json::parse(R"({"use_poisson_depth": "true"})"));
+    CHECK(p.usePoissonDepth());
+    CHECK_THROWS(p.setFromJson(Json::parse(R"({"allele_error_rates": [0.1]})")));
+}
+
+int main(int argc, char** argv)
+{
+    if (argc == 4 && std::string(argv[1]) == "--dump-bam")
+    {
+        // <bam> <region>: one line per primary record, for the independent Python decoder in tests/test_hostio_cpu.py
+        BamReader reader(argv[2], "", "");
+        reader.setRegion(argv[3]);
+        Read r;
+        while (reader.getAlign(r))
+            std::cout << r.fragment_id() << "\t" << r.chrom_id() << "\t" << r.pos() << "\t" << (int)r.mapq() << "\t" << r.is_mapped()
+                      << r.is_first_mate() << r.is_mate_mapped() << r.is_reverse_strand() << r.is_mate_reverse_strand() << "\t"
+                      << r.mate_chrom_id() << "\t" << r.mate_pos() << "\t" << r.bases() << "\t" << r.quals() << "\n";
+        return 0;
+    }
+    if (argc < 2)
+    {
+        std::cerr << "usage: test_hostio <tests/golden/sites> | --dump-bam <bam> <region>\n";
+        return 2;
+    }
+    const std::string dir = argv[1];
+    const std::pair<const char*, std::function<void()>> tests[] = {
+        { "json", testJson },
+        { "coordinates", testCoordinates },
+        { "fasta", [&] { testFasta(dir); } },
+        { "bam-vs-sam", [&] { testBamAgainstSam(dir); } },
+        { "bam-index", [&] { testBamIndexConsistency(dir); } },
+        { "extraction", testExtraction },
+        { "graph-input", [&] { testGraphInput(dir); } },
+        { "graph-coordinates", testGraphCoordinates },
+        { "statistics", testStatistics },
+        { "manifest-parameters", [&] { testManifestAndParameters(dir); } },
+    };
+    for (auto const& t : tests)
+    {
+        const int before = g_failures;
+        try
+        {
+            t.second();
+        }
+        catch (std::exception const& e)
+        {
+            std::cerr << t.first << ": unexpected exception: " << e.what() << "\n";
+            ++g_failures;
+        }
+        std::cout << (g_failures == before ? "ok   " : "FAIL ") << t.first << "\n";
+    }
+    std::cout << (g_failures ? "FAILED" : "ALL OK") << "\n";
+    return g_failures ? 1 : 0;
+}

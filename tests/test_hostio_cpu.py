@@ -1,0 +1,88 @@
+"""CPU checks of the host input layer (JSON / FASTA / BAM+BAI / read extraction / graph descriptions / manifests /
+statistics): the C++ program tests/host_cpp/test_hostio holds the expectations of the reference's unit tests; here it is
+built and run, and the BAM reader is additionally compared record by record with an independent decoder (Python gzip +
+struct on the same file)."""
+import gzip
+import os
+import struct
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SITES = os.path.join(ROOT, "tests", "golden", "sites")
+
+
+@pytest.fixture(scope="module")
+def hostio():
+    from paragraph_amd import build
+    build.build_genotyping_test()
+    exe = os.path.join(ROOT, "tests", "host_cpp", "test_hostio")
+    assert os.path.exists(exe)
+    return exe
+
+
+def test_hostio_program(hostio):
+    r = subprocess.run([hostio, SITES], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ALL OK" in r.stdout
+
+
+def decode_bam(path):
+    """SAM/BAM spec section 4.2, straight from the inflated stream (BGZF = concatenated gzip members)."""
+    data = gzip.open(path, "rb").read()
+    assert data[:4] == b"BAM\1"
+    l_text, = struct.unpack_from("<i", data, 4)
+    at = 8 + l_text
+    n_ref, = struct.unpack_from("<i", data, at)
+    at += 4
+    names = []
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", data, at)
+        names.append(data[at + 4:at + 4 + l_name - 1].decode())
+        at += 4 + l_name + 4
+    recs = []
+    while at < len(data):
+        block_size, = struct.unpack_from("<i", data, at)
+        tid, pos, l_read_name, mapq, _bin, n_cigar, flag, l_seq, mtid, mpos, _tlen = struct.unpack_from("<iiBBHHHiiii", data, at + 4)
+        p = at + 36
+        name = data[p:p + l_read_name - 1].decode()
+        p += l_read_name
+        cigar = struct.unpack_from("<%dI" % n_cigar, data, p)
+        p += 4 * n_cigar
+        seq = "".join("=ACMGRSVTWYHKDBN"[(data[p + i // 2] >> (0 if i & 1 else 4)) & 15] for i in range(l_seq))
+        p += (l_seq + 1) // 2
+        qual = "".join(chr(33 + q) for q in data[p:p + l_seq])
+        ref_span = sum(c >> 4 for c in cigar if (c & 15) in (0, 2, 3, 7, 8))
+        if flag & 4 or not cigar or ref_span == 0:
+            ref_span = 1
+        recs.append(dict(name=name, tid=tid, pos=pos, mapq=mapq, flag=flag, mtid=mtid, mpos=mpos, seq=seq, qual=qual, end=pos + ref_span))
+        at += 4 + block_size
+    return names, recs
+
+
+def dump(hostio, bam, region):
+    r = subprocess.run([hostio, "--dump-bam", bam, region], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return [line.split("\t") for line in r.stdout.splitlines()]
+
+
+@pytest.mark.parametrize("region", ["chrX", "chrX:1-1000", "chrX:900-1100", "chrX:8,500-9,000", "chrX:1149", "chrX:5000-6000", "chr1"])
+def test_bam_reader_matches_independent_decoder(hostio, region):
+    bam = os.path.join(SITES, "chrX", "chrX_graph_typing.bam")
+    names, recs = decode_bam(bam)
+    chrom, _, rng = region.partition(":")
+    tid = names.index(chrom)
+    beg, end = 0, 1 << 29
+    if rng:
+        lo, _, hi = rng.replace(",", "").partition("-")
+        beg = int(lo) - 1
+        end = int(hi) if hi else 1 << 29
+    want = [r for r in recs if r["tid"] == tid and r["pos"] < end and r["end"] > beg and not r["flag"] & 0x900]
+    got = dump(hostio, bam, region)
+    assert len(got) == len(want)
+    if region == "chrX":
+        assert len(got) > 400
+    for g, w in zip(got, want):
+        flags = "%d%d%d%d%d" % (not w["flag"] & 4, bool(w["flag"] & 0x40), not w["flag"] & 8, bool(w["flag"] & 0x10), bool(w["flag"] & 0x20))
+        assert g == [w["name"], str(w["tid"]), str(w["pos"]), str(w["mapq"]), flags, str(w["mtid"]), str(w["mpos"]), w["seq"], w["qual"]]

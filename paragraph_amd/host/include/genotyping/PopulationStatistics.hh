@@ -1,0 +1,35 @@
+// Per-breakpoint population summary of a genotype document's "population" block: Hardy-Weinberg p-values (chi-square with one
+// degree of freedom; Wigginton et al. 2005 exact test when two alleles are observed and counts are small), call rate and
+// allele frequencies (genotyping::PopulationStatistics, src/c++/include/genotyping/PopulationStatistics.hh:37-88,
+// lib/genotyping/PopulationStatistics.cpp:37-327; expectations of src/c++/test/test_popstats.cpp:26-95).
+#pragma once
+#include <cstdint>
+#include <map>
+#include <vector>
+
+#include "common/Json.hh"
+#include "genotyping/Genotype.hh"
+
+namespace genotyping
+{
+class PopulationStatistics
+{
+public:
+    explicit PopulationStatistics(GenotypeSet const& genotypes);
+    common::Json toJson() const;  // hwe, hwe_fisher ("" when the exact test does not apply), call_rate, allele_frequencies
+    double getChisqPvalue() const;
+    bool needFisherExactHWE() const;
+    double getFisherExactPvalue() const;
+    double getCallrate() const { return (double)num_valid_samples / num_total_samples; }
+    std::vector<double> getAlleleFrequencies() const;
+    std::vector<uint32_t> const& alleleCounts() const { return allele_counts; }
+
+private:
+    // index of the rarest allele; when some allele has count 0 the scan starts from the commonest one and takes the LAST
+    // strictly smaller entry it meets, zeros included (kept as in the original)
+    size_t minNonZeroAlleleIndex() const;
+    int num_total_samples = 0, num_valid_samples = 0;
+    std::vector<uint32_t> allele_counts;
+    std::map<GenotypeVector, int> genotype_counts;
+};
+}  // namespace genotyping

@@ -53,6 +53,7 @@ struct BatchParameters
     // it leaves unmapped -- or that the filter chain rejects -- go on to the gssw stage (CompositeAligner.cpp:78-103, 152)
     bool path_sequence_matching = false;
     unsigned alignment_flags = (unsigned)-1;
+    int threads = 1;  // host threads for packing the reads and fanning the results back into them
 };
 
 class SiteBatcher

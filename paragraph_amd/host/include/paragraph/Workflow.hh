@@ -4,8 +4,8 @@
 // paragraph::alignAndDisambiguate (lib/paragraph/Disambiguation.cpp:152-361), driven per sample and graph by
 // grmpy::alignSingleSample (lib/grmpy/AlignSamples.cpp:115-172) and grmpy::Workflow::alignSamples (Workflow.cpp:108-146),
 // then grmpy::countAndGenotype (CountAndGenotype.cpp:46-88) per graph.  Here read extraction for ALL pairs runs first on
-// host threads (one BamReader per thread), all pairs go through ONE SiteBatcher::run() on the device, and the count
-// documents and genotypes are assembled from the batch results.
+// host threads (one BamReader per thread), thousands of pairs go through ONE SiteBatcher::run() on the device at a time,
+// and the count documents and genotypes are assembled from the batch results while the next batch's reads are extracted.
 #pragma once
 #include <list>
 #include <memory>
@@ -21,6 +21,14 @@
 
 namespace paragraph
 {
+// wall-clock seconds of the workflow's phases, filled in when a Parameters object points at one
+struct Timings
+{
+    double load_graphs = 0, extract_reads = 0, device_batch = 0, documents = 0, genotypes = 0;
+    double waited_for_input = 0;  // time the device stage stood idle until the next chunk's reads were there (load + extract run ahead)
+    size_t sites = 0, reads = 0, batches = 0;
+};
+
 // paragraph::Parameters (include/paragraph/Parameters.hh:44-126): what to compute and emit for a site
 struct Parameters
 {
@@ -42,6 +50,7 @@ struct Parameters
     bool remove_nonuniq_reads = true;
     int kmer_len = 0;
     int threads = 1;  // host threads for read extraction and document assembly
+    Timings* timings = nullptr;
     bool output_enabled(output_options o) const { return (output_options_ & o) != 0; }
 };
 
@@ -85,6 +94,8 @@ struct Parameters
     bool graph_sequence_matching = true;
     int bad_align_uniq_kmer_len = 0;
     bool output_alignments = false;  // keep "alignments" in the per-sample documents (the original writes them to a folder)
+    size_t sites_per_batch = 4096;   // (graph, sample) pairs per device batch; bounds host memory and sets the pipeline grain
+    paragraph::Timings* timings = nullptr;
 };
 
 // extraction + alignment + counting of ONE sample against ONE graph; stores the count document in the sample
@@ -95,7 +106,8 @@ void alignSingleSample(
 common::Json countAndGenotype(
     std::string const& graph_path, std::string const& reference_path, std::string const& genotyping_parameter_path,
     genotyping::Samples const& samples);
-// every graph x every sample in ONE device batch; returns one genotype document per graph, in the order given
+// every graph x every sample, `sites_per_batch` pairs per device batch, read extraction of the next batch running ahead
+// of the device; returns one genotype document per graph, in the order given
 std::vector<common::Json> genotypeGraphs(
     Parameters const& parameters, std::vector<std::string> const& graph_paths, std::string const& reference_path,
     genotyping::Samples const& samples, std::string const& genotyping_parameter_path);

@@ -2,7 +2,8 @@
 // table.  Re-implements, with the reference's names and semantics,
 //   lib/genotyping/Genotype.cpp, GenotypeSet.cpp, GenotypingParameters.cpp:37-84, 198-280, BreakpointGenotyper.cpp:41-255,
 //   BreakpointStatistics.cpp:45-176, BreakpointFinder.cpp:49-76, CombinedGenotype.cpp:45-265,
-//   GraphGenotyper.cpp:64-86, 378-421, GraphBreakpointGenotyper.cpp:42-115, lib/grmpy/CountAndGenotype.cpp:55-70.
+//   GraphGenotyper.cpp:64-86, 378-421, GraphBreakpointGenotyper.cpp:42-115, PopulationStatistics.cpp:37-327,
+//   lib/grmpy/CountAndGenotype.cpp:55-70.
 // boost::math's poisson pdf / cdf and normal cdf are written out with lgamma / erfc.  No device code: a few hundred
 // floating-point operations per site.
 #include <algorithm>
@@ -22,6 +23,7 @@
 #include "genotyping/Genotype.hh"
 #include "genotyping/GenotypingParameters.hh"
 #include "genotyping/GraphBreakpointGenotyper.hh"
+#include "genotyping/PopulationStatistics.hh"
 
 using std::string;
 using std::vector;
@@ -725,5 +727,147 @@ void GraphBreakpointGenotyper::runGenotyping()
             depth_readlength.first, depth_readlength.second, depth_sds[sample_index], p_genotype_parameter->usePoissonDepth());
         graph_genotypes[std::make_pair(samplenames[sample_index], string(""))] = combinedGenotype(all_breakpoint_gts, &b_param, &genotyper);
     }
+}
+// --------------------------------------------------------------------------------------------------- PopulationStatistics
+PopulationStatistics::PopulationStatistics(GenotypeSet const& genotypes) : num_total_samples((int)genotypes.size())
+{
+    for (Genotype const& g : genotypes)
+    {
+        if (g.gt.empty())
+            continue;
+        ++num_valid_samples;
+        ++genotype_counts[g.gt];
+        for (uint64_t allele : g.gt)
+        {
+            if (allele_counts.size() <= allele)
+                allele_counts.resize(allele + 1, 0);
+            ++allele_counts[allele];
+        }
+    }
+}
+
+common::Json PopulationStatistics::toJson() const
+{
+    common::Json out = common::Json::object();
+    out["hwe"] = getChisqPvalue();
+    if (needFisherExactHWE())
+        out["hwe_fisher"] = getFisherExactPvalue();
+    else
+        out["hwe_fisher"] = "";
+    out["call_rate"] = getCallrate();
+    out["allele_frequencies"] = common::Json::array();
+    for (double f : getAlleleFrequencies())
+        out["allele_frequencies"].append(f);
+    return out;
+}
+
+double PopulationStatistics::getChisqPvalue() const
+{
+    const double n = num_valid_samples;
+    double chisq = 0;
+    for (auto const& gc : genotype_counts)
+    {
+        if (gc.first.size() != 2)
+            continue;
+        const uint64_t h1 = gc.first[0], h2 = gc.first[1];
+        if (allele_counts[h1] == 0 || allele_counts[h2] == 0)
+            continue;
+        const double f1 = (double)allele_counts[h1] / n / 2, f2 = (double)allele_counts[h2] / n / 2;
+        const double expected = h1 == h2 ? f1 * f1 * n : 2 * f1 * f2 * n;
+        const double diff = expected - gc.second;
+        chisq += diff * diff / expected;
+    }
+    // 1 - cdf of chi-square with one degree of freedom
+    return std::erfc(std::sqrt(chisq / 2));
+}
+
+bool PopulationStatistics::needFisherExactHWE() const
+{
+    const auto observed = std::count_if(allele_counts.begin(), allele_counts.end(), [](uint32_t a) { return a > 0; });
+    if (observed != 2)
+        return false;
+    if (num_valid_samples <= 30)
+        return true;
+    for (auto const& gc : genotype_counts)
+        if (gc.second > 0 && gc.second <= 20)
+            return true;
+    const double maf = (double)allele_counts[minNonZeroAlleleIndex()] / 2 / num_valid_samples;
+    return maf * maf * num_valid_samples <= 20;
+}
+
+double PopulationStatistics::getFisherExactPvalue() const
+{
+    const size_t minor = minNonZeroAlleleIndex();
+    const auto major_it = std::max_element(allele_counts.begin(), allele_counts.end());
+    const int minor_count = (int)allele_counts[minor], major_count = (int)*major_it;
+    GenotypeVector het = { (uint64_t)(major_it - allele_counts.begin()), (uint64_t)minor };
+    std::sort(het.begin(), het.end());
+    int observed_het = 0;
+    for (auto const& gc : genotype_counts)
+        if (gc.first.size() == 2 && gc.first[0] == het[0] && gc.first[1] == het[1])
+        {
+            observed_het = gc.second;
+            break;
+        }
+    const double n = num_valid_samples;
+    const int expected_het = (int)std::round(2 * ((double)minor_count / n / 2) * ((double)major_count / n / 2) * n);
+
+    // probabilities of every heterozygote count with the parity of the expectation, relative to the expectation's own;
+    // walked upwards, then downwards, by the recurrence of the exact test
+    vector<double> scaled = { 1 };
+    double observed_scaled = -1;
+    int rare_hom = (minor_count - expected_het) / 2, common_hom = num_valid_samples - rare_hom - expected_het;
+    double prev = 1;
+    for (int hets = expected_het + 2; hets <= minor_count; hets += 2)
+    {
+        const int below = hets - 2;
+        prev = prev * (4 * rare_hom * common_hom) / ((below + 2) * (below + 1));
+        scaled.push_back(prev);
+        --rare_hom;
+        --common_hom;
+        if (observed_scaled == -1 && hets == observed_het)
+            observed_scaled = prev;
+    }
+    rare_hom = (minor_count - expected_het) / 2;
+    common_hom = num_valid_samples - rare_hom - expected_het;
+    prev = 1;
+    for (int hets = expected_het - 2; hets >= 0; hets -= 2)
+    {
+        const int above = hets + 2;
+        prev = prev / 4 * above / (rare_hom + 1) * (above - 1) / (common_hom + 1);
+        scaled.push_back(prev);
+        ++rare_hom;
+        ++common_hom;
+        if (observed_scaled == -1 && hets == observed_het)
+            observed_scaled = prev;
+    }
+    double at_most_observed = 0;
+    for (double s : scaled)
+        if (s <= observed_scaled)
+            at_most_observed += s;
+    return at_most_observed / std::accumulate(scaled.begin(), scaled.end(), 0.0);
+}
+
+vector<double> PopulationStatistics::getAlleleFrequencies() const
+{
+    const uint32_t sum = std::accumulate(allele_counts.begin(), allele_counts.end(), (uint32_t)0);
+    vector<double> out;
+    for (uint32_t ac : allele_counts)
+        out.push_back(sum > 0 ? (double)ac / sum : 0.0);
+    return out;
+}
+
+size_t PopulationStatistics::minNonZeroAlleleIndex() const
+{
+    auto pick = std::min_element(allele_counts.begin(), allele_counts.end());
+    if (*pick > 0)
+        return (size_t)(pick - allele_counts.begin());
+    pick = std::max_element(allele_counts.begin(), allele_counts.end());
+    if (*pick == 0)
+        return 0;
+    for (auto it = allele_counts.begin(); it != allele_counts.end(); ++it)
+        if (*it < *pick)
+            pick = it;
+    return (size_t)(pick - allele_counts.begin());
 }
 }  // namespace genotyping

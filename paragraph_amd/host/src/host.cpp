@@ -3,6 +3,8 @@
 // No alignment arithmetic happens on the host and there is no CPU fallback: without a device every call throws.
 #include <algorithm>
 #include <cctype>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <stdexcept>
@@ -15,6 +17,7 @@
 #include "grm/KmerAligner.hh"
 #include "grm/PathAligner.hh"
 #include "paragraph/SiteBatcher.hh"
+#include "parallel.hh"
 
 using common::Read;
 using graphtools::Graph;
@@ -665,6 +668,16 @@ void SiteBatcher::run(BatchParameters const& prm)
         return;
     pg_ctx* ctx = deviceContext();
     std::lock_guard<std::mutex> lock(deviceMutex());
+    // PG_BATCH_TIMING=1: wall-clock of the phases of this call on stderr
+    const bool timing = std::getenv("PG_BATCH_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!timing)
+            return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[SiteBatcher] %-18s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     GraphCsr csr;
     for (const Graph* g : impl_->graphs)
         csr.add(*g);
@@ -688,25 +701,43 @@ void SiteBatcher::run(BatchParameters const& prm)
     check(ctx, pg_graphs_set_labels(ctx, G, csr.label_mask.empty() ? nullptr : csr.label_mask.data(), csr.n_labels.data()),
           "pg_graphs_set_labels");
 
-    std::vector<uint32_t> base_off{ 0 }, gor, frag;
-    std::vector<uint8_t> is_rev;
-    std::vector<Read*> flat;
-    std::string bases;
+    mark("graphs");
+    // ---- pack the reads of all sites: offsets first, then every site fills its own slice --------------------
+    std::vector<uint64_t> site_read0(n_sites + 1, 0), site_base0(n_sites + 1, 0);
     for (size_t s = 0; s < n_sites; ++s)
     {
-        std::unordered_map<std::string, uint32_t> frag_ids;  // fragment ids are local to a site
-        for (auto& r : *impl_->reads[s])
-        {
-            flat.push_back(r.get());
-            bases += r->bases();
-            base_off.push_back((uint32_t)bases.size());
-            gor.push_back((uint32_t)s);
-            auto it = frag_ids.emplace(r->fragment_id(), (uint32_t)frag_ids.size()).first;
-            frag.push_back(it->second);
-            is_rev.push_back(r->is_reverse_strand() ? 1 : 0);
-            r->set_graph_mapping_status(Read::UNMAPPED);
-        }
+        uint64_t site_bases = 0;
+        for (auto const& r : *impl_->reads[s])
+            site_bases += r->bases().size();
+        site_read0[s + 1] = site_read0[s] + impl_->reads[s]->size();
+        site_base0[s + 1] = site_base0[s] + site_bases;
     }
+    if (site_read0[n_sites] > 0xFFFFFFFFull || site_base0[n_sites] > 0xFFFFFFFFull)
+        throw std::runtime_error("SiteBatcher: more than 2^32 reads or bases in one batch");
+    std::vector<uint32_t> base_off(site_read0[n_sites] + 1, 0), gor(site_read0[n_sites]), frag(site_read0[n_sites]);
+    std::vector<uint8_t> is_rev(site_read0[n_sites]);
+    std::vector<Read*> flat(site_read0[n_sites]);
+    std::string bases(site_base0[n_sites], '\0');
+    pghost::parallelFor(
+        n_sites, prm.threads,
+        [&](size_t s) {
+            std::unordered_map<std::string, uint32_t> frag_ids;  // fragment ids are local to a site
+            uint64_t i = site_read0[s], at = site_base0[s];
+            for (auto& r : *impl_->reads[s])
+            {
+                flat[i] = r.get();
+                std::copy(r->bases().begin(), r->bases().end(), bases.begin() + (std::ptrdiff_t)at);
+                at += r->bases().size();
+                base_off[i + 1] = (uint32_t)at;
+                gor[i] = (uint32_t)s;
+                frag[i] = frag_ids.emplace(r->fragment_id(), (uint32_t)frag_ids.size()).first->second;
+                is_rev[i] = r->is_reverse_strand() ? 1 : 0;
+                r->set_graph_mapping_status(Read::UNMAPPED);
+                ++i;
+            }
+        },
+        8);
+    mark("pack reads");
     const uint32_t n = (uint32_t)flat.size();
     check(ctx, pg_batch_create(ctx, &guard.b), "pg_batch_create");
     check(ctx, pg_batch_upload(ctx, guard.b, G, n, gor.data(), base_off.data(), bases.data()), "pg_batch_upload");
@@ -740,6 +771,7 @@ void SiteBatcher::run(BatchParameters const& prm)
         // keep the path-stage records of the finished reads (the extension flag is ignored when flags == PG_AF_ALL)
         align_flags = (align_flags & (PG_AF_CIGAR | PG_AF_BOTH_STRANDS | PG_AF_REVERSE_GRAPH)) | PG_AF_KEEP_RESULTS;
     }
+    mark("upload (+ path)");
     check(ctx, pg_batch_align(ctx, guard.b, align_flags), "pg_batch_align");
     check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
 
@@ -759,57 +791,61 @@ void SiteBatcher::run(BatchParameters const& prm)
     check(ctx, pg_batch_download_counts(ctx, guard.b, table.data(), sup.data(), path.data(), path.size(), &n_path),
           "pg_batch_download_counts");
 
+    mark("align+count+download");
     // ---- fan results back into the reads ---------------------------------------------------------------
-    for (uint32_t i = 0; i < n; ++i)
-    {
-        Read& read = *flat[i];
-        if (read.bases().empty() || sup[i].status == 0)
-            continue;
-        if (sup[i].status == 3)
-            throw std::runtime_error("invalid alignment on the device path for fragment " + read.fragment_id());
-        if (res[i].status & PG_STATUS_PATH_ALIGNER)
-        {
-            // PathAligner.cpp:121-161: the match's own strand, bases replaced, qualities untouched
-            if (res[i].returned_reverse)
-                read.set_bases(reverseComplement(read.bases()));
-            read.set_is_graph_reverse_strand(res[i].returned_reverse != 0);
-            std::string buf(16 + 12 * (size_t)res[i].n_ops, '\0');
-            buf.resize(pg_render_cigar(&res[i], ops.data(), &buf[0], buf.size()));
-            read.set_graph_cigar(buf);
-            read.set_graph_pos(res[i].graph_pos);
-            read.set_graph_alignment_score(res[i].score);
-            read.set_is_graph_alignment_unique(res[i].is_unique != 0);
-            read.set_graph_mapq(res[i].mapq);
-        }
-        else
-            applyResult(read, res[i], ops.data(), true);
-        read.set_graph_mapping_status(sup[i].status == 1 ? Read::MAPPED : Read::BAD_ALIGN);
-        read.clear_graph_nodes_supported();
-        read.clear_graph_edges_supported();
-        read.clear_graph_sequences_supported();
-        if (sup[i].status != 1)
-            continue;
-        const Graph& g = *impl_->graphs[gor[i]];
-        uint32_t prev = 0;
-        std::vector<std::pair<std::string, std::string>> edges;
-        for (uint32_t k = 0; k < sup[i].n_path; ++k)
-        {
-            const uint32_t en = path[sup[i].path_off + k];
-            const uint32_t nd = PG_PATH_NODE(en);
-            if (PG_PATH_NODE_OK(en))
-                read.add_graph_nodes_supported(g.nodeName(nd));
-            if (k > 0 && PG_PATH_EDGE_OK(en))
-                edges.emplace_back(g.nodeName(prev), g.nodeName(nd));
-            prev = nd;
-        }
-        std::sort(edges.begin(), edges.end());  // the reference collects them in a std::set of name pairs
-        for (auto const& e : edges)
-            read.add_graph_edges_supported(e.first + "_" + e.second);
-        const auto& names = csr.label_names[gor[i]];
-        for (size_t b = 0; b < names.size(); ++b)
-            if ((sup[i].label_mask >> b) & 1)
-                read.add_graph_sequences_supported(names[b]);
-    }
+    pghost::parallelFor(
+        n, prm.threads,
+        [&](size_t i) {
+            Read& read = *flat[i];
+            if (read.bases().empty() || sup[i].status == 0)
+                return;
+            if (sup[i].status == 3)
+                throw std::runtime_error("invalid alignment on the device path for fragment " + read.fragment_id());
+            if (res[i].status & PG_STATUS_PATH_ALIGNER)
+            {
+                // PathAligner.cpp:121-161: the match's own strand, bases replaced, qualities untouched
+                if (res[i].returned_reverse)
+                    read.set_bases(reverseComplement(read.bases()));
+                read.set_is_graph_reverse_strand(res[i].returned_reverse != 0);
+                std::string buf(16 + 12 * (size_t)res[i].n_ops, '\0');
+                buf.resize(pg_render_cigar(&res[i], ops.data(), &buf[0], buf.size()));
+                read.set_graph_cigar(buf);
+                read.set_graph_pos(res[i].graph_pos);
+                read.set_graph_alignment_score(res[i].score);
+                read.set_is_graph_alignment_unique(res[i].is_unique != 0);
+                read.set_graph_mapq(res[i].mapq);
+            }
+            else
+                applyResult(read, res[i], ops.data(), true);
+            read.set_graph_mapping_status(sup[i].status == 1 ? Read::MAPPED : Read::BAD_ALIGN);
+            read.clear_graph_nodes_supported();
+            read.clear_graph_edges_supported();
+            read.clear_graph_sequences_supported();
+            if (sup[i].status != 1)
+                return;
+            const Graph& g = *impl_->graphs[gor[i]];
+            uint32_t prev = 0;
+            std::vector<std::pair<std::string, std::string>> edges;
+            for (uint32_t k = 0; k < sup[i].n_path; ++k)
+            {
+                const uint32_t en = path[sup[i].path_off + k];
+                const uint32_t nd = PG_PATH_NODE(en);
+                if (PG_PATH_NODE_OK(en))
+                    read.add_graph_nodes_supported(g.nodeName(nd));
+                if (k > 0 && PG_PATH_EDGE_OK(en))
+                    edges.emplace_back(g.nodeName(prev), g.nodeName(nd));
+                prev = nd;
+            }
+            std::sort(edges.begin(), edges.end());  // the reference collects them in a std::set of name pairs
+            for (auto const& e : edges)
+                read.add_graph_edges_supported(e.first + "_" + e.second);
+            const auto& names = csr.label_names[gor[i]];
+            for (size_t b = 0; b < names.size(); ++b)
+                if ((sup[i].label_mask >> b) & 1)
+                    read.add_graph_sequences_supported(names[b]);
+        },
+        512);
+    mark("results -> reads");
     // ---- per-site tables --------------------------------------------------------------------------------
     auto entry = [&](uint64_t off) {
         CountEntry e;
@@ -819,48 +855,51 @@ void SiteBatcher::run(BatchParameters const& prm)
         e.rev = table[off + 3];
         return e;
     };
-    for (size_t s = 0; s < n_sites; ++s)
-    {
-        const Graph& g = *impl_->graphs[s];
-        SiteCounts& sc = impl_->counts[s];
-        const uint32_t nb = csr.node_off[s];
-        for (NodeId nd = 0; nd != g.numNodes(); ++nd)
-        {
-            CountEntry e = entry(lay.node_base + 4ull * (nb + nd));
-            if (e.count)
-                sc.by_node[g.nodeName(nd)] = e;
-            for (uint32_t q = csr.pred_off[nb + nd]; q < csr.pred_off[nb + nd + 1]; ++q)
+    pghost::parallelFor(
+        n_sites, prm.threads,
+        [&](size_t s) {
+            const Graph& g = *impl_->graphs[s];
+            SiteCounts& sc = impl_->counts[s];
+            const uint32_t nb = csr.node_off[s];
+            for (NodeId nd = 0; nd != g.numNodes(); ++nd)
             {
-                CountEntry ee = entry(lay.edge_base + 4ull * q);
-                if (ee.count)
-                    sc.by_edge[g.nodeName(csr.pred[q]) + "_" + g.nodeName(nd)] = ee;
+                CountEntry e = entry(lay.node_base + 4ull * (nb + nd));
+                if (e.count)
+                    sc.by_node[g.nodeName(nd)] = e;
+                for (uint32_t q = csr.pred_off[nb + nd]; q < csr.pred_off[nb + nd + 1]; ++q)
+                {
+                    CountEntry ee = entry(lay.edge_base + 4ull * q);
+                    if (ee.count)
+                        sc.by_edge[g.nodeName(csr.pred[q]) + "_" + g.nodeName(nd)] = ee;
+                }
             }
-        }
-        const auto& names = csr.label_names[s];
-        for (uint64_t m = 1; m < seq_off[s + 1] - seq_off[s]; ++m)
-        {
-            CountEntry e = entry(lay.seq_base + 4ull * (seq_off[s] + m));
-            if (!e.count)
-                continue;
-            std::string key;
-            for (size_t b = 0; b < names.size(); ++b)
-                if ((m >> b) & 1)
-                    key += (key.empty() ? "" : ",") + names[b];  // names are sorted -> sorted join
-            sc.by_sequence[key] = e;
-        }
-        const uint64_t t = lay.tally_base + 4ull * s;
-        sc.aligned = table[t] & 0x7FFFFFFFu;
-        sc.mapped = table[t + 1];
-        sc.bad_align = table[t + 2];
-        sc.nonuniq = table[t + 3];
-        if (table[t] >> 31)
-            throw std::runtime_error("a fragment touched more than 48 distinct nodes/edges (device count-table limit)");
-        // only MAPPED reads survive (Align.cpp:155)
-        std::vector<common::p_Read> kept;
-        for (auto& r : *impl_->reads[s])
-            if (!r->bases().empty() && r->graph_mapping_status() == Read::MAPPED)
-                kept.emplace_back(std::move(r));
-        impl_->reads[s]->swap(kept);
-    }
+            const auto& names = csr.label_names[s];
+            for (uint64_t m = 1; m < seq_off[s + 1] - seq_off[s]; ++m)
+            {
+                CountEntry e = entry(lay.seq_base + 4ull * (seq_off[s] + m));
+                if (!e.count)
+                    continue;
+                std::string key;
+                for (size_t b = 0; b < names.size(); ++b)
+                    if ((m >> b) & 1)
+                        key += (key.empty() ? "" : ",") + names[b];  // names are sorted -> sorted join
+                sc.by_sequence[key] = e;
+            }
+            const uint64_t t = lay.tally_base + 4ull * s;
+            sc.aligned = table[t] & 0x7FFFFFFFu;
+            sc.mapped = table[t + 1];
+            sc.bad_align = table[t + 2];
+            sc.nonuniq = table[t + 3];
+            if (table[t] >> 31)
+                throw std::runtime_error("a fragment touched more than 48 distinct nodes/edges (device count-table limit)");
+            // only MAPPED reads survive (Align.cpp:155)
+            std::vector<common::p_Read> kept;
+            for (auto& r : *impl_->reads[s])
+                if (!r->bases().empty() && r->graph_mapping_status() == Read::MAPPED)
+                    kept.emplace_back(std::move(r));
+            impl_->reads[s]->swap(kept);
+        },
+        8);
+    mark("site tables");
 }
 }  // namespace paragraph

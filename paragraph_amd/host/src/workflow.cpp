@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <set>
 #include <sstream>
@@ -14,52 +15,22 @@
 #include "common/ReadExtraction.hh"
 #include "genotyping/BreakpointStatistics.hh"
 #include "genotyping/GraphBreakpointGenotyper.hh"
+#include "genotyping/PopulationStatistics.hh"
 #include "grm/GraphInput.hh"
 #include "paragraph/SiteBatcher.hh"
 #include "paragraph/Statistics.hh"
+#include "parallel.hh"
 
 using common::Json;
 
 namespace
 {
-// run fn(i) for i in [0, n) on up to `threads` host threads; the first exception is rethrown on the caller
-template <typename Fn> void parallelFor(size_t n, int threads, Fn fn)
+double now()
 {
-    const size_t workers = std::max<size_t>(1, std::min<size_t>((size_t)std::max(threads, 1), n));
-    if (workers == 1)
-    {
-        for (size_t i = 0; i < n; ++i)
-            fn(i);
-        return;
-    }
-    std::atomic<size_t> next(0);
-    std::exception_ptr failure;
-    std::atomic<bool> failed(false);
-    std::vector<std::thread> pool;
-    for (size_t w = 0; w < workers; ++w)
-        pool.emplace_back([&] {
-            for (;;)
-            {
-                const size_t i = next.fetch_add(1);
-                if (i >= n || failed.load())
-                    return;
-                try
-                {
-                    fn(i);
-                }
-                catch (...)
-                {
-                    if (!failed.exchange(true))
-                        failure = std::current_exception();
-                    return;
-                }
-            }
-        });
-    for (auto& t : pool)
-        t.join();
-    if (failure)
-        std::rethrow_exception(failure);
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+
+using pghost::parallelFor;
 }  // namespace
 
 namespace paragraph
@@ -194,8 +165,11 @@ std::vector<Json> alignAndDisambiguateBatch(Parameters const& parameters, std::v
     bp.bad_align_frac = parameters.bad_align_frac;
     bp.kmer_len = parameters.kmer_len;
     bp.path_sequence_matching = parameters.path_sequence_matching;
+    bp.threads = parameters.threads;
+    const double t_batch = now();
     if (!sites.empty())
         batcher.run(bp);
+    const double t_documents = now();
 
     std::vector<Json> documents(sites.size());
     parallelFor(sites.size(), parameters.threads, [&](size_t s) {
@@ -247,6 +221,14 @@ std::vector<Json> alignAndDisambiguateBatch(Parameters const& parameters, std::v
         }
         documents[s] = std::move(out);
     });
+    if (parameters.timings)
+    {
+        parameters.timings->device_batch += t_documents - t_batch;
+        parameters.timings->documents += now() - t_documents;
+        parameters.timings->sites += sites.size();
+        for (size_t n : reads_in)
+            parameters.timings->reads += n;
+    }
     return documents;
 }
 
@@ -272,6 +254,7 @@ paragraph::Parameters siteParameters(Parameters const& p)
     sp.graph_sequence_matching = p.graph_sequence_matching;
     sp.kmer_len = p.bad_align_uniq_kmer_len;
     sp.threads = p.threads;
+    sp.timings = p.timings;
     sp.output_options_ = paragraph::Parameters::NODE_READ_COUNTS | paragraph::Parameters::EDGE_READ_COUNTS
         | paragraph::Parameters::PATH_READ_COUNTS | paragraph::Parameters::DETAILED_READ_COUNTS;
     if (p.output_alignments)
@@ -339,7 +322,7 @@ std::map<std::string, int32_t> edgeCounts(Json const& doc)
     return out;
 }
 
-// GraphGenotyper::addAlignment + getGenotypes (lib/genotyping/GraphGenotyper.cpp:88-330) without the "population" block
+// GraphGenotyper::addAlignment + getGenotypes (lib/genotyping/GraphGenotyper.cpp:88-337)
 Json genotypeDocument(
     graphtools::Graph const& graph, Json const& root, std::string const& genotyping_parameter_path,
     std::vector<genotyping::SampleInfo const*> const& samples, std::vector<Json const*> const& documents)
@@ -425,13 +408,16 @@ Json genotypeDocument(
     }
     genotyper.runGenotyping();
     auto const& allele_names = genotyper.alleleNames();
+    std::map<std::string, genotyping::GenotypeSet> by_breakpoint;  // "" = the combined genotype
     for (size_t i = 0; i < samples.size(); ++i)
     {
         const std::string name = samples[i]->sample_name();
         Json& entry = result["samples"][name];
         entry["breakpoints"] = Json::object();
+        by_breakpoint[""].add(allele_names, genotyper.getGenotype(name, ""));
         for (auto const& bp : breakpoints)
         {
+            by_breakpoint[bp.first].add(allele_names, genotyper.getGenotype(name, bp.first));
             Json bj = Json::object();
             bj["gt"] = genotypeToJson(genotyper.getGenotype(name, bp.first), allele_names);
             Json counts = Json::object();
@@ -445,6 +431,14 @@ Json genotypeDocument(
             entry["breakpoints"][bp.first] = bj;
         }
         entry["gt"] = genotypeToJson(genotyper.getGenotype(name, ""), allele_names);
+    }
+    if (samples.size() > 1)
+    {
+        Json pop = genotyping::PopulationStatistics(by_breakpoint[""]).toJson();
+        for (auto const& kv : by_breakpoint)
+            if (!kv.first.empty())
+                pop["breakpoints"][kv.first] = genotyping::PopulationStatistics(kv.second).toJson();
+        result["population"] = pop;
     }
     return result;
 }
@@ -481,78 +475,164 @@ Json countAndGenotype(
     return genotypeDocument(graph, flat, genotyping_parameter_path, sample_ptrs, docs);
 }
 
+namespace
+{
+// graphs [g0, g1) x all samples, loaded and with their reads extracted: the unit that moves through the pipeline
+struct Chunk
+{
+    size_t g0 = 0, g1 = 0;
+    std::vector<paragraph::GraphDescription> graphs;
+    std::vector<common::ReadBuffer> reads;  // [(g - g0) * n_samples + s]
+    double load_s = 0, extract_s = 0;
+};
+
+std::unique_ptr<Chunk> prepareChunk(
+    Parameters const& parameters, std::vector<std::string> const& graph_paths, std::string const& reference_path,
+    genotyping::Samples const& samples, size_t g0, size_t g1, int threads)
+{
+    std::unique_ptr<Chunk> chunk(new Chunk);
+    chunk->g0 = g0;
+    chunk->g1 = g1;
+    const size_t n_graphs = g1 - g0, n_samples = samples.size();
+    chunk->graphs.resize(n_graphs);
+    const double t_load = now();
+    parallelFor(n_graphs, threads, [&](size_t g) { chunk->graphs[g] = paragraph::GraphDescription::load(graph_paths[g0 + g], reference_path); });
+    const double t_extract = now();
+    chunk->load_s = t_extract - t_load;
+
+    // tasks in sample-major order so a worker mostly stays on one BAM; every worker owns its readers
+    chunk->reads.resize(n_graphs * n_samples);
+    const size_t n_tasks = n_graphs * n_samples;
+    const size_t workers = std::max<size_t>(1, std::min<size_t>((size_t)std::max(threads, 1), n_tasks));
+    std::atomic<size_t> next(0);
+    std::exception_ptr failure;
+    std::atomic<bool> failed(false);
+    auto work = [&] {
+        std::map<size_t, std::unique_ptr<common::BamReader>> readers;
+        try
+        {
+            for (;;)
+            {
+                const size_t task = next.fetch_add(1);
+                if (task >= n_tasks || failed.load())
+                    return;
+                const size_t s = task / n_graphs, g = task % n_graphs;
+                auto& reader = readers[s];
+                if (!reader)
+                    reader.reset(new common::BamReader(samples[s].filename(), samples[s].index_filename(), reference_path));
+                paragraph::GraphDescription const& d = chunk->graphs[g];
+                const int max_reads = d.max_reads >= 0 ? (int)d.max_reads : parameters.max_reads;
+                common::extractReads(*reader, d.target_regions, max_reads, (unsigned)d.longest_alt_insertion, chunk->reads[g * n_samples + s]);
+            }
+        }
+        catch (...)
+        {
+            if (!failed.exchange(true))
+                failure = std::current_exception();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t w = 1; w < workers; ++w)
+        pool.emplace_back(work);
+    work();
+    for (auto& t : pool)
+        t.join();
+    if (failure)
+        std::rethrow_exception(failure);
+    chunk->extract_s = now() - t_extract;
+    return chunk;
+}
+}  // namespace
+
 std::vector<Json> genotypeGraphs(
     Parameters const& parameters, std::vector<std::string> const& graph_paths, std::string const& reference_path,
     genotyping::Samples const& samples, std::string const& genotyping_parameter_path)
 {
     const size_t n_graphs = graph_paths.size(), n_samples = samples.size();
-    std::vector<paragraph::GraphDescription> graphs(n_graphs);
-    parallelFor(n_graphs, parameters.threads, [&](size_t g) { graphs[g] = paragraph::GraphDescription::load(graph_paths[g], reference_path); });
+    std::vector<Json> genotypes(n_graphs);
+    if (n_graphs == 0 || n_samples == 0)
+        return genotypes;
+    const size_t per_batch = std::max<size_t>(1, parameters.sites_per_batch / n_samples);
+    const paragraph::Parameters site_parameters = siteParameters(parameters);
 
-    // extraction: tasks in sample-major order so a worker mostly stays on one BAM; every worker owns its readers
-    std::vector<common::ReadBuffer> reads(n_graphs * n_samples);
+    // Two stages, double-buffered: while the device batch of chunk k runs (and its documents / genotypes are put
+    // together), a helper thread already loads the graphs and extracts the reads of chunk k + 1.
+    struct Prefetch
     {
-        const size_t workers = std::max<size_t>(1, std::min<size_t>((size_t)std::max(parameters.threads, 1), n_graphs * n_samples));
-        std::atomic<size_t> next(0);
+        std::thread thread;
+        std::unique_ptr<Chunk> chunk;
         std::exception_ptr failure;
-        std::atomic<bool> failed(false);
-        auto work = [&] {
-            std::map<size_t, std::unique_ptr<common::BamReader>> readers;
+        void join()
+        {
+            if (thread.joinable())
+                thread.join();
+            if (failure)
+                std::rethrow_exception(failure);
+        }
+        ~Prefetch()
+        {
+            if (thread.joinable())
+                thread.join();
+        }
+    };
+    auto launch = [&](Prefetch& slot, size_t g0) {
+        const size_t g1 = std::min(n_graphs, g0 + per_batch);
+        slot.thread = std::thread([&slot, &parameters, &graph_paths, &reference_path, &samples, g0, g1] {
             try
             {
-                for (;;)
-                {
-                    const size_t task = next.fetch_add(1);
-                    if (task >= n_graphs * n_samples || failed.load())
-                        return;
-                    const size_t s = task / n_graphs, g = task % n_graphs;
-                    auto& reader = readers[s];
-                    if (!reader)
-                        reader.reset(new common::BamReader(samples[s].filename(), samples[s].index_filename(), reference_path));
-                    const int max_reads = graphs[g].max_reads >= 0 ? (int)graphs[g].max_reads : parameters.max_reads;
-                    common::extractReads(
-                        *reader, graphs[g].target_regions, max_reads, (unsigned)graphs[g].longest_alt_insertion, reads[g * n_samples + s]);
-                }
+                slot.chunk = prepareChunk(parameters, graph_paths, reference_path, samples, g0, g1, parameters.threads);
             }
             catch (...)
             {
-                if (!failed.exchange(true))
-                    failure = std::current_exception();
+                slot.failure = std::current_exception();
             }
-        };
-        std::vector<std::thread> pool;
-        for (size_t w = 1; w < workers; ++w)
-            pool.emplace_back(work);
-        work();
-        for (auto& t : pool)
-            t.join();
-        if (failure)
-            std::rethrow_exception(failure);
+        });
+    };
+    Prefetch ahead;
+    launch(ahead, 0);
+    for (size_t g0 = 0; g0 < n_graphs; g0 += per_batch)
+    {
+        const double t_wait = now();
+        ahead.join();
+        std::unique_ptr<Chunk> chunk = std::move(ahead.chunk);
+        const double waited = now() - t_wait;
+        if (chunk->g1 < n_graphs)
+            launch(ahead, chunk->g1);  // the slot's previous thread has been joined: safe to re-arm
+        const size_t n_here = chunk->g1 - chunk->g0;
+        std::vector<paragraph::SiteInput> sites(n_here * n_samples);
+        for (size_t i = 0; i < sites.size(); ++i)
+        {
+            sites[i].description = &chunk->graphs[i / n_samples];
+            sites[i].reads = &chunk->reads[i];
+        }
+        std::vector<Json> documents = paragraph::alignAndDisambiguateBatch(site_parameters, sites);
+        for (size_t i = 0; i < documents.size(); ++i)
+            finishSampleDocument(documents[i], samples[i % n_samples].filename(), parameters.output_alignments);
+
+        const double t_genotype = now();
+        parallelFor(n_here, parameters.threads, [&](size_t g) {
+            std::vector<genotyping::SampleInfo const*> sample_ptrs;
+            std::vector<Json const*> docs;
+            for (size_t s = 0; s < n_samples; ++s)
+            {
+                sample_ptrs.push_back(&samples[s]);
+                docs.push_back(&documents[g * n_samples + s]);
+            }
+            genotypes[chunk->g0 + g]
+                = genotypeDocument(*chunk->graphs[g].graph, chunk->graphs[g].description, genotyping_parameter_path, sample_ptrs, docs);
+        });
+        // hundreds of thousands of small strings: give them back on all threads rather than in one destructor
+        parallelFor(chunk->reads.size(), parameters.threads, [&](size_t i) { common::ReadBuffer().swap(chunk->reads[i]); }, 16);
+        parallelFor(documents.size(), parameters.threads, [&](size_t i) { documents[i] = Json(); }, 16);
+        if (parameters.timings)
+        {
+            parameters.timings->load_graphs += chunk->load_s;
+            parameters.timings->extract_reads += chunk->extract_s;
+            parameters.timings->waited_for_input += waited;
+            parameters.timings->genotypes += now() - t_genotype;
+            parameters.timings->batches += 1;
+        }
     }
-
-    std::vector<paragraph::SiteInput> sites(n_graphs * n_samples);
-    for (size_t g = 0; g < n_graphs; ++g)
-        for (size_t s = 0; s < n_samples; ++s)
-        {
-            sites[g * n_samples + s].description = &graphs[g];
-            sites[g * n_samples + s].reads = &reads[g * n_samples + s];
-        }
-    std::vector<Json> documents = paragraph::alignAndDisambiguateBatch(siteParameters(parameters), sites);
-    for (size_t g = 0; g < n_graphs; ++g)
-        for (size_t s = 0; s < n_samples; ++s)
-            finishSampleDocument(documents[g * n_samples + s], samples[s].filename(), parameters.output_alignments);
-
-    std::vector<Json> genotypes(n_graphs);
-    parallelFor(n_graphs, parameters.threads, [&](size_t g) {
-        std::vector<genotyping::SampleInfo const*> sample_ptrs;
-        std::vector<Json const*> docs;
-        for (size_t s = 0; s < n_samples; ++s)
-        {
-            sample_ptrs.push_back(&samples[s]);
-            docs.push_back(&documents[g * n_samples + s]);
-        }
-        genotypes[g] = genotypeDocument(*graphs[g].graph, graphs[g].description, genotyping_parameter_path, sample_ptrs, docs);
-    });
     return genotypes;
 }
 }  // namespace grmpy

@@ -16,6 +16,7 @@
 #include "genotyping/BreakpointStatistics.hh"
 #include "genotyping/CombinedGenotype.hh"
 #include "genotyping/GraphBreakpointGenotyper.hh"
+#include "genotyping/PopulationStatistics.hh"
 
 using namespace genotyping;
 using std::string;
@@ -296,6 +297,47 @@ static int dump(unsigned seed, int n)
     return 0;
 }
 
+// src/c++/test/test_popstats.cpp:26-95
+static void testPopulationStatistics()
+{
+    GenotypeSet pop;
+    const Genotype ref({ 0, 0 }), het({ 0, 1 }), alt({ 1, 1 });
+    const vector<string> alleles = { "REF", "ALT" };
+    for (int i = 0; i < 83; ++i)
+        pop.add(alleles, ref);
+    EXPECT_EQ(PopulationStatistics(pop).getChisqPvalue(), 1.0);
+    EXPECT_EQ(PopulationStatistics(pop).needFisherExactHWE(), false);
+    for (int i = 0; i < 13; ++i)
+        pop.add(alleles, het);
+    for (int i = 0; i < 4; ++i)
+        pop.add(alleles, alt);
+    const PopulationStatistics ps1(pop);
+    EXPECT_NEAR_REL(ps1.getChisqPvalue(), 0.0020474148859159769, 1e-12);
+    EXPECT_NEAR_REL(ps1.getFisherExactPvalue(), 0.010293433548874801, 1e-13);
+    EXPECT_EQ(ps1.needFisherExactHWE(), true);
+    EXPECT_EQ(ps1.getCallrate(), 1.0);
+    EXPECT_NEAR_REL(ps1.getAlleleFrequencies()[1], 21.0 / 200.0, 1e-15);
+    const common::Json doc = ps1.toJson();
+    EXPECT_NEAR_REL(doc["hwe_fisher"].asDouble(), 0.010293433548874801, 1e-13);
+    EXPECT_EQ(doc["allele_frequencies"].size(), (size_t)2);
+
+    const Genotype e02({ 0, 2 }), e12({ 1, 2 }), e22({ 2, 2 });
+    const vector<string> multi = { "REF", "ALT1", "ALT2" };
+    GenotypeSet pop2;
+    const std::pair<const Genotype*, int> groups[] = { { &ref, 24 }, { &het, 31 }, { &alt, 10 }, { &e02, 19 }, { &e12, 11 }, { &e22, 5 } };
+    for (auto const& g : groups)
+        for (int i = 0; i < g.second; ++i)
+            pop2.add(multi, *g.first);
+    const PopulationStatistics ps2(pop2);
+    EXPECT_NEAR_REL(ps2.getChisqPvalue(), 0.50000945615245529, 1e-12);
+    EXPECT_EQ(ps2.needFisherExactHWE(), false);
+    EXPECT_EQ(ps2.toJson()["hwe_fisher"].asString(), string(""));
+    // no-calls lower the call rate and are left out of every count
+    pop2.add({}, Genotype());
+    EXPECT_NEAR_REL(PopulationStatistics(pop2).getCallrate(), 100.0 / 101.0, 1e-15);
+    EXPECT_NEAR_REL(PopulationStatistics(pop2).getChisqPvalue(), 0.50000945615245529, 1e-12);
+}
+
 int main(int argc, char** argv)
 {
     if (argc == 4 && string(argv[1]) == "--dump")
@@ -306,6 +348,7 @@ int main(int argc, char** argv)
         testCombinedGenotype();
         testGenotypeAndParameters();
         testGraphBreakpointGenotyper();
+        testPopulationStatistics();
     }
     catch (std::exception const& e)
     {

@@ -148,6 +148,9 @@ static void testGenotypesSingleSwap(std::string const& dir)
     CHECK(one_by_one["samples"]["SAMPLE1"]["breakpoints"].size() >= 2);
     CHECK(one_by_one["samples"]["SAMPLE1"]["gt"]["num_reads"].asInt64() > 50);
     CHECK(Json::parse(one_by_one.dump(2)) == one_by_one);
+    // two samples -> a "population" block: both call REF, so one observed allele, no exact test, call rate 1
+    CHECK(one_by_one["population"]["call_rate"].asDouble() == 1.0 && one_by_one["population"]["hwe_fisher"].asString().empty());
+    CHECK(one_by_one["population"]["breakpoints"].size() == one_by_one["samples"]["SAMPLE1"]["breakpoints"].size());
 
     // the batched shape: both samples (x the same graph listed twice) in one device batch, same documents
     parameters.threads = 4;

@@ -86,3 +86,47 @@ def test_bam_reader_matches_independent_decoder(hostio, region):
     for g, w in zip(got, want):
         flags = "%d%d%d%d%d" % (not w["flag"] & 4, bool(w["flag"] & 0x40), not w["flag"] & 8, bool(w["flag"] & 0x10), bool(w["flag"] & 0x20))
         assert g == [w["name"], str(w["tid"]), str(w["pos"]), str(w["mapq"]), flags, str(w["mtid"]), str(w["mpos"]), w["seq"], w["qual"]]
+
+
+def test_bam_reader_on_synthetic_multiblock_bam(hostio, tmp_path):
+    """Thousands of records over several BGZF blocks, two contigs, soft clips / deletions / unmapped mates placed with their
+    partner, secondary records to be skipped: region queries through the written BAI equal the filter over all records."""
+    import random
+    from tests import bamwriter
+    rng = random.Random(12)
+    recs = []
+    for tid, length in ((0, 300000), (1, 90000)):
+        pos = 0
+        while True:
+            pos += rng.choice([0, 1, 3, 40, 200]) if rng.random() < 0.998 else 30000
+            if pos > length - 200:
+                break
+            L = rng.randint(30, 150)
+            kind = rng.random()
+            cigar = [(L, "M")]
+            if kind < 0.1:
+                cigar = [(10, "S"), (L - 10, "M")]
+            elif kind < 0.2:
+                cigar = [(20, "M"), (rng.choice([5, 5000]), "D"), (L - 20, "M")]
+            flag = rng.choice([0x63, 0x93, 0x53, 0xa3, 0x100 | 0x63, 0x800 | 0x63, 0x4 | 0x41])
+            recs.append(dict(name="r%d_%d" % (tid, len(recs)), tid=tid, pos=pos, seq="".join(rng.choice("ACGTN") for _ in range(L)),
+                             qual="".join(chr(33 + rng.randint(0, 41)) for _ in range(L)), flag=flag, mapq=rng.randint(0, 60), mtid=tid,
+                             mpos=max(0, pos + rng.randint(-400, 400)), cigar=cigar))
+    assert len(recs) > 3000
+    bam = str(tmp_path / "synthetic.bam")
+    bamwriter.write_bam(bam, [("ctgA", 300000), ("ctgB", 90000)], recs)
+    names, decoded = decode_bam(bam)
+    assert names == ["ctgA", "ctgB"] and len(decoded) == len(recs)
+    for region in ["ctgA", "ctgB", "ctgA:1-20000", "ctgA:16,300-16,500", "ctgA:100000-100001", "ctgB:40000-89999", "ctgA:299000", "ctgB:1-1"] + [
+            "ctgA:%d-%d" % (b, b + rng.randint(0, 3000)) for b in (rng.randint(1, 299000) for _ in range(25))]:
+        chrom, _, span = region.partition(":")
+        tid = names.index(chrom)
+        beg, end = 0, 1 << 29
+        if span:
+            lo, _, hi = span.replace(",", "").partition("-")
+            beg, end = int(lo) - 1, int(hi) if hi else 1 << 29
+        want = [r for r in decoded if r["tid"] == tid and r["pos"] < end and r["end"] > beg and not r["flag"] & 0x900]
+        got = dump(hostio, bam, region)
+        assert [g[0] for g in got] == [w["name"] for w in want], region
+        for g, w in zip(got, want):
+            assert g[2] == str(w["pos"]) and g[7] == w["seq"] and g[8] == w["qual"]

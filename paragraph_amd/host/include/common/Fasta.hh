@@ -1,6 +1,6 @@
 // Indexed FASTA access for graph nodes given as reference intervals (common::FastaFile, src/c++/include/common/Fasta.hh:40-70).
 // Uses the samtools .fai next to the file (scans the FASTA when there is none); sequence comes back upper-cased with everything but ACGT turned into N
-// (lib/common/Fasta.cpp:435-462).
+// (lib/common/Fasta.cpp:435-462).  Queries are positional reads: one object may be shared by many threads.
 #pragma once
 #include <cstdint>
 #include <memory>

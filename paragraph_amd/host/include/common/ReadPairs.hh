@@ -16,6 +16,8 @@ public:
     const Read& second_mate() const { return second_; }
     int numInitialized() const { return (int)first_.is_initialized() + (int)second_.is_initialized(); }
     void add(const Read& read) { (read.is_first_mate() ? first_ : second_) = read; }
+    Read& first_mate() { return first_; }
+    Read& second_mate() { return second_; }
 
 private:
     Read first_, second_;
@@ -33,6 +35,8 @@ public:
     int num_reads() const { return num_reads_; }
     void getReads(std::vector<Read>& reads) const;
     void getReads(std::vector<p_Read>& reads) const;
+    // like getReads, but moves the reads out (this container is left empty): no second copy of every read's strings
+    void takeReads(std::vector<p_Read>& reads);
     void clear();
 
 private:

@@ -4,6 +4,7 @@
 #include <list>
 #include <string>
 
+#include "common/Fasta.hh"
 #include "common/Json.hh"
 #include "graphcore/Graph.hh"
 
@@ -15,6 +16,8 @@ namespace grm
 // Throws std::runtime_error where the original asserts (no nodes, duplicate names, node without sequence / reference, edges
 // not an array, unknown edge ends).
 graphtools::Graph graphFromJson(common::Json const& in, std::string const& reference, bool store_ref_sequence = true);
+// the same with an already opened reference (shared between threads when many graphs are loaded)
+graphtools::Graph graphFromJson(common::Json const& in, common::FastaFile const& reference, bool store_ref_sequence = true);
 // every path runs from offset 0 of its first node to the last base of its last node
 std::list<graphtools::Path> pathsFromJson(graphtools::Graph const* graph, common::Json const& in_paths);
 }  // namespace grm

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "common/Fasta.hh"
 #include "common/Json.hh"
 #include "common/Read.hh"
 #include "common/ReadReader.hh"
@@ -21,12 +22,12 @@
 
 namespace paragraph
 {
-// wall-clock seconds of the workflow's phases, filled in when a Parameters object points at one
+// seconds spent in the workflow's phases, summed over lanes (so they can add up to more than the wall clock), filled in
+// when a Parameters object points at one
 struct Timings
 {
-    double load_graphs = 0, extract_reads = 0, device_batch = 0, documents = 0, genotypes = 0;
-    double waited_for_input = 0;  // time the device stage stood idle until the next chunk's reads were there (load + extract run ahead)
-    size_t sites = 0, reads = 0, batches = 0;
+    double load_graphs = 0, extract_reads = 0, device_batch = 0, documents = 0, genotypes = 0, release = 0;
+    size_t sites = 0, reads = 0, batches = 0, lanes = 1;
 };
 
 // paragraph::Parameters (include/paragraph/Parameters.hh:44-126): what to compute and emit for a site
@@ -58,8 +59,13 @@ struct Parameters
 // flattened, its target regions, "max_reads" override and the longest explicit node sequence.
 struct GraphDescription
 {
-    static GraphDescription load(std::string const& graph_path, std::string const& reference_path, std::string const& override_target_regions = "");
-    static GraphDescription fromJson(common::Json root, std::string const& reference_path, std::string const& override_target_regions = "");
+    // `opened_reference`: an already opened FASTA of reference_path to share between loads (may be null)
+    static GraphDescription load(
+        std::string const& graph_path, std::string const& reference_path, std::string const& override_target_regions = "",
+        common::FastaFile const* opened_reference = nullptr);
+    static GraphDescription fromJson(
+        common::Json root, std::string const& reference_path, std::string const& override_target_regions = "",
+        common::FastaFile const* opened_reference = nullptr);
     common::Json description;
     std::string reference_path;
     std::list<common::Region> target_regions;
@@ -94,7 +100,8 @@ struct Parameters
     bool graph_sequence_matching = true;
     int bad_align_uniq_kmer_len = 0;
     bool output_alignments = false;  // keep "alignments" in the per-sample documents (the original writes them to a folder)
-    size_t sites_per_batch = 4096;   // (graph, sample) pairs per device batch; bounds host memory and sets the pipeline grain
+    size_t sites_per_batch = 1024;   // (graph, sample) pairs per device batch; bounds host memory and sets the pipeline grain
+    int lanes = 4;                   // chunks in flight: each lane carries one chunk through all stages with threads / lanes workers
     paragraph::Timings* timings = nullptr;
 };
 
@@ -106,8 +113,8 @@ void alignSingleSample(
 common::Json countAndGenotype(
     std::string const& graph_path, std::string const& reference_path, std::string const& genotyping_parameter_path,
     genotyping::Samples const& samples);
-// every graph x every sample, `sites_per_batch` pairs per device batch, read extraction of the next batch running ahead
-// of the device; returns one genotype document per graph, in the order given
+// every graph x every sample, `sites_per_batch` pairs per device batch, `lanes` batches in flight (their host stages
+// overlap, the device stage is serialised); returns one genotype document per graph, in the order given
 std::vector<common::Json> genotypeGraphs(
     Parameters const& parameters, std::vector<std::string> const& graph_paths, std::string const& reference_path,
     genotyping::Samples const& samples, std::string const& genotyping_parameter_path);

@@ -43,7 +43,24 @@ bool isFile(std::string const& p)
 // ----------------------------------------------------------------------------------------------------------------------
 namespace grm
 {
+namespace
+{
+Graph buildGraph(Json const& in, std::string const& reference, common::FastaFile const* opened, bool store_ref_sequence);
+}
+
 Graph graphFromJson(Json const& in, std::string const& reference, bool store_ref_sequence)
+{
+    return buildGraph(in, reference, nullptr, store_ref_sequence);
+}
+
+Graph graphFromJson(Json const& in, common::FastaFile const& reference, bool store_ref_sequence)
+{
+    return buildGraph(in, reference.getFilename(), &reference, store_ref_sequence);
+}
+
+namespace
+{
+Graph buildGraph(Json const& in, std::string const& reference, common::FastaFile const* opened, bool store_ref_sequence)
 {
     Json const& spec = in.isMember("graph") ? in["graph"] : in;
     if (!spec["nodes"].isArray())
@@ -51,11 +68,13 @@ Graph graphFromJson(Json const& in, std::string const& reference, bool store_ref
     if (!spec["edges"].isNull() && !spec["edges"].isArray())
         fail("Graph description: \"edges\" must be an array");
     Json::Elements const& nodes = spec["nodes"].elements();
-    std::unique_ptr<common::FastaFile> fasta;  // opened on first use: graphs with explicit sequences need no reference
+    std::unique_ptr<common::FastaFile> own;  // opened on first use: graphs with explicit sequences need no reference
     auto ref_bases = [&](std::string const& where) {
-        if (!fasta)
-            fasta.reset(new common::FastaFile(reference));
-        return fasta->query(where);
+        if (opened)
+            return opened->query(where);
+        if (!own)
+            own.reset(new common::FastaFile(reference));
+        return own->query(where);
     };
 
     Graph graph(nodes.size(), false);
@@ -128,6 +147,7 @@ Graph graphFromJson(Json const& in, std::string const& reference, bool store_ref
     }
     return graph;
 }
+}  // namespace
 
 std::list<graphtools::Path> pathsFromJson(Graph const* graph, Json const& in_paths)
 {

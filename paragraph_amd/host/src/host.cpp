@@ -667,7 +667,6 @@ void SiteBatcher::run(BatchParameters const& prm)
     if (n_sites == 0)
         return;
     pg_ctx* ctx = deviceContext();
-    std::lock_guard<std::mutex> lock(deviceMutex());
     // PG_BATCH_TIMING=1: wall-clock of the phases of this call on stderr
     const bool timing = std::getenv("PG_BATCH_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
@@ -681,27 +680,7 @@ void SiteBatcher::run(BatchParameters const& prm)
     GraphCsr csr;
     for (const Graph* g : impl_->graphs)
         csr.add(*g);
-    pg_graphs* G = nullptr;
-    check(ctx, pg_graphs_upload(ctx, (uint32_t)n_sites, csr.node_off.data(), csr.seq_off.data(), csr.seq.data(),
-                                csr.pred_off.data(), csr.pred.empty() ? nullptr : csr.pred.data(), &G),
-          "pg_graphs_upload");
-    struct Guard
-    {
-        pg_ctx* c;
-        pg_graphs* g;
-        pg_batch* b;
-        ~Guard()
-        {
-            if (b)
-                pg_batch_destroy(c, b);
-            if (g)
-                pg_graphs_destroy(c, g);
-        }
-    } guard{ ctx, G, nullptr };
-    check(ctx, pg_graphs_set_labels(ctx, G, csr.label_mask.empty() ? nullptr : csr.label_mask.data(), csr.n_labels.data()),
-          "pg_graphs_set_labels");
-
-    mark("graphs");
+    mark("graph csr");
     // ---- pack the reads of all sites: offsets first, then every site fills its own slice --------------------
     std::vector<uint64_t> site_read0(n_sites + 1, 0), site_base0(n_sites + 1, 0);
     for (size_t s = 0; s < n_sites; ++s)
@@ -738,59 +717,86 @@ void SiteBatcher::run(BatchParameters const& prm)
         },
         8);
     mark("pack reads");
-    const uint32_t n = (uint32_t)flat.size();
-    check(ctx, pg_batch_create(ctx, &guard.b), "pg_batch_create");
-    check(ctx, pg_batch_upload(ctx, guard.b, G, n, gor.data(), base_off.data(), bases.data()), "pg_batch_upload");
-    check(ctx, pg_batch_set_fragments(ctx, guard.b, frag.data(), is_rev.data()), "pg_batch_set_fragments");
-    pg_count_params cp{};
-    cp.remove_nonuniq = prm.remove_nonuniq_reads ? 1 : 0;
-    cp.use_support_filters = prm.use_support_filters ? 1 : 0;
-    cp.bad_align_frac = prm.bad_align_frac;
-    if (prm.kmer_len != 0)
-    {
-        // createReadFilter(graph, nonuniq, frac, kmer_len): NonUniq -> BadAlign -> KmerFilter (ReadFilter.cpp:74-90)
-        check(ctx, pg_graphs_build_filter_index(ctx, G, prm.kmer_len, nullptr), "pg_graphs_build_filter_index");
-        cp.use_kmer_filter = 1;
-    }
-    uint32_t align_flags = prm.alignment_flags;
-    if (prm.path_sequence_matching && n)
-    {
-        // stage 1: PathAligner on every read; the filter chain runs on the device (count pass) and decides who goes on
-        check(ctx, pg_graphs_build_path_index(ctx, G, 32), "pg_graphs_build_path_index");
-        check(ctx, pg_batch_path_align(ctx, guard.b), "pg_batch_path_align");
-        check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
-        std::vector<uint8_t> stage_flags(n), active(n, 1);
-        std::vector<pg_read_support> stage_sup(n);
-        uint64_t np = 0;
-        check(ctx, pg_batch_download_path_flags(ctx, guard.b, stage_flags.data()), "pg_batch_download_path_flags");
-        check(ctx, pg_batch_download_counts(ctx, guard.b, nullptr, stage_sup.data(), nullptr, 0, &np), "pg_batch_download_counts");
-        for (uint32_t i = 0; i < n; ++i)
-            if ((stage_flags[i] & 1) && stage_sup[i].status == 1)
-                active[i] = 0;  // MAPPED by the path stage and accepted by the filters: done
-        check(ctx, pg_batch_set_active(ctx, guard.b, active.data()), "pg_batch_set_active");
-        // keep the path-stage records of the finished reads (the extension flag is ignored when flags == PG_AF_ALL)
-        align_flags = (align_flags & (PG_AF_CIGAR | PG_AF_BOTH_STRANDS | PG_AF_REVERSE_GRAPH)) | PG_AF_KEEP_RESULTS;
-    }
-    mark("upload (+ path)");
-    check(ctx, pg_batch_align(ctx, guard.b, align_flags), "pg_batch_align");
-    check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
-
-    uint64_t n_ops = 0, n_path = 0;
-    check(ctx, pg_batch_ops_count(ctx, guard.b, &n_ops), "pg_batch_ops_count");
-    std::vector<pg_result> res(n);
-    std::vector<pg_op> ops(n_ops + 1);
-    check(ctx, pg_batch_download(ctx, guard.b, res.data(), ops.data(), ops.size(), &n_ops), "pg_batch_download");
-    pg_count_layout lay{};
-    check(ctx, pg_graphs_count_layout(G, &lay), "pg_graphs_count_layout");
+    // ---- device section: calls on one context are serialised; everything before and after overlaps across threads ------
+    std::vector<pg_result> res;
+    std::vector<pg_op> ops;
     std::vector<uint64_t> seq_off(n_sites + 1);
-    check(ctx, pg_graphs_seq_offsets(G, seq_off.data()), "pg_graphs_seq_offsets");
-    std::vector<uint32_t> table(lay.n_counters), path;
-    std::vector<pg_read_support> sup(n);
-    check(ctx, pg_batch_download_counts(ctx, guard.b, nullptr, nullptr, nullptr, 0, &n_path), "pg_batch_download_counts");
-    path.resize(n_path + 1);
-    check(ctx, pg_batch_download_counts(ctx, guard.b, table.data(), sup.data(), path.data(), path.size(), &n_path),
-          "pg_batch_download_counts");
+    std::vector<uint32_t> table, path;
+    std::vector<pg_read_support> sup;
+    pg_count_layout lay{};
+    const uint32_t n = (uint32_t)flat.size();
+    {
+        std::lock_guard<std::mutex> lock(deviceMutex());
+        pg_graphs* G = nullptr;
+        check(ctx, pg_graphs_upload(ctx, (uint32_t)n_sites, csr.node_off.data(), csr.seq_off.data(), csr.seq.data(),
+                                    csr.pred_off.data(), csr.pred.empty() ? nullptr : csr.pred.data(), &G),
+              "pg_graphs_upload");
+        struct Guard
+        {
+            pg_ctx* c;
+            pg_graphs* g;
+            pg_batch* b;
+            ~Guard()
+            {
+                if (b)
+                    pg_batch_destroy(c, b);
+                if (g)
+                    pg_graphs_destroy(c, g);
+            }
+        } guard{ ctx, G, nullptr };
+        check(ctx, pg_graphs_set_labels(ctx, G, csr.label_mask.empty() ? nullptr : csr.label_mask.data(), csr.n_labels.data()),
+              "pg_graphs_set_labels");
 
+        check(ctx, pg_batch_create(ctx, &guard.b), "pg_batch_create");
+        check(ctx, pg_batch_upload(ctx, guard.b, G, n, gor.data(), base_off.data(), bases.data()), "pg_batch_upload");
+        check(ctx, pg_batch_set_fragments(ctx, guard.b, frag.data(), is_rev.data()), "pg_batch_set_fragments");
+        pg_count_params cp{};
+        cp.remove_nonuniq = prm.remove_nonuniq_reads ? 1 : 0;
+        cp.use_support_filters = prm.use_support_filters ? 1 : 0;
+        cp.bad_align_frac = prm.bad_align_frac;
+        if (prm.kmer_len != 0)
+        {
+            // createReadFilter(graph, nonuniq, frac, kmer_len): NonUniq -> BadAlign -> KmerFilter (ReadFilter.cpp:74-90)
+            check(ctx, pg_graphs_build_filter_index(ctx, G, prm.kmer_len, nullptr), "pg_graphs_build_filter_index");
+            cp.use_kmer_filter = 1;
+        }
+        uint32_t align_flags = prm.alignment_flags;
+        if (prm.path_sequence_matching && n)
+        {
+            // stage 1: PathAligner on every read; the filter chain runs on the device (count pass) and decides who goes on
+            check(ctx, pg_graphs_build_path_index(ctx, G, 32), "pg_graphs_build_path_index");
+            check(ctx, pg_batch_path_align(ctx, guard.b), "pg_batch_path_align");
+            check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
+            std::vector<uint8_t> stage_flags(n), active(n, 1);
+            std::vector<pg_read_support> stage_sup(n);
+            uint64_t np = 0;
+            check(ctx, pg_batch_download_path_flags(ctx, guard.b, stage_flags.data()), "pg_batch_download_path_flags");
+            check(ctx, pg_batch_download_counts(ctx, guard.b, nullptr, stage_sup.data(), nullptr, 0, &np), "pg_batch_download_counts");
+            for (uint32_t i = 0; i < n; ++i)
+                if ((stage_flags[i] & 1) && stage_sup[i].status == 1)
+                    active[i] = 0;  // MAPPED by the path stage and accepted by the filters: done
+            check(ctx, pg_batch_set_active(ctx, guard.b, active.data()), "pg_batch_set_active");
+            // keep the path-stage records of the finished reads (the extension flag is ignored when flags == PG_AF_ALL)
+            align_flags = (align_flags & (PG_AF_CIGAR | PG_AF_BOTH_STRANDS | PG_AF_REVERSE_GRAPH)) | PG_AF_KEEP_RESULTS;
+        }
+        mark("upload (+ path)");
+        check(ctx, pg_batch_align(ctx, guard.b, align_flags), "pg_batch_align");
+        check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
+
+        uint64_t n_ops = 0, n_path = 0;
+        check(ctx, pg_batch_ops_count(ctx, guard.b, &n_ops), "pg_batch_ops_count");
+        res.resize(n);
+        ops.resize(n_ops + 1);
+        check(ctx, pg_batch_download(ctx, guard.b, res.data(), ops.data(), ops.size(), &n_ops), "pg_batch_download");
+        check(ctx, pg_graphs_count_layout(G, &lay), "pg_graphs_count_layout");
+        check(ctx, pg_graphs_seq_offsets(G, seq_off.data()), "pg_graphs_seq_offsets");
+        table.resize(lay.n_counters);
+        sup.resize(n);
+        check(ctx, pg_batch_download_counts(ctx, guard.b, nullptr, nullptr, nullptr, 0, &n_path), "pg_batch_download_counts");
+        path.resize(n_path + 1);
+        check(ctx, pg_batch_download_counts(ctx, guard.b, table.data(), sup.data(), path.data(), path.size(), &n_path),
+              "pg_batch_download_counts");
+    }  // device objects released, mutex dropped
     mark("align+count+download");
     // ---- fan results back into the reads ---------------------------------------------------------------
     pghost::parallelFor(

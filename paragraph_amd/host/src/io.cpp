@@ -1,5 +1,7 @@
 // Sample-side input of the host workflow: coordinates, FASTA, BGZF/BAM/BAI, read-pair bookkeeping and per-site read
 // extraction.  Headers under include/common cite the reference interfaces each class mirrors.
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -8,6 +10,8 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <unordered_map>
@@ -75,16 +79,21 @@ struct FastaFile::Impl
         size_t length, offset, line_bases, line_bytes;
     };
     std::string filename;
-    mutable std::ifstream in;
+    int fd = -1;  // queries use pread: one FastaFile can serve many threads
     std::unordered_map<std::string, Contig> contigs;
     std::vector<std::string> order;
+    ~Impl()
+    {
+        if (fd >= 0)
+            ::close(fd);
+    }
 };
 
 FastaFile::FastaFile(std::string const& path) : impl_(new Impl)
 {
     impl_->filename = path;
-    impl_->in.open(path, std::ios::binary);
-    if (!impl_->in.good())
+    impl_->fd = ::open(path.c_str(), O_RDONLY);
+    if (impl_->fd < 0)
         throw std::runtime_error("Cannot open FASTA file " + path);
     std::ifstream fai(path + ".fai");
     if (!fai.good())
@@ -101,7 +110,8 @@ FastaFile::FastaFile(std::string const& path) : impl_(new Impl)
                 impl_->order.push_back(name);
             }
         };
-        while (std::getline(impl_->in, line))
+        std::ifstream scan(path, std::ios::binary);
+        while (std::getline(scan, line))
         {
             const size_t bytes = line.size() + 1;
             if (!line.empty() && line.back() == '\r')
@@ -128,7 +138,6 @@ FastaFile::FastaFile(std::string const& path) : impl_(new Impl)
         for (auto& kv : impl_->contigs)
             if (kv.second.line_bases == 0)
                 kv.second.line_bases = kv.second.line_bytes = 1;
-        impl_->in.clear();
         return;
     }
     std::string line;
@@ -191,11 +200,13 @@ std::string FastaFile::query(std::string const& chrom, int64_t start, int64_t en
     const size_t first_byte = c.offset + ((size_t)start / c.line_bases) * c.line_bytes + (size_t)start % c.line_bases;
     const size_t last_byte = c.offset + (last / c.line_bases) * c.line_bytes + last % c.line_bases;
     std::string raw(last_byte - first_byte + 1, '\0');
-    impl_->in.clear();
-    impl_->in.seekg((std::streamoff)first_byte);
-    impl_->in.read(&raw[0], (std::streamsize)raw.size());
-    if ((size_t)impl_->in.gcount() != raw.size())
-        throw std::runtime_error("Short read from FASTA file " + impl_->filename);
+    for (size_t got = 0; got < raw.size();)
+    {
+        const ssize_t n = ::pread(impl_->fd, &raw[got], raw.size() - got, (off_t)(first_byte + got));
+        if (n <= 0)
+            throw std::runtime_error("Short read from FASTA file " + impl_->filename);
+        got += (size_t)n;
+    }
     std::string out;
     out.reserve(last - (size_t)start + 1);
     for (char ch : raw)
@@ -397,20 +408,29 @@ struct RegionCursor
 };
 }  // namespace
 
-struct BamReader::Impl
+// header and index of one BAM: parsed once per process and shared by every reader of that file (the workflow opens one
+// reader per worker thread)
+struct BamMeta
 {
-    std::string path, index_path, reference;
-    std::unique_ptr<Bgzf> bgzf;
     std::string header_text;
     std::vector<std::string> names;
     std::vector<int64_t> lengths;
     std::unordered_map<std::string, int> tid_of;
     std::vector<RefIndex> index;
+    uint64_t first_record = 0;  // virtual offset just past the header
+};
+
+struct BamReader::Impl
+{
+    std::string path, index_path, reference;
+    std::unique_ptr<Bgzf> bgzf;
+    std::shared_ptr<const BamMeta> meta;
     RegionCursor cursor;
     std::vector<unsigned char> scratch;
 
     void open();
-    void loadIndex();
+    void parseHeader(BamMeta& m);
+    void loadIndex(BamMeta& m);
     bool readRecord(BamRecord& rec);
     RegionCursor query(int32_t tid, int64_t beg, int64_t end) const;
     bool next(RegionCursor& cur, BamRecord& rec);
@@ -445,6 +465,23 @@ void toRead(BamRecord const& rec, Read& read)
 void BamReader::Impl::open()
 {
     bgzf.reset(new Bgzf(path));
+    static std::mutex cache_mutex;
+    static std::map<std::pair<std::string, std::string>, std::weak_ptr<const BamMeta>> cache;
+    std::lock_guard<std::mutex> lock(cache_mutex);
+    auto& slot = cache[{ path, index_path }];
+    meta = slot.lock();
+    if (!meta)
+    {
+        auto fresh = std::make_shared<BamMeta>();
+        parseHeader(*fresh);
+        loadIndex(*fresh);
+        meta = fresh;
+        slot = meta;
+    }
+}
+
+void BamReader::Impl::parseHeader(BamMeta& m)
+{
     unsigned char b[8];
     bgzf->readExact(b, 4, "magic");
     if (memcmp(b, "BAM\1", 4) != 0)
@@ -454,9 +491,9 @@ void BamReader::Impl::open()
         throw std::runtime_error("ERROR: Unknown alignment file format.");
     }
     bgzf->readExact(b, 4, "header length");
-    header_text.resize(le32(b));
-    if (!header_text.empty())
-        bgzf->readExact(&header_text[0], header_text.size(), "header text");
+    m.header_text.resize(le32(b));
+    if (!m.header_text.empty())
+        bgzf->readExact(&m.header_text[0], m.header_text.size(), "header text");
     bgzf->readExact(b, 4, "reference count");
     const uint32_t n_ref = le32(b);
     for (uint32_t i = 0; i < n_ref; ++i)
@@ -468,14 +505,14 @@ void BamReader::Impl::open()
         while (!name.empty() && name.back() == '\0')
             name.pop_back();
         bgzf->readExact(b, 4, "reference length");
-        tid_of[name] = (int)i;
-        names.push_back(name);
-        lengths.push_back((int64_t)le32(b));
+        m.tid_of[name] = (int)i;
+        m.names.push_back(name);
+        m.lengths.push_back((int64_t)le32(b));
     }
-    loadIndex();
+    m.first_record = bgzf->tell();
 }
 
-void BamReader::Impl::loadIndex()
+void BamReader::Impl::loadIndex(BamMeta& m)
 {
     std::string use = index_path;
     if (use.empty())
@@ -498,7 +535,7 @@ void BamReader::Impl::loadIndex()
         throw std::runtime_error("ERROR: " + use + " is not a BAI index");
     const uint32_t n_ref = le32(buf.data() + 4);
     at = 8;
-    index.resize(n_ref);
+    m.index.resize(n_ref);
     for (uint32_t r = 0; r < n_ref; ++r)
     {
         need(4);
@@ -513,7 +550,7 @@ void BamReader::Impl::loadIndex()
             need((size_t)n_chunk * 16);
             if (bin != 37450)  // the pseudo-bin holds statistics, not chunks
             {
-                auto& chunks = index[r].bins[bin];
+                auto& chunks = m.index[r].bins[bin];
                 for (uint32_t c = 0; c < n_chunk; ++c)
                     chunks.push_back(Chunk{ le64(buf.data() + at + c * 16), le64(buf.data() + at + c * 16 + 8) });
             }
@@ -523,9 +560,9 @@ void BamReader::Impl::loadIndex()
         const uint32_t n_intv = le32(buf.data() + at);
         at += 4;
         need((size_t)n_intv * 8);
-        index[r].linear.resize(n_intv);
+        m.index[r].linear.resize(n_intv);
         for (uint32_t i = 0; i < n_intv; ++i)
-            index[r].linear[i] = le64(buf.data() + at + (size_t)i * 8);
+            m.index[r].linear[i] = le64(buf.data() + at + (size_t)i * 8);
         at += (size_t)n_intv * 8;
     }
 }
@@ -587,19 +624,19 @@ bool BamReader::Impl::readRecord(BamRecord& rec)
 RegionCursor BamReader::Impl::query(int32_t tid, int64_t beg, int64_t end) const
 {
     RegionCursor cur;
-    if (tid < 0 || (size_t)tid >= names.size())
+    if (tid < 0 || (size_t)tid >= meta->names.size())
         return cur;
     cur.valid = true;
     cur.tid = tid;
     cur.beg = std::max<int64_t>(beg, 0);
     cur.end = std::max(end, cur.beg);
     cur.finished = false;
-    if ((size_t)tid >= index.size() || cur.end <= cur.beg)
+    if ((size_t)tid >= meta->index.size() || cur.end <= cur.beg)
     {
         cur.finished = true;
         return cur;
     }
-    RefIndex const& ri = index[(size_t)tid];
+    RefIndex const& ri = meta->index[(size_t)tid];
     // records overlapping window beg >> 14 start at or after this offset; a 0 entry (empty window) just disables the cut
     uint64_t min_off = 0;
     if (!ri.linear.empty())
@@ -693,9 +730,9 @@ BamReader::BamReader(const std::string& path, const std::string& index_path, con
 BamReader::~BamReader() = default;
 BamReader::BamReader(BamReader&&) noexcept = default;
 BamReader& BamReader::operator=(BamReader&&) noexcept = default;
-std::vector<std::string> const& BamReader::contigNames() const { return impl_->names; }
-std::vector<int64_t> const& BamReader::contigLengths() const { return impl_->lengths; }
-std::string const& BamReader::headerText() const { return impl_->header_text; }
+std::vector<std::string> const& BamReader::contigNames() const { return impl_->meta->names; }
+std::vector<int64_t> const& BamReader::contigLengths() const { return impl_->meta->lengths; }
+std::string const& BamReader::headerText() const { return impl_->meta->header_text; }
 
 void BamReader::setRegion(const std::string& region_encoding)
 {
@@ -703,8 +740,8 @@ void BamReader::setRegion(const std::string& region_encoding)
     // contig as a whole wins (contig names may hold ':')
     std::string name = region_encoding;
     int64_t beg = 0, end = (int64_t)1 << 29;
-    auto whole = impl_->tid_of.find(region_encoding);
-    if (whole == impl_->tid_of.end())
+    auto whole = impl_->meta->tid_of.find(region_encoding);
+    if (whole == impl_->meta->tid_of.end())
     {
         const size_t colon = region_encoding.rfind(':');
         if (colon != std::string::npos)
@@ -724,8 +761,8 @@ void BamReader::setRegion(const std::string& region_encoding)
                 end = beg;  // empty interval
         }
     }
-    auto it = impl_->tid_of.find(name);
-    if (it == impl_->tid_of.end())
+    auto it = impl_->meta->tid_of.find(name);
+    if (it == impl_->meta->tid_of.end())
         throw std::runtime_error("Failed to jump to " + region_encoding + " in " + impl_->path);
     impl_->cursor = impl_->query(it->second, beg, end);
 }
@@ -804,6 +841,18 @@ void ReadPairs::getReads(std::vector<p_Read>& reads) const
     }
 }
 
+void ReadPairs::takeReads(std::vector<p_Read>& reads)
+{
+    for (auto& kv : pairs_)
+    {
+        if (kv.second.first_mate().is_initialized())
+            reads.emplace_back(new Read(std::move(kv.second.first_mate())));
+        if (kv.second.second_mate().is_initialized())
+            reads.emplace_back(new Read(std::move(kv.second.second_mate())));
+    }
+    clear();
+}
+
 void ReadPairs::clear()
 {
     pairs_.clear();
@@ -875,7 +924,7 @@ std::pair<int, int> extractReadsFromRegion(
         recoverMissingMates(reader, read_pairs);
         extracted.second = read_pairs.num_reads() - extracted.first;
     }
-    read_pairs.getReads(all_reads);
+    read_pairs.takeReads(all_reads);
     return extracted;
 }
 

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <map>
+#include <mutex>
 #include <set>
 #include <sstream>
 #include <stdexcept>
@@ -35,12 +36,15 @@ using pghost::parallelFor;
 
 namespace paragraph
 {
-GraphDescription GraphDescription::load(std::string const& graph_path, std::string const& reference_path, std::string const& override_target_regions)
+GraphDescription GraphDescription::load(
+    std::string const& graph_path, std::string const& reference_path, std::string const& override_target_regions,
+    common::FastaFile const* opened_reference)
 {
-    return fromJson(Json::parseFile(graph_path), reference_path, override_target_regions);
+    return fromJson(Json::parseFile(graph_path), reference_path, override_target_regions, opened_reference);
 }
 
-GraphDescription GraphDescription::fromJson(Json root, std::string const& reference_path, std::string const& override_target_regions)
+GraphDescription GraphDescription::fromJson(
+    Json root, std::string const& reference_path, std::string const& override_target_regions, common::FastaFile const* opened_reference)
 {
     GraphDescription d;
     d.reference_path = reference_path;
@@ -75,7 +79,8 @@ GraphDescription GraphDescription::fromJson(Json root, std::string const& refere
     for (Json const& node : root["nodes"].elements())
         if (node.isMember("sequence"))
             d.longest_alt_insertion = std::max(d.longest_alt_insertion, node["sequence"].asString().size());
-    d.graph = std::make_shared<graphtools::Graph>(grm::graphFromJson(root, reference_path));
+    d.graph = std::make_shared<graphtools::Graph>(
+        opened_reference ? grm::graphFromJson(root, *opened_reference) : grm::graphFromJson(root, reference_path));
     d.paths = grm::pathsFromJson(d.graph.get(), root["paths"]);
     d.description = std::move(root);
     return d;
@@ -488,7 +493,7 @@ struct Chunk
 
 std::unique_ptr<Chunk> prepareChunk(
     Parameters const& parameters, std::vector<std::string> const& graph_paths, std::string const& reference_path,
-    genotyping::Samples const& samples, size_t g0, size_t g1, int threads)
+    genotyping::Samples const& samples, size_t g0, size_t g1, int threads, common::FastaFile const* fasta)
 {
     std::unique_ptr<Chunk> chunk(new Chunk);
     chunk->g0 = g0;
@@ -496,7 +501,7 @@ std::unique_ptr<Chunk> prepareChunk(
     const size_t n_graphs = g1 - g0, n_samples = samples.size();
     chunk->graphs.resize(n_graphs);
     const double t_load = now();
-    parallelFor(n_graphs, threads, [&](size_t g) { chunk->graphs[g] = paragraph::GraphDescription::load(graph_paths[g0 + g], reference_path); });
+    parallelFor(n_graphs, threads, [&](size_t g) { chunk->graphs[g] = paragraph::GraphDescription::load(graph_paths[g0 + g], reference_path, "", fasta); });
     const double t_extract = now();
     chunk->load_s = t_extract - t_load;
 
@@ -553,85 +558,100 @@ std::vector<Json> genotypeGraphs(
     if (n_graphs == 0 || n_samples == 0)
         return genotypes;
     const size_t per_batch = std::max<size_t>(1, parameters.sites_per_batch / n_samples);
-    const paragraph::Parameters site_parameters = siteParameters(parameters);
+    const size_t n_chunks = (n_graphs + per_batch - 1) / per_batch;
+    // Lanes: each lane takes the next chunk and carries it through every stage (load + extract, device batch, documents,
+    // genotypes) with its share of the host threads.  The device part of SiteBatcher::run() is serialised by the device
+    // mutex; everything else of different chunks overlaps -- one lane extracts while another is on the device and a third
+    // writes documents.
+    const size_t lanes = std::max<size_t>(1, std::min<size_t>((size_t)std::max(parameters.lanes, 1), n_chunks));
+    const int lane_threads = std::max(1, parameters.threads / (int)lanes);
+    paragraph::Timings lane_timings_total;
+    std::mutex timings_mutex;
+    const common::FastaFile fasta(reference_path);  // one handle for all graph loads (positional reads)
+    // one reader per sample kept open for the whole call: fails early on unreadable inputs and keeps the parsed header /
+    // index of every BAM alive, so the workers' own readers share it instead of parsing it again per chunk
+    std::vector<std::unique_ptr<common::BamReader>> keep_alive;
+    for (auto const& sample : samples)
+        keep_alive.emplace_back(new common::BamReader(sample.filename(), sample.index_filename(), reference_path));
 
-    // Two stages, double-buffered: while the device batch of chunk k runs (and its documents / genotypes are put
-    // together), a helper thread already loads the graphs and extracts the reads of chunk k + 1.
-    struct Prefetch
-    {
-        std::thread thread;
-        std::unique_ptr<Chunk> chunk;
-        std::exception_ptr failure;
-        void join()
+    std::atomic<size_t> next_chunk(0);
+    std::exception_ptr failure;
+    std::atomic<bool> failed(false);
+    auto lane = [&] {
+        paragraph::Timings mine;
+        paragraph::Parameters site_parameters = siteParameters(parameters);
+        site_parameters.threads = lane_threads;
+        site_parameters.timings = parameters.timings ? &mine : nullptr;
+        try
         {
-            if (thread.joinable())
-                thread.join();
-            if (failure)
-                std::rethrow_exception(failure);
-        }
-        ~Prefetch()
-        {
-            if (thread.joinable())
-                thread.join();
-        }
-    };
-    auto launch = [&](Prefetch& slot, size_t g0) {
-        const size_t g1 = std::min(n_graphs, g0 + per_batch);
-        slot.thread = std::thread([&slot, &parameters, &graph_paths, &reference_path, &samples, g0, g1] {
-            try
+            for (;;)
             {
-                slot.chunk = prepareChunk(parameters, graph_paths, reference_path, samples, g0, g1, parameters.threads);
-            }
-            catch (...)
-            {
-                slot.failure = std::current_exception();
-            }
-        });
-    };
-    Prefetch ahead;
-    launch(ahead, 0);
-    for (size_t g0 = 0; g0 < n_graphs; g0 += per_batch)
-    {
-        const double t_wait = now();
-        ahead.join();
-        std::unique_ptr<Chunk> chunk = std::move(ahead.chunk);
-        const double waited = now() - t_wait;
-        if (chunk->g1 < n_graphs)
-            launch(ahead, chunk->g1);  // the slot's previous thread has been joined: safe to re-arm
-        const size_t n_here = chunk->g1 - chunk->g0;
-        std::vector<paragraph::SiteInput> sites(n_here * n_samples);
-        for (size_t i = 0; i < sites.size(); ++i)
-        {
-            sites[i].description = &chunk->graphs[i / n_samples];
-            sites[i].reads = &chunk->reads[i];
-        }
-        std::vector<Json> documents = paragraph::alignAndDisambiguateBatch(site_parameters, sites);
-        for (size_t i = 0; i < documents.size(); ++i)
-            finishSampleDocument(documents[i], samples[i % n_samples].filename(), parameters.output_alignments);
+                const size_t c = next_chunk.fetch_add(1);
+                if (c >= n_chunks || failed.load())
+                    break;
+                const size_t g0 = c * per_batch, g1 = std::min(n_graphs, g0 + per_batch), n_here = g1 - g0;
+                std::unique_ptr<Chunk> chunk = prepareChunk(parameters, graph_paths, reference_path, samples, g0, g1, lane_threads, &fasta);
+                std::vector<paragraph::SiteInput> sites(n_here * n_samples);
+                for (size_t i = 0; i < sites.size(); ++i)
+                {
+                    sites[i].description = &chunk->graphs[i / n_samples];
+                    sites[i].reads = &chunk->reads[i];
+                }
+                std::vector<Json> documents = paragraph::alignAndDisambiguateBatch(site_parameters, sites);
+                for (size_t i = 0; i < documents.size(); ++i)
+                    finishSampleDocument(documents[i], samples[i % n_samples].filename(), parameters.output_alignments);
 
-        const double t_genotype = now();
-        parallelFor(n_here, parameters.threads, [&](size_t g) {
-            std::vector<genotyping::SampleInfo const*> sample_ptrs;
-            std::vector<Json const*> docs;
-            for (size_t s = 0; s < n_samples; ++s)
-            {
-                sample_ptrs.push_back(&samples[s]);
-                docs.push_back(&documents[g * n_samples + s]);
+                const double t_genotype = now();
+                parallelFor(n_here, lane_threads, [&](size_t g) {
+                    std::vector<genotyping::SampleInfo const*> sample_ptrs;
+                    std::vector<Json const*> docs;
+                    for (size_t s = 0; s < n_samples; ++s)
+                    {
+                        sample_ptrs.push_back(&samples[s]);
+                        docs.push_back(&documents[g * n_samples + s]);
+                    }
+                    genotypes[g0 + g]
+                        = genotypeDocument(*chunk->graphs[g].graph, chunk->graphs[g].description, genotyping_parameter_path, sample_ptrs, docs);
+                });
+                const double t_release = now();
+                // hundreds of thousands of small strings: give them back on all of the lane's threads
+                parallelFor(chunk->reads.size(), lane_threads, [&](size_t i) { common::ReadBuffer().swap(chunk->reads[i]); }, 16);
+                parallelFor(documents.size(), lane_threads, [&](size_t i) { documents[i] = Json(); }, 16);
+                mine.load_graphs += chunk->load_s;
+                mine.extract_reads += chunk->extract_s;
+                mine.genotypes += t_release - t_genotype;
+                mine.release += now() - t_release;
+                mine.batches += 1;
             }
-            genotypes[chunk->g0 + g]
-                = genotypeDocument(*chunk->graphs[g].graph, chunk->graphs[g].description, genotyping_parameter_path, sample_ptrs, docs);
-        });
-        // hundreds of thousands of small strings: give them back on all threads rather than in one destructor
-        parallelFor(chunk->reads.size(), parameters.threads, [&](size_t i) { common::ReadBuffer().swap(chunk->reads[i]); }, 16);
-        parallelFor(documents.size(), parameters.threads, [&](size_t i) { documents[i] = Json(); }, 16);
-        if (parameters.timings)
-        {
-            parameters.timings->load_graphs += chunk->load_s;
-            parameters.timings->extract_reads += chunk->extract_s;
-            parameters.timings->waited_for_input += waited;
-            parameters.timings->genotypes += now() - t_genotype;
-            parameters.timings->batches += 1;
         }
+        catch (...)
+        {
+            if (!failed.exchange(true))
+                failure = std::current_exception();
+        }
+        std::lock_guard<std::mutex> lock(timings_mutex);
+        lane_timings_total.load_graphs += mine.load_graphs;
+        lane_timings_total.extract_reads += mine.extract_reads;
+        lane_timings_total.device_batch += mine.device_batch;
+        lane_timings_total.documents += mine.documents;
+        lane_timings_total.genotypes += mine.genotypes;
+        lane_timings_total.release += mine.release;
+        lane_timings_total.sites += mine.sites;
+        lane_timings_total.reads += mine.reads;
+        lane_timings_total.batches += mine.batches;
+    };
+    std::vector<std::thread> pool;
+    for (size_t l = 1; l < lanes; ++l)
+        pool.emplace_back(lane);
+    lane();
+    for (auto& t : pool)
+        t.join();
+    if (failure)
+        std::rethrow_exception(failure);
+    if (parameters.timings)
+    {
+        *parameters.timings = lane_timings_total;
+        parameters.timings->lanes = lanes;
     }
     return genotypes;
 }

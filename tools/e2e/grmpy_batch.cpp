@@ -1,6 +1,6 @@
 // End-to-end probe: every graph of a list x every sample of a manifest through grmpy::genotypeGraphs (one device batch),
 // with the wall-clock split by phase.  Not a product CLI -- a measuring stick for the host side of the workflow.
-//   grmpy_batch <reference.fa> <manifest.txt> <graphs.txt> <threads> [genotypes.json] [sites_per_batch]
+//   grmpy_batch <reference.fa> <manifest.txt> <graphs.txt> <threads> [genotypes.json] [sites_per_batch] [lanes]
 #include <chrono>
 #include <fstream>
 #include <iostream>
@@ -26,6 +26,8 @@ int main(int argc, char** argv)
         parameters.threads = std::atoi(argv[4]);
         if (argc > 6)
             parameters.sites_per_batch = (size_t)std::atoll(argv[6]);
+        if (argc > 7)
+            parameters.lanes = std::atoi(argv[7]);
         common::Json runs = common::Json::array();
         std::vector<common::Json> genotypes;
         for (int rep = 0; rep < 2; ++rep)  // the first pass pays device start-up and cold file cache
@@ -42,8 +44,9 @@ int main(int argc, char** argv)
             run["device_batch_s"] = t.device_batch;
             run["documents_s"] = t.documents;
             run["genotypes_s"] = t.genotypes;
-            run["waited_for_input_s"] = t.waited_for_input;
+            run["release_s"] = t.release;
             run["batches"] = (uint64_t)t.batches;
+            run["lanes"] = (uint64_t)t.lanes;
             run["sites"] = (uint64_t)t.sites;
             run["reads"] = (uint64_t)t.reads;
             run["sites_per_s"] = (double)t.sites / total;

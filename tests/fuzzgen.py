@@ -160,3 +160,10 @@ def long_read_case(rng, n_reads=6):
             r = "".join(comp.get(c, "N") for c in reversed(r))
         reads.append(r)
     return seqs, edges, reads
+
+
+def salted(seed):
+    """Seeds of the GPU fuzz tests: PG_SEED_SALT=<n> shifts all of them, so `for n in ...: PG_SEED_SALT=$n pytest -m gpu -k fuzz`
+    runs the same comparisons on fresh random inputs (tools/stress_gpu.sh)."""
+    import os
+    return seed + 7919 * int(os.environ.get("PG_SEED_SALT", "0"))

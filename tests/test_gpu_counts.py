@@ -56,7 +56,7 @@ def test_reference_unit_vectors_supports(gpu_ctx):
 def test_counts_fuzz(gpu_ctx, checker):
     from oracle import counts as oc
     check = count_checker()
-    rng = random.Random(777)
+    rng = random.Random(fuzzgen.salted(777))
     for kw in (dict(remove_nonuniq=True, use_support_filters=True), dict(remove_nonuniq=False, use_support_filters=True),
                dict(remove_nonuniq=False, use_support_filters=False, bad_align_frac=0.5)):
         graphs, labels, names, reads, gor, frag, isrev, want = [], [], [], [], [], [], [], []
@@ -111,7 +111,7 @@ def test_kmer_filter_fuzz(gpu_ctx, filter_k):
     from oracle import kmerfilter as kf
     check = count_checker()
     fcheck = kf.ref_kmer_filter if oc.have_ref() else kf.port_kmer_filter
-    rng = random.Random(4040 + filter_k)
+    rng = random.Random(fuzzgen.salted(4040 + filter_k))
     graphs, labels, names, reads, gor, frag, isrev = [], [], [], [], [], [], []
     while len(graphs) < 80:
         seqs, edges = fuzzgen.rand_graph(rng, max_len=40, max_nodes=6)

@@ -59,7 +59,7 @@ def test_reference_unit_vectors(gpu_ctx):
 
 def test_klib_stage_fuzz_bubbles(gpu_ctx):
     chk = checker()
-    rng = random.Random(4242)
+    rng = random.Random(fuzzgen.salted(4242))
     graphs, paths, reads, gor, want = [], [], [], [], []
     for gi in range(120):
         nodes, ps, rs = random_case(rng, 10)
@@ -94,7 +94,7 @@ def _rand_paths(rng, n_nodes, edges):
 def test_klib_stage_fuzz_dags(gpu_ctx):
     from oracle.pathalign import _rc
     chk = checker()
-    rng = random.Random(99)
+    rng = random.Random(fuzzgen.salted(99))
     graphs, paths, reads, gor, want = [], [], [], [], []
     for gi in range(100):
         seqs, edges = fuzzgen.rand_graph(rng, max_len=60, max_nodes=7, shape=rng.choice(["del", "bubble", "dag", "longdel"]))
@@ -125,7 +125,7 @@ def test_klib_stage_fuzz_dags(gpu_ctx):
 def test_klib_stage_150bp_site(gpu_ctx):
     """Reads of the bench's shape (150 bp, ~500 bp of paths) incl. indel-bearing ones: R = 3 rows per lane."""
     chk = checker()
-    rng = random.Random(7)
+    rng = random.Random(fuzzgen.salted(7))
     lf = "".join(rng.choice("ACGT") for _ in range(200))
     rf = "".join(rng.choice("ACGT") for _ in range(200))
     alt = "".join(rng.choice("ACGT") for _ in range(60))
@@ -150,7 +150,7 @@ def test_klib_stage_150bp_site(gpu_ctx):
 def test_klib_stage_long_reads(gpu_ctx):
     """300..512 bp reads: R = 5..8 rows per lane, 8 direction bytes per lane per step."""
     chk = checker()
-    rng = random.Random(11)
+    rng = random.Random(fuzzgen.salted(11))
     graphs, paths, reads, gor, want = [], [], [], [], []
     for gi in range(12):
         seqs, edges, rs = fuzzgen.long_read_case(rng, 6)

@@ -74,7 +74,7 @@ def _rand_paths(rng, n_nodes, edges):
 def test_kmer_stage_fuzz(gpu_ctx, k):
     from oracle import kmeralign as ka
     from oracle.pathalign import _rc
-    rng = random.Random(77 + k)
+    rng = random.Random(fuzzgen.salted(77 + k))
     graphs, paths, reads, gor, want = [], [], [], [], []
     for gi in range(150):
         seqs, edges = fuzzgen.rand_graph(rng, max_len=50, max_nodes=6, shape=rng.choice(["del", "bubble", "dag", "longdel"]))

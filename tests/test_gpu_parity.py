@@ -64,7 +64,7 @@ def test_fuzz_many_graphs(gpu_ctx, checker):
 
 def test_fuzz_long_reads(gpu_ctx, checker):
     import random
-    rng = random.Random(5)
+    rng = random.Random(fuzzgen.salted(5))
     graphs, reads, gor, want = [], [], [], []
     for gi in range(60):
         seqs, edges = fuzzgen.rand_graph(rng, max_len=150, max_nodes=5)
@@ -81,7 +81,7 @@ def test_fuzz_word_mode_reads(gpu_ctx, checker):
     """251..512 bp reads: the wide kernel variants (two bytes of H per cell) = gssw's 16-bit word mode, incl. the
     reference's byte-pointer scan of word matrices in alignsEndAtMultNodes (scores 251..255 / >= 256)."""
     import random
-    rng = random.Random(512)
+    rng = random.Random(fuzzgen.salted(512))
     graphs, reads, gor, want = [], [], [], []
     for gi in range(120):
         if gi % 3 == 0:
@@ -131,7 +131,7 @@ def test_empty_and_ragged(gpu_ctx, checker):
 def test_length_boundaries(gpu_ctx, checker):
     """Every variant boundary: rows-per-lane steps (multiples of 32 / 64), byte vs wide (250 / 251), the 512 limit."""
     import random
-    rng = random.Random(1234)
+    rng = random.Random(fuzzgen.salted(1234))
     seqs, edges, _ = fuzzgen.long_read_case(rng, 1)
     path = seqs[0] + seqs[1] + seqs[-1]
     lens = [1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 159, 160, 161, 191, 192, 193, 223, 224,
@@ -191,7 +191,7 @@ def test_many_tiny_nodes(gpu_ctx, checker):
     """Graphs with hundreds of 1-4 bp nodes: single-column nodes (FIRST and LAST on the same column), long
     predecessor lists, seeds on every column, node-key table far larger than the profile."""
     import random
-    rng = random.Random(4321)
+    rng = random.Random(fuzzgen.salted(4321))
     graphs, reads, gor, want = [], [], [], []
     for gi in range(6):
         n = rng.choice([60, 150, 300])

@@ -69,7 +69,7 @@ def _path_reads(rng, seqs, edges, k, n):
 @pytest.mark.parametrize("k", [8, 16, 32])
 def test_path_stage_fuzz(gpu_ctx, k):
     check = path_checker()
-    rng = random.Random(1000 + k)
+    rng = random.Random(fuzzgen.salted(1000 + k))
     graphs, reads, gor, want = [], [], [], []
     for gi in range(250):
         seqs, edges = fuzzgen.rand_graph(rng, max_len=60, max_nodes=6)

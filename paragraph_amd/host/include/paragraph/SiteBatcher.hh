@@ -16,6 +16,8 @@
 
 #include "common/Read.hh"
 #include "graphcore/Graph.hh"
+#include "paragraph/PackedReads.hh"
+#include "paragraph/Statistics.hh"
 
 namespace paragraph
 {
@@ -63,11 +65,15 @@ public:
     ~SiteBatcher();
     // graph and reads must outlive run(); returns the site index
     size_t addSite(const graphtools::Graph* graph, std::vector<common::p_Read>* reads);
+    // the packed form: the reads are only read; what the statistics need of the MAPPED ones is available through views()
+    // after run().  One batch holds sites of one form only.
+    size_t addSite(const graphtools::Graph* graph, PackedSite const* reads);
     // Aligns and counts every site added so far.  Afterwards each site's read vector holds only the MAPPED
     // reads (as grm::alignReads leaves it, Align.cpp:155) with their supports filled in.
     void run(BatchParameters const& parameters = BatchParameters());
     size_t numSites() const;
     SiteCounts const& counts(size_t site) const;
+    SiteReadViews const& views(size_t site) const;  // packed sites only
 
 private:
     struct Impl;

@@ -41,6 +41,40 @@ private:
     double heights_[5] = { 0, 0, 0, 0, 0 }, actual_[5] = { 1, 2, 3, 4, 5 }, desired_[5] = { 1, 2, 3, 4, 5 };
 };
 
-common::Json fragmentStatistics(graphtools::Graph const& graph, std::vector<common::Read const*> const& reads);
-common::Json alignmentStatistics(graphtools::Graph const& graph, std::vector<common::Read const*> const& reads);
+// What the statistics need of one read that survived alignment + filters, independent of where it is kept (a common::Read
+// with its graph CIGAR string, or the flat device results of a packed batch)
+struct MappedReadView
+{
+    uint32_t fragment = 0;  // dense id of the read's fragment within the site, numbered by first appearance
+    uint32_t read_length = 0;
+    int32_t chrom_id = -1, pos = -1, mate_chrom_id = -1, mate_pos = -1;
+    int32_t graph_pos = 0, graph_alignment_score = 0;
+    bool is_mapped = false, is_mate_mapped = false, is_reverse_strand = false, is_mate_reverse_strand = false;
+    bool is_graph_mapped = false, is_graph_reverse_strand = false;
+    uint32_t pieces_off = 0, n_pieces = 0;  // node alignments in SiteReadViews::pieces
+    uint64_t sequences = 0;                 // supported sequence labels, bit i = SiteReadViews::label_names[i]
+    uint32_t support_off = 0, n_support = 0;  // PG_PATH-coded path entries in SiteReadViews::support (packed batches only)
+};
+
+struct SiteReadViews
+{
+    std::vector<MappedReadView> reads;
+    std::vector<NodeAlignment> pieces;
+    std::vector<uint32_t> support;
+    std::vector<std::string> label_names;  // the graph's edge labels, sorted
+    uint32_t n_fragments = 0;
+};
+// views of reads held as objects (fragments numbered by fragment_id, graph CIGARs decoded)
+SiteReadViews viewsOfReads(graphtools::Graph const& graph, std::vector<common::Read const*> const& reads);
+
+common::Json fragmentStatistics(graphtools::Graph const& graph, SiteReadViews const& views);
+common::Json alignmentStatistics(graphtools::Graph const& graph, SiteReadViews const& views);
+inline common::Json fragmentStatistics(graphtools::Graph const& graph, std::vector<common::Read const*> const& reads)
+{
+    return fragmentStatistics(graph, viewsOfReads(graph, reads));
+}
+inline common::Json alignmentStatistics(graphtools::Graph const& graph, std::vector<common::Read const*> const& reads)
+{
+    return alignmentStatistics(graph, viewsOfReads(graph, reads));
+}
 }  // namespace paragraph

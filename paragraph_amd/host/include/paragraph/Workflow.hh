@@ -19,6 +19,7 @@
 #include "common/Region.hh"
 #include "genotyping/SampleInfo.hh"
 #include "graphcore/Graph.hh"
+#include "paragraph/PackedReads.hh"
 
 namespace paragraph
 {
@@ -81,9 +82,17 @@ struct SiteInput
     common::ReadBuffer* reads = nullptr;  // in: extracted reads; out: the reads the document was built from
 };
 
+struct PackedSiteInput
+{
+    GraphDescription const* description = nullptr;
+    PackedSite const* reads = nullptr;  // from extractPacked; not modified
+};
+
 // One device batch over all sites; returns one count document per site: the description plus "reference",
 // "read_counts_by_node" / "_by_edge" / "_by_sequence", "fragment_statistics", "alignment_statistics" and optionally "alignments".
 std::vector<common::Json> alignAndDisambiguateBatch(Parameters const& parameters, std::vector<SiteInput> const& sites);
+// the same documents (minus "alignments", which this form cannot give) from reads kept in the packed form
+std::vector<common::Json> alignAndDisambiguateBatch(Parameters const& parameters, std::vector<PackedSiteInput> const& sites);
 // single-site convenience with the reference's shape
 common::Json alignAndDisambiguate(Parameters const& parameters, GraphDescription const& description, common::ReadBuffer& all_reads);
 }  // namespace paragraph
@@ -100,6 +109,9 @@ struct Parameters
     bool graph_sequence_matching = true;
     int bad_align_uniq_kmer_len = 0;
     bool output_alignments = false;  // keep "alignments" in the per-sample documents (the original writes them to a folder)
+    // keep the reads of a site as flat arrays instead of common::Read objects (several times less host work); switched off
+    // automatically when output_alignments needs the per-read records
+    bool packed_reads = true;
     size_t sites_per_batch = 1024;   // (graph, sample) pairs per device batch; bounds host memory and sets the pipeline grain
     int lanes = 4;                   // chunks in flight: each lane carries one chunk through all stages with threads / lanes workers
     paragraph::Timings* timings = nullptr;

@@ -539,6 +539,49 @@ double RunningStats::mean() const { return n_ ? sum_ / (double)n_ : std::numeric
 double RunningStats::variance() const { return var_; }
 double RunningStats::median() const { return heights_[2]; }
 
+SiteReadViews viewsOfReads(Graph const& graph, std::vector<common::Read const*> const& reads)
+{
+    SiteReadViews v;
+    const std::set<std::string> labels = graph.allLabels();
+    v.label_names.assign(labels.begin(), labels.end());
+    std::unordered_map<std::string, uint32_t> fragment_of;
+    v.reads.reserve(reads.size());
+    for (common::Read const* read : reads)
+    {
+        MappedReadView m;
+        m.fragment = fragment_of.emplace(read->fragment_id(), (uint32_t)fragment_of.size()).first->second;
+        m.read_length = (uint32_t)read->bases().size();
+        m.chrom_id = read->chrom_id();
+        m.pos = read->pos();
+        m.mate_chrom_id = read->mate_chrom_id();
+        m.mate_pos = read->mate_pos();
+        m.is_mapped = read->is_mapped();
+        m.is_mate_mapped = read->is_mate_mapped();
+        m.is_reverse_strand = read->is_reverse_strand();
+        m.is_mate_reverse_strand = read->is_mate_reverse_strand();
+        m.is_graph_mapped = read->graph_mapping_status() == common::Read::MAPPED;
+        m.is_graph_reverse_strand = read->is_graph_reverse_strand();
+        m.graph_pos = read->graph_pos();
+        m.graph_alignment_score = read->graph_alignment_score();
+        if (m.is_graph_mapped)
+        {
+            const auto pieces = decodeGraphCigar(read->graph_cigar(), graph);
+            m.pieces_off = (uint32_t)v.pieces.size();
+            m.n_pieces = (uint32_t)pieces.size();
+            v.pieces.insert(v.pieces.end(), pieces.begin(), pieces.end());
+        }
+        for (auto const& name : read->graph_sequences_supported())
+        {
+            const auto it = std::lower_bound(v.label_names.begin(), v.label_names.end(), name);
+            if (it != v.label_names.end() && *it == name)
+                m.sequences |= 1ull << (it - v.label_names.begin());
+        }
+        v.reads.push_back(m);
+    }
+    v.n_fragments = (uint32_t)fragment_of.size();
+    return v;
+}
+
 namespace
 {
 const uint64_t kNoLength = std::numeric_limits<uint64_t>::max();
@@ -551,25 +594,25 @@ struct FragmentShape
     std::vector<uint64_t> lengths;
 };
 
-void addToFragment(FragmentShape& f, graphtools::GraphCoordinates const& coords, common::Read const& read)
+void addToFragment(FragmentShape& f, graphtools::GraphCoordinates const& coords, SiteReadViews const& views, MappedReadView const& read)
 {
     ++f.n_reads;
-    const bool proper = read.is_mapped() && read.is_mate_mapped() && read.is_reverse_strand() != read.is_mate_reverse_strand()
-        && read.mate_chrom_id() == read.chrom_id();
-    f.bam_length = (!proper || f.n_reads > 2) ? kNoLength : (uint64_t)std::abs(read.mate_pos() - read.pos()) + read.bases().size();
-    if (read.graph_mapping_status() != common::Read::MAPPED)
+    const bool proper = read.is_mapped && read.is_mate_mapped && read.is_reverse_strand != read.is_mate_reverse_strand
+        && read.mate_chrom_id == read.chrom_id;
+    f.bam_length = (!proper || f.n_reads > 2) ? kNoLength : (uint64_t)std::abs(read.mate_pos - read.pos) + read.read_length;
+    if (!read.is_graph_mapped || read.n_pieces == 0)
         return;
-    const auto nodes = decodeGraphCigar(read.graph_cigar(), coords.getGraph());
+    const NodeAlignment* nodes = &views.pieces[read.pieces_off];
     graphtools::Path walk;
     walk.graph = &coords.getGraph();
-    walk.start_position = read.graph_pos();
+    walk.start_position = read.graph_pos;
     uint64_t query_length = 0;
-    for (auto const& na : nodes)
+    for (uint32_t k = 0; k < read.n_pieces; ++k)
     {
-        walk.nodes.push_back(na.node);
-        query_length += na.queryLength();
+        walk.nodes.push_back(nodes[k].node);
+        query_length += nodes[k].queryLength();
     }
-    walk.end_position = (int32_t)nodes.back().referenceLength() + (nodes.size() == 1 ? read.graph_pos() : 0);
+    walk.end_position = (int32_t)nodes[read.n_pieces - 1].referenceLength() + (read.n_pieces == 1 ? read.graph_pos : 0);
     f.spans.push_back(coords.canonicalStartAndEnd(walk));
     f.lengths.push_back(query_length);
     if (f.spans.size() == 1)
@@ -604,20 +647,22 @@ void addToFragment(FragmentShape& f, graphtools::GraphCoordinates const& coords,
 }
 }  // namespace
 
-Json fragmentStatistics(Graph const& graph, std::vector<common::Read const*> const& reads)
+Json fragmentStatistics(Graph const& graph, SiteReadViews const& views)
 {
     graphtools::GraphCoordinates coords(&graph);
-    std::list<FragmentShape> fragments;
-    std::unordered_map<std::string, FragmentShape*> by_id;
-    for (common::Read const* read : reads)
+    // fragments in order of first appearance (the order the running estimators see them in)
+    std::vector<FragmentShape> fragments;
+    std::vector<uint32_t> slot_of(views.n_fragments, (uint32_t)-1);
+    for (MappedReadView const& read : views.reads)
     {
-        auto it = by_id.find(read->fragment_id());
-        if (it == by_id.end())
+        if (read.fragment >= slot_of.size())
+            slot_of.resize(read.fragment + 1, (uint32_t)-1);
+        if (slot_of[read.fragment] == (uint32_t)-1)
         {
+            slot_of[read.fragment] = (uint32_t)fragments.size();
             fragments.emplace_back();
-            it = by_id.emplace(read->fragment_id(), &fragments.back()).first;
         }
-        addToFragment(*it->second, coords, *read);
+        addToFragment(fragments[slot_of[read.fragment]], coords, views, read);
     }
     RunningStats linear, on_graph;
     uint64_t bad_linear = 0, bad_graph = 0, single = 0, paired = 0, multi = 0;
@@ -682,7 +727,7 @@ struct Tally
 };
 }  // namespace
 
-Json alignmentStatistics(Graph const& graph, std::vector<common::Read const*> const& reads)
+Json alignmentStatistics(Graph const& graph, SiteReadViews const& views)
 {
     const NodeId n_nodes = (NodeId)graph.numNodes();
     // an allele's length: the nodes that carry its label on an edge in AND an edge out
@@ -701,13 +746,13 @@ Json alignmentStatistics(Graph const& graph, std::vector<common::Read const*> co
     const bool terminals = n_nodes && (graph.nodeName(0) == "source" || graph.nodeName(n_nodes - 1) == "sink");
     std::map<std::string, Tally> node_stats, edge_stats, allele_stats;
     std::map<std::string, int> allele_score;
-    for (common::Read const* read : reads)
+    for (MappedReadView const& read : views.reads)
     {
-        if (read->graph_mapping_status() != common::Read::MAPPED)
+        if (!read.is_graph_mapped)
             continue;
-        const auto pieces = decodeGraphCigar(read->graph_cigar(), graph);
-        const bool reverse = read->is_graph_reverse_strand();
-        for (size_t k = 0; k < pieces.size(); ++k)
+        const NodeAlignment* pieces = read.n_pieces ? &views.pieces[read.pieces_off] : nullptr;
+        const bool reverse = read.is_graph_reverse_strand;
+        for (size_t k = 0; k < read.n_pieces; ++k)
         {
             const NodeId node = pieces[k].node;
             const bool terminal = terminals && (node == 0 || node == n_nodes - 1);
@@ -726,13 +771,16 @@ Json alignmentStatistics(Graph const& graph, std::vector<common::Read const*> co
             et.bases(pieces[k], terminal);
             et.strand(reverse);
         }
-        for (auto const& allele : read->graph_sequences_supported())
+        for (size_t b = 0; b < views.label_names.size(); ++b)
         {
+            if (!((read.sequences >> b) & 1))
+                continue;
+            std::string const& allele = views.label_names[b];
             Tally& at = allele_stats.emplace(allele, Tally(allele_length[allele])).first->second;
-            for (auto const& piece : pieces)
-                at.bases(piece, !(terminals && (piece.node == 0 || piece.node == n_nodes - 1)));
+            for (size_t k = 0; k < read.n_pieces; ++k)
+                at.bases(pieces[k], !(terminals && (pieces[k].node == 0 || pieces[k].node == n_nodes - 1)));
             at.strand(reverse);
-            allele_score[allele] += read->graph_alignment_score();
+            allele_score[allele] += read.graph_alignment_score;
         }
     }
     Json out = Json::object();

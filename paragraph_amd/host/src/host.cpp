@@ -645,7 +645,9 @@ struct SiteBatcher::Impl
 {
     std::vector<const Graph*> graphs;
     std::vector<std::vector<common::p_Read>*> reads;
+    std::vector<const PackedSite*> packed;
     std::vector<SiteCounts> counts;
+    std::vector<SiteReadViews> views;
 };
 
 SiteBatcher::SiteBatcher() : impl_(new Impl()) {}
@@ -653,10 +655,21 @@ SiteBatcher::~SiteBatcher() = default;
 size_t SiteBatcher::numSites() const { return impl_->graphs.size(); }
 SiteCounts const& SiteBatcher::counts(size_t site) const { return impl_->counts.at(site); }
 
+SiteReadViews const& SiteBatcher::views(size_t site) const { return impl_->views.at(site); }
+
 size_t SiteBatcher::addSite(const Graph* graph, std::vector<common::p_Read>* reads)
 {
     impl_->graphs.push_back(graph);
     impl_->reads.push_back(reads);
+    impl_->packed.push_back(nullptr);
+    return impl_->graphs.size() - 1;
+}
+
+size_t SiteBatcher::addSite(const Graph* graph, PackedSite const* reads)
+{
+    impl_->graphs.push_back(graph);
+    impl_->reads.push_back(nullptr);
+    impl_->packed.push_back(reads);
     return impl_->graphs.size() - 1;
 }
 
@@ -682,26 +695,52 @@ void SiteBatcher::run(BatchParameters const& prm)
         csr.add(*g);
     mark("graph csr");
     // ---- pack the reads of all sites: offsets first, then every site fills its own slice --------------------
+    const bool packed_mode = impl_->packed[0] != nullptr;
+    for (size_t s = 0; s < n_sites; ++s)
+        if ((impl_->packed[s] != nullptr) != packed_mode || (!packed_mode && !impl_->reads[s]))
+            throw std::logic_error("SiteBatcher: a batch holds either object sites or packed sites");
     std::vector<uint64_t> site_read0(n_sites + 1, 0), site_base0(n_sites + 1, 0);
     for (size_t s = 0; s < n_sites; ++s)
     {
-        uint64_t site_bases = 0;
-        for (auto const& r : *impl_->reads[s])
-            site_bases += r->bases().size();
-        site_read0[s + 1] = site_read0[s] + impl_->reads[s]->size();
+        uint64_t site_bases = 0, site_reads = 0;
+        if (packed_mode)
+        {
+            site_bases = impl_->packed[s]->bases.size();
+            site_reads = impl_->packed[s]->size();
+        }
+        else
+        {
+            for (auto const& r : *impl_->reads[s])
+                site_bases += r->bases().size();
+            site_reads = impl_->reads[s]->size();
+        }
+        site_read0[s + 1] = site_read0[s] + site_reads;
         site_base0[s + 1] = site_base0[s] + site_bases;
     }
     if (site_read0[n_sites] > 0xFFFFFFFFull || site_base0[n_sites] > 0xFFFFFFFFull)
         throw std::runtime_error("SiteBatcher: more than 2^32 reads or bases in one batch");
     std::vector<uint32_t> base_off(site_read0[n_sites] + 1, 0), gor(site_read0[n_sites]), frag(site_read0[n_sites]);
     std::vector<uint8_t> is_rev(site_read0[n_sites]);
-    std::vector<Read*> flat(site_read0[n_sites]);
+    std::vector<Read*> flat(packed_mode ? 0 : site_read0[n_sites]);
     std::string bases(site_base0[n_sites], '\0');
     pghost::parallelFor(
         n_sites, prm.threads,
         [&](size_t s) {
-            std::unordered_map<std::string, uint32_t> frag_ids;  // fragment ids are local to a site
             uint64_t i = site_read0[s], at = site_base0[s];
+            if (packed_mode)
+            {
+                PackedSite const& p = *impl_->packed[s];
+                std::copy(p.bases.begin(), p.bases.end(), bases.begin() + (std::ptrdiff_t)at);
+                for (size_t k = 0; k < p.size(); ++k, ++i)
+                {
+                    base_off[i + 1] = (uint32_t)(at + p.base_end[k]);
+                    gor[i] = (uint32_t)s;
+                    frag[i] = p.fragment[k];
+                    is_rev[i] = (p.flags[k] & PackedSite::REVERSE) ? 1 : 0;
+                }
+                return;
+            }
+            std::unordered_map<std::string, uint32_t> frag_ids;  // fragment ids are local to a site
             for (auto& r : *impl_->reads[s])
             {
                 flat[i] = r.get();
@@ -724,7 +763,7 @@ void SiteBatcher::run(BatchParameters const& prm)
     std::vector<uint32_t> table, path;
     std::vector<pg_read_support> sup;
     pg_count_layout lay{};
-    const uint32_t n = (uint32_t)flat.size();
+    const uint32_t n = (uint32_t)gor.size();
     {
         std::lock_guard<std::mutex> lock(deviceMutex());
         pg_graphs* G = nullptr;
@@ -799,58 +838,128 @@ void SiteBatcher::run(BatchParameters const& prm)
     }  // device objects released, mutex dropped
     mark("align+count+download");
     // ---- fan results back into the reads ---------------------------------------------------------------
-    pghost::parallelFor(
-        n, prm.threads,
-        [&](size_t i) {
-            Read& read = *flat[i];
-            if (read.bases().empty() || sup[i].status == 0)
-                return;
-            if (sup[i].status == 3)
-                throw std::runtime_error("invalid alignment on the device path for fragment " + read.fragment_id());
-            if (res[i].status & PG_STATUS_PATH_ALIGNER)
-            {
-                // PathAligner.cpp:121-161: the match's own strand, bases replaced, qualities untouched
-                if (res[i].returned_reverse)
-                    read.set_bases(reverseComplement(read.bases()));
-                read.set_is_graph_reverse_strand(res[i].returned_reverse != 0);
-                std::string buf(16 + 12 * (size_t)res[i].n_ops, '\0');
-                buf.resize(pg_render_cigar(&res[i], ops.data(), &buf[0], buf.size()));
-                read.set_graph_cigar(buf);
-                read.set_graph_pos(res[i].graph_pos);
-                read.set_graph_alignment_score(res[i].score);
-                read.set_is_graph_alignment_unique(res[i].is_unique != 0);
-                read.set_graph_mapq(res[i].mapq);
-            }
-            else
-                applyResult(read, res[i], ops.data(), true);
-            read.set_graph_mapping_status(sup[i].status == 1 ? Read::MAPPED : Read::BAD_ALIGN);
-            read.clear_graph_nodes_supported();
-            read.clear_graph_edges_supported();
-            read.clear_graph_sequences_supported();
-            if (sup[i].status != 1)
-                return;
-            const Graph& g = *impl_->graphs[gor[i]];
-            uint32_t prev = 0;
-            std::vector<std::pair<std::string, std::string>> edges;
-            for (uint32_t k = 0; k < sup[i].n_path; ++k)
-            {
-                const uint32_t en = path[sup[i].path_off + k];
-                const uint32_t nd = PG_PATH_NODE(en);
-                if (PG_PATH_NODE_OK(en))
-                    read.add_graph_nodes_supported(g.nodeName(nd));
-                if (k > 0 && PG_PATH_EDGE_OK(en))
-                    edges.emplace_back(g.nodeName(prev), g.nodeName(nd));
-                prev = nd;
-            }
-            std::sort(edges.begin(), edges.end());  // the reference collects them in a std::set of name pairs
-            for (auto const& e : edges)
-                read.add_graph_edges_supported(e.first + "_" + e.second);
-            const auto& names = csr.label_names[gor[i]];
-            for (size_t b = 0; b < names.size(); ++b)
-                if ((sup[i].label_mask >> b) & 1)
-                    read.add_graph_sequences_supported(names[b]);
-        },
-        512);
+    if (!packed_mode)
+        pghost::parallelFor(
+            n, prm.threads,
+            [&](size_t i) {
+                Read& read = *flat[i];
+                if (read.bases().empty() || sup[i].status == 0)
+                    return;
+                if (sup[i].status == 3)
+                    throw std::runtime_error("invalid alignment on the device path for fragment " + read.fragment_id());
+                if (res[i].status & PG_STATUS_PATH_ALIGNER)
+                {
+                    // PathAligner.cpp:121-161: the match's own strand, bases replaced, qualities untouched
+                    if (res[i].returned_reverse)
+                        read.set_bases(reverseComplement(read.bases()));
+                    read.set_is_graph_reverse_strand(res[i].returned_reverse != 0);
+                    std::string buf(16 + 12 * (size_t)res[i].n_ops, '\0');
+                    buf.resize(pg_render_cigar(&res[i], ops.data(), &buf[0], buf.size()));
+                    read.set_graph_cigar(buf);
+                    read.set_graph_pos(res[i].graph_pos);
+                    read.set_graph_alignment_score(res[i].score);
+                    read.set_is_graph_alignment_unique(res[i].is_unique != 0);
+                    read.set_graph_mapq(res[i].mapq);
+                }
+                else
+                    applyResult(read, res[i], ops.data(), true);
+                read.set_graph_mapping_status(sup[i].status == 1 ? Read::MAPPED : Read::BAD_ALIGN);
+                read.clear_graph_nodes_supported();
+                read.clear_graph_edges_supported();
+                read.clear_graph_sequences_supported();
+                if (sup[i].status != 1)
+                    return;
+                const Graph& g = *impl_->graphs[gor[i]];
+                uint32_t prev = 0;
+                std::vector<std::pair<std::string, std::string>> edges;
+                for (uint32_t k = 0; k < sup[i].n_path; ++k)
+                {
+                    const uint32_t en = path[sup[i].path_off + k];
+                    const uint32_t nd = PG_PATH_NODE(en);
+                    if (PG_PATH_NODE_OK(en))
+                        read.add_graph_nodes_supported(g.nodeName(nd));
+                    if (k > 0 && PG_PATH_EDGE_OK(en))
+                        edges.emplace_back(g.nodeName(prev), g.nodeName(nd));
+                    prev = nd;
+                }
+                std::sort(edges.begin(), edges.end());  // the reference collects them in a std::set of name pairs
+                for (auto const& e : edges)
+                    read.add_graph_edges_supported(e.first + "_" + e.second);
+                const auto& names = csr.label_names[gor[i]];
+                for (size_t b = 0; b < names.size(); ++b)
+                    if ((sup[i].label_mask >> b) & 1)
+                        read.add_graph_sequences_supported(names[b]);
+            },
+            512);
+    // ---- packed sites: what the statistics need of the MAPPED reads, straight from the device records ----------
+    impl_->views.assign(n_sites, SiteReadViews());
+    if (packed_mode)
+        pghost::parallelFor(
+            n_sites, prm.threads,
+            [&](size_t s) {
+                PackedSite const& p = *impl_->packed[s];
+                SiteReadViews& v = impl_->views[s];
+                v.label_names = csr.label_names[s];
+                uint32_t n_fragments = 0;
+                for (size_t k = 0; k < p.size(); ++k)
+                {
+                    const size_t i = site_read0[s] + k;
+                    n_fragments = std::max(n_fragments, p.fragment[k] + 1);
+                    if (p.readLength(k) == 0 || sup[i].status == 0)
+                        continue;
+                    if (sup[i].status == 3)
+                        throw std::runtime_error("invalid alignment on the device path in site " + std::to_string(s));
+                    if (sup[i].status != 1)
+                        continue;
+                    MappedReadView m;
+                    m.fragment = p.fragment[k];
+                    m.read_length = p.readLength(k);
+                    m.chrom_id = p.chrom_id[k];
+                    m.pos = p.pos[k];
+                    m.mate_chrom_id = p.mate_chrom_id[k];
+                    m.mate_pos = p.mate_pos[k];
+                    m.is_mapped = (p.flags[k] & PackedSite::MAPPED) != 0;
+                    m.is_mate_mapped = (p.flags[k] & PackedSite::MATE_MAPPED) != 0;
+                    m.is_reverse_strand = (p.flags[k] & PackedSite::REVERSE) != 0;
+                    m.is_mate_reverse_strand = (p.flags[k] & PackedSite::MATE_REVERSE) != 0;
+                    m.is_graph_mapped = true;
+                    m.is_graph_reverse_strand = (res[i].status & PG_STATUS_PATH_ALIGNER) ? res[i].returned_reverse != 0
+                                                                                         : m.is_reverse_strand != (res[i].returned_reverse != 0);
+                    m.graph_pos = res[i].graph_pos;
+                    m.graph_alignment_score = res[i].score;
+                    m.pieces_off = (uint32_t)v.pieces.size();
+                    for (uint32_t o = 0; o < res[i].n_ops; ++o)
+                    {
+                        const pg_op op = ops[res[i].ops_off + o];
+                        const NodeId node = PG_OP_NODE(op);
+                        if (v.pieces.size() == m.pieces_off || v.pieces.back().node != node)
+                        {
+                            v.pieces.emplace_back();
+                            v.pieces.back().node = node;
+                        }
+                        NodeAlignment& na = v.pieces.back();
+                        const uint32_t len = PG_OP_LEN(op);
+                        switch (PG_OP_CODE(op))
+                        {
+                        case PG_OPC_M: na.matched += len; break;
+                        case PG_OPC_X: na.mismatched += len; break;
+                        case PG_OPC_N: na.missing += len; break;
+                        case PG_OPC_I: na.inserted += len; break;
+                        case PG_OPC_D: na.deleted += len; break;
+                        case PG_OPC_S: na.clipped += len; break;
+                        default: break;  // PG_OPC_EMPTY: the node is on the path with an empty CIGAR
+                        }
+                    }
+                    m.n_pieces = (uint32_t)v.pieces.size() - m.pieces_off;
+                    m.sequences = sup[i].label_mask;
+                    m.support_off = (uint32_t)v.support.size();
+                    m.n_support = sup[i].n_path;
+                    v.support.insert(v.support.end(), path.begin() + sup[i].path_off, path.begin() + sup[i].path_off + sup[i].n_path);
+                    v.reads.push_back(m);
+                }
+                v.n_fragments = n_fragments;
+            },
+            8);
     mark("results -> reads");
     // ---- per-site tables --------------------------------------------------------------------------------
     auto entry = [&](uint64_t off) {
@@ -898,6 +1007,8 @@ void SiteBatcher::run(BatchParameters const& prm)
             sc.nonuniq = table[t + 3];
             if (table[t] >> 31)
                 throw std::runtime_error("a fragment touched more than 48 distinct nodes/edges (device count-table limit)");
+            if (packed_mode)
+                return;
             // only MAPPED reads survive (Align.cpp:155)
             std::vector<common::p_Read> kept;
             for (auto& r : *impl_->reads[s])

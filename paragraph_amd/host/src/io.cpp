@@ -5,6 +5,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,6 +22,7 @@
 #include "common/ReadExtraction.hh"
 #include "common/ReadPairs.hh"
 #include "common/Region.hh"
+#include "paragraph/PackedReads.hh"
 
 namespace common
 {
@@ -945,6 +947,159 @@ void extractReads(
     extractReads(reader, target_regions, max_num_reads, longest_alt_insertion, all_reads, avr_fragment_length);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// extraction into the packed form
+// ------------------------------------------------------------------------------------------------------------------
+}  // namespace common
+
+namespace paragraph
+{
+void PackedSite::clear()
+{
+    bases.clear();
+    base_end.clear();
+    fragment.clear();
+    flags.clear();
+    chrom_id.clear();
+    pos.clear();
+    mate_chrom_id.clear();
+    mate_pos.clear();
+}
+
+namespace
+{
+// the reads of one target region while it is scanned: one slot pair per fragment id, like common::ReadPairs
+struct RegionReads
+{
+    struct Kept
+    {
+        uint32_t base_begin, base_len;
+        int32_t chrom_id, pos, mate_chrom_id, mate_pos;
+        uint8_t flags;
+    };
+    std::map<std::string, std::array<int32_t, 2>> slots;  // fragment id -> index into `kept` of first / second mate, -1 = empty
+    std::vector<Kept> kept;
+    std::string bases;
+    int num_reads = 0;
+
+    void add(common::Read const& r)
+    {
+        auto it = slots.find(r.fragment_id());
+        if (it == slots.end())
+            it = slots.emplace(r.fragment_id(), std::array<int32_t, 2>{ -1, -1 }).first;
+        int32_t& slot = it->second[r.is_first_mate() ? 0 : 1];
+        Kept k;
+        k.base_begin = (uint32_t)bases.size();
+        k.base_len = (uint32_t)r.bases().size();
+        bases += r.bases();
+        k.chrom_id = r.chrom_id();
+        k.pos = r.pos();
+        k.mate_chrom_id = r.mate_chrom_id();
+        k.mate_pos = r.mate_pos();
+        k.flags = (uint8_t)((r.is_reverse_strand() ? PackedSite::REVERSE : 0) | (r.is_first_mate() ? PackedSite::FIRST_MATE : 0)
+                            | (r.is_mapped() ? PackedSite::MAPPED : 0) | (r.is_mate_mapped() ? PackedSite::MATE_MAPPED : 0)
+                            | (r.is_mate_reverse_strand() ? PackedSite::MATE_REVERSE : 0));
+        if (slot < 0)
+        {
+            // an empty-sequence record does not make a slot "initialized" (Read::is_initialized), but a later one replaces it
+            if (k.base_len > 0)
+                ++num_reads;
+            slot = (int32_t)kept.size();
+            kept.push_back(k);
+        }
+        else
+        {
+            if (kept[(size_t)slot].base_len == 0 && k.base_len > 0)
+                ++num_reads;
+            else if (kept[(size_t)slot].base_len > 0 && k.base_len == 0)
+                --num_reads;
+            kept[(size_t)slot] = k;
+        }
+    }
+};
+}  // namespace
+
+void extractPacked(
+    common::ReadReader& reader, std::list<common::Region> const& target_regions, int max_num_reads, unsigned longest_alt_insertion,
+    PackedSite& site, int avr_fragment_length)
+{
+    std::unordered_map<std::string, uint32_t> fragment_of;  // across the regions of this site, seeded with what the site holds
+    uint32_t next_fragment = 0;
+    for (uint32_t f : site.fragment)
+        next_fragment = std::max(next_fragment, f + 1);
+    if (next_fragment != 0)
+        throw std::logic_error("extractPacked: the site must be empty (fragment ids are assigned by name)");
+    common::Read read;
+    for (common::Region const& region : target_regions)
+    {
+        reader.setRegion(region.getExtendedRegion((int64_t)avr_fragment_length * 3));
+        RegionReads pairs;
+        unsigned total_length = 0, counted = 0;
+        while (pairs.num_reads != max_num_reads && reader.getAlign(read))
+        {
+            if (!read.bases().empty())
+            {
+                total_length += (unsigned)read.bases().length();
+                ++counted;
+            }
+            if (common::isReadOrItsMateInRegion(read, region))
+                pairs.add(read);
+        }
+        const unsigned read_length = counted ? total_length / counted : 0;
+        if (max_num_reads != pairs.num_reads && read_length <= longest_alt_insertion * 2)
+        {
+            // far-away mates of half-filled fragments (recoverMissingMates): rare, so a temporary Read per lookup is fine
+            std::vector<common::Read> lonely;
+            for (auto const& kv : pairs.slots)
+            {
+                const int32_t a = kv.second[0], b = kv.second[1];
+                const bool has_a = a >= 0 && pairs.kept[(size_t)a].base_len > 0, has_b = b >= 0 && pairs.kept[(size_t)b].base_len > 0;
+                if (has_a == has_b)
+                    continue;  // both there -- or neither, which is not a read at all
+                RegionReads::Kept const& k = pairs.kept[(size_t)(has_a ? a : b)];
+                if (k.chrom_id == k.mate_chrom_id && std::abs(k.pos - k.mate_pos) < 1000)
+                    continue;
+                common::Read have;
+                have.setCoreInfo(kv.first, pairs.bases.substr(k.base_begin, k.base_len), "");
+                have.set_is_first_mate((k.flags & PackedSite::FIRST_MATE) != 0);
+                have.set_is_mate_mapped((k.flags & PackedSite::MATE_MAPPED) != 0);
+                have.set_chrom_id(k.chrom_id);
+                have.set_pos(k.pos);
+                have.set_mate_chrom_id(k.mate_chrom_id);
+                have.set_mate_pos(k.mate_pos);
+                lonely.push_back(have);
+            }
+            for (common::Read const& have : lonely)
+            {
+                common::Read mate;
+                reader.getAlignedMate(have, mate);
+                if (mate.is_initialized())
+                    pairs.add(mate);
+            }
+        }
+        for (auto const& kv : pairs.slots)
+        {
+            for (int32_t slot : kv.second)
+            {
+                if (slot < 0 || pairs.kept[(size_t)slot].base_len == 0)
+                    continue;
+                RegionReads::Kept const& k = pairs.kept[(size_t)slot];
+                site.bases.append(pairs.bases, k.base_begin, k.base_len);
+                site.base_end.push_back((uint32_t)site.bases.size());
+                site.fragment.push_back(fragment_of.emplace(kv.first, (uint32_t)fragment_of.size()).first->second);
+                site.flags.push_back(k.flags);
+                site.chrom_id.push_back(k.chrom_id);
+                site.pos.push_back(k.pos);
+                site.mate_chrom_id.push_back(k.mate_chrom_id);
+                site.mate_pos.push_back(k.mate_pos);
+            }
+        }
+    }
+}
+}  // namespace paragraph
+
+namespace common
+{
 // ------------------------------------------------------------------------------------------------------------------
 // Read -> "alignments" entry
 // ------------------------------------------------------------------------------------------------------------------

@@ -420,7 +420,10 @@ bool Json::operator==(Json const& o) const
     if (isNumber() && o.isNumber())
     {
         if (kind_ == REAL || o.kind_ == REAL)
-            return asDouble() == o.asDouble();
+        {
+            const double a = asDouble(), b = o.asDouble();
+            return a == b || (std::isnan(a) && std::isnan(b));  // both are written as null: the same document
+        }
         if (kind_ == INT && i_ < 0)
             return o.kind_ == INT && o.i_ == i_;
         if (o.kind_ == INT && o.i_ < 0)

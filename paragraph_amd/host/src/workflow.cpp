@@ -152,10 +152,130 @@ void addDetailedCounts(Json& by_sequence, common::ReadBuffer const& reads)
 }
 }  // namespace
 
-std::vector<Json> alignAndDisambiguateBatch(Parameters const& parameters, std::vector<SiteInput> const& sites)
+namespace
+{
+// the per-family node / edge breakdown from the views of a packed site (same rule as addDetailedCounts)
+void addDetailedCounts(Json& by_sequence, graphtools::Graph const& graph, SiteReadViews const& views)
+{
+    std::vector<uint32_t> order;
+    std::unordered_map<uint32_t, FragmentSupport> fragments;
+    std::unordered_map<uint32_t, uint64_t> sequences;
+    for (MappedReadView const& read : views.reads)
+    {
+        auto it = fragments.find(read.fragment);
+        if (it == fragments.end())
+        {
+            it = fragments.emplace(read.fragment, FragmentSupport()).first;
+            order.push_back(read.fragment);
+        }
+        FragmentSupport& f = it->second;
+        ++f.reads;
+        ++(read.is_graph_reverse_strand ? f.rev : f.fwd);
+        uint32_t prev = 0;
+        for (uint32_t k = 0; k < read.n_support; ++k)
+        {
+            const uint32_t entry = views.support[read.support_off + k], node = entry & 0xFFFu;
+            if ((entry >> 30) & 1u)
+                f.nodes.insert(graph.nodeName(node));
+            if (k > 0 && (entry >> 31))
+                f.edges.insert(graph.nodeName(prev) + "_" + graph.nodeName(node));
+            prev = node;
+        }
+        sequences[read.fragment] |= read.sequences;
+    }
+    auto bump = [](Json& table, std::string const& key, FragmentSupport const& f) {
+        table[key] = table[key].asUInt64() + 1;
+        table[key + ":READS"] = table[key + ":READS"].asUInt64() + f.reads;
+        table[key + ":FWD"] = table[key + ":FWD"].asUInt64() + f.fwd;
+        table[key + ":REV"] = table[key + ":REV"].asUInt64() + f.rev;
+    };
+    for (uint32_t id : order)
+    {
+        const uint64_t mask = sequences[id];
+        if (!mask)
+            continue;
+        std::string family;  // label_names are sorted, so this is the sorted join
+        for (size_t b = 0; b < views.label_names.size(); ++b)
+            if ((mask >> b) & 1)
+                family += (family.empty() ? "" : ",") + views.label_names[b];
+        FragmentSupport const& f = fragments[id];
+        Json& table = by_sequence[family];
+        for (auto const& n : f.nodes)
+            bump(table, n, f);
+        for (auto const& e : f.edges)
+            bump(table, e, f);
+    }
+}
+
+// one site's count document; `reads` is null for packed sites (then `views` is the batcher's)
+Json countDocument(
+    Parameters const& parameters, GraphDescription const& d, SiteCounts const& counts, SiteReadViews const& views, size_t reads_in,
+    common::ReadBuffer const* reads)
+{
+    Json out = d.description;
+    out["reference"] = d.reference_path;
+    out["fragment_statistics"] = fragmentStatistics(*d.graph, views);
+    if (parameters.output_enabled(Parameters::NODE_READ_COUNTS))
+        out["read_counts_by_node"] = countsToJson(counts.by_node);
+    if (parameters.output_enabled(Parameters::EDGE_READ_COUNTS))
+        out["read_counts_by_edge"] = countsToJson(counts.by_edge);
+    if (parameters.output_enabled(Parameters::PATH_READ_COUNTS))
+    {
+        Json families = Json::object();
+        for (auto const& kv : counts.by_sequence)
+        {
+            Json total = Json::object();
+            total["total"] = kv.second.count;
+            total["total:READS"] = kv.second.reads;
+            total["total:FWD"] = kv.second.fwd;
+            total["total:REV"] = kv.second.rev;
+            families[kv.first] = total;
+        }
+        if (parameters.output_enabled(Parameters::DETAILED_READ_COUNTS))
+        {
+            if (reads)
+                addDetailedCounts(families, *reads);
+            else
+                addDetailedCounts(families, *d.graph, views);
+        }
+        out["read_counts_by_sequence"] = families;
+    }
+    Json stats = alignmentStatistics(*d.graph, views);
+    // the filter tallies only exist when filtered alignments are asked for (Disambiguation.cpp:177-199, 333-346)
+    const bool tally = parameters.output_enabled(Parameters::FILTERED_ALIGNMENTS);
+    stats["bad_alignment_pct"] = (tally && reads_in) ? (double)counts.bad_align / (double)reads_in : 0.0;
+    if (tally && counts.bad_align)
+        stats["read_filter_bad_align"] = counts.bad_align;
+    if (tally && counts.nonuniq)
+        stats["read_filter_nonuniq"] = counts.nonuniq;
+    out["alignment_statistics"] = stats;
+    if (reads && parameters.output_enabled(Parameters::ALIGNMENTS))
+    {
+        Json alignments = Json::array();
+        for (auto const& r : *reads)
+            alignments.append(r->toJson());
+        out["alignments"] = alignments;
+    }
+    return out;
+}
+
+BatchParameters batchParameters(Parameters const& parameters)
 {
     if (!parameters.graph_sequence_matching)
         throw std::runtime_error("alignAndDisambiguateBatch: the gssw stage cannot be switched off in the batched workflow");
+    BatchParameters bp;
+    bp.remove_nonuniq_reads = parameters.remove_nonuniq_reads;
+    bp.bad_align_frac = parameters.bad_align_frac;
+    bp.kmer_len = parameters.kmer_len;
+    bp.path_sequence_matching = parameters.path_sequence_matching;
+    bp.threads = parameters.threads;
+    return bp;
+}
+}  // namespace
+
+std::vector<Json> alignAndDisambiguateBatch(Parameters const& parameters, std::vector<SiteInput> const& sites)
+{
+    const BatchParameters bp = batchParameters(parameters);
     SiteBatcher batcher;
     std::vector<size_t> reads_in(sites.size());
     for (size_t s = 0; s < sites.size(); ++s)
@@ -165,66 +285,18 @@ std::vector<Json> alignAndDisambiguateBatch(Parameters const& parameters, std::v
         reads_in[s] = sites[s].reads->size();
         batcher.addSite(sites[s].description->graph.get(), sites[s].reads);
     }
-    BatchParameters bp;
-    bp.remove_nonuniq_reads = parameters.remove_nonuniq_reads;
-    bp.bad_align_frac = parameters.bad_align_frac;
-    bp.kmer_len = parameters.kmer_len;
-    bp.path_sequence_matching = parameters.path_sequence_matching;
-    bp.threads = parameters.threads;
     const double t_batch = now();
     if (!sites.empty())
         batcher.run(bp);
     const double t_documents = now();
-
     std::vector<Json> documents(sites.size());
     parallelFor(sites.size(), parameters.threads, [&](size_t s) {
         GraphDescription const& d = *sites[s].description;
-        common::ReadBuffer const& reads = *sites[s].reads;
-        SiteCounts const& counts = batcher.counts(s);
-        Json out = d.description;
-        out["reference"] = d.reference_path;
         std::vector<common::Read const*> view;
-        view.reserve(reads.size());
-        for (auto const& r : reads)
+        view.reserve(sites[s].reads->size());
+        for (auto const& r : *sites[s].reads)
             view.push_back(r.get());
-        out["fragment_statistics"] = fragmentStatistics(*d.graph, view);
-        if (parameters.output_enabled(Parameters::NODE_READ_COUNTS))
-            out["read_counts_by_node"] = countsToJson(counts.by_node);
-        if (parameters.output_enabled(Parameters::EDGE_READ_COUNTS))
-            out["read_counts_by_edge"] = countsToJson(counts.by_edge);
-        if (parameters.output_enabled(Parameters::PATH_READ_COUNTS))
-        {
-            Json families = Json::object();
-            for (auto const& kv : counts.by_sequence)
-            {
-                Json total = Json::object();
-                total["total"] = kv.second.count;
-                total["total:READS"] = kv.second.reads;
-                total["total:FWD"] = kv.second.fwd;
-                total["total:REV"] = kv.second.rev;
-                families[kv.first] = total;
-            }
-            if (parameters.output_enabled(Parameters::DETAILED_READ_COUNTS))
-                addDetailedCounts(families, reads);
-            out["read_counts_by_sequence"] = families;
-        }
-        Json stats = alignmentStatistics(*d.graph, view);
-        // the filter tallies only exist when filtered alignments are asked for (Disambiguation.cpp:177-199, 333-346)
-        const bool tally = parameters.output_enabled(Parameters::FILTERED_ALIGNMENTS);
-        stats["bad_alignment_pct"] = (tally && reads_in[s]) ? (double)counts.bad_align / (double)reads_in[s] : 0.0;
-        if (tally && counts.bad_align)
-            stats["read_filter_bad_align"] = counts.bad_align;
-        if (tally && counts.nonuniq)
-            stats["read_filter_nonuniq"] = counts.nonuniq;
-        out["alignment_statistics"] = stats;
-        if (parameters.output_enabled(Parameters::ALIGNMENTS))
-        {
-            Json alignments = Json::array();
-            for (auto const& r : reads)
-                alignments.append(r->toJson());
-            out["alignments"] = alignments;
-        }
-        documents[s] = std::move(out);
+        documents[s] = countDocument(parameters, d, batcher.counts(s), viewsOfReads(*d.graph, view), reads_in[s], sites[s].reads);
     });
     if (parameters.timings)
     {
@@ -233,6 +305,37 @@ std::vector<Json> alignAndDisambiguateBatch(Parameters const& parameters, std::v
         parameters.timings->sites += sites.size();
         for (size_t n : reads_in)
             parameters.timings->reads += n;
+    }
+    return documents;
+}
+
+std::vector<Json> alignAndDisambiguateBatch(Parameters const& parameters, std::vector<PackedSiteInput> const& sites)
+{
+    if (parameters.output_enabled(Parameters::ALIGNMENTS))
+        throw std::runtime_error("alignAndDisambiguateBatch: packed sites keep no per-read records; use the object form for \"alignments\"");
+    const BatchParameters bp = batchParameters(parameters);
+    SiteBatcher batcher;
+    for (size_t s = 0; s < sites.size(); ++s)
+    {
+        if (!sites[s].description || !sites[s].reads)
+            throw std::runtime_error("alignAndDisambiguateBatch: site without description or reads");
+        batcher.addSite(sites[s].description->graph.get(), sites[s].reads);
+    }
+    const double t_batch = now();
+    if (!sites.empty())
+        batcher.run(bp);
+    const double t_documents = now();
+    std::vector<Json> documents(sites.size());
+    parallelFor(sites.size(), parameters.threads, [&](size_t s) {
+        documents[s] = countDocument(parameters, *sites[s].description, batcher.counts(s), batcher.views(s), sites[s].reads->size(), nullptr);
+    });
+    if (parameters.timings)
+    {
+        parameters.timings->device_batch += t_documents - t_batch;
+        parameters.timings->documents += now() - t_documents;
+        parameters.timings->sites += sites.size();
+        for (auto const& site : sites)
+            parameters.timings->reads += site.reads->size();
     }
     return documents;
 }
@@ -487,7 +590,8 @@ struct Chunk
 {
     size_t g0 = 0, g1 = 0;
     std::vector<paragraph::GraphDescription> graphs;
-    std::vector<common::ReadBuffer> reads;  // [(g - g0) * n_samples + s]
+    std::vector<common::ReadBuffer> reads;       // [(g - g0) * n_samples + s], object form
+    std::vector<paragraph::PackedSite> packed;   // same indexing, packed form (one of the two is filled)
     double load_s = 0, extract_s = 0;
 };
 
@@ -506,7 +610,11 @@ std::unique_ptr<Chunk> prepareChunk(
     chunk->load_s = t_extract - t_load;
 
     // tasks in sample-major order so a worker mostly stays on one BAM; every worker owns its readers
-    chunk->reads.resize(n_graphs * n_samples);
+    const bool packed = parameters.packed_reads && !parameters.output_alignments;
+    if (packed)
+        chunk->packed.resize(n_graphs * n_samples);
+    else
+        chunk->reads.resize(n_graphs * n_samples);
     const size_t n_tasks = n_graphs * n_samples;
     const size_t workers = std::max<size_t>(1, std::min<size_t>((size_t)std::max(threads, 1), n_tasks));
     std::atomic<size_t> next(0);
@@ -527,7 +635,10 @@ std::unique_ptr<Chunk> prepareChunk(
                     reader.reset(new common::BamReader(samples[s].filename(), samples[s].index_filename(), reference_path));
                 paragraph::GraphDescription const& d = chunk->graphs[g];
                 const int max_reads = d.max_reads >= 0 ? (int)d.max_reads : parameters.max_reads;
-                common::extractReads(*reader, d.target_regions, max_reads, (unsigned)d.longest_alt_insertion, chunk->reads[g * n_samples + s]);
+                if (packed)
+                    paragraph::extractPacked(*reader, d.target_regions, max_reads, (unsigned)d.longest_alt_insertion, chunk->packed[g * n_samples + s]);
+                else
+                    common::extractReads(*reader, d.target_regions, max_reads, (unsigned)d.longest_alt_insertion, chunk->reads[g * n_samples + s]);
             }
         }
         catch (...)
@@ -591,13 +702,27 @@ std::vector<Json> genotypeGraphs(
                     break;
                 const size_t g0 = c * per_batch, g1 = std::min(n_graphs, g0 + per_batch), n_here = g1 - g0;
                 std::unique_ptr<Chunk> chunk = prepareChunk(parameters, graph_paths, reference_path, samples, g0, g1, lane_threads, &fasta);
-                std::vector<paragraph::SiteInput> sites(n_here * n_samples);
-                for (size_t i = 0; i < sites.size(); ++i)
+                std::vector<Json> documents;
+                if (!chunk->packed.empty())
                 {
-                    sites[i].description = &chunk->graphs[i / n_samples];
-                    sites[i].reads = &chunk->reads[i];
+                    std::vector<paragraph::PackedSiteInput> sites(n_here * n_samples);
+                    for (size_t i = 0; i < sites.size(); ++i)
+                    {
+                        sites[i].description = &chunk->graphs[i / n_samples];
+                        sites[i].reads = &chunk->packed[i];
+                    }
+                    documents = paragraph::alignAndDisambiguateBatch(site_parameters, sites);
                 }
-                std::vector<Json> documents = paragraph::alignAndDisambiguateBatch(site_parameters, sites);
+                else
+                {
+                    std::vector<paragraph::SiteInput> sites(n_here * n_samples);
+                    for (size_t i = 0; i < sites.size(); ++i)
+                    {
+                        sites[i].description = &chunk->graphs[i / n_samples];
+                        sites[i].reads = &chunk->reads[i];
+                    }
+                    documents = paragraph::alignAndDisambiguateBatch(site_parameters, sites);
+                }
                 for (size_t i = 0; i < documents.size(); ++i)
                     finishSampleDocument(documents[i], samples[i % n_samples].filename(), parameters.output_alignments);
 

@@ -77,6 +77,7 @@ static void testJson()
     arr.append("two");
     CHECK(arr.isArray() && arr.size() == 2 && arr.dump() == "[1,\"two\"]");
     CHECK(Json(1) == Json(1.0) && Json(1) != Json(2) && Json((uint64_t)5) == Json(5));
+    CHECK(Json(std::nan("")) == Json(std::nan("")) && Json(std::nan("")) != Json(0.0));
     CHECK_THROWS(Json::parse("{\"a\": }"));
     CHECK_THROWS(Json::parse("[1, 2"));
     CHECK_THROWS(Json::parse("{} x"));

@@ -101,6 +101,40 @@ static void testMultiparagraph(std::string const& dir)
         CHECK(documents[i]["reference"].asString() == base + "dummy.fa" && documents[i].isMember("alignment_statistics"));
         CHECK(!documents[i].isMember("alignments"));
     }
+    // the packed form (no common::Read objects) yields the same documents, with and without the path stage, incl. the
+    // per-family node / edge breakdown
+    for (int pass = 0; pass < 2; ++pass)
+    {
+        paragraph::Parameters pp = parameters;
+        pp.path_sequence_matching = pass == 0;
+        pp.output_options_ |= paragraph::Parameters::DETAILED_READ_COUNTS | paragraph::Parameters::FILTERED_ALIGNMENTS;
+        std::vector<paragraph::PackedSite> packed(expected.size());
+        std::vector<common::ReadBuffer> objects(expected.size());
+        std::vector<paragraph::PackedSiteInput> packed_sites(expected.size());
+        std::vector<paragraph::SiteInput> object_sites(expected.size());
+        for (size_t i = 0; i < expected.size(); ++i)
+        {
+            common::BamReader reader(base + "reads.bam", "", "");
+            paragraph::extractPacked(reader, graphs[i].target_regions, 10000, (unsigned)graphs[i].longest_alt_insertion, packed[i]);
+            common::extractReads(reader, graphs[i].target_regions, 10000, (unsigned)graphs[i].longest_alt_insertion, objects[i]);
+            CHECK(packed[i].size() == objects[i].size());
+            for (size_t k = 0; k < packed[i].size() && k < objects[i].size(); ++k)
+                CHECK(packed[i].readLength(k) == objects[i][k]->bases().size() && packed[i].pos[k] == objects[i][k]->pos());
+            packed_sites[i].description = &graphs[i];
+            packed_sites[i].reads = &packed[i];
+            object_sites[i].description = &graphs[i];
+            object_sites[i].reads = &objects[i];
+        }
+        const std::vector<Json> from_packed = paragraph::alignAndDisambiguateBatch(pp, packed_sites);
+        const std::vector<Json> from_objects = paragraph::alignAndDisambiguateBatch(pp, object_sites);
+        for (size_t i = 0; i < expected.size(); ++i)
+        {
+            CHECK(from_packed[i] == from_objects[i]);
+            if (from_packed[i] != from_objects[i])
+                compareObject("packed-vs-objects[" + std::to_string(i) + "]", from_objects[i], from_packed[i]);
+            compareObject("packed/edges", expected[i]["graph"]["read_counts_by_edge"], from_packed[i]["read_counts_by_edge"]);
+        }
+    }
     // gssw only (grmpy's default cascade) reaches the same tables on these reads
     for (auto& r : reads)
         r.clear();
@@ -155,7 +189,12 @@ static void testGenotypesSingleSwap(std::string const& dir)
     // the batched shape: both samples (x the same graph listed twice) in one device batch, same documents
     parameters.threads = 4;
     const std::vector<Json> batched = grmpy::genotypeGraphs(parameters, { graph, graph }, fasta, samples, gparams);
-    CHECK(batched.size() == 2 && batched[0] == one_by_one && batched[1] == one_by_one);
+    CHECK(batched.size() == 2 && batched[0] == one_by_one && batched[1] == one_by_one);  // packed reads (the default) == object form
+    parameters.packed_reads = false;
+    parameters.lanes = 2;
+    parameters.sites_per_batch = 2;
+    const std::vector<Json> from_objects = grmpy::genotypeGraphs(parameters, { graph, graph, graph }, fasta, samples, gparams);
+    CHECK(from_objects.size() == 3 && from_objects[0] == one_by_one && from_objects[2] == one_by_one);
     std::cout << one_by_one["samples"]["SAMPLE2"]["gt"].dump() << "\n";
 }
 

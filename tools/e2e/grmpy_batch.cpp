@@ -1,6 +1,6 @@
 // End-to-end probe: every graph of a list x every sample of a manifest through grmpy::genotypeGraphs (one device batch),
 // with the wall-clock split by phase.  Not a product CLI -- a measuring stick for the host side of the workflow.
-//   grmpy_batch <reference.fa> <manifest.txt> <graphs.txt> <threads> [genotypes.json] [sites_per_batch] [lanes]
+//   grmpy_batch <reference.fa> <manifest.txt> <graphs.txt> <threads> [genotypes.json] [sites_per_batch] [lanes] [packed 0|1]
 #include <chrono>
 #include <fstream>
 #include <iostream>
@@ -28,6 +28,8 @@ int main(int argc, char** argv)
             parameters.sites_per_batch = (size_t)std::atoll(argv[6]);
         if (argc > 7)
             parameters.lanes = std::atoi(argv[7]);
+        if (argc > 8)
+            parameters.packed_reads = std::atoi(argv[8]) != 0;
         common::Json runs = common::Json::array();
         std::vector<common::Json> genotypes;
         for (int rep = 0; rep < 2; ++rep)  // the first pass pays device start-up and cold file cache
@@ -55,6 +57,7 @@ int main(int argc, char** argv)
         }
         common::Json out = common::Json::object();
         out["threads"] = parameters.threads;
+        out["packed_reads"] = parameters.packed_reads;
         out["graphs"] = (uint64_t)graphs.size();
         out["samples"] = (uint64_t)samples.size();
         out["runs"] = runs;
@@ -71,6 +74,11 @@ int main(int argc, char** argv)
                 all.append(brief);
             }
             std::ofstream(argv[5]) << all.dump() << "\n";
+            // and every document in full, for comparing runs (packed against object form) byte for byte
+            common::Json full = common::Json::array();
+            for (auto const& g : genotypes)
+                full.append(g);
+            std::ofstream(std::string(argv[5]) + ".full") << full.dump() << "\n";
         }
     }
     catch (std::exception const& e)

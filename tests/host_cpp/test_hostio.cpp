@@ -10,6 +10,7 @@
 #include <fstream>
 #include <functional>
 #include <iostream>
+#include <map>
 #include <random>
 #include <sstream>
 
@@ -22,6 +23,7 @@
 #include "genotyping/SampleInfo.hh"
 #include "graphcore/GraphCoordinates.hh"
 #include "grm/GraphInput.hh"
+#include "paragraph/PackedReads.hh"
 #include "paragraph/Statistics.hh"
 
 using namespace common;
@@ -582,6 +584,77 @@ static void testManifestAndParameters(std::string const& dir)
     CHECK_THROWS(p.setFromJson(Json::parse(R"({"allele_error_rates": [0.1]})")));
 }
 
+// extractPacked must keep exactly the reads extractReads keeps, in the same order, with the same fragment grouping
+static void comparePackedWithObjects(paragraph::PackedSite const& packed, std::vector<p_Read> const& objects, const char* what)
+{
+    CHECK(packed.size() == objects.size());
+    if (packed.size() != objects.size())
+    {
+        std::cerr << what << ": " << packed.size() << " packed vs " << objects.size() << " objects\n";
+        return;
+    }
+    std::map<std::string, uint32_t> fragment_of;
+    for (size_t k = 0; k < objects.size(); ++k)
+    {
+        Read const& r = *objects[k];
+        const uint32_t begin = k ? packed.base_end[k - 1] : 0;
+        CHECK(packed.bases.substr(begin, packed.base_end[k] - begin) == r.bases());
+        CHECK(packed.fragment[k] == fragment_of.emplace(r.fragment_id(), (uint32_t)fragment_of.size()).first->second);
+        const uint8_t f = packed.flags[k];
+        CHECK(((f & paragraph::PackedSite::REVERSE) != 0) == r.is_reverse_strand() && ((f & paragraph::PackedSite::FIRST_MATE) != 0) == r.is_first_mate());
+        CHECK(((f & paragraph::PackedSite::MAPPED) != 0) == r.is_mapped() && ((f & paragraph::PackedSite::MATE_MAPPED) != 0) == r.is_mate_mapped());
+        CHECK(((f & paragraph::PackedSite::MATE_REVERSE) != 0) == r.is_mate_reverse_strand());
+        CHECK(packed.chrom_id[k] == r.chrom_id() && packed.pos[k] == r.pos() && packed.mate_chrom_id[k] == r.mate_chrom_id()
+              && packed.mate_pos[k] == r.mate_pos());
+    }
+}
+
+static void testPackedExtraction(std::string const& dir)
+{
+    // real data: both target regions of the chrX swap graph (reads near both are extracted twice), with and without a cap
+    for (int max_reads : { 10000, 57, 1 })
+        for (unsigned longest_insertion : { 0u, 10u, 200u })
+        {
+            BamReader reader(dir + "/chrX/chrX_graph_typing.bam", "", "");
+            const std::list<Region> regions = { Region("chrX:850-1149"), Region("chrX:8667-8965"), Region("chrX:900-1000") };
+            std::vector<p_Read> objects;
+            extractReads(reader, regions, max_reads, longest_insertion, objects);
+            paragraph::PackedSite packed;
+            paragraph::extractPacked(reader, regions, max_reads, longest_insertion, packed);
+            CHECK(!objects.empty());
+            comparePackedWithObjects(packed, objects, "chrX");
+        }
+    // scripted: replaced mate slots, an empty-sequence record, far mates to recover
+    auto script = [](ScriptedReader& reader) {
+        Read a1 = makeRead("A", "ACGTACGTAC", true, 0, 1000, 0, 1200), a1_again = makeRead("A", "TTTTTTTTTT", true, 0, 1001, 0, 1200);
+        Read a2 = makeRead("A", "GGGGGGGGGG", false, 0, 1200, 0, 1000), empty = makeRead("E", "", true, 0, 1010, 0, 1300);
+        Read far = makeRead("F", "CCCCCCCCCC", true, 0, 1020, 0, 9000), far2 = makeRead("G", "CCCCCCCCAA", false, 0, 1030, 3, 50);
+        far.set_is_mate_mapped(true);
+        far2.set_is_mate_mapped(true);
+        reader.aligns = { a1, a2, empty, far, a1_again, far2 };
+        reader.mates["F"] = makeRead("F", "AAAAAAAAAA", false, 0, 9000, 0, 1020);
+        reader.mates["G"] = makeRead("G", "AAAAAAAATT", true, 3, 50, 0, 1030);
+    };
+    for (int max_reads : { 100, 3 })
+    {
+        ScriptedReader r1, r2;
+        script(r1);
+        script(r2);
+        std::vector<p_Read> objects;
+        extractReads(r1, { Region("chr", 990, 1100) }, max_reads, 50, objects);
+        paragraph::PackedSite packed;
+        paragraph::extractPacked(r2, { Region("chr", 990, 1100) }, max_reads, 50, packed);
+        comparePackedWithObjects(packed, objects, "scripted");
+        CHECK(r1.mate_calls == r2.mate_calls && r1.regions == r2.regions);
+        if (max_reads == 100)
+            CHECK(objects.size() == 6 && r1.mate_calls.size() == 2);  // A x2 (later first mate wins), F x2, G x2; E is not a read
+    }
+    paragraph::PackedSite not_empty;
+    not_empty.fragment.push_back(0);
+    ScriptedReader r;
+    CHECK_THROWS(paragraph::extractPacked(r, { Region("chr", 1, 2) }, 10, 0, not_empty));
+}
+
 int main(int argc, char** argv)
 {
     if (argc == 4 && std::string(argv[1]) == "--dump-bam")
@@ -609,6 +682,7 @@ int main(int argc, char** argv)
         { "bam-vs-sam", [&] { testBamAgainstSam(dir); } },
         { "bam-index", [&] { testBamIndexConsistency(dir); } },
         { "extraction", testExtraction },
+        { "packed-extraction", [&] { testPackedExtraction(dir); } },
         { "graph-input", [&] { testGraphInput(dir); } },
         { "graph-coordinates", testGraphCoordinates },
         { "statistics", testStatistics },

@@ -238,6 +238,8 @@ public:
     }
     ~Bgzf()
     {
+        if (zs_ready_)
+            inflateEnd(&zs_);
         if (fp_)
             fclose(fp_);
     }
@@ -293,13 +295,46 @@ public:
     }
 
 private:
+    // Inflated blocks are kept in a small ring: neighbouring region queries (sites a few kbp apart, a mate lookup in
+    // the middle of a scan) come back to the same 64 KiB blocks again and again.
     void loadBlock(uint64_t coff)
     {
+        within_ = 0;
+        const bool have_current = have_block_ && !eof_ && !data_.empty();
         have_block_ = true;
+        for (Cached& c : ring_)
+        {
+            if (!(c.valid && c.start == coff))
+                continue;
+            // trade places: the block asked for becomes current, the current one takes its slot
+            std::swap(block_start_, c.start);
+            std::swap(block_csize_, c.csize);
+            data_.swap(c.data);
+            c.valid = have_current;
+            eof_ = false;
+            return;
+        }
+        if (have_current)
+            stash();
+        inflateBlock(coff);
+    }
+
+    // park the current block in the ring before its buffer is reused
+    void stash()
+    {
+        Cached& slot = ring_[ring_next_];
+        ring_next_ = (ring_next_ + 1) % kRing;
+        slot.valid = true;
+        slot.start = block_start_;
+        slot.csize = block_csize_;
+        slot.data.swap(data_);
+    }
+
+    void inflateBlock(uint64_t coff)
+    {
         block_start_ = coff;
         block_csize_ = 0;
         data_.clear();
-        within_ = 0;
         if (fseeko(fp_, (off_t)coff, SEEK_SET) != 0)
             throw std::runtime_error("BGZF: seek failed in " + path_);
         unsigned char hdr[12];
@@ -312,40 +347,46 @@ private:
         if (got != sizeof hdr || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4))
             throw std::runtime_error("BGZF: bad block header in " + path_);
         const unsigned xlen = hdr[10] | (hdr[11] << 8);
-        std::vector<unsigned char> extra(xlen);
-        if (fread(extra.data(), 1, xlen, fp_) != xlen)
+        extra_.resize(xlen);
+        if (fread(extra_.data(), 1, xlen, fp_) != xlen)
             throw std::runtime_error("BGZF: truncated block header in " + path_);
         int bsize = -1;
         for (size_t i = 0; i + 4 <= xlen;)
         {
-            const unsigned slen = extra[i + 2] | (extra[i + 3] << 8);
-            if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2 && i + 6 <= xlen)
-                bsize = extra[i + 4] | (extra[i + 5] << 8);
+            const unsigned slen = extra_[i + 2] | (extra_[i + 3] << 8);
+            if (extra_[i] == 'B' && extra_[i + 1] == 'C' && slen == 2 && i + 6 <= xlen)
+                bsize = extra_[i + 4] | (extra_[i + 5] << 8);
             i += 4 + slen;
         }
         if (bsize < 0)
             throw std::runtime_error("BGZF: block without BC field in " + path_);
         block_csize_ = (uint64_t)bsize + 1;
+        if (block_csize_ < 12 + (uint64_t)xlen + 8)
+            throw std::runtime_error("BGZF: bad block size in " + path_);
         const size_t cdata_len = block_csize_ - 12 - xlen - 8;
-        std::vector<unsigned char> cdata(cdata_len + 8);
-        if (fread(cdata.data(), 1, cdata.size(), fp_) != cdata.size())
+        cdata_.resize(cdata_len + 8);
+        if (fread(cdata_.data(), 1, cdata_.size(), fp_) != cdata_.size())
             throw std::runtime_error("BGZF: truncated block in " + path_);
-        const unsigned char* tail = cdata.data() + cdata_len;
+        const unsigned char* tail = cdata_.data() + cdata_len;
         const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
         data_.resize(isize);
         if (isize)
         {
-            z_stream zs;
-            memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK)
-                throw std::runtime_error("BGZF: inflateInit2 failed");
-            zs.next_in = cdata.data();
-            zs.avail_in = (uInt)cdata_len;
-            zs.next_out = data_.data();
-            zs.avail_out = (uInt)isize;
-            const int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END || zs.avail_out != 0)
+            if (!zs_ready_)
+            {
+                memset(&zs_, 0, sizeof zs_);
+                if (inflateInit2(&zs_, -15) != Z_OK)
+                    throw std::runtime_error("BGZF: inflateInit2 failed");
+                zs_ready_ = true;
+            }
+            else
+                inflateReset(&zs_);
+            zs_.next_in = cdata_.data();
+            zs_.avail_in = (uInt)cdata_len;
+            zs_.next_out = data_.data();
+            zs_.avail_out = (uInt)isize;
+            const int rc = inflate(&zs_, Z_FINISH);
+            if (rc != Z_STREAM_END || zs_.avail_out != 0)
                 throw std::runtime_error("BGZF: inflate failed in " + path_);
             const uint32_t want_crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
             if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), data_.data(), (uInt)isize) != want_crc)
@@ -354,6 +395,18 @@ private:
         eof_ = false;
     }
 
+    enum { kRing = 8 };
+    struct Cached
+    {
+        bool valid = false;
+        uint64_t start = 0, csize = 0;
+        std::vector<unsigned char> data;
+    };
+    Cached ring_[kRing];
+    size_t ring_next_ = 0;
+    std::vector<unsigned char> extra_, cdata_;
+    z_stream zs_;
+    bool zs_ready_ = false;
     std::string path_;
     FILE* fp_ = nullptr;
     bool have_block_ = false, eof_ = false;
@@ -395,6 +448,8 @@ struct BamRecord
     uint16_t flag = 0;
     uint8_t mapq = 0;
     int64_t end_pos = 0;  // pos + reference span of the CIGAR, at least pos + 1 (bam_endpos)
+    // where the text fields sit in the reader's record buffer; decoded only for records that are handed out
+    uint32_t name_at = 0, name_len = 0, seq_at = 0, seq_len = 0;
     std::string name, bases, quals;
 };
 
@@ -433,7 +488,8 @@ struct BamReader::Impl
     void open();
     void parseHeader(BamMeta& m);
     void loadIndex(BamMeta& m);
-    bool readRecord(BamRecord& rec);
+    bool readRecord(BamRecord& rec);        // fixed fields + end_pos; valid until the next call
+    void decodeText(BamRecord& rec) const;  // name / bases / quals of the record read last
     RegionCursor query(int32_t tid, int64_t beg, int64_t end) const;
     bool next(RegionCursor& cur, BamRecord& rec);
 };
@@ -595,7 +651,8 @@ bool BamReader::Impl::readRecord(BamRecord& rec)
     size_t at = 32;
     if (at + l_name + (size_t)n_cigar * 4 + (l_seq + 1) / 2 + l_seq > block_size)
         throw std::runtime_error("Corrupt BAM record in " + path);
-    rec.name.assign((const char*)p + at, l_name ? l_name - 1 : 0);
+    rec.name_at = (uint32_t)at;
+    rec.name_len = l_name ? l_name - 1 : 0;
     at += l_name;
     int64_t ref_span = 0;
     for (uint32_t c = 0; c < n_cigar; ++c)
@@ -609,18 +666,44 @@ bool BamReader::Impl::readRecord(BamRecord& rec)
         ref_span = 0;
     rec.end_pos = (int64_t)rec.pos + (ref_span > 0 ? ref_span : 1);
     at += (size_t)n_cigar * 4;
-    static const char kBases[] = "=ACMGRSVTWYHKDBN";
-    rec.bases.resize(l_seq);
-    for (uint32_t i = 0; i < l_seq; ++i)
+    rec.seq_at = (uint32_t)at;
+    rec.seq_len = l_seq;
+    return true;
+}
+
+void BamReader::Impl::decodeText(BamRecord& rec) const
+{
+    // two bases per packed byte, looked up as a pair
+    static const struct Pairs
     {
-        const unsigned char packed = p[at + i / 2];
-        rec.bases[i] = kBases[(i & 1) ? (packed & 0xF) : (packed >> 4)];
+        char text[256][2];
+        Pairs()
+        {
+            static const char kBases[] = "=ACMGRSVTWYHKDBN";
+            for (int b = 0; b < 256; ++b)
+            {
+                text[b][0] = kBases[b >> 4];
+                text[b][1] = kBases[b & 0xF];
+            }
+        }
+    } pairs;
+    const unsigned char* p = scratch.data();
+    rec.name.assign((const char*)p + rec.name_at, rec.name_len);
+    const uint32_t l_seq = rec.seq_len;
+    rec.bases.resize(l_seq);
+    const unsigned char* packed = p + rec.seq_at;
+    char* out = l_seq ? &rec.bases[0] : nullptr;
+    for (uint32_t i = 0; i + 1 < l_seq; i += 2)
+    {
+        out[i] = pairs.text[packed[i / 2]][0];
+        out[i + 1] = pairs.text[packed[i / 2]][1];
     }
-    at += (l_seq + 1) / 2;
+    if (l_seq & 1)
+        out[l_seq - 1] = pairs.text[packed[l_seq / 2]][0];
+    const unsigned char* q = packed + (l_seq + 1) / 2;
     rec.quals.resize(l_seq);
     for (uint32_t i = 0; i < l_seq; ++i)
-        rec.quals[i] = (char)(33 + p[at + i]);  // 0xFF ("no qualities") wraps like the uint8 -> char cast it mirrors
-    return true;
+        rec.quals[i] = (char)(33 + q[i]);  // 0xFF ("no qualities") wraps like the uint8 -> char cast it mirrors
 }
 
 RegionCursor BamReader::Impl::query(int32_t tid, int64_t beg, int64_t end) const
@@ -778,6 +861,7 @@ bool BamReader::getAlign(Read& read)
     {
         if (rec.flag & (kSupplementaryAlign | kSecondaryAlign))
             continue;
+        impl_->decodeText(rec);
         toRead(rec, read);
         return true;
     }
@@ -795,6 +879,7 @@ bool BamReader::getAlignedMate(const Read& read, Read& mate)
     // like the original, `mate` is overwritten by every candidate looked at, also when none matches
     while (impl_->next(cur, rec))
     {
+        impl_->decodeText(rec);
         toRead(rec, mate);
         if (mate.fragment_id() == read.fragment_id() && mate.is_first_mate() != read.is_first_mate())
             return true;

@@ -624,21 +624,27 @@ std::unique_ptr<Chunk> prepareChunk(
         std::map<size_t, std::unique_ptr<common::BamReader>> readers;
         try
         {
+            // a worker takes runs of neighbouring graphs: sites that are close on the genome share BGZF blocks, which the
+            // reader keeps inflated
+            const size_t kRun = 8;
             for (;;)
             {
-                const size_t task = next.fetch_add(1);
-                if (task >= n_tasks || failed.load())
+                const size_t first = next.fetch_add(kRun);
+                if (first >= n_tasks || failed.load())
                     return;
-                const size_t s = task / n_graphs, g = task % n_graphs;
-                auto& reader = readers[s];
-                if (!reader)
-                    reader.reset(new common::BamReader(samples[s].filename(), samples[s].index_filename(), reference_path));
-                paragraph::GraphDescription const& d = chunk->graphs[g];
-                const int max_reads = d.max_reads >= 0 ? (int)d.max_reads : parameters.max_reads;
-                if (packed)
-                    paragraph::extractPacked(*reader, d.target_regions, max_reads, (unsigned)d.longest_alt_insertion, chunk->packed[g * n_samples + s]);
-                else
-                    common::extractReads(*reader, d.target_regions, max_reads, (unsigned)d.longest_alt_insertion, chunk->reads[g * n_samples + s]);
+                for (size_t task = first; task < std::min(n_tasks, first + kRun); ++task)
+                {
+                    const size_t s = task / n_graphs, g = task % n_graphs;
+                    auto& reader = readers[s];
+                    if (!reader)
+                        reader.reset(new common::BamReader(samples[s].filename(), samples[s].index_filename(), reference_path));
+                    paragraph::GraphDescription const& d = chunk->graphs[g];
+                    const int max_reads = d.max_reads >= 0 ? (int)d.max_reads : parameters.max_reads;
+                    if (packed)
+                        paragraph::extractPacked(*reader, d.target_regions, max_reads, (unsigned)d.longest_alt_insertion, chunk->packed[g * n_samples + s]);
+                    else
+                        common::extractReads(*reader, d.target_regions, max_reads, (unsigned)d.longest_alt_insertion, chunk->reads[g * n_samples + s]);
+                }
             }
         }
         catch (...)

@@ -426,8 +426,9 @@ extern "C" pg_status pg_graphs_upload(
         hipError_t e = hipMalloc((void**)dptr, vec.size() * sizeof(T));
         if (e != hipSuccess)
             return e;
-        return hipMemcpyAsync(*dptr, vec.data(), vec.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+        return hipMemcpyAsync(*dptr, vec.data(), vec.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream_copy);
     };
+    // on the copy stream: a graph set can be prepared while another thread's batch occupies the compute stream
     hipError_t e = up_vec(gdev, &G->d_graphs);
     if (e == hipSuccess)
         e = up_vec(nodes, &G->d_nodes);
@@ -438,7 +439,7 @@ extern "C" pg_status pg_graphs_upload(
     if (e == hipSuccess)
         e = up_vec(seqchars, &G->d_seqchars);
     if (e == hipSuccess)
-        e = hipStreamSynchronize(ctx->stream);
+        e = hipStreamSynchronize(ctx->stream_copy);
     if (e != hipSuccess)
     {
         pg_graphs_destroy(ctx, G);

@@ -548,14 +548,14 @@ extern "C" pg_status pg_graphs_set_labels(
     (void)hipFree(G->d_label_mask);
     (void)hipFree(G->d_out_mask);
     (void)hipFree(G->d_in_mask);
-    HIP_TRY(ctx, dev_upload(cg, &G->d_cnt_graphs, ctx->stream));
-    HIP_TRY(ctx, dev_upload(G->h_pred_off, &G->d_cnt_pred_off, ctx->stream));
-    HIP_TRY(ctx, dev_upload(G->h_pred, &G->d_cnt_pred, ctx->stream));
-    HIP_TRY(ctx, dev_upload(G->h_node_len, &G->d_cnt_node_len, ctx->stream));
-    HIP_TRY(ctx, dev_upload(lm, &G->d_label_mask, ctx->stream));
-    HIP_TRY(ctx, dev_upload(outm, &G->d_out_mask, ctx->stream));
-    HIP_TRY(ctx, dev_upload(inm, &G->d_in_mask, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, dev_upload(cg, &G->d_cnt_graphs, ctx->stream_copy));
+    HIP_TRY(ctx, dev_upload(G->h_pred_off, &G->d_cnt_pred_off, ctx->stream_copy));
+    HIP_TRY(ctx, dev_upload(G->h_pred, &G->d_cnt_pred, ctx->stream_copy));
+    HIP_TRY(ctx, dev_upload(G->h_node_len, &G->d_cnt_node_len, ctx->stream_copy));
+    HIP_TRY(ctx, dev_upload(lm, &G->d_label_mask, ctx->stream_copy));
+    HIP_TRY(ctx, dev_upload(outm, &G->d_out_mask, ctx->stream_copy));
+    HIP_TRY(ctx, dev_upload(inm, &G->d_in_mask, ctx->stream_copy));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
     G->labels_set = true;
     return PG_OK;
 }

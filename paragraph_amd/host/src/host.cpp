@@ -648,6 +648,7 @@ struct SiteBatcher::Impl
     std::vector<const PackedSite*> packed;
     std::vector<SiteCounts> counts;
     std::vector<SiteReadViews> views;
+    struct Run;
 };
 
 SiteBatcher::SiteBatcher() : impl_(new Impl()) {}
@@ -673,13 +674,44 @@ size_t SiteBatcher::addSite(const Graph* graph, PackedSite const* reads)
     return impl_->graphs.size() - 1;
 }
 
+// The state of one run(): the flat inputs handed to the device and the flat records that come back.  Its steps are the
+// phases PG_BATCH_TIMING=1 reports.
+struct SiteBatcher::Impl::Run
+{
+    Run(Impl& impl_, BatchParameters const& prm_) : impl(impl_), prm(prm_), n_sites(impl_.graphs.size()) {}
+    void graphCsr();
+    void packReads();
+    void deviceSection();
+    void resultsToReads();
+    void viewsOfPackedSites();
+    void siteTables();
+
+    Impl& impl;
+    BatchParameters const& prm;
+    const size_t n_sites;
+    bool packed_mode = false;
+    GraphCsr csr;
+    // inputs of pg_batch_upload / pg_batch_set_fragments, all sites back to back
+    std::vector<uint64_t> site_read0, site_base0;
+    std::vector<uint32_t> base_off, gor, frag;
+    std::vector<uint8_t> is_rev;
+    std::vector<Read*> flat;  // object sites only
+    std::string bases;
+    // what the device hands back
+    std::vector<pg_result> res;
+    std::vector<pg_op> ops;
+    std::vector<uint64_t> seq_off;
+    std::vector<uint32_t> table, path;
+    std::vector<pg_read_support> sup;
+    pg_count_layout lay{};
+};
+
 void SiteBatcher::run(BatchParameters const& prm)
 {
-    const size_t n_sites = impl_->graphs.size();
-    impl_->counts.assign(n_sites, SiteCounts());
-    if (n_sites == 0)
+    impl_->counts.assign(impl_->graphs.size(), SiteCounts());
+    impl_->views.assign(impl_->graphs.size(), SiteReadViews());
+    if (impl_->graphs.empty())
         return;
-    pg_ctx* ctx = deviceContext();
     // PG_BATCH_TIMING=1: wall-clock of the phases of this call on stderr
     const bool timing = std::getenv("PG_BATCH_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
@@ -690,46 +722,69 @@ void SiteBatcher::run(BatchParameters const& prm)
         fprintf(stderr, "[SiteBatcher] %-18s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
         t_prev = t;
     };
-    GraphCsr csr;
-    for (const Graph* g : impl_->graphs)
-        csr.add(*g);
+    Impl::Run run(*impl_, prm);
+    run.graphCsr();
     mark("graph csr");
+    run.packReads();
+    mark("pack reads");
+    run.deviceSection();  // the only part under the device mutex
+    mark("device");
+    if (run.packed_mode)
+        run.viewsOfPackedSites();
+    else
+        run.resultsToReads();
+    mark("results -> reads");
+    run.siteTables();
+    mark("site tables");
+}
+
+void SiteBatcher::Impl::Run::graphCsr()
+{
+    for (const Graph* g : impl.graphs)
+        csr.add(*g);
+}
+
+void SiteBatcher::Impl::Run::packReads()
+{
     // ---- pack the reads of all sites: offsets first, then every site fills its own slice --------------------
-    const bool packed_mode = impl_->packed[0] != nullptr;
+    packed_mode = impl.packed[0] != nullptr;
+    site_read0.assign(n_sites + 1, 0);
+    site_base0.assign(n_sites + 1, 0);
     for (size_t s = 0; s < n_sites; ++s)
-        if ((impl_->packed[s] != nullptr) != packed_mode || (!packed_mode && !impl_->reads[s]))
+        if ((impl.packed[s] != nullptr) != packed_mode || (!packed_mode && !impl.reads[s]))
             throw std::logic_error("SiteBatcher: a batch holds either object sites or packed sites");
-    std::vector<uint64_t> site_read0(n_sites + 1, 0), site_base0(n_sites + 1, 0);
     for (size_t s = 0; s < n_sites; ++s)
     {
         uint64_t site_bases = 0, site_reads = 0;
         if (packed_mode)
         {
-            site_bases = impl_->packed[s]->bases.size();
-            site_reads = impl_->packed[s]->size();
+            site_bases = impl.packed[s]->bases.size();
+            site_reads = impl.packed[s]->size();
         }
         else
         {
-            for (auto const& r : *impl_->reads[s])
+            for (auto const& r : *impl.reads[s])
                 site_bases += r->bases().size();
-            site_reads = impl_->reads[s]->size();
+            site_reads = impl.reads[s]->size();
         }
         site_read0[s + 1] = site_read0[s] + site_reads;
         site_base0[s + 1] = site_base0[s] + site_bases;
     }
     if (site_read0[n_sites] > 0xFFFFFFFFull || site_base0[n_sites] > 0xFFFFFFFFull)
         throw std::runtime_error("SiteBatcher: more than 2^32 reads or bases in one batch");
-    std::vector<uint32_t> base_off(site_read0[n_sites] + 1, 0), gor(site_read0[n_sites]), frag(site_read0[n_sites]);
-    std::vector<uint8_t> is_rev(site_read0[n_sites]);
-    std::vector<Read*> flat(packed_mode ? 0 : site_read0[n_sites]);
-    std::string bases(site_base0[n_sites], '\0');
+    base_off.assign(site_read0[n_sites] + 1, 0);
+    gor.resize(site_read0[n_sites]);
+    frag.resize(site_read0[n_sites]);
+    is_rev.resize(site_read0[n_sites]);
+    flat.resize(packed_mode ? 0 : site_read0[n_sites]);
+    bases.assign(site_base0[n_sites], '\0');
     pghost::parallelFor(
         n_sites, prm.threads,
         [&](size_t s) {
             uint64_t i = site_read0[s], at = site_base0[s];
             if (packed_mode)
             {
-                PackedSite const& p = *impl_->packed[s];
+                PackedSite const& p = *impl.packed[s];
                 std::copy(p.bases.begin(), p.bases.end(), bases.begin() + (std::ptrdiff_t)at);
                 for (size_t k = 0; k < p.size(); ++k, ++i)
                 {
@@ -741,7 +796,7 @@ void SiteBatcher::run(BatchParameters const& prm)
                 return;
             }
             std::unordered_map<std::string, uint32_t> frag_ids;  // fragment ids are local to a site
-            for (auto& r : *impl_->reads[s])
+            for (auto& r : *impl.reads[s])
             {
                 flat[i] = r.get();
                 std::copy(r->bases().begin(), r->bases().end(), bases.begin() + (std::ptrdiff_t)at);
@@ -755,212 +810,232 @@ void SiteBatcher::run(BatchParameters const& prm)
             }
         },
         8);
-    mark("pack reads");
+}
+
+void SiteBatcher::Impl::Run::deviceSection()
+{
     // ---- device section: calls on one context are serialised; everything before and after overlaps across threads ------
-    std::vector<pg_result> res;
-    std::vector<pg_op> ops;
-    std::vector<uint64_t> seq_off(n_sites + 1);
-    std::vector<uint32_t> table, path;
-    std::vector<pg_read_support> sup;
-    pg_count_layout lay{};
+    pg_ctx* ctx = deviceContext();
     const uint32_t n = (uint32_t)gor.size();
+    seq_off.assign(n_sites + 1, 0);
+    const bool timing = std::getenv("PG_BATCH_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!timing)
+            return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[SiteBatcher]   %-16s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
+    // the graph set is prepared outside the device mutex (paragraph_amd.h allows exactly that): converting a thousand
+    // graphs to column tables is host work another lane's batch should not wait for
+    std::unique_lock<std::mutex> lock(deviceMutex(), std::defer_lock);  // before `guard`: device objects go while it is held
+    pg_graphs* G = nullptr;
+    check(ctx, pg_graphs_upload(ctx, (uint32_t)n_sites, csr.node_off.data(), csr.seq_off.data(), csr.seq.data(),
+                                csr.pred_off.data(), csr.pred.empty() ? nullptr : csr.pred.data(), &G),
+          "pg_graphs_upload");
+    struct Guard
     {
-        std::lock_guard<std::mutex> lock(deviceMutex());
-        pg_graphs* G = nullptr;
-        check(ctx, pg_graphs_upload(ctx, (uint32_t)n_sites, csr.node_off.data(), csr.seq_off.data(), csr.seq.data(),
-                                    csr.pred_off.data(), csr.pred.empty() ? nullptr : csr.pred.data(), &G),
-              "pg_graphs_upload");
-        struct Guard
+        pg_ctx* c;
+        pg_graphs* g;
+        pg_batch* b;
+        ~Guard()
         {
-            pg_ctx* c;
-            pg_graphs* g;
-            pg_batch* b;
-            ~Guard()
-            {
-                if (b)
-                    pg_batch_destroy(c, b);
-                if (g)
-                    pg_graphs_destroy(c, g);
-            }
-        } guard{ ctx, G, nullptr };
-        check(ctx, pg_graphs_set_labels(ctx, G, csr.label_mask.empty() ? nullptr : csr.label_mask.data(), csr.n_labels.data()),
-              "pg_graphs_set_labels");
-
-        check(ctx, pg_batch_create(ctx, &guard.b), "pg_batch_create");
-        check(ctx, pg_batch_upload(ctx, guard.b, G, n, gor.data(), base_off.data(), bases.data()), "pg_batch_upload");
-        check(ctx, pg_batch_set_fragments(ctx, guard.b, frag.data(), is_rev.data()), "pg_batch_set_fragments");
-        pg_count_params cp{};
-        cp.remove_nonuniq = prm.remove_nonuniq_reads ? 1 : 0;
-        cp.use_support_filters = prm.use_support_filters ? 1 : 0;
-        cp.bad_align_frac = prm.bad_align_frac;
-        if (prm.kmer_len != 0)
-        {
-            // createReadFilter(graph, nonuniq, frac, kmer_len): NonUniq -> BadAlign -> KmerFilter (ReadFilter.cpp:74-90)
-            check(ctx, pg_graphs_build_filter_index(ctx, G, prm.kmer_len, nullptr), "pg_graphs_build_filter_index");
-            cp.use_kmer_filter = 1;
+            if (b)
+                pg_batch_destroy(c, b);
+            if (g)
+                pg_graphs_destroy(c, g);
         }
-        uint32_t align_flags = prm.alignment_flags;
-        if (prm.path_sequence_matching && n)
-        {
-            // stage 1: PathAligner on every read; the filter chain runs on the device (count pass) and decides who goes on
-            check(ctx, pg_graphs_build_path_index(ctx, G, 32), "pg_graphs_build_path_index");
-            check(ctx, pg_batch_path_align(ctx, guard.b), "pg_batch_path_align");
-            check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
-            std::vector<uint8_t> stage_flags(n), active(n, 1);
-            std::vector<pg_read_support> stage_sup(n);
-            uint64_t np = 0;
-            check(ctx, pg_batch_download_path_flags(ctx, guard.b, stage_flags.data()), "pg_batch_download_path_flags");
-            check(ctx, pg_batch_download_counts(ctx, guard.b, nullptr, stage_sup.data(), nullptr, 0, &np), "pg_batch_download_counts");
-            for (uint32_t i = 0; i < n; ++i)
-                if ((stage_flags[i] & 1) && stage_sup[i].status == 1)
-                    active[i] = 0;  // MAPPED by the path stage and accepted by the filters: done
-            check(ctx, pg_batch_set_active(ctx, guard.b, active.data()), "pg_batch_set_active");
-            // keep the path-stage records of the finished reads (the extension flag is ignored when flags == PG_AF_ALL)
-            align_flags = (align_flags & (PG_AF_CIGAR | PG_AF_BOTH_STRANDS | PG_AF_REVERSE_GRAPH)) | PG_AF_KEEP_RESULTS;
-        }
-        mark("upload (+ path)");
-        check(ctx, pg_batch_align(ctx, guard.b, align_flags), "pg_batch_align");
+    } guard{ ctx, G, nullptr };
+    check(ctx, pg_graphs_set_labels(ctx, G, csr.label_mask.empty() ? nullptr : csr.label_mask.data(), csr.n_labels.data()),
+          "pg_graphs_set_labels");
+    mark("graphs up");
+    lock.lock();
+    mark("wait for device");
+    check(ctx, pg_batch_create(ctx, &guard.b), "pg_batch_create");
+    check(ctx, pg_batch_upload(ctx, guard.b, G, n, gor.data(), base_off.data(), bases.data()), "pg_batch_upload");
+    check(ctx, pg_batch_set_fragments(ctx, guard.b, frag.data(), is_rev.data()), "pg_batch_set_fragments");
+    mark("reads up");
+    pg_count_params cp{};
+    cp.remove_nonuniq = prm.remove_nonuniq_reads ? 1 : 0;
+    cp.use_support_filters = prm.use_support_filters ? 1 : 0;
+    cp.bad_align_frac = prm.bad_align_frac;
+    if (prm.kmer_len != 0)
+    {
+        // createReadFilter(graph, nonuniq, frac, kmer_len): NonUniq -> BadAlign -> KmerFilter (ReadFilter.cpp:74-90)
+        check(ctx, pg_graphs_build_filter_index(ctx, G, prm.kmer_len, nullptr), "pg_graphs_build_filter_index");
+        cp.use_kmer_filter = 1;
+    }
+    uint32_t align_flags = prm.alignment_flags;
+    if (prm.path_sequence_matching && n)
+    {
+        // stage 1: PathAligner on every read; the filter chain runs on the device (count pass) and decides who goes on
+        check(ctx, pg_graphs_build_path_index(ctx, G, 32), "pg_graphs_build_path_index");
+        check(ctx, pg_batch_path_align(ctx, guard.b), "pg_batch_path_align");
         check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
+        std::vector<uint8_t> stage_flags(n), active(n, 1);
+        std::vector<pg_read_support> stage_sup(n);
+        uint64_t np = 0;
+        check(ctx, pg_batch_download_path_flags(ctx, guard.b, stage_flags.data()), "pg_batch_download_path_flags");
+        check(ctx, pg_batch_download_counts(ctx, guard.b, nullptr, stage_sup.data(), nullptr, 0, &np), "pg_batch_download_counts");
+        for (uint32_t i = 0; i < n; ++i)
+            if ((stage_flags[i] & 1) && stage_sup[i].status == 1)
+                active[i] = 0;  // MAPPED by the path stage and accepted by the filters: done
+        check(ctx, pg_batch_set_active(ctx, guard.b, active.data()), "pg_batch_set_active");
+        // keep the path-stage records of the finished reads (the extension flag is ignored when flags == PG_AF_ALL)
+        align_flags = (align_flags & (PG_AF_CIGAR | PG_AF_BOTH_STRANDS | PG_AF_REVERSE_GRAPH)) | PG_AF_KEEP_RESULTS;
+    }
+    check(ctx, pg_batch_align(ctx, guard.b, align_flags), "pg_batch_align");
+    check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
+    mark("align + count");
 
-        uint64_t n_ops = 0, n_path = 0;
-        check(ctx, pg_batch_ops_count(ctx, guard.b, &n_ops), "pg_batch_ops_count");
-        res.resize(n);
-        ops.resize(n_ops + 1);
-        check(ctx, pg_batch_download(ctx, guard.b, res.data(), ops.data(), ops.size(), &n_ops), "pg_batch_download");
-        check(ctx, pg_graphs_count_layout(G, &lay), "pg_graphs_count_layout");
-        check(ctx, pg_graphs_seq_offsets(G, seq_off.data()), "pg_graphs_seq_offsets");
-        table.resize(lay.n_counters);
-        sup.resize(n);
-        check(ctx, pg_batch_download_counts(ctx, guard.b, nullptr, nullptr, nullptr, 0, &n_path), "pg_batch_download_counts");
-        path.resize(n_path + 1);
-        check(ctx, pg_batch_download_counts(ctx, guard.b, table.data(), sup.data(), path.data(), path.size(), &n_path),
-              "pg_batch_download_counts");
-    }  // device objects released, mutex dropped
-    mark("align+count+download");
+    uint64_t n_ops = 0, n_path = 0;
+    check(ctx, pg_batch_ops_count(ctx, guard.b, &n_ops), "pg_batch_ops_count");
+    res.resize(n);
+    ops.resize(n_ops + 1);
+    check(ctx, pg_batch_download(ctx, guard.b, res.data(), ops.data(), ops.size(), &n_ops), "pg_batch_download");
+    check(ctx, pg_graphs_count_layout(G, &lay), "pg_graphs_count_layout");
+    check(ctx, pg_graphs_seq_offsets(G, seq_off.data()), "pg_graphs_seq_offsets");
+    table.resize(lay.n_counters);
+    sup.resize(n);
+    check(ctx, pg_batch_download_counts(ctx, guard.b, nullptr, nullptr, nullptr, 0, &n_path), "pg_batch_download_counts");
+    path.resize(n_path + 1);
+    check(ctx, pg_batch_download_counts(ctx, guard.b, table.data(), sup.data(), path.data(), path.size(), &n_path),
+          "pg_batch_download_counts");
+    mark("results down");
+}
+
+void SiteBatcher::Impl::Run::resultsToReads()
+{
     // ---- fan results back into the reads ---------------------------------------------------------------
-    if (!packed_mode)
-        pghost::parallelFor(
-            n, prm.threads,
-            [&](size_t i) {
-                Read& read = *flat[i];
-                if (read.bases().empty() || sup[i].status == 0)
-                    return;
-                if (sup[i].status == 3)
-                    throw std::runtime_error("invalid alignment on the device path for fragment " + read.fragment_id());
-                if (res[i].status & PG_STATUS_PATH_ALIGNER)
-                {
-                    // PathAligner.cpp:121-161: the match's own strand, bases replaced, qualities untouched
-                    if (res[i].returned_reverse)
-                        read.set_bases(reverseComplement(read.bases()));
-                    read.set_is_graph_reverse_strand(res[i].returned_reverse != 0);
-                    std::string buf(16 + 12 * (size_t)res[i].n_ops, '\0');
-                    buf.resize(pg_render_cigar(&res[i], ops.data(), &buf[0], buf.size()));
-                    read.set_graph_cigar(buf);
-                    read.set_graph_pos(res[i].graph_pos);
-                    read.set_graph_alignment_score(res[i].score);
-                    read.set_is_graph_alignment_unique(res[i].is_unique != 0);
-                    read.set_graph_mapq(res[i].mapq);
-                }
-                else
-                    applyResult(read, res[i], ops.data(), true);
-                read.set_graph_mapping_status(sup[i].status == 1 ? Read::MAPPED : Read::BAD_ALIGN);
-                read.clear_graph_nodes_supported();
-                read.clear_graph_edges_supported();
-                read.clear_graph_sequences_supported();
-                if (sup[i].status != 1)
-                    return;
-                const Graph& g = *impl_->graphs[gor[i]];
-                uint32_t prev = 0;
-                std::vector<std::pair<std::string, std::string>> edges;
-                for (uint32_t k = 0; k < sup[i].n_path; ++k)
-                {
-                    const uint32_t en = path[sup[i].path_off + k];
-                    const uint32_t nd = PG_PATH_NODE(en);
-                    if (PG_PATH_NODE_OK(en))
-                        read.add_graph_nodes_supported(g.nodeName(nd));
-                    if (k > 0 && PG_PATH_EDGE_OK(en))
-                        edges.emplace_back(g.nodeName(prev), g.nodeName(nd));
-                    prev = nd;
-                }
-                std::sort(edges.begin(), edges.end());  // the reference collects them in a std::set of name pairs
-                for (auto const& e : edges)
-                    read.add_graph_edges_supported(e.first + "_" + e.second);
-                const auto& names = csr.label_names[gor[i]];
-                for (size_t b = 0; b < names.size(); ++b)
-                    if ((sup[i].label_mask >> b) & 1)
-                        read.add_graph_sequences_supported(names[b]);
-            },
-            512);
+    const uint32_t n = (uint32_t)gor.size();
+    pghost::parallelFor(
+        n, prm.threads,
+        [&](size_t i) {
+            Read& read = *flat[i];
+            if (read.bases().empty() || sup[i].status == 0)
+                return;
+            if (sup[i].status == 3)
+                throw std::runtime_error("invalid alignment on the device path for fragment " + read.fragment_id());
+            if (res[i].status & PG_STATUS_PATH_ALIGNER)
+            {
+                // PathAligner.cpp:121-161: the match's own strand, bases replaced, qualities untouched
+                if (res[i].returned_reverse)
+                    read.set_bases(reverseComplement(read.bases()));
+                read.set_is_graph_reverse_strand(res[i].returned_reverse != 0);
+                std::string buf(16 + 12 * (size_t)res[i].n_ops, '\0');
+                buf.resize(pg_render_cigar(&res[i], ops.data(), &buf[0], buf.size()));
+                read.set_graph_cigar(buf);
+                read.set_graph_pos(res[i].graph_pos);
+                read.set_graph_alignment_score(res[i].score);
+                read.set_is_graph_alignment_unique(res[i].is_unique != 0);
+                read.set_graph_mapq(res[i].mapq);
+            }
+            else
+                applyResult(read, res[i], ops.data(), true);
+            read.set_graph_mapping_status(sup[i].status == 1 ? Read::MAPPED : Read::BAD_ALIGN);
+            read.clear_graph_nodes_supported();
+            read.clear_graph_edges_supported();
+            read.clear_graph_sequences_supported();
+            if (sup[i].status != 1)
+                return;
+            const Graph& g = *impl.graphs[gor[i]];
+            uint32_t prev = 0;
+            std::vector<std::pair<std::string, std::string>> edges;
+            for (uint32_t k = 0; k < sup[i].n_path; ++k)
+            {
+                const uint32_t en = path[sup[i].path_off + k];
+                const uint32_t nd = PG_PATH_NODE(en);
+                if (PG_PATH_NODE_OK(en))
+                    read.add_graph_nodes_supported(g.nodeName(nd));
+                if (k > 0 && PG_PATH_EDGE_OK(en))
+                    edges.emplace_back(g.nodeName(prev), g.nodeName(nd));
+                prev = nd;
+            }
+            std::sort(edges.begin(), edges.end());  // the reference collects them in a std::set of name pairs
+            for (auto const& e : edges)
+                read.add_graph_edges_supported(e.first + "_" + e.second);
+            const auto& names = csr.label_names[gor[i]];
+            for (size_t b = 0; b < names.size(); ++b)
+                if ((sup[i].label_mask >> b) & 1)
+                    read.add_graph_sequences_supported(names[b]);
+        },
+        512);
+}
+
+void SiteBatcher::Impl::Run::viewsOfPackedSites()
+{
     // ---- packed sites: what the statistics need of the MAPPED reads, straight from the device records ----------
-    impl_->views.assign(n_sites, SiteReadViews());
-    if (packed_mode)
-        pghost::parallelFor(
-            n_sites, prm.threads,
-            [&](size_t s) {
-                PackedSite const& p = *impl_->packed[s];
-                SiteReadViews& v = impl_->views[s];
-                v.label_names = csr.label_names[s];
-                uint32_t n_fragments = 0;
-                for (size_t k = 0; k < p.size(); ++k)
+    pghost::parallelFor(
+        n_sites, prm.threads,
+        [&](size_t s) {
+            PackedSite const& p = *impl.packed[s];
+            SiteReadViews& v = impl.views[s];
+            v.label_names = csr.label_names[s];
+            uint32_t n_fragments = 0;
+            for (size_t k = 0; k < p.size(); ++k)
+            {
+                const size_t i = site_read0[s] + k;
+                n_fragments = std::max(n_fragments, p.fragment[k] + 1);
+                if (p.readLength(k) == 0 || sup[i].status == 0)
+                    continue;
+                if (sup[i].status == 3)
+                    throw std::runtime_error("invalid alignment on the device path in site " + std::to_string(s));
+                if (sup[i].status != 1)
+                    continue;
+                MappedReadView m;
+                m.fragment = p.fragment[k];
+                m.read_length = p.readLength(k);
+                m.chrom_id = p.chrom_id[k];
+                m.pos = p.pos[k];
+                m.mate_chrom_id = p.mate_chrom_id[k];
+                m.mate_pos = p.mate_pos[k];
+                m.is_mapped = (p.flags[k] & PackedSite::MAPPED) != 0;
+                m.is_mate_mapped = (p.flags[k] & PackedSite::MATE_MAPPED) != 0;
+                m.is_reverse_strand = (p.flags[k] & PackedSite::REVERSE) != 0;
+                m.is_mate_reverse_strand = (p.flags[k] & PackedSite::MATE_REVERSE) != 0;
+                m.is_graph_mapped = true;
+                m.is_graph_reverse_strand = (res[i].status & PG_STATUS_PATH_ALIGNER) ? res[i].returned_reverse != 0
+                                                                                     : m.is_reverse_strand != (res[i].returned_reverse != 0);
+                m.graph_pos = res[i].graph_pos;
+                m.graph_alignment_score = res[i].score;
+                m.pieces_off = (uint32_t)v.pieces.size();
+                for (uint32_t o = 0; o < res[i].n_ops; ++o)
                 {
-                    const size_t i = site_read0[s] + k;
-                    n_fragments = std::max(n_fragments, p.fragment[k] + 1);
-                    if (p.readLength(k) == 0 || sup[i].status == 0)
-                        continue;
-                    if (sup[i].status == 3)
-                        throw std::runtime_error("invalid alignment on the device path in site " + std::to_string(s));
-                    if (sup[i].status != 1)
-                        continue;
-                    MappedReadView m;
-                    m.fragment = p.fragment[k];
-                    m.read_length = p.readLength(k);
-                    m.chrom_id = p.chrom_id[k];
-                    m.pos = p.pos[k];
-                    m.mate_chrom_id = p.mate_chrom_id[k];
-                    m.mate_pos = p.mate_pos[k];
-                    m.is_mapped = (p.flags[k] & PackedSite::MAPPED) != 0;
-                    m.is_mate_mapped = (p.flags[k] & PackedSite::MATE_MAPPED) != 0;
-                    m.is_reverse_strand = (p.flags[k] & PackedSite::REVERSE) != 0;
-                    m.is_mate_reverse_strand = (p.flags[k] & PackedSite::MATE_REVERSE) != 0;
-                    m.is_graph_mapped = true;
-                    m.is_graph_reverse_strand = (res[i].status & PG_STATUS_PATH_ALIGNER) ? res[i].returned_reverse != 0
-                                                                                         : m.is_reverse_strand != (res[i].returned_reverse != 0);
-                    m.graph_pos = res[i].graph_pos;
-                    m.graph_alignment_score = res[i].score;
-                    m.pieces_off = (uint32_t)v.pieces.size();
-                    for (uint32_t o = 0; o < res[i].n_ops; ++o)
+                    const pg_op op = ops[res[i].ops_off + o];
+                    const NodeId node = PG_OP_NODE(op);
+                    if (v.pieces.size() == m.pieces_off || v.pieces.back().node != node)
                     {
-                        const pg_op op = ops[res[i].ops_off + o];
-                        const NodeId node = PG_OP_NODE(op);
-                        if (v.pieces.size() == m.pieces_off || v.pieces.back().node != node)
-                        {
-                            v.pieces.emplace_back();
-                            v.pieces.back().node = node;
-                        }
-                        NodeAlignment& na = v.pieces.back();
-                        const uint32_t len = PG_OP_LEN(op);
-                        switch (PG_OP_CODE(op))
-                        {
-                        case PG_OPC_M: na.matched += len; break;
-                        case PG_OPC_X: na.mismatched += len; break;
-                        case PG_OPC_N: na.missing += len; break;
-                        case PG_OPC_I: na.inserted += len; break;
-                        case PG_OPC_D: na.deleted += len; break;
-                        case PG_OPC_S: na.clipped += len; break;
-                        default: break;  // PG_OPC_EMPTY: the node is on the path with an empty CIGAR
-                        }
+                        v.pieces.emplace_back();
+                        v.pieces.back().node = node;
                     }
-                    m.n_pieces = (uint32_t)v.pieces.size() - m.pieces_off;
-                    m.sequences = sup[i].label_mask;
-                    m.support_off = (uint32_t)v.support.size();
-                    m.n_support = sup[i].n_path;
-                    v.support.insert(v.support.end(), path.begin() + sup[i].path_off, path.begin() + sup[i].path_off + sup[i].n_path);
-                    v.reads.push_back(m);
+                    NodeAlignment& na = v.pieces.back();
+                    const uint32_t len = PG_OP_LEN(op);
+                    switch (PG_OP_CODE(op))
+                    {
+                    case PG_OPC_M: na.matched += len; break;
+                    case PG_OPC_X: na.mismatched += len; break;
+                    case PG_OPC_N: na.missing += len; break;
+                    case PG_OPC_I: na.inserted += len; break;
+                    case PG_OPC_D: na.deleted += len; break;
+                    case PG_OPC_S: na.clipped += len; break;
+                    default: break;  // PG_OPC_EMPTY: the node is on the path with an empty CIGAR
+                    }
                 }
-                v.n_fragments = n_fragments;
-            },
-            8);
-    mark("results -> reads");
+                m.n_pieces = (uint32_t)v.pieces.size() - m.pieces_off;
+                m.sequences = sup[i].label_mask;
+                m.support_off = (uint32_t)v.support.size();
+                m.n_support = sup[i].n_path;
+                v.support.insert(v.support.end(), path.begin() + sup[i].path_off, path.begin() + sup[i].path_off + sup[i].n_path);
+                v.reads.push_back(m);
+            }
+            v.n_fragments = n_fragments;
+        },
+        8);
+}
+
+void SiteBatcher::Impl::Run::siteTables()
+{
     // ---- per-site tables --------------------------------------------------------------------------------
     auto entry = [&](uint64_t off) {
         CountEntry e;
@@ -973,8 +1048,8 @@ void SiteBatcher::run(BatchParameters const& prm)
     pghost::parallelFor(
         n_sites, prm.threads,
         [&](size_t s) {
-            const Graph& g = *impl_->graphs[s];
-            SiteCounts& sc = impl_->counts[s];
+            const Graph& g = *impl.graphs[s];
+            SiteCounts& sc = impl.counts[s];
             const uint32_t nb = csr.node_off[s];
             for (NodeId nd = 0; nd != g.numNodes(); ++nd)
             {
@@ -1011,12 +1086,11 @@ void SiteBatcher::run(BatchParameters const& prm)
                 return;
             // only MAPPED reads survive (Align.cpp:155)
             std::vector<common::p_Read> kept;
-            for (auto& r : *impl_->reads[s])
+            for (auto& r : *impl.reads[s])
                 if (!r->bases().empty() && r->graph_mapping_status() == Read::MAPPED)
                     kept.emplace_back(std::move(r));
-            impl_->reads[s]->swap(kept);
+            impl.reads[s]->swap(kept);
         },
         8);
-    mark("site tables");
 }
 }  // namespace paragraph

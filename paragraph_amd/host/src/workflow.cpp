@@ -787,3 +787,82 @@ std::vector<Json> genotypeGraphs(
     return genotypes;
 }
 }  // namespace grmpy
+
+// ----------------------------------------------------------------------------------------------------------------------
+// C entry point (include/paragraph_workflow.h)
+// ----------------------------------------------------------------------------------------------------------------------
+#include <cstring>
+#include <fstream>
+
+#include "../../../include/paragraph_workflow.h"
+
+extern "C" int pgw_genotype_graphs(
+    const char* reference_fasta, const char* manifest, const char* const* graph_paths, size_t n_graphs,
+    const char* genotyping_parameters, const char* options_json, const char* output_path, char* error, size_t error_cap)
+{
+    auto report = [&](std::string const& what) {
+        if (error && error_cap)
+        {
+            strncpy(error, what.c_str(), error_cap - 1);
+            error[error_cap - 1] = '\0';
+        }
+        return 1;
+    };
+    try
+    {
+        if (!reference_fasta || !manifest || !output_path || (n_graphs && !graph_paths))
+            return report("pgw_genotype_graphs: null argument");
+        grmpy::Parameters parameters;
+        if (options_json && *options_json)
+        {
+            const Json options = Json::parse(options_json);
+            if (!options.isObject())
+                return report("pgw_genotype_graphs: options_json must be a JSON object");
+            for (auto const& kv : options.members())
+            {
+                if (kv.first == "threads")
+                    parameters.threads = (int)kv.second.asInt64();
+                else if (kv.first == "lanes")
+                    parameters.lanes = (int)kv.second.asInt64();
+                else if (kv.first == "sites_per_batch")
+                    parameters.sites_per_batch = (size_t)kv.second.asUInt64();
+                else if (kv.first == "max_reads")
+                    parameters.max_reads = (int)kv.second.asInt64();
+                else if (kv.first == "bad_align_frac")
+                    parameters.bad_align_frac = (float)kv.second.asDouble();
+                else if (kv.first == "path_sequence_matching")
+                    parameters.path_sequence_matching = kv.second.asBool();
+                else if (kv.first == "bad_align_uniq_kmer_len")
+                    parameters.bad_align_uniq_kmer_len = (int)kv.second.asInt64();
+                else if (kv.first == "packed_reads")
+                    parameters.packed_reads = kv.second.asBool();
+                else
+                    return report("pgw_genotype_graphs: unknown option " + kv.first);
+            }
+        }
+        std::vector<std::string> graphs(graph_paths, graph_paths + n_graphs);
+        const genotyping::Samples samples = genotyping::loadManifest(manifest);
+        const std::vector<Json> genotypes
+            = grmpy::genotypeGraphs(parameters, graphs, reference_fasta, samples, genotyping_parameters ? genotyping_parameters : "");
+        std::ofstream out(output_path, std::ios::binary);
+        if (!out.good())
+            return report(std::string("cannot write ") + output_path);
+        out << "[";
+        for (size_t g = 0; g < genotypes.size(); ++g)
+            out << (g ? ",\n" : "\n") << genotypes[g].dump();
+        out << "\n]\n";
+        out.close();
+        if (!out.good())
+            return report(std::string("error while writing ") + output_path);
+        return 0;
+    }
+    catch (std::exception const& e)
+    {
+        return report(e.what());
+    }
+    catch (...)
+    {
+        return report("unknown error");
+    }
+}
+

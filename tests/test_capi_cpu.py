@@ -67,3 +67,32 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp", ".hh")):
                 text = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "oracle" not in text.replace("no oracle", ""), os.path.join(dirpath, fn)
+
+
+def test_workflow_entry_exported_and_fails_loudly(tmp_path):
+    """include/paragraph_workflow.h: the host library exports the workflow entry; bad inputs are reported through the
+    error buffer, and without a GPU a well-formed call fails at the device instead of computing anything on the CPU."""
+    import pytest
+    from paragraph_amd import build, workflow
+    build.build_host()
+    text = open(os.path.join(ROOT, "include", "paragraph_workflow.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    assert re.findall(r"\b(pgw_[a-z_0-9]+)\s*\(", text) == ["pgw_genotype_graphs"]
+    lib = workflow.load_library()
+    assert hasattr(lib, "pgw_genotype_graphs")
+    sites = os.path.join(ROOT, "tests", "golden", "sites", "chrX")
+    fasta, graph = os.path.join(sites, "chrX_graph_typing.fa"), os.path.join(sites, "chrX_graph_typing.2sample.json")
+    with pytest.raises(RuntimeError, match="Unable to open manifest"):
+        workflow.genotype_graphs(fasta, str(tmp_path / "missing.txt"), [graph])
+    manifest = tmp_path / "manifest.txt"
+    manifest.write_text("id\tpath\tdepth\tread length\nS1\t%s\t44.2\t150\n" % os.path.join(sites, "chrX_graph_typing.bam"))
+    with pytest.raises(RuntimeError, match="unknown option"):
+        workflow.genotype_graphs(fasta, str(manifest), [graph], colour="red")
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present")
+    except ImportError:
+        pass
+    with pytest.raises(RuntimeError, match="pg_ctx_create"):
+        workflow.genotype_graphs(fasta, str(manifest), [graph], threads=2)

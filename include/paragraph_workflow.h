@@ -21,7 +21,8 @@ extern "C" {
  *   graph_paths/n_graphs   graph descriptions (JSON, share/schema/graph_schema.json)
  *   genotyping_parameters  grmpy -G document, or NULL / "" for the defaults
  *   options_json           NULL / "" or an object with any of: "threads", "lanes", "sites_per_batch", "max_reads",
- *                          "bad_align_frac", "path_sequence_matching", "bad_align_uniq_kmer_len", "packed_reads"
+ *                          "bad_align_frac", "path_sequence_matching", "kmer_sequence_matching", "klib_sequence_matching",
+ *                          "bad_align_uniq_kmer_len", "packed_reads"
  *                          (grmpy's option names and defaults, grmpy/Parameters.hh:30-74)
  *   error/error_cap        receives the message when the call fails (may be NULL)
  *

@@ -9,6 +9,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <list>
 #include <map>
 #include <memory>
 #include <string>
@@ -54,6 +55,11 @@ struct BatchParameters
     // --path-sequence-matching (default ON in `paragraph`, OFF in grmpy): exact 32-mer-anchored path matching first; reads
     // it leaves unmapped -- or that the filter chain rejects -- go on to the gssw stage (CompositeAligner.cpp:78-103, 152)
     bool path_sequence_matching = false;
+    // --kmer-sequence-matching / --klib-sequence-matching (default OFF in both tools): the k-mer seed stage (k = 16) and the
+    // ksw stage between the path stage and gssw, each on the reads the stages before left unmapped or filtered
+    // (CompositeAligner.cpp:105-150).  Both need the sites' paths (addSite's `paths`).
+    bool kmer_sequence_matching = false;
+    bool klib_sequence_matching = false;
     unsigned alignment_flags = (unsigned)-1;
     int threads = 1;  // host threads for packing the reads and fanning the results back into them
 };
@@ -64,10 +70,11 @@ public:
     SiteBatcher();
     ~SiteBatcher();
     // graph and reads must outlive run(); returns the site index
-    size_t addSite(const graphtools::Graph* graph, std::vector<common::p_Read>* reads);
+    // `paths` (grm::pathsFromJson) are only read by the k-mer and klib stages; they must outlive run() too
+    size_t addSite(const graphtools::Graph* graph, std::vector<common::p_Read>* reads, std::list<graphtools::Path> const* paths = nullptr);
     // the packed form: the reads are only read; what the statistics need of the MAPPED ones is available through views()
     // after run().  One batch holds sites of one form only.
-    size_t addSite(const graphtools::Graph* graph, PackedSite const* reads);
+    size_t addSite(const graphtools::Graph* graph, PackedSite const* reads, std::list<graphtools::Path> const* paths = nullptr);
     // Aligns and counts every site added so far.  Afterwards each site's read vector holds only the MAPPED
     // reads (as grm::alignReads leaves it, Align.cpp:155) with their supports filled in.
     void run(BatchParameters const& parameters = BatchParameters());

@@ -49,6 +49,8 @@ struct Parameters
     int output_options_ = NODE_READ_COUNTS | EDGE_READ_COUNTS | PATH_READ_COUNTS;  // the `paragraph` tool's default
     bool path_sequence_matching = true;    // `paragraph` default; grmpy turns it off
     bool graph_sequence_matching = true;
+    bool kmer_sequence_matching = false;   // the optional seed stages between the path stage and gssw
+    bool klib_sequence_matching = false;
     bool remove_nonuniq_reads = true;
     int kmer_len = 0;
     int threads = 1;  // host threads for read extraction and document assembly
@@ -107,6 +109,8 @@ struct Parameters
     float bad_align_frac = 0.8f;
     bool path_sequence_matching = false;
     bool graph_sequence_matching = true;
+    bool klib_sequence_matching = false;
+    bool kmer_sequence_matching = false;
     int bad_align_uniq_kmer_len = 0;
     bool output_alignments = false;  // keep "alignments" in the per-sample documents (the original writes them to a folder)
     // keep the reads of a site as flat arrays instead of common::Read objects (several times less host work); switched off

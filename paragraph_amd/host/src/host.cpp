@@ -646,6 +646,7 @@ struct SiteBatcher::Impl
     std::vector<const Graph*> graphs;
     std::vector<std::vector<common::p_Read>*> reads;
     std::vector<const PackedSite*> packed;
+    std::vector<std::list<graphtools::Path> const*> paths;
     std::vector<SiteCounts> counts;
     std::vector<SiteReadViews> views;
     struct Run;
@@ -658,19 +659,21 @@ SiteCounts const& SiteBatcher::counts(size_t site) const { return impl_->counts.
 
 SiteReadViews const& SiteBatcher::views(size_t site) const { return impl_->views.at(site); }
 
-size_t SiteBatcher::addSite(const Graph* graph, std::vector<common::p_Read>* reads)
+size_t SiteBatcher::addSite(const Graph* graph, std::vector<common::p_Read>* reads, std::list<graphtools::Path> const* paths)
 {
     impl_->graphs.push_back(graph);
     impl_->reads.push_back(reads);
     impl_->packed.push_back(nullptr);
+    impl_->paths.push_back(paths);
     return impl_->graphs.size() - 1;
 }
 
-size_t SiteBatcher::addSite(const Graph* graph, PackedSite const* reads)
+size_t SiteBatcher::addSite(const Graph* graph, PackedSite const* reads, std::list<graphtools::Path> const* paths)
 {
     impl_->graphs.push_back(graph);
     impl_->reads.push_back(nullptr);
     impl_->packed.push_back(reads);
+    impl_->paths.push_back(paths);
     return impl_->graphs.size() - 1;
 }
 
@@ -867,24 +870,69 @@ void SiteBatcher::Impl::Run::deviceSection()
         cp.use_kmer_filter = 1;
     }
     uint32_t align_flags = prm.alignment_flags;
-    if (prm.path_sequence_matching && n)
-    {
-        // stage 1: PathAligner on every read; the filter chain runs on the device (count pass) and decides who goes on
-        check(ctx, pg_graphs_build_path_index(ctx, G, 32), "pg_graphs_build_path_index");
-        check(ctx, pg_batch_path_align(ctx, guard.b), "pg_batch_path_align");
+    // Seed stages of the cascade (CompositeAligner.cpp:78-150).  After each one the filter chain runs on the device (count
+    // pass); a read that is MAPPED and accepted is done, everything else goes on to the next stage with the earlier
+    // records kept.
+    std::vector<uint8_t> stage_flags, active;
+    std::vector<pg_read_support> stage_sup;
+    uint32_t keep = 0;
+    auto hand_over = [&]() {
         check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
-        std::vector<uint8_t> stage_flags(n), active(n, 1);
-        std::vector<pg_read_support> stage_sup(n);
         uint64_t np = 0;
+        stage_flags.resize(n);
+        stage_sup.resize(n);
+        if (active.empty())
+            active.assign(n, 1);
         check(ctx, pg_batch_download_path_flags(ctx, guard.b, stage_flags.data()), "pg_batch_download_path_flags");
         check(ctx, pg_batch_download_counts(ctx, guard.b, nullptr, stage_sup.data(), nullptr, 0, &np), "pg_batch_download_counts");
         for (uint32_t i = 0; i < n; ++i)
-            if ((stage_flags[i] & 1) && stage_sup[i].status == 1)
-                active[i] = 0;  // MAPPED by the path stage and accepted by the filters: done
+            if (active[i] && (stage_flags[i] & 1) && stage_sup[i].status == 1)
+                active[i] = 0;
         check(ctx, pg_batch_set_active(ctx, guard.b, active.data()), "pg_batch_set_active");
-        // keep the path-stage records of the finished reads (the extension flag is ignored when flags == PG_AF_ALL)
-        align_flags = (align_flags & (PG_AF_CIGAR | PG_AF_BOTH_STRANDS | PG_AF_REVERSE_GRAPH)) | PG_AF_KEEP_RESULTS;
+        keep = PG_AF_KEEP_RESULTS;
+    };
+    std::vector<uint32_t> path_off{ 0 }, path_node_off{ 0 }, path_nodes;
+    if ((prm.kmer_sequence_matching || prm.klib_sequence_matching) && n)
+    {
+        for (size_t s = 0; s < n_sites; ++s)
+        {
+            if (!impl.paths[s])
+                throw std::logic_error("SiteBatcher: the k-mer and klib stages need the paths of every site");
+            for (auto const& p : *impl.paths[s])
+            {
+                path_nodes.insert(path_nodes.end(), p.nodes.begin(), p.nodes.end());
+                path_node_off.push_back((uint32_t)path_nodes.size());
+            }
+            path_off.push_back((uint32_t)path_node_off.size() - 1);
+        }
+        if (path_nodes.empty())
+            path_nodes.push_back(0);
     }
+    if (prm.path_sequence_matching && n)
+    {
+        check(ctx, pg_graphs_build_path_index(ctx, G, 32), "pg_graphs_build_path_index");
+        check(ctx, pg_batch_path_align(ctx, guard.b), "pg_batch_path_align");
+        hand_over();
+    }
+    if (prm.kmer_sequence_matching && n)
+    {
+        check(ctx, pg_graphs_build_kmer_index(ctx, G, 16, path_off.data(), path_node_off.data(), path_nodes.data()),
+              "pg_graphs_build_kmer_index");
+        check(ctx, pg_batch_kmer_align(ctx, guard.b, keep), "pg_batch_kmer_align");
+        hand_over();
+    }
+    if (prm.klib_sequence_matching && n)
+    {
+        check(ctx, pg_graphs_build_klib_index(ctx, G, path_off.data(), path_node_off.data(), path_nodes.data()), "pg_graphs_build_klib_index");
+        check(ctx, pg_batch_klib_align(ctx, guard.b, keep), "pg_batch_klib_align");
+        hand_over();
+        uint32_t overflow = 0;
+        check(ctx, pg_graphs_klib_error(ctx, G, &overflow), "pg_graphs_klib_error");
+        if (overflow)
+            throw std::runtime_error("klib stage: CIGAR buffer overflow on the device");
+    }
+    if (keep)  // (the extension flag is ignored when flags == PG_AF_ALL)
+        align_flags = (align_flags & (PG_AF_CIGAR | PG_AF_BOTH_STRANDS | PG_AF_REVERSE_GRAPH)) | PG_AF_KEEP_RESULTS;
     check(ctx, pg_batch_align(ctx, guard.b, align_flags), "pg_batch_align");
     check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
     mark("align + count");
@@ -931,8 +979,8 @@ void SiteBatcher::Impl::Run::resultsToReads()
                 read.set_is_graph_alignment_unique(res[i].is_unique != 0);
                 read.set_graph_mapq(res[i].mapq);
             }
-            else
-                applyResult(read, res[i], ops.data(), true);
+            else  // the k-mer and klib stages replace the bases of a reverse hit but leave the qualities as they are
+                applyResult(read, res[i], ops.data(), true, !(res[i].status & (PG_STATUS_KMER_ALIGNER | PG_STATUS_KLIB_ALIGNER)));
             read.set_graph_mapping_status(sup[i].status == 1 ? Read::MAPPED : Read::BAD_ALIGN);
             read.clear_graph_nodes_supported();
             read.clear_graph_edges_supported();

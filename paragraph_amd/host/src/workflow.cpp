@@ -268,6 +268,8 @@ BatchParameters batchParameters(Parameters const& parameters)
     bp.bad_align_frac = parameters.bad_align_frac;
     bp.kmer_len = parameters.kmer_len;
     bp.path_sequence_matching = parameters.path_sequence_matching;
+    bp.kmer_sequence_matching = parameters.kmer_sequence_matching;
+    bp.klib_sequence_matching = parameters.klib_sequence_matching;
     bp.threads = parameters.threads;
     return bp;
 }
@@ -283,7 +285,7 @@ std::vector<Json> alignAndDisambiguateBatch(Parameters const& parameters, std::v
         if (!sites[s].description || !sites[s].reads)
             throw std::runtime_error("alignAndDisambiguateBatch: site without description or reads");
         reads_in[s] = sites[s].reads->size();
-        batcher.addSite(sites[s].description->graph.get(), sites[s].reads);
+        batcher.addSite(sites[s].description->graph.get(), sites[s].reads, &sites[s].description->paths);
     }
     const double t_batch = now();
     if (!sites.empty())
@@ -319,7 +321,7 @@ std::vector<Json> alignAndDisambiguateBatch(Parameters const& parameters, std::v
     {
         if (!sites[s].description || !sites[s].reads)
             throw std::runtime_error("alignAndDisambiguateBatch: site without description or reads");
-        batcher.addSite(sites[s].description->graph.get(), sites[s].reads);
+        batcher.addSite(sites[s].description->graph.get(), sites[s].reads, &sites[s].description->paths);
     }
     const double t_batch = now();
     if (!sites.empty())
@@ -360,6 +362,8 @@ paragraph::Parameters siteParameters(Parameters const& p)
     sp.bad_align_frac = p.bad_align_frac;
     sp.path_sequence_matching = p.path_sequence_matching;
     sp.graph_sequence_matching = p.graph_sequence_matching;
+    sp.kmer_sequence_matching = p.kmer_sequence_matching;
+    sp.klib_sequence_matching = p.klib_sequence_matching;
     sp.kmer_len = p.bad_align_uniq_kmer_len;
     sp.threads = p.threads;
     sp.timings = p.timings;
@@ -832,6 +836,10 @@ extern "C" int pgw_genotype_graphs(
                     parameters.bad_align_frac = (float)kv.second.asDouble();
                 else if (kv.first == "path_sequence_matching")
                     parameters.path_sequence_matching = kv.second.asBool();
+                else if (kv.first == "kmer_sequence_matching")
+                    parameters.kmer_sequence_matching = kv.second.asBool();
+                else if (kv.first == "klib_sequence_matching")
+                    parameters.klib_sequence_matching = kv.second.asBool();
                 else if (kv.first == "bad_align_uniq_kmer_len")
                     parameters.bad_align_uniq_kmer_len = (int)kv.second.asInt64();
                 else if (kv.first == "packed_reads")

@@ -4,6 +4,7 @@
 //   DisambiguationTest         src/c++/test/test_disambiguation.cpp:44-105
 // Exit code 0 = all checks passed.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -17,6 +18,7 @@
 #include "grm/GraphAligner.hh"
 #include "genotyping/GraphBreakpointGenotyper.hh"
 #include "paragraph/SiteBatcher.hh"
+#include "paragraph/Statistics.hh"
 
 using namespace common;
 using namespace grm;
@@ -531,12 +533,132 @@ static void testSiteToGenotype()
     }
 }
 
+// the whole cascade (path -> k-mer -> klib -> gssw, filters between the stages) batched on the device == the per-read
+// cascade of CompositeAligner with the NonUniq + BadAlign chain as its filter
+static void testSiteBatcherFullCascade()
+{
+    std::mt19937_64 rng(17);
+    auto rnd = [&](size_t n) {
+        std::string s(n, 'A');
+        for (auto& c : s)
+            c = "ACGT"[rng() % 4];
+        return s;
+    };
+    Graph g(4, false);
+    const std::string seqs[4] = { rnd(150), rnd(60), rnd(35), rnd(150) };
+    const char* names[4] = { "LF", "REF", "ALT", "RF" };
+    for (NodeId n = 0; n < 4; ++n)
+    {
+        g.setNodeName(n, names[n]);
+        g.setNodeSeq(n, seqs[n]);
+    }
+    g.addEdge(0, 1);
+    g.addEdge(0, 2);
+    g.addEdge(1, 3);
+    g.addEdge(2, 3);
+    g.addLabelToEdge(0, 1, "REF");
+    g.addLabelToEdge(1, 3, "REF");
+    g.addLabelToEdge(0, 2, "ALT");
+    g.addLabelToEdge(2, 3, "ALT");
+    std::list<Path> paths;
+    for (NodeId mid : { 1u, 2u })
+    {
+        Path p;
+        p.graph = &g;
+        p.nodes = { 0, mid, 3 };
+        p.start_position = 0;
+        p.end_position = (int32_t)seqs[3].size() - 1;
+        paths.push_back(p);
+    }
+    const std::string hap[2] = { seqs[0] + seqs[1] + seqs[3], seqs[0] + seqs[2] + seqs[3] };
+    std::vector<p_Read> a, b;
+    for (int i = 0; i < 160; ++i)
+    {
+        const std::string& h = hap[i & 1];
+        std::string r = h.substr(rng() % (h.size() - 100), 100);
+        switch (i % 5)
+        {
+        case 1:  // one substitution: k-mer stage
+            r[10 + rng() % 80] = "ACGT"[rng() % 4];
+            break;
+        case 2:  // a small deletion or insertion: klib stage
+            if (rng() & 1)
+                r.erase(30 + rng() % 40, 1 + rng() % 3);
+            else
+                r.insert(30 + rng() % 40, rnd(1 + rng() % 3));
+            break;
+        case 3:  // noisy: a substitution every ~12 bases
+            for (size_t k = rng() % 12; k < r.size(); k += 8 + rng() % 8)
+                r[k] = "ACGT"[rng() % 4];
+            break;
+        case 4:  // half of the read is foreign: clipped, BadAlign rejects it whatever stage finds it
+            r = r.substr(0, 45) + rnd(55);
+            break;
+        default: break;  // exact: path stage
+        }
+        if (i % 3 == 0)
+            r = revComp(r);
+        a.emplace_back(new Read("f" + std::to_string(i), r, std::string(r.size(), '#')));
+        b.emplace_back(new Read("f" + std::to_string(i), r, std::string(r.size(), '#')));
+    }
+    paragraph::SiteBatcher batcher;
+    batcher.addSite(&g, &a, &paths);
+    paragraph::BatchParameters prm;
+    prm.path_sequence_matching = true;
+    prm.kmer_sequence_matching = true;
+    prm.klib_sequence_matching = true;
+    batcher.run(prm);
+
+    CompositeAligner comp(true, true, true, true);
+    comp.setGraph(&g, paths);
+    std::vector<Read*> ptrs;
+    for (auto& r : b)
+        ptrs.push_back(r.get());
+    comp.alignReads(ptrs, [&](Read& read) {  // createReadFilter(graph, nonuniq = true, 0.8, kmer_len = 0)
+        if (!read.is_graph_alignment_unique())
+            return true;
+        size_t clipped = 0, query = 0;
+        for (auto const& piece : paragraph::decodeGraphCigar(read.graph_cigar(), g))
+        {
+            clipped += piece.clipped;
+            query += piece.queryLength();
+        }
+        return (double)(query - clipped) < std::round(0.8 * (double)query);
+    });
+    EXPECT_TRUE(comp.mappedPath() > 10u);
+    EXPECT_TRUE(comp.mappedKmers() > 10u);
+    EXPECT_TRUE(comp.mappedKlib() > 5u);
+    EXPECT_TRUE(comp.filtered() > 5u);  // the half-foreign reads: rejected after klib, again after gssw (klib maps the rest)
+    // the batcher keeps the MAPPED reads, in input order
+    size_t k = 0;
+    for (auto& r : b)
+    {
+        if (r->graph_mapping_status() != Read::MAPPED)
+            continue;
+        EXPECT_TRUE(k < a.size());
+        if (k >= a.size())
+            break;
+        EXPECT_EQ(a[k]->fragment_id(), r->fragment_id());
+        EXPECT_EQ(a[k]->graph_cigar(), r->graph_cigar());
+        EXPECT_EQ(a[k]->graph_pos(), r->graph_pos());
+        EXPECT_EQ(a[k]->graph_mapq(), r->graph_mapq());
+        EXPECT_EQ(a[k]->graph_alignment_score(), r->graph_alignment_score());
+        EXPECT_EQ(a[k]->is_graph_reverse_strand(), r->is_graph_reverse_strand());
+        EXPECT_EQ(a[k]->bases(), r->bases());
+        EXPECT_EQ(a[k]->quals(), r->quals());
+        ++k;
+    }
+    EXPECT_EQ(k, a.size());
+    EXPECT_EQ((uint64_t)(b.size() - k), batcher.counts(0).bad_align + batcher.counts(0).nonuniq);
+}
+
 int main()
 {
     try
     {
         testSiteToGenotype();
         testSiteBatcherPathStage();
+        testSiteBatcherFullCascade();
         testKlibAligner();
         testKmerAligner();
         testPathAligner();

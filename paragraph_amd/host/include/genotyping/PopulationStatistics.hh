@@ -16,20 +16,24 @@ class PopulationStatistics
 {
 public:
     explicit PopulationStatistics(GenotypeSet const& genotypes);
-    common::Json toJson() const;  // hwe, hwe_fisher ("" when the exact test does not apply), call_rate, allele_frequencies
+
+    // fraction of samples with a call; per-allele share of all called alleles
+    double getCallrate() const { return (double)n_called_ / n_samples_; }
+    std::vector<double> getAlleleFrequencies() const;
+    std::vector<uint32_t> const& alleleCounts() const { return allele_count_; }
+    // Hardy-Weinberg: the chi-square p-value always; the exact one where needFisherExactHWE() says it is called for
     double getChisqPvalue() const;
     bool needFisherExactHWE() const;
     double getFisherExactPvalue() const;
-    double getCallrate() const { return (double)num_valid_samples / num_total_samples; }
-    std::vector<double> getAlleleFrequencies() const;
-    std::vector<uint32_t> const& alleleCounts() const { return allele_counts; }
+    // { "hwe", "hwe_fisher" ("" when the exact test does not apply), "call_rate", "allele_frequencies" }
+    common::Json toJson() const;
 
 private:
     // index of the rarest allele; when some allele has count 0 the scan starts from the commonest one and takes the LAST
     // strictly smaller entry it meets, zeros included (kept as in the original)
     size_t minNonZeroAlleleIndex() const;
-    int num_total_samples = 0, num_valid_samples = 0;
-    std::vector<uint32_t> allele_counts;
-    std::map<GenotypeVector, int> genotype_counts;
+    int n_samples_ = 0, n_called_ = 0;
+    std::vector<uint32_t> allele_count_;
+    std::map<GenotypeVector, int> genotype_count_;
 };
 }  // namespace genotyping

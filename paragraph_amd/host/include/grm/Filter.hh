@@ -1,4 +1,5 @@
-// Read filter callback: returns true when the alignment should be rejected (src/c++/include/grm/Filter.hh:36).
+// The callback a cascade stage asks whether to reject the alignment it just produced: true = reject, the read goes on to
+// the next stage (role of grm::ReadFilter, src/c++/include/grm/Filter.hh:36).
 #pragma once
 #include <functional>
 
@@ -6,5 +7,5 @@
 
 namespace grm
 {
-typedef std::function<bool(common::Read&)> ReadFilter;
+using ReadFilter = std::function<bool(common::Read& aligned_read)>;
 }

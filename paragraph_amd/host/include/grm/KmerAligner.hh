@@ -1,33 +1,28 @@
-// grm::KmerAligner<KMER_LENGTH> over the device library (src/c++/include/grm/KmerAligner.hh): ungapped alignment
-// along the JSON paths seeded by exact k-mers, at most 2 mismatches; a second equally good but different
-// alignment makes the read BAD_ALIGN.
+// k-mer seed stage front end (grm::KmerAligner<KMER_LENGTH>, src/c++/include/grm/KmerAligner.hh): ungapped placement along
+// the JSON paths seeded by exact k-mers, at most 2 mismatches; a second, equally good but different placement makes the
+// read BAD_ALIGN.  The template only fixes k; the work is in the base.
 #pragma once
-#include <list>
 #include <memory>
-#include <vector>
 
-#include "common/Read.hh"
-#include "graphcore/Graph.hh"
+#include "grm/Types.hh"
 
 namespace grm
 {
-class KmerAlignerBase
+class KmerAlignerBase : public StageTally
 {
 public:
-    explicit KmerAlignerBase(unsigned kmer_length);
+    explicit KmerAlignerBase(unsigned kmer_length);  // <= 16
+    KmerAlignerBase(KmerAlignerBase&&) noexcept;
+    KmerAlignerBase& operator=(KmerAlignerBase&&) noexcept;
     virtual ~KmerAlignerBase();
-    KmerAlignerBase(KmerAlignerBase&& rhs) noexcept;
-    KmerAlignerBase& operator=(KmerAlignerBase&& rhs) noexcept;
-    void setGraph(graphtools::Graph const* g, std::list<graphtools::Path> const& paths);
+
+    void setGraph(GraphPtr graph, PathList const& paths);
+    void alignReads(ReadPtrs const& reads);  // one device batch
     void alignRead(common::Read& read);
-    void alignReads(std::vector<common::Read*> const& reads);
-    unsigned attempted() const { return attempted_; }
-    unsigned mapped() const { return mapped_; }
 
 private:
     struct Impl;
     std::unique_ptr<Impl> impl_;
-    unsigned attempted_ = 0, mapped_ = 0;
 };
 
 template <unsigned KMER_LENGTH> class KmerAligner : public KmerAlignerBase

@@ -1,35 +1,31 @@
-// grm::PathAligner over the device library (src/c++/include/grm/PathAligner.hh): exact matching of whole reads
-// along graph paths, anchored on k-mers that occur on exactly one path (k = 32 by default).
+// Exact-match stage front end (grm::PathAligner, src/c++/include/grm/PathAligner.hh): whole reads are matched base for base
+// along graph walks, anchored on k-mers that occur on exactly one walk (k = 32 unless told otherwise).
 #pragma once
-#include <list>
+#include <cstdint>
 #include <memory>
-#include <vector>
 
-#include "common/Read.hh"
-#include "graphcore/Graph.hh"
+#include "grm/Types.hh"
 
 namespace grm
 {
-class PathAligner
+class PathAligner : public StageTally
 {
 public:
     explicit PathAligner(int32_t kmer_size = 32);
+    PathAligner(PathAligner&&) noexcept;
+    PathAligner& operator=(PathAligner&&) noexcept;
     virtual ~PathAligner();
-    PathAligner(PathAligner&& rhs) noexcept;
-    PathAligner& operator=(PathAligner&& rhs) noexcept;
 
-    void setGraph(graphtools::Graph const* g, std::list<graphtools::Path> const& paths);
-    // Sets the graph_* fields and MAPPED status when the read matches a path end to end (PathAligner.cpp:75-164)
+    // the JSON paths are accepted for interface parity; the index is built from the graph itself
+    void setGraph(GraphPtr graph, PathList const& paths);
+    // a read that matches a walk end to end gets its graph_* fields and MAPPED (PathAligner.cpp:75-164); others are untouched
+    void alignReads(ReadPtrs const& reads);
     void alignRead(common::Read& read);
-    void alignReads(std::vector<common::Read*> const& reads);
-
-    unsigned attempted() const { return attempted_; }
-    unsigned mapped() const { return mapped_; }
-    unsigned anchored() const { return anchored_; }
+    unsigned anchored() const { return anchored_; }  // reads with at least one unique k-mer hit
 
 private:
     struct Impl;
     std::unique_ptr<Impl> impl_;
-    unsigned attempted_ = 0, mapped_ = 0, anchored_ = 0;
+    unsigned anchored_ = 0;
 };
 }  // namespace grm

@@ -729,19 +729,19 @@ void GraphBreakpointGenotyper::runGenotyping()
     }
 }
 // --------------------------------------------------------------------------------------------------- PopulationStatistics
-PopulationStatistics::PopulationStatistics(GenotypeSet const& genotypes) : num_total_samples((int)genotypes.size())
+PopulationStatistics::PopulationStatistics(GenotypeSet const& genotypes) : n_samples_((int)genotypes.size())
 {
     for (Genotype const& g : genotypes)
     {
         if (g.gt.empty())
             continue;
-        ++num_valid_samples;
-        ++genotype_counts[g.gt];
+        ++n_called_;
+        ++genotype_count_[g.gt];
         for (uint64_t allele : g.gt)
         {
-            if (allele_counts.size() <= allele)
-                allele_counts.resize(allele + 1, 0);
-            ++allele_counts[allele];
+            if (allele_count_.size() <= allele)
+                allele_count_.resize(allele + 1, 0);
+            ++allele_count_[allele];
         }
     }
 }
@@ -763,16 +763,16 @@ common::Json PopulationStatistics::toJson() const
 
 double PopulationStatistics::getChisqPvalue() const
 {
-    const double n = num_valid_samples;
+    const double n = n_called_;
     double chisq = 0;
-    for (auto const& gc : genotype_counts)
+    for (auto const& gc : genotype_count_)
     {
         if (gc.first.size() != 2)
             continue;
         const uint64_t h1 = gc.first[0], h2 = gc.first[1];
-        if (allele_counts[h1] == 0 || allele_counts[h2] == 0)
+        if (allele_count_[h1] == 0 || allele_count_[h2] == 0)
             continue;
-        const double f1 = (double)allele_counts[h1] / n / 2, f2 = (double)allele_counts[h2] / n / 2;
+        const double f1 = (double)allele_count_[h1] / n / 2, f2 = (double)allele_count_[h2] / n / 2;
         const double expected = h1 == h2 ? f1 * f1 * n : 2 * f1 * f2 * n;
         const double diff = expected - gc.second;
         chisq += diff * diff / expected;
@@ -783,40 +783,40 @@ double PopulationStatistics::getChisqPvalue() const
 
 bool PopulationStatistics::needFisherExactHWE() const
 {
-    const auto observed = std::count_if(allele_counts.begin(), allele_counts.end(), [](uint32_t a) { return a > 0; });
+    const auto observed = std::count_if(allele_count_.begin(), allele_count_.end(), [](uint32_t a) { return a > 0; });
     if (observed != 2)
         return false;
-    if (num_valid_samples <= 30)
+    if (n_called_ <= 30)
         return true;
-    for (auto const& gc : genotype_counts)
+    for (auto const& gc : genotype_count_)
         if (gc.second > 0 && gc.second <= 20)
             return true;
-    const double maf = (double)allele_counts[minNonZeroAlleleIndex()] / 2 / num_valid_samples;
-    return maf * maf * num_valid_samples <= 20;
+    const double maf = (double)allele_count_[minNonZeroAlleleIndex()] / 2 / n_called_;
+    return maf * maf * n_called_ <= 20;
 }
 
 double PopulationStatistics::getFisherExactPvalue() const
 {
     const size_t minor = minNonZeroAlleleIndex();
-    const auto major_it = std::max_element(allele_counts.begin(), allele_counts.end());
-    const int minor_count = (int)allele_counts[minor], major_count = (int)*major_it;
-    GenotypeVector het = { (uint64_t)(major_it - allele_counts.begin()), (uint64_t)minor };
+    const auto major_it = std::max_element(allele_count_.begin(), allele_count_.end());
+    const int minor_count = (int)allele_count_[minor], major_count = (int)*major_it;
+    GenotypeVector het = { (uint64_t)(major_it - allele_count_.begin()), (uint64_t)minor };
     std::sort(het.begin(), het.end());
     int observed_het = 0;
-    for (auto const& gc : genotype_counts)
+    for (auto const& gc : genotype_count_)
         if (gc.first.size() == 2 && gc.first[0] == het[0] && gc.first[1] == het[1])
         {
             observed_het = gc.second;
             break;
         }
-    const double n = num_valid_samples;
+    const double n = n_called_;
     const int expected_het = (int)std::round(2 * ((double)minor_count / n / 2) * ((double)major_count / n / 2) * n);
 
     // probabilities of every heterozygote count with the parity of the expectation, relative to the expectation's own;
     // walked upwards, then downwards, by the recurrence of the exact test
     vector<double> scaled = { 1 };
     double observed_scaled = -1;
-    int rare_hom = (minor_count - expected_het) / 2, common_hom = num_valid_samples - rare_hom - expected_het;
+    int rare_hom = (minor_count - expected_het) / 2, common_hom = n_called_ - rare_hom - expected_het;
     double prev = 1;
     for (int hets = expected_het + 2; hets <= minor_count; hets += 2)
     {
@@ -829,7 +829,7 @@ double PopulationStatistics::getFisherExactPvalue() const
             observed_scaled = prev;
     }
     rare_hom = (minor_count - expected_het) / 2;
-    common_hom = num_valid_samples - rare_hom - expected_het;
+    common_hom = n_called_ - rare_hom - expected_het;
     prev = 1;
     for (int hets = expected_het - 2; hets >= 0; hets -= 2)
     {
@@ -850,24 +850,24 @@ double PopulationStatistics::getFisherExactPvalue() const
 
 vector<double> PopulationStatistics::getAlleleFrequencies() const
 {
-    const uint32_t sum = std::accumulate(allele_counts.begin(), allele_counts.end(), (uint32_t)0);
+    const uint32_t sum = std::accumulate(allele_count_.begin(), allele_count_.end(), (uint32_t)0);
     vector<double> out;
-    for (uint32_t ac : allele_counts)
+    for (uint32_t ac : allele_count_)
         out.push_back(sum > 0 ? (double)ac / sum : 0.0);
     return out;
 }
 
 size_t PopulationStatistics::minNonZeroAlleleIndex() const
 {
-    auto pick = std::min_element(allele_counts.begin(), allele_counts.end());
+    auto pick = std::min_element(allele_count_.begin(), allele_count_.end());
     if (*pick > 0)
-        return (size_t)(pick - allele_counts.begin());
-    pick = std::max_element(allele_counts.begin(), allele_counts.end());
+        return (size_t)(pick - allele_count_.begin());
+    pick = std::max_element(allele_count_.begin(), allele_count_.end());
     if (*pick == 0)
         return 0;
-    for (auto it = allele_counts.begin(); it != allele_counts.end(); ++it)
+    for (auto it = allele_count_.begin(); it != allele_count_.end(); ++it)
         if (*it < *pick)
             pick = it;
-    return (size_t)(pick - allele_counts.begin());
+    return (size_t)(pick - allele_count_.begin());
 }
 }  // namespace genotyping

@@ -507,11 +507,11 @@ void toRead(BamRecord const& rec, Read& read)
     read.set_fragment_id(rec.name);
     read.set_bases(rec.bases);
     read.set_quals(rec.quals);
-    read.set_is_mapped((rec.flag & BamReader::kIsMapped) == 0);
-    read.set_is_first_mate((rec.flag & BamReader::kIsFirstMate) != 0);
-    read.set_is_mate_mapped((rec.flag & BamReader::kIsMateMapped) == 0);
-    read.set_is_reverse_strand((rec.flag & 0x10) != 0);
-    read.set_is_mate_reverse_strand((rec.flag & 0x20) != 0);
+    read.set_is_mapped((rec.flag & samflag::kUnmapped) == 0);
+    read.set_is_first_mate((rec.flag & samflag::kFirstInPair) != 0);
+    read.set_is_mate_mapped((rec.flag & samflag::kMateUnmapped) == 0);
+    read.set_is_reverse_strand((rec.flag & samflag::kReverse) != 0);
+    read.set_is_mate_reverse_strand((rec.flag & samflag::kMateReverse) != 0);
     read.set_chrom_id(rec.tid);
     read.set_pos(rec.pos);
     read.set_mapq(rec.mapq);
@@ -859,7 +859,7 @@ bool BamReader::getAlign(Read& read)
     BamRecord rec;
     while (impl_->next(impl_->cursor, rec))
     {
-        if (rec.flag & (kSupplementaryAlign | kSecondaryAlign))
+        if (rec.flag & (samflag::kSupplementary | samflag::kSecondary))
             continue;
         impl_->decodeText(rec);
         toRead(rec, read);

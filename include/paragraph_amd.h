@@ -40,10 +40,10 @@
  *
  * Threading: one pg_ctx per device; calls on one ctx must be serialised by the caller (same rule
  * as one CompositeAligner instance per worker in the reference, Align.cpp:107-110).  Exception:
- * pg_graphs_upload and pg_graphs_set_labels only build a new graph set (host work + copy stream) and
- * may run while another thread is inside a pg_batch_* call on the same ctx -- a graph set can be
- * prepared for the next batch while the current one is on the device.  pg_last_error is then
- * whichever call failed last.
+ * pg_graphs_upload, pg_graphs_set_labels and the pg_graphs_build_*_index calls only build up a new
+ * graph set (host work + copy stream) and may run while another thread is inside a pg_batch_* call
+ * on the same ctx with OTHER graph sets -- a graph set can be prepared for the next batch while the
+ * current one is on the device.  pg_last_error is then whichever call failed last.
  * Scoring is fixed as in the reference: match +1, mismatch -4, gap open 6, gap extend 1,
  * N / non-ACGTU = 0 (GraphAligner.cpp:229-233, gssw.c:4188-4220).
  */

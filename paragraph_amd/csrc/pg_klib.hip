@@ -864,14 +864,14 @@ extern "C" pg_status pg_graphs_build_klib_index(
     pg_klib_index* ix = new pg_klib_index();
     ix->max_paths = max_paths;
     ix->max_path_len = max_len;
-    hipError_t e = upl(gd, &ix->d_graphs, ctx->stream);
-    if (e == hipSuccess) e = upl(pd, &ix->d_paths, ctx->stream);
-    if (e == hipSuccess) e = upl(pathseq, &ix->d_pathseq, ctx->stream);
-    if (e == hipSuccess) e = upl(pathcode, &ix->d_pathcode, ctx->stream);
-    if (e == hipSuccess) e = upl(starts, &ix->d_starts, ctx->stream);
+    hipError_t e = upl(gd, &ix->d_graphs, ctx->stream_copy);
+    if (e == hipSuccess) e = upl(pd, &ix->d_paths, ctx->stream_copy);
+    if (e == hipSuccess) e = upl(pathseq, &ix->d_pathseq, ctx->stream_copy);
+    if (e == hipSuccess) e = upl(pathcode, &ix->d_pathcode, ctx->stream_copy);
+    if (e == hipSuccess) e = upl(starts, &ix->d_starts, ctx->stream_copy);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->d_error, sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemsetAsync(ix->d_error, 0, sizeof(uint32_t), ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ix->d_error, 0, sizeof(uint32_t), ctx->stream_copy);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream_copy);
     if (e != hipSuccess)
     {
         pg_klib_index_free(ix);

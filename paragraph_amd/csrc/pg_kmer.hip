@@ -601,13 +601,13 @@ extern "C" pg_status pg_graphs_build_kmer_index(
     ix->k = kmer_len;
     ix->max_path_len = max_len;
     ix->max_path_kmers = max_kmers;
-    hipError_t e = upk(gd, &ix->d_graphs, ctx->stream);
-    if (e == hipSuccess) e = upk(pd, &ix->d_paths, ctx->stream);
-    if (e == hipSuccess) e = upk(pathseq, &ix->d_pathseq, ctx->stream);
-    if (e == hipSuccess) e = upk(starts, &ix->d_starts, ctx->stream);
-    if (e == hipSuccess) e = upk(kmers, &ix->d_kmers, ctx->stream);
-    if (e == hipSuccess) e = upk(kpos, &ix->d_kpos, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = upk(gd, &ix->d_graphs, ctx->stream_copy);
+    if (e == hipSuccess) e = upk(pd, &ix->d_paths, ctx->stream_copy);
+    if (e == hipSuccess) e = upk(pathseq, &ix->d_pathseq, ctx->stream_copy);
+    if (e == hipSuccess) e = upk(starts, &ix->d_starts, ctx->stream_copy);
+    if (e == hipSuccess) e = upk(kmers, &ix->d_kmers, ctx->stream_copy);
+    if (e == hipSuccess) e = upk(kpos, &ix->d_kpos, ctx->stream_copy);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream_copy);
     if (e != hipSuccess)
     {
         pg_kmer_index_free(ix);

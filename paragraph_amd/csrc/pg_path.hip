@@ -563,15 +563,15 @@ pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32
         ix->pow_k1 *= HASH_B;
     std::vector<uint32_t> node_off(noff.begin(), noff.end());
     std::vector<char> rawv(raw.begin(), raw.end());
-    hipError_t e = up(gd, &ix->d_graphs, ctx->stream);
-    if (e == hipSuccess) e = up(table, &ix->d_table, ctx->stream);
-    if (e == hipSuccess) e = up(pool, &ix->d_pool, ctx->stream);
-    if (e == hipSuccess) e = up(node_off, &ix->d_node_off, ctx->stream);
-    if (e == hipSuccess) e = up(rawv, &ix->d_raw, ctx->stream);
-    if (e == hipSuccess) e = up(succ_off, &ix->d_succ_off, ctx->stream);
-    if (e == hipSuccess) e = up(succ, &ix->d_succ, ctx->stream);
-    if (e == hipSuccess) e = up(node_uniq, &ix->d_node_uniq, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = up(gd, &ix->d_graphs, ctx->stream_copy);
+    if (e == hipSuccess) e = up(table, &ix->d_table, ctx->stream_copy);
+    if (e == hipSuccess) e = up(pool, &ix->d_pool, ctx->stream_copy);
+    if (e == hipSuccess) e = up(node_off, &ix->d_node_off, ctx->stream_copy);
+    if (e == hipSuccess) e = up(rawv, &ix->d_raw, ctx->stream_copy);
+    if (e == hipSuccess) e = up(succ_off, &ix->d_succ_off, ctx->stream_copy);
+    if (e == hipSuccess) e = up(succ, &ix->d_succ, ctx->stream_copy);
+    if (e == hipSuccess) e = up(node_uniq, &ix->d_node_uniq, ctx->stream_copy);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream_copy);
     if (e != hipSuccess)
     {
         pg_path_index_free(ix);
@@ -598,9 +598,9 @@ extern "C" pg_status pg_graphs_build_path_index(pg_ctx* ctx, pg_graphs* G, uint3
     // the extension walks predecessors too: reuse / create the caller-indexed predecessor tables
     if (!G->d_cnt_pred_off)
     {
-        HIP_TRY(ctx, up(G->h_pred_off, &G->d_cnt_pred_off, ctx->stream));
-        HIP_TRY(ctx, up(G->h_pred, &G->d_cnt_pred, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, up(G->h_pred_off, &G->d_cnt_pred_off, ctx->stream_copy));
+        HIP_TRY(ctx, up(G->h_pred, &G->d_cnt_pred, ctx->stream_copy));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
     }
     return PG_OK;
 }

@@ -852,6 +852,33 @@ void SiteBatcher::Impl::Run::deviceSection()
     } guard{ ctx, G, nullptr };
     check(ctx, pg_graphs_set_labels(ctx, G, csr.label_mask.empty() ? nullptr : csr.label_mask.data(), csr.n_labels.data()),
           "pg_graphs_set_labels");
+    // ... and so are the per-graph indexes of the optional stages and of the KmerFilter
+    std::vector<uint32_t> path_off{ 0 }, path_node_off{ 0 }, path_nodes;
+    if ((prm.kmer_sequence_matching || prm.klib_sequence_matching) && n)
+    {
+        for (size_t s = 0; s < n_sites; ++s)
+        {
+            if (!impl.paths[s])
+                throw std::logic_error("SiteBatcher: the k-mer and klib stages need the paths of every site");
+            for (auto const& p : *impl.paths[s])
+            {
+                path_nodes.insert(path_nodes.end(), p.nodes.begin(), p.nodes.end());
+                path_node_off.push_back((uint32_t)path_nodes.size());
+            }
+            path_off.push_back((uint32_t)path_node_off.size() - 1);
+        }
+        if (path_nodes.empty())
+            path_nodes.push_back(0);
+    }
+    if (prm.path_sequence_matching && n)
+        check(ctx, pg_graphs_build_path_index(ctx, G, 32), "pg_graphs_build_path_index");
+    if (prm.kmer_sequence_matching && n)
+        check(ctx, pg_graphs_build_kmer_index(ctx, G, 16, path_off.data(), path_node_off.data(), path_nodes.data()),
+              "pg_graphs_build_kmer_index");
+    if (prm.klib_sequence_matching && n)
+        check(ctx, pg_graphs_build_klib_index(ctx, G, path_off.data(), path_node_off.data(), path_nodes.data()), "pg_graphs_build_klib_index");
+    if (prm.kmer_len != 0)  // createReadFilter(graph, nonuniq, frac, kmer_len): NonUniq -> BadAlign -> KmerFilter (ReadFilter.cpp:74-90)
+        check(ctx, pg_graphs_build_filter_index(ctx, G, prm.kmer_len, nullptr), "pg_graphs_build_filter_index");
     mark("graphs up");
     lock.lock();
     mark("wait for device");
@@ -865,9 +892,7 @@ void SiteBatcher::Impl::Run::deviceSection()
     cp.bad_align_frac = prm.bad_align_frac;
     if (prm.kmer_len != 0)
     {
-        // createReadFilter(graph, nonuniq, frac, kmer_len): NonUniq -> BadAlign -> KmerFilter (ReadFilter.cpp:74-90)
-        check(ctx, pg_graphs_build_filter_index(ctx, G, prm.kmer_len, nullptr), "pg_graphs_build_filter_index");
-        cp.use_kmer_filter = 1;
+        cp.use_kmer_filter = 1;  // the index was built above
     }
     uint32_t align_flags = prm.alignment_flags;
     // Seed stages of the cascade (CompositeAligner.cpp:78-150).  After each one the filter chain runs on the device (count
@@ -891,39 +916,18 @@ void SiteBatcher::Impl::Run::deviceSection()
         check(ctx, pg_batch_set_active(ctx, guard.b, active.data()), "pg_batch_set_active");
         keep = PG_AF_KEEP_RESULTS;
     };
-    std::vector<uint32_t> path_off{ 0 }, path_node_off{ 0 }, path_nodes;
-    if ((prm.kmer_sequence_matching || prm.klib_sequence_matching) && n)
-    {
-        for (size_t s = 0; s < n_sites; ++s)
-        {
-            if (!impl.paths[s])
-                throw std::logic_error("SiteBatcher: the k-mer and klib stages need the paths of every site");
-            for (auto const& p : *impl.paths[s])
-            {
-                path_nodes.insert(path_nodes.end(), p.nodes.begin(), p.nodes.end());
-                path_node_off.push_back((uint32_t)path_nodes.size());
-            }
-            path_off.push_back((uint32_t)path_node_off.size() - 1);
-        }
-        if (path_nodes.empty())
-            path_nodes.push_back(0);
-    }
     if (prm.path_sequence_matching && n)
     {
-        check(ctx, pg_graphs_build_path_index(ctx, G, 32), "pg_graphs_build_path_index");
         check(ctx, pg_batch_path_align(ctx, guard.b), "pg_batch_path_align");
         hand_over();
     }
     if (prm.kmer_sequence_matching && n)
     {
-        check(ctx, pg_graphs_build_kmer_index(ctx, G, 16, path_off.data(), path_node_off.data(), path_nodes.data()),
-              "pg_graphs_build_kmer_index");
         check(ctx, pg_batch_kmer_align(ctx, guard.b, keep), "pg_batch_kmer_align");
         hand_over();
     }
     if (prm.klib_sequence_matching && n)
     {
-        check(ctx, pg_graphs_build_klib_index(ctx, G, path_off.data(), path_node_off.data(), path_nodes.data()), "pg_graphs_build_klib_index");
         check(ctx, pg_batch_klib_align(ctx, guard.b, keep), "pg_batch_klib_align");
         hand_over();
         uint32_t overflow = 0;

@@ -130,3 +130,43 @@ def test_bam_reader_on_synthetic_multiblock_bam(hostio, tmp_path):
         assert [g[0] for g in got] == [w["name"] for w in want], region
         for g, w in zip(got, want):
             assert g[2] == str(w["pos"]) and g[7] == w["seq"] and g[8] == w["qual"]
+
+
+def _reference_bams():
+    root = "/root/reference/share/test-data"
+    found = []
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith(".bam") and (os.path.exists(os.path.join(dp, f + ".bai")) or os.path.exists(os.path.join(dp, f[:-4] + ".bai"))):
+                found.append(os.path.join(dp, f))
+    return sorted(found)
+
+
+@pytest.mark.parametrize("bam", _reference_bams() or [None])
+def test_bam_reader_on_the_reference_test_bams(hostio, bam):
+    """Every indexed BAM of the reference's test data (samtools-written: records span BGZF blocks, many contigs, real
+    indexes), read through the index contig by contig and in windows, against the independent decoder.  Runs only where
+    /root/reference is mounted (the build container)."""
+    if bam is None:
+        pytest.skip("/root/reference is not mounted here")
+    names, recs = decode_bam(bam)
+    primary = [r for r in recs if not r["flag"] & 0x900]
+    by_tid = {}
+    for r in primary:
+        by_tid.setdefault(r["tid"], []).append(r)
+    checked = 0
+    for tid, rs in sorted(by_tid.items()):
+        if tid < 0:
+            continue
+        got = dump(hostio, bam, names[tid])
+        assert [(g[0], g[2], g[7]) for g in got] == [(w["name"], str(w["pos"]), w["seq"]) for w in rs], (bam, names[tid])
+        checked += len(got)
+        # a few windows inside the covered span
+        lo, hi = rs[0]["pos"], rs[-1]["pos"]
+        for k in range(4):
+            beg = lo + (hi - lo) * k // 4
+            end = beg + 700
+            want = [w for w in rs if w["pos"] < end and w["end"] > beg]
+            got = dump(hostio, bam, "%s:%d-%d" % (names[tid], beg + 1, end))
+            assert [(g[0], g[2]) for g in got] == [(w["name"], str(w["pos"])) for w in want], (bam, names[tid], beg, end)
+    assert checked == len([r for r in primary if r["tid"] >= 0])

@@ -192,7 +192,7 @@ pg_status pg_align_batch(
  * ------------------------------------------------------------------------------------------------- */
 typedef struct pg_count_params
 {
-    uint32_t remove_nonuniq;      /* paragraph --bad-align-nonuniq (default 1); grmpy has no such filter (0) */
+    uint32_t remove_nonuniq;      /* paragraph --bad-align-nonuniq (default 1; grmpy keeps that default, Parameters.hh:141) */
     uint32_t use_support_filters; /* 1: production nodefilter/edgefilter (Disambiguation.cpp:212-296); 0: none
                                      (what the reference's unit tests call disambiguateReads with) */
     double bad_align_frac;        /* --bad-align-frac, default 0.8 */

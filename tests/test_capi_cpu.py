@@ -96,3 +96,45 @@ def test_workflow_entry_exported_and_fails_loudly(tmp_path):
         pass
     with pytest.raises(RuntimeError, match="pg_ctx_create"):
         workflow.genotype_graphs(fasta, str(manifest), [graph], threads=2)
+
+
+def test_grmpy_command_line_parsing(tmp_path):
+    """paragraph_amd/bin/grmpy keeps the reference's option names (src/c++/main/grmpy.cpp:60-200): what can be checked
+    without a device -- usage, missing / unknown options, bool parsing, response files -- and that a complete command
+    line fails at the device here instead of computing on the CPU."""
+    import subprocess
+    from paragraph_amd import build
+    build.build_host()
+    exe = build.GRMPY_BIN
+    sites = os.path.join(ROOT, "tests", "golden", "sites", "chrX")
+    fasta, graph = os.path.join(sites, "chrX_graph_typing.fa"), os.path.join(sites, "chrX_graph_typing.2sample.json")
+
+    def run(*args):
+        r = subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=120)
+        return r.returncode, r.stdout + r.stderr
+
+    rc, out = run("--help")
+    assert rc == 0 and "grmpy -r <reference> -g <graphs> -m <manifest>" in out
+    assert run("-g", graph, "-m", "x") == (1, "Reference genome is missing.\n")
+    assert run("-r", fasta, "-m", "x") == (1, "Graph spec is missing.\n")
+    assert run("-r", fasta, "-g", graph) == (1, "Manifest file is missing.\n")
+    rc, out = run("-r", fasta, "-g", graph, "-m", "x", "--colour", "red")
+    assert rc == 1 and "unrecognised option '--colour'" in out
+    rc, out = run("-r", fasta, "-g", graph, "-m", "x", "--path-sequence-matching", "maybe")
+    assert rc == 1 and "is invalid" in out
+    rc, out = run("-r", fasta, "-g", graph, "-m", "x", "-A", "dir")
+    assert rc == 1 and "not available" in out
+    manifest = tmp_path / "manifest with space.txt"
+    manifest.write_text("id\tpath\tdepth\tread length\nS1\t%s\t44.2\t150\n" % os.path.join(sites, "chrX_graph_typing.bam"))
+    response = tmp_path / "response.txt"
+    # the way multigrmpy.py writes it: one line of options, then the graphs one per line (multigrmpy.py:262-306)
+    response.write_text(" -r %s -m '%s' -o %s -z -t 2 --graph-sequence-matching True --log-level=warning --log-file %s --log-async no -g\n%s\n%s"
+                        % (fasta, manifest, tmp_path / "out.json.gz", tmp_path / "log.txt", graph, graph))
+    rc, out = run("--response-file=%s" % response)
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except ImportError:
+        has_gpu = False
+    if not has_gpu:
+        assert rc == 1 and "pg_ctx_create" in out  # parsed everything, loaded graphs and manifest, then needed the device

@@ -42,3 +42,94 @@ def test_python_entry_genotypes_single_swap(tmp_path):
     again = workflow.genotype_graphs(os.path.join(sites, "chrX_graph_typing.fa"), str(manifest), [graph],
                                      genotyping_parameters=os.path.join(sites, "param.json"), packed_reads=False)
     assert again[0] == docs[0]
+
+
+def test_grmpy_binary_as_multigrmpy_calls_it(tmp_path):
+    """paragraph_amd/bin/grmpy driven the way src/python/bin/multigrmpy.py:262-315 drives the reference's binary: options in
+    a response file, graphs one per line after -g, gzip-compressed JSON array out; and -O with one file per graph."""
+    import gzip
+    import json
+    from paragraph_amd import build
+    if not os.path.exists(build.GRMPY_BIN):
+        build.build_host()
+    sites = os.path.join(ROOT, "tests", "golden", "sites", "chrX")
+    bam = os.path.join(sites, "chrX_graph_typing.bam")
+    manifest = tmp_path / "manifest.txt"
+    manifest.write_text("#id\tpath\tdepth\tread length\tdepth sd\tsex\nSAMPLE1\t%s\t44.2\t150\t20\tmale\nSAMPLE2\t%s\t44.2\t150\t20\tfemale\n"
+                        % (bam, bam))
+    graph = os.path.join(sites, "chrX_graph_typing.2sample.json")
+    out = tmp_path / "genotypes.json.gz"
+    response = tmp_path / "response.txt"
+    response.write_text(" -r %s -m %s -o %s -z -G %s -M 10000 -t 4 --graph-sequence-matching True --log-level=warning --log-file %s --log-async no -g\n%s\n%s"
+                        % (os.path.join(sites, "chrX_graph_typing.fa"), manifest, out, os.path.join(sites, "param.json"), tmp_path / "grmpy.log",
+                           graph, graph))
+    r = subprocess.run([build.GRMPY_BIN, "--response-file=%s" % response], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    docs = json.loads(gzip.open(out, "rt").read())
+    assert isinstance(docs, list) and len(docs) == 2 and docs[0] == docs[1]
+    assert docs[0]["samples"]["SAMPLE1"]["gt"]["GT"] == "REF" and docs[0]["samples"]["SAMPLE2"]["gt"]["GT"] == "REF/REF"
+    # one graph, stdout, plain: a single document (not an array), as the original writes it
+    r = subprocess.run([build.GRMPY_BIN, "-r", os.path.join(sites, "chrX_graph_typing.fa"), "-m", str(manifest), "-g", graph, "-G",
+                        os.path.join(sites, "param.json")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout) == docs[0]
+    folder = tmp_path / "per_graph"
+    folder.mkdir()
+    r = subprocess.run([build.GRMPY_BIN, "-r", os.path.join(sites, "chrX_graph_typing.fa"), "-m", str(manifest), "-g", graph, "-G",
+                        os.path.join(sites, "param.json"), "-O", str(folder), "-z"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout == "", r.stderr
+    assert json.loads(gzip.open(folder / "chrX_graph_typing.2sample.json.gz", "rt").read()) == docs[0]
+
+
+def test_config1_round_trip_genotyping(tmp_path):
+    """BASELINE configs[0]: share/test-data/round-trip-genotyping (two samples with a handful of 50 bp reads, an insertion and
+    a one-base deletion at chr1:161).  The reference's Python round trip ends in expected-vcf-record.txt; the same GT / DP /
+    AD / PL and the no-call filter come out of graph_templates -> workflow.genotype_graphs for the two records' events."""
+    import json
+    from paragraph_amd import graph_templates, workflow
+    d = os.path.join(ROOT, "tests", "golden", "sites", "round-trip")
+    records = {}
+    for line in open(os.path.join(d, "expected-vcf-record.txt")):
+        f = line.rstrip("\n").split("\t")
+        if line.startswith("#"):
+            names = f[9:]
+            continue
+        keys = f[8].split(":")
+        records[f[2]] = dict(ref=f[3], alt=f[4], pos=int(f[1]), samples={n: dict(zip(keys, v.split(":"))) for n, v in zip(names, f[9:])})
+    assert set(records) == {"test-ins", "test-del"}
+    graphs, alt_label = [], {}
+    for rid, rec in sorted(records.items()):
+        # VCF record -> event: the padding base stays, REF[1:] is deleted / ALT[1:] inserted after it
+        deleted, inserted = rec["ref"][1:], rec["alt"][1:]
+        event = {"chrom": "chr1", "start": rec["pos"] + 1, "end": rec["pos"] + len(deleted)}
+        if inserted:
+            event["ins"] = inserted
+        kind, graph = graph_templates.make_graph(event)
+        alt_label[rid] = "INS" if inserted else "DEL"
+        graph["ID"] = rid
+        path = tmp_path / (rid + ".json")
+        path.write_text(json.dumps(graph))
+        graphs.append(str(path))
+    docs = {doc["graphinfo"]["ID"]: doc for doc in
+            workflow.genotype_graphs(os.path.join(d, "dummy.fa"), os.path.join(d, "samples.txt"), graphs, threads=2)}
+    for rid, rec in records.items():
+        alt = alt_label[rid]
+        for sample, want in rec["samples"].items():
+            got = docs[rid]["samples"][sample]
+            gt = got["gt"]
+            if want["GT"] == ".":
+                assert gt["GT"] == "." and "NO_VALID_GT" in gt["filters"] and "NO_VALID_GT" in want["FT"], (rid, sample, gt)
+                assert int(want["DP"]) == 0 and "num_reads" not in gt
+                continue
+            assert want["GT"] == "1/1" and gt["GT"] == "%s/%s" % (alt, alt), (rid, sample, gt)
+            assert gt["num_reads"] == int(want["DP"])
+            ref_ad, alt_ad = (int(x) for x in want["AD"].split(","))
+            for bp in got["breakpoints"].values():
+                assert bp["counts"]["alleles"]["REF"] == ref_ad and bp["counts"]["alleles"][alt] == alt_ad, (rid, sample, bp["counts"])
+            # PL as vcfupdate.py:284-310 derives it: round(-10 x log10 likelihood) minus the smallest, order REF/REF, REF/ALT, ALT/ALT
+            gl = gt["GL"]
+            order = ["REF/REF", "%s/REF" % alt if "%s/REF" % alt in gl else "REF/%s" % alt, "%s/%s" % (alt, alt)]
+            phred = [round(-10 * gl[k]) for k in order]
+            assert [str(x - min(phred)) for x in phred] == want["PL"].split(","), (rid, sample, gl, want["PL"])
+            if want["FT"] == "PASS":
+                assert gt["filters"] == ["PASS"]

@@ -34,7 +34,8 @@ def build_hip(force=False, verbose=False):
 
 HOST_LIB = os.path.join(_HERE, "libparagraph_host.so")
 HOST_TEST = os.path.join(ROOT, "tests", "host_cpp", "test_host")
-GRMPY_BIN = os.path.join(_HERE, "bin", "grmpy")  # the reference's `grmpy` command line over the batched workflow
+GRMPY_BIN = os.path.join(_HERE, "bin", "grmpy")  # the reference's `grmpy` / `paragraph` command lines over the batched workflow
+PARAGRAPH_BIN = os.path.join(_HERE, "bin", "paragraph")
 
 
 HOST_CPU_SOURCES = ["genotyping.cpp", "json.cpp", "io.cpp", "graphio.cpp"]  # no device calls: also built into the CPU test programs
@@ -62,11 +63,13 @@ def build_host(force=False, verbose=False):
     if force or _stale(HOST_LIB, cpu_src + gpu_src + [LIB] + hdrs):
         _run([cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-I" + inc, "-o", HOST_LIB] + gpu_src + cpu_src
              + ["-L" + _HERE, "-lparagraph_amd", "-lz", "-Wl,-rpath,$ORIGIN"], verbose)
-    grmpy_src = os.path.join(_HERE, "host", "src", "grmpy_main.cpp")
-    if force or _stale(GRMPY_BIN, [grmpy_src, HOST_LIB] + hdrs):
-        os.makedirs(os.path.dirname(GRMPY_BIN), exist_ok=True)
-        _run([cxx, "-std=c++17", "-O2", "-pthread", "-I" + inc, "-o", GRMPY_BIN, grmpy_src, "-L" + _HERE, "-lparagraph_host",
-              "-lparagraph_amd", "-lz", "-Wl,-rpath,$ORIGIN/.."], verbose)
+    cli_hdr = os.path.join(_HERE, "host", "src", "cli_common.hh")
+    for exe, main_src in ((GRMPY_BIN, "grmpy_main.cpp"), (PARAGRAPH_BIN, "paragraph_main.cpp")):
+        main_src = os.path.join(_HERE, "host", "src", main_src)
+        if force or _stale(exe, [main_src, cli_hdr, HOST_LIB] + hdrs):
+            os.makedirs(os.path.dirname(exe), exist_ok=True)
+            _run([cxx, "-std=c++17", "-O2", "-pthread", "-I" + inc, "-o", exe, main_src, "-L" + _HERE, "-lparagraph_host",
+                  "-lparagraph_amd", "-lz", "-Wl,-rpath,$ORIGIN/.."], verbose)
     for name in ("test_host", "test_workflow"):
         tsrc = os.path.join(ROOT, "tests", "host_cpp", name + ".cpp")
         exe = os.path.join(ROOT, "tests", "host_cpp", name)

@@ -95,6 +95,14 @@ struct PackedSiteInput
 std::vector<common::Json> alignAndDisambiguateBatch(Parameters const& parameters, std::vector<SiteInput> const& sites);
 // the same documents (minus "alignments", which this form cannot give) from reads kept in the packed form
 std::vector<common::Json> alignAndDisambiguateBatch(Parameters const& parameters, std::vector<PackedSiteInput> const& sites);
+// The `paragraph` tool's job (lib/paragraph/Workflow.cpp:77-233): every graph against the given BAM(s).  One BAM: one count
+// document per graph with "bam" = its path.  Several BAMs: their reads are pooled per graph ("joint inputs") and "bam" lists
+// them.  All graphs go through the device in batches of `sites_per_batch`; target_regions ("chr:a-b,chr:c-d") overrides the
+// graphs' own.  Documents come back in the order of graph_paths.
+std::vector<common::Json> countGraphs(
+    Parameters const& parameters, std::vector<std::string> const& graph_paths, std::string const& reference_path,
+    std::vector<std::string> const& bam_paths, std::vector<std::string> const& bam_index_paths = {},
+    std::string const& target_regions = "", size_t sites_per_batch = 1024);
 // single-site convenience with the reference's shape
 common::Json alignAndDisambiguate(Parameters const& parameters, GraphDescription const& description, common::ReadBuffer& all_reads);
 }  // namespace paragraph

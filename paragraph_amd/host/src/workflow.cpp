@@ -342,6 +342,83 @@ std::vector<Json> alignAndDisambiguateBatch(Parameters const& parameters, std::v
     return documents;
 }
 
+std::vector<Json> countGraphs(
+    Parameters const& parameters, std::vector<std::string> const& graph_paths, std::string const& reference_path,
+    std::vector<std::string> const& bam_paths, std::vector<std::string> const& bam_index_paths, std::string const& target_regions,
+    size_t sites_per_batch)
+{
+    if (bam_paths.empty())
+        throw std::runtime_error("ERROR: BAM file is missing.");
+    if (!bam_index_paths.empty() && bam_index_paths.size() != bam_paths.size())
+        throw std::runtime_error("ERROR: the number of BAM index files differs from the number of BAM files");
+    auto index_of = [&](size_t b) { return bam_index_paths.empty() ? std::string() : bam_index_paths[b]; };
+    const bool packed = bam_paths.size() == 1 && !parameters.output_enabled(Parameters::ALIGNMENTS);
+    const common::FastaFile fasta(reference_path);
+    std::vector<std::unique_ptr<common::BamReader>> keep_alive;  // also shares the parsed header / index with the workers
+    for (size_t b = 0; b < bam_paths.size(); ++b)
+        keep_alive.emplace_back(new common::BamReader(bam_paths[b], index_of(b), reference_path));
+    Json bam_value = bam_paths.size() == 1 ? Json(bam_paths[0]) : Json::array();
+    if (bam_paths.size() != 1)
+        for (auto const& b : bam_paths)
+            bam_value.append(b);
+
+    std::vector<Json> documents(graph_paths.size());
+    sites_per_batch = std::max<size_t>(1, sites_per_batch);
+    for (size_t g0 = 0; g0 < graph_paths.size(); g0 += sites_per_batch)
+    {
+        const size_t n_here = std::min(sites_per_batch, graph_paths.size() - g0);
+        std::vector<GraphDescription> graphs(n_here);
+        std::vector<PackedSite> packed_reads(packed ? n_here : 0);
+        std::vector<common::ReadBuffer> object_reads(packed ? 0 : n_here);
+        const size_t kRun = 8;  // neighbouring graphs per grab, see prepareChunk
+        parallelFor((n_here + kRun - 1) / kRun, parameters.threads, [&](size_t run) {
+            std::vector<std::unique_ptr<common::BamReader>> readers;
+            for (size_t g = run * kRun; g < std::min(n_here, (run + 1) * kRun); ++g)
+            {
+                graphs[g] = GraphDescription::load(graph_paths[g0 + g], reference_path, target_regions, &fasta);
+                const int max_reads = graphs[g].max_reads >= 0 ? (int)graphs[g].max_reads : parameters.max_reads;
+                for (size_t b = 0; b < bam_paths.size(); ++b)
+                {
+                    if (readers.size() <= b)
+                        readers.emplace_back(new common::BamReader(bam_paths[b], index_of(b), reference_path));
+                    if (packed)
+                        extractPacked(*readers[b], graphs[g].target_regions, max_reads, (unsigned)graphs[g].longest_alt_insertion, packed_reads[g]);
+                    else
+                        common::extractReads(
+                            *readers[b], graphs[g].target_regions, max_reads, (unsigned)graphs[g].longest_alt_insertion, object_reads[g]);
+                }
+            }
+        });
+        std::vector<Json> batch;
+        if (packed)
+        {
+            std::vector<PackedSiteInput> sites(n_here);
+            for (size_t g = 0; g < n_here; ++g)
+            {
+                sites[g].description = &graphs[g];
+                sites[g].reads = &packed_reads[g];
+            }
+            batch = alignAndDisambiguateBatch(parameters, sites);
+        }
+        else
+        {
+            std::vector<SiteInput> sites(n_here);
+            for (size_t g = 0; g < n_here; ++g)
+            {
+                sites[g].description = &graphs[g];
+                sites[g].reads = &object_reads[g];
+            }
+            batch = alignAndDisambiguateBatch(parameters, sites);
+        }
+        for (size_t g = 0; g < n_here; ++g)
+        {
+            batch[g]["bam"] = bam_value;
+            documents[g0 + g] = std::move(batch[g]);
+        }
+    }
+    return documents;
+}
+
 Json alignAndDisambiguate(Parameters const& parameters, GraphDescription const& description, common::ReadBuffer& all_reads)
 {
     std::vector<SiteInput> one(1);

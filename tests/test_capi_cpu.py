@@ -138,3 +138,26 @@ def test_grmpy_command_line_parsing(tmp_path):
         has_gpu = False
     if not has_gpu:
         assert rc == 1 and "pg_ctx_create" in out  # parsed everything, loaded graphs and manifest, then needed the device
+
+
+def test_paragraph_command_line_parsing():
+    """paragraph_amd/bin/paragraph keeps the reference's option names (src/c++/main/paragraph.cpp:83-290); outputs this build
+    does not compute are refused by name instead of being silently dropped."""
+    import subprocess
+    from paragraph_amd import build
+    build.build_host()
+
+    def run(*args):
+        r = subprocess.run([build.PARAGRAPH_BIN] + list(args), capture_output=True, text=True, timeout=120)
+        return r.returncode, r.stdout + r.stderr
+
+    rc, out = run("--help")
+    assert rc == 0 and "paragraph -r <reference> -g <graph(s)> -b <input bam(s)>" in out
+    assert run("-g", "g.json", "-r", "r.fa") == (1, "ERROR: BAM file is missing.\n")
+    assert run("-b", "x.bam", "-r", "r.fa") == (1, "ERROR: File with variant specification is missing.\n")
+    assert run("-b", "x.bam", "-g", "g.json") == (1, "ERROR: Reference genome is missing.\n")
+    for refused in ("-v", "--output-path-coverage", "--output-node-coverage", "--output-read-haplotypes", "-E"):
+        rc, out = run("-b", "x.bam", "-g", "g.json", "-r", "r.fa", refused)
+        assert rc == 1 and "not available in this build" in out, refused
+    rc, out = run("-b", "x.bam", "-g", "g.json", "-r", "r.fa", "--output-variants", "false", "--bad-align-nonuniq", "0", "--threads", "3")
+    assert rc == 1 and "r.fa" in out  # accepted; fails only at the missing reference file

@@ -167,3 +167,54 @@ def test_synthetic_sites_packed_equals_objects_and_truth(tmp_path):
     # fragment statistics see real pairs here: the running median / variance are exercised beyond the seed samples
     rich = [d["samples"]["SYN"] for d in base if d["samples"]["SYN"]["paired_read"] >= 5]
     assert rich and all(s["median_graph"] > 100 and s["variance_graph"] > 0 and s["mean_graph"] > 100 for s in rich)
+
+
+def test_paragraph_binary_reproduces_multiparagraph(tmp_path):
+    """The chain of src/python/bin/multiparagraph.py on its own test data: candidates.json -> event templates -> `paragraph`
+    (here paragraph_amd/bin/paragraph, all five graphs in one call) -> the graph part of expected.json, key for key
+    (src/python/test/test_multiparagraph.py:83-105 removes bam / reference / alignment_statistics before comparing)."""
+    import gzip
+    import json
+    import math
+    from paragraph_amd import build, graph_templates
+    if not os.path.exists(build.PARAGRAPH_BIN):
+        build.build_host()
+    d = os.path.join(ROOT, "tests", "golden", "sites", "multiparagraph")
+    expected = json.load(open(os.path.join(d, "expected.json")))
+    graphs = []
+    for i, event in enumerate(json.load(open(os.path.join(d, "candidates.json")))):
+        kind, graph = graph_templates.make_graph({k: v for k, v in event.items() if k != "desc"})
+        assert kind == expected[i]["type"]
+        path = tmp_path / ("event_%d.json" % i)
+        path.write_text(json.dumps(graph))
+        graphs.append(str(path))
+    out = tmp_path / "out.json.gz"
+    r = subprocess.run([build.PARAGRAPH_BIN, "-r", os.path.join(d, "dummy.fa"), "-b", os.path.join(d, "reads.bam"), "-o", str(out), "-z",
+                        "--threads", "2", "-g"] + graphs, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    observed = json.loads(gzip.open(out, "rt").read())
+    assert len(observed) == len(expected)
+
+    def same(a, b):
+        if isinstance(a, float) or isinstance(b, float):
+            return (a is None and b is None) or (a is not None and b is not None and math.isclose(a, b, rel_tol=1e-12, abs_tol=0))
+        if isinstance(a, dict):
+            return isinstance(b, dict) and a.keys() == b.keys() and all(same(a[k], b[k]) for k in a)
+        if isinstance(a, list):
+            return isinstance(b, list) and len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        return a == b
+
+    for want, got in zip(expected, observed):
+        assert got["bam"] == os.path.join(d, "reads.bam") and got["reference"] == os.path.join(d, "dummy.fa")
+        for key in ("bam", "reference", "alignment_statistics"):
+            got.pop(key)
+        assert same(want["graph"], got), (want["desc"], json.dumps(want["graph"], sort_keys=True)[:400], json.dumps(got, sort_keys=True)[:400])
+    # two BAMs: pooled per graph, "bam" lists both, twice the fragments ... of which the same-named ones merge
+    r = subprocess.run([build.PARAGRAPH_BIN, "-r", os.path.join(d, "dummy.fa"), "-b", os.path.join(d, "reads.bam"), os.path.join(d, "reads.bam"),
+                        "-g", graphs[0], "--output-detailed-read-counts"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    joint = json.loads(r.stdout)
+    assert joint["bam"] == [os.path.join(d, "reads.bam")] * 2
+    assert joint["read_counts_by_edge"]["LF_MID"] == expected[0]["graph"]["read_counts_by_edge"]["LF_MID"]          # fragments
+    assert joint["read_counts_by_edge"]["LF_MID:READS"] == 2 * expected[0]["graph"]["read_counts_by_edge"]["LF_MID:READS"]  # reads
+    assert "LF_MID" in joint["read_counts_by_sequence"]["REF"]

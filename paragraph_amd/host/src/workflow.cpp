@@ -4,6 +4,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
 #include <map>
 #include <mutex>
 #include <set>
@@ -775,7 +778,24 @@ std::vector<Json> genotypeGraphs(
     std::atomic<size_t> next_chunk(0);
     std::exception_ptr failure;
     std::atomic<bool> failed(false);
+    // PG_WORKFLOW_TRACE=<file>: one line per (lane, chunk, phase) with start / end seconds since the call began
+    const char* trace_path = std::getenv("PG_WORKFLOW_TRACE");
+    const double t_call = now();
+    std::vector<std::string> trace;
+    std::atomic<int> lane_ids(0);
     auto lane = [&] {
+        const int lane_id = lane_ids.fetch_add(1);
+        std::vector<std::string> my_trace;
+        double t_mark = now();
+        auto phase = [&](size_t chunk_index, const char* what) {
+            if (!trace_path)
+                return;
+            const double t = now();
+            char line[160];
+            snprintf(line, sizeof line, "%d\t%zu\t%s\t%.6f\t%.6f", lane_id, chunk_index, what, t_mark - t_call, t - t_call);
+            my_trace.push_back(line);
+            t_mark = t;
+        };
         paragraph::Timings mine;
         paragraph::Parameters site_parameters = siteParameters(parameters);
         site_parameters.threads = lane_threads;
@@ -788,7 +808,9 @@ std::vector<Json> genotypeGraphs(
                 if (c >= n_chunks || failed.load())
                     break;
                 const size_t g0 = c * per_batch, g1 = std::min(n_graphs, g0 + per_batch), n_here = g1 - g0;
+                t_mark = now();
                 std::unique_ptr<Chunk> chunk = prepareChunk(parameters, graph_paths, reference_path, samples, g0, g1, lane_threads, &fasta);
+                phase(c, "prepare");
                 std::vector<Json> documents;
                 if (!chunk->packed.empty())
                 {
@@ -812,6 +834,7 @@ std::vector<Json> genotypeGraphs(
                 }
                 for (size_t i = 0; i < documents.size(); ++i)
                     finishSampleDocument(documents[i], samples[i % n_samples].filename(), parameters.output_alignments);
+                phase(c, "batch+documents");
 
                 const double t_genotype = now();
                 parallelFor(n_here, lane_threads, [&](size_t g) {
@@ -825,10 +848,12 @@ std::vector<Json> genotypeGraphs(
                     genotypes[g0 + g]
                         = genotypeDocument(*chunk->graphs[g].graph, chunk->graphs[g].description, genotyping_parameter_path, sample_ptrs, docs);
                 });
+                phase(c, "genotypes");
                 const double t_release = now();
                 // hundreds of thousands of small strings: give them back on all of the lane's threads
                 parallelFor(chunk->reads.size(), lane_threads, [&](size_t i) { common::ReadBuffer().swap(chunk->reads[i]); }, 16);
                 parallelFor(documents.size(), lane_threads, [&](size_t i) { documents[i] = Json(); }, 16);
+                phase(c, "release");
                 mine.load_graphs += chunk->load_s;
                 mine.extract_reads += chunk->extract_s;
                 mine.genotypes += t_release - t_genotype;
@@ -842,6 +867,7 @@ std::vector<Json> genotypeGraphs(
                 failure = std::current_exception();
         }
         std::lock_guard<std::mutex> lock(timings_mutex);
+        trace.insert(trace.end(), my_trace.begin(), my_trace.end());
         lane_timings_total.load_graphs += mine.load_graphs;
         lane_timings_total.extract_reads += mine.extract_reads;
         lane_timings_total.device_batch += mine.device_batch;
@@ -852,6 +878,7 @@ std::vector<Json> genotypeGraphs(
         lane_timings_total.reads += mine.reads;
         lane_timings_total.batches += mine.batches;
     };
+    const double t_lanes = now();
     std::vector<std::thread> pool;
     for (size_t l = 1; l < lanes; ++l)
         pool.emplace_back(lane);
@@ -860,6 +887,13 @@ std::vector<Json> genotypeGraphs(
         t.join();
     if (failure)
         std::rethrow_exception(failure);
+    if (trace_path)
+    {
+        std::ofstream out(trace_path, std::ios::app);
+        out << "# lanes=" << lanes << " threads/lane=" << lane_threads << " chunks=" << n_chunks << " setup_s=" << (t_lanes - t_call) << " total_s=" << (now() - t_call) << "\n";
+        for (auto const& line : trace)
+            out << line << "\n";
+    }
     if (parameters.timings)
     {
         *parameters.timings = lane_timings_total;

@@ -196,7 +196,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     const uint32_t PADPK = ((uint32_t)PAD & 0xFFFFu) | ((uint32_t)PAD << 16);
 
     uint32_t* __restrict__ seed = (uint32_t*)(a.workspace + itp->seed_off);    // [node][lane][SEED_DW]
-    uint32_t* __restrict__ trace = (uint32_t*)(a.workspace + itp->trace_off);  // [step][lane][TRACE_DW]
+    uint32_t* __restrict__ trace = (uint32_t*)(a.workspace + itp->trace_off);  // [step][TRACE_DW][lane]: one store instruction = 256 contiguous bytes
 
     uint32_t Hp[C], E[C];
 #pragma unroll
@@ -219,7 +219,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     const uint32_t GE2 = PG_GAP_EXT | (PG_GAP_EXT << 16);
     const uint32_t nsteps = gd.ncols + PG_GROUP_LANES - 1;
     const uint32_t* profl = prof + grp * 4 * ROWS + k * C;
-    const uint32_t trace_lane_off = (uint32_t)lane * TRACE_DW * 4u;
+    const uint32_t trace_lane_off = (uint32_t)lane * 4u;
 
     // Column meta words: the word of step t is the same for the whole wavefront, so it is read with SCALAR loads through
     // the constant address space (the graph tables are never written by a kernel), two steps ahead.  Scalar loads count
@@ -382,26 +382,33 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         // ---- running node maximum + first column reaching it (gssw.c:369-386) -----------------------
         if (WIDE)
         {
-            // also the smallest row holding it: the reference's alignsEndAtMultNodes reads word-mode matrices through a
-            // byte pointer and so only sees the first half of every node's cells (epilogue)
-            uint32_t cm = hs[0];
+            // tree reduction, as below (hs is scratch from here on; Hp still holds this column)
 #pragma unroll
-            for (int r = 1; r < C; ++r)
-                cm = pk_maxu(cm, hs[r]);
-            const uint32_t Mn = pk_maxu(M, cm);
+            for (int w = 1; w < C; w *= 2)
+#pragma unroll
+                for (int r = 0; r + w < C; r += 2 * w)
+                    hs[r] = pk_maxu(hs[r], hs[r + w]);
+            const uint32_t Mn = pk_maxu(M, hs[0]);
             uint32_t inc = pk_minu(pk_sub(Mn, M), 0x00010001u);
             inc = pk_sub(0u, inc);
+            asm volatile("" : "+v"(inc));
             FC = (FC & ~inc) | (colv & inc);
-            if (inc)
+            // The row of the maximum matters in one case only: a node whose final maximum is 251..255 -- the reference's
+            // alignsEndAtMultNodes reads word-mode matrices through a byte pointer and then only sees the first half of the
+            // node's cells (epilogue).  A maximum passes through each of those five values at most once, so the row search
+            // runs a handful of times per node instead of at every growth step.  (The traceback's start row is found from
+            // the H trace in the epilogue, like in the byte variants.)
+            const uint32_t mnA = Mn & 0xFFFFu, mnB = Mn >> 16;
+            const bool needA = (inc & 0xFFFFu) && (mnA - 251u) <= 4u, needB = (inc >> 16) && (mnB - 251u) <= 4u;
+            if (needA || needB)
             {
                 uint32_t frA = FR & 0xFFFFu, frB = FR >> 16;
-                const uint32_t mnA = Mn & 0xFFFFu, mnB = Mn >> 16;
 #pragma unroll
                 for (int r = C - 1; r >= 0; --r)
                 {
-                    if ((inc & 0xFFFFu) && (hs[r] & 0xFFFFu) == mnA)
+                    if (needA && (Hp[r] & 0xFFFFu) == mnA)
                         frA = (uint32_t)r;
-                    if ((inc >> 16) && (hs[r] >> 16) == mnB)
+                    if (needB && (Hp[r] >> 16) == mnB)
                         frB = (uint32_t)r;
                 }
                 FR = frA | (frB << 16);
@@ -436,13 +443,13 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             {
 #pragma unroll
                 for (int r = 0; r < C; ++r)
-                    tp[r] = Hp[r];  // halves A_r, B_r
+                    tp[r * 64] = Hp[r];  // halves A_r, B_r
             }
             else
             {
 #pragma unroll
                 for (int r = 0; r < C; r += 2)
-                    tp[r / 2] = __builtin_amdgcn_perm(Hp[r + 1], Hp[r], 0x06020400u);  // bytes A_r, A_r+1, B_r, B_r+1 (one v_perm)
+                    tp[(r / 2) * 64] = __builtin_amdgcn_perm(Hp[r + 1], Hp[r], 0x06020400u);  // bytes A_r, A_r+1, B_r, B_r+1 (one v_perm)
             }
         }
 
@@ -556,10 +563,26 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         fs.pad[0] = fs.pad[1] = 0;
         if (best > 0 && DIR == 0)
         {
+            // the key's row field orders the lanes (lane * C + a row < C that is only exact for maxima of 251..255); the row
+            // itself = the first row of that lane holding `best` in the H trace of column `col`
             const uint32_t col = 0xFFFFu - (uint32_t)((bestkey >> 16) & 0xFFFFu);
+            const uint32_t kk = (0xFFFFu - (uint32_t)(bestkey & 0xFFFFu)) / (uint32_t)C;
+            const uint32_t* tp = trace + (size_t)(col + kk) * 64 * TRACE_DW + (grp * 16 + kk);
+            int rr = 0;
+            bool found = false;
+#pragma unroll
+            for (int r = 0; r < C; ++r)
+            {
+                const uint32_t hval = (tp[r * 64] >> (strand * 16)) & 0xFFFFu;
+                if (!found && hval == best)
+                {
+                    rr = r;
+                    found = true;
+                }
+            }
             fs.end_col = (int32_t)col;
             fs.ref_end = (int32_t)(col - nodes[bestnode].col_start);
-            fs.read_end = (int32_t)(0xFFFFu - (uint32_t)(bestkey & 0xFFFFu));
+            fs.read_end = (int32_t)(kk * C) + rr;
         }
         a.fillsum[((size_t)item_idx * PG_GROUPS + grp) * 2 + strand] = fs;
     }
@@ -593,13 +616,13 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         {
             const uint32_t col = 0xFFFFu - ((bestkey >> 4) & 0xFFFFu);
             const uint32_t kk = 15u - (bestkey & 15u);
-            const uint32_t* tp = trace + ((size_t)(col + kk) * 64 + (grp * 16 + kk)) * TRACE_DW;
+            const uint32_t* tp = trace + (size_t)(col + kk) * 64 * TRACE_DW + (grp * 16 + kk);
             int rr = 0;
             bool found = false;
 #pragma unroll
             for (int r = 0; r < C; r += 2)
             {
-                const uint32_t w = tp[r / 2];
+                const uint32_t w = tp[(r / 2) * 64];
                 const uint32_t b0 = (w >> (strand * 16)) & 0xFFu;
                 const uint32_t b1 = (w >> (strand * 16 + 8)) & 0xFFu;
                 if (!found && b0 == best)

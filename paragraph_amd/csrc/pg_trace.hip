@@ -182,17 +182,17 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
     auto qchar = [&](int j) -> uint32_t {
         return s == 0 ? upper_c((uint8_t)bases[j]) : comp_c((uint8_t)bases[L - 1 - j]);
     };
-    // byte variants: trace [step][lane][C/2] dwords of bytes (A_r, A_r+1, B_r, B_r+1), seed [node][lane][C] dwords of
-    // bytes (H_A, H_B, Enext_A, Enext_B); wide variants: trace [step][lane][C] dwords (A_r | B_r << 16), seed
+    // byte variants: trace [step][C/2][lane] dwords of bytes (A_r, A_r+1, B_r, B_r+1), seed [node][lane][C] dwords of
+    // bytes (H_A, H_B, Enext_A, Enext_B); wide variants: trace [step][C][lane] dwords (A_r | B_r << 16), seed
     // [node][lane][2C] dwords (H_A | H_B << 16), (Enext_A | Enext_B << 16)
     auto Hcell = [&](uint32_t col, int j) -> int {
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
         if (WIDE)
         {
-            const size_t dw = ((size_t)(col + kq) * 64 + (grp * 16 + kq)) * C + r;
+            const size_t dw = ((size_t)(col + kq) * C + r) * 64 + (grp * 16 + kq);
             return (int)((const uint16_t*)trace)[dw * 2 + (uint32_t)s];
         }
-        const size_t dw = ((size_t)(col + kq) * 64 + (grp * 16 + kq)) * (C / 2) + r / 2;
+        const size_t dw = ((size_t)(col + kq) * (C / 2) + r / 2) * 64 + (grp * 16 + kq);
         return (int)trace[dw * 4 + (r & 1u) + 2u * (uint32_t)s];
     };
     auto seedH = [&](uint32_t node, int j) -> int {

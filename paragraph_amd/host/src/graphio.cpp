@@ -710,6 +710,15 @@ struct Tally
             clip += a.clipped;
     }
     void strand(bool reverse) { ++(reverse ? rev : fwd); }
+    void merge(Tally const& o)  // two edges whose "<from>_<to>" names coincide share one entry in the document
+    {
+        match += o.match;
+        mismatch += o.mismatch;
+        gap += o.gap;
+        clip += o.clip;
+        fwd += o.fwd;
+        rev += o.rev;
+    }
     Json toJson() const
     {
         Json out = Json::object();
@@ -744,8 +753,13 @@ Json alignmentStatistics(Graph const& graph, SiteReadViews const& views)
                 allele_length[label] += graph.nodeSeq(node).size();
     }
     const bool terminals = n_nodes && (graph.nodeName(0) == "source" || graph.nodeName(n_nodes - 1) == "sink");
-    std::map<std::string, Tally> node_stats, edge_stats, allele_stats;
-    std::map<std::string, int> allele_score;
+    // tallies are kept by id while the reads go by (names only when the document is written)
+    std::vector<Tally> node_tally(n_nodes);
+    std::vector<bool> node_seen(n_nodes, false);
+    std::map<std::pair<NodeId, NodeId>, Tally> edge_tally;
+    std::vector<Tally> allele_tally(views.label_names.size());
+    std::vector<bool> allele_seen(views.label_names.size(), false);
+    std::vector<int> allele_score_by_label(views.label_names.size(), 0);
     for (MappedReadView const& read : views.reads)
     {
         if (!read.is_graph_mapped)
@@ -756,33 +770,57 @@ Json alignmentStatistics(Graph const& graph, SiteReadViews const& views)
         {
             const NodeId node = pieces[k].node;
             const bool terminal = terminals && (node == 0 || node == n_nodes - 1);
-            Tally& nt = node_stats.emplace(graph.nodeName(node), Tally(graph.nodeSeq(node).size())).first->second;
-            nt.bases(pieces[k], !terminal);
-            nt.strand(reverse);
+            if (!node_seen[node])
+            {
+                node_seen[node] = true;
+                node_tally[node] = Tally(graph.nodeSeq(node).size());
+            }
+            node_tally[node].bases(pieces[k], !terminal);
+            node_tally[node].strand(reverse);
             if (k == 0)
                 continue;
             const NodeId prev = pieces[k - 1].node;
-            Tally& et = edge_stats
-                            .emplace(graph.nodeName(prev) + "_" + graph.nodeName(node), Tally(graph.nodeSeq(prev).size() + graph.nodeSeq(node).size()))
-                            .first->second;
+            auto it = edge_tally.find({ prev, node });
+            if (it == edge_tally.end())
+                it = edge_tally.emplace(std::make_pair(prev, node), Tally(graph.nodeSeq(prev).size() + graph.nodeSeq(node).size())).first;
             // clips on the `from` side count only when the `to` node is node 1 of a graph with terminals; on the `to` side
             // only when `to` is itself a terminal (the original's argument order, GraphSummaryStatistics.cpp:131-135)
-            et.bases(pieces[k - 1], terminals && node == 1);
-            et.bases(pieces[k], terminal);
-            et.strand(reverse);
+            it->second.bases(pieces[k - 1], terminals && node == 1);
+            it->second.bases(pieces[k], terminal);
+            it->second.strand(reverse);
         }
         for (size_t b = 0; b < views.label_names.size(); ++b)
         {
             if (!((read.sequences >> b) & 1))
                 continue;
-            std::string const& allele = views.label_names[b];
-            Tally& at = allele_stats.emplace(allele, Tally(allele_length[allele])).first->second;
+            if (!allele_seen[b])
+            {
+                allele_seen[b] = true;
+                allele_tally[b] = Tally(allele_length[views.label_names[b]]);
+            }
             for (size_t k = 0; k < read.n_pieces; ++k)
-                at.bases(pieces[k], !(terminals && (pieces[k].node == 0 || pieces[k].node == n_nodes - 1)));
-            at.strand(reverse);
-            allele_score[allele] += read.graph_alignment_score;
+                allele_tally[b].bases(pieces[k], !(terminals && (pieces[k].node == 0 || pieces[k].node == n_nodes - 1)));
+            allele_tally[b].strand(reverse);
+            allele_score_by_label[b] += read.graph_alignment_score;
         }
     }
+    std::map<std::string, Tally> node_stats, edge_stats, allele_stats;
+    std::map<std::string, int> allele_score;
+    for (NodeId node = 0; node < n_nodes; ++node)
+        if (node_seen[node])
+            node_stats.emplace(graph.nodeName(node), node_tally[node]);
+    for (auto const& kv : edge_tally)
+    {
+        auto placed = edge_stats.emplace(graph.nodeName(kv.first.first) + "_" + graph.nodeName(kv.first.second), kv.second);
+        if (!placed.second)
+            placed.first->second.merge(kv.second);
+    }
+    for (size_t b = 0; b < views.label_names.size(); ++b)
+        if (allele_seen[b])
+        {
+            allele_stats.emplace(views.label_names[b], allele_tally[b]);
+            allele_score[views.label_names[b]] = allele_score_by_label[b];
+        }
     Json out = Json::object();
     out["nodes"] = Json::object();
     out["edges"] = Json::object();

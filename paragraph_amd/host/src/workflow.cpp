@@ -160,53 +160,115 @@ namespace
 // the per-family node / edge breakdown from the views of a packed site (same rule as addDetailedCounts)
 void addDetailedCounts(Json& by_sequence, graphtools::Graph const& graph, SiteReadViews const& views)
 {
+    // Support sets are collected by id (a node id / a (from, to) pair); names are made once per distinct element when the
+    // tables are written.  Ids stand in for names only as long as names are unambiguous: two edges spelling the same
+    // "<from>_<to>" would be ONE element of the original's name sets, so such graphs take the name-keyed path.
+    struct Support
+    {
+        uint64_t reads = 0, fwd = 0, rev = 0, sequences = 0;
+        std::vector<uint32_t> nodes;
+        std::vector<uint64_t> edges;  // from << 32 | to
+    };
+    struct Counter
+    {
+        uint64_t count = 0, reads = 0, fwd = 0, rev = 0;
+    };
     std::vector<uint32_t> order;
-    std::unordered_map<uint32_t, FragmentSupport> fragments;
-    std::unordered_map<uint32_t, uint64_t> sequences;
+    std::unordered_map<uint32_t, Support> fragments;
+    bool ambiguous_names = false;
+    {
+        std::set<std::string> names;
+        for (graphtools::NodeId n = 0; n < graph.numNodes() && !ambiguous_names; ++n)
+        {
+            ambiguous_names = !names.insert(graph.nodeName(n)).second;
+            for (graphtools::NodeId s : graph.successors(n))
+                if (!names.insert(graph.nodeName(n) + "_" + graph.nodeName(s)).second)
+                    ambiguous_names = true;
+        }
+    }
     for (MappedReadView const& read : views.reads)
     {
         auto it = fragments.find(read.fragment);
         if (it == fragments.end())
         {
-            it = fragments.emplace(read.fragment, FragmentSupport()).first;
+            it = fragments.emplace(read.fragment, Support()).first;
             order.push_back(read.fragment);
         }
-        FragmentSupport& f = it->second;
+        Support& f = it->second;
         ++f.reads;
         ++(read.is_graph_reverse_strand ? f.rev : f.fwd);
+        f.sequences |= read.sequences;
         uint32_t prev = 0;
         for (uint32_t k = 0; k < read.n_support; ++k)
         {
             const uint32_t entry = views.support[read.support_off + k], node = entry & 0xFFFu;
             if ((entry >> 30) & 1u)
-                f.nodes.insert(graph.nodeName(node));
+                f.nodes.push_back(node);
             if (k > 0 && (entry >> 31))
-                f.edges.insert(graph.nodeName(prev) + "_" + graph.nodeName(node));
+                f.edges.push_back((uint64_t)prev << 32 | node);
             prev = node;
         }
-        sequences[read.fragment] |= read.sequences;
     }
-    auto bump = [](Json& table, std::string const& key, FragmentSupport const& f) {
-        table[key] = table[key].asUInt64() + 1;
-        table[key + ":READS"] = table[key + ":READS"].asUInt64() + f.reads;
-        table[key + ":FWD"] = table[key + ":FWD"].asUInt64() + f.fwd;
-        table[key + ":REV"] = table[key + ":REV"].asUInt64() + f.rev;
+    auto add = [](Counter& c, Support const& f) {
+        ++c.count;
+        c.reads += f.reads;
+        c.fwd += f.fwd;
+        c.rev += f.rev;
     };
+    std::map<uint64_t, std::pair<std::map<uint32_t, Counter>, std::map<uint64_t, Counter>>> by_family;  // by label bit set
+    std::map<uint64_t, std::map<std::string, Counter>> by_family_named;                                    // ambiguous names
     for (uint32_t id : order)
     {
-        const uint64_t mask = sequences[id];
-        if (!mask)
+        Support& f = fragments[id];
+        if (!f.sequences)
             continue;
+        std::sort(f.nodes.begin(), f.nodes.end());
+        f.nodes.erase(std::unique(f.nodes.begin(), f.nodes.end()), f.nodes.end());
+        std::sort(f.edges.begin(), f.edges.end());
+        f.edges.erase(std::unique(f.edges.begin(), f.edges.end()), f.edges.end());
+        if (ambiguous_names)
+        {
+            std::set<std::string> elements;
+            for (uint32_t n : f.nodes)
+                elements.insert(graph.nodeName(n));
+            for (uint64_t e : f.edges)
+                elements.insert(graph.nodeName((uint32_t)(e >> 32)) + "_" + graph.nodeName((uint32_t)e));
+            for (auto const& name : elements)
+                add(by_family_named[f.sequences][name], f);
+            continue;
+        }
+        auto& tables = by_family[f.sequences];
+        for (uint32_t n : f.nodes)
+            add(tables.first[n], f);
+        for (uint64_t e : f.edges)
+            add(tables.second[e], f);
+    }
+    auto family_name = [&](uint64_t mask) {
         std::string family;  // label_names are sorted, so this is the sorted join
         for (size_t b = 0; b < views.label_names.size(); ++b)
             if ((mask >> b) & 1)
                 family += (family.empty() ? "" : ",") + views.label_names[b];
-        FragmentSupport const& f = fragments[id];
-        Json& table = by_sequence[family];
-        for (auto const& n : f.nodes)
-            bump(table, n, f);
-        for (auto const& e : f.edges)
-            bump(table, e, f);
+        return family;
+    };
+    auto write = [](Json& table, std::string const& key, Counter const& c) {
+        table[key] = c.count;
+        table[key + ":READS"] = c.reads;
+        table[key + ":FWD"] = c.fwd;
+        table[key + ":REV"] = c.rev;
+    };
+    for (auto const& fam : by_family)
+    {
+        Json& table = by_sequence[family_name(fam.first)];
+        for (auto const& kv : fam.second.first)
+            write(table, graph.nodeName(kv.first), kv.second);
+        for (auto const& kv : fam.second.second)
+            write(table, graph.nodeName((uint32_t)(kv.first >> 32)) + "_" + graph.nodeName((uint32_t)kv.first), kv.second);
+    }
+    for (auto const& fam : by_family_named)
+    {
+        Json& table = by_sequence[family_name(fam.first)];
+        for (auto const& kv : fam.second)
+            write(table, kv.first, kv.second);
     }
 }
 

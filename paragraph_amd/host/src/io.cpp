@@ -549,14 +549,20 @@ void BamReader::Impl::parseHeader(BamMeta& m)
         throw std::runtime_error("ERROR: Unknown alignment file format.");
     }
     bgzf->readExact(b, 4, "header length");
+    if (le32(b) > (1u << 30))
+        throw std::runtime_error("Corrupt BAM header (text length) in " + path);
     m.header_text.resize(le32(b));
     if (!m.header_text.empty())
         bgzf->readExact(&m.header_text[0], m.header_text.size(), "header text");
     bgzf->readExact(b, 4, "reference count");
     const uint32_t n_ref = le32(b);
+    if (n_ref > (1u << 24))
+        throw std::runtime_error("Corrupt BAM header (reference count) in " + path);
     for (uint32_t i = 0; i < n_ref; ++i)
     {
         bgzf->readExact(b, 4, "reference name length");
+        if (le32(b) > (1u << 16))
+            throw std::runtime_error("Corrupt BAM header (reference name length) in " + path);
         std::string name(le32(b), '\0');
         if (!name.empty())
             bgzf->readExact(&name[0], name.size(), "reference name");
@@ -593,6 +599,8 @@ void BamReader::Impl::loadIndex(BamMeta& m)
         throw std::runtime_error("ERROR: " + use + " is not a BAI index");
     const uint32_t n_ref = le32(buf.data() + 4);
     at = 8;
+    if ((uint64_t)n_ref * 8 > buf.size())  // every reference has at least a bin count and an interval count
+        throw std::runtime_error("ERROR: Corrupt index " + use);
     m.index.resize(n_ref);
     for (uint32_t r = 0; r < n_ref; ++r)
     {
@@ -634,7 +642,7 @@ bool BamReader::Impl::readRecord(BamRecord& rec)
     if (got != 4)
         throw std::runtime_error("Truncated BAM (record length) in " + path);
     const uint32_t block_size = le32(b4);
-    if (block_size < 32)
+    if (block_size < 32 || block_size > (1u << 29))
         throw std::runtime_error("Corrupt BAM record in " + path);
     scratch.resize(block_size);
     bgzf->readExact(scratch.data(), block_size, "record");

@@ -660,6 +660,8 @@ int main(int argc, char** argv)
     if (argc == 4 && std::string(argv[1]) == "--dump-bam")
     {
         // <bam> <region>: one line per primary record, for the independent Python decoder in tests/test_hostio_cpu.py
+        try
+        {
         BamReader reader(argv[2], "", "");
         reader.setRegion(argv[3]);
         Read r;
@@ -667,11 +669,34 @@ int main(int argc, char** argv)
             std::cout << r.fragment_id() << "\t" << r.chrom_id() << "\t" << r.pos() << "\t" << (int)r.mapq() << "\t" << r.is_mapped()
                       << r.is_first_mate() << r.is_mate_mapped() << r.is_reverse_strand() << r.is_mate_reverse_strand() << "\t"
                       << r.mate_chrom_id() << "\t" << r.mate_pos() << "\t" << r.bases() << "\t" << r.quals() << "\n";
+        }
+        catch (std::exception const& e)
+        {
+            std::cerr << "error: " << e.what() << "\n";
+            return 1;
+        }
+        return 0;
+    }
+    if (argc == 4 && std::string(argv[1]) == "--load-graph")
+    {
+        // <graph.json> <reference.fa>: parse + build, for robustness checks on damaged descriptions (exit 1 = clean refusal)
+        try
+        {
+            const Json doc = Json::parseFile(argv[2]);
+            const auto g = grm::graphFromJson(doc, argv[3]);
+            const auto paths = grm::pathsFromJson(&g, (doc.isMember("graph") ? doc["graph"] : doc)["paths"]);
+            std::cout << g.numNodes() << " nodes, " << g.numEdges() << " edges, " << paths.size() << " paths\n";
+        }
+        catch (std::exception const& e)
+        {
+            std::cerr << "error: " << e.what() << "\n";
+            return 1;
+        }
         return 0;
     }
     if (argc < 2)
     {
-        std::cerr << "usage: test_hostio <tests/golden/sites> | --dump-bam <bam> <region>\n";
+        std::cerr << "usage: test_hostio <tests/golden/sites> | --dump-bam <bam> <region> | --load-graph <json> <fasta>\n";
         return 2;
     }
     const std::string dir = argv[1];

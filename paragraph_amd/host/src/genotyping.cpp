@@ -53,7 +53,8 @@ double logPoissonPdf(double mean, int32_t k)
         throw std::domain_error("Poisson mean must be > 0");
     if (k < 0)
         throw std::domain_error("Poisson count must be >= 0");
-    return k * std::log(mean) - mean - std::lgamma((double)k + 1.0);
+    int sign = 0;  // lgamma_r: plain lgamma writes the process-wide `signgam`, and genotyping runs on several threads
+    return k * std::log(mean) - mean - lgamma_r((double)k + 1.0, &sign);
 }
 
 // boost::math::cdf(poisson_distribution<>(mean), k) = Q(k + 1, mean)

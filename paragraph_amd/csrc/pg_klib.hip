@@ -154,7 +154,17 @@ __device__ __forceinline__ void klib_local(
         key[r] = (row % slen) * 8 + row / slen;
     }
     int my_hlast = 0, my_f = 0, diag0 = 0;
-    int best_h = 0, best_col = -1, best_key = 0;
+    // per row: its maximum and the first column reaching it (two selects per cell); the lane's (score, first column,
+    // smallest key in that column) is put together from these after the sweep
+    int row_h[R], row_col[R];
+    bool row_ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+    {
+        row_h[r] = 0;
+        row_col[r] = -1;
+        row_ok[r] = lane * R + r < nrows;
+    }
     const int steps = ncols + nl - 1;
     const bool lane_on = lane < nl;
     int tc_next = (lane_on && lane == 0 && ncols > 0) ? (int)tcode[t0] : 4;
@@ -187,23 +197,28 @@ __device__ __forceinline__ void klib_local(
                 E[r] = e > o ? e : o;
                 f -= K_GAPE;
                 f = f > o ? f : o;
-                if (lane * R + r < nrows)
-                {
-                    if (h > best_h)
-                    {
-                        best_h = h;
-                        best_col = i;
-                        best_key = key[r];
-                    }
-                    else if (h == best_h && i == best_col && key[r] < best_key)
-                        best_key = key[r];
-                }
+                const bool grew = row_ok[r] && h > row_h[r];
+                row_h[r] = grew ? h : row_h[r];
+                row_col[r] = grew ? i : row_col[r];
             }
             my_hlast = h;
             my_f = f;
             diag0 = up_h;
         }
     }
+    int best_h = 0, best_col = -1, best_key = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        best_h = row_h[r] > best_h ? row_h[r] : best_h;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (row_h[r] == best_h && best_h > 0 && (best_col < 0 || row_col[r] < best_col))
+            best_col = row_col[r];
+    best_key = 0x7FFFFFFF;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (row_h[r] == best_h && row_col[r] == best_col && key[r] < best_key)
+            best_key = key[r];
     unsigned long long comp = 0;
     if (best_h > 0)
         comp = ((unsigned long long)best_h << 44) | ((unsigned long long)(0xFFFFF - best_col) << 24) | (unsigned long long)(0xFFFFFF - best_key);

@@ -42,6 +42,17 @@ pg_ctx* deviceContext()
         pg_status st = pg_ctx_create(dev ? std::atoi(dev) : 0, &ctx);
         if (st != PG_OK)
             throw std::runtime_error(std::string("pg_ctx_create: ") + pg_strerror(st));
+        // Workspace budget (H trace + seeds of the reads in flight; allocated on demand up to this): the library's default
+        // of 8 GiB cuts a 1000-site batch into ~9 chunks of 25 k reads, too few threads for the one-thread-per-read
+        // traceback kernel.  An MI355X has 288 GB: 64 GiB (what bench.py uses) keeps such a batch in one or two chunks.
+        const char* gib = std::getenv("PG_WORKSPACE_GIB");
+        const double budget_gib = gib ? std::atof(gib) : 64.0;
+        if (budget_gib > 0)
+        {
+            st = pg_ctx_set_workspace_bytes(ctx, (uint64_t)(budget_gib * (double)(1ull << 30)));
+            if (st != PG_OK)
+                throw std::runtime_error(std::string("pg_ctx_set_workspace_bytes: ") + pg_strerror(st));
+        }
     }
     return ctx;
 }

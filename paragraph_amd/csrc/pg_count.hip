@@ -598,7 +598,7 @@ extern "C" pg_status pg_batch_set_fragments(
     const uint32_t n_frags = (uint32_t)frag_off.size();
     frag_off.push_back(n);
     b->n_frags = n_frags;
-    if (n > b->cap_count_reads)
+    if (n > b->cap_count_reads || !b->d_support)  // also for a batch without reads: the later calls expect the buffers
     {
         (void)hipFree(b->d_support);
         (void)hipFree(b->d_frag_reads);

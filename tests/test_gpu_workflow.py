@@ -218,3 +218,16 @@ def test_paragraph_binary_reproduces_multiparagraph(tmp_path):
     assert joint["read_counts_by_edge"]["LF_MID"] == expected[0]["graph"]["read_counts_by_edge"]["LF_MID"]          # fragments
     assert joint["read_counts_by_edge"]["LF_MID:READS"] == 2 * expected[0]["graph"]["read_counts_by_edge"]["LF_MID:READS"]  # reads
     assert "LF_MID" in joint["read_counts_by_sequence"]["REF"]
+    # -T overrides the graphs' target regions: a window without reads gives empty tables (and a batch without any read
+    # goes through the device path without complaint); a window over the reads gives the usual ones
+    for window, expect_reads in (("chr:150-160", False), ("chr:1-160", True)):
+        r = subprocess.run([build.PARAGRAPH_BIN, "-r", os.path.join(d, "dummy.fa"), "-b", os.path.join(d, "reads.bam"), "-g", graphs[0], "-T", window],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        doc = json.loads(r.stdout)
+        assert doc["target_regions"] == expected[0]["graph"]["target_regions"]  # the description is echoed as given
+        assert bool(doc["read_counts_by_edge"]) == expect_reads, (window, doc["read_counts_by_edge"])
+        if expect_reads:
+            assert doc["read_counts_by_edge"] == expected[0]["graph"]["read_counts_by_edge"]
+        else:
+            assert doc["fragment_statistics"]["single_read"] == 0 and doc["read_counts_by_node"] == {}

@@ -231,3 +231,36 @@ def test_paragraph_binary_reproduces_multiparagraph(tmp_path):
             assert doc["read_counts_by_edge"] == expected[0]["graph"]["read_counts_by_edge"]
         else:
             assert doc["fragment_statistics"]["single_read"] == 0 and doc["read_counts_by_node"] == {}
+
+
+def test_swaps_600x_genotypes(tmp_path):
+    """share/test-data/genotyping_test_2: three sequence swaps simulated as 0/0, 1/1 and 0/1 (GT column of swaps.vcf) at
+    600x, graphs as vcf2paragraph wrote them (chrA/B/C.json), through bin/grmpy: the simulated genotypes come back, PASS,
+    as in the reference's expected-genotypes.vcf."""
+    import json
+    from paragraph_amd import build
+    if not os.path.exists(build.GRMPY_BIN):
+        build.build_host()
+    d = os.path.join(ROOT, "tests", "golden", "sites", "swaps")
+    truth = {}
+    for line in open(os.path.join(d, "expected-genotypes.vcf")):
+        if not line.startswith("#"):
+            f = line.split("\t")
+            truth[f[0]] = f[9].split(":")[0]
+    assert truth == {"chrA": "0/0", "chrB": "1/1", "chrC": "0/1"}
+    graphs = [os.path.join(d, "chr%s.json" % c) for c in "ABC"]
+    out = tmp_path / "genotypes.json"
+    r = subprocess.run([build.GRMPY_BIN, "-r", os.path.join(d, "swaps.fa"), "-m", os.path.join(d, "samples.txt"), "-o", str(out), "-t", "4", "-g"] + graphs,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    docs = json.load(open(out))
+    assert len(docs) == 3
+    for doc in docs:
+        chrom = doc["graphinfo"]["target_regions"][0].split(":")[0]
+        gt = doc["samples"]["SWAPS"]["gt"]
+        alleles = gt["GT"].split("/")
+        called = "/".join(sorted("0" if a == "REF" else "1" for a in alleles))
+        assert called == truth[chrom], (chrom, gt)
+        assert gt["filters"] == ["PASS"] and gt["num_reads"] > 800, (chrom, gt)
+        # every breakpoint agrees with the site call
+        assert all(bp["gt"]["GT"] == gt["GT"] for bp in doc["samples"]["SWAPS"]["breakpoints"].values()), chrom

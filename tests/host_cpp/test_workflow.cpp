@@ -103,10 +103,11 @@ static void testMultiparagraph(std::string const& dir)
     }
     // the packed form (no common::Read objects) yields the same documents, with and without the path stage, incl. the
     // per-family node / edge breakdown
-    for (int pass = 0; pass < 2; ++pass)
+    for (int pass = 0; pass < 3; ++pass)
     {
         paragraph::Parameters pp = parameters;
-        pp.path_sequence_matching = pass == 0;
+        pp.path_sequence_matching = pass != 1;
+        pp.kmer_sequence_matching = pp.klib_sequence_matching = pass == 2;  // the whole cascade
         pp.output_options_ |= paragraph::Parameters::DETAILED_READ_COUNTS | paragraph::Parameters::FILTERED_ALIGNMENTS;
         std::vector<paragraph::PackedSite> packed(expected.size());
         std::vector<common::ReadBuffer> objects(expected.size());
@@ -132,7 +133,8 @@ static void testMultiparagraph(std::string const& dir)
             CHECK(from_packed[i] == from_objects[i]);
             if (from_packed[i] != from_objects[i])
                 compareObject("packed-vs-objects[" + std::to_string(i) + "]", from_objects[i], from_packed[i]);
-            compareObject("packed/edges", expected[i]["graph"]["read_counts_by_edge"], from_packed[i]["read_counts_by_edge"]);
+            if (pass < 2)  // expected.json is a path + gssw result; the seed stages place a few more reads
+                compareObject("packed/edges", expected[i]["graph"]["read_counts_by_edge"], from_packed[i]["read_counts_by_edge"]);
         }
     }
     // gssw only (grmpy's default cascade) reaches the same tables on these reads

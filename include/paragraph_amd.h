@@ -43,7 +43,11 @@
  * pg_graphs_upload, pg_graphs_set_labels and the pg_graphs_build_*_index calls only build up a new
  * graph set (host work + copy stream) and may run while another thread is inside a pg_batch_* call
  * on the same ctx with OTHER graph sets -- a graph set can be prepared for the next batch while the
- * current one is on the device.  pg_last_error is then whichever call failed last.
+ * current one is on the device.  Likewise pg_batch_create / _upload / _set_fragments, the _download* calls and
+ * pg_batch_destroy touch only their own batch and the copy stream: they may overlap the stage calls
+ * (pg_batch_path_align / _kmer_align / _klib_align / _align / _count / _set_active, which share the ctx workspace and
+ * stay serialised) of OTHER batches -- batch k+1 goes up and batch k-1 comes down while batch k computes.
+ * pg_last_error is then whichever call failed last.
  * Scoring is fixed as in the reference: match +1, mismatch -4, gap open 6, gap extend 1,
  * N / non-ACGTU = 0 (GraphAligner.cpp:229-233, gssw.c:4188-4220).
  */

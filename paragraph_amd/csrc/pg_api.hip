@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -27,8 +28,12 @@
 
 pg_status pg_fail(pg_ctx* ctx, pg_status st, const std::string& msg)
 {
+    static std::mutex err_mutex;  // uploads / downloads of one batch may overlap the stage calls of another (paragraph_amd.h)
     if (ctx)
+    {
+        std::lock_guard<std::mutex> lock(err_mutex);
         ctx->err = msg;
+    }
     return st;
 }
 static pg_status fail(pg_ctx* ctx, pg_status st, const std::string& msg) { return pg_fail(ctx, st, msg); }
@@ -546,10 +551,10 @@ extern "C" void pg_batch_destroy(pg_ctx* ctx, pg_batch* b)
         return;
     if (ctx)
     {
+        // only this batch's own work has to be over: other batches may be on the device right now
         (void)hipSetDevice(ctx->device);
+        (void)pg_batch_wait(ctx, b);
         (void)hipStreamSynchronize(ctx->stream_copy);
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamSynchronize(ctx->stream2);
     }
     batch_free_device(b);
     if (b->ev_upload)
@@ -585,9 +590,9 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
             continue;
         keys.push_back(Key{ (uint32_t)pg_variant_of(L), graph_of_read[i], i });
     }
-    std::stable_sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) {
-        return x.c != y.c ? x.c < y.c : x.graph < y.graph;
-    });
+    const auto key_less = [](const Key& x, const Key& y) { return x.c != y.c ? x.c < y.c : x.graph < y.graph; };
+    if (!std::is_sorted(keys.begin(), keys.end(), key_less))  // reads of one length, site after site, arrive in order
+        std::stable_sort(keys.begin(), keys.end(), key_less);
 
     // ---- work items (pairs: forward graph, reversed graph) + chunk plan -----------------------------
     std::vector<PgWorkItem> items;
@@ -671,7 +676,14 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
     }
     if (!items.empty())
         HIP_TRY(ctx, hipMemcpyAsync(b->d_items, items.data(), items.size() * sizeof(PgWorkItem), hipMemcpyHostToDevice, cs));
-    // workspace / scratch owned by the ctx (shared by its batches)
+    HIP_TRY(ctx, hipStreamSynchronize(cs));  // `items` goes out of scope
+    return PG_OK;
+}
+
+// Workspace / CIGAR scratch owned by the ctx and shared by its batches: grown when a batch that needs more reaches
+// pg_batch_align (never while planning, so that a batch can be uploaded while another one is on the device).
+static pg_status ensure_ctx_workspace(pg_ctx* ctx, const pg_batch* b)
+{
     if (2 * b->max_ws > ctx->ws_cap)
     {
         // two halves: chunk i uses half (i & 1) so that trace(i) can overlap fill(i + 1)
@@ -695,7 +707,6 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
         HIP_TRY(ctx, hipMalloc((void**)&ctx->ops_scratch, b->max_scratch * sizeof(pg_op)));
         ctx->ops_scratch_cap = b->max_scratch;
     }
-    HIP_TRY(ctx, hipStreamSynchronize(cs));  // `items` goes out of scope
     return PG_OK;
 }
 
@@ -797,8 +808,11 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         return fail(ctx, PG_ERR_INVALID, "pg_batch_align: batch not uploaded");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const pg_graphs* G = b->graphs;
-    if (2 * b->max_ws > ctx->ws_cap || b->max_scratch > ctx->ops_scratch_cap)
-        return fail(ctx, PG_ERR_INVALID, "ctx workspace was shrunk after the batch was planned");
+    {
+        const pg_status ws = ensure_ctx_workspace(ctx, b);
+        if (ws != PG_OK)
+            return ws;
+    }
     HIP_TRY(ctx, pg_stage_begin(ctx, b));
     if (!(flags & PG_AF_KEEP_RESULTS) || (flags == PG_AF_ALL))
         HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));

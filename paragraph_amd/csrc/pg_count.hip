@@ -587,9 +587,24 @@ extern "C" pg_status pg_batch_set_fragments(
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
     const std::vector<uint32_t>& gor = b->h_graph_of_read;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-        return gor[x] != gor[y] ? gor[x] < gor[y] : fragment_of_read[x] < fragment_of_read[y];
-    });
+    if (std::is_sorted(gor.begin(), gor.end()))
+    {
+        // reads arrive site after site: order each site's own range (short, cache-resident) by fragment id
+        for (uint32_t lo = 0; lo < n;)
+        {
+            uint32_t hi = lo + 1;
+            while (hi < n && gor[hi] == gor[lo])
+                ++hi;
+            if (!std::is_sorted(fragment_of_read + lo, fragment_of_read + hi))
+                std::stable_sort(order.begin() + lo, order.begin() + hi,
+                                 [&](uint32_t x, uint32_t y) { return fragment_of_read[x] < fragment_of_read[y]; });
+            lo = hi;
+        }
+    }
+    else
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            return gor[x] != gor[y] ? gor[x] < gor[y] : fragment_of_read[x] < fragment_of_read[y];
+        });
     std::vector<uint32_t> frag_off;
     frag_off.reserve(n / 2 + 2);
     for (uint32_t i = 0; i < n; ++i)

@@ -58,8 +58,50 @@ pg_ctx* deviceContext()
 }
 std::mutex& deviceMutex()
 {
-    static std::mutex m;  // calls on one ctx must be serialised (paragraph_amd.h)
+    static std::mutex m;  // the stage calls on one ctx must be serialised (paragraph_amd.h)
     return m;
+}
+
+// Batch objects keep their device buffers between uses: SiteBatcher::run takes one from here and hands it back, so
+// that after the first few batches no run() allocates or frees device memory (hipMalloc / hipFree stall the queues).
+struct BatchPool
+{
+    std::mutex m;
+    std::vector<pg_batch*> idle;
+    pg_batch* take(pg_ctx* ctx)
+    {
+        {
+            std::lock_guard<std::mutex> lock(m);
+            if (!idle.empty())
+            {
+                pg_batch* b = idle.back();
+                idle.pop_back();
+                return b;
+            }
+        }
+        pg_batch* b = nullptr;
+        check(ctx, pg_batch_create(ctx, &b), "pg_batch_create");
+        return b;
+    }
+    void giveBack(pg_ctx* ctx, pg_batch* b, bool reusable)
+    {
+        static const size_t keep = 16;
+        if (reusable)
+        {
+            std::lock_guard<std::mutex> lock(m);
+            if (idle.size() < keep)
+            {
+                idle.push_back(b);
+                return;
+            }
+        }
+        pg_batch_destroy(ctx, b);
+    }
+};
+BatchPool& batchPool()
+{
+    static BatchPool* pool = new BatchPool();  // lives as long as the context (never torn down, like it)
+    return *pool;
 }
 
 struct GraphCsr
@@ -841,9 +883,10 @@ void SiteBatcher::Impl::Run::deviceSection()
         fprintf(stderr, "[SiteBatcher]   %-16s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
         t_prev = t;
     };
-    // the graph set is prepared outside the device mutex (paragraph_amd.h allows exactly that): converting a thousand
-    // graphs to column tables is host work another lane's batch should not wait for
-    std::unique_lock<std::mutex> lock(deviceMutex(), std::defer_lock);  // before `guard`: device objects go while it is held
+    // Three steps, each of which another lane's batch can be in at the same time (paragraph_amd.h, "Threading"):
+    //   1. graph set + indexes and then the reads go up the copy stream (work items and fragment tables are host work),
+    //   2. the stage calls, which share the context's workspace (deviceMutex),
+    //   3. the results come down; the batch object returns to the pool with its device buffers.
     pg_graphs* G = nullptr;
     check(ctx, pg_graphs_upload(ctx, (uint32_t)n_sites, csr.node_off.data(), csr.seq_off.data(), csr.seq.data(),
                                 csr.pred_off.data(), csr.pred.empty() ? nullptr : csr.pred.data(), &G),
@@ -853,14 +896,15 @@ void SiteBatcher::Impl::Run::deviceSection()
         pg_ctx* c;
         pg_graphs* g;
         pg_batch* b;
+        bool finished;
         ~Guard()
         {
             if (b)
-                pg_batch_destroy(c, b);
+                batchPool().giveBack(c, b, finished);
             if (g)
                 pg_graphs_destroy(c, g);
         }
-    } guard{ ctx, G, nullptr };
+    } guard{ ctx, G, nullptr, false };
     check(ctx, pg_graphs_set_labels(ctx, G, csr.label_mask.empty() ? nullptr : csr.label_mask.data(), csr.n_labels.data()),
           "pg_graphs_set_labels");
     // ... and so are the per-graph indexes of the optional stages and of the KmerFilter
@@ -891,12 +935,12 @@ void SiteBatcher::Impl::Run::deviceSection()
     if (prm.kmer_len != 0)  // createReadFilter(graph, nonuniq, frac, kmer_len): NonUniq -> BadAlign -> KmerFilter (ReadFilter.cpp:74-90)
         check(ctx, pg_graphs_build_filter_index(ctx, G, prm.kmer_len, nullptr), "pg_graphs_build_filter_index");
     mark("graphs up");
-    lock.lock();
-    mark("wait for device");
-    check(ctx, pg_batch_create(ctx, &guard.b), "pg_batch_create");
+    guard.b = batchPool().take(ctx);
     check(ctx, pg_batch_upload(ctx, guard.b, G, n, gor.data(), base_off.data(), bases.data()), "pg_batch_upload");
     check(ctx, pg_batch_set_fragments(ctx, guard.b, frag.data(), is_rev.data()), "pg_batch_set_fragments");
     mark("reads up");
+    std::unique_lock<std::mutex> lock(deviceMutex());
+    mark("wait for device");
     pg_count_params cp{};
     cp.remove_nonuniq = prm.remove_nonuniq_reads ? 1 : 0;
     cp.use_support_filters = prm.use_support_filters ? 1 : 0;
@@ -950,6 +994,7 @@ void SiteBatcher::Impl::Run::deviceSection()
         align_flags = (align_flags & (PG_AF_CIGAR | PG_AF_BOTH_STRANDS | PG_AF_REVERSE_GRAPH)) | PG_AF_KEEP_RESULTS;
     check(ctx, pg_batch_align(ctx, guard.b, align_flags), "pg_batch_align");
     check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
+    lock.unlock();  // the kernels are queued; the next batch may queue its own behind them
     mark("align + count");
 
     uint64_t n_ops = 0, n_path = 0;
@@ -965,6 +1010,7 @@ void SiteBatcher::Impl::Run::deviceSection()
     path.resize(n_path + 1);
     check(ctx, pg_batch_download_counts(ctx, guard.b, table.data(), sup.data(), path.data(), path.size(), &n_path),
           "pg_batch_download_counts");
+    guard.finished = true;
     mark("results down");
 }
 

@@ -36,6 +36,7 @@ int main(int argc, char** argv)
         {
             paragraph::Timings t;
             parameters.timings = &t;
+            std::vector<common::Json>().swap(genotypes);  // the previous pass's documents are not part of this one
             const auto t0 = std::chrono::steady_clock::now();
             genotypes = grmpy::genotypeGraphs(parameters, graphs, argv[1], samples, "");
             const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

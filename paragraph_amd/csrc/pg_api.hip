@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -684,17 +685,28 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
 // pg_batch_align (never while planning, so that a batch can be uploaded while another one is on the device).
 static pg_status ensure_ctx_workspace(pg_ctx* ctx, const pg_batch* b)
 {
-    if (2 * b->max_ws > ctx->ws_cap)
+    // Two halves when the batch has more than one chunk: chunk i uses half (i & 1) so that trace(i) can overlap fill(i + 1).
+    // A single-chunk batch (the usual workflow batch) lives at offset 0 and needs no second half.
+    const uint64_t need = b->chunks.size() > 1 ? 2 * b->max_ws : b->max_ws;
+    if (need > ctx->ws_cap)
     {
-        // two halves: chunk i uses half (i & 1) so that trace(i) can overlap fill(i + 1)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
         if (ctx->workspace)
             HIP_TRY(ctx, hipFree(ctx->workspace));
         ctx->workspace = nullptr;
         ctx->ws_cap = 0;
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->workspace, 2 * b->max_ws));
-        ctx->ws_cap = 2 * b->max_ws;
+        // batches of one workflow differ by a few percent: one eighth of headroom spares the next, slightly larger one a
+        // second multi-GiB allocation (each costs up to a second)
+        uint64_t want = std::min<uint64_t>(need + need / 8, std::max<uint64_t>(ctx->ws_limit, need));
+        want = align_up(want, 512);
+        if (hipMalloc((void**)&ctx->workspace, want) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            want = align_up(need, 512);
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->workspace, want));
+        }
+        ctx->ws_cap = want;
     }
     if (b->max_scratch > ctx->ops_scratch_cap)
     {
@@ -809,9 +821,15 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const pg_graphs* G = b->graphs;
     {
+        const auto t0 = std::chrono::steady_clock::now();
+        const uint64_t cap0 = ctx->ws_cap;
         const pg_status ws = ensure_ctx_workspace(ctx, b);
         if (ws != PG_OK)
             return ws;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ctx->ws_cap != cap0 && std::getenv("PG_BATCH_TIMING"))
+            fprintf(stderr, "[pg_batch_align] workspace %.2f -> %.2f GiB (%zu chunk(s) of up to %.2f GiB) in %.1f ms\n",
+                    cap0 / 1073741824.0, ctx->ws_cap / 1073741824.0, b->chunks.size(), b->max_ws / 1073741824.0, ms);
     }
     HIP_TRY(ctx, pg_stage_begin(ctx, b));
     if (!(flags & PG_AF_KEEP_RESULTS) || (flags == PG_AF_ALL))
@@ -819,7 +837,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     const bool revg = (flags & PG_AF_REVERSE_GRAPH) != 0;
     // Chunk pipeline on two streams: fill(i) runs on `stream`, pick+trace(i) on `stream2`; chunk i uses workspace
     // half (i & 1), so the latency-bound traceback of chunk i overlaps the VALU-bound fill of chunk i+1.
-    const uint64_t half = ctx->ws_cap / 2;
+    const uint64_t half = (ctx->ws_cap / 2) & ~(uint64_t)255;  // keeps the 256-byte alignment of the trace rows
     std::vector<hipEvent_t> trace_done;
     {
         // the trace stream must see everything queued on the main stream so far (memsets, uploads, path stage)

@@ -124,8 +124,9 @@ struct Parameters
     // keep the reads of a site as flat arrays instead of common::Read objects (several times less host work); switched off
     // automatically when output_alignments needs the per-read records
     bool packed_reads = true;
-    size_t sites_per_batch = 1024;   // (graph, sample) pairs per device batch; bounds host memory and sets the pipeline grain
-    int lanes = 4;                   // chunks in flight: each lane carries one chunk through all stages with threads / lanes workers
+    size_t sites_per_batch = 512;    // (graph, sample) pairs per device batch; bounds host memory and sets the pipeline grain
+    int lanes = 0;                   // chunks in flight: each lane carries one chunk through all stages with threads / lanes
+                                     // workers; 0 = one lane per four threads, at most eight
     paragraph::Timings* timings = nullptr;
 };
 

@@ -826,7 +826,8 @@ std::vector<Json> genotypeGraphs(
     // genotypes) with its share of the host threads.  The device part of SiteBatcher::run() is serialised by the device
     // mutex; everything else of different chunks overlaps -- one lane extracts while another is on the device and a third
     // writes documents.
-    const size_t lanes = std::max<size_t>(1, std::min<size_t>((size_t)std::max(parameters.lanes, 1), n_chunks));
+    const int lanes_wanted = parameters.lanes > 0 ? parameters.lanes : std::min(8, std::max(1, parameters.threads / 4));
+    const size_t lanes = std::max<size_t>(1, std::min<size_t>((size_t)lanes_wanted, n_chunks));
     const int lane_threads = std::max(1, parameters.threads / (int)lanes);
     paragraph::Timings lane_timings_total;
     std::mutex timings_mutex;

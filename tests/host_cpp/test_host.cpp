@@ -10,6 +10,7 @@
 #include <iostream>
 #include <list>
 #include <random>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -652,6 +653,108 @@ static void testSiteBatcherFullCascade()
     EXPECT_EQ((uint64_t)(b.size() - k), batcher.counts(0).bad_align + batcher.counts(0).nonuniq);
 }
 
+// Batches of different threads overlap on the device (uploads / downloads beside another batch's kernels, pooled batch
+// objects, one shared workspace): every batcher must reproduce what it produced alone.
+static void testConcurrentBatchers()
+{
+    const int n_batchers = 6, n_rounds = 4;
+    struct Job
+    {
+        std::vector<std::unique_ptr<Graph>> graphs;
+        std::vector<std::vector<p_Read>> reads;
+    };
+    std::vector<Job> jobs(n_batchers);
+    std::mt19937_64 rng(4711);
+    auto rnd = [&](size_t n) {
+        std::string s(n, 'A');
+        for (auto& c : s)
+            c = "ACGT"[rng() % 4];
+        return s;
+    };
+    for (int j = 0; j < n_batchers; ++j)
+    {
+        const int n_sites = 3 + j * 5;
+        for (int k = 0; k < n_sites; ++k)
+        {
+            const std::string l = rnd(120 + rng() % 80), d = rnd(20 + rng() % 200), r = rnd(120 + rng() % 80);
+            jobs[j].graphs.emplace_back(new Graph(deletionGraph(l.c_str(), d.c_str(), r.c_str())));
+            const std::string hap[2] = { l + d + r, l + r };
+            std::vector<p_Read> reads;
+            const int n_reads = 40 + (int)(rng() % 120);
+            const size_t len = (j == 2) ? 250 : (j == 4 ? 300 : 100);  // byte, long-byte and 16-bit kernels side by side
+            for (int i = 0; i < n_reads; ++i)
+            {
+                const std::string& h = hap[rng() & 1];
+                if (h.size() <= len)
+                    continue;
+                std::string q = h.substr(rng() % (h.size() - len), len);
+                for (size_t e = rng() % 60; e < q.size(); e += 20 + rng() % 60)
+                    q[e] = "ACGT"[rng() % 4];
+                if (rng() & 1)
+                    q = revComp(q);
+                reads.emplace_back(new Read("f" + std::to_string(i / 2), q, std::string(q.size(), '#')));
+            }
+            jobs[j].reads.push_back(std::move(reads));
+        }
+    }
+    auto snapshot = [&](int j) {
+        // a fresh copy of the reads each time: run() rewrites them
+        std::vector<std::vector<p_Read>> mine(jobs[j].reads.size());
+        for (size_t k = 0; k < mine.size(); ++k)
+            for (auto const& r : jobs[j].reads[k])
+                mine[k].emplace_back(new Read(r->fragment_id(), r->bases(), r->quals()));
+        paragraph::SiteBatcher batcher;
+        for (size_t k = 0; k < mine.size(); ++k)
+            batcher.addSite(jobs[j].graphs[k].get(), &mine[k]);
+        paragraph::BatchParameters prm;
+        prm.path_sequence_matching = (j % 2) == 1;
+        batcher.run(prm);
+        std::string out;
+        for (size_t k = 0; k < mine.size(); ++k)
+        {
+            auto const& c = batcher.counts(k);
+            out += "|" + std::to_string(c.aligned) + "," + std::to_string(c.mapped) + "," + std::to_string(c.bad_align) + ","
+                + std::to_string(c.nonuniq);
+            for (auto const& kv : c.by_edge)
+                out += ";" + kv.first + "=" + std::to_string(kv.second.count) + "/" + std::to_string(kv.second.fwd) + "/"
+                    + std::to_string(kv.second.rev);
+            for (auto const& kv : c.by_sequence)
+                out += ";" + kv.first + "=" + std::to_string(kv.second.count);
+            for (auto const& r : mine[k])
+                out += ":" + r->graph_cigar() + "@" + std::to_string(r->graph_pos());
+        }
+        return out;
+    };
+    std::vector<std::string> alone(n_batchers);
+    for (int j = 0; j < n_batchers; ++j)
+        alone[j] = snapshot(j);
+    EXPECT_TRUE(alone[0].size() > 100);
+    for (int round = 0; round < n_rounds; ++round)
+    {
+        std::vector<std::string> together(n_batchers);
+        std::vector<std::string> errors(n_batchers);
+        std::vector<std::thread> threads;
+        for (int j = 0; j < n_batchers; ++j)
+            threads.emplace_back([&, j] {
+                try
+                {
+                    together[j] = snapshot(j);
+                }
+                catch (std::exception const& e)
+                {
+                    errors[j] = e.what();
+                }
+            });
+        for (auto& t : threads)
+            t.join();
+        for (int j = 0; j < n_batchers; ++j)
+        {
+            EXPECT_EQ(errors[j], std::string());
+            EXPECT_TRUE(together[j] == alone[j]);
+        }
+    }
+}
+
 int main()
 {
     try
@@ -659,6 +762,7 @@ int main()
         testSiteToGenotype();
         testSiteBatcherPathStage();
         testSiteBatcherFullCascade();
+        testConcurrentBatchers();
         testKlibAligner();
         testKmerAligner();
         testPathAligner();

@@ -20,6 +20,7 @@
 #include <chrono>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/paragraph_amd.h"
@@ -39,6 +40,112 @@ pg_status pg_fail(pg_ctx* ctx, pg_status st, const std::string& msg)
 }
 static pg_status fail(pg_ctx* ctx, pg_status st, const std::string& msg) { return pg_fail(ctx, st, msg); }
 static void recycle_sync_events(pg_ctx* ctx);
+
+
+// ---------------------------------------------------------------------------------------------------
+// cache of idle device blocks (pg_internal.h)
+// ---------------------------------------------------------------------------------------------------
+namespace
+{
+struct DevCache
+{
+    std::mutex m;
+    std::unordered_map<size_t, std::vector<void*>> idle;  // by class size
+    std::unordered_map<void*, size_t> class_of;           // every block that came from pg_dev_alloc
+    size_t idle_bytes = 0;
+};
+const size_t PG_DEV_CACHE_MAX_IDLE = 8ull << 30;
+DevCache& dev_cache()
+{
+    static DevCache* caches = new DevCache[64];  // one per device ordinal; never torn down (like the HIP runtime itself)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return caches[dev & 63];
+}
+size_t class_size(size_t bytes)
+{
+    size_t c = 256;
+    while (c < bytes)
+        c <<= 1;
+    if (c >= 2048)
+    {
+        const size_t step = c / 16;  // eight classes between c / 2 and c
+        c = (bytes + step - 1) / step * step;
+    }
+    return c;
+}
+}  // namespace
+
+hipError_t pg_dev_alloc(void** p, size_t bytes)
+{
+    DevCache& dc = dev_cache();
+    const size_t c = class_size(std::max<size_t>(bytes, 1));
+    {
+        std::lock_guard<std::mutex> lock(dc.m);
+        auto it = dc.idle.find(c);
+        if (it != dc.idle.end() && !it->second.empty())
+        {
+            *p = it->second.back();
+            it->second.pop_back();
+            dc.idle_bytes -= c;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, c);
+    if (e != hipSuccess)
+    {
+        (void)hipGetLastError();
+        pg_dev_cache_release();  // idle blocks may be what is in the way
+        e = hipMalloc(p, c);
+    }
+    if (e == hipSuccess)
+    {
+        std::lock_guard<std::mutex> lock(dc.m);
+        dc.class_of[*p] = c;
+    }
+    return e;
+}
+
+hipError_t pg_dev_free(void* p)
+{
+    if (!p)
+        return hipSuccess;
+    DevCache& dc = dev_cache();
+    {
+        std::lock_guard<std::mutex> lock(dc.m);
+        auto it = dc.class_of.find(p);
+        if (it != dc.class_of.end() && dc.idle_bytes + it->second <= PG_DEV_CACHE_MAX_IDLE)
+        {
+            dc.idle[it->second].push_back(p);
+            dc.idle_bytes += it->second;
+            return hipSuccess;
+        }
+        if (it != dc.class_of.end())
+            dc.class_of.erase(it);
+    }
+    return hipFree(p);
+}
+
+void pg_dev_cache_release()
+{
+    DevCache& dc = dev_cache();
+    std::vector<void*> blocks;
+    {
+        std::lock_guard<std::mutex> lock(dc.m);
+        for (auto& kv : dc.idle)
+        {
+            for (void* p : kv.second)
+            {
+                blocks.push_back(p);
+                dc.class_of.erase(p);
+            }
+            kv.second.clear();
+        }
+        dc.idle_bytes = 0;
+    }
+    for (void* p : blocks)
+        (void)hipFree(p);
+}
 
 extern "C" const char* pg_strerror(pg_status st)
 {
@@ -111,6 +218,7 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
         (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream_copy)
         (void)hipStreamDestroy(ctx->stream_copy);
+    pg_dev_cache_release();
     delete ctx;
 }
 
@@ -429,7 +537,7 @@ extern "C" pg_status pg_graphs_upload(
     }
     auto up_vec = [&](auto& vec, auto** dptr) -> hipError_t {
         using T = typename std::remove_reference<decltype(vec)>::type::value_type;
-        hipError_t e = hipMalloc((void**)dptr, vec.size() * sizeof(T));
+        hipError_t e = pg_dev_alloc((void**)dptr, vec.size() * sizeof(T));
         if (e != hipSuccess)
             return e;
         return hipMemcpyAsync(*dptr, vec.data(), vec.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream_copy);
@@ -464,18 +572,18 @@ extern "C" void pg_graphs_destroy(pg_ctx* ctx, pg_graphs* G)
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    (void)hipFree(G->d_graphs);
-    (void)hipFree(G->d_nodes);
-    (void)hipFree(G->d_preds);
-    (void)hipFree(G->d_colmeta);
-    (void)hipFree(G->d_seqchars);
-    (void)hipFree(G->d_cnt_graphs);
-    (void)hipFree(G->d_cnt_pred_off);
-    (void)hipFree(G->d_cnt_pred);
-    (void)hipFree(G->d_cnt_node_len);
-    (void)hipFree(G->d_label_mask);
-    (void)hipFree(G->d_out_mask);
-    (void)hipFree(G->d_in_mask);
+    (void)pg_dev_free(G->d_graphs);
+    (void)pg_dev_free(G->d_nodes);
+    (void)pg_dev_free(G->d_preds);
+    (void)pg_dev_free(G->d_colmeta);
+    (void)pg_dev_free(G->d_seqchars);
+    (void)pg_dev_free(G->d_cnt_graphs);
+    (void)pg_dev_free(G->d_cnt_pred_off);
+    (void)pg_dev_free(G->d_cnt_pred);
+    (void)pg_dev_free(G->d_cnt_node_len);
+    (void)pg_dev_free(G->d_label_mask);
+    (void)pg_dev_free(G->d_out_mask);
+    (void)pg_dev_free(G->d_in_mask);
     pg_path_index_free(G->path_index);
     pg_path_index_free(G->filter_index);
     pg_kmer_index_free(G->kmer_index);
@@ -505,26 +613,26 @@ extern "C" pg_status pg_batch_create(pg_ctx* ctx, pg_batch** out)
 
 static void batch_free_device(pg_batch* b)
 {
-    (void)hipFree(b->d_base_off);
-    (void)hipFree(b->d_bases);
-    (void)hipFree(b->d_items);
-    (void)hipFree(b->d_fillsum);
-    (void)hipFree(b->d_results);
-    (void)hipFree(b->d_ops);
-    (void)hipFree(b->d_ops_counter);
-    (void)hipFree(b->d_graph_of_read);
-    (void)hipFree(b->d_path_flags);
+    (void)pg_dev_free(b->d_base_off);
+    (void)pg_dev_free(b->d_bases);
+    (void)pg_dev_free(b->d_items);
+    (void)pg_dev_free(b->d_fillsum);
+    (void)pg_dev_free(b->d_results);
+    (void)pg_dev_free(b->d_ops);
+    (void)pg_dev_free(b->d_ops_counter);
+    (void)pg_dev_free(b->d_graph_of_read);
+    (void)pg_dev_free(b->d_path_flags);
     b->d_path_flags = nullptr;
-    (void)hipFree(b->d_active);
+    (void)pg_dev_free(b->d_active);
     b->d_active = nullptr;
     b->has_active = false;
-    (void)hipFree(b->d_support);
-    (void)hipFree(b->d_path);
-    (void)hipFree(b->d_path_counter);
-    (void)hipFree(b->d_frag_off);
-    (void)hipFree(b->d_frag_reads);
-    (void)hipFree(b->d_is_rev);
-    (void)hipFree(b->d_counts);
+    (void)pg_dev_free(b->d_support);
+    (void)pg_dev_free(b->d_path);
+    (void)pg_dev_free(b->d_path_counter);
+    (void)pg_dev_free(b->d_frag_off);
+    (void)pg_dev_free(b->d_frag_reads);
+    (void)pg_dev_free(b->d_is_rev);
+    (void)pg_dev_free(b->d_counts);
     b->d_graph_of_read = nullptr;
     b->d_support = nullptr;
     b->d_path = nullptr;
@@ -669,11 +777,11 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
     if (items.size() > b->cap_items)
     {
         HIP_TRY(ctx, pg_batch_wait(ctx, b));  // kernels of an earlier use of this batch may still read them
-        (void)hipFree(b->d_items);
-        (void)hipFree(b->d_fillsum);
+        (void)pg_dev_free(b->d_items);
+        (void)pg_dev_free(b->d_fillsum);
         b->cap_items = std::max<size_t>(items.size(), 2);
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_items, b->cap_items * sizeof(PgWorkItem)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_fillsum, b->cap_items * PG_GROUPS * 2 * sizeof(PgFillSummary)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_items, b->cap_items * sizeof(PgWorkItem)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_fillsum, b->cap_items * PG_GROUPS * 2 * sizeof(PgFillSummary)));
     }
     if (!items.empty())
         HIP_TRY(ctx, hipMemcpyAsync(b->d_items, items.data(), items.size() * sizeof(PgWorkItem), hipMemcpyHostToDevice, cs));
@@ -703,6 +811,7 @@ static pg_status ensure_ctx_workspace(pg_ctx* ctx, const pg_batch* b)
         if (hipMalloc((void**)&ctx->workspace, want) != hipSuccess)
         {
             (void)hipGetLastError();
+            pg_dev_cache_release();  // idle blocks of dropped graph sets / batches may be what is in the way
             want = align_up(need, 512);
             HIP_TRY(ctx, hipMalloc((void**)&ctx->workspace, want));
         }
@@ -774,14 +883,14 @@ extern "C" pg_status pg_batch_upload(
         b->cap_reads = n_reads + 1;
         b->cap_bases = std::max<size_t>(n_bases, 1);
         b->ops_cap = std::max<uint64_t>(ops_total, 1);
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_base_off, b->cap_reads * sizeof(uint32_t)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_bases, b->cap_bases));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_results, std::max<size_t>(n_reads, 1) * sizeof(pg_result)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_ops, b->ops_cap * sizeof(pg_op)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_ops_counter, sizeof(unsigned long long)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_graph_of_read, b->cap_reads * sizeof(uint32_t)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_path_flags, b->cap_reads));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_active, b->cap_reads));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_base_off, b->cap_reads * sizeof(uint32_t)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_bases, b->cap_bases));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_results, std::max<size_t>(n_reads, 1) * sizeof(pg_result)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_ops, b->ops_cap * sizeof(pg_op)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_ops_counter, sizeof(unsigned long long)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_graph_of_read, b->cap_reads * sizeof(uint32_t)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_path_flags, b->cap_reads));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_active, b->cap_reads));
     }
     if (n_reads)
     {

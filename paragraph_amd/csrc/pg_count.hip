@@ -485,7 +485,7 @@ __global__ __launch_bounds__(FRAG_BLOCK) void pg_fragment_kernel(CountArgs a)
 
 template <typename T> hipError_t dev_upload(const std::vector<T>& v, T** d, hipStream_t s)
 {
-    hipError_t e = hipMalloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(T));
+    hipError_t e = pg_dev_alloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(T));
     if (e != hipSuccess || v.empty())
         return e;
     return hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
@@ -541,13 +541,15 @@ extern "C" pg_status pg_graphs_set_labels(
         cg[g].seq_base = G->h_seq_off[g];
         G->h_seq_off[g + 1] = G->h_seq_off[g] + (nl <= PG_MAX_SEQ_TABLE_LABELS ? (1ull << nl) : 0);
     }
-    (void)hipFree(G->d_cnt_graphs);
-    (void)hipFree(G->d_cnt_pred_off);
-    (void)hipFree(G->d_cnt_pred);
-    (void)hipFree(G->d_cnt_node_len);
-    (void)hipFree(G->d_label_mask);
-    (void)hipFree(G->d_out_mask);
-    (void)hipFree(G->d_in_mask);
+    if (G->d_cnt_graphs)  // labels set again: kernels of an earlier batch may still read the old tables
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    (void)pg_dev_free(G->d_cnt_graphs);
+    (void)pg_dev_free(G->d_cnt_pred_off);
+    (void)pg_dev_free(G->d_cnt_pred);
+    (void)pg_dev_free(G->d_cnt_node_len);
+    (void)pg_dev_free(G->d_label_mask);
+    (void)pg_dev_free(G->d_out_mask);
+    (void)pg_dev_free(G->d_in_mask);
     HIP_TRY(ctx, dev_upload(cg, &G->d_cnt_graphs, ctx->stream_copy));
     HIP_TRY(ctx, dev_upload(G->h_pred_off, &G->d_cnt_pred_off, ctx->stream_copy));
     HIP_TRY(ctx, dev_upload(G->h_pred, &G->d_cnt_pred, ctx->stream_copy));
@@ -615,23 +617,25 @@ extern "C" pg_status pg_batch_set_fragments(
     b->n_frags = n_frags;
     if (n > b->cap_count_reads || !b->d_support)  // also for a batch without reads: the later calls expect the buffers
     {
-        (void)hipFree(b->d_support);
-        (void)hipFree(b->d_frag_reads);
-        (void)hipFree(b->d_is_rev);
-        (void)hipFree(b->d_path);
+        HIP_TRY(ctx, pg_batch_wait(ctx, b));  // an earlier use of this batch may still run
+        (void)pg_dev_free(b->d_support);
+        (void)pg_dev_free(b->d_frag_reads);
+        (void)pg_dev_free(b->d_is_rev);
+        (void)pg_dev_free(b->d_path);
         b->cap_count_reads = n;
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_support, std::max<size_t>(n, 1) * sizeof(pg_read_support)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_frag_reads, std::max<size_t>(n, 1) * sizeof(uint32_t)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_is_rev, std::max<size_t>(n, 1)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_path, std::max<uint64_t>(b->ops_cap, 1) * sizeof(uint32_t)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_support, std::max<size_t>(n, 1) * sizeof(pg_read_support)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_frag_reads, std::max<size_t>(n, 1) * sizeof(uint32_t)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_is_rev, std::max<size_t>(n, 1)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_path, std::max<uint64_t>(b->ops_cap, 1) * sizeof(uint32_t)));
     }
     if (!b->d_path_counter)
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_path_counter, sizeof(unsigned long long)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_path_counter, sizeof(unsigned long long)));
     if (n_frags + 1 > b->cap_frags)
     {
-        (void)hipFree(b->d_frag_off);
+        HIP_TRY(ctx, pg_batch_wait(ctx, b));
+        (void)pg_dev_free(b->d_frag_off);
         b->cap_frags = n_frags + 1;
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_frag_off, b->cap_frags * sizeof(uint32_t)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_frag_off, b->cap_frags * sizeof(uint32_t)));
     }
     if (n)
     {
@@ -672,9 +676,10 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     {
         if (lay.n_counters > b->cap_counts)
         {
-            (void)hipFree(b->d_counts);
+            HIP_TRY(ctx, pg_batch_wait(ctx, b));
+            (void)pg_dev_free(b->d_counts);
             b->cap_counts = lay.n_counters;
-            HIP_TRY(ctx, hipMalloc((void**)&b->d_counts, lay.n_counters * sizeof(uint32_t)));
+            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_counts, lay.n_counters * sizeof(uint32_t)));
         }
         counts = b->d_counts;
         HIP_TRY(ctx, hipMemsetAsync(counts, 0, lay.n_counters * sizeof(uint32_t), ctx->stream));

@@ -140,6 +140,14 @@ hipError_t pg_stage_end(pg_ctx* ctx, pg_batch* b);
 hipError_t pg_batch_wait(pg_ctx* ctx, pg_batch* b);
 
 
+// Device memory of graph sets and batches comes from a per-device cache of idle blocks (size classes of an eighth of an
+// octave): hipFree synchronises the whole device and hipMalloc takes a driver round trip, and a workflow creates and drops
+// a dozen small tables per batch.  A block must be idle on the device when it is handed back (callers wait for the owning
+// batch / the compute stream first); the cache keeps at most PG_DEV_CACHE_MAX_IDLE bytes and releases the rest.
+hipError_t pg_dev_alloc(void** p, size_t bytes);
+hipError_t pg_dev_free(void* p);
+void pg_dev_cache_release();  // hipFree of every idle block of the current device
+
 pg_status pg_fail(pg_ctx* ctx, pg_status st, const std::string& msg);
 
 #define HIP_TRY(ctx, call)                                                                                     \

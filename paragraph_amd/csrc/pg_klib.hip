@@ -797,21 +797,21 @@ void pg_klib_index_free(pg_klib_index* ix)
 {
     if (!ix)
         return;
-    (void)hipFree(ix->d_graphs);
-    (void)hipFree(ix->d_paths);
-    (void)hipFree(ix->d_pathseq);
-    (void)hipFree(ix->d_pathcode);
-    (void)hipFree(ix->d_starts);
-    (void)hipFree(ix->d_items);
-    (void)hipFree(ix->d_cigars);
-    (void)hipFree(ix->d_z);
-    (void)hipFree(ix->d_error);
+    (void)pg_dev_free(ix->d_graphs);
+    (void)pg_dev_free(ix->d_paths);
+    (void)pg_dev_free(ix->d_pathseq);
+    (void)pg_dev_free(ix->d_pathcode);
+    (void)pg_dev_free(ix->d_starts);
+    (void)pg_dev_free(ix->d_items);
+    (void)pg_dev_free(ix->d_cigars);
+    (void)pg_dev_free(ix->d_z);
+    (void)pg_dev_free(ix->d_error);
     delete ix;
 }
 
 template <typename T> static hipError_t upl(const std::vector<T>& v, T** d, hipStream_t s)
 {
-    hipError_t e = hipMalloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(T));
+    hipError_t e = pg_dev_alloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(T));
     if (e != hipSuccess || v.empty())
         return e;
     return hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
@@ -884,7 +884,7 @@ extern "C" pg_status pg_graphs_build_klib_index(
     if (e == hipSuccess) e = upl(pathseq, &ix->d_pathseq, ctx->stream_copy);
     if (e == hipSuccess) e = upl(pathcode, &ix->d_pathcode, ctx->stream_copy);
     if (e == hipSuccess) e = upl(starts, &ix->d_starts, ctx->stream_copy);
-    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_error, sizeof(uint32_t));
+    if (e == hipSuccess) e = pg_dev_alloc((void**)&ix->d_error, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(ix->d_error, 0, sizeof(uint32_t), ctx->stream_copy);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream_copy);
     if (e != hipSuccess)
@@ -902,10 +902,10 @@ template <typename T> static pg_status grow(pg_ctx* ctx, T** d, size_t* cap, siz
     if (need <= *cap)
         return PG_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(*d);
+    (void)pg_dev_free(*d);
     *d = nullptr;
     *cap = 0;
-    HIP_TRY(ctx, hipMalloc((void**)d, need * sizeof(T)));
+    HIP_TRY(ctx, pg_dev_alloc((void**)d, need * sizeof(T)));
     *cap = need;
     return PG_OK;
 }

@@ -509,18 +509,18 @@ void pg_kmer_index_free(pg_kmer_index* ix)
 {
     if (!ix)
         return;
-    (void)hipFree(ix->d_graphs);
-    (void)hipFree(ix->d_paths);
-    (void)hipFree(ix->d_pathseq);
-    (void)hipFree(ix->d_starts);
-    (void)hipFree(ix->d_kmers);
-    (void)hipFree(ix->d_kpos);
+    (void)pg_dev_free(ix->d_graphs);
+    (void)pg_dev_free(ix->d_paths);
+    (void)pg_dev_free(ix->d_pathseq);
+    (void)pg_dev_free(ix->d_starts);
+    (void)pg_dev_free(ix->d_kmers);
+    (void)pg_dev_free(ix->d_kpos);
     delete ix;
 }
 
 template <typename T> static hipError_t upk(const std::vector<T>& v, T** d, hipStream_t s)
 {
-    hipError_t e = hipMalloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(T));
+    hipError_t e = pg_dev_alloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(T));
     if (e != hipSuccess || v.empty())
         return e;
     return hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);

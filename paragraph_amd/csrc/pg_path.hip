@@ -335,20 +335,20 @@ void pg_path_index_free(pg_path_index* ix)
 {
     if (!ix)
         return;
-    (void)hipFree(ix->d_graphs);
-    (void)hipFree(ix->d_table);
-    (void)hipFree(ix->d_pool);
-    (void)hipFree(ix->d_node_off);
-    (void)hipFree(ix->d_raw);
-    (void)hipFree(ix->d_succ_off);
-    (void)hipFree(ix->d_succ);
-    (void)hipFree(ix->d_node_uniq);
+    (void)pg_dev_free(ix->d_graphs);
+    (void)pg_dev_free(ix->d_table);
+    (void)pg_dev_free(ix->d_pool);
+    (void)pg_dev_free(ix->d_node_off);
+    (void)pg_dev_free(ix->d_raw);
+    (void)pg_dev_free(ix->d_succ_off);
+    (void)pg_dev_free(ix->d_succ);
+    (void)pg_dev_free(ix->d_node_uniq);
     delete ix;
 }
 
 template <typename T> static hipError_t up(const std::vector<T>& v, T** d, hipStream_t s)
 {
-    hipError_t e = hipMalloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(T));
+    hipError_t e = pg_dev_alloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(T));
     if (e != hipSuccess || v.empty())
         return e;
     return hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);

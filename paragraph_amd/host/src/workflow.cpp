@@ -860,6 +860,16 @@ std::vector<Json> genotypeGraphs(
             t_mark = t;
         };
         paragraph::Timings mine;
+        std::thread reaper;
+        struct JoinOnExit
+        {
+            std::thread& t;
+            ~JoinOnExit()
+            {
+                if (t.joinable())
+                    t.join();
+            }
+        } join_reaper{ reaper };
         paragraph::Parameters site_parameters = siteParameters(parameters);
         site_parameters.threads = lane_threads;
         site_parameters.timings = parameters.timings ? &mine : nullptr;
@@ -913,12 +923,21 @@ std::vector<Json> genotypeGraphs(
                 });
                 phase(c, "genotypes");
                 const double t_release = now();
-                // hundreds of thousands of small strings: give them back on all of the lane's threads
-                parallelFor(chunk->reads.size(), lane_threads, [&](size_t i) { common::ReadBuffer().swap(chunk->reads[i]); }, 16);
-                parallelFor(documents.size(), lane_threads, [&](size_t i) { documents[i] = Json(); }, 16);
-                phase(c, "release");
+                // hundreds of thousands of small strings and JSON nodes go back to the allocator beside the lane's next
+                // chunk (one helper per lane; the previous one has long finished by now)
+                if (reaper.joinable())
+                    reaper.join();
                 mine.load_graphs += chunk->load_s;
                 mine.extract_reads += chunk->extract_s;
+                {
+                    Chunk* old_chunk = chunk.release();
+                    auto* old_documents = new std::vector<Json>(std::move(documents));
+                    reaper = std::thread([old_chunk, old_documents] {
+                        delete old_documents;
+                        delete old_chunk;
+                    });
+                }
+                phase(c, "release");
                 mine.genotypes += t_release - t_genotype;
                 mine.release += now() - t_release;
                 mine.batches += 1;

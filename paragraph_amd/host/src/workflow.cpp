@@ -821,13 +821,33 @@ std::vector<Json> genotypeGraphs(
     if (n_graphs == 0 || n_samples == 0)
         return genotypes;
     const size_t per_batch = std::max<size_t>(1, parameters.sites_per_batch / n_samples);
-    const size_t n_chunks = (n_graphs + per_batch - 1) / per_batch;
+    const size_t n_even_chunks = (n_graphs + per_batch - 1) / per_batch;
     // Lanes: each lane takes the next chunk and carries it through every stage (load + extract, device batch, documents,
     // genotypes) with its share of the host threads.  The device part of SiteBatcher::run() is serialised by the device
     // mutex; everything else of different chunks overlaps -- one lane extracts while another is on the device and a third
     // writes documents.
     const int lanes_wanted = parameters.lanes > 0 ? parameters.lanes : std::min(8, std::max(1, parameters.threads / 4));
-    const size_t lanes = std::max<size_t>(1, std::min<size_t>((size_t)lanes_wanted, n_chunks));
+    const size_t lanes = std::max<size_t>(1, std::min<size_t>((size_t)lanes_wanted, n_even_chunks));
+    // Chunk boundaries.  All lanes start at once, so with equal chunks the device would see nothing while every lane
+    // prepares its first chunk and then all first batches together: the first round is staggered (lane k takes (k+1)/lanes
+    // of a chunk), and the last chunks shrink (a quarter of a chunk at least) so that the lanes finish together.
+    std::vector<std::pair<size_t, size_t>> chunk_ranges;
+    {
+        size_t g = 0;
+        const bool shaped = lanes > 1 && n_even_chunks > lanes;
+        for (size_t k = 0; g < n_graphs; ++k)
+        {
+            size_t size = per_batch;
+            if (shaped && k < lanes)
+                size = std::max<size_t>(1, per_batch * (k + 1) / lanes);
+            else if (shaped)
+                size = std::min(per_batch, std::max<size_t>(std::max<size_t>(1, per_batch / 4), (n_graphs - g) / lanes));
+            size = std::min(size, n_graphs - g);
+            chunk_ranges.emplace_back(g, g + size);
+            g += size;
+        }
+    }
+    const size_t n_chunks = chunk_ranges.size();
     const int lane_threads = std::max(1, parameters.threads / (int)lanes);
     paragraph::Timings lane_timings_total;
     std::mutex timings_mutex;
@@ -880,7 +900,7 @@ std::vector<Json> genotypeGraphs(
                 const size_t c = next_chunk.fetch_add(1);
                 if (c >= n_chunks || failed.load())
                     break;
-                const size_t g0 = c * per_batch, g1 = std::min(n_graphs, g0 + per_batch), n_here = g1 - g0;
+                const size_t g0 = chunk_ranges[c].first, g1 = chunk_ranges[c].second, n_here = g1 - g0;
                 t_mark = now();
                 std::unique_ptr<Chunk> chunk = prepareChunk(parameters, graph_paths, reference_path, samples, g0, g1, lane_threads, &fasta);
                 phase(c, "prepare");

@@ -23,7 +23,9 @@ extern "C" {
  *   options_json           NULL / "" or an object with any of: "threads", "lanes", "sites_per_batch", "max_reads",
  *                          "bad_align_frac", "path_sequence_matching", "kmer_sequence_matching", "klib_sequence_matching",
  *                          "bad_align_uniq_kmer_len", "packed_reads"
- *                          (grmpy's option names and defaults, grmpy/Parameters.hh:30-74)
+ *                          (grmpy's option names and defaults, grmpy/Parameters.hh:30-74; "sites_per_batch" = (graph,
+ *                          sample) pairs per device batch, default 512; "lanes" = batches in flight, default one per
+ *                          four threads, at most 8)
  *   error/error_cap        receives the message when the call fails (may be NULL)
  *
  * Returns 0 on success, 1 on failure (nothing usable is written then).

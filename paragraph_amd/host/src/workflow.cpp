@@ -772,7 +772,7 @@ std::unique_ptr<Chunk> prepareChunk(
         {
             // a worker takes runs of neighbouring graphs: sites that are close on the genome share BGZF blocks, which the
             // reader keeps inflated
-            const size_t kRun = 8;
+            const size_t kRun = std::max<size_t>(8, std::min<size_t>(32, n_tasks / (workers * 4)));
             for (;;)
             {
                 const size_t first = next.fetch_add(kRun);

@@ -429,14 +429,14 @@ std::vector<Json> countGraphs(
 
     std::vector<Json> documents(graph_paths.size());
     sites_per_batch = std::max<size_t>(1, sites_per_batch);
-    for (size_t g0 = 0; g0 < graph_paths.size(); g0 += sites_per_batch)
-    {
+    // one chunk of graphs: load + extract, ONE device batch, documents -- with `lane.threads` workers
+    auto processChunk = [&](size_t g0, Parameters const& lane) {
         const size_t n_here = std::min(sites_per_batch, graph_paths.size() - g0);
         std::vector<GraphDescription> graphs(n_here);
         std::vector<PackedSite> packed_reads(packed ? n_here : 0);
         std::vector<common::ReadBuffer> object_reads(packed ? 0 : n_here);
         const size_t kRun = 8;  // neighbouring graphs per grab, see prepareChunk
-        parallelFor((n_here + kRun - 1) / kRun, parameters.threads, [&](size_t run) {
+        parallelFor((n_here + kRun - 1) / kRun, lane.threads, [&](size_t run) {
             std::vector<std::unique_ptr<common::BamReader>> readers;
             for (size_t g = run * kRun; g < std::min(n_here, (run + 1) * kRun); ++g)
             {
@@ -463,7 +463,7 @@ std::vector<Json> countGraphs(
                 sites[g].description = &graphs[g];
                 sites[g].reads = &packed_reads[g];
             }
-            batch = alignAndDisambiguateBatch(parameters, sites);
+            batch = alignAndDisambiguateBatch(lane, sites);
         }
         else
         {
@@ -473,14 +473,60 @@ std::vector<Json> countGraphs(
                 sites[g].description = &graphs[g];
                 sites[g].reads = &object_reads[g];
             }
-            batch = alignAndDisambiguateBatch(parameters, sites);
+            batch = alignAndDisambiguateBatch(lane, sites);
         }
         for (size_t g = 0; g < n_here; ++g)
         {
             batch[g]["bam"] = bam_value;
             documents[g0 + g] = std::move(batch[g]);
         }
+    };
+    // Several chunks: lanes as in grmpy::genotypeGraphs -- one chunk is on the device while others extract reads or write
+    // documents (one lane per four threads, at most eight).
+    const size_t n_chunks = (graph_paths.size() + sites_per_batch - 1) / sites_per_batch;
+    const size_t lanes = std::max<size_t>(1, std::min<size_t>(n_chunks, (size_t)std::min(8, std::max(1, parameters.threads / 4))));
+    if (lanes == 1)
+    {
+        for (size_t c = 0; c < n_chunks; ++c)
+            processChunk(c * sites_per_batch, parameters);
+        return documents;
     }
+    std::atomic<size_t> next_chunk(0);
+    std::atomic<bool> failed(false);
+    std::exception_ptr failure;
+    std::mutex timings_mutex;
+    auto lane_body = [&] {
+        Timings mine;
+        Parameters lane = parameters;
+        lane.threads = std::max(1, parameters.threads / (int)lanes);
+        lane.timings = parameters.timings ? &mine : nullptr;
+        try
+        {
+            for (size_t c = next_chunk.fetch_add(1); c < n_chunks && !failed.load(); c = next_chunk.fetch_add(1))
+                processChunk(c * sites_per_batch, lane);
+        }
+        catch (...)
+        {
+            if (!failed.exchange(true))
+                failure = std::current_exception();
+        }
+        if (parameters.timings)
+        {
+            std::lock_guard<std::mutex> lock(timings_mutex);
+            parameters.timings->device_batch += mine.device_batch;
+            parameters.timings->documents += mine.documents;
+            parameters.timings->sites += mine.sites;
+            parameters.timings->reads += mine.reads;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t l = 1; l < lanes; ++l)
+        pool.emplace_back(lane_body);
+    lane_body();
+    for (auto& t : pool)
+        t.join();
+    if (failure)
+        std::rethrow_exception(failure);
     return documents;
 }
 

@@ -197,6 +197,25 @@ static void testGenotypesSingleSwap(std::string const& dir)
     parameters.sites_per_batch = 2;
     const std::vector<Json> from_objects = grmpy::genotypeGraphs(parameters, { graph, graph, graph }, fasta, samples, gparams);
     CHECK(from_objects.size() == 3 && from_objects[0] == one_by_one && from_objects[2] == one_by_one);
+    // many small chunks on three lanes: the staggered first round and the shrinking last chunks change nothing
+    parameters.packed_reads = true;
+    parameters.lanes = 3;
+    parameters.threads = 6;
+    parameters.sites_per_batch = 4;  // two graphs x two samples per chunk
+    const std::vector<Json> many = grmpy::genotypeGraphs(parameters, std::vector<std::string>(25, graph), fasta, samples, gparams);
+    CHECK(many.size() == 25);
+    for (Json const& document : many)
+        CHECK(document == one_by_one);
+
+    // paragraph::countGraphs: one chunk after the other == chunks on lanes
+    paragraph::Parameters count_parameters;
+    count_parameters.threads = 8;
+    const std::string bam = base + "chrX_graph_typing.bam";
+    const std::vector<Json> one_chunk = paragraph::countGraphs(count_parameters, std::vector<std::string>(7, graph), fasta, { bam });
+    const std::vector<Json> on_lanes = paragraph::countGraphs(count_parameters, std::vector<std::string>(7, graph), fasta, { bam }, {}, "", 2);
+    CHECK(one_chunk.size() == 7 && on_lanes.size() == 7);
+    for (size_t i = 0; i < on_lanes.size() && i < one_chunk.size(); ++i)
+        CHECK(on_lanes[i] == one_chunk[0] && one_chunk[i] == one_chunk[0] && on_lanes[i]["read_counts_by_edge"].size() > 0);
     std::cout << one_by_one["samples"]["SAMPLE2"]["gt"].dump() << "\n";
 }
 

@@ -143,4 +143,9 @@ common::Json countAndGenotype(
 std::vector<common::Json> genotypeGraphs(
     Parameters const& parameters, std::vector<std::string> const& graph_paths, std::string const& reference_path,
     genotyping::Samples const& samples, std::string const& genotyping_parameter_path);
+// the [first, last) graph ranges genotypeGraphs cuts its work into: all lanes start at once, so the first round is staggered
+// (lane k takes (k+1)/lanes of a chunk: the device gets work while the other lanes still prepare) and the last chunks shrink
+// to a quarter of a chunk at least, so that the lanes finish together; plain equal chunks when there is one lane or no
+// more chunks than lanes
+std::vector<std::pair<size_t, size_t>> chunkSchedule(size_t n_graphs, size_t graphs_per_chunk, size_t lanes);
 }  // namespace grmpy

@@ -839,3 +839,33 @@ Json alignmentStatistics(Graph const& graph, SiteReadViews const& views)
     return out;
 }
 }  // namespace paragraph
+
+// ----------------------------------------------------------------------------------------------------------------------
+// chunk schedule of grmpy::genotypeGraphs (no device calls: lives here so that the CPU test programs link it)
+// ----------------------------------------------------------------------------------------------------------------------
+#include "paragraph/Workflow.hh"
+
+namespace grmpy
+{
+std::vector<std::pair<size_t, size_t>> chunkSchedule(size_t n_graphs, size_t graphs_per_chunk, size_t lanes)
+{
+    std::vector<std::pair<size_t, size_t>> ranges;
+    const size_t per_chunk = std::max<size_t>(1, graphs_per_chunk);
+    lanes = std::max<size_t>(1, lanes);
+    const size_t n_even_chunks = (n_graphs + per_chunk - 1) / per_chunk;
+    const bool shaped = lanes > 1 && n_even_chunks > lanes;
+    size_t g = 0;
+    for (size_t k = 0; g < n_graphs; ++k)
+    {
+        size_t size = per_chunk;
+        if (shaped && k < lanes)
+            size = std::max<size_t>(1, per_chunk * (k + 1) / lanes);
+        else if (shaped)
+            size = std::min(per_chunk, std::max<size_t>(std::max<size_t>(1, per_chunk / 4), (n_graphs - g) / lanes));
+        size = std::min(size, n_graphs - g);
+        ranges.emplace_back(g, g + size);
+        g += size;
+    }
+    return ranges;
+}
+}  // namespace grmpy

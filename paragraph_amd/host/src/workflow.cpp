@@ -874,25 +874,7 @@ std::vector<Json> genotypeGraphs(
     // writes documents.
     const int lanes_wanted = parameters.lanes > 0 ? parameters.lanes : std::min(8, std::max(1, parameters.threads / 4));
     const size_t lanes = std::max<size_t>(1, std::min<size_t>((size_t)lanes_wanted, n_even_chunks));
-    // Chunk boundaries.  All lanes start at once, so with equal chunks the device would see nothing while every lane
-    // prepares its first chunk and then all first batches together: the first round is staggered (lane k takes (k+1)/lanes
-    // of a chunk), and the last chunks shrink (a quarter of a chunk at least) so that the lanes finish together.
-    std::vector<std::pair<size_t, size_t>> chunk_ranges;
-    {
-        size_t g = 0;
-        const bool shaped = lanes > 1 && n_even_chunks > lanes;
-        for (size_t k = 0; g < n_graphs; ++k)
-        {
-            size_t size = per_batch;
-            if (shaped && k < lanes)
-                size = std::max<size_t>(1, per_batch * (k + 1) / lanes);
-            else if (shaped)
-                size = std::min(per_batch, std::max<size_t>(std::max<size_t>(1, per_batch / 4), (n_graphs - g) / lanes));
-            size = std::min(size, n_graphs - g);
-            chunk_ranges.emplace_back(g, g + size);
-            g += size;
-        }
-    }
+    const std::vector<std::pair<size_t, size_t>> chunk_ranges = chunkSchedule(n_graphs, per_batch, lanes);
     const size_t n_chunks = chunk_ranges.size();
     const int lane_threads = std::max(1, parameters.threads / (int)lanes);
     paragraph::Timings lane_timings_total;

@@ -25,6 +25,7 @@
 #include "grm/GraphInput.hh"
 #include "paragraph/PackedReads.hh"
 #include "paragraph/Statistics.hh"
+#include "paragraph/Workflow.hh"
 
 using namespace common;
 
@@ -655,6 +656,36 @@ static void testPackedExtraction(std::string const& dir)
     CHECK_THROWS(paragraph::extractPacked(r, { Region("chr", 1, 2) }, 10, 0, not_empty));
 }
 
+static void testChunkSchedule()
+{
+    for (size_t n : { 0u, 1u, 7u, 512u, 513u, 4096u, 10000u })
+        for (size_t per : { 1u, 2u, 64u, 512u })
+            for (size_t lanes : { 1u, 3u, 8u })
+            {
+                const auto ranges = grmpy::chunkSchedule(n, per, lanes);
+                size_t at = 0;
+                for (auto const& r : ranges)
+                {
+                    CHECK(r.first == at && r.second > r.first && r.second - r.first <= per);
+                    at = r.second;
+                }
+                CHECK(at == n);
+                const size_t even = (n + per - 1) / per;
+                if (lanes == 1 || even <= lanes)
+                    CHECK(ranges.size() == even);
+                else
+                {
+                    // staggered first round, then full chunks, then a tail of at least a quarter chunk (but the very last)
+                    for (size_t k = 0; k + 1 < std::min(lanes, ranges.size()); ++k)
+                        CHECK(ranges[k].second - ranges[k].first <= ranges[k + 1].second - ranges[k + 1].first);
+                    for (size_t k = lanes; k + 1 < ranges.size(); ++k)
+                        CHECK(ranges[k].second - ranges[k].first >= std::max<size_t>(1, per / 4));
+                }
+            }
+    const auto ten_k = grmpy::chunkSchedule(10000, 512, 8);
+    CHECK(ten_k[0].second == 64 && ten_k[7].second - ten_k[7].first == 512);
+}
+
 int main(int argc, char** argv)
 {
     if (argc == 4 && std::string(argv[1]) == "--dump-bam")
@@ -708,6 +739,7 @@ int main(int argc, char** argv)
         { "bam-index", [&] { testBamIndexConsistency(dir); } },
         { "extraction", testExtraction },
         { "packed-extraction", [&] { testPackedExtraction(dir); } },
+        { "chunk-schedule", [&] { testChunkSchedule(); } },
         { "graph-input", [&] { testGraphInput(dir); } },
         { "graph-coordinates", testGraphCoordinates },
         { "statistics", testStatistics },

@@ -154,9 +154,25 @@ const char* pg_last_error(const pg_ctx* ctx);
 /* bytes of HBM the ctx may use for traceback state per chunk (default 8 GiB) */
 pg_status pg_ctx_set_workspace_bytes(pg_ctx* ctx, uint64_t bytes);
 pg_status pg_ctx_sync(pg_ctx* ctx);
+/* waits for the compute streams only (stage calls queued so far); uploads / downloads of other batches keep running */
+pg_status pg_ctx_sync_compute(pg_ctx* ctx);
 pg_status pg_ctx_timing_enable(pg_ctx* ctx, int enable);
 pg_status pg_ctx_timing_reset(pg_ctx* ctx);
 pg_status pg_ctx_timing_get(pg_ctx* ctx, pg_timing* out); /* synchronises */
+
+/* ---------------------------------------------------------------------------------------------------
+ * Pinned host staging.  The reference packs a site's reads on worker threads (src/c++/lib/grmpy/AlignSamples.cpp:115-172,
+ * src/c++/lib/common/ReadExtraction.cpp:38-219) into std::vector<p_Read>; the batched form of that hand-over is a set
+ * of flat arrays, and when those live in page-locked memory every copy of pg_batch_upload / pg_batch_set_fragments /
+ * pg_batch_download* is a DMA on the copy stream that overlaps another batch's kernels (double buffering: two sets of
+ * pinned arrays, two pg_batch objects).  Pageable arrays still work -- the runtime then stages through bounce buffers on
+ * the calling thread.  pg_host_alloc'ed memory is visible to every device (portable).
+ * ------------------------------------------------------------------------------------------------- */
+pg_status pg_host_alloc(pg_ctx* ctx, size_t bytes, void** out);
+void pg_host_free(pg_ctx* ctx, void* p);
+/* page-locks / releases memory the caller allocated itself (e.g. the storage of a std::vector that is kept alive) */
+pg_status pg_host_register(pg_ctx* ctx, void* p, size_t bytes);
+pg_status pg_host_unregister(pg_ctx* ctx, void* p);
 
 /*
  * Upload n_graphs variant graphs.  Graph g owns nodes [node_off[g], node_off[g+1]); node ids inside a
@@ -260,6 +276,9 @@ pg_status pg_batch_set_fragments(
  * it; e.g. a torch tensor that is then all-reduced with RCCL), or NULL to use a table owned by the batch
  * (zeroed per call). */
 pg_status pg_batch_count(pg_ctx* ctx, pg_batch* batch, const pg_count_params* params, uint32_t* d_counts);
+/* Zeroes a caller-owned counter table ON THE CTX STREAM, i.e. ordered against the pg_batch_count calls before and after
+ * it (a memset on any other stream is not).  Asynchronous. */
+pg_status pg_counts_zero(pg_ctx* ctx, uint32_t* d_counts, uint64_t n_counters);
 /* Copies the count table (if the batch owns it; pass NULL otherwise), per-read supports and path entries
  * (capacity path_cap entries; *n_path receives the number used) to host memory; synchronises. */
 pg_status pg_batch_download_counts(
@@ -318,6 +337,9 @@ pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* batch, const uint8_t* activ
 /* Renders "<node>[<len><op>...]..." for one read into buf (NUL-terminated); returns the string length
  * (which may be >= cap, in which case the output was truncated). Host-only helper. */
 size_t pg_render_cigar(const pg_result* r, const pg_op* ops, char* buf, size_t cap);
+/* pg_render_cigar for n results into fixed slots of `stride` bytes (slot i at buf + i * stride, NUL-padded to the end of
+ * the slot); PG_ERR_OVERFLOW when a string did not fit its slot (that slot holds the truncated string). Host-only helper. */
+pg_status pg_render_cigars(const pg_result* results, uint64_t n, const pg_op* ops, char* buf, size_t stride);
 
 #ifdef __cplusplus
 }

@@ -131,6 +131,12 @@ class _Base:
         return out
 
 
+# numpy mirror of AlignResult (13 x int32)
+RESULT_NP = np.dtype([("graph_pos", "<i4"), ("score", "<i4"), ("mapq", "<i4"), ("unique", "<i4"), ("returned_reverse", "<i4"),
+                      ("multi", "<i4", (4,)), ("scores", "<i4", (4,)), ("cigar_len", "<i4")])
+assert RESULT_NP.itemsize == C.sizeof(AlignResult)
+
+
 def result_dict(r, cigar):
     return {
         "graph_pos": r.graph_pos,
@@ -142,6 +148,35 @@ def result_dict(r, cigar):
         "scores": [int(x) for x in r.scores],
         "cigar": cigar,
     }
+
+
+def _align_into(self, node_seqs, edges, off, bases, res, cig, threads=1, flags=AF_ALL):
+    """Array form of align_batch for large samples: off = uint32 offsets[n+1], bases = uint8 array, res = RESULT_NP array
+    (n entries), cig = (n, stride) uint8 array or None; both outputs may live in shared memory (they are written in place).
+    Chunk-per-thread inside this process (threads), as Align.cpp:114-156."""
+    seq_off, seq, pred_off, pred = graph_csr(node_seqs, edges)
+    off = np.ascontiguousarray(off, dtype=np.uint32)
+    n = len(off) - 1
+    if off[0] != 0:
+        bases = bases[int(off[0]):int(off[-1])]
+        off = off - off[0]
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    assert res.dtype == RESULT_NP and len(res) >= n and res.flags.c_contiguous
+    stride = 0
+    cig_p = None
+    if cig is not None:
+        assert cig.dtype == np.uint8 and cig.ndim == 2 and len(cig) >= n and cig.flags.c_contiguous
+        stride = cig.shape[1]
+        cig_p = C.cast(cig.ctypes.data, C.c_char_p)
+    u32 = C.c_uint32
+    rc = self._fn("align_batch")(len(node_seqs), _p(seq_off, u32), seq, _p(pred_off, u32), _p(pred, u32), n,
+                                 _p(off, u32), C.cast(bases.ctypes.data, C.c_char_p), flags & 0xFFFFFFFF, threads,
+                                 C.cast(res.ctypes.data, C.POINTER(AlignResult)), cig_p, stride)
+    if rc != 0:
+        raise RuntimeError("%s_align_batch failed: %d" % (self.prefix, rc))
+
+
+_Base.align_into = _align_into
 
 
 class _Graph:

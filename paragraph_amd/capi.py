@@ -46,6 +46,8 @@ EXPORTS = [
     "pg_graphs_seq_offsets", "pg_batch_set_fragments", "pg_batch_count", "pg_batch_download_counts", "pg_graphs_build_path_index",
     "pg_batch_path_align", "pg_batch_download_path_flags", "pg_batch_set_active", "pg_graphs_build_kmer_index",
     "pg_batch_kmer_align", "pg_graphs_build_klib_index", "pg_batch_klib_align", "pg_graphs_klib_error", "pg_graphs_build_filter_index",
+    "pg_host_alloc", "pg_host_free", "pg_host_register", "pg_host_unregister", "pg_counts_zero", "pg_ctx_sync_compute",
+    "pg_render_cigars",
 ]
 
 
@@ -111,7 +113,7 @@ def load_library():
     L.pg_batch_destroy.restype = None
     L.pg_batch_destroy.argtypes = [vp, vp]
     L.pg_batch_upload.restype = C.c_int32
-    L.pg_batch_upload.argtypes = [vp, vp, vp, C.c_uint32, u32p, u32p, C.c_char_p]
+    L.pg_batch_upload.argtypes = [vp, vp, vp, C.c_uint32, u32p, u32p, vp]
     L.pg_batch_align.restype = C.c_int32
     L.pg_batch_align.argtypes = [vp, vp, C.c_uint32]
     L.pg_batch_ops_count.restype = C.c_int32
@@ -154,6 +156,20 @@ def load_library():
     L.pg_batch_klib_align.argtypes = [vp, vp, C.c_uint32]
     L.pg_graphs_klib_error.restype = C.c_int32
     L.pg_graphs_klib_error.argtypes = [vp, vp, u32p]
+    L.pg_host_alloc.restype = C.c_int32
+    L.pg_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.pg_host_free.restype = None
+    L.pg_host_free.argtypes = [vp, vp]
+    L.pg_host_register.restype = C.c_int32
+    L.pg_host_register.argtypes = [vp, vp, C.c_size_t]
+    L.pg_host_unregister.restype = C.c_int32
+    L.pg_host_unregister.argtypes = [vp, vp]
+    L.pg_counts_zero.restype = C.c_int32
+    L.pg_counts_zero.argtypes = [vp, vp, C.c_uint64]
+    L.pg_ctx_sync_compute.restype = C.c_int32
+    L.pg_ctx_sync_compute.argtypes = [vp]
+    L.pg_render_cigars.restype = C.c_int32
+    L.pg_render_cigars.argtypes = [vp, C.c_uint64, vp, vp, C.c_size_t]
     L.pg_render_cigar.restype = C.c_size_t
     L.pg_render_cigar.argtypes = [vp, vp, C.c_char_p, C.c_size_t]
     _lib = L
@@ -193,8 +209,36 @@ def graphs_csr(graphs):
             _u32(pred if pred else [0]))
 
 
+def _bases_ptr(bases):
+    """bytes or a uint8 numpy array (e.g. over pinned memory) -> (address, keep-alive object)."""
+    if isinstance(bases, np.ndarray):
+        a = np.ascontiguousarray(bases, dtype=np.uint8)
+        return a.ctypes.data, a
+    buf = C.c_char_p(bases)
+    return C.cast(buf, C.c_void_p).value, buf
+
+
+class _PinnedBlock:
+    """Owner of one pg_host_alloc block; numpy arrays made over it keep it alive through their .base chain."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        p = C.c_void_p()
+        ctx._chk(ctx.L.pg_host_alloc(ctx.h, max(int(nbytes), 1), C.byref(p)))
+        self.ptr = p
+        self.buf = (C.c_uint8 * max(int(nbytes), 1)).from_address(p.value)
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.h:
+                self.ctx.L.pg_host_free(self.ctx.h, self.ptr)
+            self.ptr = None
+        except Exception:
+            pass
+
+
 def pack_reads(reads):
-    """list[str] or (offsets, bytes) -> (uint32 offsets[n+1], bytes)."""
+    """list[str] or (offsets, bytes | uint8 array) -> (uint32 offsets[n+1], bytes | uint8 array)."""
     if isinstance(reads, tuple):
         return _u32(reads[0]), reads[1]
     lens = np.fromiter((len(r) for r in reads), dtype=np.int64, count=len(reads))
@@ -233,6 +277,30 @@ class Context:
 
     def sync(self):
         self._chk(self.L.pg_ctx_sync(self.h))
+
+    def sync_compute(self):
+        self._chk(self.L.pg_ctx_sync_compute(self.h))
+
+    def pinned_empty(self, shape, dtype):
+        """numpy array over page-locked host memory (pg_host_alloc); freed when the last view goes away."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) if not isinstance(shape, int) else int(shape)
+        blk = _PinnedBlock(self, n * dt.itemsize)
+        a = np.frombuffer(blk.buf, dtype=dt, count=n)
+        a = a.reshape(shape)
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(blk)  # the ctypes buffer does not own the block: keep it until the context goes
+        return a
+
+    def pinned_copy(self, arr):
+        a = np.ascontiguousarray(arr)
+        out = self.pinned_empty(a.shape, a.dtype)
+        out[...] = a
+        return out
+
+    def counts_zero(self, d_ptr, n_counters):
+        """memset of a caller-owned device counter table on the ctx stream (ordered with Batch.count)."""
+        self._chk(self.L.pg_counts_zero(self.h, d_ptr, int(n_counters)))
 
     def timing_enable(self, on=True):
         self._chk(self.L.pg_ctx_timing_enable(self.h, 1 if on else 0))
@@ -363,11 +431,13 @@ class Batch:
     def upload(self, graphs, reads, graph_of_read=None):
         off, bases = pack_reads(reads)
         n = len(off) - 1
-        gor = _u32(np.zeros(n, dtype=np.uint32) if graph_of_read is None else graph_of_read)
+        gor = _u32(np.zeros(n, dtype=np.uint32) if graph_of_read is None else graph_of_read)  # no copy if already uint32
         if len(gor) != n:
             raise ValueError("graph_of_read length mismatch")
         self._graphs = graphs
-        self.ctx._chk(self.ctx.L.pg_batch_upload(self.ctx.h, self.h, graphs.h, n, _p32(gor), _p32(off), bases))
+        ptr, keep = _bases_ptr(bases)
+        self.ctx._chk(self.ctx.L.pg_batch_upload(self.ctx.h, self.h, graphs.h, n, _p32(gor), _p32(off), ptr))
+        del keep
         self.n_reads = n
 
     def path_align(self):
@@ -417,24 +487,38 @@ class Batch:
                           1 if use_kmer_filter else 0, 0)
         self.ctx._chk(self.ctx.L.pg_batch_count(self.ctx.h, self.h, C.byref(prm), d_counts))
 
-    def download_counts(self, want_table=True):
-        """-> (counts table or None, supports (SUPPORT_DTYPE), path entries)."""
+    def download_counts(self, want_table=True, into=None):
+        """-> (counts table or None, supports (SUPPORT_DTYPE), path entries).  into = (counts, supports, path) arrays to
+        fill instead of fresh ones (e.g. pinned: the copies are then DMAs beside another batch's kernels)."""
         lay = self._graphs.layout
-        counts = np.zeros(int(lay.n_counters), dtype=np.uint32) if want_table else None
-        sup = np.zeros(max(self.n_reads, 1), dtype=SUPPORT_DTYPE)
         npath = C.c_uint64()
         self.ctx._chk(self.ctx.L.pg_batch_download_counts(self.ctx.h, self.h, None, None, None, 0, C.byref(npath)))
-        path = np.zeros(max(int(npath.value), 1), dtype=np.uint32)
+        if into is not None:
+            counts, sup, path = into
+            if not want_table:
+                counts = None
+            if len(sup) < self.n_reads or len(path) < int(npath.value) or (counts is not None and len(counts) < int(lay.n_counters)):
+                raise ValueError("download_counts: `into` arrays too small")
+        else:
+            counts = np.zeros(int(lay.n_counters), dtype=np.uint32) if want_table else None
+            sup = np.zeros(max(self.n_reads, 1), dtype=SUPPORT_DTYPE)
+            path = np.zeros(max(int(npath.value), 1), dtype=np.uint32)
         self.ctx._chk(self.ctx.L.pg_batch_download_counts(
             self.ctx.h, self.h, counts.ctypes.data if want_table else None, sup.ctypes.data, path.ctypes.data,
             len(path), C.byref(npath)))
         return counts, sup[:self.n_reads], path[:int(npath.value)]
 
-    def download(self):
+    def download(self, into=None):
+        """-> (results (RESULT_DTYPE), ops).  into = (results, ops) arrays to fill (e.g. pinned) instead of fresh ones."""
         cnt = C.c_uint64()
         self.ctx._chk(self.ctx.L.pg_batch_ops_count(self.ctx.h, self.h, C.byref(cnt)))
-        res = np.zeros(max(self.n_reads, 1), dtype=RESULT_DTYPE)
-        ops = np.zeros(max(cnt.value, 1), dtype=np.uint32)
+        if into is not None:
+            res, ops = into
+            if len(res) < self.n_reads or len(ops) < cnt.value:
+                raise ValueError("download: `into` arrays too small")
+        else:
+            res = np.zeros(max(self.n_reads, 1), dtype=RESULT_DTYPE)
+            ops = np.zeros(max(cnt.value, 1), dtype=np.uint32)
         got = C.c_uint64()
         self.ctx._chk(self.ctx.L.pg_batch_download(self.ctx.h, self.h, res.ctypes.data, ops.ctypes.data, len(ops),
                                                    C.byref(got)))
@@ -459,6 +543,18 @@ def render_cigar(res_row, ops):
     if cur is not None:
         out.append("]")
     return "".join(out)
+
+
+def render_cigars(res, ops, stride=128):
+    """All CIGAR strings at once: (n, stride) uint8 array, slot i = NUL-padded string of read i (pg_render_cigars)."""
+    L = load_library()
+    res = np.ascontiguousarray(res)
+    ops = np.ascontiguousarray(ops, dtype=np.uint32)
+    buf = np.zeros((len(res), stride), dtype=np.uint8)
+    st = L.pg_render_cigars(res.ctypes.data, len(res), ops.ctypes.data, buf.ctypes.data, stride)
+    if st != PG_OK:
+        raise PgError(st, "pg_render_cigars(stride=%d)" % stride)
+    return buf
 
 
 def results_to_dicts(res, ops):

@@ -40,6 +40,7 @@ pg_status pg_fail(pg_ctx* ctx, pg_status st, const std::string& msg)
 }
 static pg_status fail(pg_ctx* ctx, pg_status st, const std::string& msg) { return pg_fail(ctx, st, msg); }
 static void recycle_sync_events(pg_ctx* ctx);
+static void recycle_done_sync_events(pg_ctx* ctx);
 
 
 // ---------------------------------------------------------------------------------------------------
@@ -242,6 +243,67 @@ extern "C" pg_status pg_ctx_sync(pg_ctx* ctx)
     return PG_OK;
 }
 
+// Pinned (page-locked) host staging: with it every hipMemcpyAsync of the upload / download calls is a real DMA that runs
+// beside the kernels; from pageable memory the runtime stages through its own bounce buffers on the calling thread.
+extern "C" pg_status pg_host_alloc(pg_ctx* ctx, size_t bytes, void** out)
+{
+    if (!ctx || !out)
+        return PG_ERR_INVALID;
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocPortable));
+    return PG_OK;
+}
+
+extern "C" void pg_host_free(pg_ctx* ctx, void* p)
+{
+    if (!p)
+        return;
+    if (ctx)
+        (void)hipSetDevice(ctx->device);
+    (void)hipHostFree(p);
+}
+
+extern "C" pg_status pg_host_register(pg_ctx* ctx, void* p, size_t bytes)
+{
+    if (!ctx || !p || !bytes)
+        return PG_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipHostRegister(p, bytes, hipHostRegisterPortable));
+    return PG_OK;
+}
+
+extern "C" pg_status pg_host_unregister(pg_ctx* ctx, void* p)
+{
+    if (!ctx || !p)
+        return PG_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipHostUnregister(p));
+    return PG_OK;
+}
+
+extern "C" pg_status pg_counts_zero(pg_ctx* ctx, uint32_t* d_counts, uint64_t n_counters)
+{
+    if (!ctx || (!d_counts && n_counters))
+        return PG_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n_counters)
+        HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, n_counters * sizeof(uint32_t), ctx->stream));
+    return PG_OK;
+}
+
+// Blocks the host until everything queued on the compute streams so far is done (the copy stream is left alone): the
+// ordering point between pg_batch_count into a caller-owned table and the caller's all-reduce of that table.
+extern "C" pg_status pg_ctx_sync_compute(pg_ctx* ctx)
+{
+    if (!ctx)
+        return PG_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
+    return PG_OK;
+}
+
 hipError_t pg_stage_begin(pg_ctx* ctx, pg_batch* b)
 {
     if (b->upload_recorded)
@@ -343,6 +405,17 @@ static void recycle_sync_events(pg_ctx* ctx)
     for (auto e : ctx->sync_events_in_flight)
         ctx->sync_event_pool.push_back(e);
     ctx->sync_events_in_flight.clear();
+}
+// A workflow never calls pg_ctx_sync: ordering events whose work is over (they complete in the order they were recorded
+// per stream, so the scan stops at the first one still pending) go back to the pool at the start of every pg_batch_align.
+static void recycle_done_sync_events(pg_ctx* ctx)
+{
+    size_t done = 0;
+    while (done < ctx->sync_events_in_flight.size() && hipEventQuery(ctx->sync_events_in_flight[done]) == hipSuccess)
+        ctx->sync_event_pool.push_back(ctx->sync_events_in_flight[done++]);
+    if (done)
+        ctx->sync_events_in_flight.erase(ctx->sync_events_in_flight.begin(), ctx->sync_events_in_flight.begin() + (std::ptrdiff_t)done);
+    (void)hipGetLastError();  // hipErrorNotReady of the first pending event is not an error
 }
 
 static hipError_t get_event(pg_ctx* ctx, hipEvent_t* ev)
@@ -848,7 +921,7 @@ extern "C" pg_status pg_batch_upload(
     b->has_skipped = false;
     b->fragments_set = false;
     b->has_active = false;
-    b->host_template.assign(n_reads, pg_result{});
+    b->host_template.clear();  // built only when a read is skipped (rare)
     uint64_t ops_total = 0;
     for (uint32_t i = 0; i < n_reads; ++i)
     {
@@ -862,6 +935,8 @@ extern "C" pg_status pg_batch_upload(
         if (L == 0)
         {
             // grm::sequentialAlignReads skips reads without bases (Align.cpp:74-77)
+            if (!b->has_skipped)
+                b->host_template.assign(n_reads, pg_result{});
             b->host_template[i].status = 1;
             b->has_skipped = true;
             continue;
@@ -898,7 +973,11 @@ extern "C" pg_status pg_batch_upload(
         HIP_TRY(ctx, hipMemcpyAsync(b->d_graph_of_read, graph_of_read, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
         if (n_bases)
             HIP_TRY(ctx, hipMemcpyAsync(b->d_bases, bases, n_bases, hipMemcpyHostToDevice, cs));
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_results, b->host_template.data(), n_reads * sizeof(pg_result), hipMemcpyHostToDevice, cs));
+        // the template is all zero except for reads the device never sees (empty reads: status 1)
+        if (b->has_skipped)
+            HIP_TRY(ctx, hipMemcpyAsync(b->d_results, b->host_template.data(), n_reads * sizeof(pg_result), hipMemcpyHostToDevice, cs));
+        else
+            HIP_TRY(ctx, hipMemsetAsync(b->d_results, 0, n_reads * sizeof(pg_result), cs));
         HIP_TRY(ctx, hipMemsetAsync(b->d_path_flags, 0, n_reads, cs));
     }
     HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), cs));
@@ -928,6 +1007,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     if (!ctx || !b || !b->graphs)
         return fail(ctx, PG_ERR_INVALID, "pg_batch_align: batch not uploaded");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    recycle_done_sync_events(ctx);
     const pg_graphs* G = b->graphs;
     {
         const auto t0 = std::chrono::steady_clock::now();
@@ -1134,4 +1214,21 @@ extern "C" size_t pg_render_cigar(const pg_result* r, const pg_op* ops, char* bu
     if (buf && cap)
         buf[len < cap ? len : cap - 1] = 0;
     return len;
+}
+
+extern "C" pg_status pg_render_cigars(const pg_result* results, uint64_t n, const pg_op* ops, char* buf, size_t stride)
+{
+    if ((n && (!results || !buf)) || stride < 2)
+        return PG_ERR_INVALID;
+    pg_status st = PG_OK;
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        char* slot = buf + i * stride;
+        const size_t len = pg_render_cigar(&results[i], ops, slot, stride);
+        if (len >= stride)
+            st = PG_ERR_OVERFLOW;
+        else
+            memset(slot + len, 0, stride - len);
+    }
+    return st;
 }

@@ -36,8 +36,18 @@ def partition_fragments(fragment_of_read, world):
 
 
 def allreduce_counts(table):
-    """In-place SUM all-reduce of a counter table (torch tensor, int32/int64) over the default process group."""
+    """In-place SUM all-reduce of a counter table (torch tensor, int32/int64) over the default process group -- the only
+    collective of the path.  With the "nccl" backend (= RCCL) the tensor is reduced where it lives, in HBM over xGMI; a
+    device tensor under a host backend ("gloo": CPU tests, or several ranks sharing one GPU) takes one hop through host
+    memory.  The caller orders it against the kernels that filled the table (pg_ctx_sync_compute) -- the library's streams
+    are not torch's."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return table
+    if table.is_cuda and dist.get_backend() != "nccl":
+        host = table.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        table.copy_(host)
+    else:
         dist.all_reduce(table, op=dist.ReduceOp.SUM)
     return table

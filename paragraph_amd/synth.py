@@ -276,17 +276,28 @@ def _paired_reads(rng, hap, keep_lo, keep_hi, depth, read_len, sub_rate, frag0):
     return reads, frag, rev
 
 
-def mixed_sites(n_sites, seed=3, contig_len=None, read_len=150, depth=30.0, flank=150, sub_rate=0.01, margin=450):
+def mixed_sites(n_sites, seed=3, contig_len=None, read_len=150, depth=30.0, flank=150, sub_rate=0.01, margin=450,
+                site_streams=False, indices=None, contig=None):
     """n_sites DEL/INS sites on one synthetic contig with 30x paired reads from a diploid genotype
     (0/0 : 0/1 : 1/1 = 1 : 2 : 1).  DEL length log-uniform 50..10000 (> 2*flank -> long-deletion template),
-    INS length log-uniform 50..1000.  Returns list[SiteReads]."""
+    INS length log-uniform 50..1000.  Returns list[SiteReads].
+
+    site_streams=False: one random stream runs through all sites (the data sets of round 1).  site_streams=True: every
+    site draws from its own stream seeded by (seed, site index), so any subset (`indices`) can be generated on its own --
+    in parallel (mixed_sites_parallel) or per rank -- and is identical to the same sites of the full set."""
     rng = SplitMix64(seed)
     spacing = 14000
     contig_len = contig_len or (n_sites * spacing + 20000)
-    contig = np.frombuffer(random_contig(seed * 7919 + 1, contig_len), dtype=np.uint8)
-    cb = contig.tobytes()
+    if contig is None:
+        contig = np.frombuffer(random_contig(seed * 7919 + 1, contig_len), dtype=np.uint8)
+    cb = contig.tobytes() if not isinstance(contig, bytes) else contig
+    contig = np.frombuffer(cb, dtype=np.uint8)
     out = []
-    for s in range(n_sites):
+    if indices is not None and not site_streams:
+        raise ValueError("indices needs site_streams=True")
+    for s in (range(n_sites) if indices is None else indices):
+        if site_streams:
+            rng = SplitMix64((seed * 0x9E3779B1 + 0x632BE59B * (s + 1)) & _MASK)
         center = 10000 + s * spacing
         is_del = rng.uniform() < 0.5
         gt = [0, 1, 1, 2][rng.below(4)]  # number of ALT alleles
@@ -327,6 +338,34 @@ def mixed_sites(n_sites, seed=3, contig_len=None, read_len=150, depth=30.0, flan
         rev = np.concatenate([p[2] for p in parts]) if parts else np.zeros(0, np.uint8)
         out.append(SiteReads(site, reads, frag, rev, gt))
     return out
+
+
+_POOL_ARGS = None
+
+
+def _pool_sites(idx):
+    n_sites, seed, kw, contig = _POOL_ARGS
+    return mixed_sites(n_sites, seed, site_streams=True, indices=idx, contig=contig, **kw)
+
+
+def mixed_sites_parallel(n_sites, seed=3, procs=8, **kw):
+    """mixed_sites(..., site_streams=True) generated by `procs` forked workers (call BEFORE the process touches HIP: the
+    workers are plain forks).  Same result as the serial call."""
+    global _POOL_ARGS
+    import multiprocessing as mp
+    contig_len = n_sites * 14000 + 20000
+    contig = random_contig(seed * 7919 + 1, contig_len)
+    procs = max(1, min(int(procs), n_sites))
+    if procs == 1:
+        return mixed_sites(n_sites, seed, site_streams=True, contig=contig, **kw)
+    chunks = [list(range(lo, min(n_sites, lo + 64))) for lo in range(0, n_sites, 64)]
+    _POOL_ARGS = (n_sites, seed, kw, contig)
+    try:
+        with mp.get_context("fork").Pool(procs) as pool:
+            parts = pool.map(_pool_sites, chunks)
+    finally:
+        _POOL_ARGS = None
+    return [s for part in parts for s in part]
 
 
 def long_node_site(seed, alt_len, flank=300, ref_mid=60):

@@ -1,4 +1,4 @@
-"""Large randomized device-vs-reference comparison (not collected by pytest; run by hand on the GPU box):
+"""Large randomized device-vs-reference comparison (tests/test_gpu_scale.py runs two salts of it; by hand for more):
 
     python tests/stress_parity.py [n_graphs] [seed]
 
@@ -15,12 +15,8 @@ from tests import fuzzgen  # noqa: E402
 from tests.test_gpu_parity import compare, gpu_align  # noqa: E402
 
 
-def main():
-    n_graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def run(n_graphs, seed, ctx, checker, verbose=True):
     rng = random.Random(seed)
-    checker = orc.RefOracle() if orc.have_ref() else orc.PortOracle()
-    ctx = capi.Context(0)
     total = 0
     t0 = time.time()
     for block in range(0, n_graphs, 500):
@@ -43,7 +39,16 @@ def main():
         got = gpu_align(ctx, graphs, reads, gor)
         compare(got, want, reads, "stress block %d" % block)
         total += len(reads)
-        print("block %d ok: %d reads so far, %.0fs" % (block, total, time.time() - t0), flush=True)
+        if verbose:
+            print("block %d ok: %d reads so far, %.0fs" % (block, total, time.time() - t0), flush=True)
+    return total
+
+
+def main():
+    n_graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    checker = orc.RefOracle() if orc.have_ref() else orc.PortOracle()
+    total = run(n_graphs, seed, capi.Context(0), checker)
     print("stress parity OK: %d graphs, %d reads" % (n_graphs, total))
 
 

@@ -1,0 +1,133 @@
+"""Full-size parity on the GPU: the BASELINE.json configurations at sizes the driver's bench runs, against the reference's
+own gssw.c / graph-tools code (oracle/_ref; the plain-C port where it is absent).  The reference side is computed by
+tests/scale_oracle.py in a process of its own, fanned out over the host's cores; comparisons are vectorised.
+
+  configs[1]  262 144 config-2 reads                      (every pg_result field + CIGAR string)
+  configs[2]  2 000 mixed DEL / long-DEL / INS sites, 30x  (alignments, per-read supports, per-site count tables)
+  configs[4]  2 400 reads of 250 bp on 2-8 kb ALT nodes
+  stress      tests/stress_parity.py, two salts            (adversarial graphs, word mode, far predecessors)
+  N > 1       bench.py --gpus 2 --workload config3 on this box (ranks share the GPU, gloo): reduced table == 1-rank table"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _upload_and_align(ctx, graphs, arr, gor=None):
+    from paragraph_amd import capi
+    G = ctx.upload_graphs(graphs)
+    n, L = arr.shape
+    off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L)).astype(np.uint32)
+    b = ctx.new_batch()
+    b.upload(G, (off, np.ascontiguousarray(arr).reshape(-1)), gor)
+    b.align(capi.AF_ALL)
+    res, ops = b.download()
+    return G, b, res, ops
+
+
+def test_config2_262144_reads(gpu_ctx):
+    import bench
+    from paragraph_amd import capi, synth
+    from tests import scale_oracle
+    n = 262144
+    site, arr = synth.config2_reads_packed(n, read_len=150, seed=2)
+    ref_res, ref_cig = scale_oracle.run("config2", n, 2)
+    G, b, res, ops = _upload_and_align(gpu_ctx, [(site.seqs, site.edges)], arr)
+    v = bench.verify_against_reference(capi, res, ops, ref_res, ref_cig)
+    b.close()
+    G.close()
+    assert v["reads"] == n and v["mismatches"] == 0, v
+
+
+def test_config3_2000_sites(gpu_ctx):
+    import bench
+    from paragraph_amd import capi, synth
+    from tests import scale_oracle
+    n_sites = 2000
+    sites = synth.mixed_sites(n_sites, seed=5, site_streams=True)
+    want = scale_oracle.run("config3", n_sites, 5)
+    arr = np.concatenate([s.reads for s in sites])
+    gor = np.concatenate([np.full(len(s.reads), i, dtype=np.uint32) for i, s in enumerate(sites)])
+    G, b, res, ops = _upload_and_align(gpu_ctx, [(s.site.seqs, s.site.edges) for s in sites], arr, gor)
+    G.set_labels([s.site.labels for s in sites])
+    b.set_fragments(np.concatenate([s.fragment for s in sites]), np.concatenate([s.is_reverse for s in sites]))
+    b.count(remove_nonuniq=True)
+    table, sup, path = b.download_counts()
+    # ---- alignments, all reads at once
+    ref_res = np.concatenate([w["res"] for w in want])
+    ref_cig = np.concatenate([w["cig"] for w in want])
+    v = bench.verify_against_reference(capi, res, ops, ref_res, ref_cig)
+    assert v["reads"] == len(arr) > 400000 and v["mismatches"] == 0, v
+    # ---- per-read outcome of the count path, all reads at once
+    ref_status = np.concatenate([w["status"] for w in want])
+    ref_labels = np.concatenate([w["label_mask"] for w in want])
+    assert np.array_equal(sup["status"], ref_status), np.nonzero(sup["status"] != ref_status)[0][:5]
+    mapped = ref_status == 1
+    assert np.array_equal(sup["label_mask"][mapped], ref_labels[mapped])
+    # ---- node / edge supports read by read on every 16th site, count tables on every site
+    cnt = capi.decode_counts(G, table)
+    k = 0
+    kinds = set()
+    for si, (s, w) in enumerate(zip(sites, want)):
+        kinds.add(s.site.kind)
+        n = len(s.reads)
+        if si % 16 == 0:
+            ds = capi.decode_supports(G, gor[k:k + n], sup[k:k + n], path)
+            for i in range(n):
+                if w["status"][i] == 1:
+                    assert ds[i]["nodes"] == w["nodes"][i] and ds[i]["edges"] == w["edges"][i], (si, i)
+        c = cnt[si]
+        assert np.array_equal(c["node_counts"], w["node_counts"]), (si, s.site.kind)
+        for ei, e in enumerate(s.site.edges):
+            assert c["edge_counts"][tuple(e)] == [int(x) for x in w["edge_counts"][ei]], (si, e)
+        assert c["seq_counts"] == w["seq_counts"], (si, c["seq_counts"], w["seq_counts"])
+        k += n
+    b.close()
+    G.close()
+    assert kinds == {"del", "longdel", "ins"}
+
+
+def test_config5_2400_long_node_reads(gpu_ctx):
+    import bench
+    from paragraph_amd import capi
+    from tests import scale_oracle
+    cases = scale_oracle.config5_cases(50, 48, 9)
+    want = scale_oracle.run("config5", 50, 48, 9)
+    arr = np.concatenate([a for _, a in cases])
+    gor = np.concatenate([np.full(len(a), i, dtype=np.uint32) for i, (_, a) in enumerate(cases)])
+    G, b, res, ops = _upload_and_align(gpu_ctx, [(s.seqs, s.edges) for s, _ in cases], arr, gor)
+    v = bench.verify_against_reference(capi, res, ops, np.concatenate([w["res"] for w in want]), np.concatenate([w["cig"] for w in want]))
+    b.close()
+    G.close()
+    assert v["reads"] == 2400 and v["mismatches"] == 0, v
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_stress_parity(gpu_ctx, checker, seed):
+    from tests import fuzzgen, stress_parity
+    total = stress_parity.run(1500, fuzzgen.salted(seed), gpu_ctx, checker, verbose=False)
+    assert total > 9000
+
+
+def test_bench_two_ranks_shard_one_site_set():
+    """configs[3] on this box: bench.py spawns 2 ranks itself; with one GPU they share it and reduce over gloo.  The reduced
+    counter table must equal the table of a 1-rank pass over all sites."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "config3", "--sites", "400",
+                        "--steps", "2", "--warmup", "1", "--workspace-gib", "16"], stdout=subprocess.PIPE, env=env, timeout=900)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["dist"]["world"] == 2
+    assert out["sites"]["reduce_equals_single"] is True, out["sites"]
+    assert out["sites"]["sites"] == 400 and len(out["sites"]["shard_reads"]) == 2 and min(out["sites"]["shard_reads"]) > 0
+    assert out["sites"]["tallies"]["aligned"] == out["sites"]["reads"]

@@ -22,7 +22,10 @@ extern "C" {
  *   genotyping_parameters  grmpy -G document, or NULL / "" for the defaults
  *   options_json           NULL / "" or an object with any of: "threads", "lanes", "sites_per_batch", "max_reads",
  *                          "bad_align_frac", "path_sequence_matching", "kmer_sequence_matching", "klib_sequence_matching",
- *                          "bad_align_uniq_kmer_len", "packed_reads"
+ *                          "bad_align_uniq_kmer_len", "packed_reads", "devices" (array of HIP device ordinals the
+ *                          lanes are spread over, lane l on devices[l % n]; default: the PG_DEVICES environment
+ *                          variable -- "0,1,2,3" or "all" -- else device 0; sites are independent, the devices
+ *                          exchange nothing)
  *                          (grmpy's option names and defaults, grmpy/Parameters.hh:30-74; "sites_per_batch" = (graph,
  *                          sample) pairs per device batch, default 512; "lanes" = batches in flight, default one per
  *                          four threads, at most 8)

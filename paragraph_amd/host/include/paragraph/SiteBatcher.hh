@@ -62,7 +62,17 @@ struct BatchParameters
     bool klib_sequence_matching = false;
     unsigned alignment_flags = (unsigned)-1;
     int threads = 1;  // host threads for packing the reads and fanning the results back into them
+    int device = 0;   // slot of the device list (setDevices / PG_DEVICES) this batch runs on
 };
+
+// The HIP devices the host library drives, one context each: `ordinals` as hipSetDevice takes them; the same ordinal may
+// appear more than once (two contexts on one GPU -- how a 1-GPU box exercises the multi-device paths).  Default: the
+// environment's PG_DEVICES ("0,1,2,3" or "all"), else PG_DEVICE, else device 0.  Must be called before the first device
+// call (the list is fixed once a context exists; repeating the same list is fine).
+void setDevices(std::vector<int> const& ordinals);
+size_t deviceCount();
+// page-locked staging memory obtained so far (the flat arrays of SiteBatcher::run live there)
+size_t pinnedStagingBytes();
 
 class SiteBatcher
 {

@@ -54,6 +54,7 @@ struct Parameters
     bool remove_nonuniq_reads = true;
     int kmer_len = 0;
     int threads = 1;  // host threads for read extraction and document assembly
+    int device = 0;   // slot of the device list (paragraph::setDevices / PG_DEVICES) the batch runs on
     Timings* timings = nullptr;
     bool output_enabled(output_options o) const { return (output_options_ & o) != 0; }
 };
@@ -126,7 +127,9 @@ struct Parameters
     bool packed_reads = true;
     size_t sites_per_batch = 512;    // (graph, sample) pairs per device batch; bounds host memory and sets the pipeline grain
     int lanes = 0;                   // chunks in flight: each lane carries one chunk through all stages with threads / lanes
-                                     // workers; 0 = one lane per four threads, at most eight
+                                     // workers; 0 = one lane per four threads, at most eight per device, at least one per device
+    std::vector<int> devices;        // HIP ordinals to spread the lanes over (lane l -> devices[l % n]); empty = the list of
+                                     // paragraph::setDevices / PG_DEVICES / PG_DEVICE / {0}
     paragraph::Timings* timings = nullptr;
 };
 

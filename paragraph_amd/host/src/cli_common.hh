@@ -3,6 +3,7 @@
 #pragma once
 #include <zlib.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -13,6 +14,25 @@
 
 namespace cli
 {
+// --devices 0,1,2,3 | all  ("all" is resolved by the host library through PG_DEVICES: an empty list means "its default")
+inline std::vector<int> deviceList(std::string const& value)
+{
+    std::vector<int> out;
+    if (value == "all")
+    {
+        setenv("PG_DEVICES", "all", 1);
+        return out;
+    }
+    std::stringstream ss(value);
+    std::string item;
+    while (std::getline(ss, item, ','))
+        if (!item.empty())
+            out.push_back(std::stoi(item));
+    if (out.empty())
+        throw std::runtime_error("--devices expects a comma-separated list of device ordinals or 'all'");
+    return out;
+}
+
 inline std::vector<std::string> splitShell(std::string const& text)
 {
     std::vector<std::string> out;

@@ -25,6 +25,7 @@ const char* kUsage = "grmpy -r <reference> -g <graphs> -m <manifest> [optional a
                      "      --klib-sequence-matching BOOL (false)   --kmer-sequence-matching BOOL (false)\n"
                      "      --bad-align-uniq-kmer-len N   (0)\n"
                      "  -t, --sample-threads N            host threads (1)\n"
+                     "      --devices LIST                GPUs to spread the site batches over: 0,1,2,3 or 'all' (default: PG_DEVICES, else 0)\n"
                      "      --response-file FILE          read further options from FILE\n";
 }
 
@@ -72,6 +73,8 @@ int main(int argc, char** argv)
                 parameters.bad_align_uniq_kmer_len = std::stoi(args.value());
             else if (args.is("-t", "--sample-threads"))
                 parameters.threads = std::max(1, std::stoi(args.value()));
+            else if (args.is(nullptr, "--devices"))
+                parameters.devices = cli::deviceList(args.value());
             else if (args.is("-z", "--gzip-output"))
                 gzip = args.optionalBool();
             else if (args.is(nullptr, "--progress"))

@@ -6,8 +6,11 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
+#include <string>
 #include <unordered_map>
 
 #include "../../../include/paragraph_amd.h"
@@ -18,6 +21,7 @@
 #include "grm/PathAligner.hh"
 #include "paragraph/SiteBatcher.hh"
 #include "parallel.hh"
+#include "pinned.hh"
 
 using common::Read;
 using graphtools::Graph;
@@ -31,17 +35,101 @@ void check(pg_ctx* ctx, pg_status st, const char* what)
         throw std::runtime_error(std::string(what) + ": " + pg_strerror(st) + " (" + (ctx ? pg_last_error(ctx) : "") + ")");
 }
 
-pg_ctx* deviceContext()
+// ---- devices: slot s of the device list -> one pg_ctx (own streams, workspace, stage mutex, batch pool) -----------------
+// The list comes from paragraph::setDevices(), else PG_DEVICES ("0,1,2,3" or "all"), else PG_DEVICE, else {0}.  The
+// reference's only parallelism is thread-per-chunk / thread-per-(sample, graph) (Align.cpp:114-156, grmpy/Workflow.cpp:
+// 225-231); the device analogue is lane-per-chunk with the lanes spread over the devices, no data-path collective.
+struct DeviceSlot
 {
-    static pg_ctx* ctx = nullptr;
-    static std::mutex m;
-    std::lock_guard<std::mutex> lock(m);
-    if (!ctx)
+    int ordinal = 0;
+    pg_ctx* ctx = nullptr;
+    std::mutex create;       // guards ctx creation
+    std::mutex stage;        // the stage calls on one ctx must be serialised (paragraph_amd.h)
+    std::mutex pool_mutex;
+    std::vector<pg_batch*> idle;
+};
+struct DeviceTable
+{
+    std::mutex m;
+    std::vector<std::unique_ptr<DeviceSlot>> slots;
+    bool fixed = false;  // a context exists: the list can no longer change
+};
+DeviceTable& deviceTable()
+{
+    static DeviceTable* t = new DeviceTable();  // never torn down (like the HIP runtime itself)
+    return *t;
+}
+std::vector<int> devicesFromEnvironment()
+{
+    std::vector<int> out;
+    if (const char* list = std::getenv("PG_DEVICES"))
+    {
+        const std::string s(list);
+        if (s == "all")
+        {
+            // pg_ctx_create fails with PG_ERR_NO_DEVICE past the last ordinal
+            for (int d = 0; d < 64; ++d)
+            {
+                pg_ctx* probe = nullptr;
+                if (pg_ctx_create(d, &probe) != PG_OK)
+                    break;
+                pg_ctx_destroy(probe);
+                out.push_back(d);
+            }
+        }
+        else
+        {
+            size_t at = 0;
+            while (at < s.size())
+            {
+                size_t end = s.find(',', at);
+                if (end == std::string::npos)
+                    end = s.size();
+                if (end > at)
+                    out.push_back(std::atoi(s.substr(at, end - at).c_str()));
+                at = end + 1;
+            }
+        }
+    }
+    if (out.empty())
     {
         const char* dev = std::getenv("PG_DEVICE");
-        pg_status st = pg_ctx_create(dev ? std::atoi(dev) : 0, &ctx);
+        out.push_back(dev ? std::atoi(dev) : 0);
+    }
+    return out;
+}
+void ensureDeviceList(DeviceTable& t)
+{
+    if (t.slots.empty())
+        for (int d : devicesFromEnvironment())
+        {
+            t.slots.emplace_back(new DeviceSlot());
+            t.slots.back()->ordinal = d;
+        }
+}
+DeviceSlot& deviceSlot(int slot)
+{
+    DeviceTable& t = deviceTable();
+    std::lock_guard<std::mutex> lock(t.m);
+    ensureDeviceList(t);
+    if (slot < 0 || (size_t)slot >= t.slots.size())
+        throw std::out_of_range("device slot " + std::to_string(slot) + " of " + std::to_string(t.slots.size()));
+    return *t.slots[(size_t)slot];
+}
+
+pg_ctx* deviceContext(int slot = 0)
+{
+    DeviceSlot& ds = deviceSlot(slot);
+    std::lock_guard<std::mutex> lock(ds.create);
+    if (!ds.ctx)
+    {
+        pg_status st = pg_ctx_create(ds.ordinal, &ds.ctx);
         if (st != PG_OK)
-            throw std::runtime_error(std::string("pg_ctx_create: ") + pg_strerror(st));
+            throw std::runtime_error("pg_ctx_create(device " + std::to_string(ds.ordinal) + "): " + pg_strerror(st));
+        {
+            std::lock_guard<std::mutex> tl(deviceTable().m);
+            deviceTable().fixed = true;
+        }
         // Workspace budget (H trace + seeds of the reads in flight; allocated on demand up to this): the library's default
         // of 8 GiB cuts a 1000-site batch into ~9 chunks of 25 k reads, too few threads for the one-thread-per-read
         // traceback kernel.  An MI355X has 288 GB: 64 GiB (what bench.py uses) keeps such a batch in one or two chunks.
@@ -49,33 +137,28 @@ pg_ctx* deviceContext()
         const double budget_gib = gib ? std::atof(gib) : 64.0;
         if (budget_gib > 0)
         {
-            st = pg_ctx_set_workspace_bytes(ctx, (uint64_t)(budget_gib * (double)(1ull << 30)));
+            st = pg_ctx_set_workspace_bytes(ds.ctx, (uint64_t)(budget_gib * (double)(1ull << 30)));
             if (st != PG_OK)
                 throw std::runtime_error(std::string("pg_ctx_set_workspace_bytes: ") + pg_strerror(st));
         }
     }
-    return ctx;
+    return ds.ctx;
 }
-std::mutex& deviceMutex()
-{
-    static std::mutex m;  // the stage calls on one ctx must be serialised (paragraph_amd.h)
-    return m;
-}
+std::mutex& deviceMutex(int slot = 0) { return deviceSlot(slot).stage; }
 
 // Batch objects keep their device buffers between uses: SiteBatcher::run takes one from here and hands it back, so
 // that after the first few batches no run() allocates or frees device memory (hipMalloc / hipFree stall the queues).
 struct BatchPool
 {
-    std::mutex m;
-    std::vector<pg_batch*> idle;
+    DeviceSlot& ds;
     pg_batch* take(pg_ctx* ctx)
     {
         {
-            std::lock_guard<std::mutex> lock(m);
-            if (!idle.empty())
+            std::lock_guard<std::mutex> lock(ds.pool_mutex);
+            if (!ds.idle.empty())
             {
-                pg_batch* b = idle.back();
-                idle.pop_back();
+                pg_batch* b = ds.idle.back();
+                ds.idle.pop_back();
                 return b;
             }
         }
@@ -88,21 +171,17 @@ struct BatchPool
         static const size_t keep = 16;
         if (reusable)
         {
-            std::lock_guard<std::mutex> lock(m);
-            if (idle.size() < keep)
+            std::lock_guard<std::mutex> lock(ds.pool_mutex);
+            if (ds.idle.size() < keep)
             {
-                idle.push_back(b);
+                ds.idle.push_back(b);
                 return;
             }
         }
         pg_batch_destroy(ctx, b);
     }
 };
-BatchPool& batchPool()
-{
-    static BatchPool* pool = new BatchPool();  // lives as long as the context (never torn down, like it)
-    return *pool;
-}
+BatchPool batchPool(int slot = 0) { return BatchPool{ deviceSlot(slot) }; }
 
 struct GraphCsr
 {
@@ -184,6 +263,136 @@ void applyResult(Read& read, const pg_result& r, const pg_op* ops, bool want_cig
     }
 }
 }  // namespace
+
+namespace pghost
+{
+namespace
+{
+struct PinnedPool
+{
+    std::mutex m;
+    std::multimap<size_t, PinnedBlock> idle;  // by capacity
+    size_t idle_bytes = 0, allocated = 0;
+    bool warned = false;
+};
+PinnedPool& pinnedPool()
+{
+    static PinnedPool* p = new PinnedPool();
+    return *p;
+}
+const size_t kPinnedIdleMax = 4ull << 30;
+size_t pinnedClass(size_t bytes)
+{
+    size_t c = 4096;
+    while (c < bytes)
+        c <<= 1;
+    if (c >= 65536)
+    {
+        const size_t step = c / 8;  // four classes between c / 2 and c
+        c = (bytes + step - 1) / step * step;
+    }
+    return c;
+}
+}  // namespace
+
+PinnedBlock pinnedTake(size_t bytes)
+{
+    PinnedPool& pool = pinnedPool();
+    const size_t want = pinnedClass(std::max<size_t>(bytes, 1));
+    {
+        std::lock_guard<std::mutex> lock(pool.m);
+        auto it = pool.idle.lower_bound(want);
+        if (it != pool.idle.end() && it->first <= want + want / 2)
+        {
+            PinnedBlock blk = it->second;
+            pool.idle_bytes -= blk.bytes;
+            pool.idle.erase(it);
+            return blk;
+        }
+    }
+    PinnedBlock blk;
+    blk.bytes = want;
+    pg_ctx* ctx = deviceContext(0);
+    if (pg_host_alloc(ctx, want, &blk.p) == PG_OK)
+    {
+        blk.pinned = true;
+        std::lock_guard<std::mutex> lock(pool.m);
+        pool.allocated += want;
+        return blk;
+    }
+    blk.p = std::malloc(want);
+    if (!blk.p)
+        throw std::bad_alloc();
+    std::lock_guard<std::mutex> lock(pool.m);
+    if (!pool.warned)
+        fprintf(stderr, "paragraph_amd: page-locking %zu bytes of staging memory failed (%s); copies go through pageable memory\n",
+                want, pg_last_error(ctx));
+    pool.warned = true;
+    return blk;
+}
+
+void pinnedGive(PinnedBlock const& blk)
+{
+    if (!blk.p)
+        return;
+    PinnedPool& pool = pinnedPool();
+    {
+        std::lock_guard<std::mutex> lock(pool.m);
+        if (pool.idle_bytes + blk.bytes <= kPinnedIdleMax)
+        {
+            pool.idle.emplace(blk.bytes, blk);
+            pool.idle_bytes += blk.bytes;
+            return;
+        }
+    }
+    if (blk.pinned)
+        pg_host_free(deviceContext(0), blk.p);
+    else
+        std::free(blk.p);
+}
+
+size_t pinnedBytesAllocated()
+{
+    std::lock_guard<std::mutex> lock(pinnedPool().m);
+    return pinnedPool().allocated;
+}
+}  // namespace pghost
+
+namespace paragraph
+{
+void setDevices(std::vector<int> const& ordinals)
+{
+    DeviceTable& t = deviceTable();
+    std::lock_guard<std::mutex> lock(t.m);
+    if (t.fixed)
+    {
+        std::vector<int> now;
+        for (auto const& s : t.slots)
+            now.push_back(s->ordinal);
+        if (now == ordinals || ordinals.empty())
+            return;
+        throw std::logic_error("paragraph::setDevices: the device list cannot change once a device context exists");
+    }
+    if (ordinals.empty())
+        return;
+    t.slots.clear();
+    for (int d : ordinals)
+    {
+        t.slots.emplace_back(new DeviceSlot());
+        t.slots.back()->ordinal = d;
+    }
+}
+
+size_t deviceCount()
+{
+    DeviceTable& t = deviceTable();
+    std::lock_guard<std::mutex> lock(t.m);
+    ensureDeviceList(t);
+    return t.slots.size();
+}
+
+size_t pinnedStagingBytes() { return pghost::pinnedBytesAllocated(); }
+}  // namespace paragraph
 
 namespace grm
 {
@@ -748,17 +957,19 @@ struct SiteBatcher::Impl::Run
     bool packed_mode = false;
     GraphCsr csr;
     // inputs of pg_batch_upload / pg_batch_set_fragments, all sites back to back
+    // (page-locked staging from the process-wide pool: every copy of the device section is a DMA on the copy stream; the
+    // lanes of a workflow hold one set each -- the double buffer of "pinned hipMemcpyAsync double-buffering")
     std::vector<uint64_t> site_read0, site_base0;
-    std::vector<uint32_t> base_off, gor, frag;
-    std::vector<uint8_t> is_rev;
+    pghost::PinnedVec<uint32_t> base_off, gor, frag;
+    pghost::PinnedVec<uint8_t> is_rev;
     std::vector<Read*> flat;  // object sites only
-    std::string bases;
+    pghost::PinnedVec<char> bases;
     // what the device hands back
-    std::vector<pg_result> res;
-    std::vector<pg_op> ops;
+    pghost::PinnedVec<pg_result> res;
+    pghost::PinnedVec<pg_op> ops;
     std::vector<uint64_t> seq_off;
-    std::vector<uint32_t> table, path;
-    std::vector<pg_read_support> sup;
+    pghost::PinnedVec<uint32_t> table, path;
+    pghost::PinnedVec<pg_read_support> sup;
     pg_count_layout lay{};
 };
 
@@ -828,12 +1039,13 @@ void SiteBatcher::Impl::Run::packReads()
     }
     if (site_read0[n_sites] > 0xFFFFFFFFull || site_base0[n_sites] > 0xFFFFFFFFull)
         throw std::runtime_error("SiteBatcher: more than 2^32 reads or bases in one batch");
-    base_off.assign(site_read0[n_sites] + 1, 0);
+    base_off.resize(site_read0[n_sites] + 1);
+    base_off[0] = 0;
     gor.resize(site_read0[n_sites]);
     frag.resize(site_read0[n_sites]);
     is_rev.resize(site_read0[n_sites]);
     flat.resize(packed_mode ? 0 : site_read0[n_sites]);
-    bases.assign(site_base0[n_sites], '\0');
+    bases.resize(site_base0[n_sites]);
     pghost::parallelFor(
         n_sites, prm.threads,
         [&](size_t s) {
@@ -871,7 +1083,7 @@ void SiteBatcher::Impl::Run::packReads()
 void SiteBatcher::Impl::Run::deviceSection()
 {
     // ---- device section: calls on one context are serialised; everything before and after overlaps across threads ------
-    pg_ctx* ctx = deviceContext();
+    pg_ctx* ctx = deviceContext(prm.device);
     const uint32_t n = (uint32_t)gor.size();
     seq_off.assign(n_sites + 1, 0);
     const bool timing = std::getenv("PG_BATCH_TIMING") != nullptr;
@@ -897,14 +1109,15 @@ void SiteBatcher::Impl::Run::deviceSection()
         pg_graphs* g;
         pg_batch* b;
         bool finished;
+        int slot;
         ~Guard()
         {
             if (b)
-                batchPool().giveBack(c, b, finished);
+                batchPool(slot).giveBack(c, b, finished);
             if (g)
                 pg_graphs_destroy(c, g);
         }
-    } guard{ ctx, G, nullptr, false };
+    } guard{ ctx, G, nullptr, false, prm.device };
     check(ctx, pg_graphs_set_labels(ctx, G, csr.label_mask.empty() ? nullptr : csr.label_mask.data(), csr.n_labels.data()),
           "pg_graphs_set_labels");
     // ... and so are the per-graph indexes of the optional stages and of the KmerFilter
@@ -935,11 +1148,11 @@ void SiteBatcher::Impl::Run::deviceSection()
     if (prm.kmer_len != 0)  // createReadFilter(graph, nonuniq, frac, kmer_len): NonUniq -> BadAlign -> KmerFilter (ReadFilter.cpp:74-90)
         check(ctx, pg_graphs_build_filter_index(ctx, G, prm.kmer_len, nullptr), "pg_graphs_build_filter_index");
     mark("graphs up");
-    guard.b = batchPool().take(ctx);
+    guard.b = batchPool(prm.device).take(ctx);
     check(ctx, pg_batch_upload(ctx, guard.b, G, n, gor.data(), base_off.data(), bases.data()), "pg_batch_upload");
     check(ctx, pg_batch_set_fragments(ctx, guard.b, frag.data(), is_rev.data()), "pg_batch_set_fragments");
     mark("reads up");
-    std::unique_lock<std::mutex> lock(deviceMutex());
+    std::unique_lock<std::mutex> lock(deviceMutex(prm.device));
     mark("wait for device");
     pg_count_params cp{};
     cp.remove_nonuniq = prm.remove_nonuniq_reads ? 1 : 0;

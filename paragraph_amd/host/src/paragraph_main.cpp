@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "cli_common.hh"
+#include "paragraph/SiteBatcher.hh"
 #include "paragraph/Workflow.hh"
 
 namespace
@@ -27,6 +28,7 @@ const char* kUsage = "paragraph -r <reference> -g <graph(s)> -b <input bam(s)> [
                      "      --output-detailed-read-counts [BOOL]    -a, --output-alignments [BOOL]\n"
                      "  -A, --output-filtered-alignments [BOOL]     (filter tallies; filtered reads are not re-emitted)\n"
                      "      --threads N                   host threads (1)\n"
+                     "      --devices LIST                GPUs to spread the site batches over: 0,1,2,3 or 'all' (default: PG_DEVICES, else 0)\n"
                      "      --response-file FILE\n";
 }
 
@@ -92,6 +94,8 @@ int main(int argc, char** argv)
                 output_flag(paragraph::Parameters::FILTERED_ALIGNMENTS, args.optionalBool());
             else if (args.is(nullptr, "--threads"))
                 parameters.threads = std::max(1, std::stoi(args.value()));
+            else if (args.is(nullptr, "--devices"))
+                paragraph::setDevices(cli::deviceList(args.value()));
             else if (args.is(nullptr, "--validate-alignments") || args.is(nullptr, "--progress"))
                 (void)args.optionalBool();
             else if (args.is(nullptr, "--variant-min-reads") || args.is(nullptr, "--variant-min-frac") || args.is(nullptr, "--log-level")

@@ -336,6 +336,7 @@ BatchParameters batchParameters(Parameters const& parameters)
     bp.kmer_sequence_matching = parameters.kmer_sequence_matching;
     bp.klib_sequence_matching = parameters.klib_sequence_matching;
     bp.threads = parameters.threads;
+    bp.device = parameters.device;
     return bp;
 }
 }  // namespace
@@ -483,8 +484,11 @@ std::vector<Json> countGraphs(
     };
     // Several chunks: lanes as in grmpy::genotypeGraphs -- one chunk is on the device while others extract reads or write
     // documents (one lane per four threads, at most eight).
+    // With several devices (paragraph::setDevices / PG_DEVICES) lane l works on device l % devices, at least one lane each.
     const size_t n_chunks = (graph_paths.size() + sites_per_batch - 1) / sites_per_batch;
-    const size_t lanes = std::max<size_t>(1, std::min<size_t>(n_chunks, (size_t)std::min(8, std::max(1, parameters.threads / 4))));
+    const size_t n_devices = paragraph::deviceCount();
+    const size_t lanes_by_threads = (size_t)std::min<size_t>(8 * n_devices, (size_t)std::max(1, parameters.threads / 4));
+    const size_t lanes = std::max<size_t>(1, std::min<size_t>(n_chunks, std::max(lanes_by_threads, n_devices)));
     if (lanes == 1)
     {
         for (size_t c = 0; c < n_chunks; ++c)
@@ -495,11 +499,13 @@ std::vector<Json> countGraphs(
     std::atomic<bool> failed(false);
     std::exception_ptr failure;
     std::mutex timings_mutex;
+    std::atomic<int> lane_ids(0);
     auto lane_body = [&] {
         Timings mine;
         Parameters lane = parameters;
         lane.threads = std::max(1, parameters.threads / (int)lanes);
         lane.timings = parameters.timings ? &mine : nullptr;
+        lane.device = (int)((size_t)lane_ids.fetch_add(1) % n_devices);
         try
         {
             for (size_t c = next_chunk.fetch_add(1); c < n_chunks && !failed.load(); c = next_chunk.fetch_add(1))
@@ -872,7 +878,14 @@ std::vector<Json> genotypeGraphs(
     // genotypes) with its share of the host threads.  The device part of SiteBatcher::run() is serialised by the device
     // mutex; everything else of different chunks overlaps -- one lane extracts while another is on the device and a third
     // writes documents.
-    const int lanes_wanted = parameters.lanes > 0 ? parameters.lanes : std::min(8, std::max(1, parameters.threads / 4));
+    // Several devices (parameters.devices, else paragraph::setDevices / PG_DEVICES): lane l works on device l % devices --
+    // chunks of sites are independent, so the devices never exchange anything (the reference's thread-per-(sample, graph)
+    // parallelism, grmpy/Workflow.cpp:225-231, with a GPU behind every lane); at least one lane per device.
+    if (!parameters.devices.empty())
+        paragraph::setDevices(parameters.devices);
+    const size_t n_devices = paragraph::deviceCount();
+    const int lanes_default = std::max((int)n_devices, std::min(8 * (int)n_devices, std::max(1, parameters.threads / 4)));
+    const int lanes_wanted = parameters.lanes > 0 ? parameters.lanes : lanes_default;
     const size_t lanes = std::max<size_t>(1, std::min<size_t>((size_t)lanes_wanted, n_even_chunks));
     const std::vector<std::pair<size_t, size_t>> chunk_ranges = chunkSchedule(n_graphs, per_batch, lanes);
     const size_t n_chunks = chunk_ranges.size();
@@ -921,6 +934,7 @@ std::vector<Json> genotypeGraphs(
         paragraph::Parameters site_parameters = siteParameters(parameters);
         site_parameters.threads = lane_threads;
         site_parameters.timings = parameters.timings ? &mine : nullptr;
+        site_parameters.device = (int)((size_t)lane_id % n_devices);
         try
         {
             for (;;)
@@ -1085,6 +1099,13 @@ extern "C" int pgw_genotype_graphs(
                     parameters.bad_align_uniq_kmer_len = (int)kv.second.asInt64();
                 else if (kv.first == "packed_reads")
                     parameters.packed_reads = kv.second.asBool();
+                else if (kv.first == "devices")
+                {
+                    if (!kv.second.isArray())
+                        return report("pgw_genotype_graphs: \"devices\" must be an array of device ordinals");
+                    for (size_t d = 0; d < kv.second.size(); ++d)
+                        parameters.devices.push_back((int)kv.second[d].asInt64());
+                }
                 else
                     return report("pgw_genotype_graphs: unknown option " + kv.first);
             }

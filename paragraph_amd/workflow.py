@@ -32,7 +32,8 @@ def load_library():
 def genotype_graphs(reference_fasta, manifest, graph_paths, genotyping_parameters=None, output_path=None, **options):
     """Genotypes every graph against every sample of the manifest; returns the list of genotype documents (and leaves the
     JSON array in output_path when one is given).  Options: threads, lanes, sites_per_batch, max_reads, bad_align_frac,
-    path_sequence_matching, kmer_sequence_matching, klib_sequence_matching, bad_align_uniq_kmer_len, packed_reads."""
+    path_sequence_matching, kmer_sequence_matching, klib_sequence_matching, bad_align_uniq_kmer_len, packed_reads,
+    devices (list of HIP ordinals the lanes are spread over; default PG_DEVICES, else device 0)."""
     L = load_library()
     paths = (C.c_char_p * len(graph_paths))(*[os.fsencode(p) for p in graph_paths])
     err = C.create_string_buffer(4096)

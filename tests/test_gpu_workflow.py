@@ -264,3 +264,39 @@ def test_swaps_600x_genotypes(tmp_path):
         assert gt["filters"] == ["PASS"] and gt["num_reads"] > 800, (chrom, gt)
         # every breakpoint agrees with the site call
         assert all(bp["gt"]["GT"] == gt["GT"] for bp in doc["samples"]["SWAPS"]["breakpoints"].values()), chrom
+
+
+def test_two_device_slots_give_the_same_documents(tmp_path):
+    """Lanes spread over a device list (PG_DEVICES / the "devices" option): on a 1-GPU box the list names the GPU twice = two
+    contexts (own streams, workspace, stage mutex, batch pool) on one device.  Six copies of the chrX graph in chunks of one
+    graph, two lanes -> lane 0 on slot 0, lane 1 on slot 1; the documents equal the single-device ones.  The batch staging
+    arrays come from the page-locked pool (pg_host_alloc)."""
+    import json
+    import sys
+    sites = os.path.join(ROOT, "tests", "golden", "sites", "chrX")
+    bam = os.path.join(sites, "chrX_graph_typing.bam")
+    manifest = tmp_path / "manifest.txt"
+    manifest.write_text("#id\tpath\tdepth\tread length\tdepth sd\tsex\nSAMPLE1\t%s\t44.2\t150\t20\tmale\nSAMPLE2\t%s\t44.2\t150\t20\tfemale\n"
+                        % (bam, bam))
+    graph = os.path.join(sites, "chrX_graph_typing.2sample.json")
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import json, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from paragraph_amd import workflow\n"
+        "opts = json.loads(sys.argv[1])\n"
+        "docs = workflow.genotype_graphs(%r, %r, [%r] * 6, genotyping_parameters=%r, threads=8, sites_per_batch=2, **opts)\n"
+        "print(json.dumps(docs))\n" % (ROOT, os.path.join(sites, "chrX_graph_typing.fa"), str(manifest), graph, os.path.join(sites, "param.json")))
+    env = dict(os.environ, PG_BATCH_TIMING="1")
+    env.pop("PG_DEVICES", None)
+    outs = []
+    for opts in ({"lanes": 2, "devices": [0, 0]}, {"lanes": 1}):
+        r = subprocess.run([sys.executable, str(script), json.dumps(opts)], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.splitlines()[-1]))
+    assert len(outs[0]) == 6 and outs[0] == outs[1]
+    assert outs[0][0]["samples"]["SAMPLE1"]["gt"]["GT"] == "REF" and outs[0][0]["samples"]["SAMPLE2"]["gt"]["GT"] == "REF/REF"
+    # the same through the environment (what bin/grmpy --devices all resolves to)
+    r = subprocess.run([sys.executable, str(script), json.dumps({"lanes": 2})], capture_output=True, text=True, timeout=600,
+                       env=dict(env, PG_DEVICES="0,0"))
+    assert r.returncode == 0 and json.loads(r.stdout.splitlines()[-1]) == outs[1], r.stderr[-2000:]

@@ -802,7 +802,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
             ++q;
         const int C = (int)keys[p].c;
         const HostGraph& hg = G->host[keys[p].graph];
-        const uint64_t nsteps = (uint64_t)hg.ncols + PG_GROUP_LANES - 1;
+        const uint64_t nsteps = pg_fill_steps(hg.ncols);
         const uint64_t trace_bytes = align_up(nsteps * 64 * pg_trace_lane_bytes(C), 256);
         const uint64_t seed_bytes = pg_seed_region_bytes(C, hg.n_nodes) + pg_key_region_bytes(hg.n_nodes);
         const uint64_t need = trace_bytes + 2 * seed_bytes;

@@ -30,6 +30,10 @@
 #define PG_META_IDLE 4u  // code 4 (scores 0 against everything), no flags
 #define PG_META_PAD 160   // idle words appended to every direction's column array (64-wide block prefetch)
 
+// pipeline steps of one sweep: the 16 lanes of a read are skewed by one column each (ncols + 15 steps); rounded up to an
+// even count because the step loop is unrolled twice with ping-pong register naming (the extra step runs on an idle column)
+static inline __host__ __device__ uint32_t pg_fill_steps(uint32_t ncols) { return (ncols + PG_GROUP_LANES) & ~1u; }
+
 #define PG_GAP_OPEN 6
 #define PG_GAP_EXT 1
 #define PG_PAD_SCORE (-300)        // byte variants (scores <= 250)

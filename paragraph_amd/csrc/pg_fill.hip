@@ -198,14 +198,18 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     uint32_t* __restrict__ seed = (uint32_t*)(a.workspace + itp->seed_off);    // [node][lane][SEED_DW]
     uint32_t* __restrict__ trace = (uint32_t*)(a.workspace + itp->trace_off);  // [step][TRACE_DW][lane]: one store instruction = 256 contiguous bytes
 
-    uint32_t Hp[C], E[C];
+    // H of the previous column lives in one of two register sets (HA / HB): a step reads one and writes the other, and the
+    // step loop is unrolled twice with the roles swapped -- no register-to-register copies at the loop edge (the same for the
+    // profile rows of the current / next column, sA / sB).
+    uint32_t HA[C], HB[C], E[C];
 #pragma unroll
     for (int r = 0; r < C; ++r)
     {
-        Hp[r] = 0;
+        HA[r] = 0;
+        HB[r] = 0;
         E[r] = 0;
     }
-    uint32_t Hsend = 0, Fsend = 0;
+    uint32_t Fsend = 0;
     // one-entry seed cache (byte variants): the seed this lane stored last stays in registers, so the usual bubble
     // (LF -> {ALT, RF}: RF's far predecessor is LF) needs no memory round trip -- a load there stalls the whole wavefront
     uint32_t cseed[WIDE ? 1 : C];
@@ -217,7 +221,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     colv |= colv << 16;
     const uint32_t GO2 = PG_GAP_OPEN | (PG_GAP_OPEN << 16);
     const uint32_t GE2 = PG_GAP_EXT | (PG_GAP_EXT << 16);
-    const uint32_t nsteps = gd.ncols + PG_GROUP_LANES - 1;
+    const uint32_t nsteps = pg_fill_steps(gd.ncols);  // even
     const uint32_t* profl = prof + grp * 4 * ROWS + k * C;
     const uint32_t trace_lane_off = (uint32_t)lane * 4u;
 
@@ -228,9 +232,9 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
     const const_u32_ptr cmeta = (const_u32_ptr)(uintptr_t)smeta;
     uint32_t mw1 = cmeta[1], mw2 = cmeta[2];
-    // software pipeline: `meta` / `s[]` always belong to the step about to be computed
+    // software pipeline: `meta` and the current profile rows always belong to the step about to be computed
     uint32_t meta = row_shr1_keep(cmeta[0], PG_META_IDLE);
-    uint32_t s[C];
+    uint32_t sA[C], sB[C];
     {
         const uint32_t code = PG_META_CODE(meta);
         const uint32_t* pr = profl + (code & 3u) * ROWS;
@@ -238,89 +242,155 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         for (int r = 0; r < C; r += 2)
         {
             const uint2 v = *(const uint2*)(pr + r);
-            s[r] = v.x;
-            s[r + 1] = v.y;
+            sA[r] = v.x;
+            sA[r + 1] = v.y;
         }
         if (code >= 4u)
         {
 #pragma unroll
             for (int r = 0; r < C; ++r)
-                s[r] = (uint32_t)r < real_rows ? 0u : PADPK;
+                sA[r] = (uint32_t)r < real_rows ? 0u : PADPK;
         }
-    }
-
-    for (uint32_t t = 0; t < nsteps; ++t)
-    {
-        const uint32_t meta_cur = meta;
-        const uint32_t dH = row_shr1_zero(Hsend);
-        uint32_t F = row_shr1_zero(Fsend);
-
-        // ---- prefetch the next step's meta word and profile rows -----------------------------------
-        meta = row_shr1_keep(mw1, meta_cur);
-        mw1 = mw2;
-        mw2 = cmeta[t + 3];
-        uint32_t sn[C];
-        {
-            const uint32_t code = PG_META_CODE(meta);
-            const uint32_t* pr = profl + (code & 3u) * ROWS;
 #pragma unroll
-            for (int r = 0; r < C; r += 2)
+        for (int r = 0; r < C; ++r)
+            sB[r] = 0;
+    }
+    // the H trace of one step is [TRACE_DW][64 lanes] dwords behind a wave-uniform base that advances by one step per step:
+    // the stores take the scalar-base form (SGPR pair + 32-bit lane offset + immediate), no per-step vector address arithmetic
+    // (readfirstlane: the base is uniform by construction; this makes it so for the compiler, which must keep it in SGPRs)
+    uint64_t tbase = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)(uintptr_t)trace >> 32)) << 32)
+        | __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)trace);
+    constexpr uint32_t TRACE_STEP_BYTES = 64u * 4u * (uint32_t)TRACE_DW;
+
+    // ---- one column of the affine-gap recurrence for C rows x 2 strands (Hin: previous column, Hout: this column) -----------
+    auto column = [&](uint32_t (&Hin)[C], uint32_t (&Hout)[C], const uint32_t (&sc)[C], uint32_t dH, uint32_t F) __attribute__((always_inline)) {
+        uint32_t diag = dH;
+#pragma unroll
+        for (int r = 0; r < C; ++r)
+        {
+            uint32_t h = pk_add(diag, sc[r]);  // H(i-1,j-1) + s   (may be negative: signed compare next)
+            h = pk_maxi(h, E[r]);              // E >= 0 makes the explicit max(.,0) unnecessary
+            h = pk_maxu(h, F);
+            diag = Hin[r];
+            Hout[r] = h;
+            const uint32_t tt = pk_subsat(h, GO2);
+            E[r] = pk_maxu(pk_subsat(E[r], GE2), tt);
+            F = pk_maxu(pk_subsat(F, GE2), tt);
+        }
+        Fsend = F;
+
+        // ---- running node maximum + first column reaching it (gssw.c:369-386) -----------------------
+        uint32_t cm[C];
+#pragma unroll
+        for (int r = 0; r < C; ++r)
+            cm[r] = Hout[r];
+        // tree reduction (a chain would serialise 2C dependent packed ops)
+#pragma unroll
+        for (int w = 1; w < C; w *= 2)
+#pragma unroll
+            for (int r = 0; r + w < C; r += 2 * w)
+                cm[r] = pk_maxu(cm[r], cm[r + w]);
+        const uint32_t Mn = pk_maxu(M, cm[0]);
+        if (DIR == 0 || WIDE)
+        {
+            // mask = 0xFFFF in the halves whose maximum grew: (M - Mn) is negative there as a 16-bit integer
+            uint32_t grew;
+            asm("v_pk_sub_u16 %0, %1, %2\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=v"(grew) : "v"(M), "v"(Mn));
+            if (WIDE)
             {
-                const uint2 v = *(const uint2*)(pr + r);
-                sn[r] = v.x;
-                sn[r + 1] = v.y;
+                // The row of the maximum matters in one case only: a node whose final maximum is 251..255 -- the reference's
+                // alignsEndAtMultNodes reads word-mode matrices through a byte pointer and then only sees the first half of the
+                // node's cells (epilogue).  A maximum passes through each of those five values at most once, so the row search
+                // runs a handful of times per node instead of at every growth step.  (The traceback's start row is found from
+                // the H trace in the epilogue, like in the byte variants.)
+                const uint32_t mnA = Mn & 0xFFFFu, mnB = Mn >> 16;
+                const bool needA = (grew & 0xFFFFu) && (mnA - 251u) <= 4u, needB = (grew >> 16) && (mnB - 251u) <= 4u;
+                if (needA || needB)
+                {
+                    uint32_t frA = FR & 0xFFFFu, frB = FR >> 16;
+#pragma unroll
+                    for (int r = C - 1; r >= 0; --r)
+                    {
+                        if (needA && (Hout[r] & 0xFFFFu) == mnA)
+                            frA = (uint32_t)r;
+                        if (needB && (Hout[r] >> 16) == mnB)
+                            frB = (uint32_t)r;
+                    }
+                    FR = frA | (frB << 16);
+                }
             }
-            if (code >= 4u)
-            {  // rare: N in the graph, or the idle columns behind its end
+            asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(FC) : "v"(grew), "v"(colv));
+        }
+        M = Mn;
+
+        if (DIR == 0)
+        {
+            if (WIDE)
+            {
 #pragma unroll
                 for (int r = 0; r < C; ++r)
-                    sn[r] = (uint32_t)r < real_rows ? 0u : PADPK;
-            }
-        }
-
-        if (meta_cur & PG_META_FIRST)
-        {
-            // seed = lane-wise max over predecessors (gssw_create_seed_byte); the predecessor that
-            // directly precedes this node in the layout is still in Hp/E.
-            const uint32_t node = PG_META_NODE(meta_cur);
-            uint32_t sh[C], se[C];
-#pragma unroll
-            for (int r = 0; r < C; ++r)
-            {
-                sh[r] = 0;
-                se[r] = 0;
-            }
-            bool adj = (meta_cur & PG_META_PRED_ADJ) != 0;
-            if (!WIDE && !(meta_cur & PG_META_PRED_MANY))
-            {
-                // predecessor summary in the meta word: no table loads
-                if (meta_cur & PG_META_PRED_ONE)
                 {
-                    const uint32_t pid = meta_cur >> PG_META_PRED_SHIFT;
-                    uint32_t w[C];
-                    if (pid == cnode)
-                    {
-#pragma unroll
-                        for (int r = 0; r < C; ++r)
-                            w[r] = cseed[WIDE ? 0 : r];
-                    }
+                    if (r < 16)
+                        asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(trace_lane_off), "v"(Hout[r]), "s"(tbase), "n"(r * 256) : "memory");
                     else
-                    {
-                        const uint32_t* sp = seed + ((size_t)pid * 64 + lane) * SEED_DW;
-#pragma unroll
-                        for (int r = 0; r < C; ++r)
-                            w[r] = sp[r];
-                    }
-#pragma unroll
-                    for (int r = 0; r < C; ++r)
-                    {
-                        sh[r] = __builtin_amdgcn_perm(0u, w[r], 0x0c010c00u);
-                        se[r] = __builtin_amdgcn_perm(0u, w[r], 0x0c030c02u);
-                    }
+                        asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(trace_lane_off), "v"(Hout[r]), "s"(tbase + 4096u), "n"((r - 16) * 256) : "memory");
                 }
             }
             else
             {
+#pragma unroll
+                for (int r = 0; r < C; r += 2)
+                {
+                    const uint32_t packed = __builtin_amdgcn_perm(Hout[r + 1], Hout[r], 0x06020400u);  // bytes A_r, A_r+1, B_r, B_r+1 (one v_perm)
+                    asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(trace_lane_off), "v"(packed), "s"(tbase), "n"((r / 2) * 256) : "memory");
+                }
+            }
+        }
+    };
+
+    // ---- node boundaries ---------------------------------------------------------------------------------------------------
+    // first column: seed = lane-wise max over the predecessors (gssw_create_seed_byte); the predecessor that directly
+    // precedes this node in the layout is still in Hin / E
+    auto first_column = [&](uint32_t (&Hin)[C], uint32_t meta_cur) __attribute__((always_inline)) {
+        const uint32_t node = PG_META_NODE(meta_cur);
+        uint32_t sh[C], se[C];
+#pragma unroll
+        for (int r = 0; r < C; ++r)
+        {
+            sh[r] = 0;
+            se[r] = 0;
+        }
+        bool adj = (meta_cur & PG_META_PRED_ADJ) != 0;
+        if (!WIDE && !(meta_cur & PG_META_PRED_MANY))
+        {
+            // predecessor summary in the meta word: no table loads
+            if (meta_cur & PG_META_PRED_ONE)
+            {
+                const uint32_t pid = meta_cur >> PG_META_PRED_SHIFT;
+                uint32_t w[C];
+                if (pid == cnode)
+                {
+#pragma unroll
+                    for (int r = 0; r < C; ++r)
+                        w[r] = cseed[WIDE ? 0 : r];
+                }
+                else
+                {
+                    const uint32_t* sp = seed + ((size_t)pid * 64 + lane) * SEED_DW;
+#pragma unroll
+                    for (int r = 0; r < C; ++r)
+                        w[r] = sp[r];
+                }
+#pragma unroll
+                for (int r = 0; r < C; ++r)
+                {
+                    sh[r] = __builtin_amdgcn_perm(0u, w[r], 0x0c010c00u);
+                    se[r] = __builtin_amdgcn_perm(0u, w[r], 0x0c030c02u);
+                }
+            }
+        }
+        else
+        {
             adj = false;
             const PgNode nd = nodes[node];
             for (uint32_t p = 0; p < nd.n_pred; ++p)
@@ -348,162 +418,112 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                     }
                 }
             }
-            }
+        }
+#pragma unroll
+        for (int r = 0; r < C; ++r)
+        {
+            Hin[r] = adj ? pk_maxu(Hin[r], sh[r]) : sh[r];
+            E[r] = adj ? pk_maxu(E[r], se[r]) : se[r];
+        }
+        M = 0;
+        FC = 0;
+        FR = 0;
+    };
+    // last column: the seed for the successors, and the node's maximum into its key
+    auto last_column = [&](const uint32_t (&Hout)[C], uint32_t meta_cur) __attribute__((always_inline)) {
+        const uint32_t node = PG_META_NODE(meta_cur);
+        if (meta_cur & PG_META_SAVE)
+        {
+            uint32_t* sp = seed + ((size_t)node * 64 + lane) * SEED_DW;
 #pragma unroll
             for (int r = 0; r < C; ++r)
             {
-                Hp[r] = adj ? pk_maxu(Hp[r], sh[r]) : sh[r];
-                E[r] = adj ? pk_maxu(E[r], se[r]) : se[r];
+                if (WIDE)
+                {
+                    sp[2 * r] = Hout[r];
+                    sp[2 * r + 1] = E[r];
+                }
+                else
+                {
+                    const uint32_t w = __builtin_amdgcn_perm(E[r], Hout[r], 0x06040200u);
+                    sp[r] = w;
+                    cseed[r] = w;
+                }
             }
-            M = 0;
-            FC = 0;
-            FR = 0;
+            cnode = node;
         }
-
-        // ---- one column of the affine-gap recurrence for C rows x 2 strands ------------------------
-        uint32_t diag = dH;
-        uint32_t hs[C];
-#pragma unroll
-        for (int r = 0; r < C; ++r)
-        {
-            uint32_t h = pk_add(diag, s[r]);  // H(i-1,j-1) + s   (may be negative: signed compare next)
-            h = pk_maxi(h, E[r]);             // E >= 0 makes the explicit max(.,0) unnecessary
-            h = pk_maxu(h, F);
-            diag = Hp[r];
-            Hp[r] = h;
-            hs[r] = h;
-            const uint32_t tt = pk_subsat(h, GO2);
-            E[r] = pk_maxu(pk_subsat(E[r], GE2), tt);
-            F = pk_maxu(pk_subsat(F, GE2), tt);
-        }
-        Hsend = diag;
-        Fsend = F;
-
-        // ---- running node maximum + first column reaching it (gssw.c:369-386) -----------------------
+        // key: max (12 bits) | inverted column (16 bits; a direction has <= 65519 columns) | inverted lane (4 bits)
+        const uint32_t kinv = (uint32_t)(15 - k);
+        const uint32_t mA = M & 0xFFFFu, mB = M >> 16;
+        const uint32_t cA = FC & 0xFFFFu, cB = FC >> 16;
         if (WIDE)
         {
-            // tree reduction, as below (hs is scratch from here on; Hp still holds this column)
-#pragma unroll
-            for (int w = 1; w < C; w *= 2)
-#pragma unroll
-                for (int r = 0; r + w < C; r += 2 * w)
-                    hs[r] = pk_maxu(hs[r], hs[r + w]);
-            const uint32_t Mn = pk_maxu(M, hs[0]);
-            uint32_t inc = pk_minu(pk_sub(Mn, M), 0x00010001u);
-            inc = pk_sub(0u, inc);
-            asm volatile("" : "+v"(inc));
-            FC = (FC & ~inc) | (colv & inc);
-            // The row of the maximum matters in one case only: a node whose final maximum is 251..255 -- the reference's
-            // alignsEndAtMultNodes reads word-mode matrices through a byte pointer and then only sees the first half of the
-            // node's cells (epilogue).  A maximum passes through each of those five values at most once, so the row search
-            // runs a handful of times per node instead of at every growth step.  (The traceback's start row is found from
-            // the H trace in the epilogue, like in the byte variants.)
-            const uint32_t mnA = Mn & 0xFFFFu, mnB = Mn >> 16;
-            const bool needA = (inc & 0xFFFFu) && (mnA - 251u) <= 4u, needB = (inc >> 16) && (mnB - 251u) <= 4u;
-            if (needA || needB)
-            {
-                uint32_t frA = FR & 0xFFFFu, frB = FR >> 16;
-#pragma unroll
-                for (int r = C - 1; r >= 0; --r)
-                {
-                    if (needA && (Hp[r] & 0xFFFFu) == mnA)
-                        frA = (uint32_t)r;
-                    if (needB && (Hp[r] >> 16) == mnB)
-                        frB = (uint32_t)r;
-                }
-                FR = frA | (frB << 16);
-            }
-            M = Mn;
+            // key: max | inverted column (16 bits) | inverted row (16 bits)
+            const uint32_t rA = (uint32_t)(k * C) + (FR & 0xFFFFu), rB = (uint32_t)(k * C) + (FR >> 16);
+            if (mA)
+                atomicMax(&nodekey64[node * 8 + grp * 2 + 0],
+                          ((unsigned long long)mA << 32) | ((unsigned long long)(0xFFFFu - cA) << 16) | (0xFFFFu - rA));
+            if (mB)
+                atomicMax(&nodekey64[node * 8 + grp * 2 + 1],
+                          ((unsigned long long)mB << 32) | ((unsigned long long)(0xFFFFu - cB) << 16) | (0xFFFFu - rB));
         }
         else
         {
-            // tree reduction (a chain would serialise 2C dependent packed ops)
-#pragma unroll
-            for (int w = 1; w < C; w *= 2)
-#pragma unroll
-                for (int r = 0; r + w < C; r += 2 * w)
-                    hs[r] = pk_maxu(hs[r], hs[r + w]);
-            const uint32_t Mn = pk_maxu(M, hs[0]);
-            if (DIR == 0)
-            {
-                uint32_t inc = pk_minu(pk_sub(Mn, M), 0x00010001u);  // 1 where the half grew
-                inc = pk_sub(0u, inc);                               // 0xFFFF where it grew
-                asm volatile("" : "+v"(inc));                        // keep it a mask: one v_bfi_b32, not compare + select per half
-                FC = (FC & ~inc) | (colv & inc);
-            }
-            M = Mn;
+            if (mA)
+                atomicMax(&nodekey[(node * 8 + grp * 2 + 0) * 2], (mA << 20) | ((0xFFFFu - cA) << 4) | kinv);
+            if (mB)
+                atomicMax(&nodekey[(node * 8 + grp * 2 + 1) * 2], (mB << 20) | ((0xFFFFu - cB) << 4) | kinv);
         }
+    };
 
-        if (DIR == 0)
+    // ---- one pipeline step: reads Hin (previous column) / sc (this column's profile rows), writes Hout / sn (next column's) ---
+    auto step = [&](uint32_t (&Hin)[C], uint32_t (&Hout)[C], uint32_t (&sc)[C], uint32_t (&sn)[C], uint32_t t) __attribute__((always_inline)) {
+        const uint32_t meta_cur = meta;
+        // Hout still holds the column before the previous one: its last row is what the next lane needs as its diagonal
+        // input one step later (lane k + 1 works one column behind lane k)
+        const uint32_t dH = row_shr1_zero(Hout[C - 1]);
+        const uint32_t F = row_shr1_zero(Fsend);
+        // prefetch the next step's meta word and profile rows
+        meta = row_shr1_keep(mw1, meta_cur);
+        mw1 = mw2;
+        mw2 = cmeta[t + 3];
         {
-            // uniform step base + 32-bit lane offset: the store takes the scalar-base addressing form, no per-step VALU
-            // address arithmetic
-            uint32_t* tp = (uint32_t*)((char*)(trace + (size_t)t * 64 * TRACE_DW) + trace_lane_off);
-            if (WIDE)
+            const uint32_t* pr = profl + (PG_META_CODE(meta) & 3u) * ROWS;
+#pragma unroll
+            for (int r = 0; r < C; r += 2)
             {
+                const uint2 v = *(const uint2*)(pr + r);
+                sn[r] = v.x;
+                sn[r + 1] = v.y;
+            }
+        }
+        // one test for everything that is rare: a node boundary in this column, or a next column that carries code 4
+        if (((meta_cur & (PG_META_FIRST | PG_META_LAST)) | (meta & 4u)) != 0u)
+        {
+            if (meta & 4u)
+            {  // N in the graph, or the idle columns behind its end
 #pragma unroll
                 for (int r = 0; r < C; ++r)
-                    tp[r * 64] = Hp[r];  // halves A_r, B_r
+                    sn[r] = (uint32_t)r < real_rows ? 0u : PADPK;
             }
-            else
-            {
-#pragma unroll
-                for (int r = 0; r < C; r += 2)
-                    tp[(r / 2) * 64] = __builtin_amdgcn_perm(Hp[r + 1], Hp[r], 0x06020400u);  // bytes A_r, A_r+1, B_r, B_r+1 (one v_perm)
-            }
+            if (meta_cur & PG_META_FIRST)
+                first_column(Hin, meta_cur);
+            column(Hin, Hout, sc, dH, F);
+            if (meta_cur & PG_META_LAST)
+                last_column(Hout, meta_cur);
         }
-
-        if (meta_cur & PG_META_LAST)
-        {
-            const uint32_t node = PG_META_NODE(meta_cur);
-            if (meta_cur & PG_META_SAVE)
-            {
-                uint32_t* sp = seed + ((size_t)node * 64 + lane) * SEED_DW;
-#pragma unroll
-                for (int r = 0; r < C; ++r)
-                {
-                    if (WIDE)
-                    {
-                        sp[2 * r] = Hp[r];
-                        sp[2 * r + 1] = E[r];
-                    }
-                    else
-                    {
-                        const uint32_t w = __builtin_amdgcn_perm(E[r], Hp[r], 0x06040200u);
-                        sp[r] = w;
-                        cseed[r] = w;
-                    }
-                }
-                cnode = node;
-            }
-            // key: max (12 bits) | inverted column (16 bits; a direction has <= 65519 columns) | inverted lane (4 bits)
-            const uint32_t kinv = (uint32_t)(15 - k);
-            const uint32_t mA = M & 0xFFFFu, mB = M >> 16;
-            const uint32_t cA = FC & 0xFFFFu, cB = FC >> 16;
-            if (WIDE)
-            {
-                // key: max | inverted column (16 bits) | inverted row (16 bits)
-                const uint32_t rA = (uint32_t)(k * C) + (FR & 0xFFFFu), rB = (uint32_t)(k * C) + (FR >> 16);
-                if (mA)
-                    atomicMax(&nodekey64[node * 8 + grp * 2 + 0],
-                              ((unsigned long long)mA << 32) | ((unsigned long long)(0xFFFFu - cA) << 16) | (0xFFFFu - rA));
-                if (mB)
-                    atomicMax(&nodekey64[node * 8 + grp * 2 + 1],
-                              ((unsigned long long)mB << 32) | ((unsigned long long)(0xFFFFu - cB) << 16) | (0xFFFFu - rB));
-            }
-            else
-            {
-                if (mA)
-                    atomicMax(&nodekey[(node * 8 + grp * 2 + 0) * 2], (mA << 20) | ((0xFFFFu - cA) << 4) | kinv);
-                if (mB)
-                    atomicMax(&nodekey[(node * 8 + grp * 2 + 1) * 2], (mB << 20) | ((0xFFFFu - cB) << 4) | kinv);
-            }
-        }
+        else
+            column(Hin, Hout, sc, dH, F);
         colv = pk_add(colv, 0x00010001u);
-#pragma unroll
-        for (int r = 0; r < C; ++r)
-            s[r] = sn[r];
+        tbase += TRACE_STEP_BYTES;
+    };
+
+    for (uint32_t t = 0; t < nsteps; t += 2)
+    {
+        step(HA, HB, sA, sB, t);
+        step(HB, HA, sB, sA, t + 1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trace stores above are invisible to the compiler's own counters
 
     __threadfence_block();
     __syncthreads();

@@ -211,8 +211,6 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
         (void)hipEventDestroy(e);
     if (ctx->workspace)
         (void)hipFree(ctx->workspace);
-    if (ctx->ops_scratch)
-        (void)hipFree(ctx->ops_scratch);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2)
@@ -288,7 +286,7 @@ extern "C" pg_status pg_counts_zero(pg_ctx* ctx, uint32_t* d_counts, uint64_t n_
         return PG_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (n_counters)
-        HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, n_counters * sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, n_counters * sizeof(uint32_t), ctx->stream2));  // the stream the count path runs on
     return PG_OK;
 }
 
@@ -304,20 +302,40 @@ extern "C" pg_status pg_ctx_sync_compute(pg_ctx* ctx)
     return PG_OK;
 }
 
-hipError_t pg_stage_begin(pg_ctx* ctx, pg_batch* b)
+// A stage waits for the batch's inputs and for the batch's previous stage (which may have run on the other compute stream).
+hipError_t pg_stage_begin_on(pg_ctx* ctx, pg_batch* b, hipStream_t s)
 {
+    (void)ctx;
+    hipError_t e = hipSuccess;
     if (b->upload_recorded)
-        return hipStreamWaitEvent(ctx->stream, b->ev_upload, 0);
-    return hipSuccess;
+        e = hipStreamWaitEvent(s, b->ev_upload, 0);
+    if (e == hipSuccess && b->busy_recorded)
+        e = hipStreamWaitEvent(s, b->ev_busy, 0);
+    return e;
 }
 
-hipError_t pg_stage_end(pg_ctx* ctx, pg_batch* b)
+hipError_t pg_stage_end_on(pg_ctx* ctx, pg_batch* b, hipStream_t s)
 {
+    if (const pg_graphs* G = b->graphs)
+    {
+        const int w = s == ctx->stream ? 0 : 1;
+        hipError_t e = hipSuccess;
+        if (!G->ev_use[w])
+            e = hipEventCreateWithFlags(&G->ev_use[w], hipEventDisableTiming);
+        if (e == hipSuccess)
+            e = hipEventRecord(G->ev_use[w], s);
+        if (e != hipSuccess)
+            return e;
+        G->use_recorded[w] = true;
+    }
     if (!b->ev_busy)
         return hipSuccess;
     b->busy_recorded = true;
-    return hipEventRecord(b->ev_busy, ctx->stream);
+    return hipEventRecord(b->ev_busy, s);
 }
+
+hipError_t pg_stage_begin(pg_ctx* ctx, pg_batch* b) { return pg_stage_begin_on(ctx, b, ctx->stream); }
+hipError_t pg_stage_end(pg_ctx* ctx, pg_batch* b) { return pg_stage_end_on(ctx, b, ctx->stream); }
 
 hipError_t pg_batch_wait(pg_ctx* ctx, pg_batch* b)
 {
@@ -405,6 +423,7 @@ static void recycle_sync_events(pg_ctx* ctx)
     for (auto e : ctx->sync_events_in_flight)
         ctx->sync_event_pool.push_back(e);
     ctx->sync_events_in_flight.clear();
+    ctx->half_free[0] = ctx->half_free[1] = nullptr;  // every traceback is over (the caller synchronised both streams)
 }
 // A workflow never calls pg_ctx_sync: ordering events whose work is over (they complete in the order they were recorded
 // per stream, so the scan stops at the first one still pending) go back to the pool at the start of every pg_batch_align.
@@ -412,7 +431,13 @@ static void recycle_done_sync_events(pg_ctx* ctx)
 {
     size_t done = 0;
     while (done < ctx->sync_events_in_flight.size() && hipEventQuery(ctx->sync_events_in_flight[done]) == hipSuccess)
-        ctx->sync_event_pool.push_back(ctx->sync_events_in_flight[done++]);
+    {
+        const hipEvent_t e = ctx->sync_events_in_flight[done++];
+        for (int h = 0; h < 2; ++h)
+            if (ctx->half_free[h] == e)
+                ctx->half_free[h] = nullptr;  // that traceback is over: the half needs no wait (and the event gets a new job)
+        ctx->sync_event_pool.push_back(e);
+    }
     if (done)
         ctx->sync_events_in_flight.erase(ctx->sync_events_in_flight.begin(), ctx->sync_events_in_flight.begin() + (std::ptrdiff_t)done);
     (void)hipGetLastError();  // hipErrorNotReady of the first pending event is not an error
@@ -641,9 +666,14 @@ extern "C" void pg_graphs_destroy(pg_ctx* ctx, pg_graphs* G)
     if (!G)
         return;
     if (ctx)
-    {
         (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
+    // only the stages that used THIS graph set have to be over (other lanes' batches keep the streams busy all the time)
+    for (int w = 0; w < 2; ++w)
+    {
+        if (G->use_recorded[w])
+            (void)hipEventSynchronize(G->ev_use[w]);
+        if (G->ev_use[w])
+            (void)hipEventDestroy(G->ev_use[w]);
     }
     (void)pg_dev_free(G->d_graphs);
     (void)pg_dev_free(G->d_nodes);
@@ -781,16 +811,13 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
     items.reserve(keys.size() / 2 + 16);
     Chunk cur{};
     bool open = false;
-    uint64_t cur_scratch = 0;
     b->max_ws = 0;
-    b->max_scratch = 0;
     auto close_chunk = [&]() {
         if (open)
         {
             cur.pair_end = (uint32_t)(items.size() / 2);
             b->chunks.push_back(cur);
             b->max_ws = std::max(b->max_ws, cur.ws_bytes);
-            b->max_scratch = std::max(b->max_scratch, cur_scratch);
             open = false;
         }
     };
@@ -815,7 +842,6 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
             cur = Chunk{};
             cur.C = C;
             cur.pair_begin = (uint32_t)(items.size() / 2);
-            cur_scratch = 0;
             open = true;
         }
         PgWorkItem fw{}, rv{};
@@ -840,7 +866,6 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
         cur.ws_bytes += need;
         cur.trace_bytes += nsteps * 64 * pg_trace_lane_bytes(C);
         cur.max_nodes = std::max(cur.max_nodes, hg.n_nodes);
-        cur_scratch += (uint64_t)PG_GROUPS * pg_ops_cap(C);
         items.push_back(fw);
         items.push_back(rv);
         p = q;
@@ -866,9 +891,9 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
 // pg_batch_align (never while planning, so that a batch can be uploaded while another one is on the device).
 static pg_status ensure_ctx_workspace(pg_ctx* ctx, const pg_batch* b)
 {
-    // Two halves when the batch has more than one chunk: chunk i uses half (i & 1) so that trace(i) can overlap fill(i + 1).
-    // A single-chunk batch (the usual workflow batch) lives at offset 0 and needs no second half.
-    const uint64_t need = b->chunks.size() > 1 ? 2 * b->max_ws : b->max_ws;
+    // Two halves, used alternately by the chunks of all batches (ctx->chunk_seq): the traceback of a chunk overlaps the fill of
+    // the next chunk -- of the same batch or of the next batch.
+    const uint64_t need = 2 * b->max_ws;
     if (need > ctx->ws_cap)
     {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -877,6 +902,7 @@ static pg_status ensure_ctx_workspace(pg_ctx* ctx, const pg_batch* b)
             HIP_TRY(ctx, hipFree(ctx->workspace));
         ctx->workspace = nullptr;
         ctx->ws_cap = 0;
+        ctx->half_free[0] = ctx->half_free[1] = nullptr;  // both streams are idle: nothing reads the old halves
         // batches of one workflow differ by a few percent: one eighth of headroom spares the next, slightly larger one a
         // second multi-GiB allocation (each costs up to a second)
         uint64_t want = std::min<uint64_t>(need + need / 8, std::max<uint64_t>(ctx->ws_limit, need));
@@ -889,17 +915,6 @@ static pg_status ensure_ctx_workspace(pg_ctx* ctx, const pg_batch* b)
             HIP_TRY(ctx, hipMalloc((void**)&ctx->workspace, want));
         }
         ctx->ws_cap = want;
-    }
-    if (b->max_scratch > ctx->ops_scratch_cap)
-    {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
-        if (ctx->ops_scratch)
-            HIP_TRY(ctx, hipFree(ctx->ops_scratch));
-        ctx->ops_scratch = nullptr;
-        ctx->ops_scratch_cap = 0;
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->ops_scratch, b->max_scratch * sizeof(pg_op)));
-        ctx->ops_scratch_cap = b->max_scratch;
     }
     return PG_OK;
 }
@@ -1024,25 +1039,26 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     if (!(flags & PG_AF_KEEP_RESULTS) || (flags == PG_AF_ALL))
         HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
     const bool revg = (flags & PG_AF_REVERSE_GRAPH) != 0;
-    // Chunk pipeline on two streams: fill(i) runs on `stream`, pick+trace(i) on `stream2`; chunk i uses workspace
-    // half (i & 1), so the latency-bound traceback of chunk i overlaps the VALU-bound fill of chunk i+1.
+    // Chunk pipeline on two streams: fill(c) runs on `stream`, pick + traceback(c) on `stream2`; chunk number ctx->chunk_seq
+    // (counted over all batches of the ctx) uses workspace half (chunk_seq & 1), so the latency-bound traceback of a chunk
+    // overlaps the VALU-bound fill of the next one -- also across batches: nothing of this call makes the main stream wait
+    // for a traceback except the one that still reads the half about to be overwritten.
     const uint64_t half = (ctx->ws_cap / 2) & ~(uint64_t)255;  // keeps the 256-byte alignment of the trace rows
-    std::vector<hipEvent_t> trace_done;
     {
-        // the trace stream must see everything queued on the main stream so far (memsets, uploads, path stage)
+        // the trace stream must see everything queued on the main stream so far (memsets, uploads, seed stages)
         hipEvent_t e0;
         HIP_TRY(ctx, get_sync_event(ctx, &e0));
         HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, e0, 0));
         ctx->sync_events_in_flight.push_back(e0);
     }
-    size_t ci = 0;
     for (const Chunk& ch : b->chunks)
     {
         const uint32_t n_pairs = ch.pair_end - ch.pair_begin;
-        uint8_t* ws = ctx->workspace + (ci & 1) * half;
-        if (ci >= 2)
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, trace_done[ci - 2], 0));  // workspace half is free again
+        const unsigned h = (unsigned)(ctx->chunk_seq & 1u);
+        uint8_t* ws = ctx->workspace + h * half;
+        if (ctx->half_free[h])
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->half_free[h], 0));  // the traceback that read this half is done
         PgFillArgs fa{};
         fa.items = b->d_items;
         fa.item_begin = 2 * ch.pair_begin;
@@ -1091,7 +1107,6 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         ta.workspace = ws;
         ta.fillsum = b->d_fillsum;
         ta.results = b->d_results;
-        ta.ops_scratch = ctx->ops_scratch;
         ta.ops = b->d_ops;
         ta.ops_counter = b->d_ops_counter;
         if (ctx->timing)
@@ -1110,14 +1125,13 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         hipEvent_t td;
         HIP_TRY(ctx, get_sync_event(ctx, &td));
         HIP_TRY(ctx, hipEventRecord(td, ctx->stream2));
-        trace_done.push_back(td);
+        ctx->half_free[h] = td;
         ctx->sync_events_in_flight.push_back(td);
-        ++ci;
+        ++ctx->chunk_seq;
     }
-    // everything later on the main stream (count path, downloads) sees the finished tracebacks
-    for (size_t k = trace_done.size() >= 2 ? trace_done.size() - 2 : 0; k < trace_done.size(); ++k)
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, trace_done[k], 0));
-    HIP_TRY(ctx, pg_stage_end(ctx, b));
+    // the batch is busy until its last traceback is over; later stages of THIS batch wait for that (pg_stage_begin*), other
+    // batches' fills do not
+    HIP_TRY(ctx, pg_stage_end_on(ctx, b, ctx->stream2));
     return PG_OK;
 }
 

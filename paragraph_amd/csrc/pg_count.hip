@@ -542,7 +542,10 @@ extern "C" pg_status pg_graphs_set_labels(
         G->h_seq_off[g + 1] = G->h_seq_off[g] + (nl <= PG_MAX_SEQ_TABLE_LABELS ? (1ull << nl) : 0);
     }
     if (G->d_cnt_graphs)  // labels set again: kernels of an earlier batch may still read the old tables
+    {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
+    }
     (void)pg_dev_free(G->d_cnt_graphs);
     (void)pg_dev_free(G->d_cnt_pred_off);
     (void)pg_dev_free(G->d_cnt_pred);
@@ -666,7 +669,9 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     if (!b->fragments_set)
         return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_count: call pg_batch_set_fragments first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, pg_stage_begin(ctx, b));
+    // the count path runs behind the traceback on the second compute stream: the main stream stays free for the next batch's fill
+    hipStream_t cs = ctx->stream2;
+    HIP_TRY(ctx, pg_stage_begin_on(ctx, b, cs));
     const uint32_t n = b->n_reads;
     pg_count_layout lay;
     layout_of(G, &lay);
@@ -682,10 +687,10 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
             HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_counts, lay.n_counters * sizeof(uint32_t)));
         }
         counts = b->d_counts;
-        HIP_TRY(ctx, hipMemsetAsync(counts, 0, lay.n_counters * sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(counts, 0, lay.n_counters * sizeof(uint32_t), cs));
         b->counts_owned_valid = true;
     }
-    HIP_TRY(ctx, hipMemsetAsync(b->d_path_counter, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_path_counter, 0, sizeof(unsigned long long), cs));
     CountArgs a{};
     a.n_reads = n;
     a.prm = *params;
@@ -724,12 +729,12 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     }
     if (n)
     {
-        hipLaunchKernelGGL(pg_support_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL(pg_support_kernel, dim3((n + 63) / 64), dim3(64), 0, cs, a);
         HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(pg_fragment_kernel, dim3((b->n_frags + FRAG_BLOCK - 1) / FRAG_BLOCK), dim3(FRAG_BLOCK), 0, ctx->stream, a);
+        hipLaunchKernelGGL(pg_fragment_kernel, dim3((b->n_frags + FRAG_BLOCK - 1) / FRAG_BLOCK), dim3(FRAG_BLOCK), 0, cs, a);
         HIP_TRY(ctx, hipGetLastError());
     }
-    HIP_TRY(ctx, pg_stage_end(ctx, b));
+    HIP_TRY(ctx, pg_stage_end_on(ctx, b, cs));
     return PG_OK;
 }
 

@@ -258,8 +258,9 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // the H trace of one step is [TRACE_DW][64 lanes] dwords behind a wave-uniform base that advances by one step per step:
     // the stores take the scalar-base form (SGPR pair + 32-bit lane offset + immediate), no per-step vector address arithmetic
     // (readfirstlane: the base is uniform by construction; this makes it so for the compiler, which must keep it in SGPRs)
-    uint64_t tbase = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)(uintptr_t)trace >> 32)) << 32)
-        | __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)trace);
+    // (the builtin returns a signed int: without the casts the low half would be sign-extended over the high one)
+    uint64_t tbase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)(uintptr_t)trace >> 32)) << 32)
+        | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)trace);
     constexpr uint32_t TRACE_STEP_BYTES = 64u * 4u * (uint32_t)TRACE_DW;
 
     // ---- one column of the affine-gap recurrence for C rows x 2 strands (Hin: previous column, Hout: this column) -----------

@@ -37,11 +37,14 @@ struct pg_ctx
     hipStream_t stream2 = nullptr;  // pick + traceback of chunk i overlaps the fill of chunk i + 1
     hipStream_t stream_copy = nullptr;  // uploads of the NEXT batch / downloads of the PREVIOUS one overlap the kernels
     std::vector<hipEvent_t> sync_event_pool, sync_events_in_flight;
+    // The workspace is two halves used alternately by the chunks of ALL batches in the order they are aligned (chunk_seq):
+    // the fill of a chunk (main stream) only waits for the traceback of the chunk two before it (half_free), so the
+    // traceback + count of one batch (second stream) run under the fill of the next batch.
+    uint64_t chunk_seq = 0;
+    hipEvent_t half_free[2] = { nullptr, nullptr };
     uint64_t ws_limit = 8ull << 30;
     uint8_t* workspace = nullptr;
     uint64_t ws_cap = 0;
-    pg_op* ops_scratch = nullptr;
-    uint64_t ops_scratch_cap = 0;  // entries
     bool timing = false;
     std::vector<EventPair> events;
     std::vector<hipEvent_t> event_pool;
@@ -59,6 +62,10 @@ void pg_klib_index_free(pg_klib_index* ix);
 struct pg_graphs
 {
     uint32_t n_graphs = 0;
+    // last stage queued on this graph set, per compute stream (main, second): pg_graphs_destroy waits for these two events
+    // only -- not for whatever other batches have queued on the streams
+    mutable hipEvent_t ev_use[2] = { nullptr, nullptr };
+    mutable bool use_recorded[2] = { false, false };
     std::vector<HostGraph> host;
     PgGraphDev* d_graphs = nullptr;
     PgNode* d_nodes = nullptr;
@@ -103,7 +110,6 @@ struct pg_batch
     unsigned long long* d_ops_counter = nullptr;
     std::vector<Chunk> chunks;
     uint64_t max_ws = 0;
-    uint64_t max_scratch = 0;
     size_t cap_reads = 0, cap_bases = 0, cap_items = 0;
     std::vector<pg_result> host_template;  // status for reads the device never sees (empty reads)
     bool has_skipped = false;
@@ -137,6 +143,10 @@ struct pg_batch
 // batch's queued stages and uploads are complete -- without waiting for other batches' work.
 hipError_t pg_stage_begin(pg_ctx* ctx, pg_batch* b);
 hipError_t pg_stage_end(pg_ctx* ctx, pg_batch* b);
+// the same for a stage that runs on the second stream (traceback, count path): never touches the main stream, so the
+// fills of other batches queued there are not held up
+hipError_t pg_stage_begin_on(pg_ctx* ctx, pg_batch* b, hipStream_t s);
+hipError_t pg_stage_end_on(pg_ctx* ctx, pg_batch* b, hipStream_t s);
 hipError_t pg_batch_wait(pg_ctx* ctx, pg_batch* b);
 
 

@@ -37,7 +37,6 @@ struct PgTraceArgs
     const uint8_t* workspace;
     const PgFillSummary* fillsum;
     pg_result* results;     // [read]
-    pg_op* ops_scratch;     // [(pair - pair_begin) * 4 + group][pg_ops_cap(C)]
     pg_op* ops;             // compact output
     unsigned long long* ops_counter;
 };

@@ -1,4 +1,13 @@
-// pg_trace.hip -- strand pick + traceback kernel: one thread per read.
+// pg_trace.hip -- strand pick + traceback kernel: one 16-lane DPP row per read (4 reads per wavefront, the fill kernel's
+// own grouping).  The walk itself is sequential, but its cost is the latency of dependent single-byte loads from the H
+// trace; the 16 lanes of a read take that latency 16 cells at a time:
+//   * diagonal runs: lane d loads H(i-1-d, j-1-d) and the two characters of depth d, every lane checks its own step
+//     (H(d-1) == H(d) + s(d)), one ballot gives the length of the run, and the run's M / X / N segments are emitted
+//     run-length encoded -- one round of loads per 16 matched bases instead of 16;
+//   * the "score == F(i,j)" scan after a failed diagonal: 16 candidate gap lengths per round;
+//   * everything else (gap steps, node boundaries) is the scalar logic, executed redundantly by the row's lanes (the same
+//     address in every lane: one transaction).
+// CIGAR elements are collected in LDS (written by the row's first lane) and copied out by all 16.
 //
 // Replaces
 //   GraphAligner::alignRead strand/uniqueness logic     src/c++/lib/grm/GraphAligner.cpp:340-401
@@ -76,7 +85,8 @@ __device__ __forceinline__ int sub_score(uint32_t a, uint32_t b)
 
 struct Emitter
 {
-    pg_op* slot;  // written from the tail backwards
+    uint32_t* slot;  // LDS, written from the tail backwards by the row's first lane
+    bool writer;
     uint32_t cap;
     uint32_t n;
     uint32_t last_node, last_op, last_len;
@@ -89,7 +99,8 @@ struct Emitter
         {
             if (n < cap)
             {
-                slot[cap - 1 - n] = (last_node << 20) | (last_op << 16) | (last_len & 0xFFFFu);
+                if (writer)
+                    slot[cap - 1 - n] = (last_node << 20) | (last_op << 16) | (last_len & 0xFFFFu);
                 ++n;
             }
             else
@@ -115,15 +126,21 @@ struct Emitter
 template <int C, bool WIDE>
 __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
 {
-    const uint32_t tid = blockIdx.x * 64u + threadIdx.x;
-    if (tid >= a.n_pairs * PG_GROUPS)
-        return;
-    const uint32_t pair = a.pair_begin + tid / PG_GROUPS;
-    const uint32_t grp = tid % PG_GROUPS;
+    extern __shared__ uint32_t ops_lds[];  // [4 reads][pg_ops_cap]
+    const uint32_t lane = threadIdx.x;
+    const uint32_t grp = lane >> 4;  // the read of this 16-lane row
+    const uint32_t k = lane & 15u;
+    const uint32_t pair = a.pair_begin + blockIdx.x;
+    const uint32_t tid = blockIdx.x * PG_GROUPS + grp;
+    (void)tid;
+    // row-level collectives; the control flow below is uniform within a row, so a lane only ever talks to active lanes
+    auto row_ballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> (grp * 16u)) & 0xFFFFu; };
+    auto row_get = [&](uint32_t v, uint32_t src) -> uint32_t { return (uint32_t)__shfl((int)v, (int)(grp * 16u + src)); };
     const PgWorkItem* fw = a.items + 2 * (size_t)pair;
     const uint32_t ridx = fw->read[grp];
     if (ridx == PG_NONE)
         return;
+    const bool writer = k == 0u;
     const uint32_t off = a.base_off[ridx];
     const int L = (int)(a.base_off[ridx + 1] - off);
     const char* __restrict__ bases = a.bases + off;
@@ -169,7 +186,8 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
     {
         // all-zero fill: gssw returns an empty CIGAR at position 0 (gssw.c:2728-2732, 2778)
         res.status = 1;
-        a.results[ridx] = res;
+        if (writer)
+            a.results[ridx] = res;
         return;
     }
 
@@ -210,7 +228,8 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
 
     Emitter em;
     em.cap = pg_ops_cap(WIDE ? PG_VAR_WIDE + C : C);
-    em.slot = a.ops_scratch + (size_t)tid * em.cap;
+    em.slot = ops_lds + grp * em.cap;
+    em.writer = writer;
     em.n = 0;
     em.last_op = 0xFFu;
     em.last_node = 0;
@@ -223,6 +242,7 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
     int j = fs.read_end;
     int sc = fs.score;
     bool inE = false, inF = false;
+    bool skip_probe = false;
     int status = 0;
     uint32_t clipped = 0;
     if (L - 1 - j > 0)
@@ -273,6 +293,46 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
                     sc += PG_GAP_EXT;
                 continue;
             }
+            if (i > 0 && j > 0 && !skip_probe)
+            {
+                // ---- diagonal run, 16 cells per round: lane d looks at cell (i - d, j - d) -----------------------------
+                const int ii = i - (int)k, jj = j - (int)k;
+                const bool valid = ii > 0 && jj > 0;
+                int hd = 0, subd = 0;
+                uint32_t opd = PG_OPC_M;
+                if (valid)
+                {
+                    hd = Hcell(c0 + ii - 1, jj - 1);
+                    const uint32_t rc = (uint8_t)refc[c0 + ii];
+                    const uint32_t qc = qchar(jj);
+                    subd = sub_score(nt_code(rc), nt_code(qc));
+                    opd = (rc == 'N' || qc == 'N') ? PG_OPC_N : (rc == qc ? PG_OPC_M : PG_OPC_X);
+                }
+                const int above = (int)row_get((uint32_t)hd, k == 0u ? 0u : k - 1u);
+                const int cur = k == 0u ? sc : above;  // the score the walk holds when it arrives at depth d
+                const bool ok = valid && cur > 0 && cur == hd + subd;
+                const uint32_t fail = ~row_ballot(ok) & 0xFFFFu;
+                const uint32_t run = fail ? (uint32_t)__builtin_ctz(fail) : 16u;
+                if (run > 0u)
+                {
+                    const uint32_t prev_op = row_get(opd, k == 0u ? 0u : k - 1u);
+                    uint32_t starts = row_ballot(k < run && (k == 0u || opd != prev_op));
+                    while (starts)
+                    {
+                        const uint32_t s0 = (uint32_t)__builtin_ctz(starts);
+                        starts &= starts - 1u;
+                        const uint32_t s1 = starts ? (uint32_t)__builtin_ctz(starts) : run;
+                        em.emit(n, row_get(opd, s0), s1 - s0);
+                    }
+                    sc = (int)row_get((uint32_t)hd, run - 1u);
+                    i -= (int)run;
+                    j -= (int)run;
+                }
+                skip_probe = run < 16u;  // the cell the run stopped at is handled by the scalar logic below
+                if (run > 0u)
+                    continue;
+            }
+            skip_probe = false;
             const uint32_t rch = (uint8_t)refc[c0 + i];
             const uint32_t qch = qchar(j);
             const int sub = sub_score(nt_code(rch), nt_code(qch));
@@ -309,13 +369,12 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
                 // score == F(i,j) ?
                 bool isF = false;
                 const int kmax = (j + 1 - sc - PG_GAP_OPEN + PG_GAP_EXT) / (1 + PG_GAP_EXT);
-                for (int kk = 1; kk <= kmax && kk <= j; ++kk)
-                {
-                    if (Hcell(c0 + i, j - kk) - PG_GAP_OPEN - (kk - 1) * PG_GAP_EXT == sc)
-                    {
-                        isF = true;
-                        break;
-                    }
+                const int lim = kmax < j ? kmax : j;
+                for (int base = 1; base <= lim && !isF; base += 16)
+                {  // 16 gap lengths per round
+                    const int kk = base + (int)k;
+                    const bool hit = kk <= lim && Hcell(c0 + i, j - kk) - PG_GAP_OPEN - (kk - 1) * PG_GAP_EXT == sc;
+                    isF = row_ballot(hit) != 0u;
                 }
                 if (isF)
                 {
@@ -426,36 +485,44 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
     res.clipped = (uint16_t)clipped;
     res.status = (uint16_t)status;
     res.n_ops = (uint16_t)em.n;
-    // compact: bump-allocate and copy the tail-aligned scratch slot into forward order
-    const unsigned long long base = atomicAdd(a.ops_counter, (unsigned long long)em.n);
-    for (uint32_t e = 0; e < em.n; ++e)
+    // compact: bump-allocate (first lane) and copy the tail-aligned LDS slot into forward order (all 16 lanes)
+    unsigned long long base = 0;
+    if (writer)
+        base = atomicAdd(a.ops_counter, (unsigned long long)em.n);
+    base = ((unsigned long long)row_get((uint32_t)(base >> 32), 0u) << 32) | row_get((uint32_t)base, 0u);
+    for (uint32_t e = k; e < em.n; e += 16u)
         a.ops[base + e] = em.slot[em.cap - em.n + e];
     res.ops_off = (uint32_t)base;
-    a.results[ridx] = res;
+    if (writer)
+        a.results[ridx] = res;
+}
+
+template <int C, bool WIDE> static hipError_t launch_trace_c(const PgTraceArgs& args, hipStream_t stream)
+{
+    const size_t lds = (size_t)PG_GROUPS * pg_ops_cap(WIDE ? PG_VAR_WIDE + C : C) * sizeof(uint32_t);
+    hipLaunchKernelGGL((pg_trace_kernel<C, WIDE>), dim3(args.n_pairs), dim3(64), lds, stream, args);
+    return hipGetLastError();
 }
 
 hipError_t pg_launch_trace(const PgTraceArgs& args, hipStream_t stream)
 {
-    const uint32_t threads = args.n_pairs * PG_GROUPS;
-    if (threads == 0)
+    if (args.n_pairs == 0)
         return hipSuccess;
-    const dim3 grid((threads + 63) / 64), block(64);
     switch (args.C)
     {
-    case 2: hipLaunchKernelGGL((pg_trace_kernel<2, false>), grid, block, 0, stream, args); break;
-    case 4: hipLaunchKernelGGL((pg_trace_kernel<4, false>), grid, block, 0, stream, args); break;
-    case 6: hipLaunchKernelGGL((pg_trace_kernel<6, false>), grid, block, 0, stream, args); break;
-    case 8: hipLaunchKernelGGL((pg_trace_kernel<8, false>), grid, block, 0, stream, args); break;
-    case 10: hipLaunchKernelGGL((pg_trace_kernel<10, false>), grid, block, 0, stream, args); break;
-    case 12: hipLaunchKernelGGL((pg_trace_kernel<12, false>), grid, block, 0, stream, args); break;
-    case 14: hipLaunchKernelGGL((pg_trace_kernel<14, false>), grid, block, 0, stream, args); break;
-    case 16: hipLaunchKernelGGL((pg_trace_kernel<16, false>), grid, block, 0, stream, args); break;
-    case PG_VAR_WIDE + 16: hipLaunchKernelGGL((pg_trace_kernel<16, true>), grid, block, 0, stream, args); break;
-    case PG_VAR_WIDE + 20: hipLaunchKernelGGL((pg_trace_kernel<20, true>), grid, block, 0, stream, args); break;
-    case PG_VAR_WIDE + 24: hipLaunchKernelGGL((pg_trace_kernel<24, true>), grid, block, 0, stream, args); break;
-    case PG_VAR_WIDE + 28: hipLaunchKernelGGL((pg_trace_kernel<28, true>), grid, block, 0, stream, args); break;
-    case PG_VAR_WIDE + 32: hipLaunchKernelGGL((pg_trace_kernel<32, true>), grid, block, 0, stream, args); break;
+    case 2: return launch_trace_c<2, false>(args, stream);
+    case 4: return launch_trace_c<4, false>(args, stream);
+    case 6: return launch_trace_c<6, false>(args, stream);
+    case 8: return launch_trace_c<8, false>(args, stream);
+    case 10: return launch_trace_c<10, false>(args, stream);
+    case 12: return launch_trace_c<12, false>(args, stream);
+    case 14: return launch_trace_c<14, false>(args, stream);
+    case 16: return launch_trace_c<16, false>(args, stream);
+    case PG_VAR_WIDE + 16: return launch_trace_c<16, true>(args, stream);
+    case PG_VAR_WIDE + 20: return launch_trace_c<20, true>(args, stream);
+    case PG_VAR_WIDE + 24: return launch_trace_c<24, true>(args, stream);
+    case PG_VAR_WIDE + 28: return launch_trace_c<28, true>(args, stream);
+    case PG_VAR_WIDE + 32: return launch_trace_c<32, true>(args, stream);
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }

@@ -336,7 +336,6 @@ __global__ __launch_bounds__(64) void pg_support_kernel(CountArgs a)
     a.support[r] = sup;
 }
 
-constexpr int FRAG_SET_CAP = 48;
 constexpr int FRAG_BLOCK = 256;
 constexpr uint32_t FRAG_LDS_COUNTERS = 4096;
 
@@ -364,15 +363,18 @@ __global__ __launch_bounds__(FRAG_BLOCK) void pg_fragment_kernel(CountArgs a)
     }
     __syncthreads();
 
+    // Pass 1: the fragment's read tallies and label set.  Pass 2: every node / edge supported by at least one of its reads gets
+    // {1, reads, fwd, rev} once (Fragment::addRead unions the supports, Fragment.cpp:141-181): an element of read q counts
+    // unless an earlier read of the fragment supports it too.  A path visits its nodes in ascending id order, so "does read
+    // q2 support node x" is a short scan -- no per-thread set, hence no limit on the nodes a fragment may touch.
     uint32_t n = 0, fwd = 0, rev = 0;
     uint64_t labels = 0;
-    uint32_t nodes[FRAG_SET_CAP], edges[FRAG_SET_CAP];
-    int nn = 0, ne = 0;
     uint32_t graph = g_first;
-    bool overflow = false;
+    uint32_t b = 0, e = 0;
     if (f < a.n_frags)
     {
-        const uint32_t b = a.frag_off[f], e = a.frag_off[f + 1];
+        b = a.frag_off[f];
+        e = a.frag_off[f + 1];
         for (uint32_t q = b; q < e; ++q)
         {
             const uint32_t r = a.frag_reads[q];
@@ -380,7 +382,6 @@ __global__ __launch_bounds__(FRAG_BLOCK) void pg_fragment_kernel(CountArgs a)
             if (sup.status != 1)
                 continue;  // only MAPPED reads survive alignReads (Align.cpp:81-84,155)
             graph = a.graph_of_read[r];
-            const PgCountGraph cg = a.graphs[graph];
             ++n;
             const bool read_rev = a.is_rev[r] != 0;
             const pg_result rr = a.results[r];
@@ -393,44 +394,6 @@ __global__ __launch_bounds__(FRAG_BLOCK) void pg_fragment_kernel(CountArgs a)
             else
                 ++fwd;
             labels |= sup.label_mask;
-            uint32_t pnode = 0;
-            for (uint32_t k = 0; k < sup.n_path; ++k)
-            {
-                const uint32_t en = a.path[sup.path_off + k];
-                const uint32_t nd = PG_PATH_NODE(en);
-                if (PG_PATH_NODE_OK(en))
-                {
-                    bool seen = false;
-                    for (int t = 0; t < nn; ++t)
-                        seen |= nodes[t] == nd;
-                    if (!seen)
-                    {
-                        if (nn < FRAG_SET_CAP)
-                            nodes[nn++] = nd;
-                        else
-                            overflow = true;
-                    }
-                }
-                if (k > 0 && PG_PATH_EDGE_OK(en))
-                {
-                    const uint32_t gn = cg.node_base + nd;
-                    uint32_t eidx = 0xFFFFFFFFu;
-                    for (uint32_t p = a.pred_off[gn]; p < a.pred_off[gn + 1]; ++p)
-                        if (a.pred[p] == pnode)
-                            eidx = p;
-                    bool seen = false;
-                    for (int t = 0; t < ne; ++t)
-                        seen |= edges[t] == eidx;
-                    if (!seen && eidx != 0xFFFFFFFFu)
-                    {
-                        if (ne < FRAG_SET_CAP)
-                            edges[ne++] = eidx;
-                        else
-                            overflow = true;
-                    }
-                }
-                pnode = nd;
-            }
         }
     }
     if (n != 0)
@@ -442,26 +405,58 @@ __global__ __launch_bounds__(FRAG_BLOCK) void pg_fragment_kernel(CountArgs a)
             atomicAdd(&c[2], fwd);
             atomicAdd(&c[3], rev);
         };
-        if (use_lds)
+        // does an earlier MAPPED read of the fragment (positions [b, q)) support node `nd` / the edge pnode -> nd ?
+        auto seen_before = [&](uint32_t q, uint32_t nd, bool want_edge, uint32_t pnode) -> bool {
+            for (uint32_t q2 = b; q2 < q; ++q2)
+            {
+                const pg_read_support s2 = a.support[a.frag_reads[q2]];
+                if (s2.status != 1)
+                    continue;
+                uint32_t prev = 0;
+                for (uint32_t k = 0; k < s2.n_path; ++k)
+                {
+                    const uint32_t en = a.path[s2.path_off + k];
+                    const uint32_t x = PG_PATH_NODE(en);
+                    if (x == nd)
+                    {
+                        if (!want_edge ? PG_PATH_NODE_OK(en) != 0 : (k > 0 && PG_PATH_EDGE_OK(en) && prev == pnode))
+                            return true;
+                        break;
+                    }
+                    if (x > nd)
+                        break;
+                    prev = x;
+                }
+            }
+            return false;
+        };
+        for (uint32_t q = b; q < e; ++q)
         {
-            for (int t = 0; t < nn; ++t)
-                add(lcnt + 4 * nodes[t]);
-            for (int t = 0; t < ne; ++t)
-                add(lcnt + l_edge + 4 * (edges[t] - e_base));
-            if (labels != 0 && n_seq_g)
-                add(lcnt + l_seq + 4 * (uint32_t)labels);
+            const pg_read_support sup = a.support[a.frag_reads[q]];
+            if (sup.status != 1)
+                continue;
+            uint32_t pnode = 0;
+            for (uint32_t k = 0; k < sup.n_path; ++k)
+            {
+                const uint32_t en = a.path[sup.path_off + k];
+                const uint32_t nd = PG_PATH_NODE(en);
+                if (PG_PATH_NODE_OK(en) && !seen_before(q, nd, false, 0))
+                    add(use_lds ? lcnt + 4 * nd : a.counts + a.lay.node_base + 4ull * (cg.node_base + nd));
+                if (k > 0 && PG_PATH_EDGE_OK(en))
+                {
+                    const uint32_t gn = cg.node_base + nd;
+                    uint32_t eidx = 0xFFFFFFFFu;
+                    for (uint32_t p = a.pred_off[gn]; p < a.pred_off[gn + 1]; ++p)
+                        if (a.pred[p] == pnode)
+                            eidx = p;
+                    if (eidx != 0xFFFFFFFFu && !seen_before(q, nd, true, pnode))
+                        add(use_lds ? lcnt + l_edge + 4 * (eidx - e_base) : a.counts + a.lay.edge_base + 4ull * eidx);
+                }
+                pnode = nd;
+            }
         }
-        else
-        {
-            for (int t = 0; t < nn; ++t)
-                add(a.counts + a.lay.node_base + 4ull * (cg.node_base + nodes[t]));
-            for (int t = 0; t < ne; ++t)
-                add(a.counts + a.lay.edge_base + 4ull * edges[t]);
-            if (labels != 0 && cg.n_labels <= PG_MAX_SEQ_TABLE_LABELS)
-                add(a.counts + a.lay.seq_base + 4ull * (cg.seq_base + labels));
-        }
-        if (overflow)
-            atomicAdd(a.counts + a.lay.tally_base + 4ull * graph, 0x80000000u);  // poison: > 48 nodes/edges per fragment
+        if (labels != 0 && cg.n_labels <= PG_MAX_SEQ_TABLE_LABELS)
+            add(use_lds ? lcnt + l_seq + 4 * (uint32_t)labels : a.counts + a.lay.seq_base + 4ull * (cg.seq_base + labels));
     }
     __syncthreads();
     if (use_lds)

@@ -498,8 +498,11 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 sn[r + 1] = v.y;
             }
         }
-        // one test for everything that is rare: a node boundary in this column, or a next column that carries code 4
-        if (((meta_cur & (PG_META_FIRST | PG_META_LAST)) | (meta & 4u)) != 0u)
+        // one test for what is rare BEFORE the column (a first column, or a next column that carries code 4), one for what is
+        // rare after it (a last column).  The column itself is outside the branches: with the lanes of a read skewed by one
+        // column each, a node boundary keeps SOME lane of the wavefront in a rare path for 16 steps in a row, and a column
+        // inside the branch would then be executed twice, once per side.
+        if (((meta_cur & PG_META_FIRST) | (meta & 4u)) != 0u)
         {
             if (meta & 4u)
             {  // N in the graph, or the idle columns behind its end
@@ -509,12 +512,10 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             }
             if (meta_cur & PG_META_FIRST)
                 first_column(Hin, meta_cur);
-            column(Hin, Hout, sc, dH, F);
-            if (meta_cur & PG_META_LAST)
-                last_column(Hout, meta_cur);
         }
-        else
-            column(Hin, Hout, sc, dH, F);
+        column(Hin, Hout, sc, dH, F);
+        if (meta_cur & PG_META_LAST)
+            last_column(Hout, meta_cur);
         colv = pk_add(colv, 0x00010001u);
         tbase += TRACE_STEP_BYTES;
     };

@@ -1402,8 +1402,43 @@ void SiteBatcher::Impl::Run::siteTables()
             sc.mapped = table[t + 1];
             sc.bad_align = table[t + 2];
             sc.nonuniq = table[t + 3];
-            if (table[t] >> 31)
-                throw std::runtime_error("a fragment touched more than 48 distinct nodes/edges (device count-table limit)");
+            if (names.size() > PG_MAX_SEQ_TABLE_LABELS)
+            {
+                // the device keeps a dense sequence-set table only for graphs with <= 8 labels (2^labels slots); for the others the
+                // totals of countPathFamilies (ReadCounting.cpp:96-127) are summed here from the per-read label sets: a fragment
+                // supports the union of its MAPPED reads' sets
+                struct Agg
+                {
+                    uint64_t labels = 0;
+                    uint32_t n = 0, fwd = 0, rev = 0;
+                };
+                std::map<uint32_t, Agg> fragments;
+                for (uint64_t i = site_read0[s]; i < site_read0[s + 1]; ++i)
+                {
+                    if (sup[i].status != 1)
+                        continue;
+                    Agg& f = fragments[frag[i]];
+                    f.labels |= sup[i].label_mask;
+                    ++f.n;
+                    const bool graph_rev = (res[i].status & PG_STATUS_PATH_ALIGNER) ? res[i].returned_reverse != 0
+                                                                                    : (is_rev[i] != 0) != (res[i].returned_reverse != 0);
+                    ++(graph_rev ? f.rev : f.fwd);
+                }
+                for (auto const& kv : fragments)
+                {
+                    if (!kv.second.labels)
+                        continue;
+                    std::string key;
+                    for (size_t b = 0; b < names.size(); ++b)
+                        if ((kv.second.labels >> b) & 1)
+                            key += (key.empty() ? "" : ",") + names[b];
+                    CountEntry& e = sc.by_sequence[key];
+                    e.count += 1;
+                    e.reads += kv.second.n;
+                    e.fwd += kv.second.fwd;
+                    e.rev += kv.second.rev;
+                }
+            }
             if (packed_mode)
                 return;
             // only MAPPED reads survive (Align.cpp:155)

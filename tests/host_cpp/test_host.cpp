@@ -214,6 +214,73 @@ static void testSiteBatcher()
     EXPECT_EQ(c1.by_edge.at("LF_RF").count, uint64_t(1));
 }
 
+// More than 8 sequence labels on a graph (the device keeps no dense sequence-set table then: the family totals are summed on
+// the host from the per-read label sets), and a fragment that supports 60 nodes / 59 edges (no per-fragment limit).
+static void testManyLabelsAndLongPaths()
+{
+    Graph g0 = alignsGraph();
+    for (int extra = 2; extra <= 5; ++extra)
+    {
+        const std::string p = "P" + std::to_string(extra), q = "Q" + std::to_string(extra);
+        g0.addLabelToEdge(0, 1, p);
+        g0.addLabelToEdge(1, 3, p);
+        g0.addLabelToEdge(0, 2, q);
+        g0.addLabelToEdge(2, 3, q);
+    }
+    auto r0 = alignsReads();  // 11 labels: D, P, P2..P5, Q, Q2..Q5
+    // a chain of 60 three-base nodes; one fragment of two reads that together cover all of it
+    const int kNodes = 60;
+    Graph g1((size_t)kNodes);
+    std::string whole;
+    unsigned state = 12345;
+    for (int n = 0; n < kNodes; ++n)
+    {
+        std::string seq;
+        for (int c = 0; c < 3; ++c)
+        {
+            state = state * 1103515245u + 12345u;
+            seq += "ACGT"[(state >> 16) & 3];
+        }
+        g1.setNodeName((NodeId)n, "n" + std::to_string(n));
+        g1.setNodeSeq((NodeId)n, seq);
+        whole += seq;
+        if (n)
+        {
+            g1.addEdge((NodeId)(n - 1), (NodeId)n);
+            g1.addLabelToEdge((NodeId)(n - 1), (NodeId)n, "CHAIN");
+        }
+    }
+    std::vector<p_Read> r1;
+    r1.emplace_back(new Read("pair", whole.substr(0, 120), std::string(120, '#')));
+    r1.emplace_back(new Read("pair", whole.substr(60), std::string(whole.size() - 60, '#')));
+    r1[1]->set_is_first_mate(false);
+
+    paragraph::SiteBatcher batcher;
+    batcher.addSite(&g0, &r0);
+    batcher.addSite(&g1, &r1);
+    paragraph::BatchParameters prm;
+    prm.remove_nonuniq_reads = false;
+    prm.use_support_filters = false;
+    batcher.run(prm);
+    auto const& c0 = batcher.counts(0);
+    EXPECT_EQ(c0.by_sequence.size(), size_t(3));
+    EXPECT_EQ(c0.by_sequence.at("P,P2,P3,P4,P5").count, uint64_t(2));
+    EXPECT_EQ(c0.by_sequence.at("Q,Q2,Q3,Q4,Q5").count, uint64_t(3));
+    EXPECT_EQ(c0.by_sequence.at("Q,Q2,Q3,Q4,Q5").fwd + c0.by_sequence.at("Q,Q2,Q3,Q4,Q5").rev, uint64_t(3));
+    EXPECT_EQ(c0.by_sequence.at("D").count, uint64_t(1));
+    EXPECT_EQ(join(r0[0]->graph_sequences_supported()), std::string("P,P2,P3,P4,P5"));
+    auto const& c1 = batcher.counts(1);
+    EXPECT_EQ(r1.size(), size_t(2));
+    EXPECT_EQ(c1.by_node.size(), size_t(kNodes));
+    EXPECT_EQ(c1.by_edge.size(), size_t(kNodes - 1));
+    for (auto const& kv : c1.by_node)
+    {
+        EXPECT_EQ(kv.second.count, uint64_t(1));  // ONE fragment, however many of its reads cover the node
+        EXPECT_EQ(kv.second.reads, uint64_t(2));
+    }
+    EXPECT_EQ(c1.by_sequence.at("CHAIN").count, uint64_t(1));
+}
+
 static Graph deletionGraph(const char* l, const char* d, const char* r)
 {
     // graphtools::makeDeletionGraph (GT!/src/graphcore/GraphBuilders.cpp): left -> {deletion, right}, deletion -> right
@@ -760,6 +827,7 @@ int main()
     try
     {
         testSiteToGenotype();
+        testManyLabelsAndLongPaths();
         testSiteBatcherPathStage();
         testSiteBatcherFullCascade();
         testConcurrentBatchers();

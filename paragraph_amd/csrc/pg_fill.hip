@@ -58,6 +58,73 @@ __device__ __forceinline__ uint32_t pk_subsat(uint32_t a, uint32_t b)
     return asW(__builtin_elementwise_sub_sat(asU(a), asU(b)));
 }
 
+// ---- the recurrence's arithmetic: integer scores carried as half-precision numbers -----------------------------------------
+// A score n is held as the f16 number 1024 + n, two strands per VGPR.  Every integer below 2048 is exact in f16 and so are
+// sums and differences of them, so this is integer arithmetic in disguise -- but gfx950 has a THREE-input packed maximum for
+// f16 (v_pk_maximum3_f16) and none for integers: h = max(diag + s, E, F) is 2 instructions instead of 3, E' = max(E - ge,
+// h - go, 0) is 2 with the clamp at zero folded in (gssw's saturating _mm_subs_epu8), and the 11-way column maximum is 5
+// instead of 10.  7 instead of 8 instructions per cell pair.  Between 1024 and 2048 one ulp is 1, so the bit pattern of
+// 1024 + n is 0x6400 | n: the byte / 16-bit value the H trace and the seeds store is simply the low part of the register,
+// and comparing bit patterns as unsigned integers compares the scores (everything is positive), which is what the rare
+// paths do with the integer v_pk_max_u16.
+#define PG_F16_BIAS2 0x64006400u  // (1024.0, 1024.0)
+#define PG_F16_NEG_GO2 0xC600C600u  // (-6.0, -6.0)
+static_assert(PG_GAP_OPEN == 6 && PG_GAP_EXT == 1, "the f16 constants above encode gap open 6 / extend 1");
+__device__ __forceinline__ uint32_t pk_addh(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_pk_add_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_addh_s(uint32_t a, uint32_t sconst)
+{  // second operand wave-uniform (an SGPR)
+    uint32_t d;
+    asm("v_pk_add_f16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(sconst));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_dech(uint32_t a)
+{  // a - gap extend
+    uint32_t d;
+    asm("v_pk_add_f16 %0, %1, -1.0 op_sel_hi:[1,0]" : "=v"(d) : "v"(a));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_max3h(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_max3h_s(uint32_t a, uint32_t b, uint32_t sconst)
+{
+    uint32_t d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(sconst));
+    return d;
+}
+__device__ __forceinline__ uint32_t f16_bits(int v) { return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)v); }
+// maximum of N packed values with three-input instructions: ceil((N - 1) / 2) of them
+template <int N> __device__ __forceinline__ uint32_t pk_max_all(const uint32_t (&v)[N])
+{
+    if constexpr (N == 1)
+        return v[0];
+    else if constexpr (N == 2)
+        return asW(__builtin_elementwise_max(asU(v[0]), asU(v[1])));
+    else if constexpr (N == 3)
+        return pk_max3h(v[0], v[1], v[2]);
+    else
+    {
+        // full triples are reduced, a remainder of one or two values is carried to the next level as it is
+        constexpr int T = N / 3, R = N % 3, K = T + R;
+        uint32_t w[K];
+#pragma unroll
+        for (int g = 0; g < T; ++g)
+            w[g] = pk_max3h(v[3 * g], v[3 * g + 1], v[3 * g + 2]);
+#pragma unroll
+        for (int g = 0; g < R; ++g)
+            w[T + g] = v[3 * T + g];
+        return pk_max_all<K>(w);
+    }
+}
+
 // row_shr:1 within each 16-lane DPP row. bound_ctrl=true: lane 0 of a row receives 0.
 __device__ __forceinline__ uint32_t row_shr1_zero(uint32_t v)
 {
@@ -176,7 +243,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         {
             const int sA = cA == 5u ? PAD : sub_score(code, cA);
             const int sB = cB == 5u ? PAD : sub_score(code, cB);
-            prof[(g * 4 + code) * ROWS + row] = ((uint32_t)sA & 0xFFFFu) | ((uint32_t)sB << 16);
+            prof[(g * 4 + code) * ROWS + row] = f16_bits(sA) | (f16_bits(sB) << 16);
         }
         }
     }
@@ -193,7 +260,8 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         const uint32_t Lg = ridx == PG_NONE ? 0u : a.base_off[ridx + 1] - a.base_off[ridx];
         real_rows = Lg > (uint32_t)(k * C) ? Lg - (uint32_t)(k * C) : 0u;
     }
-    const uint32_t PADPK = ((uint32_t)PAD & 0xFFFFu) | ((uint32_t)PAD << 16);
+    const uint32_t PADPK = f16_bits(PAD) | (f16_bits(PAD) << 16);
+    const uint32_t BIAS2 = PG_F16_BIAS2;  // the score 0
 
     uint32_t* __restrict__ seed = (uint32_t*)(a.workspace + itp->seed_off);    // [node][lane][SEED_DW]
     uint32_t* __restrict__ trace = (uint32_t*)(a.workspace + itp->trace_off);  // [step][TRACE_DW][lane]: one store instruction = 256 contiguous bytes
@@ -205,22 +273,24 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 #pragma unroll
     for (int r = 0; r < C; ++r)
     {
-        HA[r] = 0;
-        HB[r] = 0;
-        E[r] = 0;
+        HA[r] = BIAS2;
+        HB[r] = BIAS2;
+        E[r] = BIAS2;
     }
-    uint32_t Fsend = 0;
+    uint32_t Fsend = BIAS2;
+    // what the row's first lane sees as "the lane above": score 0.  row_shr:1 never writes lane 0 of a row, so these two keep
+    // the constant there for the whole sweep while the other lanes receive their neighbour's value every step.
+    uint32_t dHin = BIAS2, Fin = BIAS2;
     // one-entry seed cache (byte variants): the seed this lane stored last stays in registers, so the usual bubble
     // (LF -> {ALT, RF}: RF's far predecessor is LF) needs no memory round trip -- a load there stalls the whole wavefront
     uint32_t cseed[WIDE ? 1 : C];
     uint32_t cnode = 0xFFFFFFFFu;
-    uint32_t M = 0, FC = 0;
+    uint32_t M = BIAS2, FC = 0;
     uint32_t FR = 0;  // WIDE: smallest row (within the lane) holding the lane's maximum in column FC, per strand
     // packed (col | col << 16) of the column this lane works on; col = t - k (wraps for idle lanes)
     uint32_t colv = (uint32_t)(0x10000 - k) & 0xFFFFu;
     colv |= colv << 16;
-    const uint32_t GO2 = PG_GAP_OPEN | (PG_GAP_OPEN << 16);
-    const uint32_t GE2 = PG_GAP_EXT | (PG_GAP_EXT << 16);
+    const uint32_t NEG_GO2 = PG_F16_NEG_GO2;
     const uint32_t nsteps = pg_fill_steps(gd.ncols);  // even
     const uint32_t* profl = prof + grp * 4 * ROWS + k * C;
     const uint32_t trace_lane_off = (uint32_t)lane * 4u;
@@ -269,29 +339,23 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 #pragma unroll
         for (int r = 0; r < C; ++r)
         {
-            uint32_t h = pk_add(diag, sc[r]);  // H(i-1,j-1) + s   (may be negative: signed compare next)
-            h = pk_maxi(h, E[r]);              // E >= 0 makes the explicit max(.,0) unnecessary
-            h = pk_maxu(h, F);
+            const uint32_t h = pk_max3h(pk_addh(diag, sc[r]), E[r], F);  // max(H(i-1,j-1) + s, E, F); E >= 0 is the local-alignment floor
             diag = Hin[r];
             Hout[r] = h;
-            const uint32_t tt = pk_subsat(h, GO2);
-            E[r] = pk_maxu(pk_subsat(E[r], GE2), tt);
-            F = pk_maxu(pk_subsat(F, GE2), tt);
+            const uint32_t tt = pk_addh_s(h, NEG_GO2);  // h - gap open (may dip below 0: E clamps, F is only ever compared)
+            E[r] = pk_max3h_s(pk_dech(E[r]), tt, BIAS2);
+            F = pk_maxu(pk_dech(F), tt);
         }
         Fsend = F;
 
         // ---- running node maximum + first column reaching it (gssw.c:369-386) -----------------------
-        uint32_t cm[C];
+        // three-input maxima: 10 rows + the running maximum in 5 instructions
+        uint32_t cm[C + 1];
 #pragma unroll
         for (int r = 0; r < C; ++r)
             cm[r] = Hout[r];
-        // tree reduction (a chain would serialise 2C dependent packed ops)
-#pragma unroll
-        for (int w = 1; w < C; w *= 2)
-#pragma unroll
-            for (int r = 0; r + w < C; r += 2 * w)
-                cm[r] = pk_maxu(cm[r], cm[r + w]);
-        const uint32_t Mn = pk_maxu(M, cm[0]);
+        cm[C] = M;
+        const uint32_t Mn = pk_max_all<C + 1>(cm);
         if (DIR == 0 || WIDE)
         {
             // mask = 0xFFFF in the halves whose maximum grew: (M - Mn) is negative there as a 16-bit integer
@@ -304,8 +368,8 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 // node's cells (epilogue).  A maximum passes through each of those five values at most once, so the row search
                 // runs a handful of times per node instead of at every growth step.  (The traceback's start row is found from
                 // the H trace in the epilogue, like in the byte variants.)
-                const uint32_t mnA = Mn & 0xFFFFu, mnB = Mn >> 16;
-                const bool needA = (grew & 0xFFFFu) && (mnA - 251u) <= 4u, needB = (grew >> 16) && (mnB - 251u) <= 4u;
+                const uint32_t mnA = Mn & 0xFFFFu, mnB = Mn >> 16;  // bit patterns: 0x6400 | score
+                const bool needA = (grew & 0xFFFFu) && ((mnA & 0x3FFu) - 251u) <= 4u, needB = (grew >> 16) && ((mnB & 0x3FFu) - 251u) <= 4u;
                 if (needA || needB)
                 {
                     uint32_t frA = FR & 0xFFFFu, frB = FR >> 16;
@@ -358,8 +422,8 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 #pragma unroll
         for (int r = 0; r < C; ++r)
         {
-            sh[r] = 0;
-            se[r] = 0;
+            sh[r] = BIAS2;  // no predecessor: score 0
+            se[r] = BIAS2;
         }
         bool adj = (meta_cur & PG_META_PRED_ADJ) != 0;
         if (!WIDE && !(meta_cur & PG_META_PRED_MANY))
@@ -385,8 +449,9 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 #pragma unroll
                 for (int r = 0; r < C; ++r)
                 {
-                    sh[r] = __builtin_amdgcn_perm(0u, w[r], 0x0c010c00u);
-                    se[r] = __builtin_amdgcn_perm(0u, w[r], 0x0c030c02u);
+                    // bytes (H_A, H_B, Enext_A, Enext_B) -> (0x6400 | H_A, 0x6400 | H_B), the 0x64 bytes come from the constant
+                    sh[r] = __builtin_amdgcn_perm(BIAS2, w[r], 0x07010500u);
+                    se[r] = __builtin_amdgcn_perm(BIAS2, w[r], 0x07030502u);
                 }
             }
         }
@@ -407,15 +472,15 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 for (int r = 0; r < C; ++r)
                 {
                     if (WIDE)
-                    {  // dwords: (H_A | H_B << 16), (Enext_A | Enext_B << 16)
+                    {  // dwords: (H_A | H_B << 16), (Enext_A | Enext_B << 16) as stored by last_column: the registers' bit patterns
                         sh[r] = pk_maxu(sh[r], sp[2 * r]);
                         se[r] = pk_maxu(se[r], sp[2 * r + 1]);
                     }
                     else
                     {
                         const uint32_t w = sp[r];  // bytes: H_A, H_B, Enext_A, Enext_B
-                        sh[r] = pk_maxu(sh[r], __builtin_amdgcn_perm(0u, w, 0x0c010c00u));
-                        se[r] = pk_maxu(se[r], __builtin_amdgcn_perm(0u, w, 0x0c030c02u));
+                        sh[r] = pk_maxu(sh[r], __builtin_amdgcn_perm(BIAS2, w, 0x07010500u));
+                        se[r] = pk_maxu(se[r], __builtin_amdgcn_perm(BIAS2, w, 0x07030502u));
                     }
                 }
             }
@@ -426,7 +491,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             Hin[r] = adj ? pk_maxu(Hin[r], sh[r]) : sh[r];
             E[r] = adj ? pk_maxu(E[r], se[r]) : se[r];
         }
-        M = 0;
+        M = BIAS2;
         FC = 0;
         FR = 0;
     };
@@ -455,7 +520,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         }
         // key: max (12 bits) | inverted column (16 bits; a direction has <= 65519 columns) | inverted lane (4 bits)
         const uint32_t kinv = (uint32_t)(15 - k);
-        const uint32_t mA = M & 0xFFFFu, mB = M >> 16;
+        const uint32_t mA = M & 0x3FFu, mB = (M >> 16) & 0x3FFu;  // the scores under the 0x6400 of their f16 patterns
         const uint32_t cA = FC & 0xFFFFu, cB = FC >> 16;
         if (WIDE)
         {
@@ -482,8 +547,9 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         const uint32_t meta_cur = meta;
         // Hout still holds the column before the previous one: its last row is what the next lane needs as its diagonal
         // input one step later (lane k + 1 works one column behind lane k)
-        const uint32_t dH = row_shr1_zero(Hout[C - 1]);
-        const uint32_t F = row_shr1_zero(Fsend);
+        dHin = row_shr1_keep(dHin, Hout[C - 1]);
+        Fin = row_shr1_keep(Fin, Fsend);
+        const uint32_t dH = dHin, F = Fin;
         // prefetch the next step's meta word and profile rows
         meta = row_shr1_keep(mw1, meta_cur);
         mw1 = mw2;
@@ -595,7 +661,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 #pragma unroll
             for (int r = 0; r < C; ++r)
             {
-                const uint32_t hval = (tp[r * 64] >> (strand * 16)) & 0xFFFFu;
+                const uint32_t hval = (tp[r * 64] >> (strand * 16)) & 0x3FFu;  // the score under the 0x6400 of its f16 pattern
                 if (!found && hval == best)
                 {
                     rr = r;

@@ -202,13 +202,13 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
     };
     // byte variants: trace [step][C/2][lane] dwords of bytes (A_r, A_r+1, B_r, B_r+1), seed [node][lane][C] dwords of
     // bytes (H_A, H_B, Enext_A, Enext_B); wide variants: trace [step][C][lane] dwords (A_r | B_r << 16), seed
-    // [node][lane][2C] dwords (H_A | H_B << 16), (Enext_A | Enext_B << 16)
+    // [node][lane][2C] dwords (H_A | H_B << 16), (Enext_A | Enext_B << 16), each 16-bit field = 0x6400 | score
     auto Hcell = [&](uint32_t col, int j) -> int {
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
         if (WIDE)
         {
             const size_t dw = ((size_t)(col + kq) * C + r) * 64 + (grp * 16 + kq);
-            return (int)((const uint16_t*)trace)[dw * 2 + (uint32_t)s];
+            return (int)(((const uint16_t*)trace)[dw * 2 + (uint32_t)s] & 0x3FFu);  // f16 pattern 0x6400 | score (pg_fill.hip)
         }
         const size_t dw = ((size_t)(col + kq) * (C / 2) + r / 2) * 64 + (grp * 16 + kq);
         return (int)trace[dw * 4 + (r & 1u) + 2u * (uint32_t)s];
@@ -216,13 +216,13 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
     auto seedH = [&](uint32_t node, int j) -> int {
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
         if (WIDE)
-            return (int)((seed[((size_t)node * 64 + (grp * 16 + kq)) * (2 * C) + 2 * r] >> (16 * s)) & 0xFFFFu);
+            return (int)((seed[((size_t)node * 64 + (grp * 16 + kq)) * (2 * C) + 2 * r] >> (16 * s)) & 0x3FFu);
         return (int)((seed[((size_t)node * 64 + (grp * 16 + kq)) * C + r] >> (8 * s)) & 0xFFu);
     };
     auto seedE = [&](uint32_t node, int j) -> int {
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
         if (WIDE)
-            return (int)((seed[((size_t)node * 64 + (grp * 16 + kq)) * (2 * C) + 2 * r + 1] >> (16 * s)) & 0xFFFFu);
+            return (int)((seed[((size_t)node * 64 + (grp * 16 + kq)) * (2 * C) + 2 * r + 1] >> (16 * s)) & 0x3FFu);
         return (int)((seed[((size_t)node * 64 + (grp * 16 + kq)) * C + r] >> (16 + 8 * s)) & 0xFFu);
     };
 

@@ -184,6 +184,13 @@ template <int C, int DIR, bool WIDE>
 __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair, uint32_t* lds)
 {
     constexpr int PAD = WIDE ? PG_PAD_SCORE_WIDE : PG_PAD_SCORE;
+    // Register / LDS budget.  The byte variants keep the next column's profile rows (fetched one step ahead) and the lane's
+    // last seed in registers: 128 VGPRs or fewer up to C = 12 (4 wavefronts per SIMD; the 4 KB x C / 4 of LDS profile allow
+    // 16 / 13 wavefronts per CU at C = 10 / 12) and at most 170 up to C = 16 (3 per SIMD; LDS allows 10 per CU there).  The
+    // wide variants from C = 20 on would fall to one wavefront per SIMD with the prefetch registers; they fetch the rows at
+    // the start of the step instead.
+    constexpr bool PREFETCH = WIDE ? C <= 16 : true;
+    constexpr bool SEEDCACHE = !WIDE;
     constexpr int TRACE_DW = WIDE ? C : C / 2;  // dwords of H trace per lane per step
     constexpr int SEED_DW = WIDE ? 2 * C : C;   // dwords of seed per lane per node
     constexpr int ROWS = PG_GROUP_LANES * C;
@@ -283,7 +290,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     uint32_t dHin = BIAS2, Fin = BIAS2;
     // one-entry seed cache (byte variants): the seed this lane stored last stays in registers, so the usual bubble
     // (LF -> {ALT, RF}: RF's far predecessor is LF) needs no memory round trip -- a load there stalls the whole wavefront
-    uint32_t cseed[WIDE ? 1 : C];
+    uint32_t cseed[SEEDCACHE ? C : 1];
     uint32_t cnode = 0xFFFFFFFFu;
     uint32_t M = BIAS2, FC = 0;
     uint32_t FR = 0;  // WIDE: smallest row (within the lane) holding the lane's maximum in column FC, per strand
@@ -418,14 +425,16 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // precedes this node in the layout is still in Hin / E
     auto first_column = [&](uint32_t (&Hin)[C], uint32_t meta_cur) __attribute__((always_inline)) {
         const uint32_t node = PG_META_NODE(meta_cur);
-        uint32_t sh[C], se[C];
+        // (the maxima are taken in place: no second copy of a column in registers)
+        if (!(meta_cur & PG_META_PRED_ADJ))
+        {  // nothing of the node before it in the layout flows in: start from score 0
 #pragma unroll
-        for (int r = 0; r < C; ++r)
-        {
-            sh[r] = BIAS2;  // no predecessor: score 0
-            se[r] = BIAS2;
+            for (int r = 0; r < C; ++r)
+            {
+                Hin[r] = BIAS2;
+                E[r] = BIAS2;
+            }
         }
-        bool adj = (meta_cur & PG_META_PRED_ADJ) != 0;
         if (!WIDE && !(meta_cur & PG_META_PRED_MANY))
         {
             // predecessor summary in the meta word: no table loads
@@ -433,11 +442,11 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             {
                 const uint32_t pid = meta_cur >> PG_META_PRED_SHIFT;
                 uint32_t w[C];
-                if (pid == cnode)
+                if (SEEDCACHE && pid == cnode)
                 {
 #pragma unroll
                     for (int r = 0; r < C; ++r)
-                        w[r] = cseed[WIDE ? 0 : r];
+                        w[r] = cseed[SEEDCACHE ? r : 0];
                 }
                 else
                 {
@@ -450,46 +459,36 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 for (int r = 0; r < C; ++r)
                 {
                     // bytes (H_A, H_B, Enext_A, Enext_B) -> (0x6400 | H_A, 0x6400 | H_B), the 0x64 bytes come from the constant
-                    sh[r] = __builtin_amdgcn_perm(BIAS2, w[r], 0x07010500u);
-                    se[r] = __builtin_amdgcn_perm(BIAS2, w[r], 0x07030502u);
+                    Hin[r] = pk_maxu(Hin[r], __builtin_amdgcn_perm(BIAS2, w[r], 0x07010500u));
+                    E[r] = pk_maxu(E[r], __builtin_amdgcn_perm(BIAS2, w[r], 0x07030502u));
                 }
             }
         }
         else
         {
-            adj = false;
             const PgNode nd = nodes[node];
             for (uint32_t p = 0; p < nd.n_pred; ++p)
             {
                 const uint32_t pid = a.preds[nd.pred_off + p];
                 if (pid + 1 == node)
-                {
-                    adj = true;
-                    continue;
-                }
+                    continue;  // the adjacent predecessor is what Hin / E hold already
                 const uint32_t* sp = seed + ((size_t)pid * 64 + lane) * SEED_DW;
 #pragma unroll
                 for (int r = 0; r < C; ++r)
                 {
                     if (WIDE)
                     {  // dwords: (H_A | H_B << 16), (Enext_A | Enext_B << 16) as stored by last_column: the registers' bit patterns
-                        sh[r] = pk_maxu(sh[r], sp[2 * r]);
-                        se[r] = pk_maxu(se[r], sp[2 * r + 1]);
+                        Hin[r] = pk_maxu(Hin[r], sp[2 * r]);
+                        E[r] = pk_maxu(E[r], sp[2 * r + 1]);
                     }
                     else
                     {
                         const uint32_t w = sp[r];  // bytes: H_A, H_B, Enext_A, Enext_B
-                        sh[r] = pk_maxu(sh[r], __builtin_amdgcn_perm(BIAS2, w, 0x07010500u));
-                        se[r] = pk_maxu(se[r], __builtin_amdgcn_perm(BIAS2, w, 0x07030502u));
+                        Hin[r] = pk_maxu(Hin[r], __builtin_amdgcn_perm(BIAS2, w, 0x07010500u));
+                        E[r] = pk_maxu(E[r], __builtin_amdgcn_perm(BIAS2, w, 0x07030502u));
                     }
                 }
             }
-        }
-#pragma unroll
-        for (int r = 0; r < C; ++r)
-        {
-            Hin[r] = adj ? pk_maxu(Hin[r], sh[r]) : sh[r];
-            E[r] = adj ? pk_maxu(E[r], se[r]) : se[r];
         }
         M = BIAS2;
         FC = 0;
@@ -513,10 +512,12 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 {
                     const uint32_t w = __builtin_amdgcn_perm(E[r], Hout[r], 0x06040200u);
                     sp[r] = w;
-                    cseed[r] = w;
+                    if (SEEDCACHE)
+                        cseed[r] = w;
                 }
             }
-            cnode = node;
+            if (SEEDCACHE)
+                cnode = node;
         }
         // key: max (12 bits) | inverted column (16 bits; a direction has <= 65519 columns) | inverted lane (4 bits)
         const uint32_t kinv = (uint32_t)(15 - k);
@@ -550,31 +551,33 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         dHin = row_shr1_keep(dHin, Hout[C - 1]);
         Fin = row_shr1_keep(Fin, Fsend);
         const uint32_t dH = dHin, F = Fin;
-        // prefetch the next step's meta word and profile rows
+        // the next step's meta word; the profile rows of the next column (PREFETCH) or of this one
         meta = row_shr1_keep(mw1, meta_cur);
         mw1 = mw2;
         mw2 = cmeta[t + 3];
+        const uint32_t meta_rows = PREFETCH ? meta : meta_cur;
+        uint32_t (&rows)[C] = PREFETCH ? sn : sc;
         {
-            const uint32_t* pr = profl + (PG_META_CODE(meta) & 3u) * ROWS;
+            const uint32_t* pr = profl + (PG_META_CODE(meta_rows) & 3u) * ROWS;
 #pragma unroll
             for (int r = 0; r < C; r += 2)
             {
                 const uint2 v = *(const uint2*)(pr + r);
-                sn[r] = v.x;
-                sn[r + 1] = v.y;
+                rows[r] = v.x;
+                rows[r + 1] = v.y;
             }
         }
-        // one test for what is rare BEFORE the column (a first column, or a next column that carries code 4), one for what is
+        // one test for what is rare BEFORE the column (a first column, or a column that carries code 4), one for what is
         // rare after it (a last column).  The column itself is outside the branches: with the lanes of a read skewed by one
         // column each, a node boundary keeps SOME lane of the wavefront in a rare path for 16 steps in a row, and a column
         // inside the branch would then be executed twice, once per side.
-        if (((meta_cur & PG_META_FIRST) | (meta & 4u)) != 0u)
+        if (((meta_cur & PG_META_FIRST) | (meta_rows & 4u)) != 0u)
         {
-            if (meta & 4u)
+            if (meta_rows & 4u)
             {  // N in the graph, or the idle columns behind its end
 #pragma unroll
                 for (int r = 0; r < C; ++r)
-                    sn[r] = (uint32_t)r < real_rows ? 0u : PADPK;
+                    rows[r] = (uint32_t)r < real_rows ? 0u : PADPK;
             }
             if (meta_cur & PG_META_FIRST)
                 first_column(Hin, meta_cur);
@@ -588,8 +591,16 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 
     for (uint32_t t = 0; t < nsteps; t += 2)
     {
-        step(HA, HB, sA, sB, t);
-        step(HB, HA, sB, sA, t + 1);
+        if (PREFETCH)
+        {
+            step(HA, HB, sA, sB, t);
+            step(HB, HA, sB, sA, t + 1);
+        }
+        else
+        {
+            step(HA, HB, sA, sA, t);
+            step(HB, HA, sA, sA, t + 1);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trace stores above are invisible to the compiler's own counters
 

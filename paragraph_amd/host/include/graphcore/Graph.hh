@@ -81,5 +81,24 @@ struct Path
     int32_t start_position = 0;
     std::vector<NodeId> nodes;
     int32_t end_position = 0;
+    std::vector<NodeId> const& nodeIds() const { return nodes; }
+    // "(first@start)-(mid)-...-(last@end)"; a one-node path is "(n@start)-(n@end)" (GT!/src/graphcore/Path.cpp:152-179)
+    std::string encode() const
+    {
+        std::string out;
+        for (size_t i = 0; i < nodes.size(); ++i)
+        {
+            const std::string name = std::to_string(nodes[i]);
+            std::string piece;
+            if (i == 0)
+                piece = "(" + name + "@" + std::to_string(start_position) + ")";
+            if (i + 1 == nodes.size())
+                piece += "-(" + name + "@" + std::to_string(end_position) + ")";
+            if (i != 0 && i + 1 != nodes.size())
+                piece = "-(" + name + ")";
+            out += piece;
+        }
+        return out;
+    }
 };
 }  // namespace graphtools

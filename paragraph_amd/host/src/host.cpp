@@ -2,6 +2,7 @@
 // Everything here is marshalling: graphs -> CSR, reads -> packed bytes, pg_result/pg_op -> common::Read.
 // No alignment arithmetic happens on the host and there is no CPU fallback: without a device every call throws.
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <chrono>
 #include <cstdio>
@@ -19,6 +20,7 @@
 #include "grm/GraphAligner.hh"
 #include "grm/KmerAligner.hh"
 #include "grm/PathAligner.hh"
+#include "grm/ValidationAligner.hh"
 #include "paragraph/SiteBatcher.hh"
 #include "parallel.hh"
 #include "pinned.hh"
@@ -880,10 +882,6 @@ void alignReads(
     bool path_sequence_matching, bool graph_sequence_matching, bool klib_sequence_matching, bool kmer_sequence_matching,
     bool validate_alignments, uint32_t /*threads*/)
 {
-    if (validate_alignments)
-        throw std::logic_error("--validate-alignments (ValidationAligner) is not part of the device path");
-    CompositeAligner aligner(path_sequence_matching, graph_sequence_matching, klib_sequence_matching, kmer_sequence_matching);
-    aligner.setGraph(graph, paths);
     std::vector<Read*> todo;
     for (auto& r : reads)
     {
@@ -892,13 +890,94 @@ void alignReads(
         r->set_graph_mapping_status(Read::UNMAPPED);
         todo.push_back(r.get());
     }
-    aligner.alignReads(todo, filter);
+    if (validate_alignments)
+    {  // Align.cpp:96-104
+        ValidationAligner<CompositeAligner> aligner(
+            CompositeAligner(path_sequence_matching, graph_sequence_matching, klib_sequence_matching, kmer_sequence_matching), graph, paths);
+        aligner.setGraph(graph, paths);
+        aligner.alignReads(todo, filter);
+    }
+    else
+    {
+        CompositeAligner aligner(path_sequence_matching, graph_sequence_matching, klib_sequence_matching, kmer_sequence_matching);
+        aligner.setGraph(graph, paths);
+        aligner.alignReads(todo, filter);
+    }
     std::vector<common::p_Read> kept;
     for (auto& r : reads)
         if (!r->bases().empty() && r->graph_mapping_status() == Read::MAPPED)
             kept.emplace_back(std::move(r));
     reads.swap(kept);  // Align.cpp:155
 }
+// ---- ValidationAligner (lib/grm/ValidationAligner.cpp) ------------------------------------------------------------------
+namespace
+{
+std::atomic<unsigned> validation_mismapped(0), validation_repeats(0), validation_aligned(0), validation_total(0);
+}
+template <typename AlignerT>
+ValidationAligner<AlignerT>::ValidationAligner(AlignerT&& aligner, const graphtools::Graph* /*graph*/, std::list<graphtools::Path> const& paths)
+    : AlignerT(std::move(aligner))
+{
+    for (auto const& p : paths)
+    {
+        std::string& nodes = pathNodes_[p.encode()];
+        nodes.clear();
+        for (auto n : p.nodeIds())
+            nodes += (nodes.empty() ? "" : "->") + std::to_string(n);
+    }
+}
+template <typename AlignerT> void ValidationAligner<AlignerT>::account(Read& read)
+{
+    ++validation_total;
+    if (read.graph_mapping_status() == Read::MAPPED)
+    {
+        ++validation_aligned;
+        const std::string cigarNodes = getNodes(read.graph_cigar());
+        const std::string& simulatedPathNodes = pathNodes_[getSimulatedPathId(read)];
+        validation_mismapped += std::string::npos == simulatedPathNodes.find(cigarNodes);
+    }
+    else if (read.graph_mapping_status() == Read::BAD_ALIGN && !read.is_graph_alignment_unique())
+        ++validation_repeats;
+}
+template <typename AlignerT> void ValidationAligner<AlignerT>::alignRead(Read& read, ReadFilter filter)
+{
+    AlignerT::alignRead(read, filter);
+    account(read);
+}
+template <typename AlignerT> void ValidationAligner<AlignerT>::alignReads(std::vector<Read*> const& reads, ReadFilter filter)
+{
+    AlignerT::alignReads(reads, filter);
+    for (Read* r : reads)
+        account(*r);
+}
+template <typename AlignerT> std::string ValidationAligner<AlignerT>::getNodes(const std::string& cigar)
+{
+    std::string out;
+    bool inCigar = false;
+    for (const char c : cigar)
+    {
+        if (c == '[')
+            inCigar = true;
+        else if (c == ']')
+            inCigar = false;
+        else if (!inCigar)
+        {
+            if (!out.empty())
+                out += "->";
+            out += c;
+        }
+    }
+    return out;
+}
+template <typename AlignerT> std::string ValidationAligner<AlignerT>::getSimulatedPathId(Read& read)
+{
+    return read.fragment_id().substr(0, read.fragment_id().find('_'));
+}
+template <typename AlignerT> unsigned ValidationAligner<AlignerT>::mismapped() { return validation_mismapped; }
+template <typename AlignerT> unsigned ValidationAligner<AlignerT>::repeats() { return validation_repeats; }
+template <typename AlignerT> unsigned ValidationAligner<AlignerT>::aligned() { return validation_aligned; }
+template <typename AlignerT> unsigned ValidationAligner<AlignerT>::total() { return validation_total; }
+template class ValidationAligner<CompositeAligner>;
 }  // namespace grm
 
 namespace paragraph

@@ -96,7 +96,14 @@ int main(int argc, char** argv)
                 parameters.threads = std::max(1, std::stoi(args.value()));
             else if (args.is(nullptr, "--devices"))
                 paragraph::setDevices(cli::deviceList(args.value()));
-            else if (args.is(nullptr, "--validate-alignments") || args.is(nullptr, "--progress"))
+            else if (args.is(nullptr, "--validate-alignments"))
+            {
+                // simulated-read bookkeeping (grm::ValidationAligner): available through grm::alignReads(validate_alignments =
+                // true), not in the batched count workflow of this front end -- say so rather than ignore the request
+                if (args.optionalBool())
+                    throw std::runtime_error("option '--validate-alignments' is not available in this front end (use grm::alignReads)");
+            }
+            else if (args.is(nullptr, "--progress"))
                 (void)args.optionalBool();
             else if (args.is(nullptr, "--variant-min-reads") || args.is(nullptr, "--variant-min-frac") || args.is(nullptr, "--log-level")
                      || args.is(nullptr, "--log-file") || args.is(nullptr, "--log-async"))

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <list>
 #include <random>
@@ -18,6 +19,7 @@
 #include "grm/CompositeAligner.hh"
 #include "grm/GraphAligner.hh"
 #include "genotyping/GraphBreakpointGenotyper.hh"
+#include "grm/ValidationAligner.hh"
 #include "paragraph/SiteBatcher.hh"
 #include "paragraph/Statistics.hh"
 
@@ -122,6 +124,48 @@ static void testAlignReads()
         EXPECT_EQ(r.is_graph_reverse_strand(), kAligns[i].reverse);
         EXPECT_EQ(int(r.graph_mapping_status()), int(Read::MAPPED));
     }
+}
+
+// grm::alignReads(validate_alignments = true): the ValidationAligner bookkeeping (lib/grm/ValidationAligner.cpp:59-88) --
+// reads named "<Path::encode() of the simulated path>_<n>", an alignment whose node sequence is not part of that path is
+// "mismapped"; the reads themselves come out as without validation
+static void testValidationAligner()
+{
+    Graph graph = alignsGraph();
+    std::list<graphtools::Path> paths;
+    graphtools::Path p, q;
+    p.graph = q.graph = &graph;
+    p.nodes = { 0, 1, 3 };
+    q.nodes = { 0, 2, 3 };
+    p.start_position = q.start_position = 0;
+    p.end_position = q.end_position = 10;
+    paths.push_back(p);
+    paths.push_back(q);
+    EXPECT_EQ(p.encode(), std::string("(0@0)-(1)-(3@10)"));
+    graphtools::Path single;
+    single.nodes = { 2 };
+    single.start_position = 1;
+    single.end_position = 5;
+    EXPECT_EQ(single.encode(), std::string("(2@1)-(2@5)"));
+    using VA = grm::ValidationAligner<grm::CompositeAligner>;
+    const unsigned total0 = VA::total(), aligned0 = VA::aligned(), mis0 = VA::mismapped(), rep0 = VA::repeats();
+    std::vector<p_Read> reads;
+    reads.emplace_back(new Read(p.encode() + "_0", kAligns[0].bases, std::string(strlen(kAligns[0].bases), '#')));  // from P, aligns to P
+    reads.emplace_back(new Read(p.encode() + "_1", kAligns[2].bases, std::string(strlen(kAligns[2].bases), '#')));  // named P, aligns to Q
+    reads.emplace_back(new Read(q.encode() + "_2", kAligns[3].bases, std::string(strlen(kAligns[3].bases), '#')));  // from Q, aligns to Q
+    reads.emplace_back(new Read(q.encode() + "_3", kAligns[5].bases, std::string(strlen(kAligns[5].bases), '#')));  // 0[..]3[..]: not a piece of Q
+    std::vector<p_Read> plain;
+    for (auto const& r : reads)
+        plain.emplace_back(new Read(*r));
+    grm::alignReads(&graph, paths, reads, grm::ReadFilter(), false, true, false, false, true, 1);
+    grm::alignReads(&graph, paths, plain, grm::ReadFilter(), false, true, false, false, false, 1);
+    EXPECT_EQ(VA::total() - total0, 4u);
+    EXPECT_EQ(VA::aligned() - aligned0, 4u);
+    EXPECT_EQ(VA::mismapped() - mis0, 2u);
+    EXPECT_EQ(VA::repeats() - rep0, 0u);
+    EXPECT_EQ(reads.size(), plain.size());
+    for (size_t i = 0; i < reads.size() && i < plain.size(); ++i)
+        EXPECT_EQ(reads[i]->graph_cigar(), plain[i]->graph_cigar());
 }
 
 static void testGraphAlignerAlign()
@@ -835,6 +879,7 @@ int main()
         testKmerAligner();
         testPathAligner();
         testAlignReads();
+        testValidationAligner();
         testGraphAlignerAlign();
         testCompositeAlignerFilter();
         testSiteBatcher();

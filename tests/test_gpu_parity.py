@@ -208,3 +208,38 @@ def test_many_tiny_nodes(gpu_ctx, checker):
         want.extend(checker.align_batch(seqs, edges, rs))
     got = gpu_align(gpu_ctx, graphs, reads, gor)
     compare(got, want, reads, "tiny-nodes")
+
+
+def test_documented_limits_fail_loudly(gpu_ctx):
+    """Every limit of the envelope (include/paragraph_amd.h) answers with PG_ERR_UNSUPPORTED -- never with a wrong result:
+    4096 nodes, a direction longer than 65519 columns, 65 labels, 31 klib paths, a 513-base read."""
+    from paragraph_amd import capi
+    chain = (["ACGT"] * 4096, [(i, i + 1) for i in range(4095)])
+    with pytest.raises(capi.PgError) as e:
+        gpu_ctx.upload_graphs([chain])
+    assert e.value.status == 4 and "4095" in str(e.value)
+    ok = gpu_ctx.upload_graphs([(["ACGT"] * 4095, [(i, i + 1) for i in range(4094)])])  # the largest graph that is in
+    ok.close()
+    with pytest.raises(capi.PgError) as e:
+        gpu_ctx.upload_graphs([(["A" * 40000, "C" * 25600], [(0, 1)])])
+    assert e.value.status == 4
+    G = gpu_ctx.upload_graphs([ALIGNS_GRAPH])
+    names = ["L%02d" % i for i in range(65)]
+    with pytest.raises(capi.PgError) as e:
+        G.set_labels([{(0, 1): names[:1]}], [names])  # 65 labels declared
+    assert e.value.status == 4
+    G.set_labels([{(0, 1): names[:64]}], [names[:64]])  # 64 labels are in
+    with pytest.raises(capi.PgError) as e:
+        G.build_klib_index([[[0, 1, 3]] * 31])
+    assert e.value.status == 4
+    G.build_klib_index([[[0, 1, 3]] * 30])
+    b = gpu_ctx.new_batch()
+    with pytest.raises(capi.PgError) as e:
+        b.upload(G, ["A" * 513])
+    assert e.value.status == 4
+    b.upload(G, ["A" * 512])
+    b.align()
+    res, _ = b.download()
+    assert res[0]["status"] & 0xFF in (0, 1)
+    b.close()
+    G.close()

@@ -34,6 +34,10 @@
 // even count because the step loop is unrolled twice with ping-pong register naming (the extra step runs on an idle column)
 static inline __host__ __device__ uint32_t pg_fill_steps(uint32_t ncols) { return (ncols + PG_GROUP_LANES) & ~1u; }
 
+// The fill kernel keeps scores in a frame that moves by one per pipeline step (pg_fill.hip): the H trace holds
+// (score + PG_TAU0 + (step & 255)) & 0xFF per cell (& 0x3FF in the 16-bit wide variants), step = column + lane of the row.
+#define PG_TAU0 8u
+
 #define PG_GAP_OPEN 6
 #define PG_GAP_EXT 1
 #define PG_PAD_SCORE (-300)        // byte variants (scores <= 250)

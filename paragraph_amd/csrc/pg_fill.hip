@@ -216,7 +216,21 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     uint32_t* nodekey = (uint32_t*)(a.workspace + itp->seed_off + pg_seed_region_bytes(WIDE ? PG_VAR_WIDE + C : C, n_nodes));
     unsigned long long* nodekey64 = (unsigned long long*)nodekey;  // [n_nodes][4 reads][2 strands] 64-bit slots
 
-    // ---- query profiles of the 8 fills into LDS (gssw_qP_byte) ------------------------------------
+    // ---- the moving frame ----------------------------------------------------------------------------------------------------
+    // Quantities of pipeline step t are held as the f16 number 1024 + score + tau(t), tau(t) = PG_TAU0 + (t & 255): the frame
+    // moves up by one per step.  The horizontal gap E decays by the gap-extension cost 1 per column = per step, so in the
+    // moving frame it does not change at all: E' = max(E - 1, h - 6, 0) becomes max(E, h - 5, floor(t + 1)) -- the decrement is
+    // gone (6 instead of 7 instructions per cell pair); the diagonal term pays for it with a constant (+1, folded into the
+    // profile: diag + s + 1; +2 for a lane's first row, whose diagonal input is two steps old) and the floor of local
+    // alignment with a wave-uniform constant per step (an SGPR).  The vertical gap F lives inside one step and keeps its
+    // decrement.  Every 256 steps 256 is subtracted from all state, which keeps everything below 2048, where f16 holds
+    // integers exactly (range used: 1024 - 300 .. 1024 + 512 + 8 + 256 + 2).  What leaves the registers is converted with
+    // integer arithmetic on the bit patterns (0x6400 + n for 1024 + n): seeds and node maxima to plain scores on the rare
+    // paths; the H trace keeps the low byte (10 bits when WIDE) of score + tau, which pg_trace.hip undoes per cell.
+    const uint32_t PADPK = (f16_bits(PAD + 1) | (f16_bits(PAD + 1) << 16));
+    const uint32_t BIAS2 = PG_F16_BIAS2;  // the score 0 in frame 0
+
+    // ---- query profiles of the 8 fills into LDS (gssw_qP_byte), shifted by the frame step ------------------------------
     // (read index, offset and length are uniform per read: loaded once, not per profile entry)
 #pragma unroll
     for (int g = 0; g < PG_GROUPS; ++g)
@@ -230,8 +244,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         }
         for (int row = lane; row < ROWS; row += 64)
         {
-        uint32_t cA = 5u, cB = 5u;  // 5 = padding row
-        {
+            uint32_t cA = 5u, cB = 5u;  // 5 = padding row
             if ((uint32_t)row < L)
             {
                 const uint32_t f = (uint8_t)a.bases[off + row];
@@ -244,14 +257,14 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 cA = nt_code(chA);
                 cB = nt_code(chB);
             }
-        }
+            const int shift = (row % C) == 0 ? 2 : 1;  // a lane's first row takes its diagonal input from two steps back
 #pragma unroll
-        for (uint32_t code = 0; code < 4; ++code)
-        {
-            const int sA = cA == 5u ? PAD : sub_score(code, cA);
-            const int sB = cB == 5u ? PAD : sub_score(code, cB);
-            prof[(g * 4 + code) * ROWS + row] = f16_bits(sA) | (f16_bits(sB) << 16);
-        }
+            for (uint32_t code = 0; code < 4; ++code)
+            {
+                const int sA = (cA == 5u ? PAD : sub_score(code, cA)) + shift;
+                const int sB = (cB == 5u ? PAD : sub_score(code, cB)) + shift;
+                prof[(g * 4 + code) * ROWS + row] = f16_bits(sA) | (f16_bits(sB) << 16);
+            }
         }
     }
     // (device-scope stores / loads on the keys, but only a workgroup-scope fence: an agent-scope fence would write the
@@ -267,37 +280,36 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         const uint32_t Lg = ridx == PG_NONE ? 0u : a.base_off[ridx + 1] - a.base_off[ridx];
         real_rows = Lg > (uint32_t)(k * C) ? Lg - (uint32_t)(k * C) : 0u;
     }
-    const uint32_t PADPK = f16_bits(PAD) | (f16_bits(PAD) << 16);
-    const uint32_t BIAS2 = PG_F16_BIAS2;  // the score 0
 
     uint32_t* __restrict__ seed = (uint32_t*)(a.workspace + itp->seed_off);    // [node][lane][SEED_DW]
     uint32_t* __restrict__ trace = (uint32_t*)(a.workspace + itp->trace_off);  // [step][TRACE_DW][lane]: one store instruction = 256 contiguous bytes
 
     // H of the previous column lives in one of two register sets (HA / HB): a step reads one and writes the other, and the
     // step loop is unrolled twice with the roles swapped -- no register-to-register copies at the loop edge (the same for the
-    // profile rows of the current / next column, sA / sB).
+    // profile rows of the current / next column, sA / sB).  Initial values: score 0 in the frames of steps -1 / -2 / 0.
+    constexpr uint32_t ONE2 = 0x00010001u;
     uint32_t HA[C], HB[C], E[C];
 #pragma unroll
     for (int r = 0; r < C; ++r)
     {
-        HA[r] = BIAS2;
-        HB[r] = BIAS2;
-        E[r] = BIAS2;
+        HA[r] = BIAS2 + (PG_TAU0 - 1) * ONE2;
+        HB[r] = BIAS2 + (PG_TAU0 - 2) * ONE2;
+        E[r] = BIAS2 + PG_TAU0 * ONE2;
     }
+    // F is handed down as "F + 1" (the receiving row uses it as it is where every other row decrements first)
     uint32_t Fsend = BIAS2;
-    // what the row's first lane sees as "the lane above": score 0.  row_shr:1 never writes lane 0 of a row, so these two keep
-    // the constant there for the whole sweep while the other lanes receive their neighbour's value every step.
-    uint32_t dHin = BIAS2, Fin = BIAS2;
+    // What the row's first lane sees as "the lane above": score 0 two steps ago for the diagonal (incremented with the frame
+    // every step), anything not above score 0 for F.  row_shr:1 never writes lane 0 of a row, so that lane keeps these while
+    // the other lanes receive their neighbour's values every step.
+    uint32_t dHin = BIAS2 + (PG_TAU0 - 3) * ONE2, Fin = BIAS2;
     // one-entry seed cache (byte variants): the seed this lane stored last stays in registers, so the usual bubble
     // (LF -> {ALT, RF}: RF's far predecessor is LF) needs no memory round trip -- a load there stalls the whole wavefront
     uint32_t cseed[SEEDCACHE ? C : 1];
     uint32_t cnode = 0xFFFFFFFFu;
-    uint32_t M = BIAS2, FC = 0;
+    uint32_t M = BIAS2 + (PG_TAU0 - 1) * ONE2, FC = 0;  // node maximum (frame of the previous step) / step that first reached it
     uint32_t FR = 0;  // WIDE: smallest row (within the lane) holding the lane's maximum in column FC, per strand
-    // packed (col | col << 16) of the column this lane works on; col = t - k (wraps for idle lanes)
-    uint32_t colv = (uint32_t)(0x10000 - k) & 0xFFFFu;
-    colv |= colv << 16;
-    const uint32_t NEG_GO2 = PG_F16_NEG_GO2;
+    const uint32_t NEG5 = 0xC500C500u;    // (-5.0, -5.0): gap extend - gap open
+    const uint32_t NEG256 = 0xDC00DC00u;  // (-256.0, -256.0)
     const uint32_t nsteps = pg_fill_steps(gd.ncols);  // even
     const uint32_t* profl = prof + grp * 4 * ROWS + k * C;
     const uint32_t trace_lane_off = (uint32_t)lane * 4u;
@@ -311,6 +323,12 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     uint32_t mw1 = cmeta[1], mw2 = cmeta[2];
     // software pipeline: `meta` and the current profile rows always belong to the step about to be computed
     uint32_t meta = row_shr1_keep(cmeta[0], PG_META_IDLE);
+    // code 4 (N / idle column: score 0 on real rows) in the profile's shifted form
+    auto code4_rows = [&](uint32_t (&rows)[C]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < C; ++r)
+            rows[r] = (uint32_t)r < real_rows ? (r == 0 ? 0x40004000u : 0x3C003C00u) : PADPK;  // (2.0, 2.0) / (1.0, 1.0)
+    };
     uint32_t sA[C], sB[C];
     {
         const uint32_t code = PG_META_CODE(meta);
@@ -323,51 +341,53 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             sA[r + 1] = v.y;
         }
         if (code >= 4u)
-        {
-#pragma unroll
-            for (int r = 0; r < C; ++r)
-                sA[r] = (uint32_t)r < real_rows ? 0u : PADPK;
-        }
+            code4_rows(sA);
 #pragma unroll
         for (int r = 0; r < C; ++r)
             sB[r] = 0;
     }
     // the H trace of one step is [TRACE_DW][64 lanes] dwords behind a wave-uniform base that advances by one step per step:
     // the stores take the scalar-base form (SGPR pair + 32-bit lane offset + immediate), no per-step vector address arithmetic
-    // (readfirstlane: the base is uniform by construction; this makes it so for the compiler, which must keep it in SGPRs)
-    // (the builtin returns a signed int: without the casts the low half would be sign-extended over the high one)
+    // (readfirstlane: the base is uniform by construction; this makes it so for the compiler, which must keep it in SGPRs;
+    // the builtin returns a signed int: without the casts the low half would be sign-extended over the high one)
     uint64_t tbase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)(uintptr_t)trace >> 32)) << 32)
         | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)trace);
     constexpr uint32_t TRACE_STEP_BYTES = 64u * 4u * (uint32_t)TRACE_DW;
 
     // ---- one column of the affine-gap recurrence for C rows x 2 strands (Hin: previous column, Hout: this column) -----------
-    auto column = [&](uint32_t (&Hin)[C], uint32_t (&Hout)[C], const uint32_t (&sc)[C], uint32_t dH, uint32_t F) __attribute__((always_inline)) {
+    // floorE = the bit pattern of score 0 in the frame of step t + 1; tau = tau(t); tvec = (t | t << 16), all wave-uniform
+    auto column = [&](uint32_t (&Hin)[C], uint32_t (&Hout)[C], const uint32_t (&sc)[C], uint32_t dH, uint32_t Fabove, uint32_t floorE,
+                      uint32_t tau, uint32_t tvec) __attribute__((always_inline)) {
+        (void)tau;
         uint32_t diag = dH;
+        uint32_t F = Fabove;
 #pragma unroll
         for (int r = 0; r < C; ++r)
         {
-            const uint32_t h = pk_max3h(pk_addh(diag, sc[r]), E[r], F);  // max(H(i-1,j-1) + s, E, F); E >= 0 is the local-alignment floor
+            const uint32_t f = r == 0 ? F : pk_dech(F);                      // F of this row in this step's frame
+            const uint32_t h = pk_max3h(pk_addh(diag, sc[r]), E[r], f);      // max(H(i-1,j-1) + s, E, F); E >= 0 is the local-alignment floor
             diag = Hin[r];
             Hout[r] = h;
-            const uint32_t tt = pk_addh_s(h, NEG_GO2);  // h - gap open (may dip below 0: E clamps, F is only ever compared)
-            E[r] = pk_max3h_s(pk_dech(E[r]), tt, BIAS2);
-            F = pk_maxu(pk_dech(F), tt);
+            const uint32_t tt = pk_addh_s(h, NEG5);                          // (h - gap open) in the next step's / next row's terms
+            E[r] = pk_max3h_s(E[r], tt, floorE);                             // no decrement: the frame moves instead
+            F = pk_maxu(f, tt);                                              // "F + 1" of the next row
         }
         Fsend = F;
 
-        // ---- running node maximum + first column reaching it (gssw.c:369-386) -----------------------
-        // three-input maxima: 10 rows + the running maximum in 5 instructions
+        // ---- running node maximum + first step reaching it (gssw.c:369-386) -----------------------
+        // three-input maxima: C rows + the running maximum (moved into this step's frame) in (C + 1) / 2 instructions
+        const uint32_t Mprev = pk_add(M, ONE2);  // into this step's frame (integer + 1 on the bit pattern = + 1.0 above 1024)
         uint32_t cm[C + 1];
 #pragma unroll
         for (int r = 0; r < C; ++r)
             cm[r] = Hout[r];
-        cm[C] = M;
+        cm[C] = Mprev;
         const uint32_t Mn = pk_max_all<C + 1>(cm);
         if (DIR == 0 || WIDE)
         {
-            // mask = 0xFFFF in the halves whose maximum grew: (M - Mn) is negative there as a 16-bit integer
+            // mask = 0xFFFF in the halves whose maximum grew: (Mprev - Mn) is negative there as a 16-bit integer
             uint32_t grew;
-            asm("v_pk_sub_u16 %0, %1, %2\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=v"(grew) : "v"(M), "v"(Mn));
+            asm("v_pk_sub_u16 %0, %1, %2\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=v"(grew) : "v"(Mprev), "v"(Mn));
             if (WIDE)
             {
                 // The row of the maximum matters in one case only: a node whose final maximum is 251..255 -- the reference's
@@ -375,8 +395,9 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 // node's cells (epilogue).  A maximum passes through each of those five values at most once, so the row search
                 // runs a handful of times per node instead of at every growth step.  (The traceback's start row is found from
                 // the H trace in the epilogue, like in the byte variants.)
-                const uint32_t mnA = Mn & 0xFFFFu, mnB = Mn >> 16;  // bit patterns: 0x6400 | score
-                const bool needA = (grew & 0xFFFFu) && ((mnA & 0x3FFu) - 251u) <= 4u, needB = (grew >> 16) && ((mnB & 0x3FFu) - 251u) <= 4u;
+                const uint32_t mnA = Mn & 0xFFFFu, mnB = Mn >> 16;  // bit patterns: 0x6400 + score + tau
+                const bool needA = (grew & 0xFFFFu) && ((mnA & 0x3FFu) - tau - 251u) <= 4u;
+                const bool needB = (grew >> 16) && ((mnB & 0x3FFu) - tau - 251u) <= 4u;
                 if (needA || needB)
                 {
                     uint32_t frA = FR & 0xFFFFu, frB = FR >> 16;
@@ -391,7 +412,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                     FR = frA | (frB << 16);
                 }
             }
-            asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(FC) : "v"(grew), "v"(colv));
+            asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(FC) : "v"(grew), "s"(tvec));
         }
         M = Mn;
 
@@ -419,20 +440,20 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             }
         }
     };
-
     // ---- node boundaries ---------------------------------------------------------------------------------------------------
     // first column: seed = lane-wise max over the predecessors (gssw_create_seed_byte); the predecessor that directly
-    // precedes this node in the layout is still in Hin / E
-    auto first_column = [&](uint32_t (&Hin)[C], uint32_t meta_cur) __attribute__((always_inline)) {
+    // precedes this node in the layout is still in Hin / E.  Seeds are stored as plain scores; tau = tau(t).
+    auto first_column = [&](uint32_t (&Hin)[C], uint32_t meta_cur, uint32_t tau) __attribute__((always_inline)) {
         const uint32_t node = PG_META_NODE(meta_cur);
+        const uint32_t hshift = (tau - 1u) * ONE2, eshift = tau * ONE2;  // previous column's H lives one frame back
         // (the maxima are taken in place: no second copy of a column in registers)
         if (!(meta_cur & PG_META_PRED_ADJ))
         {  // nothing of the node before it in the layout flows in: start from score 0
 #pragma unroll
             for (int r = 0; r < C; ++r)
             {
-                Hin[r] = BIAS2;
-                E[r] = BIAS2;
+                Hin[r] = BIAS2 + hshift;
+                E[r] = BIAS2 + eshift;
             }
         }
         if (!WIDE && !(meta_cur & PG_META_PRED_MANY))
@@ -458,9 +479,10 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 #pragma unroll
                 for (int r = 0; r < C; ++r)
                 {
-                    // bytes (H_A, H_B, Enext_A, Enext_B) -> (0x6400 | H_A, 0x6400 | H_B), the 0x64 bytes come from the constant
-                    Hin[r] = pk_maxu(Hin[r], __builtin_amdgcn_perm(BIAS2, w[r], 0x07010500u));
-                    E[r] = pk_maxu(E[r], __builtin_amdgcn_perm(BIAS2, w[r], 0x07030502u));
+                    // bytes (H_A, H_B, Enext_A, Enext_B) -> (0x6400 | H_A, 0x6400 | H_B) (the 0x64 bytes come from the constant),
+                    // then into the frame with an integer addition on the bit patterns
+                    Hin[r] = pk_maxu(Hin[r], pk_add(__builtin_amdgcn_perm(BIAS2, w[r], 0x07010500u), hshift));
+                    E[r] = pk_maxu(E[r], pk_add(__builtin_amdgcn_perm(BIAS2, w[r], 0x07030502u), eshift));
                 }
             }
         }
@@ -477,40 +499,43 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 for (int r = 0; r < C; ++r)
                 {
                     if (WIDE)
-                    {  // dwords: (H_A | H_B << 16), (Enext_A | Enext_B << 16) as stored by last_column: the registers' bit patterns
-                        Hin[r] = pk_maxu(Hin[r], sp[2 * r]);
-                        E[r] = pk_maxu(E[r], sp[2 * r + 1]);
+                    {  // dwords: (H_A | H_B << 16), (Enext_A | Enext_B << 16), each 16-bit field = 0x6400 | score
+                        Hin[r] = pk_maxu(Hin[r], pk_add(sp[2 * r], hshift));
+                        E[r] = pk_maxu(E[r], pk_add(sp[2 * r + 1], eshift));
                     }
                     else
                     {
                         const uint32_t w = sp[r];  // bytes: H_A, H_B, Enext_A, Enext_B
-                        Hin[r] = pk_maxu(Hin[r], __builtin_amdgcn_perm(BIAS2, w, 0x07010500u));
-                        E[r] = pk_maxu(E[r], __builtin_amdgcn_perm(BIAS2, w, 0x07030502u));
+                        Hin[r] = pk_maxu(Hin[r], pk_add(__builtin_amdgcn_perm(BIAS2, w, 0x07010500u), hshift));
+                        E[r] = pk_maxu(E[r], pk_add(__builtin_amdgcn_perm(BIAS2, w, 0x07030502u), eshift));
                     }
                 }
             }
         }
-        M = BIAS2;
+        M = BIAS2 + hshift;  // maximum so far: score 0, in the previous step's frame (the column moves it on)
         FC = 0;
         FR = 0;
     };
-    // last column: the seed for the successors, and the node's maximum into its key
-    auto last_column = [&](const uint32_t (&Hout)[C], uint32_t meta_cur) __attribute__((always_inline)) {
+    // last column: the seed for the successors, and the node's maximum into its key.  Hout is in the frame of step t, E
+    // (already the next column's) in that of step t + 1.
+    auto last_column = [&](const uint32_t (&Hout)[C], uint32_t meta_cur, uint32_t tau) __attribute__((always_inline)) {
         const uint32_t node = PG_META_NODE(meta_cur);
         if (meta_cur & PG_META_SAVE)
         {
             uint32_t* sp = seed + ((size_t)node * 64 + lane) * SEED_DW;
+            const uint32_t hshift = tau * ONE2, eshift = (tau + 1u) * ONE2;
 #pragma unroll
             for (int r = 0; r < C; ++r)
             {
+                const uint32_t hs = pk_sub(Hout[r], hshift), es = pk_sub(E[r], eshift);  // 0x6400 | score
                 if (WIDE)
                 {
-                    sp[2 * r] = Hout[r];
-                    sp[2 * r + 1] = E[r];
+                    sp[2 * r] = hs;
+                    sp[2 * r + 1] = es;
                 }
                 else
                 {
-                    const uint32_t w = __builtin_amdgcn_perm(E[r], Hout[r], 0x06040200u);
+                    const uint32_t w = __builtin_amdgcn_perm(es, hs, 0x06040200u);
                     sp[r] = w;
                     if (SEEDCACHE)
                         cseed[r] = w;
@@ -521,8 +546,8 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         }
         // key: max (12 bits) | inverted column (16 bits; a direction has <= 65519 columns) | inverted lane (4 bits)
         const uint32_t kinv = (uint32_t)(15 - k);
-        const uint32_t mA = M & 0x3FFu, mB = (M >> 16) & 0x3FFu;  // the scores under the 0x6400 of their f16 patterns
-        const uint32_t cA = FC & 0xFFFFu, cB = FC >> 16;
+        const uint32_t mA = (M & 0x3FFu) - tau, mB = ((M >> 16) & 0x3FFu) - tau;  // the scores under 0x6400 + tau of their f16 patterns
+        const uint32_t cA = ((FC & 0xFFFFu) - (uint32_t)k) & 0xFFFFu, cB = ((FC >> 16) - (uint32_t)k) & 0xFFFFu;  // step -> column
         if (WIDE)
         {
             // key: max | inverted column (16 bits) | inverted row (16 bits)
@@ -546,8 +571,13 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // ---- one pipeline step: reads Hin (previous column) / sc (this column's profile rows), writes Hout / sn (next column's) ---
     auto step = [&](uint32_t (&Hin)[C], uint32_t (&Hout)[C], uint32_t (&sc)[C], uint32_t (&sn)[C], uint32_t t) __attribute__((always_inline)) {
         const uint32_t meta_cur = meta;
+        const uint32_t tau = PG_TAU0 + (t & 255u);                 // wave-uniform: scalar registers
+        const uint32_t floorE = BIAS2 + (tau + 1u) * ONE2;         // score 0 in the next step's frame
+        const uint32_t tvec = (t & 0xFFFFu) * ONE2;
         // Hout still holds the column before the previous one: its last row is what the next lane needs as its diagonal
-        // input one step later (lane k + 1 works one column behind lane k)
+        // input one step later (lane k + 1 works one column behind lane k).  The row's first lane has no lane above: it keeps
+        // its own register, which follows the frame by one per step.
+        dHin = pk_add(dHin, ONE2);
         dHin = row_shr1_keep(dHin, Hout[C - 1]);
         Fin = row_shr1_keep(Fin, Fsend);
         const uint32_t dH = dHin, F = Fin;
@@ -567,30 +597,43 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 rows[r + 1] = v.y;
             }
         }
-        // one test for what is rare BEFORE the column (a first column, or a column that carries code 4), one for what is
-        // rare after it (a last column).  The column itself is outside the branches: with the lanes of a read skewed by one
-        // column each, a node boundary keeps SOME lane of the wavefront in a rare path for 16 steps in a row, and a column
-        // inside the branch would then be executed twice, once per side.
-        if (((meta_cur & PG_META_FIRST) | (meta_rows & 4u)) != 0u)
+        // ONE test for everything that is rare: a node boundary in this column, or a column that carries code 4.  The column
+        // itself is outside the branches: with the lanes of a read skewed by one column each, a node boundary keeps SOME lane
+        // of the wavefront in a rare path for 16 steps in a row, and a column inside the branch would then be executed twice,
+        // once per side.
+        const bool rare = ((meta_cur & (PG_META_FIRST | PG_META_LAST)) | (meta_rows & 4u)) != 0u;
+        if (rare)
         {
-            if (meta_rows & 4u)
-            {  // N in the graph, or the idle columns behind its end
-#pragma unroll
-                for (int r = 0; r < C; ++r)
-                    rows[r] = (uint32_t)r < real_rows ? 0u : PADPK;
-            }
+            if (meta_rows & 4u)  // N in the graph, or the idle columns behind its end
+                code4_rows(rows);
             if (meta_cur & PG_META_FIRST)
-                first_column(Hin, meta_cur);
+                first_column(Hin, meta_cur, tau);
         }
-        column(Hin, Hout, sc, dH, F);
-        if (meta_cur & PG_META_LAST)
-            last_column(Hout, meta_cur);
-        colv = pk_add(colv, 0x00010001u);
+        column(Hin, Hout, sc, dH, F, floorE, tau, tvec);
+        if (rare)
+        {
+            if (meta_cur & PG_META_LAST)
+                last_column(Hout, meta_cur, tau);
+        }
         tbase += TRACE_STEP_BYTES;
     };
 
     for (uint32_t t = 0; t < nsteps; t += 2)
     {
+        if ((t & 255u) == 0u && t != 0u)
+        {
+            // keep the frame small: 256 off everything that carries it (wave-uniform branch, once per 256 steps)
+#pragma unroll
+            for (int r = 0; r < C; ++r)
+            {
+                HA[r] = pk_addh_s(HA[r], NEG256);
+                HB[r] = pk_addh_s(HB[r], NEG256);
+                E[r] = pk_addh_s(E[r], NEG256);
+            }
+            Fsend = pk_addh_s(Fsend, NEG256);
+            dHin = pk_addh_s(dHin, NEG256);
+            M = pk_addh_s(M, NEG256);
+        }
         if (PREFETCH)
         {
             step(HA, HB, sA, sB, t);
@@ -672,7 +715,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 #pragma unroll
             for (int r = 0; r < C; ++r)
             {
-                const uint32_t hval = (tp[r * 64] >> (strand * 16)) & 0x3FFu;  // the score under the 0x6400 of its f16 pattern
+                const uint32_t hval = (((tp[r * 64] >> (strand * 16)) & 0x3FFu) - (PG_TAU0 + ((col + kk) & 255u))) & 0x3FFu;  // score + tau under 0x6400
                 if (!found && hval == best)
                 {
                     rr = r;
@@ -722,8 +765,9 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             for (int r = 0; r < C; r += 2)
             {
                 const uint32_t w = tp[(r / 2) * 64];
-                const uint32_t b0 = (w >> (strand * 16)) & 0xFFu;
-                const uint32_t b1 = (w >> (strand * 16 + 8)) & 0xFFu;
+                const uint32_t tau = PG_TAU0 + ((col + kk) & 255u);  // the trace holds (score + tau) & 0xFF of the step it was written in
+                const uint32_t b0 = (((w >> (strand * 16)) & 0xFFu) - tau) & 0xFFu;
+                const uint32_t b1 = (((w >> (strand * 16 + 8)) & 0xFFu) - tau) & 0xFFu;
                 if (!found && b0 == best)
                 {
                     rr = r;

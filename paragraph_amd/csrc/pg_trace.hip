@@ -205,13 +205,15 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
     // [node][lane][2C] dwords (H_A | H_B << 16), (Enext_A | Enext_B << 16), each 16-bit field = 0x6400 | score
     auto Hcell = [&](uint32_t col, int j) -> int {
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
+        // the fill kernel stores (score + tau) of the step the cell was computed in (PG_TAU0, pg_device.h)
+        const uint32_t tau = PG_TAU0 + ((col + kq) & 255u);
         if (WIDE)
         {
             const size_t dw = ((size_t)(col + kq) * C + r) * 64 + (grp * 16 + kq);
-            return (int)(((const uint16_t*)trace)[dw * 2 + (uint32_t)s] & 0x3FFu);  // f16 pattern 0x6400 | score (pg_fill.hip)
+            return (int)(((((const uint16_t*)trace)[dw * 2 + (uint32_t)s] & 0x3FFu) - tau) & 0x3FFu);  // f16 pattern 0x6400 + score + tau
         }
         const size_t dw = ((size_t)(col + kq) * (C / 2) + r / 2) * 64 + (grp * 16 + kq);
-        return (int)trace[dw * 4 + (r & 1u) + 2u * (uint32_t)s];
+        return (int)(((uint32_t)trace[dw * 4 + (r & 1u) + 2u * (uint32_t)s] - tau) & 0xFFu);
     };
     auto seedH = [&](uint32_t node, int j) -> int {
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libparagraph_amd.so")
+LIB_PATH = os.environ.get("PG_LIB") or os.path.join(_HERE, "libparagraph_amd.so")  # PG_LIB: another build of the same ABI (tools/build_variant.sh, A/B timing)
 
 AF_CIGAR = 1
 AF_BOTH_STRANDS = 2

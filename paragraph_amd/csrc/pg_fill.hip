@@ -100,6 +100,10 @@ __device__ __forceinline__ uint32_t pk_max3h_s(uint32_t a, uint32_t b, uint32_t 
     asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(sconst));
     return d;
 }
+// in-place forms for the rare paths: the value stays in its register (a tied operand), so the merge after the branch needs no
+// copy on the common path (without them the compiler copied all C registers of the previous column at the top of every step)
+__device__ __forceinline__ void pk_maxu_into(uint32_t& acc, uint32_t x) { asm("v_pk_max_u16 %0, %0, %1" : "+v"(acc) : "v"(x)); }
+__device__ __forceinline__ void mov_into(uint32_t& dst, uint32_t sconst) { asm("v_mov_b32 %0, %1" : "+v"(dst) : "s"(sconst)); }
 __device__ __forceinline__ uint32_t f16_bits(int v) { return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)v); }
 // maximum of N packed values with three-input instructions: ceil((N - 1) / 2) of them
 template <int N> __device__ __forceinline__ uint32_t pk_max_all(const uint32_t (&v)[N])
@@ -452,7 +456,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 #pragma unroll
             for (int r = 0; r < C; ++r)
             {
-                Hin[r] = BIAS2 + hshift;
+                mov_into(Hin[r], BIAS2 + hshift);
                 E[r] = BIAS2 + eshift;
             }
         }
@@ -481,7 +485,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 {
                     // bytes (H_A, H_B, Enext_A, Enext_B) -> (0x6400 | H_A, 0x6400 | H_B) (the 0x64 bytes come from the constant),
                     // then into the frame with an integer addition on the bit patterns
-                    Hin[r] = pk_maxu(Hin[r], pk_add(__builtin_amdgcn_perm(BIAS2, w[r], 0x07010500u), hshift));
+                    pk_maxu_into(Hin[r], pk_add(__builtin_amdgcn_perm(BIAS2, w[r], 0x07010500u), hshift));
                     E[r] = pk_maxu(E[r], pk_add(__builtin_amdgcn_perm(BIAS2, w[r], 0x07030502u), eshift));
                 }
             }
@@ -500,13 +504,13 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 {
                     if (WIDE)
                     {  // dwords: (H_A | H_B << 16), (Enext_A | Enext_B << 16), each 16-bit field = 0x6400 | score
-                        Hin[r] = pk_maxu(Hin[r], pk_add(sp[2 * r], hshift));
+                        pk_maxu_into(Hin[r], pk_add(sp[2 * r], hshift));
                         E[r] = pk_maxu(E[r], pk_add(sp[2 * r + 1], eshift));
                     }
                     else
                     {
                         const uint32_t w = sp[r];  // bytes: H_A, H_B, Enext_A, Enext_B
-                        Hin[r] = pk_maxu(Hin[r], pk_add(__builtin_amdgcn_perm(BIAS2, w, 0x07010500u), hshift));
+                        pk_maxu_into(Hin[r], pk_add(__builtin_amdgcn_perm(BIAS2, w, 0x07010500u), hshift));
                         E[r] = pk_maxu(E[r], pk_add(__builtin_amdgcn_perm(BIAS2, w, 0x07030502u), eshift));
                     }
                 }

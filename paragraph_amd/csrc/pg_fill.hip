@@ -428,9 +428,9 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 for (int r = 0; r < C; ++r)
                 {
                     if (r < 16)
-                        asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(trace_lane_off), "v"(Hout[r]), "s"(tbase), "n"(r * 256) : "memory");
+                        asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(trace_lane_off), "v"(Hout[r]), "s"(tbase), "n"(r * 256) : "memory");
                     else
-                        asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(trace_lane_off), "v"(Hout[r]), "s"(tbase + 4096u), "n"((r - 16) * 256) : "memory");
+                        asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(trace_lane_off), "v"(Hout[r]), "s"(tbase + 4096u), "n"((r - 16) * 256) : "memory");
                 }
             }
             else
@@ -439,7 +439,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 for (int r = 0; r < C; r += 2)
                 {
                     const uint32_t packed = __builtin_amdgcn_perm(Hout[r + 1], Hout[r], 0x06020400u);  // bytes A_r, A_r+1, B_r, B_r+1 (one v_perm)
-                    asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(trace_lane_off), "v"(packed), "s"(tbase), "n"((r / 2) * 256) : "memory");
+                    asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(trace_lane_off), "v"(packed), "s"(tbase), "n"((r / 2) * 256) : "memory");
                 }
             }
         }

@@ -35,7 +35,7 @@
 static inline __host__ __device__ uint32_t pg_fill_steps(uint32_t ncols) { return (ncols + PG_GROUP_LANES) & ~1u; }
 
 // The fill kernel keeps scores in a frame that moves by one per pipeline step (pg_fill.hip): the H trace holds
-// (score + PG_TAU0 + (step & 255)) & 0xFF per cell (& 0x3FF in the 16-bit wide variants), step = column + lane of the row.
+// (score + PG_TAU0 + (step & 255)) & 0xFF per cell, step = column + lane of the row.
 #define PG_TAU0 8u
 
 #define PG_GAP_OPEN 6
@@ -109,8 +109,9 @@ static inline __host__ __device__ int pg_variant_of(uint32_t L)
     return L <= 250u ? (int)(2u * ((L + 31u) / 32u)) : PG_VAR_WIDE + (int)(4u * ((L + 63u) / 64u));
 }
 static inline __host__ __device__ uint32_t pg_rows(int V) { return (uint32_t)(PG_GROUP_LANES * pg_var_c(V)); }
-// bytes of H trace one lane writes per pipeline step: C rows x 2 strands (x 2 bytes when wide)
-static inline __host__ __device__ uint32_t pg_trace_lane_bytes(int V) { return (uint32_t)((pg_var_wide(V) ? 4 : 2) * pg_var_c(V)); }
+// bytes of H trace one lane writes per pipeline step: C rows x 2 strands, one byte per cell in every variant (the wide
+// variants store H mod 256: neighbouring cells differ by less than 128, which lets the traceback carry exact scores along)
+static inline __host__ __device__ uint32_t pg_trace_lane_bytes(int V) { return (uint32_t)(2 * pg_var_c(V)); }
 // bytes of seed (H, next-column E of both strands) one lane keeps per node
 static inline __host__ __device__ uint32_t pg_seed_lane_bytes(int V) { return (uint32_t)((pg_var_wide(V) ? 8 : 4) * pg_var_c(V)); }
 // seed region of one work item: [node][lane][seed dwords], 256-byte aligned; behind it the per-node maxima keys

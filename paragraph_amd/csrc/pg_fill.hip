@@ -195,7 +195,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // the start of the step instead.
     constexpr bool PREFETCH = WIDE ? C <= 16 : true;
     constexpr bool SEEDCACHE = !WIDE;
-    constexpr int TRACE_DW = WIDE ? C : C / 2;  // dwords of H trace per lane per step
+    constexpr int TRACE_DW = C / 2;             // dwords of H trace per lane per step: one byte per cell, two strands
     constexpr int SEED_DW = WIDE ? 2 * C : C;   // dwords of seed per lane per node
     constexpr int ROWS = PG_GROUP_LANES * C;
     // LDS holds the profiles of the four real reference codes only: [4 reads][4 codes][ROWS] packed (strand A | strand B << 16)
@@ -230,7 +230,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // decrement.  Every 256 steps 256 is subtracted from all state, which keeps everything below 2048, where f16 holds
     // integers exactly (range used: 1024 - 300 .. 1024 + 512 + 8 + 256 + 2).  What leaves the registers is converted with
     // integer arithmetic on the bit patterns (0x6400 + n for 1024 + n): seeds and node maxima to plain scores on the rare
-    // paths; the H trace keeps the low byte (10 bits when WIDE) of score + tau, which pg_trace.hip undoes per cell.
+    // paths; the H trace keeps the low byte of score + tau, which pg_trace.hip undoes per cell.
     const uint32_t PADPK = (f16_bits(PAD + 1) | (f16_bits(PAD + 1) << 16));
     const uint32_t BIAS2 = PG_F16_BIAS2;  // the score 0 in frame 0
 
@@ -422,25 +422,13 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 
         if (DIR == 0)
         {
-            if (WIDE)
-            {
+            // one byte per cell: the low byte of the bit pattern = (score + tau) mod 256 (all of the score in the byte variants;
+            // in the wide ones the traceback keeps exact scores by following differences, which are small between neighbours)
 #pragma unroll
-                for (int r = 0; r < C; ++r)
-                {
-                    if (r < 16)
-                        asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(trace_lane_off), "v"(Hout[r]), "s"(tbase), "n"(r * 256) : "memory");
-                    else
-                        asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(trace_lane_off), "v"(Hout[r]), "s"(tbase + 4096u), "n"((r - 16) * 256) : "memory");
-                }
-            }
-            else
+            for (int r = 0; r < C; r += 2)
             {
-#pragma unroll
-                for (int r = 0; r < C; r += 2)
-                {
-                    const uint32_t packed = __builtin_amdgcn_perm(Hout[r + 1], Hout[r], 0x06020400u);  // bytes A_r, A_r+1, B_r, B_r+1 (one v_perm)
-                    asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(trace_lane_off), "v"(packed), "s"(tbase), "n"((r / 2) * 256) : "memory");
-                }
+                const uint32_t packed = __builtin_amdgcn_perm(Hout[r + 1], Hout[r], 0x06020400u);  // bytes A_r, A_r+1, B_r, B_r+1 (one v_perm)
+                asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(trace_lane_off), "v"(packed), "s"(tbase), "n"((r / 2) * 256) : "memory");
             }
         }
     };
@@ -713,16 +701,26 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             // itself = the first row of that lane holding `best` in the H trace of column `col`
             const uint32_t col = 0xFFFFu - (uint32_t)((bestkey >> 16) & 0xFFFFu);
             const uint32_t kk = (0xFFFFu - (uint32_t)(bestkey & 0xFFFFu)) / (uint32_t)C;
+            // (bytes = (score + tau) mod 256: within one lane's C <= 32 rows of a column the scores differ by far less than 256,
+            // so comparing modulo 256 finds the same first row)
             const uint32_t* tp = trace + (size_t)(col + kk) * 64 * TRACE_DW + (grp * 16 + kk);
+            const uint32_t tau = PG_TAU0 + ((col + kk) & 255u);
             int rr = 0;
             bool found = false;
 #pragma unroll
-            for (int r = 0; r < C; ++r)
+            for (int r = 0; r < C; r += 2)
             {
-                const uint32_t hval = (((tp[r * 64] >> (strand * 16)) & 0x3FFu) - (PG_TAU0 + ((col + kk) & 255u))) & 0x3FFu;  // score + tau under 0x6400
-                if (!found && hval == best)
+                const uint32_t w = tp[(r / 2) * 64];
+                const uint32_t b0 = (((w >> (strand * 16)) & 0xFFu) - tau) & 0xFFu;
+                const uint32_t b1 = (((w >> (strand * 16 + 8)) & 0xFFu) - tau) & 0xFFu;
+                if (!found && b0 == (best & 0xFFu))
                 {
                     rr = r;
+                    found = true;
+                }
+                if (!found && b1 == (best & 0xFFu))
+                {
+                    rr = r + 1;
                     found = true;
                 }
             }

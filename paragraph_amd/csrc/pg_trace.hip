@@ -201,19 +201,31 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
         return s == 0 ? upper_c((uint8_t)bases[j]) : comp_c((uint8_t)bases[L - 1 - j]);
     };
     // byte variants: trace [step][C/2][lane] dwords of bytes (A_r, A_r+1, B_r, B_r+1), seed [node][lane][C] dwords of
-    // bytes (H_A, H_B, Enext_A, Enext_B); wide variants: trace [step][C][lane] dwords (A_r | B_r << 16), seed
-    // [node][lane][2C] dwords (H_A | H_B << 16), (Enext_A | Enext_B << 16), each 16-bit field = 0x6400 | score
+    // bytes (H_A, H_B, Enext_A, Enext_B); wide variants: the same trace, seed [node][lane][2C] dwords (H_A | H_B << 16),
+    // (Enext_A | Enext_B << 16), each 16-bit field = 0x6400 | score
     auto Hcell = [&](uint32_t col, int j) -> int {
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
         // the fill kernel stores (score + tau) of the step the cell was computed in (PG_TAU0, pg_device.h)
         const uint32_t tau = PG_TAU0 + ((col + kq) & 255u);
-        if (WIDE)
-        {
-            const size_t dw = ((size_t)(col + kq) * C + r) * 64 + (grp * 16 + kq);
-            return (int)(((((const uint16_t*)trace)[dw * 2 + (uint32_t)s] & 0x3FFu) - tau) & 0x3FFu);  // f16 pattern 0x6400 + score + tau
-        }
         const size_t dw = ((size_t)(col + kq) * (C / 2) + r / 2) * 64 + (grp * 16 + kq);
         return (int)(((uint32_t)trace[dw * 4 + (r & 1u) + 2u * (uint32_t)s] - tau) & 0xFFu);
+    };
+    // The byte is the whole score in the byte variants (reads <= 250 bases).  In the wide ones it is the score modulo 256: the
+    // walk itself carries the exact score (`sc`), and every test below relates the scores of cells that are neighbours or on
+    // one short diagonal / vertical run, whose true values differ by far less than 128 -- so equality modulo 256 is equality
+    // (same(): x == y for the byte variants, x == y mod 256 for the wide ones); where a run is long (the F scan) the exact
+    // values are carried from cell to cell by the signed 8-bit differences of the bytes.
+    auto same = [&](int x, int y) -> bool { return WIDE ? (((uint32_t)(x - y)) & 0xFFu) == 0u : x == y; };
+    // inclusive prefix sum over the 16 lanes of the row
+    auto row_scan = [&](int v) -> int {
+#pragma unroll
+        for (uint32_t off = 1; off < 16u; off *= 2u)
+        {
+            const int up = (int)row_get((uint32_t)v, k >= off ? k - off : 0u);
+            if (k >= off)
+                v += up;
+        }
+        return v;
     };
     auto seedH = [&](uint32_t node, int j) -> int {
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
                 const int hup = Hcell(c0 + i - 1, j);
                 em.emit(n, PG_OPC_D, 1);
                 --i;
-                if (sc == hup - PG_GAP_OPEN)
+                if (same(sc, hup - PG_GAP_OPEN))
                 {
                     sc += PG_GAP_OPEN;
                     inE = false;
@@ -286,7 +298,7 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
                 const int hl = Hcell(c0 + i, j - 1);
                 em.emit(n, PG_OPC_I, 1);
                 --j;
-                if (sc == hl - PG_GAP_OPEN)
+                if (same(sc, hl - PG_GAP_OPEN))
                 {
                     sc += PG_GAP_OPEN;
                     inF = false;
@@ -310,9 +322,21 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
                     subd = sub_score(nt_code(rc), nt_code(qc));
                     opd = (rc == 'N' || qc == 'N') ? PG_OPC_N : (rc == qc ? PG_OPC_M : PG_OPC_X);
                 }
-                const int above = (int)row_get((uint32_t)hd, k == 0u ? 0u : k - 1u);
-                const int cur = k == 0u ? sc : above;  // the score the walk holds when it arrives at depth d
-                const bool ok = valid && cur > 0 && cur == hd + subd;
+                // the score the walk holds when it arrives at depth d: H of depth d - 1 (byte variants), or the exact score minus
+                // the substitution scores of the depths before (wide variants, where H is known modulo 256 only)
+                int cur;
+                int sub_before = 0;
+                if (WIDE)
+                {
+                    sub_before = row_scan(subd) - subd;
+                    cur = sc - sub_before;
+                }
+                else
+                {
+                    const int above = (int)row_get((uint32_t)hd, k == 0u ? 0u : k - 1u);
+                    cur = k == 0u ? sc : above;
+                }
+                const bool ok = valid && cur > 0 && same(cur, hd + subd);
                 const uint32_t fail = ~row_ballot(ok) & 0xFFFFu;
                 const uint32_t run = fail ? (uint32_t)__builtin_ctz(fail) : 16u;
                 if (run > 0u)
@@ -326,7 +350,10 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
                         const uint32_t s1 = starts ? (uint32_t)__builtin_ctz(starts) : run;
                         em.emit(n, row_get(opd, s0), s1 - s0);
                     }
-                    sc = (int)row_get((uint32_t)hd, run - 1u);
+                    if (WIDE)
+                        sc -= (int)row_get((uint32_t)(sub_before + subd), run - 1u);
+                    else
+                        sc = (int)row_get((uint32_t)hd, run - 1u);
                     i -= (int)run;
                     j -= (int)run;
                 }
@@ -340,7 +367,7 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
             const int sub = sub_score(nt_code(rch), nt_code(qch));
             if (i > 0 && j > 0)
             {
-                if (sc == Hcell(c0 + i - 1, j - 1) + sub)
+                if (same(sc, Hcell(c0 + i - 1, j - 1) + sub))
                 {
                     const uint32_t op = (rch == 'N' || qch == 'N') ? PG_OPC_N : (rch == qch ? PG_OPC_M : PG_OPC_X);
                     em.emit(n, op, 1);
@@ -372,10 +399,26 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
                 bool isF = false;
                 const int kmax = (j + 1 - sc - PG_GAP_OPEN + PG_GAP_EXT) / (1 + PG_GAP_EXT);
                 const int lim = kmax < j ? kmax : j;
+                int run_exact = sc;                        // exact H(i, j - (base - 1)); H(i, j) = sc
+                uint32_t run_byte = (uint32_t)sc & 0xFFu;  // ... and its byte
                 for (int base = 1; base <= lim && !isF; base += 16)
                 {  // 16 gap lengths per round
                     const int kk = base + (int)k;
-                    const bool hit = kk <= lim && Hcell(c0 + i, j - kk) - PG_GAP_OPEN - (kk - 1) * PG_GAP_EXT == sc;
+                    const bool in = kk <= lim;
+                    int h = 0;
+                    if (in)
+                        h = Hcell(c0 + i, j - kk);
+                    if (WIDE)
+                    {
+                        // exact values along the column: add up the signed differences of neighbouring bytes
+                        const uint32_t above = row_get((uint32_t)h, k == 0u ? 0u : k - 1u);
+                        const int diff = (int)(int8_t)(uint8_t)((uint32_t)h - (k == 0u ? run_byte : above));
+                        const int exact = run_exact + row_scan(in ? diff : 0);
+                        run_exact = (int)row_get((uint32_t)exact, 15u);
+                        run_byte = row_get((uint32_t)h, 15u);
+                        h = exact;
+                    }
+                    const bool hit = in && h - PG_GAP_OPEN - (kk - 1) * PG_GAP_EXT == sc;
                     isF = row_ballot(hit) != 0u;
                 }
                 if (isF)

@@ -1,0 +1,102 @@
+"""CPU-side checks of what bench.py and the full-size GPU tests are built from: the site-set generator (per-site streams:
+any subset equals the same sites of the full set, the forked generator equals the serial one), the partition the ranks use,
+the CPU baseline leg (threads and processes write the same records into shared buffers; they equal the per-read oracle
+calls) and the field-by-field comparison that produces bench.py's `verified` object."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_site_streams_subsets_and_forked_generator():
+    from paragraph_amd import synth
+    full = synth.mixed_sites(90, seed=4, site_streams=True)
+    part = synth.mixed_sites(90, seed=4, site_streams=True, indices=[3, 41, 89])
+    for got, i in zip(part, (3, 41, 89)):
+        assert got.site.seqs == full[i].site.seqs and np.array_equal(got.reads, full[i].reads)
+        assert np.array_equal(got.fragment, full[i].fragment) and np.array_equal(got.is_reverse, full[i].is_reverse)
+    forked = synth.mixed_sites_parallel(90, seed=4, procs=3)
+    assert len(forked) == 90
+    assert all(a.site.seqs == b.site.seqs and np.array_equal(a.reads, b.reads) for a, b in zip(forked, full))
+    assert {s.site.kind for s in full} == {"del", "longdel", "ins"}
+
+
+def test_site_partition_is_balanced_and_complete():
+    import bench
+    from paragraph_amd import synth
+    sites = synth.mixed_sites(400, seed=6, site_streams=True)
+    for world in (1, 2, 8):
+        sset = bench.SiteSet(sites, 150, world)
+        seen = np.concatenate(sset.parts)
+        assert sorted(seen.tolist()) == list(range(400))
+        loads = [sset.weights[p].sum() for p in sset.parts]
+        assert max(loads) <= 1.02 * sum(loads) / world
+        arr, gor, frag, rev = sset.shard_arrays(sset.parts[-1])
+        assert len(arr) == len(gor) == len(frag) == len(rev) == int(sset.n_reads_site[sset.parts[-1]].sum())
+        assert set(np.unique(gor).tolist()) <= set(sset.parts[-1].tolist())
+
+
+def test_cpu_leg_and_verification(tmp_path):
+    """bench.py --cpu-leg on 3 000 config-2 reads: its records equal per-read oracle calls; verify_against_reference accepts a
+    matching pg_result table built from them and counts an edited one."""
+    import bench
+    from oracle import oracle as orc
+    from paragraph_amd import capi, synth
+    site, arr = synth.config2_reads_packed(3000, read_len=150, seed=2)
+    reads_file, out_file = tmp_path / "reads.npy", tmp_path / "cpu.npz"
+    np.save(reads_file, arr)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-leg", "--cpu-reads-file", str(reads_file), "--cpu-out",
+                        str(out_file), "--cpu-seconds", "0.5"], stdout=subprocess.PIPE, check=True)
+    base = json.loads(p.stdout.decode().splitlines()[-1])
+    assert base["unit"] == "reads/s" and base["value"] > 0 and base["cores"] >= 1 and base["kind"] in ("reference", "port")
+    assert {"threads_one_process", "process_per_chunk", "probes", "sample"} <= set(base)
+    z = np.load(out_file)
+    res, cig = z["res"], z["cig"]
+    assert len(res) == len(cig) >= 2000 and cig.shape[1] == bench.CIGAR_STRIDE
+    chk = orc.RefOracle() if orc.have_ref() else orc.PortOracle()
+    reads = [row.tobytes().decode() for row in arr[:40]]
+    for i, w in enumerate(chk.align_batch(site.seqs, site.edges, reads)):
+        assert w["cigar"].encode() == bytes(cig[i]).split(b"\0")[0] and w["graph_pos"] == res[i]["graph_pos"] and w["score"] == res[i]["score"]
+
+    # a pg_result / pg_op table that says the same thing (host-only: pg_render_cigars needs no device)
+    n = 300
+    gres = np.zeros(n, dtype=capi.RESULT_DTYPE)
+    ops = []
+    codes = {c: k for k, c in enumerate(capi.OP_CHARS)}
+    import re
+    for i in range(n):
+        gres[i]["graph_pos"], gres[i]["score"], gres[i]["mapq"] = res[i]["graph_pos"], res[i]["score"], res[i]["mapq"]
+        gres[i]["is_unique"], gres[i]["returned_reverse"] = res[i]["unique"], res[i]["returned_reverse"]
+        gres[i]["multi_mask"] = sum(int(res[i]["multi"][k]) << k for k in range(4))
+        gres[i]["status"] = 1 if res[i]["score"] == 0 else 0
+        gres[i]["ops_off"] = len(ops)
+        text = bytes(cig[i]).split(b"\0")[0].decode()
+        for node, body in re.findall(r"(\d+)\[([^\]]*)\]", text):
+            for ln, op in re.findall(r"(\d+)([MXNIDS])", body):
+                ops.append((int(node) << 20) | (codes[op] << 16) | int(ln))
+        gres[i]["n_ops"] = len(ops) - gres[i]["ops_off"]
+    ops = np.array(ops, dtype=np.uint32)
+    v = bench.verify_against_reference(capi, gres, ops, res[:n], cig[:n])
+    assert v == {"reads": n, "mismatches": 0, "fields": v["fields"]}
+    gres[7]["graph_pos"] += 1
+    ops[int(gres[9]["ops_off"])] ^= 1  # one CIGAR element one base longer / shorter
+    v = bench.verify_against_reference(capi, gres, ops, res[:n], cig[:n])
+    assert v["mismatches"] == 2 and v["first_mismatch"]["read"] == 7
+
+
+def test_bench_spawn_command(monkeypatch):
+    """--gpus N without WORLD_SIZE: bench.py re-executes itself under torch.distributed.run on 127.0.0.1 with N ranks."""
+    import bench
+    seen = {}
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--workload", "config3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.main() == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--workload", "config3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "PG_BENCH_LAUNCHER" in os.environ

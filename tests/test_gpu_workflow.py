@@ -300,3 +300,39 @@ def test_two_device_slots_give_the_same_documents(tmp_path):
     r = subprocess.run([sys.executable, str(script), json.dumps({"lanes": 2})], capture_output=True, text=True, timeout=600,
                        env=dict(env, PG_DEVICES="0,0"))
     assert r.returncode == 0 and json.loads(r.stdout.splitlines()[-1]) == outs[1], r.stderr[-2000:]
+
+
+def test_config1_round_trip_from_the_vcf(tmp_path):
+    """BASELINE configs[0] with the VCF itself as input, as `multigrmpy.py -i candidates.vcf` takes it: paragraph_amd.vcf2paragraph
+    (one allele graph per line, the reference's vcf2paragraph options) -> workflow.genotype_graphs -> the GT / DP / AD of
+    expected-vcf-record.txt.  Allele names are the variant's allele ids (`test-ins:1`); the REF allele carries the `REF` path label
+    and `<id>:0` on the same edges."""
+    import json
+    from paragraph_amd import vcf2paragraph, workflow
+    d = os.path.join(ROOT, "tests", "golden", "sites", "round-trip")
+    want = {}
+    for line in open(os.path.join(d, "expected-vcf-record.txt")):
+        f = line.rstrip("\n").split("\t")
+        if line.startswith("#"):
+            names = f[9:]
+            continue
+        keys = f[8].split(":")
+        want[f[2]] = {n: dict(zip(keys, v.split(":"))) for n, v in zip(names, f[9:])}
+    graphs = vcf2paragraph.convert_vcf_to_graphs(os.path.join(d, "candidates.vcf"), os.path.join(d, "dummy.fa"), retrieve_reference_sequence=True)
+    paths = []
+    for g in graphs:
+        doc = dict(g["graph"], ID=g["ID"])
+        p = tmp_path / ("g%d.json" % len(paths))
+        p.write_text(json.dumps(doc))
+        paths.append(str(p))
+    docs = workflow.genotype_graphs(os.path.join(d, "dummy.fa"), os.path.join(d, "samples.txt"), paths, threads=2)
+    assert [doc["graphinfo"]["ID"] for doc in docs] == [g["ID"] for g in graphs]
+    for rid, doc in zip(("test-ins", "test-del"), docs):
+        for sample, w in want[rid].items():
+            gt = doc["samples"][sample]["gt"]
+            if w["GT"] == ".":
+                assert gt["GT"] == "." and "NO_VALID_GT" in gt["filters"], (rid, sample, gt)
+                continue
+            alleles = gt["GT"].split("/")
+            assert len(alleles) == 2 and all(a.endswith(rid + ":1") or (rid + ":1") in a.split(",") for a in alleles), (rid, sample, gt)  # 1/1
+            assert gt["num_reads"] == int(w["DP"]), (rid, sample, gt, w)

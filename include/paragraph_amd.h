@@ -330,6 +330,11 @@ pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* batch, uint32_t flags);
  * for a read's CIGAR, bit1 a path CIGAR exceeded 2 * L + 4 runs: those reads stay unmapped).  Synchronises, clears. */
 pg_status pg_graphs_klib_error(pg_ctx* ctx, pg_graphs* graphs, uint32_t* error);
 
+/* Which kernels the last pg_batch_klib_align on this graph set ran: 1 = the packed two-strand kernels (every read <= 250 bases
+ * and every path of the set at least as long as the longest read), 0 = the general ones.  Both give KlibAligner's results
+ * (src/c++/lib/grm/KlibAligner.cpp:388-442); the tests use this to know which of the two they have checked. */
+pg_status pg_graphs_klib_last_kernels(pg_ctx* ctx, pg_graphs* graphs, uint32_t* packed);
+
 /* Restricts the following stage calls (pg_batch_path_align / pg_batch_kmer_align / pg_batch_klib_align / pg_batch_align) to reads with active[i] != 0 (NULL = every read): the next
  * stage of the cascade runs only on reads the previous stage left unmapped / filtered. */
 pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* batch, const uint8_t* active);

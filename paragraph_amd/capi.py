@@ -45,7 +45,7 @@ EXPORTS = [
     "pg_batch_download", "pg_align_batch", "pg_render_cigar", "pg_graphs_set_labels", "pg_graphs_count_layout",
     "pg_graphs_seq_offsets", "pg_batch_set_fragments", "pg_batch_count", "pg_batch_download_counts", "pg_graphs_build_path_index",
     "pg_batch_path_align", "pg_batch_download_path_flags", "pg_batch_set_active", "pg_graphs_build_kmer_index",
-    "pg_batch_kmer_align", "pg_graphs_build_klib_index", "pg_batch_klib_align", "pg_graphs_klib_error", "pg_graphs_build_filter_index",
+    "pg_batch_kmer_align", "pg_graphs_build_klib_index", "pg_batch_klib_align", "pg_graphs_klib_error", "pg_graphs_klib_last_kernels", "pg_graphs_build_filter_index",
     "pg_host_alloc", "pg_host_free", "pg_host_register", "pg_host_unregister", "pg_counts_zero", "pg_ctx_sync_compute",
     "pg_render_cigars",
 ]
@@ -156,6 +156,8 @@ def load_library():
     L.pg_batch_klib_align.argtypes = [vp, vp, C.c_uint32]
     L.pg_graphs_klib_error.restype = C.c_int32
     L.pg_graphs_klib_error.argtypes = [vp, vp, u32p]
+    L.pg_graphs_klib_last_kernels.restype = C.c_int32
+    L.pg_graphs_klib_last_kernels.argtypes = [vp, vp, u32p]
     L.pg_host_alloc.restype = C.c_int32
     L.pg_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.pg_host_free.restype = None
@@ -370,6 +372,12 @@ class Graphs:
         e = np.zeros(1, dtype=np.uint32)
         self.ctx._chk(self.ctx.L.pg_graphs_klib_error(self.ctx.h, self.h, _p32(e)))
         return int(e[0])
+
+    def klib_used_packed_kernels(self):
+        """True when the last klib_align on this graph set ran the packed two-strand kernels (tests)."""
+        e = np.zeros(1, dtype=np.uint32)
+        self.ctx._chk(self.ctx.L.pg_graphs_klib_last_kernels(self.ctx.h, self.h, _p32(e)))
+        return bool(e[0])
 
     def set_labels(self, edge_labels, labels=None):
         """edge_labels: per graph a dict {(from,to): [label,...]}; labels: per graph the ordered label list

@@ -24,16 +24,18 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
 #include "../../include/paragraph_amd.h"
 #include "pg_device.h"
 #include "pg_internal.h"
+#include "pg_klib.h"
 
 namespace
 {
-constexpr int MAX_PATHS = 30;
+constexpr int MAX_PATHS = PG_KLIB_MAX_PATHS;
 constexpr int HEAP_CAP = MAX_PATHS + 2;
 // KlibAlignerImpl's scoring (KlibAligner.cpp:134-142): ksw charges gapo + gape for the first gap base
 constexpr int K_MATCH = 1, K_MISMATCH = -4, K_GAPO = 5, K_GAPE = 1, K_GAPOE = K_GAPO + K_GAPE;
@@ -41,76 +43,8 @@ constexpr int K_MINUS_INF = -0x40000000;
 // direction bytes per lane per step: one per row, padded to a dword (R <= 4) or two (R <= 8)
 constexpr int z_lane_bytes(int R) { return R <= 4 ? 4 : 8; }
 
-struct LPathDev
-{
-    uint32_t seq_off;  // into pathseq[] / pathcode[]
-    uint32_t len;
-    uint32_t start_off;  // into starts[] (pairs: start position, node id)
-    uint32_t n_nodes;
-};
-struct LGraphDev
-{
-    uint32_t path_off;
-    uint32_t n_paths;
-};
-
-struct KlibItem
-{  // result of one KlibAlignment::update()
-    int32_t score, tb, te, qb, qe;
-    uint32_t n_cigar;   // entries of the ksw_global CIGAR (len<<4 | op, op 0 M / 1 I / 2 D)
-    uint32_t cig_begin; // first entry inside this item's slot
-    uint32_t valid;     // 1 = candidate (te >= tb), 0 = none
-};
-
-struct KlibArgs
-{
-    uint32_t n_reads;
-    uint32_t max_paths;  // items per read = 2 * max_paths
-    const uint32_t* base_off;
-    const char* bases;
-    const uint32_t* graph_of_read;
-    const LGraphDev* graphs;
-    const LPathDev* paths;
-    const char* pathseq;
-    const uint8_t* pathcode;
-    const uint32_t* starts;
-    const uint8_t* active;
-    KlibItem* items;
-    uint32_t* cigars;    // [n_items][cig_cap]
-    uint32_t cig_cap;
-    uint8_t* z;          // [gridDim.x][z_bytes]
-    uint64_t z_bytes;
-    // pick kernel
-    pg_result* results;
-    pg_op* ops;
-    unsigned long long* ops_counter;
-    uint64_t ops_cap;
-    uint8_t* flags;
-    uint32_t* error;  // bit0 = ops overflow, bit1 = cigar slot overflow
-};
-
-__device__ __forceinline__ uint32_t comp_raw(uint32_t c)
-{
-    switch (c)
-    {
-    case 'A': return 'T';
-    case 'C': return 'G';
-    case 'G': return 'C';
-    case 'T': return 'A';
-    default: return 'N';
-    }
-}
-__device__ __forceinline__ int ksw_code(uint32_t c)
-{  // KlibImpl.hh translation_matrix: A/a/U/u 0, C/c 1, G/g 2, T/t 3, others 4 (index & 0x7f)
-    switch (c & 0x7f)
-    {
-    case 'A': case 'a': case 'U': case 'u': return 0;
-    case 'C': case 'c': return 1;
-    case 'G': case 'g': return 2;
-    case 'T': case 't': return 3;
-    default: return 4;
-    }
-}
+__device__ __forceinline__ uint32_t comp_raw(uint32_t c) { return klib_comp_raw(c); }
+__device__ __forceinline__ int ksw_code(uint32_t c) { return klib_code(c); }
 __device__ __forceinline__ int ksw_score(int a, int b) { return ((a | b) & 4) ? 0 : (a == b ? K_MATCH : K_MISMATCH); }
 
 struct ReadView
@@ -457,7 +391,7 @@ __global__ __launch_bounds__(64) void pg_klib_pair_kernel(KlibArgs a)
                 out.qb = qb;
                 out.qe = qe;
                 out.n_cigar = n;
-                out.cig_begin = a.cig_cap - n;
+                out.cig_begin = (uint32_t)(item * a.cig_cap) + a.cig_cap - n;
                 out.valid = te >= tb ? 1u : 0u;
                 a.items[item] = out;
             }
@@ -490,9 +424,9 @@ struct KGen
     __device__ uint32_t node_of(uint32_t i) const { return a.starts[p.start_off + 2 * i + 1]; }
     __device__ uint32_t node_len(uint32_t i) const { return (i + 1 < p.n_nodes ? start_of(i + 1) : p.len) - start_of(i); }
 
-    __device__ void init(const KlibItem& ki, const uint32_t* slot, int L)
+    __device__ void init(const KlibItem& ki, const uint32_t* cigars, int L)
     {
-        cig = slot + ki.cig_begin;
+        cig = cigars + ki.cig_begin;
         n_cig = ki.n_cigar;
         left = (uint32_t)ki.qb;
         right = (uint32_t)(L - ki.qe - 1);
@@ -652,6 +586,41 @@ __device__ void kheap_pop(HeapEnt* h, int& n)
     n = len;
 }
 
+// Replays a read's candidate heap on the scores of the first pass (KlibAligner.cpp:388-442: push, evict the worst beyond
+// paths + 2) and puts the candidates the pick kernel can look at -- those holding the best score -- on the work list of the
+// finish kernel.
+__global__ __launch_bounds__(64) void pg_klib_select_kernel(KlibArgs a)
+{
+    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+    if (r >= a.n_reads || (a.active && !a.active[r]))
+        return;
+    if (a.base_off[r + 1] == a.base_off[r])
+        return;
+    const LGraphDev g = a.graphs[a.graph_of_read[r]];
+    if (g.n_paths == 0 || g.n_paths > MAX_PATHS)
+        return;
+    const uint32_t per_read = 2u * a.max_paths;
+    const uint64_t item0 = (uint64_t)r * per_read;
+    HeapEnt heap[HEAP_CAP];
+    int hn = 0;
+    const int cap = (int)g.n_paths + 2;
+    for (uint32_t s = 0; s < 2u * g.n_paths; ++s)
+    {
+        const KlibItem ki = a.items[item0 + s];
+        if (!ki.valid)
+            continue;
+        kheap_push(heap, hn, HeapEnt{ ki.score, s });
+        if (hn == cap)
+            kheap_pop(heap, hn);
+    }
+    int best = 0;
+    for (int i = 0; i < hn; ++i)
+        best = heap[i].score > best ? heap[i].score : best;
+    for (int i = 0; i < hn; ++i)
+        if (heap[i].score == best)
+            a.worklist[atomicAdd(a.work_count, 1u)] = (uint32_t)(item0 + heap[i].item);
+}
+
 __global__ __launch_bounds__(64) void pg_klib_pick_kernel(KlibArgs a)
 {
     const uint32_t r = blockIdx.x * 64u + threadIdx.x;
@@ -689,7 +658,6 @@ __global__ __launch_bounds__(64) void pg_klib_pick_kernel(KlibArgs a)
             bi = i;
     const HeapEnt best = heap[bi];
     const KlibItem kb = a.items[item0 + best.item];
-    const uint32_t* slot_b = a.cigars + (item0 + best.item) * a.cig_cap;
     const LPathDev pb = a.paths[g.path_off + (best.item >> 1)];
     const bool rev_b = (best.item & 1u) != 0;
     bool bad = false;
@@ -707,8 +675,8 @@ __global__ __launch_bounds__(64) void pg_klib_pick_kernel(KlibArgs a)
             const KlibItem ks = a.items[item0 + sb.item];
             KGen g1{ a, pb, rv, rev_b };
             KGen g2{ a, a.paths[g.path_off + (sb.item >> 1)], rv, (sb.item & 1u) != 0 };
-            g1.init(kb, slot_b, L);
-            g2.init(ks, a.cigars + (item0 + sb.item) * a.cig_cap, L);
+            g1.init(kb, a.cigars, L);
+            g2.init(ks, a.cigars, L);
             bool differ = g1.graph_pos != g2.graph_pos;
             while (!differ)
             {
@@ -731,7 +699,7 @@ __global__ __launch_bounds__(64) void pg_klib_pick_kernel(KlibArgs a)
     }
     // ---- emit the best alignment
     KGen gen{ a, pb, rv, rev_b };
-    gen.init(kb, slot_b, L);
+    gen.init(kb, a.cigars, L);
     uint32_t n_ops = 0, score = 0, clipped = 0;
     {
         uint32_t nd, op, len;
@@ -744,7 +712,7 @@ __global__ __launch_bounds__(64) void pg_klib_pick_kernel(KlibArgs a)
         atomicOr(a.error, 1u);
         return;
     }
-    gen.init(kb, slot_b, L);
+    gen.init(kb, a.cigars, L);
     {
         uint32_t nd, op, len, e = 0;
         while (gen.next(nd, op, len))
@@ -777,8 +745,13 @@ __global__ __launch_bounds__(64) void pg_klib_pick_kernel(KlibArgs a)
 struct pg_klib_index
 {
     uint32_t max_paths = 0;     // per graph
-    uint32_t max_path_len = 0;
+    uint32_t max_path_len = 0, min_path_len = 0;
     LGraphDev* d_graphs = nullptr;
+    uint32_t* d_pathmeta = nullptr;  // packed kernels: one word per path column (its code) + PG_META_PAD idle words per path
+    uint32_t* d_worklist = nullptr;
+    size_t worklist_cap = 0;
+    uint32_t* d_work_count = nullptr;
+    uint32_t last_packed = 0;
     LPathDev* d_paths = nullptr;
     char* d_pathseq = nullptr;
     uint8_t* d_pathcode = nullptr;
@@ -802,6 +775,9 @@ void pg_klib_index_free(pg_klib_index* ix)
     (void)pg_dev_free(ix->d_pathseq);
     (void)pg_dev_free(ix->d_pathcode);
     (void)pg_dev_free(ix->d_starts);
+    (void)pg_dev_free(ix->d_pathmeta);
+    (void)pg_dev_free(ix->d_worklist);
+    (void)pg_dev_free(ix->d_work_count);
     (void)pg_dev_free(ix->d_items);
     (void)pg_dev_free(ix->d_cigars);
     (void)pg_dev_free(ix->d_z);
@@ -828,7 +804,8 @@ extern "C" pg_status pg_graphs_build_klib_index(
     std::vector<char> pathseq;
     std::vector<uint8_t> pathcode;
     std::vector<uint32_t> starts;
-    uint32_t max_len = 0, max_paths = 0;
+    uint32_t max_len = 0, max_paths = 0, min_len = 0xFFFFFFFFu;
+    size_t meta_words = 0;
     for (uint32_t g = 0; g < G->n_graphs; ++g)
     {
         const uint32_t nb = G->h_node_off[g], n_nodes = G->h_node_off[g + 1] - nb;
@@ -861,6 +838,11 @@ extern "C" pg_status pg_graphs_build_klib_index(
             if (pos >= (1u << 20))
                 return pg_fail(ctx, PG_ERR_UNSUPPORTED, "path longer than 2^20 bases");
             max_len = std::max(max_len, pos);
+            min_len = std::min(min_len, pos);
+            lp.meta_off = (uint32_t)meta_words;
+            meta_words += (size_t)pos + PG_META_PAD;
+            if (meta_words >= (1ull << 32))
+                return pg_fail(ctx, PG_ERR_UNSUPPORTED, "more than 2^32 path bases in one graph set");
             pd.push_back(lp);
         }
     }
@@ -876,14 +858,21 @@ extern "C" pg_status pg_graphs_build_klib_index(
         default: pathcode[i] = 4;
         }
     }
+    std::vector<uint32_t> pathmeta(meta_words, PG_META_IDLE);
+    for (const LPathDev& lp : pd)
+        for (uint32_t i = 0; i < lp.len; ++i)
+            pathmeta[lp.meta_off + i] = pathcode[lp.seq_off + i];
     pg_klib_index* ix = new pg_klib_index();
     ix->max_paths = max_paths;
     ix->max_path_len = max_len;
+    ix->min_path_len = pd.empty() ? 0u : min_len;
     hipError_t e = upl(gd, &ix->d_graphs, ctx->stream_copy);
     if (e == hipSuccess) e = upl(pd, &ix->d_paths, ctx->stream_copy);
     if (e == hipSuccess) e = upl(pathseq, &ix->d_pathseq, ctx->stream_copy);
     if (e == hipSuccess) e = upl(pathcode, &ix->d_pathcode, ctx->stream_copy);
     if (e == hipSuccess) e = upl(starts, &ix->d_starts, ctx->stream_copy);
+    if (e == hipSuccess) e = upl(pathmeta, &ix->d_pathmeta, ctx->stream_copy);
+    if (e == hipSuccess) e = pg_dev_alloc((void**)&ix->d_work_count, sizeof(uint32_t));
     if (e == hipSuccess) e = pg_dev_alloc((void**)&ix->d_error, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(ix->d_error, 0, sizeof(uint32_t), ctx->stream_copy);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream_copy);
@@ -933,17 +922,12 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
         return PG_OK;
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(n_items, (uint64_t)n_cu * 32u);
-    // direction bytes: the window has at most 2 * L target columns (a local alignment with positive score cannot
-    // delete more bases than it matches) and never more than the path; + 64 steps of skew
-    const uint64_t z_steps = std::min<uint64_t>(2ull * max_len, ix->max_path_len) + 64 + 1;
-    const uint64_t z_bytes = z_steps * 64 * z_lane_bytes(R);
     const uint32_t cig_cap = 2 * max_len + 4;
-    pg_status st = grow(ctx, &ix->d_items, &ix->items_cap, (size_t)n_items);
-    if (st == PG_OK) st = grow(ctx, &ix->d_cigars, &ix->cigars_cap, (size_t)n_items * cig_cap);
-    if (st == PG_OK) st = grow(ctx, &ix->d_z, &ix->z_cap, (size_t)grid * z_bytes);
-    if (st != PG_OK)
-        return st;
+    // The packed kernels take reads of up to 250 bases (the byte variants of the fill kernel: C <= 16 rows per lane) on paths
+    // no shorter than a read (ksw_global's band = path length then covers the whole window) and short enough for a 16-bit
+    // step counter; anything else runs on the general kernels.
+    const bool packed = max_len <= 250 && ix->min_path_len >= max_len && ix->max_path_len <= 65000u && !std::getenv("PG_KLIB_GENERAL");
+    ix->last_packed = packed ? 1u : 0u;
     KlibArgs a{};
     a.n_reads = b->n_reads;
     a.max_paths = ix->max_paths;
@@ -954,31 +938,86 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     a.paths = ix->d_paths;
     a.pathseq = ix->d_pathseq;
     a.pathcode = ix->d_pathcode;
+    a.pathmeta = ix->d_pathmeta;
     a.starts = ix->d_starts;
     a.active = b->has_active ? b->d_active : nullptr;
-    a.items = ix->d_items;
-    a.cigars = ix->d_cigars;
     a.cig_cap = cig_cap;
-    a.z = ix->d_z;
-    a.z_bytes = z_bytes;
     a.results = b->d_results;
     a.ops = b->d_ops;
     a.ops_counter = b->d_ops_counter;
     a.ops_cap = b->ops_cap;
     a.flags = b->d_path_flags;
     a.error = ix->d_error;
-    switch (R)
+    pg_status st = grow(ctx, &ix->d_items, &ix->items_cap, (size_t)n_items);
+    if (st != PG_OK)
+        return st;
+    a.items = ix->d_items;
+    if (packed)
     {
-    case 1: hipLaunchKernelGGL(pg_klib_pair_kernel<1>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL(pg_klib_pair_kernel<2>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL(pg_klib_pair_kernel<3>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
-    case 4: hipLaunchKernelGGL(pg_klib_pair_kernel<4>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
-    case 5: hipLaunchKernelGGL(pg_klib_pair_kernel<5>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
-    case 6: hipLaunchKernelGGL(pg_klib_pair_kernel<6>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
-    case 7: hipLaunchKernelGGL(pg_klib_pair_kernel<7>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
-    default: hipLaunchKernelGGL(pg_klib_pair_kernel<8>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        st = grow(ctx, &ix->d_worklist, &ix->worklist_cap, (size_t)n_items);
+        if (st != PG_OK)
+            return st;
+        a.worklist = ix->d_worklist;
+        a.work_count = ix->d_work_count;
+        a.work = b->d_items;
+        HIP_TRY(ctx, hipMemsetAsync(ix->d_work_count, 0, sizeof(uint32_t), ctx->stream));
+        // first pass: the batch's wavefront work items (4 reads of one graph and one length class each), every path of the graph
+        for (const Chunk& c : b->chunks)
+        {
+            a.pair_begin = c.pair_begin;
+            HIP_TRY(ctx, pg_klib_launch_local(c.C, a, c.pair_end - c.pair_begin, ctx->stream));
+        }
+        hipLaunchKernelGGL(pg_klib_select_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
+        HIP_TRY(ctx, hipGetLastError());
+        // the size of the second pass is only known now (one small read-back; the stage's caller reads the flags back next anyway)
+        uint32_t n_work = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&n_work, ix->d_work_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if ((uint64_t)n_work * cig_cap >= (1ull << 32))
+            return pg_fail(ctx, PG_ERR_UNSUPPORTED, "pg_batch_klib_align: batch too large (CIGAR scratch index)");
+        const int C = pg_variant_of(max_len);
+        const uint32_t waves = (n_work + 7u) / 8u;
+        const uint32_t grid = std::min<uint32_t>(waves, (uint32_t)n_cu * 8u);
+        const uint64_t z_bytes = pg_klib_finish_z_bytes(C);
+        st = grow(ctx, &ix->d_cigars, &ix->cigars_cap, std::max<size_t>((size_t)n_work * cig_cap, 1));
+        if (st == PG_OK) st = grow(ctx, &ix->d_z, &ix->z_cap, std::max<size_t>((size_t)grid * z_bytes, 1));
+        if (st != PG_OK)
+            return st;
+        a.cigars = ix->d_cigars;
+        a.z = ix->d_z;
+        a.z_bytes = z_bytes;
+        a.n_work = n_work;
+        HIP_TRY(ctx, pg_klib_launch_finish(C, a, grid, ctx->stream));
     }
-    HIP_TRY(ctx, hipGetLastError());
+    else
+    {
+        if (n_items * cig_cap >= (1ull << 32))
+            return pg_fail(ctx, PG_ERR_UNSUPPORTED, "pg_batch_klib_align: batch too large (CIGAR scratch index)");
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(n_items, (uint64_t)n_cu * 32u);
+        // direction bytes: the window has at most 2 * L target columns (a local alignment with positive score cannot
+        // delete more bases than it matches) and never more than the path; + 64 steps of skew
+        const uint64_t z_steps = std::min<uint64_t>(2ull * max_len, ix->max_path_len) + 64 + 1;
+        const uint64_t z_bytes = z_steps * 64 * z_lane_bytes(R);
+        st = grow(ctx, &ix->d_cigars, &ix->cigars_cap, (size_t)n_items * cig_cap);
+        if (st == PG_OK) st = grow(ctx, &ix->d_z, &ix->z_cap, (size_t)grid * z_bytes);
+        if (st != PG_OK)
+            return st;
+        a.cigars = ix->d_cigars;
+        a.z = ix->d_z;
+        a.z_bytes = z_bytes;
+        switch (R)
+        {
+        case 1: hipLaunchKernelGGL(pg_klib_pair_kernel<1>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        case 2: hipLaunchKernelGGL(pg_klib_pair_kernel<2>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        case 3: hipLaunchKernelGGL(pg_klib_pair_kernel<3>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        case 4: hipLaunchKernelGGL(pg_klib_pair_kernel<4>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        case 5: hipLaunchKernelGGL(pg_klib_pair_kernel<5>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        case 6: hipLaunchKernelGGL(pg_klib_pair_kernel<6>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        case 7: hipLaunchKernelGGL(pg_klib_pair_kernel<7>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        default: hipLaunchKernelGGL(pg_klib_pair_kernel<8>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+    }
     hipLaunchKernelGGL(pg_klib_pick_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, pg_stage_end(ctx, b));
@@ -994,5 +1033,13 @@ extern "C" pg_status pg_graphs_klib_error(pg_ctx* ctx, pg_graphs* G, uint32_t* e
     HIP_TRY(ctx, hipMemcpyAsync(error, G->klib_index->d_error, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(G->klib_index->d_error, 0, sizeof(uint32_t), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+
+extern "C" pg_status pg_graphs_klib_last_kernels(pg_ctx* ctx, pg_graphs* G, uint32_t* packed)
+{
+    if (!ctx || !G || !G->klib_index || !packed)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_graphs_klib_last_kernels: bad argument");
+    *packed = G->klib_index->last_packed;
     return PG_OK;
 }

@@ -18,16 +18,20 @@ def checker():
     return ok.ref_klib() if ok.have_ref() else ok.port_klib()
 
 
-def gpu_klib(ctx, graphs, paths, reads, gor):
+def gpu_klib(ctx, graphs, paths, reads, gor, expect_packed=None, active=None):
     from paragraph_amd import capi
     G = ctx.upload_graphs(graphs)
     G.build_klib_index(paths)
     b = ctx.new_batch()
     b.upload(G, reads, gor)
+    if active is not None:
+        b.set_active(active)
     flags = b.klib_align()
     res, ops = b.download()
     out = capi.results_to_dicts(res, ops)
     assert G.klib_error() == 0
+    if expect_packed is not None:
+        assert G.klib_used_packed_kernels() == expect_packed
     b.close()
     G.close()
     return flags, out
@@ -196,3 +200,108 @@ def test_klib_after_kmer_keeps_results(gpu_ctx):
             assert all(out[i][k] == w[k] for k in KEYS), (i, out[i], w)
     b.close()
     G.close()
+
+
+# ---- the packed two-strand kernels (reads <= 250 bases, every path at least as long as the longest read) -------------------
+
+def _site(rng, n_alt, flank):
+    """LF, n_alt ALT nodes (some equal to each other or to a piece of a flank: ties between paths), RF; paths LF-ALT-RF and
+    LF-RF.  Flanks of `flank` bases keep every path longer than the reads."""
+    lf = fuzzgen.rand_seq(rng, flank + rng.randint(0, 40), rng.choice(["rand", "rand", "rand", "period", "two"]))
+    rf = fuzzgen.rand_seq(rng, flank + rng.randint(0, 40), rng.choice(["rand", "rand", "rand", "period", "two"]))
+    alts = []
+    for _ in range(n_alt):
+        u = rng.random()
+        if alts and u < 0.25:
+            alts.append(rng.choice(alts))  # a second node with the same sequence: equal-score candidates on different paths
+        elif u < 0.4:
+            alts.append(fuzzgen.mutate(rng, rng.choice(alts), sub=0.05, indel=0.02) or "A" if alts else fuzzgen.rand_seq(rng, 30))
+        else:
+            alts.append(fuzzgen.rand_seq(rng, rng.randint(1, 120)))
+    nodes = [lf] + alts + [rf]
+    if rng.random() < 0.3:
+        i = rng.randrange(len(nodes))
+        s = list(nodes[i])
+        for _ in range(rng.randint(1, 3)):
+            s[rng.randrange(len(s))] = "N"
+        nodes[i] = "".join(s)
+    last = len(nodes) - 1
+    paths = [[0, i, last] for i in range(1, last)] + [[0, last]]
+    return nodes, paths
+
+
+def _site_reads(rng, nodes, paths, n, max_len):
+    from oracle.pathalign import _rc
+    reads = []
+    for _ in range(n):
+        u = rng.random()
+        if u < 0.04:
+            r = fuzzgen.rand_seq(rng, rng.randint(1, max_len))  # unrelated
+        else:
+            seq = "".join(nodes[x] for x in rng.choice(paths))
+            L = rng.choice([rng.randint(1, 40), rng.randint(30, max_len), 150, 150, max_len])
+            st = rng.randrange(max(1, len(seq) - L + 1))
+            r = seq[st:st + L]
+            r = fuzzgen.mutate(rng, r, sub=rng.choice([0.0, 0.0, 0.01, 0.05, 0.15]), indel=rng.choice([0.0, 0.0, 0.01, 0.04]),
+                               nrate=rng.choice([0.0, 0.0, 0.02])) or "A"
+            if rng.random() < 0.15 and len(r) > 60:  # a long deletion / insertion inside the read
+                cut = rng.randrange(20, len(r) - 20)
+                r = r[:cut] + (fuzzgen.rand_seq(rng, rng.randint(1, 30)) if rng.random() < 0.5 else "") + r[cut + rng.randint(0, 40):]
+            if rng.random() < 0.1:  # clipped ends
+                r = fuzzgen.rand_seq(rng, rng.randint(1, 25)) + r + fuzzgen.rand_seq(rng, rng.randint(0, 25))
+        r = r[:max_len] or "A"
+        if rng.random() < 0.5:
+            r = _rc(r)
+        if rng.random() < 0.05:
+            r = r.lower()
+        reads.append(r)
+    return reads
+
+
+def _packed_case(seed, n_graphs, reads_per_graph, max_len, flank):
+    chk = checker()
+    rng = random.Random(fuzzgen.salted(seed))
+    graphs, paths, reads, gor, want = [], [], [], [], []
+    for gi in range(n_graphs):
+        nodes, ps = _site(rng, rng.randint(1, 5), flank)
+        rs = _site_reads(rng, nodes, ps, reads_per_graph, max_len)
+        graphs.append((nodes, edges_of(ps)))
+        paths.append(ps)
+        reads.extend(rs)
+        gor.extend([gi] * len(rs))
+        want.extend(chk.align(nodes, ps, rs))
+    return graphs, paths, reads, gor, want
+
+
+@pytest.mark.parametrize("seed,max_len,flank", [(501, 150, 160), (502, 250, 260), (503, 100, 130), (504, 33, 40)])
+def test_klib_packed_kernels_fuzz(gpu_ctx, seed, max_len, flank):
+    """Mixed read lengths (several rows-per-lane classes in one batch), ties between paths, N, lower case, long gaps, clips."""
+    graphs, paths, reads, gor, want = _packed_case(seed, 40, 60, max_len, flank)
+    flags, got = gpu_klib(gpu_ctx, graphs, paths, reads, gor, expect_packed=True)
+    n = check(flags, got, want, reads, "klib-packed-%d" % seed)
+    assert n > 0.85 * len(reads)
+    assert sum(1 for w in want if w["status"] == 2) > 3
+
+
+def test_klib_packed_and_general_kernels_agree(gpu_ctx, monkeypatch):
+    """The same batch through both kernel sets (PG_KLIB_GENERAL forces the general one): identical results."""
+    graphs, paths, reads, gor, want = _packed_case(611, 25, 40, 200, 210)
+    f1, g1 = gpu_klib(gpu_ctx, graphs, paths, reads, gor, expect_packed=True)
+    monkeypatch.setenv("PG_KLIB_GENERAL", "1")
+    f2, g2 = gpu_klib(gpu_ctx, graphs, paths, reads, gor, expect_packed=False)
+    assert list(f1) == list(f2)
+    for a, b, f in zip(g1, g2, f1):
+        if f & 5:
+            assert all(a[k] == b[k] for k in KEYS + ("mapq", "unique", "returned_reverse")), (a, b)
+    check(f1, g1, want, reads, "klib-both")
+
+
+def test_klib_packed_kernels_active_subset(gpu_ctx):
+    """Cascade use at scale: only the reads an earlier stage left are planned into wavefronts; the others keep their flags."""
+    import numpy as np
+    graphs, paths, reads, gor, want = _packed_case(707, 30, 50, 150, 160)
+    rng = random.Random(5)
+    active = np.array([1 if rng.random() < 0.4 else 0 for _ in reads], dtype=np.uint8)
+    flags, got = gpu_klib(gpu_ctx, graphs, paths, reads, gor, expect_packed=True, active=active)
+    idx = [i for i in range(len(reads)) if active[i]]
+    check([flags[i] for i in idx], [got[i] for i in idx], [want[i] for i in idx], [reads[i] for i in idx], "klib-active")

@@ -628,55 +628,95 @@ __global__ __launch_bounds__(64) void pg_klib_finish_kernel(KlibArgs a)
         __threadfence_block();
         __syncthreads();
 
-        // ---- traceback (ksw.c:513-528): lanes 0 / 1 of a read walk candidate A / B
-        if (k < 2)
+        // ---- traceback (ksw.c:513-528).  Eight lanes per candidate (lanes 0-7 of a read: A, 8-15: B) walk it together: in the
+        // H state they look at the next eight cells of the diagonal at once and take the whole run of matches (one round trip
+        // to memory instead of eight); gap states step one cell at a time.  Every lane of the eight follows the same state;
+        // the first one writes the CIGAR.
         {
-            const FinishInfo& f = k == 0 ? gA : gB;
-            if (f.item != PG_NONE)
-            {
-                const uint32_t w = base + (uint32_t)(2 * grp + k);
-                const uint32_t slot_base = w * a.cig_cap;
-                uint32_t* slot = a.cigars + slot_base;
-                const uint8_t* zb = (const uint8_t*)zw;
-                const int ql = f.qe - f.qb + 1, tl = f.te - f.tb + 1;
-                uint32_t n = 0, cur = 0;
-                bool have = false, overflow = false;
-                auto push = [&](uint32_t op, uint32_t len) {
-                    if (have && (cur & 0xfu) == op)
-                        cur += len << 4;
-                    else
-                    {
-                        if (have)
-                        {
-                            if (n < a.cig_cap)
-                                slot[a.cig_cap - 1 - n] = cur;
-                            else
-                                overflow = true;
-                            ++n;
-                        }
-                        cur = (len << 4) | op;
-                        have = true;
-                    }
-                };
-                int i = tl - 1, j = ql - 1;
-                uint32_t which = 0;
-                while (i >= 0 && j >= 0)
+            const int h = k >> 3, d = k & 7;
+            const FinishInfo& f = h == 0 ? gA : gB;
+            const bool live = f.item != PG_NONE;
+            const uint32_t w = base + (uint32_t)(2 * grp + h);
+            const uint32_t slot_base = w * a.cig_cap;
+            uint32_t* slot = a.cigars + slot_base;
+            const uint8_t* zb = (const uint8_t*)zw;
+            const int ql = f.qe - f.qb + 1, tl = f.te - f.tb + 1;
+            uint32_t n = 0, cur = 0;
+            bool have = false, overflow = false;
+            auto push = [&](uint32_t op, uint32_t len) {
+                if (have && (cur & 0xfu) == op)
+                    cur += len << 4;
+                else
                 {
-                    const int kk = j / C, rr = j % C;
-                    const uint32_t b = zb[(((size_t)(i + kk) * ZDW + (size_t)(rr / 2)) * 64 + (size_t)(grp * 16 + kk)) * 4 + (size_t)(k * 2 + (rr & 1))];
-                    if (which == 0)
-                        which = !(b & 2u) ? 2u : (!(b & 1u) ? 1u : 0u);
-                    else if (which == 1)
-                        which = (b & 4u) ? 1u : 0u;
-                    else
-                        which = (b & 8u) ? 2u : 0u;
-                    if (which == 0)
+                    if (have)
+                    {
+                        if (n < a.cig_cap)
+                        {
+                            if (d == 0)
+                                slot[a.cig_cap - 1 - n] = cur;
+                        }
+                        else
+                            overflow = true;
+                        ++n;
+                    }
+                    cur = (len << 4) | op;
+                    have = true;
+                }
+            };
+            auto zbyte = [&](int ci, int cj) -> uint32_t {
+                const int kk = cj / C, rr = cj % C;
+                return zb[(((size_t)(ci + kk) * ZDW + (size_t)(rr / 2)) * 64 + (size_t)(grp * 16 + kk)) * 4 + (size_t)(h * 2 + (rr & 1))];
+            };
+            int i = live ? tl - 1 : -1, j = live ? ql - 1 : -1;
+            uint32_t which = 0;
+            const int sub_shift = grp * 16 + h * 8;
+            while (__any(i >= 0 && j >= 0))
+            {
+                const bool on = i >= 0 && j >= 0;
+                if (which == 0)
+                {
+                    const int ci = i - d, cj = j - d;
+                    const bool inb = on && ci >= 0 && cj >= 0;
+                    const uint32_t b = inb ? zbyte(ci, cj) : 0u;
+                    const unsigned long long bal = __ballot(inb && (b & 3u) == 3u);
+                    const uint32_t m8 = (uint32_t)(bal >> sub_shift) & 0xFFu;
+                    const int m = __builtin_ctz(~m8);  // leading run of matches (0..8)
+                    const uint32_t bm = (uint32_t)__shfl((int)b, (lane & ~7) | (m & 7));  // the cell that ends the run
+                    if (on)
+                    {
+                        if (m > 0)
+                        {
+                            push(0, (uint32_t)m);
+                            i -= m;
+                            j -= m;
+                        }
+                        if (m < 8 && i >= 0 && j >= 0)
+                        {
+                            which = !(bm & 2u) ? 2u : 1u;  // not a match: F == H comes first, else E == H
+                            if (which == 1u)
+                            {
+                                push(2, 1);
+                                --i;
+                            }
+                            else
+                            {
+                                push(1, 1);
+                                --j;
+                            }
+                        }
+                    }
+                }
+                else if (on)
+                {
+                    const uint32_t b = zbyte(i, j);
+                    which = which == 1u ? ((b & 4u) ? 1u : 0u) : ((b & 8u) ? 2u : 0u);
+                    if (which == 0u)
                     {
                         push(0, 1);
                         --i;
                         --j;
                     }
-                    else if (which == 1)
+                    else if (which == 1u)
                     {
                         push(2, 1);
                         --i;
@@ -687,6 +727,9 @@ __global__ __launch_bounds__(64) void pg_klib_finish_kernel(KlibArgs a)
                         --j;
                     }
                 }
+            }
+            if (live && d == 0)
+            {
                 if (i >= 0)
                     push(2, (uint32_t)(i + 1));
                 if (j >= 0)

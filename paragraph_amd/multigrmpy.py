@@ -1,0 +1,442 @@
+"""The reference's entry point over this build's grmpy: variants (VCF or JSON events) + manifest + reference FASTA ->
+graphs -> `bin/grmpy` on the device -> genotypes.json.gz, and for a VCF input genotypes.vcf.gz with the genotypes written
+back into the records.
+
+Follows src/python/bin/multigrmpy.py:39-343 (options, output files, the grmpy command line via a response file) and
+src/python/lib/grm/vcfgraph/vcfupdate.py:30-310 (matching records to genotype documents by GRMPY_ID, else by allele ids;
+GT / DP / FT / AD / ADF / ADR / PL per sample; UNMATCHED / MULTIMATCHED / BP_DEPTH record filters) without pysam:
+the VCF is read and written as text.  Where the reference's output depends on Python set order (the order of FT's filter
+names, the order of added samples) this one is deterministic: UNMATCHED first then the genotype's filters; VCF samples
+first, then manifest samples in manifest order.  One pysam artefact is not reproduced: a sample whose FT was written before
+a longer one of the same record shows as dots there (share/test-data/round-trip-genotyping/expected-vcf-record.txt has
+"...." where the genotype's filter is PASS); here FT is the filter string.
+
+    python -m paragraph_amd.multigrmpy -i candidates.vcf -m samples.txt -r dummy.fa -o out
+"""
+import argparse
+import gzip
+import json
+import os
+import re
+import shlex
+import subprocess
+import sys
+import tempfile
+from collections import OrderedDict
+
+from . import graph_templates, vcf2paragraph
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+GRMPY = os.path.join(_HERE, "bin", "grmpy")
+
+NEW_FORMAT = OrderedDict([
+    ("GT", '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">'),
+    ("FT", '##FORMAT=<ID=FT,Number=1,Type=String,Description="Filter for genotype">'),
+    ("DP", '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="Total filtered read depth used for genotyping.">'),
+    ("AD", '##FORMAT=<ID=AD,Number=R,Type=Integer,Description="Allele depth for each allele, including the reference.">'),
+    ("ADF", '##FORMAT=<ID=ADF,Number=R,Type=Integer,Description="Allele depth on forward strand for each allele, including the reference.">'),
+    ("ADR", '##FORMAT=<ID=ADR,Number=R,Type=Integer,Description="Allele depth on reverse strand for each allele, including the reference.">'),
+    ("PL", '##FORMAT=<ID=PL,Number=G,Type=Integer,Description="Phred-scaled likelihoods for genotypes as defined in the VCF specification">'),
+])
+NEW_FILTERS = [
+    '##FILTER=<ID=BP_DEPTH,Description="One or more breakpoints have abnormal depth">',
+    '##FILTER=<ID=NO_VALID_GT,Description="No valid genotypes from breakpoints">',
+    '##FILTER=<ID=CONFLICT,Description="Breakpoints gave different genotypes">',
+    '##FILTER=<ID=BP_NO_GT,Description="One genotype was missing">',
+    '##FILTER=<ID=NO_READS,Description="No reads could be retrieved for a breakpoint.">',
+    '##FILTER=<ID=DEPTH,Description="Poisson depth filter: observed depth deviates too far from Poisson expectation">',
+    '##FILTER=<ID=UNMATCHED,Description="VCF record could not be matched to a paragraph record.">',
+    '##FILTER=<ID=MULTIMATCHED,Description="VCF record could not be matched to a paragraph record uniquely.">',
+]
+GRMPY_ID_INFO = ('##INFO=<ID=GRMPY_ID,Number=1,Type=String,Description="Graph ID for linking to genotypes.json.gz; '
+                 'matches record.graphinfo.ID in there.">')
+OLD_GT_FORMAT = '##FORMAT=<ID=OLD_GT,Number=1,Type=String,Description="Previous GT which was replaced by paragraph">'
+SAMPLE_KEYS = ("GT", "DP", "FT", "AD", "ADF", "ADR")  # the order vcfupdate.py:195-200 sets them in; PL follows when there is one
+
+
+def _open(path, mode="rt"):
+    return gzip.open(path, mode) if path.endswith(".gz") else open(path, mode)
+
+
+def make_pl_genotypes(ploidy, alleles):
+    """All genotypes of `ploidy` over alleles 0..alleles in the VCF specification's order (vcfupdate.py:30-45)."""
+    out = []
+
+    def walk(p, top, suffix):
+        for allele in range(top + 1):
+            if p == 1:
+                out.append([allele] + suffix)
+            else:
+                walk(p - 1, allele, [allele] + suffix)
+    walk(ploidy, alleles, [])
+    return out
+
+
+def read_grmpy(path):
+    """genotypes.json(.gz) -> {"by_id": {graph id: [documents]}, "by_sequencename": {name: [documents]}} (vcfupdate.py:48-89)."""
+    with _open(path) as f:
+        data = json.load(f)
+    values = [data] if isinstance(data, dict) else data
+    by_id, by_name = OrderedDict(), OrderedDict()
+    for i, d in enumerate(values):
+        info = d.get("graphinfo", {})
+        if info.get("ID"):
+            by_id.setdefault(info["ID"], []).append(i)
+        for name in info.get("sequencenames", []):
+            if i not in by_name.setdefault(name, []):
+                by_name[name].append(i)
+    return {"by_id": {k: [values[i] for i in v] for k, v in by_id.items()},
+            "by_sequencename": {k: [values[i] for i in v] for k, v in by_name.items()}}
+
+
+def _sample_fields(n_alts, doc_sample, allele_map):
+    """FORMAT values of one sample from its genotype document (set_record_for_sample, vcfupdate.py:240-310)."""
+    gt = doc_sample["gt"]
+    filters = []
+    for f in gt["filters"]:
+        if f not in filters:
+            filters.append(f)
+    idx = sorted(allele_map.get(g, -1) for g in gt["GT"].split("/"))
+    out = {}
+    if -1 in idx:  # an allele of the genotype is not one of this record's (or there is no genotype: ".")
+        filters.insert(0, "UNMATCHED")
+        out["GT"] = "."
+    else:
+        out["GT"] = "/".join(str(i) for i in idx)
+    out["FT"] = ",".join(filters)
+    out["DP"] = str(gt.get("num_reads", 0))
+    ad, adf, adr = [0] * (1 + n_alts), [0] * (1 + n_alts), [0] * (1 + n_alts)
+    for name, counts in doc_sample["alleles"].items():
+        i = allele_map[name]  # KeyError: the caller leaves the sample's fields missing, like the reference
+        ad[i] = counts["num_fwd_reads"] + counts["num_rev_reads"]
+        adf[i] = counts["num_fwd_reads"]
+        adr[i] = counts["num_rev_reads"]
+    out["AD"], out["ADF"], out["ADR"] = (",".join(map(str, v)) for v in (ad, adf, adr))
+    if "GL" in gt:
+        order = {str(g): i for i, g in enumerate(make_pl_genotypes(len(idx), n_alts))}
+        pls = [0] * len(order)
+        lowest = None
+        for name, ll in gt["GL"].items():
+            alleles = sorted(allele_map[a] for a in name.split("/"))
+            try:
+                phred = min(round(-10 * ll), 32768)
+            except OverflowError:
+                phred = 32768
+            lowest = phred if lowest is None or phred < lowest else lowest
+            if str(alleles) in order:
+                pls[order[str(alleles)]] = phred
+        out["PL"] = ",".join(str(p - lowest) for p in pls)
+    return out
+
+
+def update_vcf_from_grmpy(in_vcf, grmpy_output, out_vcf, sample_names=None):
+    """Writes `in_vcf` with the genotypes of `grmpy_output` (read_grmpy) per sample (vcfupdate.py:92-237)."""
+    header, columns, lines = [], None, []
+    with _open(in_vcf) as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if line.startswith("##"):
+                header.append(line)
+            elif line.startswith("#"):
+                columns = line.split("\t")
+            elif line:
+                lines.append(line.split("\t"))
+    if columns is None:
+        raise ValueError("%s has no #CHROM line" % in_vcf)
+    vcf_samples = columns[9:]
+    if sample_names is None:
+        sample_names = list(vcf_samples)
+        if not sample_names:
+            raise ValueError("Didn't find sample names in either input or VCF. Paragraph cannot output any genotypes!")
+    samples = list(vcf_samples) + [s for s in OrderedDict.fromkeys(sample_names) if s not in vcf_samples]
+
+    def declared(kind, key):
+        return any(re.match(r"##%s=<ID=%s[,>]" % (kind, re.escape(key)), h) for h in header)
+    if vcf_samples:
+        header.append(OLD_GT_FORMAT)
+    for key, text in NEW_FORMAT.items():
+        if not declared("FORMAT", key):
+            header.append(text)
+    if not declared("INFO", "GRMPY_ID"):
+        header.append(GRMPY_ID_INFO)
+    header.extend(NEW_FILTERS)
+
+    stats = {"matched": 0, "unmatched": 0, "multimatched": 0}
+    with _open(out_vcf, "wt") as out:
+        for h in header:
+            out.write(h + "\n")
+        out.write("\t".join(columns[:8] + ["FORMAT"] + samples) + "\n")
+        for fields in lines:
+            fields = fields + ["."] * (8 - len(fields))
+            chrom, pos, vid, ref, alt = fields[0], int(fields[1]), fields[2], fields[3], fields[4]
+            alts = [a for a in alt.split(",") if a != "."] if alt != "." else []
+            info = OrderedDict()
+            if fields[7] != ".":
+                for item in fields[7].split(";"):
+                    key, eq, value = item.partition("=")
+                    info[key] = value if eq else None
+            record_filters = [] if fields[6] in (".", "PASS") else fields[6].split(";")
+            var_id = vid if vid not in (".", "") else "%s:%d-1" % (chrom, pos)  # VCFGraph.generate_variant_id, a fresh count per record
+            allele_ids = ["%s:%d" % (var_id, n) for n in range(1 + len(alts))]
+
+            docs = []
+            if info.get("GRMPY_ID") in grmpy_output["by_id"]:
+                candidates = [grmpy_output["by_id"][info["GRMPY_ID"]]]
+            else:
+                candidates = [grmpy_output["by_sequencename"][a] for a in allele_ids if a in grmpy_output["by_sequencename"]]
+            for group in candidates:
+                for d in group:
+                    if not any(d is x for x in docs):
+                        docs.append(d)
+
+            def write(sample_columns=None, keys=None):
+                flt = ";".join(record_filters) if record_filters else fields[6]
+                inf = ";".join(k if v is None else "%s=%s" % (k, v) for k, v in info.items()) or "."
+                row = fields[:6] + [flt, inf]
+                if keys:
+                    row += [":".join(keys)] + sample_columns
+                out.write("\t".join(row) + "\n")
+
+            if len(docs) != 1:
+                if not docs:
+                    info["GRMPY_ID"] = "UNMATCHED"
+                    record_filters.append("UNMATCHED")
+                    stats["unmatched"] += 1
+                else:
+                    info["GRMPY_ID"] = "MULTIPLE:" + ",".join(d["graphinfo"]["ID"] for d in docs if d.get("graphinfo", {}).get("ID"))
+                    record_filters.append("MULTIMATCHED")
+                    stats["multimatched"] += 1
+                # (the reference writes these records without touching their sample columns; samples added by the manifest are missing)
+                if len(fields) > 9:
+                    keys = fields[8].split(":")
+                    write(fields[9:9 + len(vcf_samples)] + ["."] * (len(samples) - len(vcf_samples)), keys)
+                else:
+                    write()
+                continue
+            stats["matched"] += 1
+            doc = docs[0]
+            info["GRMPY_ID"] = doc.get("graphinfo", {}).get("ID", "NOID")
+            allele_map = {"REF": 0, "ALT": 1}
+            for i, a in enumerate(allele_ids):
+                allele_map[a] = i
+
+            old_keys = fields[8].split(":") if len(fields) > 9 else []
+            keys = list(old_keys)
+            values = {}
+            n_bp_depth = 0
+            for si, sample in enumerate(samples):
+                v = {}
+                if vcf_samples:
+                    if si < len(vcf_samples) and len(fields) > 9 + si:
+                        v.update(zip(old_keys, fields[9 + si].split(":")))
+                        gt_old = v.get("GT", ".")
+                        v["OLD_GT"] = "/".join(sorted(re.split(r"[/|]", gt_old)))
+                    else:
+                        v["OLD_GT"] = "."
+                for key in SAMPLE_KEYS:
+                    v[key] = "."
+                v["AD"] = v["ADF"] = v["ADR"] = ",".join(["."] * (1 + len(alts)))
+                if sample in doc["samples"]:
+                    try:
+                        v.update(_sample_fields(len(alts), doc["samples"][sample], allele_map))
+                    except KeyError:
+                        sys.stderr.write("VCF key error for sample %s at %s_%d\n" % (sample, chrom, pos))
+                    else:
+                        if "BP_DEPTH" in v["FT"] or "BP_NO_GT" in v["FT"]:
+                            n_bp_depth += 1
+                values[sample] = v
+            if n_bp_depth * 2 > len(doc["samples"]):
+                record_filters.append("BP_DEPTH")
+            for key in (("OLD_GT",) if vcf_samples else ()) + SAMPLE_KEYS:
+                if key not in keys:
+                    keys.append(key)
+            if any("PL" in v for v in values.values()) and "PL" not in keys:
+                keys.append("PL")
+            n_gt = {}
+            cols = []
+            for sample in samples:
+                v = values[sample]
+                if "PL" in keys and "PL" not in v:
+                    # a vector nobody set: one missing value per genotype of a diploid call (what the reference's writer prints)
+                    n = n_gt.setdefault(len(alts), len(make_pl_genotypes(2, len(alts))))
+                    v["PL"] = ",".join(["."] * n)
+                cols.append(":".join(v.get(k, ".") or "." for k in keys))
+            write(cols, keys)
+    return stats
+
+
+def manifest_samples(path):
+    """Checks the manifest's header the way multigrmpy.py:239-259 does and returns the sample ids."""
+    allowed = ("id", "path", "idxdepth", "depth", "read length", "sex", "depth variance", "depth sd")
+    names, id_index = [], -1
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip()
+            if line.startswith("#"):
+                line = line[1:]
+            fields = re.split("\t|,", line.strip() if id_index == -1 else line)
+            if id_index == -1:
+                for field in fields:
+                    if field not in allowed:
+                        raise ValueError("Illegal header name %s. Allowed headers:\n%s" % (field, ",".join(allowed)))
+                if "id" not in fields or "path" not in fields:
+                    raise ValueError('Missing header "id" or "path" in manifest')
+                if "idxdepth" not in fields and not ("depth" in fields and "read length" in fields):
+                    raise ValueError('Missing header "idxdepth", or "depth" and "read length" in manifest.')
+                id_index = fields.index("id")
+                continue
+            if line:
+                names.append(fields[id_index])
+    return names
+
+
+def _vcf_with_ids(args, blocks_ids):
+    """variants.vcf.gz: the input records with their graph's id in INFO/GRMPY_ID (parse_vcf_lines, vcf2paragraph/__init__.py:178-266)."""
+    path = os.path.join(args.output, "variants.vcf.gz")
+    ids = iter(blocks_ids)
+    with _open(args.input) as f, gzip.open(path, "wt") as out:
+        declared = False
+        for line in f:
+            if line.startswith("##"):
+                declared = declared or line.startswith("##INFO=<ID=GRMPY_ID,")
+                out.write(line)
+            elif line.startswith("#"):
+                if not declared:
+                    out.write(GRMPY_ID_INFO + "\n")
+                out.write(line)
+            elif line.strip():
+                fields = line.rstrip("\n").split("\t")
+                fields += ["."] * (8 - len(fields))
+                items = [] if fields[7] == "." else [i for i in fields[7].split(";") if not i.startswith("GRMPY_ID=")]
+                fields[7] = ";".join(items + ["GRMPY_ID=" + next(ids)])
+                out.write("\t".join(fields) + "\n")
+    return path
+
+
+def load_graph_description(args):
+    """Graph JSON files for grmpy, one per event (multigrmpy.py:39-120)."""
+    name = args.input[:-3] if args.input.endswith(".gz") else args.input
+    extension = os.path.splitext(name)[1]
+    if extension == ".vcf":
+        events = vcf2paragraph.convert_vcf_to_graphs(
+            args.input, args.reference, read_length=args.read_length, max_ref_node_length=args.max_ref_node_length,
+            graph_type=args.graph_type, split_type=args.split_type, retrieve_reference_sequence=args.retrieve_reference_sequence,
+            alt_splitting=args.alt_splitting, alt_paths=True, ins_info_key=args.ins_info_key)
+        import hashlib
+        with open(args.input, "rb") as f:
+            vcf_id = os.path.basename(args.input) + "@" + hashlib.sha256(f.read()).hexdigest()
+        _, records = vcf2paragraph.read_vcf(args.input)
+        blocks, ids = vcf2paragraph.split_records(records, vcf_id, args.read_length, args.split_type)
+        assert [e["ID"] for e in events] == ids
+        _vcf_with_ids(args, [bid for block, bid in zip(blocks, ids) for _ in block])
+        with gzip.open(os.path.join(args.output, "variants.json.gz"), "wt") as f:
+            json.dump(events, f, sort_keys=True, indent=4, separators=(",", ": "))
+    elif extension == ".json":
+        with _open(args.input) as f:
+            events = json.load(f)
+        for event in events:
+            if "graph" not in event and "nodes" not in event and "edges" not in event:
+                event["type"], event["graph"] = graph_templates.make_graph(event)
+    else:
+        raise ValueError("Unknown input file extension %s for %s. Only VCF or JSON is allowed!" % (extension, args.input))
+    paths = []
+    for n, event in enumerate(events):
+        graph = event.get("graph", event)
+        if "graph" in event and not graph.get("ID"):
+            graph["ID"] = event.get("ID") or "%s:%d" % (os.path.basename(args.input), n)
+        with tempfile.NamedTemporaryFile(dir=args.scratch_dir, mode="wt", suffix=".json", delete=False) as f:
+            json.dump(graph, f, indent=4, separators=(",", ": "))
+            paths.append(f.name)
+    return paths
+
+
+def make_argument_parser():
+    p = argparse.ArgumentParser("multigrmpy")
+    p.add_argument("-i", "--input", required=True, help="Input file of variants. Must be either JSON or VCF.")
+    p.add_argument("-m", "--manifest", required=True, help="Manifest of samples with path and bam stats.")
+    p.add_argument("-o", "--output", required=True, help="Output directory.")
+    p.add_argument("-r", "--reference-sequence", dest="reference", required=True, help="Reference genome fasta file.")
+    p.add_argument("--threads", "-t", type=int, default=os.cpu_count() or 1, help="Host threads of grmpy.")
+    p.add_argument("--keep-scratch", action="store_true", default=None, help="Do not delete temp files.")
+    p.add_argument("--scratch-dir", default=None, help="Directory for temp files")
+    p.add_argument("--grmpy", default=GRMPY, help="Path to the grmpy executable")
+    p.add_argument("--devices", default=None, help="GPUs grmpy uses (its --devices: ordinals or 'all')")
+    p.add_argument("--logfile", default=None)
+    p.add_argument("--graph-sequence-matching", default=False, help="Use graph aligner.")
+    p.add_argument("--klib-sequence-matching", default=False, help="Use klib smith waterman aligner.")
+    p.add_argument("--kmer-sequence-matching", default=False, help="Use kmer aligner.")
+    p.add_argument("--bad-align-uniq-kmer-len", default=0, help="Kmer length for uniqueness check during read filtering.")
+    p.add_argument("--no-alt-splitting", dest="alt_splitting", default=True, action="store_false",
+                   help="Keep long insertion sequences in the graph rather than trimming them at the read / padding length.")
+    p.add_argument("-A", "--write-alignments", action="store_true", default=False, help="(not built: refused by grmpy)")
+    p.add_argument("--infer-read-haplotypes", action="store_true", default=False, help="(not built: refused by grmpy)")
+    g = p.add_mutually_exclusive_group()
+    g.add_argument("--verbose", action="store_true", default=False)
+    g.add_argument("--quiet", action="store_true", default=False)
+    g.add_argument("--debug", action="store_true", default=False)
+    p.add_argument("-G", "--genotyping-parameters", default="", help="JSON string or file with genotyping model parameters.")
+    p.add_argument("-M", "--max-reads-per-event", type=int, default=0, help="Maximum number of reads to process for a single event.")
+    p.add_argument("--vcf-split", default="lines", dest="split_type", choices=["lines", "full", "by_id", "superloci"])
+    p.add_argument("-p", "--read-length", type=int, default=150, help="Read length: reference padding of the graphs.")
+    p.add_argument("-l", "--max-ref-node-length", type=int, default=300, help="Maximum length of reference nodes before they get padded and truncated.")
+    p.add_argument("--retrieve-reference-sequence", action="store_true", default=False)
+    p.add_argument("--graph-type", choices=["alleles", "haplotypes"], default="alleles")
+    p.add_argument("--ins-info-key", default="SEQ")
+    return p
+
+
+def run(args):
+    os.makedirs(args.output, exist_ok=True)
+    if args.scratch_dir:
+        os.makedirs(args.scratch_dir, exist_ok=True)
+    samples = manifest_samples(args.manifest)
+    result_json = os.path.join(args.output, "genotypes.json.gz")
+    graph_files = load_graph_description(args)
+    response = None
+    try:
+        words = ["-r", args.reference, "-m", args.manifest, "-o", result_json, "-z"]
+        if args.genotyping_parameters:
+            words += ["-G", args.genotyping_parameters]
+        if args.max_reads_per_event:
+            words += ["-M", str(args.max_reads_per_event)]
+        if args.threads >= 1:
+            words += ["-t", str(args.threads)]
+        for flag in ("graph_sequence_matching", "klib_sequence_matching", "kmer_sequence_matching"):
+            if getattr(args, flag):
+                words += ["--" + flag.replace("_", "-"), str(getattr(args, flag))]
+        if int(args.bad_align_uniq_kmer_len):
+            words += ["--bad-align-uniq-kmer-len", str(args.bad_align_uniq_kmer_len)]
+        if args.write_alignments:
+            words += ["--alignment-output-folder", os.path.join(args.output, "alignments")]
+        if args.infer_read_haplotypes:
+            words += ["--infer-read-haplotypes"]
+        if args.devices:
+            words += ["--devices", args.devices]
+        words += ["--log-level=" + ("info" if args.verbose else "error" if args.quiet else "debug" if args.debug else "warning")]
+        words += ["--log-file", os.path.join(args.output, "grmpy.log"), "--log-async", "no", "-g"]
+        text = " ".join(shlex.quote(w) for w in words) + "".join("\n" + shlex.quote(g) for g in graph_files)
+        with tempfile.NamedTemporaryFile(dir=args.scratch_dir, mode="wt", suffix=".txt", delete=False) as f:
+            f.write(text)
+            response = f.name
+        subprocess.check_call(shlex.split(args.grmpy) + ["--response-file=" + response], stderr=subprocess.STDOUT)
+    finally:
+        if not args.keep_scratch:
+            for p in graph_files + ([response] if response else []):
+                try:
+                    os.remove(p)
+                except OSError:
+                    pass
+    name = args.input[:-3] if args.input.endswith(".gz") else args.input
+    if name.endswith("vcf"):
+        with_ids = os.path.join(args.output, "variants.vcf.gz")
+        source = with_ids if os.path.isfile(with_ids) else args.input
+        return update_vcf_from_grmpy(source, read_grmpy(result_json), os.path.join(args.output, "genotypes.vcf.gz"), samples)
+    return None
+
+
+def main(argv=None):
+    run(make_argument_parser().parse_args(argv))
+
+
+if __name__ == "__main__":
+    main()

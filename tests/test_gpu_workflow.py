@@ -336,3 +336,47 @@ def test_config1_round_trip_from_the_vcf(tmp_path):
             alleles = gt["GT"].split("/")
             assert len(alleles) == 2 and all(a.endswith(rid + ":1") or (rid + ":1") in a.split(",") for a in alleles), (rid, sample, gt)  # 1/1
             assert gt["num_reads"] == int(w["DP"]), (rid, sample, gt, w)
+
+
+def test_config1_multigrmpy_vcf_to_vcf(tmp_path):
+    """BASELINE configs[0] through the reference's entry point (README: `multigrmpy.py -i candidates.vcf -m samples.txt -r dummy.fa
+    -o test`, "the last 3 lines of genotypes.vcf.gz will be the same as in expected-vcf-record.txt"): VCF -> graphs -> bin/grmpy
+    on the device -> genotypes.json.gz -> genotypes.vcf.gz.  One documented difference (paragraph_amd/multigrmpy.py): the
+    reference's writer shows sample1's FT of the first record as dots, here it is the genotype's filter."""
+    import gzip
+    import json
+    from paragraph_amd import multigrmpy
+    d = os.path.join(ROOT, "tests", "golden", "sites", "round-trip")
+    out = tmp_path / "out"
+    args = multigrmpy.make_argument_parser().parse_args([
+        "-i", os.path.join(d, "candidates.vcf"), "-m", os.path.join(d, "samples.txt"), "-r", os.path.join(d, "dummy.fa"),
+        "-o", str(out), "-t", "2", "-M", "10000", "--graph-sequence-matching", "1", "-l", "1000", "--scratch-dir", str(tmp_path / "scratch")])
+    cwd = os.getcwd()
+    os.chdir(d)  # the manifest names its BAM files relative to itself
+    try:
+        stats = multigrmpy.run(args)
+    finally:
+        os.chdir(cwd)
+    assert stats == {"matched": 2, "unmatched": 0, "multimatched": 0}
+    assert sorted(os.listdir(out)) == ["genotypes.json.gz", "genotypes.vcf.gz", "grmpy.log", "variants.json.gz", "variants.vcf.gz"] or \
+        sorted(os.listdir(out)) == ["genotypes.json.gz", "genotypes.vcf.gz", "variants.json.gz", "variants.vcf.gz"]
+    got = [l.rstrip("\n") for l in gzip.open(out / "genotypes.vcf.gz", "rt")][-3:]
+    want = [l.rstrip("\n") for l in open(os.path.join(d, "expected-vcf-record.txt"))]
+    first = want[1].split("\t")
+    assert first[9].split(":")[2] == "...."
+    ft = got[1].split("\t")[9].split(":")[2]
+    assert ft in ("PASS", "GQ")
+    want[1] = want[1].replace("1/1:2:....:", "1/1:2:%s:" % ft)
+    assert got == want
+    with gzip.open(out / "genotypes.json.gz", "rt") as f:
+        docs = {doc["graphinfo"]["ID"]: doc for doc in json.load(f)}
+    # the reference's own check of this run (src/python/test/test_multigrmpy.py:100-108) names graphs by event id; with a VCF
+    # input the graph id is the GRMPY_ID and the called allele the record's first ALT
+    for line in got[1:]:
+        f = line.split("\t")
+        doc = docs[f[7].split("=", 1)[1]]
+        called = "sample1" if f[2] == "test-ins" else "sample2"
+        other = "sample2" if called == "sample1" else "sample1"
+        assert doc["samples"][called]["gt"]["GT"] == "%s:1/%s:1" % (f[2], f[2])
+        assert doc["samples"][other]["gt"]["GT"] == "."
+    assert not os.listdir(tmp_path / "scratch")

@@ -305,3 +305,21 @@ def test_klib_packed_kernels_active_subset(gpu_ctx):
     flags, got = gpu_klib(gpu_ctx, graphs, paths, reads, gor, expect_packed=True, active=active)
     idx = [i for i in range(len(reads)) if active[i]]
     check([flags[i] for i in idx], [got[i] for i in idx], [want[i] for i in idx], [reads[i] for i in idx], "klib-active")
+
+
+def test_klib_config2_8192_reads(gpu_ctx):
+    """The stage probe's workload (BASELINE configs[1] reads, the two paths of the DEL graph) against the reference's ksw.c:
+    every read's status, position, CIGAR, score, strand and MAPQ."""
+    from paragraph_amd import synth
+    chk = checker()
+    n = 8192
+    site, arr = synth.config2_reads_packed(n, read_len=150, seed=7)
+    raw = arr.tobytes()
+    reads = [raw[i * 150:(i + 1) * 150].decode() for i in range(n)]
+    ps = [[0, 1, 2], [0, 2]]
+    want = []
+    for i in range(0, n, 2048):
+        want.extend(chk.align(site.seqs, ps, reads[i:i + 2048]))
+    flags, got = gpu_klib(gpu_ctx, [(site.seqs, site.edges)], [ps], reads, None, expect_packed=True)
+    mapped = check(flags, got, want, reads, "klib-config2")
+    assert mapped > 0.99 * n

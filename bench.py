@@ -121,6 +121,16 @@ def _run_procs(chk, site, off, bases, res, cig, lo, hi, procs):
         raise RuntimeError("%d CPU baseline workers failed" % bad)
 
 
+def _cpu_quota():
+    """CPUs the cgroup lets this process use at once (cpu.max of cgroup v2: "<quota> <period>" or "max"), or None."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_leg_main(args):
     """Times the CPU checker on a bounded sample of the same reads, two ways:
        (a) chunk-per-thread in one process -- how the reference parallelises (Align.cpp:114-156; gssw allocates and zeroes
@@ -140,6 +150,7 @@ def cpu_leg_main(args):
     else:
         chk, kind, label = orc.PortOracle(), "port", "plain-C restatement (oracle/pg_oracle.c)"
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = _cpu_quota()  # a container may see every CPU of the host and still be held to a few of them
     res = _shared_array((n_all,), orc.RESULT_NP)
     cig = _shared_array((n_all, CIGAR_STRIDE), np.uint8)
     chk.align_into(site.seqs, site.edges, off[:65], bases, res[:64], cig[:64], threads=1)  # warm-up
@@ -160,7 +171,10 @@ def cpu_leg_main(args):
         t *= 2
     # (b) one process per chunk
     best_p, best_p_rate = 1, 0.0
-    for p in sorted({ncpu, max(1, ncpu // 2)}, reverse=True):
+    counts = {ncpu, max(1, ncpu // 2)}
+    if quota and quota < ncpu:
+        counts |= {max(1, int(round(quota))), max(1, int(round(2 * quota)))}
+    for p in sorted(counts, reverse=True):
         n = min(n_all, per_worker * p, 200000)
         t0 = time.perf_counter()
         _run_procs(chk, site, off, bases, res, cig, 0, n, p)
@@ -192,11 +206,11 @@ def cpu_leg_main(args):
            "mode": "one process per chunk" if use_procs else "threads of one process",
            "threads_one_process": {"threads": best_t, "reads_per_s": best_t_rate},
            "process_per_chunk": {"processes": best_p, "reads_per_s": best_p_rate},
-           "probes": probes, "host_cpus": ncpu,
+           "probes": probes, "host_cpus": ncpu, "cpu_quota_cores": quota,
            "sample": "the first %d of the same config-2 reads, %s, %s on %d of %d host CPUs (one aligner per contiguous "
-                     "chunk, Align.cpp:114-156; probes with %d reads per worker), %.1f s"
+                     "chunk, Align.cpp:114-156; probes with %d reads per worker), %.1f s%s"
                      % (done, label, "one forked process per chunk" if use_procs else "threads of one process", workers, ncpu,
-                        per_worker, spent)}
+                        per_worker, spent, "; the cgroup holds the process to %.0f CPUs" % quota if quota and quota < ncpu else "")}
     print(json.dumps(out))
 
 

@@ -33,6 +33,7 @@ public:
 
     void setRegion(const std::string& region_text) override;
     bool getAlign(Read& record) override;
+    bool getAlignLean(LeanAlign& record) override;
     bool getAlignedMate(const Read& read, Read& mate) override;
 
     // from the BAM header

@@ -15,7 +15,9 @@
 #include <mutex>
 #include <sstream>
 #include <stdexcept>
+#include <string_view>
 #include <unordered_map>
+#include <vector>
 
 #include "common/BamReader.hh"
 #include "common/Fasta.hh"
@@ -490,6 +492,7 @@ struct BamReader::Impl
     void loadIndex(BamMeta& m);
     bool readRecord(BamRecord& rec);        // fixed fields + end_pos; valid until the next call
     void decodeText(BamRecord& rec) const;  // name / bases / quals of the record read last
+    BamRecord lean_record;                  // getAlignLean's record (its text fields stay in `scratch`)
     RegionCursor query(int32_t tid, int64_t beg, int64_t end) const;
     bool next(RegionCursor& cur, BamRecord& rec);
 };
@@ -876,6 +879,89 @@ bool BamReader::getAlign(Read& read)
     return false;
 }
 
+bool BamReader::getAlignLean(LeanAlign& out)
+{
+    if (!impl_->cursor.valid)
+        throw std::logic_error("Error: no region has been set on " + impl_->path);
+    BamRecord& rec = impl_->lean_record;
+    while (impl_->next(impl_->cursor, rec))
+    {
+        if (rec.flag & (samflag::kSupplementary | samflag::kSecondary))
+            continue;
+        const unsigned char* p = impl_->scratch.data();
+        out.name = (const char*)p + rec.name_at;
+        out.name_len = rec.name_len;
+        out.n_bases = rec.seq_len;
+        out.packed_bases = p + rec.seq_at;
+        out.text_bases = nullptr;
+        out.chrom_id = rec.tid;
+        out.pos = rec.pos;
+        out.mate_chrom_id = rec.mtid;
+        out.mate_pos = rec.mpos;
+        out.is_mapped = (rec.flag & samflag::kUnmapped) == 0;
+        out.is_first_mate = (rec.flag & samflag::kFirstInPair) != 0;
+        out.is_mate_mapped = (rec.flag & samflag::kMateUnmapped) == 0;
+        out.is_reverse_strand = (rec.flag & samflag::kReverse) != 0;
+        out.is_mate_reverse_strand = (rec.flag & samflag::kMateReverse) != 0;
+        return true;
+    }
+    return false;
+}
+
+bool ReadReader::getAlignLean(LeanAlign& out)
+{
+    if (!getAlign(lean_scratch_))
+        return false;
+    Read const& r = lean_scratch_;
+    out.name = r.fragment_id().data();
+    out.name_len = (uint32_t)r.fragment_id().size();
+    out.n_bases = (uint32_t)r.bases().size();
+    out.packed_bases = nullptr;
+    out.text_bases = r.bases().data();
+    out.chrom_id = r.chrom_id();
+    out.pos = r.pos();
+    out.mate_chrom_id = r.mate_chrom_id();
+    out.mate_pos = r.mate_pos();
+    out.is_mapped = r.is_mapped();
+    out.is_first_mate = r.is_first_mate();
+    out.is_mate_mapped = r.is_mate_mapped();
+    out.is_reverse_strand = r.is_reverse_strand();
+    out.is_mate_reverse_strand = r.is_mate_reverse_strand();
+    return true;
+}
+
+void LeanAlign::appendBasesTo(std::string& out) const
+{
+    if (text_bases)
+    {
+        out.append(text_bases, n_bases);
+        return;
+    }
+    static const struct Pairs
+    {
+        char text[256][2];
+        Pairs()
+        {
+            static const char kBases[] = "=ACMGRSVTWYHKDBN";
+            for (int b = 0; b < 256; ++b)
+            {
+                text[b][0] = kBases[b >> 4];
+                text[b][1] = kBases[b & 0xF];
+            }
+        }
+    } pairs;
+    const size_t at = out.size();
+    out.resize(at + n_bases);
+    char* dst = n_bases ? &out[at] : nullptr;
+    for (uint32_t i = 0; i + 1 < n_bases; i += 2)
+    {
+        dst[i] = pairs.text[packed_bases[i / 2]][0];
+        dst[i + 1] = pairs.text[packed_bases[i / 2]][1];
+    }
+    if (n_bases & 1)
+        dst[n_bases - 1] = pairs.text[packed_bases[n_bases / 2]][0];
+}
+
 bool BamReader::getAlignedMate(const Read& read, Read& mate)
 {
     const int32_t tid = read.is_mate_mapped() ? read.mate_chrom_id() : read.chrom_id();
@@ -1061,6 +1147,29 @@ void PackedSite::clear()
 
 namespace
 {
+// fragment ids of one site, kept once: the maps below hold views into it (blocks never move)
+class NameArena
+{
+public:
+    std::string_view keep(const char* p, size_t n)
+    {
+        if (blocks_.empty() || used_ + n > kBlock)
+        {
+            blocks_.emplace_back(new char[std::max<size_t>(kBlock, n)]);
+            used_ = 0;
+        }
+        char* dst = blocks_.back().get() + used_;
+        memcpy(dst, p, n);
+        used_ += n;
+        return std::string_view(dst, n);
+    }
+
+private:
+    enum : size_t { kBlock = 16384 };
+    std::vector<std::unique_ptr<char[]>> blocks_;
+    size_t used_ = 0;
+};
+
 // the reads of one target region while it is scanned: one slot pair per fragment id, like common::ReadPairs
 struct RegionReads
 {
@@ -1070,28 +1179,31 @@ struct RegionReads
         int32_t chrom_id, pos, mate_chrom_id, mate_pos;
         uint8_t flags;
     };
-    std::map<std::string, std::array<int32_t, 2>> slots;  // fragment id -> index into `kept` of first / second mate, -1 = empty
+    typedef std::array<int32_t, 2> Slots;  // index into `kept` of first / second mate, -1 = empty
+    std::unordered_map<std::string_view, Slots> slots;
     std::vector<Kept> kept;
     std::string bases;
     int num_reads = 0;
+    NameArena& names;
+    explicit RegionReads(NameArena& arena) : names(arena) {}
 
-    void add(common::Read const& r)
+    void add(common::LeanAlign const& r)
     {
-        auto it = slots.find(r.fragment_id());
+        auto it = slots.find(std::string_view(r.name, r.name_len));
         if (it == slots.end())
-            it = slots.emplace(r.fragment_id(), std::array<int32_t, 2>{ -1, -1 }).first;
-        int32_t& slot = it->second[r.is_first_mate() ? 0 : 1];
+            it = slots.emplace(names.keep(r.name, r.name_len), Slots{ -1, -1 }).first;
+        int32_t& slot = it->second[r.is_first_mate ? 0 : 1];
         Kept k;
         k.base_begin = (uint32_t)bases.size();
-        k.base_len = (uint32_t)r.bases().size();
-        bases += r.bases();
-        k.chrom_id = r.chrom_id();
-        k.pos = r.pos();
-        k.mate_chrom_id = r.mate_chrom_id();
-        k.mate_pos = r.mate_pos();
-        k.flags = (uint8_t)((r.is_reverse_strand() ? PackedSite::REVERSE : 0) | (r.is_first_mate() ? PackedSite::FIRST_MATE : 0)
-                            | (r.is_mapped() ? PackedSite::MAPPED : 0) | (r.is_mate_mapped() ? PackedSite::MATE_MAPPED : 0)
-                            | (r.is_mate_reverse_strand() ? PackedSite::MATE_REVERSE : 0));
+        k.base_len = r.n_bases;
+        r.appendBasesTo(bases);
+        k.chrom_id = r.chrom_id;
+        k.pos = r.pos;
+        k.mate_chrom_id = r.mate_chrom_id;
+        k.mate_pos = r.mate_pos;
+        k.flags = (uint8_t)((r.is_reverse_strand ? PackedSite::REVERSE : 0) | (r.is_first_mate ? PackedSite::FIRST_MATE : 0)
+                            | (r.is_mapped ? PackedSite::MAPPED : 0) | (r.is_mate_mapped ? PackedSite::MATE_MAPPED : 0)
+                            | (r.is_mate_reverse_strand ? PackedSite::MATE_REVERSE : 0));
         if (slot < 0)
         {
             // an empty-sequence record does not make a slot "initialized" (Read::is_initialized), but a later one replaces it
@@ -1109,41 +1221,74 @@ struct RegionReads
             kept[(size_t)slot] = k;
         }
     }
+    void add(common::Read const& r)
+    {
+        common::LeanAlign l;
+        l.name = r.fragment_id().data();
+        l.name_len = (uint32_t)r.fragment_id().size();
+        l.n_bases = (uint32_t)r.bases().size();
+        l.text_bases = r.bases().data();
+        l.chrom_id = r.chrom_id();
+        l.pos = r.pos();
+        l.mate_chrom_id = r.mate_chrom_id();
+        l.mate_pos = r.mate_pos();
+        l.is_mapped = r.is_mapped();
+        l.is_first_mate = r.is_first_mate();
+        l.is_mate_mapped = r.is_mate_mapped();
+        l.is_reverse_strand = r.is_reverse_strand();
+        l.is_mate_reverse_strand = r.is_mate_reverse_strand();
+        add(l);
+    }
+    // (fragment id, slots) in the order common::ReadPairs (a std::map by fragment id) walks them
+    std::vector<std::pair<std::string_view, Slots>> ordered() const
+    {
+        std::vector<std::pair<std::string_view, Slots>> v(slots.begin(), slots.end());
+        std::sort(v.begin(), v.end(), [](auto const& a, auto const& b) { return a.first < b.first; });
+        return v;
+    }
 };
+
+// common::isReadOrItsMateInRegion on a lean record
+bool inRegion(common::LeanAlign const& r, common::Region const& region)
+{
+    const int64_t len = (int64_t)r.n_bases;
+    auto touches = [&](int64_t pos) { return !(pos > region.end || pos + len < region.start); };
+    if (touches(r.pos))
+        return true;
+    return r.chrom_id == r.mate_chrom_id && touches(r.mate_pos);
+}
 }  // namespace
 
 void extractPacked(
     common::ReadReader& reader, std::list<common::Region> const& target_regions, int max_num_reads, unsigned longest_alt_insertion,
     PackedSite& site, int avr_fragment_length)
 {
-    std::unordered_map<std::string, uint32_t> fragment_of;  // across the regions of this site, seeded with what the site holds
-    uint32_t next_fragment = 0;
-    for (uint32_t f : site.fragment)
-        next_fragment = std::max(next_fragment, f + 1);
-    if (next_fragment != 0)
+    if (!site.fragment.empty())
         throw std::logic_error("extractPacked: the site must be empty (fragment ids are assigned by name)");
-    common::Read read;
+    NameArena names;
+    std::unordered_map<std::string_view, uint32_t> fragment_of;  // across the regions of this site
+    common::LeanAlign rec;
     for (common::Region const& region : target_regions)
     {
         reader.setRegion(region.getExtendedRegion((int64_t)avr_fragment_length * 3));
-        RegionReads pairs;
+        RegionReads pairs(names);
         unsigned total_length = 0, counted = 0;
-        while (pairs.num_reads != max_num_reads && reader.getAlign(read))
+        while (pairs.num_reads != max_num_reads && reader.getAlignLean(rec))
         {
-            if (!read.bases().empty())
+            if (rec.n_bases)
             {
-                total_length += (unsigned)read.bases().length();
+                total_length += rec.n_bases;
                 ++counted;
             }
-            if (common::isReadOrItsMateInRegion(read, region))
-                pairs.add(read);
+            if (inRegion(rec, region))
+                pairs.add(rec);
         }
         const unsigned read_length = counted ? total_length / counted : 0;
         if (max_num_reads != pairs.num_reads && read_length <= longest_alt_insertion * 2)
         {
             // far-away mates of half-filled fragments (recoverMissingMates): rare, so a temporary Read per lookup is fine
             std::vector<common::Read> lonely;
-            for (auto const& kv : pairs.slots)
+            for (auto const& kv : pairs.ordered())
             {
                 const int32_t a = kv.second[0], b = kv.second[1];
                 const bool has_a = a >= 0 && pairs.kept[(size_t)a].base_len > 0, has_b = b >= 0 && pairs.kept[(size_t)b].base_len > 0;
@@ -1153,7 +1298,7 @@ void extractPacked(
                 if (k.chrom_id == k.mate_chrom_id && std::abs(k.pos - k.mate_pos) < 1000)
                     continue;
                 common::Read have;
-                have.setCoreInfo(kv.first, pairs.bases.substr(k.base_begin, k.base_len), "");
+                have.setCoreInfo(std::string(kv.first), pairs.bases.substr(k.base_begin, k.base_len), "");
                 have.set_is_first_mate((k.flags & PackedSite::FIRST_MATE) != 0);
                 have.set_is_mate_mapped((k.flags & PackedSite::MATE_MAPPED) != 0);
                 have.set_chrom_id(k.chrom_id);
@@ -1170,7 +1315,7 @@ void extractPacked(
                     pairs.add(mate);
             }
         }
-        for (auto const& kv : pairs.slots)
+        for (auto const& kv : pairs.ordered())
         {
             for (int32_t slot : kv.second)
             {

@@ -52,6 +52,8 @@ int main(int argc, char** argv)
             const auto t0 = std::chrono::steady_clock::now();
             genotypes = grmpy::genotypeGraphs(parameters, graphs, argv[1], samples, "");
             const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (prof_path)
+                e2eprof::enable(false);
             common::Json run = common::Json::object();
             run["total_s"] = total;
             {

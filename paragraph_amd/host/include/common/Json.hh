@@ -16,17 +16,51 @@ public:
     typedef std::map<std::string, Json> Members;
     typedef std::vector<Json> Elements;
 
-    Json() = default;
-    Json(bool v) : kind_(BOOL), u_(v) {}
-    Json(int v) : kind_(INT), i_(v) {}
-    Json(int64_t v) : kind_(INT), i_(v) {}
-    Json(unsigned v) : kind_(UINT), u_(v) {}
-    Json(uint64_t v) : kind_(UINT), u_(v) {}
-    Json(double v) : kind_(REAL), d_(v) {}
-    Json(const char* v) : kind_(STRING), s_(v) {}
-    Json(std::string v) : kind_(STRING), s_(std::move(v)) {}
-    static Json array() { Json j; j.kind_ = ARRAY; return j; }
-    static Json object() { Json j; j.kind_ = OBJECT; return j; }
+    // A value is 16 bytes: its kind and either the scalar itself or a pointer to its string / elements / members (a count
+    // document holds a few hundred values; they are built, read back by the genotyper and dropped for every site and sample).
+    Json() : kind_(NUL) { v_.u = 0; }
+    Json(bool v) : kind_(BOOL) { v_.u = v; }
+    Json(int v) : kind_(INT) { v_.i = v; }
+    Json(int64_t v) : kind_(INT) { v_.i = v; }
+    Json(unsigned v) : kind_(UINT) { v_.u = v; }
+    Json(uint64_t v) : kind_(UINT) { v_.u = v; }
+    Json(double v) : kind_(REAL) { v_.d = v; }
+    Json(const char* v) : kind_(STRING) { v_.s = new std::string(v); }
+    Json(std::string v) : kind_(STRING) { v_.s = new std::string(std::move(v)); }
+    Json(Json const& o);
+    Json(Json&& o) noexcept : kind_(o.kind_), v_(o.v_)
+    {
+        o.kind_ = NUL;
+        o.v_.u = 0;
+    }
+    Json& operator=(Json const& o);
+    Json& operator=(Json&& o) noexcept
+    {
+        if (this != &o)
+        {
+            destroy();
+            kind_ = o.kind_;
+            v_ = o.v_;
+            o.kind_ = NUL;
+            o.v_.u = 0;
+        }
+        return *this;
+    }
+    ~Json() { destroy(); }
+    static Json array()
+    {
+        Json j;
+        j.kind_ = ARRAY;
+        j.v_.elements = new Elements();
+        return j;
+    }
+    static Json object()
+    {
+        Json j;
+        j.kind_ = OBJECT;
+        j.v_.members = new Members();
+        return j;
+    }
     static Json parse(std::string const& text);       // throws std::runtime_error with line:column
     static Json parseFile(std::string const& path);   // throws if the file cannot be read
     std::string dump(int indent = -1) const;           // indent < 0: one line; NaN / inf are written as null
@@ -47,36 +81,46 @@ public:
     std::string const& asString() const;
 
     // objects; a null value silently becomes an object (array) on first write, like Json::Value
-    bool isMember(std::string const& key) const { return kind_ == OBJECT && members_.count(key) != 0; }
+    bool isMember(std::string const& key) const { return kind_ == OBJECT && v_.members->count(key) != 0; }
     Json& operator[](std::string const& key);
     Json& operator[](const char* key) { return (*this)[std::string(key)]; }
     Json const& operator[](std::string const& key) const;  // null value when absent
     Json const& operator[](const char* key) const { return (*this)[std::string(key)]; }
-    void removeMember(std::string const& key) { members_.erase(key); }
-    Members const& members() const { return members_; }
+    void removeMember(std::string const& key)
+    {
+        if (kind_ == OBJECT)
+            v_.members->erase(key);
+    }
+    Members const& members() const { return kind_ == OBJECT ? *v_.members : noMembers(); }
     std::vector<std::string> getMemberNames() const;
 
     // arrays
-    size_t size() const { return kind_ == ARRAY ? elements_.size() : kind_ == OBJECT ? members_.size() : 0; }
+    size_t size() const { return kind_ == ARRAY ? v_.elements->size() : kind_ == OBJECT ? v_.members->size() : 0; }
     Json& append(Json v);
-    Json& operator[](size_t i) { return elements_.at(i); }
-    Json const& operator[](size_t i) const { return elements_.at(i); }
-    Json& operator[](int i) { return elements_.at((size_t)i); }
-    Json const& operator[](int i) const { return elements_.at((size_t)i); }
-    Elements const& elements() const { return elements_; }
-    Elements& elements() { return elements_; }
+    Json& operator[](size_t i) { return elements().at(i); }
+    Json const& operator[](size_t i) const { return elements().at(i); }
+    Json& operator[](int i) { return elements().at((size_t)i); }
+    Json const& operator[](int i) const { return elements().at((size_t)i); }
+    Elements const& elements() const { return kind_ == ARRAY ? *v_.elements : noElements(); }
+    Elements& elements();  // of an array; a null value becomes an empty array; anything else throws
 
     bool operator==(Json const& o) const;
     bool operator!=(Json const& o) const { return !(*this == o); }
 
 private:
     void write(std::string& out, int indent, int depth) const;
-    Kind kind_ = NUL;
-    int64_t i_ = 0;
-    uint64_t u_ = 0;
-    double d_ = 0;
-    std::string s_;
-    Elements elements_;
-    Members members_;
+    void destroy() noexcept;
+    static Members const& noMembers();
+    static Elements const& noElements();
+    Kind kind_;
+    union
+    {
+        int64_t i;
+        uint64_t u;
+        double d;
+        std::string* s;
+        Elements* elements;
+        Members* members;
+    } v_;
 };
 }  // namespace common

@@ -307,13 +307,71 @@ Json Json::parseFile(std::string const& path)
     return parse(ss.str());
 }
 
+Json::Json(Json const& o) : kind_(o.kind_), v_(o.v_)
+{
+    switch (kind_)
+    {
+    case STRING: v_.s = new std::string(*o.v_.s); break;
+    case ARRAY: v_.elements = new Elements(*o.v_.elements); break;
+    case OBJECT: v_.members = new Members(*o.v_.members); break;
+    default: break;
+    }
+}
+
+Json& Json::operator=(Json const& o)
+{
+    if (this != &o)
+    {
+        Json copy(o);  // o may live inside *this
+        *this = std::move(copy);
+    }
+    return *this;
+}
+
+void Json::destroy() noexcept
+{
+    switch (kind_)
+    {
+    case STRING: delete v_.s; break;
+    case ARRAY: delete v_.elements; break;
+    case OBJECT: delete v_.members; break;
+    default: break;
+    }
+    kind_ = NUL;
+    v_.u = 0;
+}
+
+Json::Members const& Json::noMembers()
+{
+    static const Members none;
+    return none;
+}
+
+Json::Elements const& Json::noElements()
+{
+    static const Elements none;
+    return none;
+}
+
+Json::Elements& Json::elements()
+{
+    if (kind_ == NUL)
+    {
+        kind_ = ARRAY;
+        v_.elements = new Elements();
+    }
+    if (kind_ != ARRAY)
+        throw std::runtime_error("JSON value is not an array");
+    return *v_.elements;
+}
+
 bool Json::asBool() const
 {
     switch (kind_)
     {
-    case BOOL: return u_ != 0;
-    case INT: return i_ != 0;
-    case UINT: return u_ != 0;
+    case BOOL: return v_.u != 0;
+    case INT: return v_.i != 0;
+    case UINT: return v_.u != 0;
     case NUL: return false;
     default: throw std::runtime_error("JSON value is not convertible to bool");
     }
@@ -323,13 +381,13 @@ int64_t Json::asInt64() const
 {
     switch (kind_)
     {
-    case INT: return i_;
+    case INT: return v_.i;
     case UINT:
-        if (u_ > (uint64_t)INT64_MAX)
+        if (v_.u > (uint64_t)INT64_MAX)
             throw std::runtime_error("JSON value out of int64 range");
-        return (int64_t)u_;
-    case REAL: return (int64_t)d_;
-    case BOOL: return u_ ? 1 : 0;
+        return (int64_t)v_.u;
+    case REAL: return (int64_t)v_.d;
+    case BOOL: return v_.u ? 1 : 0;
     case NUL: return 0;
     default: throw std::runtime_error("JSON value is not convertible to int");
     }
@@ -340,15 +398,15 @@ uint64_t Json::asUInt64() const
     switch (kind_)
     {
     case INT:
-        if (i_ < 0)
+        if (v_.i < 0)
             throw std::runtime_error("JSON value out of uint64 range");
-        return (uint64_t)i_;
-    case UINT: return u_;
+        return (uint64_t)v_.i;
+    case UINT: return v_.u;
     case REAL:
-        if (d_ < 0)
+        if (v_.d < 0)
             throw std::runtime_error("JSON value out of uint64 range");
-        return (uint64_t)d_;
-    case BOOL: return u_ ? 1 : 0;
+        return (uint64_t)v_.d;
+    case BOOL: return v_.u ? 1 : 0;
     case NUL: return 0;
     default: throw std::runtime_error("JSON value is not convertible to uint");
     }
@@ -358,10 +416,10 @@ double Json::asDouble() const
 {
     switch (kind_)
     {
-    case INT: return (double)i_;
-    case UINT: return (double)u_;
-    case REAL: return d_;
-    case BOOL: return u_ ? 1.0 : 0.0;
+    case INT: return (double)v_.i;
+    case UINT: return (double)v_.u;
+    case REAL: return v_.d;
+    case BOOL: return v_.u ? 1.0 : 0.0;
     case NUL: return 0.0;
     default: throw std::runtime_error("JSON value is not convertible to double");
     }
@@ -374,16 +432,19 @@ std::string const& Json::asString() const
         return empty;
     if (kind_ != STRING)
         throw std::runtime_error("JSON value is not a string");
-    return s_;
+    return *v_.s;
 }
 
 Json& Json::operator[](std::string const& key)
 {
     if (kind_ == NUL)
+    {
         kind_ = OBJECT;
+        v_.members = new Members();
+    }
     if (kind_ != OBJECT)
         throw std::runtime_error("JSON value is not an object (member " + key + ")");
-    return members_[key];
+    return (*v_.members)[key];
 }
 
 Json const& Json::operator[](std::string const& key) const
@@ -393,26 +454,23 @@ Json const& Json::operator[](std::string const& key) const
         return null_value;
     if (kind_ != OBJECT)
         throw std::runtime_error("JSON value is not an object (member " + key + ")");
-    auto it = members_.find(key);
-    return it == members_.end() ? null_value : it->second;
+    auto it = v_.members->find(key);
+    return it == v_.members->end() ? null_value : it->second;
 }
 
 std::vector<std::string> Json::getMemberNames() const
 {
     std::vector<std::string> names;
-    for (auto const& kv : members_)
+    for (auto const& kv : members())
         names.push_back(kv.first);
     return names;
 }
 
 Json& Json::append(Json v)
 {
-    if (kind_ == NUL)
-        kind_ = ARRAY;
-    if (kind_ != ARRAY)
-        throw std::runtime_error("JSON value is not an array");
-    elements_.push_back(std::move(v));
-    return elements_.back();
+    Elements& e = elements();
+    e.push_back(std::move(v));
+    return e.back();
 }
 
 bool Json::operator==(Json const& o) const
@@ -424,9 +482,9 @@ bool Json::operator==(Json const& o) const
             const double a = asDouble(), b = o.asDouble();
             return a == b || (std::isnan(a) && std::isnan(b));  // both are written as null: the same document
         }
-        if (kind_ == INT && i_ < 0)
-            return o.kind_ == INT && o.i_ == i_;
-        if (o.kind_ == INT && o.i_ < 0)
+        if (kind_ == INT && v_.i < 0)
+            return o.kind_ == INT && o.v_.i == v_.i;
+        if (o.kind_ == INT && o.v_.i < 0)
             return false;
         return asUInt64() == o.asUInt64();
     }
@@ -435,10 +493,10 @@ bool Json::operator==(Json const& o) const
     switch (kind_)
     {
     case NUL: return true;
-    case BOOL: return u_ == o.u_;
-    case STRING: return s_ == o.s_;
-    case ARRAY: return elements_ == o.elements_;
-    case OBJECT: return members_ == o.members_;
+    case BOOL: return v_.u == o.v_.u;
+    case STRING: return *v_.s == *o.v_.s;
+    case ARRAY: return *v_.elements == *o.v_.elements;
+    case OBJECT: return *v_.members == *o.v_.members;
     default: return false;
     }
 }
@@ -455,12 +513,14 @@ void Json::write(std::string& out, int indent, int depth) const
     switch (kind_)
     {
     case NUL: out += "null"; break;
-    case BOOL: out += u_ ? "true" : "false"; break;
-    case INT: out += std::to_string(i_); break;
-    case UINT: out += std::to_string(u_); break;
-    case REAL: real(out, d_); break;
-    case STRING: quote(out, s_); break;
+    case BOOL: out += v_.u ? "true" : "false"; break;
+    case INT: out += std::to_string(v_.i); break;
+    case UINT: out += std::to_string(v_.u); break;
+    case REAL: real(out, v_.d); break;
+    case STRING: quote(out, *v_.s); break;
     case ARRAY:
+    {
+        Elements const& elements_ = *v_.elements;
         if (elements_.empty())
         {
             out += "[]";
@@ -477,7 +537,10 @@ void Json::write(std::string& out, int indent, int depth) const
         newline(depth);
         out += ']';
         break;
+    }
     case OBJECT:
+    {
+        Members const& members_ = *v_.members;
         if (members_.empty())
         {
             out += "{}";
@@ -500,6 +563,7 @@ void Json::write(std::string& out, int indent, int depth) const
         newline(depth);
         out += '}';
         break;
+    }
     }
 }
 

@@ -73,6 +73,9 @@ void setDevices(std::vector<int> const& ordinals);
 size_t deviceCount();
 // page-locked staging memory obtained so far (the flat arrays of SiteBatcher::run live there)
 size_t pinnedStagingBytes();
+// CPUs this process may use at once (hardware threads, affinity mask, cgroup CPU bandwidth): the command lines' default for
+// their host threads (the reference defaults to std::thread::hardware_concurrency(), grmpy.cpp:66)
+int usableCpus();
 
 class SiteBatcher
 {

@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "cli_common.hh"
+#include "paragraph/SiteBatcher.hh"
 #include "paragraph/Workflow.hh"
 
 namespace
@@ -24,7 +25,7 @@ const char* kUsage = "grmpy -r <reference> -g <graphs> -m <manifest> [optional a
                      "      --path-sequence-matching BOOL (false)   --graph-sequence-matching BOOL (true)\n"
                      "      --klib-sequence-matching BOOL (false)   --kmer-sequence-matching BOOL (false)\n"
                      "      --bad-align-uniq-kmer-len N   (0)\n"
-                     "  -t, --sample-threads N            host threads (1)\n"
+                     "  -t, --sample-threads N            host threads (the CPUs this process may use)\n"
                      "      --devices LIST                GPUs to spread the site batches over: 0,1,2,3 or 'all' (default: PG_DEVICES, else 0)\n"
                      "      --response-file FILE          read further options from FILE\n";
 }
@@ -35,6 +36,7 @@ int main(int argc, char** argv)
     {
         cli::Arguments args(cli::expandArguments(argc, argv));
         grmpy::Parameters parameters;
+        parameters.threads = paragraph::usableCpus();
         std::string reference, manifest, genotyping_parameters, output_file, output_folder;
         std::vector<std::string> graphs;
         bool gzip = false;

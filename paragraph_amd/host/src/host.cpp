@@ -394,6 +394,7 @@ size_t deviceCount()
 }
 
 size_t pinnedStagingBytes() { return pghost::pinnedBytesAllocated(); }
+int usableCpus() { return pghost::usableCpus(); }
 }  // namespace paragraph
 
 namespace grm

@@ -27,7 +27,7 @@ const char* kUsage = "paragraph -r <reference> -g <graph(s)> -b <input bam(s)> [
                      "      --klib-sequence-matching BOOL (false)   --kmer-sequence-matching BOOL (false)\n"
                      "      --output-detailed-read-counts [BOOL]    -a, --output-alignments [BOOL]\n"
                      "  -A, --output-filtered-alignments [BOOL]     (filter tallies; filtered reads are not re-emitted)\n"
-                     "      --threads N                   host threads (1)\n"
+                     "      --threads N                   host threads (the CPUs this process may use)\n"
                      "      --devices LIST                GPUs to spread the site batches over: 0,1,2,3 or 'all' (default: PG_DEVICES, else 0)\n"
                      "      --response-file FILE\n";
 }
@@ -38,6 +38,7 @@ int main(int argc, char** argv)
     {
         cli::Arguments args(cli::expandArguments(argc, argv));
         paragraph::Parameters parameters;
+        parameters.threads = paragraph::usableCpus();
         std::string reference, output_file, output_folder, target_regions;
         std::vector<std::string> graphs, bams, bam_indexes;
         bool gzip = false;

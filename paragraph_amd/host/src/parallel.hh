@@ -6,9 +6,39 @@
 #include <exception>
 #include <thread>
 #include <vector>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sched.h>
 
 namespace pghost
 {
+// CPUs this process can really run on at once: the hardware threads, its affinity mask and -- in a container -- the CPU
+// bandwidth of its cgroup (cpu.max: a box may show 256 CPUs and allow 16).  The command lines default their host threads to it.
+inline int usableCpus()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    if (n <= 0)
+        n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0)
+        n = std::min(n, (int)CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r"))
+    {
+        char quota[32];
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && strcmp(quota, "max") != 0)
+        {
+            const long q = atol(quota);
+            if (q > 0)
+                n = std::min(n, (int)std::max(1L, (q + period / 2) / period));
+        }
+        fclose(f);
+    }
+    return std::max(1, n);
+}
+
 template <typename Fn> void parallelFor(size_t n, int threads, Fn fn, size_t grain = 1)
 {
     grain = std::max<size_t>(grain, 1);

@@ -356,7 +356,7 @@ def make_argument_parser():
     p.add_argument("-m", "--manifest", required=True, help="Manifest of samples with path and bam stats.")
     p.add_argument("-o", "--output", required=True, help="Output directory.")
     p.add_argument("-r", "--reference-sequence", dest="reference", required=True, help="Reference genome fasta file.")
-    p.add_argument("--threads", "-t", type=int, default=os.cpu_count() or 1, help="Host threads of grmpy.")
+    p.add_argument("--threads", "-t", type=int, default=0, help="Host threads of grmpy (default: the CPUs the process may use).")
     p.add_argument("--keep-scratch", action="store_true", default=None, help="Do not delete temp files.")
     p.add_argument("--scratch-dir", default=None, help="Directory for temp files")
     p.add_argument("--grmpy", default=GRMPY, help="Path to the grmpy executable")

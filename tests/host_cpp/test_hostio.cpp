@@ -3,6 +3,7 @@
 //   src/c++/test/test_stringutil.cpp:86-118, test_readextraction.cpp:105-199, test_graph_input.cpp:46-155,
 //   GT!/tests/GraphCoordinatesTest.cpp:72-140, share/test-data/multiparagraph/reads.sam (text of reads.bam).
 // Usage: test_hostio <tests/golden/sites directory>
+#include <unistd.h>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -192,6 +193,42 @@ static void testBamAgainstSam(std::string const& dir)
     CHECK(!reader.getAlign(r));
     CHECK_THROWS(reader.setRegion("nochr:1-10"));
     CHECK_THROWS(BamReader(dir + "/multiparagraph/missing.bam", "", ""));
+}
+
+// a BGZF block whose stored CRC-32 (or payload) does not match is refused: the block check runs on the carry-less-multiply
+// path where the CPU has it, zlib's otherwise -- both must catch a flipped bit anywhere in a 64 KiB block
+static void testBamCorruption(std::string const& dir)
+{
+    const std::string src = dir + "/chrX/chrX_graph_typing.bam";
+    std::ifstream in(src, std::ios::binary);
+    std::string data((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    CHECK(data.size() > 1000);
+    auto scan = [&](std::string const& path) {
+        BamReader reader(path, src + ".bai", dir + "/chrX/chrX_graph_typing.fa");
+        reader.setRegion("chrX");
+        Read r;
+        size_t n = 0;
+        while (reader.getAlign(r))
+            ++n;
+        return n;
+    };
+    const size_t n_reads = scan(src);
+    CHECK(n_reads > 100);
+    // second block of the file: [header 12 + xlen][deflate data][crc32][isize]
+    auto block_size = [&](size_t at) { return (size_t)((unsigned char)data[at + 16] | ((unsigned char)data[at + 17] << 8)) + 1; };
+    const size_t b0 = block_size(0), b1 = block_size(b0);
+    CHECK(b0 + b1 < data.size());
+    const std::string tmp = "/tmp/pg_test_corrupt_" + std::to_string((long)getpid()) + ".bam";
+    for (size_t where : { b0 + b1 - 8 /* stored CRC */, b0 + b1 - 12 /* last payload bytes */ })
+    {
+        std::string bad = data;
+        bad[where] = (char)(bad[where] ^ 0x10);
+        std::ofstream(tmp, std::ios::binary) << bad;
+        CHECK_THROWS(scan(tmp));
+    }
+    std::ofstream(tmp, std::ios::binary) << data;
+    CHECK(scan(tmp) == n_reads);
+    std::remove(tmp.c_str());
 }
 
 // region queries through the index must equal a filter over the full scan, in the same order
@@ -737,6 +774,7 @@ int main(int argc, char** argv)
         { "fasta", [&] { testFasta(dir); } },
         { "bam-vs-sam", [&] { testBamAgainstSam(dir); } },
         { "bam-index", [&] { testBamIndexConsistency(dir); } },
+        { "bam-corruption", [&] { testBamCorruption(dir); } },
         { "extraction", testExtraction },
         { "packed-extraction", [&] { testPackedExtraction(dir); } },
         { "chunk-schedule", [&] { testChunkSchedule(); } },

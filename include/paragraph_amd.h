@@ -147,6 +147,12 @@ typedef struct pg_timing
     uint64_t trace_bytes; /* bytes of traceback state written by the fill kernel */
 } pg_timing;
 
+/* Host threads that wait for `device` (pg_batch_wait, downloads, pg_ctx_sync) sleep instead of spinning:
+ * hipSetDeviceFlags(hipDeviceScheduleBlockingSync).  Has an effect only before the device's first use in the process, so
+ * call it before pg_ctx_create; harmless (PG_OK) later.  For workflows whose host threads fill the CPUs they may use: a
+ * spinning wait takes a CPU from another lane's read extraction (the reference has no device to wait for; its threads
+ * block in htslib and in each other's mutexes, src/c++/lib/grmpy/Workflow.cpp:225-231). */
+pg_status pg_device_prefer_blocking_waits(int device);
 pg_status pg_ctx_create(int device, pg_ctx** out);
 void pg_ctx_destroy(pg_ctx* ctx);
 const char* pg_strerror(pg_status st);

@@ -39,7 +39,7 @@ SUPPORT_DTYPE = np.dtype([("label_mask", "<u8"), ("path_off", "<u4"), ("n_path",
 assert SUPPORT_DTYPE.itemsize == 16, SUPPORT_DTYPE.itemsize
 
 EXPORTS = [
-    "pg_ctx_create", "pg_ctx_destroy", "pg_strerror", "pg_last_error", "pg_ctx_set_workspace_bytes", "pg_ctx_sync",
+    "pg_device_prefer_blocking_waits", "pg_ctx_create", "pg_ctx_destroy", "pg_strerror", "pg_last_error", "pg_ctx_set_workspace_bytes", "pg_ctx_sync",
     "pg_ctx_timing_enable", "pg_ctx_timing_reset", "pg_ctx_timing_get", "pg_graphs_upload", "pg_graphs_destroy",
     "pg_batch_create", "pg_batch_destroy", "pg_batch_upload", "pg_batch_align", "pg_batch_ops_count",
     "pg_batch_download", "pg_align_batch", "pg_render_cigar", "pg_graphs_set_labels", "pg_graphs_count_layout",
@@ -86,6 +86,8 @@ def load_library():
     L = C.CDLL(LIB_PATH)
     u32p = C.POINTER(C.c_uint32)
     vp = C.c_void_p
+    L.pg_device_prefer_blocking_waits.restype = C.c_int32
+    L.pg_device_prefer_blocking_waits.argtypes = [C.c_int]
     L.pg_ctx_create.restype = C.c_int32
     L.pg_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.pg_ctx_destroy.restype = None

@@ -165,6 +165,18 @@ extern "C" const char* pg_strerror(pg_status st)
 
 extern "C" const char* pg_last_error(const pg_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
 
+extern "C" pg_status pg_device_prefer_blocking_waits(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+        return PG_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess)
+        return PG_ERR_HIP;
+    (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);  // refused once the device is in use: then nothing changes
+    (void)hipGetLastError();
+    return PG_OK;
+}
+
 extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
 {
     if (!out)

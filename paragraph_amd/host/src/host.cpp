@@ -73,6 +73,8 @@ std::vector<int> devicesFromEnvironment()
             for (int d = 0; d < 64; ++d)
             {
                 pg_ctx* probe = nullptr;
+                if (!std::getenv("PG_SPIN_WAITS"))
+                    (void)pg_device_prefer_blocking_waits(d);  // before the device's first use (see deviceContext)
                 if (pg_ctx_create(d, &probe) != PG_OK)
                     break;
                 pg_ctx_destroy(probe);
@@ -125,6 +127,9 @@ pg_ctx* deviceContext(int slot = 0)
     std::lock_guard<std::mutex> lock(ds.create);
     if (!ds.ctx)
     {
+        // lanes wait for their batches while other lanes need the CPU (PG_SPIN_WAITS keeps HIP's spinning default)
+        if (!std::getenv("PG_SPIN_WAITS"))
+            (void)pg_device_prefer_blocking_waits(ds.ordinal);
         pg_status st = pg_ctx_create(ds.ordinal, &ds.ctx);
         if (st != PG_OK)
             throw std::runtime_error("pg_ctx_create(device " + std::to_string(ds.ordinal) + "): " + pg_strerror(st));

@@ -15,8 +15,8 @@ r=d["runs"][2:]
 print("$name", "lanes", d["runs"][-1]["lanes"], "median sites/s %.0f" % statistics.median(x["sites_per_s"] for x in r), "cpu %.2f" % statistics.median(x["cpu_user_s"]+x["cpu_sys_s"] for x in r), ["%.0f" % x["sites_per_s"] for x in r])
 PY
 }
-run t16 16 0 A=1
-run t32 32 0 A=1
-run t14 14 0 A=1
-run t16_b256 16 0 A=1
-( time timeout 900 python -m pytest tests/test_gpu_workflow.py -m gpu -q --timeout 600 -p no:cacheprovider ) > $O/pytest.log 2>&1; tail -4 $O/pytest.log
+run block_16 16 0 A=1
+run spin_16 16 0 PG_SPIN_WAITS=1
+run block_16b 16 0 A=1
+run spin_16b 16 0 PG_SPIN_WAITS=1
+( time timeout 900 python -m pytest tests/test_gpu_workflow.py tests/test_gpu_parity.py -m gpu -q --timeout 600 -p no:cacheprovider ) > $O/pytest.log 2>&1; tail -4 $O/pytest.log

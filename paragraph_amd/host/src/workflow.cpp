@@ -884,10 +884,12 @@ std::vector<Json> genotypeGraphs(
     if (!parameters.devices.empty())
         paragraph::setDevices(parameters.devices);
     const size_t n_devices = paragraph::deviceCount();
-    // one host thread per lane as long as there are threads: a lane that does its own extraction, documents and releases
-    // stays inside one allocator arena and starts no helper threads (measured on 16 CPUs: 16 lanes x 1 thread 45 k sites/s,
-    // 8 lanes x 4 threads 31 k; more lanes than CPUs lose again)
-    const int lanes_default = std::max((int)n_devices, std::min(32 * (int)n_devices, std::max(1, parameters.threads)));
+    // One host thread per lane, and half as many lanes again as threads: a lane that does its own extraction, documents and
+    // releases stays inside one allocator arena and starts no helper threads, and it sleeps while its batch is on the device
+    // (pg_device_prefer_blocking_waits), about a quarter of its time.  Measured on the 16 CPUs the GPU box allows, 10 000
+    // sites, batches of 128: 16 lanes 57 k sites/s, 24 lanes 62 k, 32 lanes 60 k; the earlier 8 lanes x 4 threads: 31 k.
+    const int lanes_default
+        = std::max((int)n_devices, std::min(32 * (int)n_devices, std::max(1, parameters.threads + parameters.threads / 2)));
     const int lanes_wanted = parameters.lanes > 0 ? parameters.lanes : lanes_default;
     const size_t lanes = std::max<size_t>(1, std::min<size_t>((size_t)lanes_wanted, n_even_chunks));
     const std::vector<std::pair<size_t, size_t>> chunk_ranges = chunkSchedule(n_graphs, per_batch, lanes);

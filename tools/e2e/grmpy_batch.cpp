@@ -29,7 +29,8 @@ int main(int argc, char** argv)
         grmpy::Parameters parameters;
         parameters.threads = std::atoi(argv[4]);
         if (argc > 6)
-            parameters.sites_per_batch = (size_t)std::atoll(argv[6]);
+            if (std::atoll(argv[6]) > 0)  // 0: the library's default
+                parameters.sites_per_batch = (size_t)std::atoll(argv[6]);
         if (argc > 7)
             parameters.lanes = std::atoi(argv[7]);
         if (argc > 8)

@@ -103,7 +103,7 @@ std::vector<common::Json> alignAndDisambiguateBatch(Parameters const& parameters
 std::vector<common::Json> countGraphs(
     Parameters const& parameters, std::vector<std::string> const& graph_paths, std::string const& reference_path,
     std::vector<std::string> const& bam_paths, std::vector<std::string> const& bam_index_paths = {},
-    std::string const& target_regions = "", size_t sites_per_batch = 512);
+    std::string const& target_regions = "", size_t sites_per_batch = 128);
 // single-site convenience with the reference's shape
 common::Json alignAndDisambiguate(Parameters const& parameters, GraphDescription const& description, common::ReadBuffer& all_reads);
 }  // namespace paragraph

@@ -483,11 +483,11 @@ std::vector<Json> countGraphs(
         }
     };
     // Several chunks: lanes as in grmpy::genotypeGraphs -- one chunk is on the device while others extract reads or write
-    // documents (one lane per four threads, at most eight).
+    // documents (one host thread per lane, 1.5 lanes per thread, see grmpy::genotypeGraphs).
     // With several devices (paragraph::setDevices / PG_DEVICES) lane l works on device l % devices, at least one lane each.
     const size_t n_chunks = (graph_paths.size() + sites_per_batch - 1) / sites_per_batch;
     const size_t n_devices = paragraph::deviceCount();
-    const size_t lanes_by_threads = (size_t)std::min<size_t>(32 * n_devices, (size_t)std::max(1, parameters.threads));
+    const size_t lanes_by_threads = (size_t)std::min<size_t>(32 * n_devices, (size_t)std::max(1, parameters.threads + parameters.threads / 2));
     const size_t lanes = std::max<size_t>(1, std::min<size_t>(n_chunks, std::max(lanes_by_threads, n_devices)));
     if (lanes == 1)
     {

@@ -5,13 +5,13 @@ O=$R/gpurun_out/f; mkdir -p $O
 export PG_E2E_DIR=$R/tools/e2e/_data
 W=$PG_E2E_DIR
 # ---- 1. end to end, 32 host threads, 8 lanes, packed reads (three runs inside grmpy_batch? it prints its own timing) ----
-( time bash tools/e2e/run.sh 10000 30 32 512 8 1 ) > $O/e2e_run.log 2>&1; tail -4 $O/e2e_run.log
+( time PG_E2E_REPS=8 bash tools/e2e/run.sh 10000 30 16 0 0 1 ) > $O/e2e_run.log 2>&1; tail -4 $O/e2e_run.log | cut -c1-400
 cp gpurun_out/e2e_probe.json $O/e2e_probe.json 2>/dev/null
-( PG_DEVICES=0,0 $W/grmpy_batch $W/ref.fa $W/manifest.txt $W/graphs.txt 32 $W/genotypes2.json 512 8 1 ) > $O/e2e_two_slots.json 2> $O/e2e_two_slots.err; tail -c 600 $O/e2e_two_slots.json
+( PG_DEVICES=0,0 $W/grmpy_batch $W/ref.fa $W/manifest.txt $W/graphs.txt 16 $W/genotypes2.json 0 0 1 ) > $O/e2e_two_slots.json 2> $O/e2e_two_slots.err; tail -c 600 $O/e2e_two_slots.json
 export TMPDIR=/tmp  # (stay in the repo root: the manifest of the e2e data set names its BAM relative to it)
 # ---- 2. the same under rocprofv3: kernel stats, then HIP API stats (separate runs, no counters) ----
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/e2e_kernels -o e2e -- $W/grmpy_batch $W/ref.fa $W/manifest.txt $W/graphs.txt 32 $W/g3.json 512 8 1 > $O/e2e_kernels.out 2> $O/e2e_kernels.err
-timeout 300 rocprofv3 --hip-runtime-trace --stats --output-format csv -d $O/e2e_hip -o e2e -- $W/grmpy_batch $W/ref.fa $W/manifest.txt $W/graphs.txt 32 $W/g4.json 512 8 1 > $O/e2e_hip.out 2> $O/e2e_hip.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/e2e_kernels -o e2e -- $W/grmpy_batch $W/ref.fa $W/manifest.txt $W/graphs.txt 16 $W/g3.json 0 0 1 > $O/e2e_kernels.out 2> $O/e2e_kernels.err
+timeout 300 rocprofv3 --hip-runtime-trace --stats --output-format csv -d $O/e2e_hip -o e2e -- $W/grmpy_batch $W/ref.fa $W/manifest.txt $W/graphs.txt 16 $W/g4.json 0 0 1 > $O/e2e_hip.out 2> $O/e2e_hip.err
 # ---- 3. bench under rocprofv3 (kernel stats) and its HIP API stats with the streaming leg ----
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_kernels -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --sites-steps 0 --stream-batches 0 > $O/bench_kernels.json 2> $O/bench_kernels.err
 timeout 400 rocprofv3 --hip-runtime-trace --stats --output-format csv -d $O/bench_hip -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --sites-steps 0 --stream-batches 8 > $O/bench_hip.json 2> $O/bench_hip.err

@@ -544,6 +544,7 @@ extern "C" pg_status pg_graphs_upload(
         {
             PgGraphDir& gd = gdev[g].dir[dir];
             gd.meta_off = (uint32_t)colmeta.size();
+            const size_t dir_meta_begin = colmeta.size();
             gd.ncols = (uint32_t)total;
             gd.node_off = (uint32_t)nodes.size();
             gd.n_nodes = n;
@@ -588,7 +589,7 @@ extern "C" pg_status pg_graphs_upload(
                 // direction only needs seeds that a non-adjacent successor will load
                 const bool save = dir == 0 ? has_succ : has_far_succ;
                 // predecessor summary of the node, carried by its first column's meta word (no table loads on the device
-                // in the common cases): adjacent predecessor?, and none / exactly one far predecessor with id < 512 / general
+                // in the common cases): adjacent predecessor?, and none / exactly one far predecessor with id < 256 / general
                 uint32_t pred_bits = 0;
                 {
                     uint32_t n_far = 0, far = 0;
@@ -602,7 +603,7 @@ extern "C" pg_status pg_graphs_upload(
                             far = preds[k];
                         }
                     }
-                    if (n_far == 1 && far < 512)
+                    if (n_far == 1 && far < 256)
                         pred_bits |= PG_META_PRED_ONE | (far << PG_META_PRED_SHIFT);
                     else if (n_far != 0)
                         pred_bits |= PG_META_PRED_MANY;
@@ -620,6 +621,13 @@ extern "C" pg_status pg_graphs_upload(
                         seqchars.push_back(ch);
                 }
                 col += len;
+            }
+            // PG_META_RARE: node boundary, or code 4 in this column or in the next one of the layout
+            for (size_t i = dir_meta_begin; i < colmeta.size(); ++i)
+            {
+                const uint32_t next_code = i + 1 < colmeta.size() ? PG_META_CODE(colmeta[i + 1]) : 4u;
+                if ((colmeta[i] & (PG_META_FIRST | PG_META_LAST)) || PG_META_CODE(colmeta[i]) >= 4u || next_code >= 4u)
+                    colmeta[i] |= PG_META_RARE;
             }
             for (int c = 0; c < PG_META_PAD; ++c)
                 colmeta.push_back(PG_META_IDLE);

@@ -347,7 +347,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             // predecessor summary in the meta word: no table loads
             if (meta_cur & PG_META_PRED_ONE)
             {
-                const uint32_t pid = meta_cur >> PG_META_PRED_SHIFT;
+                const uint32_t pid = (meta_cur >> PG_META_PRED_SHIFT) & 0xFFu;
                 uint32_t w[C];
                 if (SEEDCACHE && pid == cnode)
                 {
@@ -487,7 +487,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         // itself is outside the branches: with the lanes of a read skewed by one column each, a node boundary keeps SOME lane
         // of the wavefront in a rare path for 16 steps in a row, and a column inside the branch would then be executed twice,
         // once per side.
-        const bool rare = ((meta_cur & (PG_META_FIRST | PG_META_LAST)) | (meta_rows & 4u)) != 0u;
+        const bool rare = (int32_t)meta_cur < 0;  // PG_META_RARE: node boundary here, or code 4 here / in the next column
         if (rare)
         {
             if (meta_rows & 4u)  // N in the graph, or the idle columns behind its end

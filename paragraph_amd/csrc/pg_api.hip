@@ -589,7 +589,7 @@ extern "C" pg_status pg_graphs_upload(
                 // direction only needs seeds that a non-adjacent successor will load
                 const bool save = dir == 0 ? has_succ : has_far_succ;
                 // predecessor summary of the node, carried by its first column's meta word (no table loads on the device
-                // in the common cases): adjacent predecessor?, and none / exactly one far predecessor with id < 256 / general
+                // in the common cases): adjacent predecessor?, and none / exactly one far predecessor with id < 128 / general
                 uint32_t pred_bits = 0;
                 {
                     uint32_t n_far = 0, far = 0;
@@ -603,7 +603,7 @@ extern "C" pg_status pg_graphs_upload(
                             far = preds[k];
                         }
                     }
-                    if (n_far == 1 && far < 256)
+                    if (n_far == 1 && far < 128)
                         pred_bits |= PG_META_PRED_ONE | (far << PG_META_PRED_SHIFT);
                     else if (n_far != 0)
                         pred_bits |= PG_META_PRED_MANY;
@@ -615,7 +615,7 @@ extern "C" pg_status pg_graphs_upload(
                     if (c == 0)
                         m |= PG_META_FIRST | pred_bits;
                     if (c == len - 1)
-                        m |= PG_META_LAST | (save ? PG_META_SAVE : 0u);
+                        m |= PG_META_LAST | PG_META_LAST_HI | (save ? PG_META_SAVE : 0u);
                     colmeta.push_back(m);
                     if (!dir)
                         seqchars.push_back(ch);

@@ -24,13 +24,16 @@
 #define PG_META_NODE(m) (((m) >> 8) & 0xFFFu)
 // first column of a node only: summary of its predecessors (bits 20..31)
 #define PG_META_PRED_ADJ (1u << 20)   // the node directly before it in the layout is a predecessor (its state is still in registers)
-#define PG_META_PRED_ONE (1u << 21)   // exactly one other predecessor, id (< 256) in bits 23..30
+#define PG_META_PRED_ONE (1u << 21)   // exactly one other predecessor, id (< 128) in bits 23..29
 #define PG_META_PRED_MANY (2u << 21)  // anything else: read the predecessor table
 #define PG_META_PRED_SHIFT 23
 // bit 31, every column: something other than the plain recurrence happens in this step -- a node boundary (FIRST / LAST), or this
 // column or the NEXT one of the layout carries code 4 (the profile rows of the next column are fetched one step ahead).  One
 // sign test per step instead of assembling the condition from two words.
 #define PG_META_RARE 0x80000000u
+// bit 30: a copy of LAST.  RARE is always set on a LAST column, so a LAST column is the only kind of word that is >= 0xC0000000
+// as an unsigned number: the test after the column is one compare.
+#define PG_META_LAST_HI 0x40000000u
 #define PG_META_IDLE (4u | PG_META_RARE)  // code 4 (scores 0 against everything)
 #define PG_META_PAD 160   // idle words appended to every direction's column array (64-wide block prefetch)
 

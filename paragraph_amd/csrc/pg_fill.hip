@@ -347,7 +347,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             // predecessor summary in the meta word: no table loads
             if (meta_cur & PG_META_PRED_ONE)
             {
-                const uint32_t pid = (meta_cur >> PG_META_PRED_SHIFT) & 0xFFu;
+                const uint32_t pid = (meta_cur >> PG_META_PRED_SHIFT) & 0x7Fu;
                 uint32_t w[C];
                 if (SEEDCACHE && pid == cnode)
                 {
@@ -496,11 +496,8 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 first_column(Hin, meta_cur, tau);
         }
         column(Hin, Hout, sc, dH, F, floorE, tau, tvec);
-        if (rare)
-        {
-            if (meta_cur & PG_META_LAST)
-                last_column(Hout, meta_cur, tau);
-        }
+        if (meta_cur >= (PG_META_RARE | PG_META_LAST_HI))  // a LAST column (the only words with bits 31 and 30 set): one compare
+            last_column(Hout, meta_cur, tau);
         tbase += TRACE_STEP_BYTES;
     };
 

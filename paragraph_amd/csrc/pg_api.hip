@@ -852,7 +852,9 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
         const uint64_t nsteps = pg_fill_steps(hg.ncols);
         const uint64_t trace_bytes = align_up(nsteps * 64 * pg_trace_lane_bytes(C), 256);
         const uint64_t seed_bytes = pg_seed_region_bytes(C, hg.n_nodes) + pg_key_region_bytes(hg.n_nodes);
-        const uint64_t need = trace_bytes + 2 * seed_bytes;
+        // + the traceback's CIGAR scratch of the pair's four reads (reversed-graph item's trace_off, which has no trace)
+        const uint64_t ops_bytes = align_up((uint64_t)PG_GROUPS * pg_ops_cap(C) * sizeof(uint32_t), 256);
+        const uint64_t need = trace_bytes + 2 * seed_bytes + ops_bytes;
         if (need > ctx->ws_limit / 2)
             return fail(ctx, PG_ERR_UNSUPPORTED, "workspace limit too small for one wavefront of this graph");
         if (open && (cur.C != C || cur.ws_bytes + need > ctx->ws_limit / 2))
@@ -881,7 +883,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
         }
         fw.trace_off = cur.ws_bytes;
         fw.seed_off = cur.ws_bytes + trace_bytes;
-        rv.trace_off = 0;
+        rv.trace_off = cur.ws_bytes + trace_bytes + 2 * seed_bytes;
         rv.seed_off = cur.ws_bytes + trace_bytes + seed_bytes;
         cur.ws_bytes += need;
         cur.trace_bytes += nsteps * 64 * pg_trace_lane_bytes(C);
@@ -1125,6 +1127,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         ta.base_off = b->d_base_off;
         ta.bases = b->d_bases;
         ta.workspace = ws;
+        ta.workspace_rw = ws;
         ta.fillsum = b->d_fillsum;
         ta.results = b->d_results;
         ta.ops = b->d_ops;

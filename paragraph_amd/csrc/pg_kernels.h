@@ -35,6 +35,7 @@ struct PgTraceArgs
     const uint32_t* base_off;
     const char* bases;
     const uint8_t* workspace;
+    uint8_t* workspace_rw;  // the same block: the CIGAR scratch of a work-item pair sits behind its seed regions
     const PgFillSummary* fillsum;
     pg_result* results;     // [read]
     pg_op* ops;             // compact output

@@ -85,7 +85,7 @@ __device__ __forceinline__ int sub_score(uint32_t a, uint32_t b)
 
 struct Emitter
 {
-    uint32_t* slot;  // LDS, written from the tail backwards by the row's first lane
+    uint32_t* slot;  // in the work item's scratch (workspace), written from the tail backwards by the row's first lane
     bool writer;
     uint32_t cap;
     uint32_t n;
@@ -124,9 +124,11 @@ struct Emitter
 }  // namespace
 
 template <int C, bool WIDE>
-__global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void pg_trace_kernel(PgTraceArgs a)
 {
-    extern __shared__ uint32_t ops_lds[];  // [4 reads][pg_ops_cap]
+    // No LDS and at most 64 VGPRs: this kernel runs on the second stream UNDER the next chunk's fill, whose 16 wavefronts per CU
+    // take all 160 KB of LDS and 448 of the 512 VGPRs of a SIMD lane -- a traceback wavefront that needs neither takes the
+    // place of no fill wavefront (with 3 KB of LDS and 80 VGPRs it cost the fill 10 % of its time).
     const uint32_t lane = threadIdx.x;
     const uint32_t grp = lane >> 4;  // the read of this 16-lane row
     const uint32_t k = lane & 15u;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
 
     Emitter em;
     em.cap = pg_ops_cap(WIDE ? PG_VAR_WIDE + C : C);
-    em.slot = ops_lds + grp * em.cap;
+    em.slot = (uint32_t*)(a.workspace_rw + a.items[2 * pair + 1].trace_off) + grp * em.cap;  // [4 reads][pg_ops_cap]
     em.writer = writer;
     em.n = 0;
     em.last_op = 0xFFu;
@@ -530,7 +532,8 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
     res.clipped = (uint16_t)clipped;
     res.status = (uint16_t)status;
     res.n_ops = (uint16_t)em.n;
-    // compact: bump-allocate (first lane) and copy the tail-aligned LDS slot into forward order (all 16 lanes)
+    // compact: bump-allocate (first lane) and copy the tail-aligned slot into forward order (all 16 lanes)
+    __threadfence_block();
     unsigned long long base = 0;
     if (writer)
         base = atomicAdd(a.ops_counter, (unsigned long long)em.n);
@@ -544,8 +547,7 @@ __global__ __launch_bounds__(64) void pg_trace_kernel(PgTraceArgs a)
 
 template <int C, bool WIDE> static hipError_t launch_trace_c(const PgTraceArgs& args, hipStream_t stream)
 {
-    const size_t lds = (size_t)PG_GROUPS * pg_ops_cap(WIDE ? PG_VAR_WIDE + C : C) * sizeof(uint32_t);
-    hipLaunchKernelGGL((pg_trace_kernel<C, WIDE>), dim3(args.n_pairs), dim3(64), lds, stream, args);
+    hipLaunchKernelGGL((pg_trace_kernel<C, WIDE>), dim3(args.n_pairs), dim3(64), 0, stream, args);
     return hipGetLastError();
 }
 

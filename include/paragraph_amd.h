@@ -336,8 +336,8 @@ pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* batch, uint32_t flags);
  * for a read's CIGAR, bit1 a path CIGAR exceeded 2 * L + 4 runs: those reads stay unmapped).  Synchronises, clears. */
 pg_status pg_graphs_klib_error(pg_ctx* ctx, pg_graphs* graphs, uint32_t* error);
 
-/* Which kernels the last pg_batch_klib_align on this graph set ran: 1 = the packed two-strand kernels (every read <= 250 bases
- * and every path of the set at least as long as the longest read), 0 = the general ones.  Both give KlibAligner's results
+/* Which kernels the last pg_batch_klib_align on this graph set ran: 1 = the packed two-strand kernels (every path
+ * of the set at least as long as the longest read), 0 = the general ones.  Both give KlibAligner's results
  * (src/c++/lib/grm/KlibAligner.cpp:388-442); the tests use this to know which of the two they have checked. */
 pg_status pg_graphs_klib_last_kernels(pg_ctx* ctx, pg_graphs* graphs, uint32_t* packed);
 

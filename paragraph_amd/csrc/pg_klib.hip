@@ -923,10 +923,10 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const uint32_t cig_cap = 2 * max_len + 4;
-    // The packed kernels take reads of up to 250 bases (the byte variants of the fill kernel: C <= 16 rows per lane) on paths
+    // The packed kernels take reads on paths
     // no shorter than a read (ksw_global's band = path length then covers the whole window) and short enough for a 16-bit
     // step counter; anything else runs on the general kernels.
-    const bool packed = max_len <= 250 && ix->min_path_len >= max_len && ix->max_path_len <= 65000u && !std::getenv("PG_KLIB_GENERAL");
+    const bool packed = ix->min_path_len >= max_len && ix->max_path_len <= 65000u && !std::getenv("PG_KLIB_GENERAL");
     ix->last_packed = packed ? 1u : 0u;
     KlibArgs a{};
     a.n_reads = b->n_reads;
@@ -965,7 +965,7 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
         for (const Chunk& c : b->chunks)
         {
             a.pair_begin = c.pair_begin;
-            HIP_TRY(ctx, pg_klib_launch_local(c.C, a, c.pair_end - c.pair_begin, ctx->stream));
+            HIP_TRY(ctx, pg_klib_launch_local(pg_var_c(c.C), a, c.pair_end - c.pair_begin, ctx->stream));
         }
         hipLaunchKernelGGL(pg_klib_select_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
         HIP_TRY(ctx, hipGetLastError());
@@ -975,7 +975,7 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if ((uint64_t)n_work * cig_cap >= (1ull << 32))
             return pg_fail(ctx, PG_ERR_UNSUPPORTED, "pg_batch_klib_align: batch too large (CIGAR scratch index)");
-        const int C = pg_variant_of(max_len);
+        const int C = pg_var_c(pg_variant_of(max_len));
         const uint32_t waves = (n_work + 7u) / 8u;
         const uint32_t grid = std::min<uint32_t>(waves, (uint32_t)n_cu * 10u);
         const uint64_t z_bytes = pg_klib_finish_z_bytes(C);

@@ -1,6 +1,6 @@
-// pg_klib_packed.hip -- the klib (ksw) stage in the packed two-strand wave form (reads up to 250 bases).
+// pg_klib_packed.hip -- the klib (ksw) stage in the packed two-strand wave form.
 //
-// Replaces, like the general kernels of pg_klib.hip (used for longer reads and for paths shorter than a read),
+// Replaces, like the general kernels of pg_klib.hip (used for paths shorter than a read),
 //   common::KlibAlignment::update                   src/c++/lib/common/Klib.cpp:144-164
 //   ksw_i16 / ksw_align(KSW_XSTART) / ksw_global    external/klib/ksw.c:223-321, 330-355, 457-531
 // but with the DP arithmetic of the gssw fill kernel (pg_fill.hip): one 64-lane wavefront = 4 x 16 lanes, two alignments
@@ -35,7 +35,8 @@ constexpr uint32_t NEG5 = 0xC500C500u;    // (-5.0, -5.0)
 constexpr uint32_t NEG6 = 0xC600C600u;    // (-6.0, -6.0)
 constexpr uint32_t NEG256 = 0xDC00DC00u;  // (-256.0, -256.0)
 constexpr uint32_t NEGINF2 = 0xFC00FC00u; // (-inf, -inf)
-constexpr int KPAD = PG_PAD_SCORE;
+// padding rows (beyond the read) score so low that they stay at the local-alignment floor: below minus the longest read
+constexpr int kpad(int C) { return C > 16 ? PG_PAD_SCORE_WIDE : PG_PAD_SCORE; }
 // ksw scoring of KlibAlignerImpl (KlibAligner.cpp:134-142): match 1, mismatch -4, first gap base 5 + 1, every further one 1 --
 // the numbers of the gssw stage, which is why its recurrence is reused as it is
 static_assert(PG_GAP_OPEN == 6 && PG_GAP_EXT == 1, "klib's gapo + gape / gape");
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(64) void pg_klib_local_kernel(KlibArgs a)
 
     const PgWorkItem* itp = a.work + 2 * (size_t)(a.pair_begin + blockIdx.x);
     const LGraphDev g = a.graphs[itp->graph];
+    constexpr int KPAD = kpad(C);
     const uint32_t PADPK = f16_bits(KPAD + 1) | (f16_bits(KPAD + 1) << 16);
 
 #pragma unroll
@@ -355,6 +357,7 @@ __global__ __launch_bounds__(64) void pg_klib_finish_kernel(KlibArgs a)
     constexpr int WIN = finish_win(C);
     constexpr int WINP = finish_winp(C);
     constexpr int ZDW = C / 2;  // dwords of direction bytes per lane per step
+    constexpr int KPAD = kpad(C);
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* prof = lds;                                        // [4 groups][5 codes][ROWS] packed (candidate A | candidate B << 16)
     uint16_t* win = (uint16_t*)(prof + PG_GROUPS * 5 * ROWS);    // [4 groups][WINP] (code A | code B << 8)
@@ -765,6 +768,12 @@ __global__ __launch_bounds__(64) void pg_klib_finish_kernel(KlibArgs a)
 template <int C> hipError_t launch_local(const KlibArgs& a, uint32_t n_pairs, hipStream_t stream)
 {
     const size_t lds = (size_t)PG_GROUPS * 4 * PG_GROUP_LANES * C * sizeof(uint32_t);
+    if (lds > 48 * 1024)
+    {
+        const hipError_t e = hipFuncSetAttribute((const void*)pg_klib_local_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
     hipLaunchKernelGGL(pg_klib_local_kernel<C>, dim3(n_pairs), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
@@ -774,6 +783,12 @@ template <int C> size_t finish_lds()
 }
 template <int C> hipError_t launch_finish(const KlibArgs& a, uint32_t grid, hipStream_t stream)
 {
+    if (finish_lds<C>() > 48 * 1024)
+    {
+        const hipError_t e = hipFuncSetAttribute((const void*)pg_klib_finish_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)finish_lds<C>());
+        if (e != hipSuccess)
+            return e;
+    }
     hipLaunchKernelGGL(pg_klib_finish_kernel<C>, dim3(grid), dim3(64), finish_lds<C>(), stream, a);
     return hipGetLastError();
 }
@@ -793,6 +808,10 @@ hipError_t pg_klib_launch_local(int C, const KlibArgs& a, uint32_t n_pairs, hipS
     case 12: return launch_local<12>(a, n_pairs, stream);
     case 14: return launch_local<14>(a, n_pairs, stream);
     case 16: return launch_local<16>(a, n_pairs, stream);
+    case 20: return launch_local<20>(a, n_pairs, stream);
+    case 24: return launch_local<24>(a, n_pairs, stream);
+    case 28: return launch_local<28>(a, n_pairs, stream);
+    case 32: return launch_local<32>(a, n_pairs, stream);
     default: return hipErrorInvalidValue;
     }
 }
@@ -811,6 +830,10 @@ hipError_t pg_klib_launch_finish(int C, const KlibArgs& a, uint32_t grid, hipStr
     case 12: return launch_finish<12>(a, grid, stream);
     case 14: return launch_finish<14>(a, grid, stream);
     case 16: return launch_finish<16>(a, grid, stream);
+    case 20: return launch_finish<20>(a, grid, stream);
+    case 24: return launch_finish<24>(a, grid, stream);
+    case 28: return launch_finish<28>(a, grid, stream);
+    case 32: return launch_finish<32>(a, grid, stream);
     default: return hipErrorInvalidValue;
     }
 }

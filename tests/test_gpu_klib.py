@@ -152,7 +152,8 @@ def test_klib_stage_150bp_site(gpu_ctx):
 
 
 def test_klib_stage_long_reads(gpu_ctx):
-    """300..512 bp reads: R = 5..8 rows per lane, 8 direction bytes per lane per step."""
+    """300..512 bp reads (the general kernels where a path is shorter than a read: R = 5..8 rows per lane, 8 direction bytes
+    per lane per step; the packed ones with C = 20..32 rows per lane otherwise)."""
     chk = checker()
     rng = random.Random(fuzzgen.salted(11))
     graphs, paths, reads, gor, want = [], [], [], [], []
@@ -273,19 +274,21 @@ def _packed_case(seed, n_graphs, reads_per_graph, max_len, flank):
     return graphs, paths, reads, gor, want
 
 
-@pytest.mark.parametrize("seed,max_len,flank", [(501, 150, 160), (502, 250, 260), (503, 100, 130), (504, 33, 40)])
+@pytest.mark.parametrize("seed,max_len,flank", [(501, 150, 160), (502, 250, 260), (503, 100, 130), (504, 33, 40), (505, 380, 400),
+                                                (506, 512, 520)])
 def test_klib_packed_kernels_fuzz(gpu_ctx, seed, max_len, flank):
     """Mixed read lengths (several rows-per-lane classes in one batch), ties between paths, N, lower case, long gaps, clips."""
-    graphs, paths, reads, gor, want = _packed_case(seed, 40, 60, max_len, flank)
+    graphs, paths, reads, gor, want = _packed_case(seed, 40 if max_len <= 250 else 12, 60 if max_len <= 250 else 40, max_len, flank)
     flags, got = gpu_klib(gpu_ctx, graphs, paths, reads, gor, expect_packed=True)
     n = check(flags, got, want, reads, "klib-packed-%d" % seed)
     assert n > 0.85 * len(reads)
     assert sum(1 for w in want if w["status"] == 2) > 3
 
 
-def test_klib_packed_and_general_kernels_agree(gpu_ctx, monkeypatch):
+@pytest.mark.parametrize("seed,max_len,flank", [(611, 200, 210), (612, 330, 340)])
+def test_klib_packed_and_general_kernels_agree(gpu_ctx, monkeypatch, seed, max_len, flank):
     """The same batch through both kernel sets (PG_KLIB_GENERAL forces the general one): identical results."""
-    graphs, paths, reads, gor, want = _packed_case(611, 25, 40, 200, 210)
+    graphs, paths, reads, gor, want = _packed_case(seed, 25 if max_len <= 250 else 10, 40, max_len, flank)
     f1, g1 = gpu_klib(gpu_ctx, graphs, paths, reads, gor, expect_packed=True)
     monkeypatch.setenv("PG_KLIB_GENERAL", "1")
     f2, g2 = gpu_klib(gpu_ctx, graphs, paths, reads, gor, expect_packed=False)

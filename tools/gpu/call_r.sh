@@ -1,7 +1,6 @@
 #!/bin/bash
-# klib stage at several read lengths (rows-per-lane classes C = 8, 10, 12, 16)
 R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
-O=$R/gpurun_out/r; mkdir -p $O; : > $O/klib_readlen.jsonl
-for L in 100 150 180 250; do
-  ${PGENV:-env} timeout 300 python tools/klib_probe.py 400000 $L 2>/dev/null | tail -1 | tee -a $O/klib_readlen.jsonl
-done
+O=$R/gpurun_out/r; mkdir -p $O
+( time timeout 600 python -m pytest tests/test_gpu_klib.py tests/test_gpu_workflow.py tests/test_gpu_parity.py -m gpu -q --timeout 500 -p no:cacheprovider ) > $O/pytest.log 2>&1; grep -E "passed|failed|Error|error" $O/pytest.log | tail -5
+PG_SEED_SALT=123 timeout 600 python -m pytest tests/test_gpu_klib.py -m gpu -q --timeout 500 -p no:cacheprovider 2>&1 | tail -1
+PG_SEED_SALT=456 timeout 600 python -m pytest tests/test_gpu_klib.py -m gpu -q --timeout 500 -p no:cacheprovider 2>&1 | tail -1

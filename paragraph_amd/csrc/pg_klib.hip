@@ -977,7 +977,9 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
             return pg_fail(ctx, PG_ERR_UNSUPPORTED, "pg_batch_klib_align: batch too large (CIGAR scratch index)");
         const int C = pg_var_c(pg_variant_of(max_len));
         const uint32_t waves = (n_work + 7u) / 8u;
-        const uint32_t grid = std::min<uint32_t>(waves, (uint32_t)n_cu * 10u);
+        // resident wavefronts per CU: 10 by LDS for reads up to 250 bases, 4 (one per SIMD, by registers) beyond; each one owns
+        // z_bytes of direction scratch
+        const uint32_t grid = std::min<uint32_t>(waves, (uint32_t)n_cu * (C > 16 ? 4u : 10u));
         const uint64_t z_bytes = pg_klib_finish_z_bytes(C);
         st = grow(ctx, &ix->d_cigars, &ix->cigars_cap, std::max<size_t>((size_t)n_work * cig_cap, 1));
         if (st == PG_OK) st = grow(ctx, &ix->d_z, &ix->z_cap, std::max<size_t>((size_t)grid * z_bytes, 1));

@@ -680,19 +680,26 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     }
 }
 
-// One launch covers both graph directions: even workgroups run the forward-graph body (stores the H trace),
-// odd ones the reversed-graph body (scores + multi flags only).  With AF_REVERSE_GRAPH off (both_dirs == 0)
-// every workgroup is a forward-graph one.
+// One launch covers both graph directions: forward-graph workgroups (they store the H trace) and reversed-graph ones (scores
+// + multi flags only, about a fifth cheaper).  Workgroups go to the eight XCDs of the chip round-robin by index, so "even =
+// forward, odd = reversed" would give four XCDs all the forward-graph work and the other four all the reversed-graph work, and
+// the launch would last as long as the heavier half.  Instead the direction changes every EIGHT workgroups: XCD x gets
+// workgroups x, x + 8, x + 16, ... = pair p forward, pair p reversed, pair p + 8 forward, ... -- the same mix on every XCD.
+// With AF_REVERSE_GRAPH off (both_dirs == 0) every workgroup is a forward-graph one.
 template <int C, bool WIDE>
 __global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if (a.both_dirs)
     {
-        if (blockIdx.x & 1u)
-            pg_fill_body<C, 1, WIDE>(a, blockIdx.x >> 1, lds);
+        const uint32_t j = blockIdx.x >> 3;
+        const uint32_t pair = (j >> 1) * 8u + (blockIdx.x & 7u);
+        if (pair >= a.n_pairs)
+            return;  // the grid is rounded up to whole runs of eight
+        if (j & 1u)
+            pg_fill_body<C, 1, WIDE>(a, pair, lds);
         else
-            pg_fill_body<C, 0, WIDE>(a, blockIdx.x >> 1, lds);
+            pg_fill_body<C, 0, WIDE>(a, pair, lds);
     }
     else
         pg_fill_body<C, 0, WIDE>(a, blockIdx.x, lds);
@@ -715,7 +722,8 @@ static hipError_t launch_c(PgFillArgs args, uint32_t n_pairs, bool revg, size_t 
             return e;
     }
     args.both_dirs = revg ? 1u : 0u;
-    hipLaunchKernelGGL(fn, dim3(revg ? 2 * n_pairs : n_pairs), dim3(64), lds, stream, args);
+    args.n_pairs = n_pairs;
+    hipLaunchKernelGGL(fn, dim3(revg ? (n_pairs + 7u) / 8u * 16u : n_pairs), dim3(64), lds, stream, args);
     return hipGetLastError();
 }
 

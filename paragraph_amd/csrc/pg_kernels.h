@@ -10,7 +10,8 @@ struct PgFillArgs
 {
     const PgWorkItem* items;
     uint32_t item_begin;
-    uint32_t both_dirs;  // 1: even workgroups = forward graph, odd = reversed graph; 0: forward graph only
+    uint32_t both_dirs;  // 1: forward-graph and reversed-graph workgroups alternate in runs of eight (pg_fill_kernel); 0: forward only
+    uint32_t n_pairs;    // work-item pairs of this launch
     const PgGraphDev* graphs;
     const PgNode* nodes;
     const uint32_t* preds;

@@ -380,3 +380,34 @@ def test_config1_multigrmpy_vcf_to_vcf(tmp_path):
         assert doc["samples"][called]["gt"]["GT"] == "%s:1/%s:1" % (f[2], f[2])
         assert doc["samples"][other]["gt"]["GT"] == "."
     assert not os.listdir(tmp_path / "scratch")
+
+
+def test_config1_multigrmpy_from_json_events(tmp_path):
+    """The other input form of the reference's entry point (multigrmpy.py:68-88): a JSON list of events without graphs; each gets
+    its graph from graph_templates.make_graph and keeps its own ID."""
+    import gzip
+    import json
+    from paragraph_amd import multigrmpy
+    d = os.path.join(ROOT, "tests", "golden", "sites", "round-trip")
+    out = tmp_path / "out"
+    args = multigrmpy.make_argument_parser().parse_args([
+        "-i", os.path.join(d, "candidates.json"), "-m", os.path.join(d, "samples.txt"), "-r", os.path.join(d, "dummy.fa"),
+        "-o", str(out), "-t", "2", "-M", "10000", "--scratch-dir", str(tmp_path / "scratch")])
+    cwd = os.getcwd()
+    os.chdir(d)
+    try:
+        assert multigrmpy.run(args) is None  # no VCF to write back into
+    finally:
+        os.chdir(cwd)
+    with gzip.open(out / "genotypes.json.gz", "rt") as f:
+        docs = {doc["graphinfo"]["ID"]: doc for doc in json.load(f)}
+    assert set(docs) == {"test-ins", "test-del"}
+    # (the events of candidates.json are not the variants of candidates.vcf -- a 2-base swap and a 3-base deletion -- so no
+    # particular call is expected from the handful of reads; the run has to go through and give complete documents)
+    for rid, doc in docs.items():
+        assert doc["graphinfo"]["sequencenames"][0] == "REF"
+        for sample in ("sample1", "sample2"):
+            gt = doc["samples"][sample]["gt"]
+            assert isinstance(gt["GT"], str) and gt["filters"], (rid, sample, gt)
+            assert "alleles" in doc["samples"][sample] and "breakpoints" in doc["samples"][sample]
+    assert not os.path.exists(out / "genotypes.vcf.gz")

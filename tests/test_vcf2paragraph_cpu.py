@@ -93,3 +93,15 @@ def test_indexed_fasta_reader_matches_plain_text():
         whole = "".join(parts)
         for a, b in ((0, 10), (55, 190), (len(whole) - 7, len(whole) + 5), (1499, 1510)):
             assert ref.fetch(chrom, a, b) == whole[a:b]
+
+
+def test_command_line_on_the_swaps_vcf(tmp_path):
+    """`python -m paragraph_amd.vcf2paragraph -r swaps.fa -g alleles -R chrA.vcf out.json` (the options
+    share/test-data/paragraph/generate.sh uses for these graphs) writes the same document."""
+    out = tmp_path / "chrA.json"
+    assert v2p.main(["-r", os.path.join(SWAPS, "swaps.fa"), "-g", "alleles", "-R", os.path.join(D, "chrA.vcf"), str(out)]) == 0
+    got = json.load(open(out))
+    want = json.load(open(os.path.join(SWAPS, "chrA.json")))
+    got.pop("model_name")
+    want.pop("model_name")
+    assert got == want

@@ -15,10 +15,13 @@ site, arr = synth.config2_reads_packed(n, read_len=150, seed=2)
 ctx = capi.Context(0, workspace_bytes=64 << 30)
 G = ctx.upload_graphs([(site.seqs, site.edges)])
 G.set_labels([site.labels])
+import numpy as np  # noqa: E402
+frag = np.arange(n, dtype=np.uint32) // 2
 batches = []
 for _ in range(2):
     b = ctx.new_batch()
     b.upload(G, synth.packed_to_capi(arr))
+    b.set_fragments(frag)
     batches.append(b)
 
 

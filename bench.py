@@ -46,6 +46,11 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+# what the kernels compute in: two 16-bit lanes per VGPR (read / reverse complement), each an IEEE half holding the exact
+# integer 1024 + score + frame (every integer below 2048 is exact in f16), i.e. integer DP carried by v_pk_*_f16 -- gssw's
+# u8 (reads <= 250 bp) / i16 (251-512 bp) score semantics bit for bit, not a reduced-precision approximation
+DTYPE = "f16x2 packed, exact integers < 2048 (gssw u8 / i16 score semantics)"
+SIMDS, CLOCK_GHZ = 256 * 4, 2.4  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
 CIGAR_STRIDE = 128
 
 
@@ -60,6 +65,10 @@ def parse_args():
                          "DEL/INS sites at 30x, sharded over the ranks (strong scaling)")
     ap.add_argument("--sites", type=int, default=10000, help="sites of the config3 set (the whole job, all ranks together)")
     ap.add_argument("--sites-steps", type=int, default=3, help="timed passes of the config3 leg of the default run (0 = skip)")
+    ap.add_argument("--hot-site-depth", type=float, default=0.0,
+                    help="config3: add one site sequenced this deep (e.g. 1500 = ~10 000 reads, grmpy's per-site cap)")
+    ap.add_argument("--split-reads", type=int, default=5000,
+                    help="config3 with N > 1: a site with this many reads or more is split over all ranks by fragment id")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--workspace-gib", type=float, default=64.0,
                     help="HBM budget for traceback state (two halves: trace of chunk i overlaps fill of chunk i+1)")
@@ -67,8 +76,15 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream-batches", type=int, default=16,
                     help="batches of the PCIe-inclusive streaming leg (0 = skip; reported beside the headline value)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_r02.json"),
-                    help="PMC-derived HBM bytes per fill launch (written by tools/pmc_traffic.py), optional")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_r03.json"),
+                    help="PMC-derived HBM bytes per fill launch (written by tools/pmc_traffic.py); used only when the kernel "
+                         "sources it was collected on are the ones of this build (kernel_source_sha)")
+    ap.add_argument("--sq-json", default=os.path.join(ROOT, "profiles", "r03_sq_counters.json"),
+                    help="SQ counters of one fill launch (tools/sq_collect.sh + tools/sq_summary.py), same rule")
+    ap.add_argument("--collective", default="auto", choices=["auto", "on", "off"],
+                    help="the all-reduce of the counter table inside every step.  auto/on: always -- with ONE rank a world-size-1 "
+                         "RCCL communicator is created, so N = 1 runs the code path of N = 8 (auto falls back to off, and says "
+                         "so in `dist`, if the communicator cannot be created); off: only with more than one rank")
     # internal: the CPU baseline runs in its own process (it forks workers; the GPU process must not)
     ap.add_argument("--cpu-leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-reads-file", help=argparse.SUPPRESS)
@@ -266,6 +282,58 @@ def verify_against_reference(capi, res, ops, ref_res, ref_cig):
 
 
 # ---------------------------------------------------------------------------------------------------
+# bounds that bind: measured HBM traffic and VALU issue of the fill kernel (rocprofv3 --pmc, collected separately)
+# ---------------------------------------------------------------------------------------------------
+def _counter_file(path, sha):
+    """A counter file is evidence for THIS run only if it was collected on the kernel sources of this build."""
+    if not path or not os.path.exists(path):
+        return None, {"file": None, "usable": False, "why": "no counter file"}
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+    except Exception as e:  # noqa: BLE001
+        return None, {"file": os.path.relpath(path, ROOT), "usable": False, "why": "unreadable: %s" % e}
+    src = {"file": os.path.relpath(path, ROOT), "kernel_source_sha": doc.get("kernel_source_sha"),
+           "collected_at_head": doc.get("collected_at_head"), "reads_in_pmc_run": doc.get("reads_in_pmc_run"),
+           "this_build_kernel_source_sha": sha, "usable": doc.get("kernel_source_sha") == sha}
+    if not src["usable"]:
+        src["why"] = "collected on other kernel sources: not reported as this run's"
+        return None, src
+    return doc, src
+
+
+def measured_bounds(args, reads_per_launch, avg_launch_s):
+    """roofline fields beyond the contract's formula: what physically bounds pg_fill_kernel.
+      traffic            HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate passes, calibrated)
+      hbm_measured_*     traffic / this run's average launch duration, against the 8 TB/s peak
+      valu               SQ counters of one launch: VALU instructions per wave-step, cycles per instruction, and the share of
+                         the SIMDs' issue cycles this run's launch duration leaves used (insts x cycles / (SIMDs x clock x t))"""
+    from paragraph_amd import build as pgbuild
+    sha = pgbuild.kernel_source_sha()
+    out = {"traffic": None, "hbm_measured_gbs": None, "hbm_measured_frac": None, "valu": None}
+    doc, src = _counter_file(args.traffic_json, sha)
+    out["traffic_source"] = src
+    if doc and avg_launch_s > 0:
+        out["traffic"] = doc["hbm_bytes_per_read"] * reads_per_launch
+        out["hbm_measured_gbs"] = out["traffic"] / avg_launch_s / 1e9
+        out["hbm_measured_frac"] = out["hbm_measured_gbs"] / HBM_PEAK_GBS
+    doc, src = _counter_file(args.sq_json, sha)
+    if doc and avg_launch_s > 0:
+        n = doc["reads_in_pmc_run"]
+        insts = doc["counters"]["SQ_INSTS_VALU"] / n * reads_per_launch
+        cyc = 4.0 * doc["counters"]["SQ_ACTIVE_INST_VALU"] / doc["counters"]["SQ_INSTS_VALU"]  # counter unit: 4 cycles
+        out["valu"] = {"insts_per_wave_step": doc["per_wave_step"]["SQ_INSTS_VALU"], "cycles_per_inst": cyc,
+                       "insts_per_launch": insts, "issue_floor_ms": insts * cyc / (SIMDS * CLOCK_GHZ * 1e9) * 1e3,
+                       "issue_frac": insts * cyc / (SIMDS * CLOCK_GHZ * 1e9) / avg_launch_s,
+                       "simds": SIMDS, "clock_ghz": CLOCK_GHZ, "source": src,
+                       "note": "share of the chip's VALU issue cycles (1 024 SIMDs at 2.4 GHz) the fill launches of THIS run "
+                               "used: the bound that binds (integer DP on packed VALU ops, no MFMA)"}
+    else:
+        out["valu"] = {"source": src}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
 # launcher
 # ---------------------------------------------------------------------------------------------------
 def _free_port():
@@ -289,27 +357,61 @@ def spawn_ranks(args):
 # ---------------------------------------------------------------------------------------------------
 class SiteSet:
     """The config3 data set + its partition.  Every rank holds the graphs of ALL sites (the counter table then has the
-    global layout on every rank and the all-reduce needs no index translation) and the reads of its own shard."""
+    global layout on every rank and the all-reduce needs no index translation) and the reads of its own shard.  Whole sites
+    go to one rank (dist.partition_sites); a HOT site -- `split_reads` reads or more; grmpy caps a site at 10 000,
+    src/c++/main/grmpy.cpp:67 -- is split over all ranks by fragment id (dist.partition_fragments), never by read: counts are
+    per fragment with mate-union semantics (ReadCounting.cpp:52-94, Fragment.cpp:141-181), so mates stay on one rank and the
+    all-reduce then really sums that site's counters."""
 
-    def __init__(self, sites, read_len, world):
+    def __init__(self, sites, read_len, world, split_reads=5000):
         from paragraph_amd import dist as pgdist
         self.sites = sites
         self.L = read_len
+        self.world = world
         self.n_reads_site = np.array([len(s.reads) for s in sites], dtype=np.int64)
         self.g_len = np.array([s.site.total_len for s in sites], dtype=np.int64)
         self.weights = self.n_reads_site * read_len * self.g_len  # DP cells per site
-        self.parts = pgdist.partition_sites(self.weights, world)
+        self.hot = [int(i) for i in np.nonzero(self.n_reads_site >= split_reads)[0]] if world > 1 else []
+        w = self.weights.copy()
+        w[self.hot] = 0
+        whole = np.array([i for i in range(len(sites)) if i not in set(self.hot)], dtype=np.int64)
+        self.parts = [whole[p] for p in pgdist.partition_sites(w[whole], world)] if len(whole) else [whole] * world
+        self.hot_reads = {i: pgdist.partition_fragments(sites[i].fragment, world) for i in self.hot}
 
-    def shard_arrays(self, idx):
-        ss = [self.sites[i] for i in idx]
-        arr = np.concatenate([s.reads for s in ss]) if ss else np.zeros((0, self.L), np.uint8)
-        gor = np.concatenate([np.full(len(self.sites[i].reads), i, dtype=np.uint32) for i in idx]) if ss else np.zeros(0, np.uint32)
-        frag = np.concatenate([s.fragment for s in ss]) if ss else np.zeros(0, np.uint32)
-        rev = np.concatenate([s.is_reverse for s in ss]) if ss else np.zeros(0, np.uint8)
-        return arr, gor, frag.astype(np.uint32), rev.astype(np.uint8)
+    def rank_arrays(self, rank):
+        """reads, graph of read, fragment id, strand flag of one rank: its whole sites + its fragments of the hot sites"""
+        pieces = [(i, None) for i in self.parts[rank]] + [(i, self.hot_reads[i][rank]) for i in self.hot]
+        return self._gather(pieces)
 
-    def b_alg(self, idx):
-        return int(sum(int(self.n_reads_site[i]) * (6 * self.L * int(self.g_len[i]) + self.L + 64) for i in idx))
+    def all_arrays(self):
+        return self._gather([(i, None) for i in range(len(self.sites))])
+
+    def _gather(self, pieces):
+        arr, gor, frag, rev = [], [], [], []
+        for i, sel in pieces:
+            s = self.sites[i]
+            sel = slice(None) if sel is None else sel
+            r = s.reads[sel]
+            arr.append(r)
+            gor.append(np.full(len(r), i, dtype=np.uint32))
+            frag.append(np.asarray(s.fragment)[sel])
+            rev.append(np.asarray(s.is_reverse)[sel])
+        if not arr:
+            return np.zeros((0, self.L), np.uint8), np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint8)
+        return (np.concatenate(arr), np.concatenate(gor), np.concatenate(frag).astype(np.uint32),
+                np.concatenate(rev).astype(np.uint8))
+
+    def rank_weight(self, rank):
+        return float(self.weights[self.parts[rank]].sum()
+                     + sum(len(self.hot_reads[i][rank]) * self.L * int(self.g_len[i]) for i in self.hot))
+
+    def rank_reads(self, rank):
+        return int(self.n_reads_site[self.parts[rank]].sum() + sum(len(self.hot_reads[i][rank]) for i in self.hot))
+
+    def b_alg(self, rank):
+        b = sum(int(self.n_reads_site[i]) * (6 * self.L * int(self.g_len[i]) + self.L + 64) for i in self.parts[rank])
+        b += sum(len(self.hot_reads[i][rank]) * (6 * self.L * int(self.g_len[i]) + self.L + 64) for i in self.hot)
+        return int(b)
 
 
 def run_sites_leg(args, env, ctx, capi, synth, sset, steps, warmup, timed_events):
@@ -321,32 +423,39 @@ def run_sites_leg(args, env, ctx, capi, synth, sset, steps, warmup, timed_events
     graphs = ctx.upload_graphs([(s.site.seqs, s.site.edges) for s in sset.sites])
     graphs.set_labels([s.site.labels for s in sset.sites])
     n_counters = int(graphs.layout.n_counters)
-    mine = sset.parts[rank]
-    arr, gor, frag, rev = sset.shard_arrays(mine)
+    arr, gor, frag, rev = sset.rank_arrays(rank)
     batch = ctx.new_batch()
     batch.upload(graphs, synth.packed_to_capi(arr), gor)
     batch.set_fragments(frag, rev)
-    table = torch.zeros(n_counters, dtype=torch.int32, device=env["device"])
+    tables = [torch.zeros(n_counters, dtype=torch.int32, device=env["device"]) for _ in range(2)]
+    red = env["reducer"]
     ctx.sync()
+    torch.cuda.synchronize()  # torch.zeros ran on torch's stream, the library zeroes and counts on its own
+    pass_no = [0]
 
-    def one_pass(b, t):
+    def one_pass(b):
+        # stream-ordered: zero + fills + traceback + count are queued on the library's streams, the reduce behind an event on
+        # a stream of torch's, the next pass (other table) right away -- the host waits for nothing until the barrier
+        t = tables[pass_no[0] & 1]
+        pass_no[0] += 1
+        if red:
+            red.acquire(t)
         ctx.counts_zero(t.data_ptr(), n_counters)
         b.align(capi.AF_ALL)
         b.count(remove_nonuniq=True, bad_align_frac=0.8, d_counts=t.data_ptr())
-        ctx.sync_compute()
-        if world > 1:
-            pgdist.allreduce_counts(t)  # the only collective of the path
-            torch.cuda.synchronize()
+        if red:
+            red.reduce(t)  # the only collective of the path
+        return t
 
     for _ in range(warmup):
-        one_pass(batch, table)
+        one_pass(batch)
     env["barrier"]()
     if timed_events:
         ctx.timing_enable(True)
         ctx.timing_reset()
     t0 = time.perf_counter()
     for _ in range(steps):
-        one_pass(batch, table)
+        table = one_pass(batch)
     env["barrier"]()
     elapsed = env["max_over_ranks"](time.perf_counter() - t0)
     tim = None
@@ -359,8 +468,10 @@ def run_sites_leg(args, env, ctx, capi, synth, sset, steps, warmup, timed_events
                      "1 all-reduce of the %d-counter table per pass" % (n_sites, sset.L, n_reads, world, n_counters),
            "sites": n_sites, "reads": n_reads, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
            "sites_per_s": n_sites * steps / elapsed, "reads_per_s": n_reads * steps / elapsed, "scaling": "strong",
-           "shard_reads": [int(sset.n_reads_site[p].sum()) for p in sset.parts],
-           "shard_imbalance": float(max(sset.weights[p].sum() for p in sset.parts) * world / max(1, sset.weights.sum())),
+           "shard_reads": [sset.rank_reads(r) for r in range(world)],
+           "shard_imbalance": float(max(sset.rank_weight(r) for r in range(world)) * world / max(1, sset.weights.sum())),
+           "hot_sites_split_by_fragment": [{"site": i, "reads": int(sset.n_reads_site[i]),
+                                            "reads_per_rank": [len(x) for x in sset.hot_reads[i]]} for i in sset.hot],
            "counters": n_counters, "reduce_equals_single": None}
     got = table.cpu().numpy().view(np.uint32).copy()
     tall = got[int(graphs.layout.tally_base):].reshape(-1, 4)
@@ -369,11 +480,12 @@ def run_sites_leg(args, env, ctx, capi, synth, sset, steps, warmup, timed_events
     out["table_sum"] = int(got.astype(np.uint64).sum())
     if world > 1 and rank == 0:
         # 1-rank pass over ALL sites on this rank's device: the reduced table must equal it entry for entry
-        arr1, gor1, frag1, rev1 = sset.shard_arrays(np.arange(n_sites))
+        arr1, gor1, frag1, rev1 = sset.all_arrays()
         b1 = ctx.new_batch()
         b1.upload(graphs, synth.packed_to_capi(arr1), gor1)
         b1.set_fragments(frag1, rev1)
         t1 = torch.zeros(n_counters, dtype=torch.int32, device=env["device"])
+        torch.cuda.synchronize()
         ctx.counts_zero(t1.data_ptr(), n_counters)
         b1.align(capi.AF_ALL)
         b1.count(remove_nonuniq=True, bad_align_frac=0.8, d_counts=t1.data_ptr())
@@ -384,13 +496,35 @@ def run_sites_leg(args, env, ctx, capi, synth, sset, steps, warmup, timed_events
         b1.close()
     batch.close()
     graphs.close()
-    return out, tim, sset.b_alg(mine), len(arr)
+    return out, tim, sset.b_alg(rank), len(arr)
 
 
 # ---------------------------------------------------------------------------------------------------
 # one rank
 # ---------------------------------------------------------------------------------------------------
+_JSON_FD = None
+
+
+def quiet_stdout():
+    """Everything but the result line goes to stderr: native libraries print to file descriptor 1 behind Python's back (RCCL
+    writes its version banner there when a communicator is created, flushed at exit -- i.e. AFTER the JSON line).  fd 1 is
+    pointed at stderr for the life of the process; the JSON line is written to the saved original."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def print_result_line(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    fd = _JSON_FD if _JSON_FD is not None else 1
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def main_rank(args):
+    quiet_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -409,7 +543,9 @@ def main_rank(args):
     if want_sites:
         log("generating the config3 site set")
         sites = synth.mixed_sites_parallel(args.sites, seed=3, procs=max(1, min(16, ncpu // max(1, world))), read_len=L)
-        sset = SiteSet(sites, L, world)
+        if args.hot_site_depth > 0:  # one deep site on top of the set: split over the ranks by fragment id
+            sites = sites + synth.mixed_sites(1, seed=11, read_len=L, depth=args.hot_site_depth, site_streams=True)
+        sset = SiteSet(sites, L, world, split_reads=args.split_reads)
     log("data ready")
 
     import torch
@@ -421,14 +557,26 @@ def main_rank(args):
     dev_index = local_rank % ndev
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
-    backend = None
-    if world > 1:
+    backend, pg_error = None, None
+    want_pg = world > 1 or args.collective in ("auto", "on")
+    if want_pg:
         backend = "gloo" if shared else "nccl"
-        if shared:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=device)
-        log("process group: backend %s, world %d, device %d%s" % (backend, dist.get_world_size(), dev_index, " (shared)" if shared else ""))
+        if world == 1:  # a communicator of one rank: the RCCL code path of N = 8 on the one GPU
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        try:
+            if shared:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=device)
+        except Exception as e:  # noqa: BLE001
+            if world > 1 or args.collective == "on":
+                raise
+            backend, pg_error = None, "%s: %s" % (type(e).__name__, e)
+        if backend:
+            log("process group: backend %s, world %d, device %d%s" % (dist.get_backend(), dist.get_world_size(), dev_index, " (shared)" if shared else ""))
 
     from paragraph_amd import capi
     from paragraph_amd import dist as pgdist
@@ -436,6 +584,7 @@ def main_rank(args):
     if shared:
         ws_gib = min(ws_gib, max(8.0, 160.0 / ((world + ndev - 1) // ndev)))
     ctx = capi.Context(dev_index, workspace_bytes=int(ws_gib * (1 << 30)))
+    reducer = pgdist.CountReduce(ctx, device) if backend else None
 
     def barrier():
         ctx.sync()
@@ -451,9 +600,24 @@ def main_rank(args):
         return float(t.item())
 
     env = {"torch": torch, "dist": dist, "rank": rank, "world": world, "device": device, "barrier": barrier,
-           "max_over_ranks": max_over_ranks}
+           "max_over_ranks": max_over_ranks, "reducer": reducer}
     dist_info = {"world": world, "backend": backend, "shared_device": bool(shared), "devices_visible": ndev,
-                 "launcher": os.environ.get("PG_BENCH_LAUNCHER", "external torch.distributed.run" if world > 1 else "single process")}
+                 "launcher": os.environ.get("PG_BENCH_LAUNCHER", "external torch.distributed.run" if world > 1 else "single process"),
+                 "collective_in_step": bool(reducer), "collective": None if not reducer else
+                 ("all_reduce(SUM) of the int32 counter table on a stream of its own, ordered by events against the library's "
+                  "count stream (paragraph_amd.dist.CountReduce): no host synchronisation inside a step, two tables take turns"
+                  if not reducer.blocking else "host hop under gloo (ranks share a device): compute streams drained, then reduced"),
+                 "process_group_error": pg_error}
+    if backend:
+        dist_info["backend"] = dist.get_backend()
+        dist_info["world"] = dist.get_world_size()
+        mine = {"rank": rank, "local_rank": local_rank, "device": dev_index, "name": torch.cuda.get_device_name(dev_index)}
+        if world > 1:
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+            dist_info["ranks"] = every
+        else:
+            dist_info["ranks"] = [mine]
 
     out = None
     if headline3:
@@ -464,7 +628,7 @@ def main_rank(args):
             out = {
                 "metric": "150bp reads aligned/sec (whole node)", "value": sites_out["reads_per_s"], "unit": "reads/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sites_out["ms_per_step"],
-                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u16x2 packed (8-bit scores)",
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE,
                 "data": "synthetic",
                 "config": {"workload": sites_out["config"], "sites": sites_out["sites"], "reads": sites_out["reads"],
                            "read_len": L, "graph_len": float(np.mean(sset.g_len)), "parallelism": "sites x%d" % world,
@@ -488,13 +652,14 @@ def main_rank(args):
                 out["sites"] = sites_out
     rc = 0
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print_result_line(out)
         if out.get("verified") and out["verified"]["mismatches"]:
             rc = 3
         if out.get("sites") and out["sites"].get("reduce_equals_single") is False:
             rc = 3
-    if world > 1:
-        dist.barrier()
+    if backend:
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
     return rc
 
@@ -525,46 +690,64 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
     ctx.sync()
     log("uploaded in %.2fs" % t_upload)
 
-    # per-site counter table {count, READS, FWD, REV} x (nodes, edges, sequence sets) + filter tallies: a torch
-    # tensor so that the reduce is ONE RCCL all-reduce over xGMI on device memory, no host hop
+    # per-site counter table {count, READS, FWD, REV} x (nodes, edges, sequence sets) + filter tallies: torch tensors so that
+    # the reduce is ONE RCCL all-reduce over xGMI on device memory, no host hop.  Two tables take turns like the batches:
+    # step n + 1 zeroes and fills the other one while reduce n runs.
     n_counters = int(graphs.layout.n_counters)
-    counts_t = torch.zeros(n_counters, dtype=torch.int32, device=device)
-
+    tables = [torch.zeros(n_counters, dtype=torch.int32, device=device) for _ in range(2)]
+    torch.cuda.synchronize()
+    red = env["reducer"]
     step_no = [0]
 
-    def step():
-        b = batches[step_no[0] & 1]
+    def step(red):
+        k = step_no[0] & 1
+        b, t = batches[k], tables[k]
         step_no[0] += 1
-        ctx.counts_zero(counts_t.data_ptr(), n_counters)  # on the stream the count kernels run on: ordered with them
+        if red:
+            red.acquire(t)  # the count stream waits for the event behind this table's previous reduce; the host does not
+        ctx.counts_zero(t.data_ptr(), n_counters)  # on the stream the count kernels run on: ordered with them
         b.align(capi.AF_ALL)
-        b.count(remove_nonuniq=True, bad_align_frac=0.8, d_counts=counts_t.data_ptr())
-        if world > 1:
-            ctx.sync_compute()
-            pgdist.allreduce_counts(counts_t)
-            torch.cuda.synchronize()
+        b.count(remove_nonuniq=True, bad_align_frac=0.8, d_counts=t.data_ptr())
+        if red:
+            red.reduce(t)  # behind an event of the count stream, on a stream of its own: nothing blocks the host here
+
+    def timed(red, steps):
+        env["barrier"]()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(red)
+        env["barrier"]()
+        return env["max_over_ranks"](time.perf_counter() - t0)
 
     for _ in range(args.warmup):
-        step()
+        step(red)
     env["barrier"]()
     log("warmup done")
     ctx.timing_enable(True)
     ctx.timing_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    env["barrier"]()
-    elapsed = env["max_over_ranks"](time.perf_counter() - t0)
+    elapsed = timed(red, args.steps)
     log("timed region %.3fs" % elapsed)
     tim = ctx.timing()
     ctx.timing_enable(False)
-
+    counts_t = tables[(step_no[0] - 1) & 1]
+    tab = counts_t.cpu().numpy().view(np.uint32).copy()
+    last_batch = batches[(step_no[0] - 1) & 1]
     # results of the last timed step (PCIe-inclusive figure, verification)
-    batch = batches[(step_no[0] - 1) & 1]
+    batch = last_batch
     t0 = time.perf_counter()
     res, ops = batch.download()
     t_download = time.perf_counter() - t0
-    tab = counts_t.cpu().numpy().view(np.uint32)
     site_counts = capi.decode_counts(graphs, tab)[0]
+
+    # A/B for the collective: the same steps again without it (N = 1 only: there it must cost nothing)
+    collective = None
+    if red and world == 1:
+        elapsed_plain = timed(None, args.steps)
+        collective = {"reduces_in_timed_region": args.steps, "ms_per_step_with": elapsed / args.steps * 1e3,
+                      "ms_per_step_without": elapsed_plain / args.steps * 1e3, "with_vs_without": elapsed / elapsed_plain,
+                      "note": "`value` is measured WITH the all-reduce in every step (world-size-1 RCCL communicator = the code "
+                              "path of N = 8); `without` = the same steps right after, no collective"}
+        log("plain region %.3fs" % elapsed_plain)
 
     # PCIe-inclusive leg, streaming form: PINNED host arrays -> device -> results in pinned host arrays, two batch objects
     # and two sets of staging buffers; the upload of batch i+1 and the download of batch i-1 are DMAs on the copy stream
@@ -623,16 +806,9 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
     fill_s = tim["fill_ms"] / 1e3
     reads_per_fill_leg = args.reads * args.steps  # this rank's fill launches
     achieved_gbs = reads_per_fill_leg * b_alg / fill_s / 1e9 if fill_s > 0 else 0.0
-    traffic = None
-    if os.path.exists(args.traffic_json):
-        try:
-            with open(args.traffic_json) as f:
-                per_read = json.load(f).get("hbm_bytes_per_read")
-            # PMC bytes (rocprofv3 FETCH_SIZE x measured 2.0 + WRITE_SIZE, separate passes) per read x the reads one
-            # launch of THIS run processes
-            traffic = per_read * reads_per_fill_leg / max(1, tim["fill_launches"])
-        except Exception:
-            traffic = None
+    launches = max(1, tim["fill_launches"])
+    avg_launch_s = fill_s / launches
+    roof_extra = measured_bounds(args, reads_per_fill_leg / launches, avg_launch_s)
     out = {
         "metric": "150bp reads aligned/sec (whole node)",
         "value": value,
@@ -644,7 +820,7 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u16x2 packed (8-bit scores)",
+        "dtype": DTYPE,
         "data": "synthetic",
         "config": {
             "workload": "configs[1]: 1 DEL graph (200bp flanks, nodes 201/100/201), %d synthetic %dbp reads per GPU, "
@@ -655,10 +831,11 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": roof_extra.pop("traffic"),
             "kernel": "pg_fill_kernel<%d, false>" % (2 * ((L + 31) // 32)),
             "launches": int(tim["fill_launches"]),
             "avg_launch_ms": tim["fill_ms"] / max(1, tim["fill_launches"]),
+            **roof_extra,
             "alg_bytes_per_read": b_alg,
             "alg_bytes_per_launch": b_alg * reads_per_fill_leg / max(1, tim["fill_launches"]),
             "gcups": tim["cells"] / fill_s / 1e9 if fill_s > 0 else 0.0,
@@ -683,6 +860,8 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
                            "over %d rank(s)" % world},
         "dist": dist_info,
     }
+    if collective:
+        out["dist"]["collective_ab"] = collective
     if world == 1 and not args.no_cpu_baseline:
         log("cpu baseline leg")
         base, ref_res, ref_cig = run_cpu_leg(args, arr)

@@ -285,6 +285,26 @@ pg_status pg_batch_count(pg_ctx* ctx, pg_batch* batch, const pg_count_params* pa
 /* Zeroes a caller-owned counter table ON THE CTX STREAM, i.e. ordered against the pg_batch_count calls before and after
  * it (a memset on any other stream is not).  Asynchronous. */
 pg_status pg_counts_zero(pg_ctx* ctx, uint32_t* d_counts, uint64_t n_counters);
+/* ---- Stream-ordered hand-over of the counter table to the caller's collective (the path's ONE all-reduce).
+ * The reference's threads meet in a mutex around the merged counts (src/c++/lib/grmpy/Workflow.cpp:225-231); across GPUs the
+ * meeting point is an RCCL all-reduce that the CALLER issues on a stream of its own.  These three calls order that stream
+ * against the library's count stream WITHOUT blocking the host (pg_ctx_sync_compute is the blocking form):
+ *   pg_ctx_count_record(ctx, ev)  hipEventRecord(ev, count stream): everything pg_counts_zero / pg_batch_count queued so far;
+ *                                 the caller's stream waits for ev before it reduces the table
+ *   pg_ctx_count_wait(ctx, ev)    hipStreamWaitEvent(count stream, ev): later pg_counts_zero / pg_batch_count calls start after
+ *                                 ev -- recorded by the caller behind its reduce -- so a table is not zeroed under a reduce.
+ *                                 With two tables taking turns step n + 1 never waits for reduce n.
+ *   pg_ctx_native_stream          the stream itself, for callers that bring their own event type (torch.cuda.ExternalStream).
+ * native_event / *out are the runtime's handles (hipEvent_t / hipStream_t) passed as plain pointers: no HIP type in the ABI. */
+enum
+{
+    PG_STREAM_FILL = 0,  /* graph fills + seed stages */
+    PG_STREAM_COUNT = 1, /* pick + traceback, count path, pg_counts_zero */
+    PG_STREAM_COPY = 2   /* uploads / downloads */
+};
+pg_status pg_ctx_native_stream(pg_ctx* ctx, int which, void** out);
+pg_status pg_ctx_count_record(pg_ctx* ctx, void* native_event);
+pg_status pg_ctx_count_wait(pg_ctx* ctx, void* native_event);
 /* Copies the count table (if the batch owns it; pass NULL otherwise), per-read supports and path entries
  * (capacity path_cap entries; *n_path receives the number used) to host memory; synchronises. */
 pg_status pg_batch_download_counts(

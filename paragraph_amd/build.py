@@ -18,6 +18,22 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+KERNEL_SHA_SOURCES = ["pg_device.h", "pg_fill.hip", "pg_kernels.h", "pg_pk16.h", "pg_trace.hip"]
+
+
+def kernel_source_sha():
+    """sha256 over the sources of the gssw-stage kernels (fill + traceback and the headers they include), first 16 hex
+    digits.  Counter files collected under rocprofv3 (profiles/traffic_rNN.json, rNN_sq_counters.json) carry the value they
+    were collected at; bench.py reports them only for the kernels they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SHA_SOURCES:
+        h.update(name.encode())
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build_hip(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> paragraph_amd/libparagraph_amd.so (the C-ABI library)."""
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]

@@ -47,7 +47,7 @@ EXPORTS = [
     "pg_batch_path_align", "pg_batch_download_path_flags", "pg_batch_set_active", "pg_graphs_build_kmer_index",
     "pg_batch_kmer_align", "pg_graphs_build_klib_index", "pg_batch_klib_align", "pg_graphs_klib_error", "pg_graphs_klib_last_kernels", "pg_graphs_build_filter_index",
     "pg_host_alloc", "pg_host_free", "pg_host_register", "pg_host_unregister", "pg_counts_zero", "pg_ctx_sync_compute",
-    "pg_render_cigars",
+    "pg_render_cigars", "pg_ctx_native_stream", "pg_ctx_count_record", "pg_ctx_count_wait",
 ]
 
 
@@ -172,6 +172,12 @@ def load_library():
     L.pg_counts_zero.argtypes = [vp, vp, C.c_uint64]
     L.pg_ctx_sync_compute.restype = C.c_int32
     L.pg_ctx_sync_compute.argtypes = [vp]
+    L.pg_ctx_native_stream.restype = C.c_int32
+    L.pg_ctx_native_stream.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.pg_ctx_count_record.restype = C.c_int32
+    L.pg_ctx_count_record.argtypes = [vp, vp]
+    L.pg_ctx_count_wait.restype = C.c_int32
+    L.pg_ctx_count_wait.argtypes = [vp, vp]
     L.pg_render_cigars.restype = C.c_int32
     L.pg_render_cigars.argtypes = [vp, C.c_uint64, vp, vp, C.c_size_t]
     L.pg_render_cigar.restype = C.c_size_t
@@ -223,14 +229,20 @@ def _bases_ptr(bases):
 
 
 class _PinnedBlock:
-    """Owner of one pg_host_alloc block; numpy arrays made over it keep it alive through their .base chain."""
+    """Owner of one pg_host_alloc block.  The ctypes buffer numpy arrays are made over carries a reference to its block
+    (`_owner`), so the block is released when the last array / view over it goes away -- not when the context does."""
 
     def __init__(self, ctx, nbytes):
         self.ctx = ctx
         p = C.c_void_p()
         ctx._chk(ctx.L.pg_host_alloc(ctx.h, max(int(nbytes), 1), C.byref(p)))
         self.ptr = p
-        self.buf = (C.c_uint8 * max(int(nbytes), 1)).from_address(p.value)
+        self.nbytes = max(int(nbytes), 1)
+
+    def buffer(self):
+        buf = (C.c_uint8 * self.nbytes).from_address(self.ptr.value)
+        buf._owner = self  # buffer -> block; the block holds no reference back (no cycle)
+        return buf
 
     def __del__(self):
         try:
@@ -286,21 +298,33 @@ class Context:
         self._chk(self.L.pg_ctx_sync_compute(self.h))
 
     def pinned_empty(self, shape, dtype):
-        """numpy array over page-locked host memory (pg_host_alloc); freed when the last view goes away."""
+        """numpy array over page-locked host memory (pg_host_alloc); the block is freed when the last array / view over it
+        goes away (it must not outlive the context)."""
         dt = np.dtype(dtype)
         n = int(np.prod(shape)) if not isinstance(shape, int) else int(shape)
         blk = _PinnedBlock(self, n * dt.itemsize)
-        a = np.frombuffer(blk.buf, dtype=dt, count=n)
-        a = a.reshape(shape)
-        self._pinned = getattr(self, "_pinned", [])
-        self._pinned.append(blk)  # the ctypes buffer does not own the block: keep it until the context goes
-        return a
+        a = np.frombuffer(blk.buffer(), dtype=dt, count=n)
+        return a.reshape(shape)
 
     def pinned_copy(self, arr):
         a = np.ascontiguousarray(arr)
         out = self.pinned_empty(a.shape, a.dtype)
         out[...] = a
         return out
+
+    def native_stream(self, which=1):
+        """hipStream_t of the ctx as an integer: 0 fill stream, 1 count stream (traceback + count path), 2 copy stream."""
+        p = C.c_void_p()
+        self._chk(self.L.pg_ctx_native_stream(self.h, int(which), C.byref(p)))
+        return p.value
+
+    def count_record(self, native_event):
+        """hipEventRecord(event, count stream) -- `native_event` = the hipEvent_t as an integer."""
+        self._chk(self.L.pg_ctx_count_record(self.h, C.c_void_p(int(native_event))))
+
+    def count_wait(self, native_event):
+        """hipStreamWaitEvent(count stream, event): later counts_zero / Batch.count calls start after the event."""
+        self._chk(self.L.pg_ctx_count_wait(self.h, C.c_void_p(int(native_event))))
 
     def counts_zero(self, d_ptr, n_counters):
         """memset of a caller-owned device counter table on the ctx stream (ordered with Batch.count)."""

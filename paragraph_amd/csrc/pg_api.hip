@@ -13,6 +13,8 @@
 // There is no CPU fallback: without a HIP device every entry point that needs one fails.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -189,9 +191,20 @@ extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
     if (!ctx)
         return PG_ERR_NOMEM;
     ctx->device = device;
+    // The three streams must sit on three HARDWARE queues: kernels of streams that share one run one after the other, and the
+    // design rests on the traceback + count of chunk n running under the fill of chunk n + 1.  The runtime hands its (by
+    // default four) hardware queues of a priority level to streams round-robin over every stream of the process -- with
+    // torch's, RCCL's and other contexts' streams around, two of ours ended up on one queue (fill 9.6 ms + traceback 1.0 ms in
+    // series, profiles/r03_*).  Queues are pooled per priority level, so the count and copy streams are created one level up:
+    // there they share a pool with nobody but each other.  (PG_STREAM_PRIORITY=0 creates all three at the default level.)
+    int prio_least = 0, prio_greatest = 0;
+    if (hipSetDevice(device) == hipSuccess)
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    const char* pe = getenv("PG_STREAM_PRIORITY");
+    const int side_prio = (pe && pe[0] == '0') ? 0 : prio_greatest;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess
-        || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess
-        || hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking) != hipSuccess)
+        || hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, side_prio) != hipSuccess
+        || hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, side_prio) != hipSuccess)
     {
         delete ctx;
         return PG_ERR_HIP;
@@ -311,6 +324,33 @@ extern "C" pg_status pg_ctx_sync_compute(pg_ctx* ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
+    return PG_OK;
+}
+
+// Non-blocking ordering between the count stream and a stream of the caller (the all-reduce of the counter table).
+extern "C" pg_status pg_ctx_native_stream(pg_ctx* ctx, int which, void** out)
+{
+    if (!ctx || !out || which < PG_STREAM_FILL || which > PG_STREAM_COPY)
+        return PG_ERR_INVALID;
+    *out = which == PG_STREAM_FILL ? (void*)ctx->stream : which == PG_STREAM_COUNT ? (void*)ctx->stream2 : (void*)ctx->stream_copy;
+    return PG_OK;
+}
+
+extern "C" pg_status pg_ctx_count_record(pg_ctx* ctx, void* native_event)
+{
+    if (!ctx || !native_event)
+        return PG_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord((hipEvent_t)native_event, ctx->stream2));
+    return PG_OK;
+}
+
+extern "C" pg_status pg_ctx_count_wait(pg_ctx* ctx, void* native_event)
+{
+    if (!ctx || !native_event)
+        return PG_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, (hipEvent_t)native_event, 0));
     return PG_OK;
 }
 

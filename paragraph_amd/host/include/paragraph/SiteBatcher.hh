@@ -94,6 +94,9 @@ public:
     size_t numSites() const;
     SiteCounts const& counts(size_t site) const;
     SiteReadViews const& views(size_t site) const;  // packed sites only
+    // "" or why the device path could not take this site (outside its envelope: a read beyond PG_MAX_READ_LEN, more than
+    // PG_MAX_NODES nodes, ...).  Such a site has empty counts and no MAPPED reads; the other sites of the batch are unaffected.
+    std::string const& error(size_t site) const;
 
 private:
     struct Impl;

@@ -31,10 +31,21 @@ using graphtools::NodeId;
 
 namespace
 {
+// PG_ERR_UNSUPPORTED: the input is outside the envelope of the device kernels (not a failure of the device).  SiteBatcher
+// catches this one per site, so that one oversize site does not take a run over thousands of sites down.
+struct OutsideEnvelope : std::runtime_error
+{
+    using std::runtime_error::runtime_error;
+};
+
 void check(pg_ctx* ctx, pg_status st, const char* what)
 {
-    if (st != PG_OK)
-        throw std::runtime_error(std::string(what) + ": " + pg_strerror(st) + " (" + (ctx ? pg_last_error(ctx) : "") + ")");
+    if (st == PG_OK)
+        return;
+    const std::string msg = std::string(what) + ": " + pg_strerror(st) + " (" + (ctx ? pg_last_error(ctx) : "") + ")";
+    if (st == PG_ERR_UNSUPPORTED)
+        throw OutsideEnvelope(msg);
+    throw std::runtime_error(msg);
 }
 
 // ---- devices: slot s of the device list -> one pg_ctx (own streams, workspace, stage mutex, batch pool) -----------------
@@ -204,7 +215,7 @@ struct GraphCsr
             names.assign(all.begin(), all.end());
         }
         if (names.size() > 64)
-            throw std::logic_error("more than 64 sequence labels on one graph");
+            throw OutsideEnvelope("more than 64 sequence labels on one graph (paragraph_amd.h: PG_MAX_LABELS)");
         for (NodeId n = 0; n != g.numNodes(); ++n)
         {
             const std::string& s = g.nodeSeq(n);
@@ -213,7 +224,7 @@ struct GraphCsr
                 const char u = (char)std::toupper((unsigned char)c);
                 if (g.isSequenceExpansionRequired() && n != 0 && n != g.numNodes() - 1 && u != 'A' && u != 'C' && u != 'G'
                     && u != 'T' && u != 'X')
-                    throw std::logic_error("degenerate node sequences need node expansion, which the device path does not do");
+                    throw OutsideEnvelope("degenerate node sequences need node expansion, which the device path does not do");
             }
             seq += s;
             seq_off.push_back((uint32_t)seq.size());
@@ -996,7 +1007,9 @@ struct SiteBatcher::Impl
     std::vector<std::list<graphtools::Path> const*> paths;
     std::vector<SiteCounts> counts;
     std::vector<SiteReadViews> views;
+    std::vector<std::string> errors;  // per site: why the device path could not take it ("" = fine)
     struct Run;
+    void runAll(BatchParameters const& prm);
 };
 
 SiteBatcher::SiteBatcher() : impl_(new Impl()) {}
@@ -1005,6 +1018,7 @@ size_t SiteBatcher::numSites() const { return impl_->graphs.size(); }
 SiteCounts const& SiteBatcher::counts(size_t site) const { return impl_->counts.at(site); }
 
 SiteReadViews const& SiteBatcher::views(size_t site) const { return impl_->views.at(site); }
+std::string const& SiteBatcher::error(size_t site) const { return impl_->errors.at(site); }
 
 size_t SiteBatcher::addSite(const Graph* graph, std::vector<common::p_Read>* reads, std::list<graphtools::Path> const* paths)
 {
@@ -1060,10 +1074,49 @@ struct SiteBatcher::Impl::Run
 
 void SiteBatcher::run(BatchParameters const& prm)
 {
-    impl_->counts.assign(impl_->graphs.size(), SiteCounts());
-    impl_->views.assign(impl_->graphs.size(), SiteReadViews());
-    if (impl_->graphs.empty())
+    const size_t n = impl_->graphs.size();
+    impl_->counts.assign(n, SiteCounts());
+    impl_->views.assign(n, SiteReadViews());
+    impl_->errors.assign(n, std::string());
+    if (n == 0)
         return;
+    try
+    {
+        impl_->runAll(prm);
+        return;
+    }
+    catch (OutsideEnvelope const& e)
+    {
+        // The reference has no bound on read length, nodes, columns or labels (gssw.c:527-786, GraphAligner.cpp:110-167,
+        // ReadCounting.cpp:96-127); the device kernels do.  A site beyond them is reported, the run goes on.
+        impl_->counts.assign(n, SiteCounts());
+        impl_->views.assign(n, SiteReadViews());
+        if (n == 1)
+        {
+            impl_->errors[0] = e.what();
+            if (impl_->reads[0])
+                impl_->reads[0]->clear();  // no read of this site is MAPPED (Align.cpp:155 keeps only those)
+            return;
+        }
+    }
+    // some site of the batch is outside the envelope: every site on its own, so the others come out as if it were not there
+    for (size_t s = 0; s < n; ++s)
+    {
+        SiteBatcher one;
+        if (impl_->packed[s])
+            one.addSite(impl_->graphs[s], impl_->packed[s], impl_->paths[s]);
+        else
+            one.addSite(impl_->graphs[s], impl_->reads[s], impl_->paths[s]);
+        one.run(prm);
+        impl_->counts[s] = std::move(one.impl_->counts[0]);
+        impl_->views[s] = std::move(one.impl_->views[0]);
+        impl_->errors[s] = std::move(one.impl_->errors[0]);
+    }
+}
+
+void SiteBatcher::Impl::runAll(BatchParameters const& prm)
+{
+    Impl* impl_ = this;
     // PG_BATCH_TIMING=1: wall-clock of the phases of this call on stderr
     const bool timing = std::getenv("PG_BATCH_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();

@@ -324,6 +324,17 @@ Json countDocument(
     return out;
 }
 
+// A site the device path could not take (SiteBatcher::error): its document keeps the graph description, has empty counts and
+// says why under "error"; one line on stderr.  The other sites of the run are unaffected.
+void noteSiteError(Json& document, GraphDescription const& d, std::string const& error)
+{
+    if (error.empty())
+        return;
+    document["error"] = error;
+    std::string id = d.description.isMember("ID") ? d.description["ID"].asString() : std::string();
+    fprintf(stderr, "[paragraph_amd] WARNING: graph %s skipped (no counts, no genotype): %s\n", id.empty() ? "<no ID>" : id.c_str(), error.c_str());
+}
+
 BatchParameters batchParameters(Parameters const& parameters)
 {
     if (!parameters.graph_sequence_matching)
@@ -365,6 +376,7 @@ std::vector<Json> alignAndDisambiguateBatch(Parameters const& parameters, std::v
         for (auto const& r : *sites[s].reads)
             view.push_back(r.get());
         documents[s] = countDocument(parameters, d, batcher.counts(s), viewsOfReads(*d.graph, view), reads_in[s], sites[s].reads);
+        noteSiteError(documents[s], d, batcher.error(s));
     });
     if (parameters.timings)
     {
@@ -396,6 +408,7 @@ std::vector<Json> alignAndDisambiguateBatch(Parameters const& parameters, std::v
     std::vector<Json> documents(sites.size());
     parallelFor(sites.size(), parameters.threads, [&](size_t s) {
         documents[s] = countDocument(parameters, *sites[s].description, batcher.counts(s), batcher.views(s), sites[s].reads->size(), nullptr);
+        noteSiteError(documents[s], *sites[s].description, batcher.error(s));
     });
     if (parameters.timings)
     {
@@ -977,6 +990,9 @@ std::vector<Json> genotypeGraphs(
                     }
                     genotypes[g0 + g]
                         = genotypeDocument(*chunk->graphs[g].graph, chunk->graphs[g].description, genotyping_parameter_path, sample_ptrs, docs);
+                    for (Json const* doc : docs)  // a graph the device path could not take: genotyped from no counts, and says so
+                        if (doc->isMember("error") && !genotypes[g0 + g].isMember("error"))
+                            genotypes[g0 + g]["error"] = (*doc)["error"];
                 });
                 phase(c, "genotypes");
                 const double t_release = now();

@@ -35,9 +35,42 @@ def test_site_partition_is_balanced_and_complete():
         assert sorted(seen.tolist()) == list(range(400))
         loads = [sset.weights[p].sum() for p in sset.parts]
         assert max(loads) <= 1.02 * sum(loads) / world
-        arr, gor, frag, rev = sset.shard_arrays(sset.parts[-1])
-        assert len(arr) == len(gor) == len(frag) == len(rev) == int(sset.n_reads_site[sset.parts[-1]].sum())
+        arr, gor, frag, rev = sset.rank_arrays(world - 1)
+        assert len(arr) == len(gor) == len(frag) == len(rev) == int(sset.n_reads_site[sset.parts[-1]].sum()) == sset.rank_reads(world - 1)
         assert set(np.unique(gor).tolist()) <= set(sset.parts[-1].tolist())
+
+
+def test_hot_site_is_split_by_fragment_not_by_read():
+    """A site at grmpy's read cap goes over all ranks by fragment id: every read lands on exactly one rank, mates on the
+    same one, the other sites stay whole (ReadCounting.cpp:52-94, Fragment.cpp:141-181)."""
+    import bench
+    from paragraph_amd import synth
+    sites = synth.mixed_sites(60, seed=6, site_streams=True) + synth.mixed_sites(1, seed=11, depth=1500.0, site_streams=True)
+    hot = len(sites) - 1
+    assert len(sites[hot].reads) >= 5000
+    for world in (2, 8):
+        sset = bench.SiteSet(sites, 150, world, split_reads=5000)
+        assert sset.hot == [hot]
+        assert sorted(np.concatenate(sset.parts).tolist()) == list(range(hot))
+        owner_of_fragment = {}
+        n_hot = 0
+        total = 0
+        for r in range(world):
+            arr, gor, frag, rev = sset.rank_arrays(r)
+            total += len(arr)
+            sel = gor == hot
+            n_hot += int(sel.sum())
+            assert sel.sum() > 0
+            for f in np.unique(frag[sel]).tolist():
+                assert owner_of_fragment.setdefault(f, r) == r  # a fragment's reads never meet on two ranks
+            whole = set(np.unique(gor[~sel]).tolist())
+            assert whole <= set(sset.parts[r].tolist())
+        assert n_hot == len(sites[hot].reads) and total == int(sset.n_reads_site.sum())
+        assert len(owner_of_fragment) == len(np.unique(sites[hot].fragment))
+        loads = [sset.rank_weight(r) for r in range(world)]
+        assert max(loads) <= 1.05 * sum(loads) / world
+    one = bench.SiteSet(sites, 150, 1)
+    assert one.hot == [] and len(one.rank_arrays(0)[0]) == int(one.n_reads_site.sum()) == len(one.all_arrays()[0])
 
 
 def test_cpu_leg_and_verification(tmp_path):

@@ -67,7 +67,19 @@ def _worker(rank, world, port, q):
     parts = pd.partition_sites([w for _, _, w in sites], world)
     mine = set(int(i) for i in parts[rank])
     t = torch.from_numpy(_table_for(sites, mine))
-    pd.allreduce_counts(t)
+
+    class Drained:  # stands in for the device context: the host backend drains the compute streams before it reduces
+        calls = 0
+
+        def sync_compute(self):
+            Drained.calls += 1
+
+    red = pd.CountReduce(Drained(), None)
+    assert red.active and red.blocking  # gloo: no stream to order against, the blocking form
+    red.acquire(t)
+    red.reduce(t)
+    red.wait()
+    assert Drained.calls == 1 and red.reduces == 1
     q.put((rank, t.numpy().copy(), sorted(mine)))
     dist.barrier()
     dist.destroy_process_group()

@@ -131,3 +131,51 @@ def test_bench_two_ranks_shard_one_site_set():
     assert out["sites"]["reduce_equals_single"] is True, out["sites"]
     assert out["sites"]["sites"] == 400 and len(out["sites"]["shard_reads"]) == 2 and min(out["sites"]["shard_reads"]) > 0
     assert out["sites"]["tallies"]["aligned"] == out["sites"]["reads"]
+
+
+def _run_bench(argv, timeout=900):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, stdout=subprocess.PIPE, env=env, timeout=timeout)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
+    return json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_two_ranks_split_a_hot_site_by_fragment():
+    """a hot site (here ~10 000 reads, grmpy's cap) is split over the ranks by FRAGMENT id -- mates stay
+    together -- and the all-reduce then really sums that site's counters: reduced table == 1-rank table."""
+    out = _run_bench(["--gpus", "2", "--workload", "config3", "--sites", "200", "--hot-site-depth", "1500", "--steps", "2",
+                      "--warmup", "1", "--workspace-gib", "16"])
+    hot = out["sites"]["hot_sites_split_by_fragment"]
+    assert len(hot) == 1 and hot[0]["reads"] >= 5000 and min(hot[0]["reads_per_rank"]) > 1000, hot
+    assert out["sites"]["reduce_equals_single"] is True, out["sites"]
+    assert out["sites"]["tallies"]["aligned"] == out["sites"]["reads"]
+
+
+def test_bench_one_rank_runs_the_rccl_reduce_stream_ordered():
+    """N = 1 with a world-size-1 RCCL communicator: the all-reduce of the counter table is inside every timed step, ordered
+    by events (no host synchronisation), and costs (next to) nothing; the counts are those of the plain path."""
+    out = _run_bench(["--reads", "400000", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--stream-batches", "0",
+                      "--sites", "300", "--sites-steps", "2"])
+    d = out["dist"]
+    assert d["backend"] == "nccl" and d["world"] == 1 and d["collective_in_step"] is True, d
+    assert d["ranks"][0]["device"] == 0
+    ab = d["collective_ab"]
+    assert ab["with_vs_without"] < 1.05, ab
+    t = out["counts"]["tallies"]
+    assert t["aligned"] == 400000, t
+    assert out["sites"]["tallies"]["aligned"] == out["sites"]["reads"]
+    plain = _run_bench(["--reads", "400000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--stream-batches", "0",
+                        "--sites-steps", "0", "--collective", "off"])
+    assert plain["dist"]["collective_in_step"] is False
+    assert plain["counts"] == out["counts"]
+
+
+def test_count_stream_events_order_a_foreign_stream():
+    """pg_ctx_count_record / pg_ctx_count_wait with the runtime's own event handles (here torch's): a foreign stream reads
+    the counter table behind the count kernels, and the next zeroing waits for that reader -- no host synchronisation.  In a
+    process of its own: torch brings its own HIP runtime, which has to be loaded before the library's (as in bench.py)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "count_events_check.py")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0 and b"count events ok" in p.stdout, p.stdout.decode()[-3000:]

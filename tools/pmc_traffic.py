@@ -33,7 +33,11 @@ def main(src, dst, n_reads):
     write_factor = GIB / ((sum(copy_w) / len(copy_w) + sum(zero_w) / len(zero_w)) / 2)
     ben_f = load(os.path.join(src, "bench_FETCH_SIZE", "bench_counter_collection.csv"))
     ben_w = load(os.path.join(src, "bench_WRITE_SIZE", "bench_counter_collection.csv"))
-    out = {"source": src, "reads_in_pmc_run": n_reads,
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from paragraph_amd import build as pgbuild
+    head_file = os.path.join(src, "head.txt")  # written by tools/pmc_collect.sh on the box (the snapshot has no .git)
+    out = {"source": src, "reads_in_pmc_run": n_reads, "kernel_source_sha": pgbuild.kernel_source_sha(),
+           "collected_at_head": open(head_file).read().strip() if os.path.exists(head_file) else None,
            "calibration": {"fetch_factor": fetch_factor, "write_factor": write_factor,
                            "how": "torch copy_ / zero_ of 1 GiB under the same --pmc pass"},
            "kernels": {}}

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libparagraph_amd.so")
-HIP_SOURCES = ["pg_api.hip", "pg_fill.hip", "pg_trace.hip", "pg_count.hip", "pg_path.hip", "pg_kmer.hip", "pg_klib.hip", "pg_klib_packed.hip"]
+HIP_SOURCES = ["pg_api.hip", "pg_fill.hip", "pg_trace.hip", "pg_count.hip", "pg_path.hip", "pg_kmer.hip", "pg_klib.hip", "pg_klib_packed.hip", "pg_general.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
@@ -37,7 +37,7 @@ def kernel_source_sha():
 def build_hip(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> paragraph_amd/libparagraph_amd.so (the C-ABI library)."""
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("pg_device.h", "pg_kernels.h", "pg_internal.h", "pg_pk16.h", "pg_klib.h")] + \
+    deps = srcs + [os.path.join(CSRC, h) for h in ("pg_device.h", "pg_kernels.h", "pg_internal.h", "pg_pk16.h", "pg_klib.h", "pg_general.h", "pg_kmerindex.h")] + \
         [os.path.join(ROOT, "include", "paragraph_amd.h")]
     if not force and not _stale(LIB, deps):
         return LIB

@@ -27,6 +27,7 @@
 
 #include "../../include/paragraph_amd.h"
 #include "pg_device.h"
+#include "pg_general.h"
 #include "pg_internal.h"
 #include "pg_kernels.h"
 
@@ -236,6 +237,8 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
         (void)hipEventDestroy(e);
     if (ctx->workspace)
         (void)hipFree(ctx->workspace);
+    if (ctx->gen_ws)
+        (void)hipFree(ctx->gen_ws);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2)
@@ -567,10 +570,14 @@ extern "C" pg_status pg_graphs_upload(
                     return fail(ctx, PG_ERR_INVALID, "predecessors must be ascending and unique");
             }
         }
-        if (total > 65535 - PG_GROUP_LANES)
-            return fail(ctx, PG_ERR_UNSUPPORTED, "graph longer than 65519 columns");
+        // beyond 65 519 columns the packed kernels' 16-bit column fields end: the graph's reads take the general path
+        // (pg_general.h), which reads nodes / predecessors / characters only -- no column words are built for it
+        const bool wide = total > 65535 - PG_GROUP_LANES;
+        if (total > 0x7FFFFFFFull)
+            return fail(ctx, PG_ERR_UNSUPPORTED, "graph longer than 2^31 columns");
         host[g].n_nodes = n;
         host[g].ncols = (uint32_t)total;
+        host[g].general_only = wide;
 
         // successors (forward ids)
         std::vector<std::vector<uint32_t>> succ(n);
@@ -651,17 +658,21 @@ extern "C" pg_status pg_graphs_upload(
                 for (uint32_t c = 0; c < len; ++c)
                 {
                     const char ch = up(dir ? seq[s0 + len - 1 - c] : seq[s0 + c]);
+                    if (!dir)
+                        seqchars.push_back(ch);
+                    if (wide)
+                        continue;
                     uint32_t m = nt_code_host(ch) | (id << 8);
                     if (c == 0)
                         m |= PG_META_FIRST | pred_bits;
                     if (c == len - 1)
                         m |= PG_META_LAST | PG_META_LAST_HI | (save ? PG_META_SAVE : 0u);
                     colmeta.push_back(m);
-                    if (!dir)
-                        seqchars.push_back(ch);
                 }
                 col += len;
             }
+            if (wide)
+                continue;
             // PG_META_RARE: node boundary, or code 4 in this column or in the next one of the layout
             for (size_t i = dir_meta_begin; i < colmeta.size(); ++i)
             {
@@ -780,6 +791,11 @@ static void batch_free_device(pg_batch* b)
     (void)pg_dev_free(b->d_bases);
     (void)pg_dev_free(b->d_items);
     (void)pg_dev_free(b->d_fillsum);
+    (void)pg_dev_free(b->d_gen_reads);
+    (void)pg_dev_free(b->d_gen_fsum);
+    b->d_gen_reads = nullptr;
+    b->d_gen_fsum = nullptr;
+    b->cap_gen = 0;
     (void)pg_dev_free(b->d_results);
     (void)pg_dev_free(b->d_ops);
     (void)pg_dev_free(b->d_ops_counter);
@@ -847,6 +863,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
     const uint32_t* base_off = b->h_base_off.data();
     const uint32_t* graph_of_read = b->h_graph_of_read.data();
     b->chunks.clear();
+    b->gen_idx.clear();
     b->n_pairs = 0;
     // ---- bucket reads by (variant, graph) -----------------------------------------------------------
     struct Key
@@ -860,6 +877,11 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
         const uint32_t L = base_off[i + 1] - base_off[i];
         if (L == 0 || (active && !active[i]))
             continue;
+        if (L > PG_MAX_READ_LEN || G->host[graph_of_read[i]].general_only)
+        {
+            b->gen_idx.push_back(i);  // outside the packed kernels' envelope: the general path (pg_general.h)
+            continue;
+        }
         keys.push_back(Key{ (uint32_t)pg_variant_of(L), graph_of_read[i], i });
     }
     const auto key_less = [](const Key& x, const Key& y) { return x.c != y.c ? x.c < y.c : x.graph < y.graph; };
@@ -981,6 +1003,94 @@ static pg_status ensure_ctx_workspace(pg_ctx* ctx, const pg_batch* b)
     return PG_OK;
 }
 
+// The general path of pg_batch_align: the reads plan_items set aside (longer than PG_MAX_READ_LEN, or on a graph of more than
+// 65 519 columns) go through pg_general.hip's one-thread-per-fill kernels on the second stream, behind the chunk pipeline, in
+// groups whose H matrices fit the workspace budget.  Slow on purpose -- it exists so that such a read, and its site, stays in
+// the run (the reference has no such bounds: gssw.c:527-786, GraphAligner.cpp:110-167).
+static pg_status run_general(pg_ctx* ctx, pg_batch* b, uint32_t flags)
+{
+    const pg_graphs* G = b->graphs;
+    const size_t n = b->gen_idx.size();
+    if (n > b->cap_gen)
+    {
+        HIP_TRY(ctx, pg_batch_wait(ctx, b));
+        (void)pg_dev_free(b->d_gen_reads);
+        (void)pg_dev_free(b->d_gen_fsum);
+        b->d_gen_reads = nullptr;
+        b->d_gen_fsum = nullptr;
+        b->cap_gen = n;
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_gen_reads, n * sizeof(PgGenRead)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_gen_fsum, n * 4 * sizeof(PgFillSummary)));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));  // an earlier launch may still read h_gen_reads / the general workspace (rare path)
+    b->h_gen_reads.assign(n, PgGenRead{});
+    std::vector<std::pair<size_t, size_t>> groups;
+    uint64_t cur = 0, largest = 0;
+    size_t begin = 0;
+    for (size_t i = 0; i < n; ++i)
+    {
+        const uint32_t r = b->gen_idx[i], g = b->h_graph_of_read[r];
+        const uint64_t L = b->h_base_off[r + 1] - b->h_base_off[r];
+        const HostGraph& hg = G->host[g];
+        const uint64_t need = pg_gen_read_bytes(L, hg.ncols, hg.n_nodes);
+        if (need > ctx->ws_limit)
+            return fail(ctx, PG_ERR_UNSUPPORTED, "workspace limit too small for one read of the general path (read length x graph columns)");
+        if (cur + need > ctx->ws_limit)
+        {
+            groups.emplace_back(begin, i);
+            begin = i;
+            cur = 0;
+        }
+        PgGenRead& gr = b->h_gen_reads[i];
+        gr.read = r;
+        gr.graph = g;
+        gr.h_off = cur;
+        gr.seed_off = gr.h_off + pg_gen_align8(2 * (uint64_t)hg.ncols * L * 2);
+        gr.col_off = gr.seed_off + pg_gen_align8(4 * 2 * (uint64_t)hg.n_nodes * L * 2);
+        gr.node_off = gr.col_off + pg_gen_align8(4 * 2 * L * 2);
+        gr.ops_off = gr.node_off + pg_gen_align8(4 * (uint64_t)hg.n_nodes * 2 * 4);
+        cur += need;
+        largest = std::max(largest, cur);
+    }
+    groups.emplace_back(begin, n);
+    if (largest > ctx->gen_ws_cap)
+    {
+        if (ctx->gen_ws)
+            HIP_TRY(ctx, hipFree(ctx->gen_ws));
+        ctx->gen_ws = nullptr;
+        ctx->gen_ws_cap = 0;
+        const uint64_t want = (largest + 511) & ~(uint64_t)511;
+        if (hipMalloc((void**)&ctx->gen_ws, want) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            pg_dev_cache_release();
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->gen_ws, want));
+        }
+        ctx->gen_ws_cap = want;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(b->d_gen_reads, b->h_gen_reads.data(), n * sizeof(PgGenRead), hipMemcpyHostToDevice, ctx->stream2));
+    for (auto const& grp : groups)
+    {
+        PgGenArgs ga{};
+        ga.reads = b->d_gen_reads + grp.first;
+        ga.n = (uint32_t)(grp.second - grp.first);
+        ga.flags = flags;
+        ga.graphs = G->d_graphs;
+        ga.nodes = G->d_nodes;
+        ga.preds = G->d_preds;
+        ga.seqchars = G->d_seqchars;
+        ga.base_off = b->d_base_off;
+        ga.bases = b->d_bases;
+        ga.ws = ctx->gen_ws;
+        ga.fsum = b->d_gen_fsum + grp.first * 4;
+        ga.results = b->d_results;
+        ga.ops = b->d_ops;
+        ga.ops_counter = b->d_ops_counter;
+        HIP_TRY(ctx, pg_launch_general(ga, ctx->stream2));
+    }
+    return PG_OK;
+}
+
 extern "C" pg_status pg_batch_upload(
     pg_ctx* ctx, pg_batch* b, const pg_graphs* G, uint32_t n_reads, const uint32_t* graph_of_read,
     const uint32_t* base_off, const char* bases)
@@ -1007,8 +1117,8 @@ extern "C" pg_status pg_batch_upload(
         const uint32_t L = base_off[i + 1] - base_off[i];
         if (graph_of_read[i] >= G->n_graphs)
             return fail(ctx, PG_ERR_INVALID, "graph_of_read out of range");
-        if (L > PG_MAX_READ_LEN)
-            return fail(ctx, PG_ERR_UNSUPPORTED, "read longer than 512 bp");
+        if (L > PG_GEN_MAX_READ_LEN)
+            return fail(ctx, PG_ERR_UNSUPPORTED, "read longer than 16000 bp");
         if (L == 0)
         {
             // grm::sequentialAlignReads skips reads without bases (Align.cpp:74-77)
@@ -1018,7 +1128,7 @@ extern "C" pg_status pg_batch_upload(
             b->has_skipped = true;
             continue;
         }
-        ops_total += pg_ops_cap(pg_variant_of(L));
+        ops_total += (L > PG_MAX_READ_LEN || G->host[graph_of_read[i]].general_only) ? pg_gen_ops_cap(L) : pg_ops_cap(pg_variant_of(L));
     }
     b->h_graph_of_read.assign(graph_of_read, graph_of_read + n_reads);
     b->h_base_off.assign(base_off, base_off + (n_reads ? n_reads + 1 : 0));
@@ -1191,6 +1301,12 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         ctx->half_free[h] = td;
         ctx->sync_events_in_flight.push_back(td);
         ++ctx->chunk_seq;
+    }
+    if (!b->gen_idx.empty())
+    {
+        const pg_status gs = run_general(ctx, b, flags);
+        if (gs != PG_OK)
+            return gs;
     }
     // the batch is busy until its last traceback is over; later stages of THIS batch wait for that (pg_stage_begin*), other
     // batches' fills do not

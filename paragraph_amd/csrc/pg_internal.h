@@ -7,12 +7,14 @@
 
 #include "../../include/paragraph_amd.h"
 #include "pg_device.h"
+#include "pg_general.h"
 #include "pg_kernels.h"
 
 struct HostGraph
 {
     uint32_t n_nodes;
     uint32_t ncols;
+    bool general_only;  // longer than the packed kernels' 65 519 columns: every read on it takes the general path (pg_general.h)
 };
 
 struct Chunk
@@ -45,6 +47,9 @@ struct pg_ctx
     uint64_t ws_limit = 8ull << 30;
     uint8_t* workspace = nullptr;
     uint64_t ws_cap = 0;
+    // workspace of the general path (reads / graphs beyond the packed kernels' envelope); used on stream2 only
+    uint8_t* gen_ws = nullptr;
+    uint64_t gen_ws_cap = 0;
     bool timing = false;
     std::vector<EventPair> events;
     std::vector<hipEvent_t> event_pool;
@@ -109,6 +114,12 @@ struct pg_batch
     uint64_t ops_cap = 0;
     unsigned long long* d_ops_counter = nullptr;
     std::vector<Chunk> chunks;
+    // reads of the current plan that take the general path, and their device-side records
+    std::vector<uint32_t> gen_idx;
+    std::vector<PgGenRead> h_gen_reads;  // host copy of the records in flight (the upload reads it asynchronously)
+    PgGenRead* d_gen_reads = nullptr;
+    PgFillSummary* d_gen_fsum = nullptr;
+    size_t cap_gen = 0;
     uint64_t max_ws = 0;
     size_t cap_reads = 0, cap_bases = 0, cap_items = 0;
     std::vector<pg_result> host_template;  // status for reads the device never sees (empty reads)

@@ -129,13 +129,14 @@ def test_empty_and_ragged(gpu_ctx, checker):
 
 
 def test_length_boundaries(gpu_ctx, checker):
-    """Every variant boundary: rows-per-lane steps (multiples of 32 / 64), byte vs wide (250 / 251), the 512 limit."""
+    """Every variant boundary: rows-per-lane steps (multiples of 32 / 64), byte vs wide (250 / 251), packed vs general path
+    (512 / 513), and the general path's own limit (16 000 bases)."""
     import random
     rng = random.Random(fuzzgen.salted(1234))
     seqs, edges, _ = fuzzgen.long_read_case(rng, 1)
     path = seqs[0] + seqs[1] + seqs[-1]
     lens = [1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 159, 160, 161, 191, 192, 193, 223, 224,
-            225, 249, 250, 251, 252, 255, 256, 257, 319, 320, 321, 383, 384, 385, 447, 448, 449, 479, 480, 481, 511, 512]
+            225, 249, 250, 251, 252, 255, 256, 257, 319, 320, 321, 383, 384, 385, 447, 448, 449, 479, 480, 481, 511, 512, 513, 514, 640, 1025]
     reads = []
     for L in lens:
         st = rng.randrange(max(1, len(path) - L))
@@ -147,7 +148,7 @@ def test_length_boundaries(gpu_ctx, checker):
     compare(got, want, reads, "length-boundaries")
     from paragraph_amd import capi
     with pytest.raises(Exception):
-        gpu_align(gpu_ctx, [(seqs, edges)], ["A" * 513])
+        gpu_align(gpu_ctx, [(seqs, edges)], ["A" * 16001])
 
 
 def test_golden_fixtures(gpu_ctx):
@@ -212,7 +213,8 @@ def test_many_tiny_nodes(gpu_ctx, checker):
 
 def test_documented_limits_fail_loudly(gpu_ctx):
     """Every limit of the envelope (include/paragraph_amd.h) answers with PG_ERR_UNSUPPORTED -- never with a wrong result:
-    4096 nodes, a direction longer than 65519 columns, 65 labels, 31 klib paths, a 513-base read."""
+    4096 nodes, 65 labels, 31 klib paths, a 16 001-base read.  (Round 3: a direction longer than 65 519 columns and reads of
+    513..16 000 bases are no longer limits -- they take the general path, tests/test_gpu_general.py.)"""
     from paragraph_amd import capi
     chain = (["ACGT"] * 4096, [(i, i + 1) for i in range(4095)])
     with pytest.raises(capi.PgError) as e:
@@ -220,9 +222,7 @@ def test_documented_limits_fail_loudly(gpu_ctx):
     assert e.value.status == 4 and "4095" in str(e.value)
     ok = gpu_ctx.upload_graphs([(["ACGT"] * 4095, [(i, i + 1) for i in range(4094)])])  # the largest graph that is in
     ok.close()
-    with pytest.raises(capi.PgError) as e:
-        gpu_ctx.upload_graphs([(["A" * 40000, "C" * 25600], [(0, 1)])])
-    assert e.value.status == 4
+    gpu_ctx.upload_graphs([(["A" * 40000, "C" * 25600], [(0, 1)])]).close()  # general path
     G = gpu_ctx.upload_graphs([ALIGNS_GRAPH])
     names = ["L%02d" % i for i in range(65)]
     with pytest.raises(capi.PgError) as e:
@@ -235,9 +235,9 @@ def test_documented_limits_fail_loudly(gpu_ctx):
     G.build_klib_index([[[0, 1, 3]] * 30])
     b = gpu_ctx.new_batch()
     with pytest.raises(capi.PgError) as e:
-        b.upload(G, ["A" * 513])
+        b.upload(G, ["A" * 16001])
     assert e.value.status == 4
-    b.upload(G, ["A" * 512])
+    b.upload(G, ["A" * 512, "A" * 513])
     b.align()
     res, _ = b.download()
     assert res[0]["status"] & 0xFF in (0, 1)

@@ -411,3 +411,41 @@ def test_config1_multigrmpy_from_json_events(tmp_path):
             assert isinstance(gt["GT"], str) and gt["filters"], (rid, sample, gt)
             assert "alleles" in doc["samples"][sample] and "breakpoints" in doc["samples"][sample]
     assert not os.path.exists(out / "genotypes.vcf.gz")
+
+
+def test_one_oversize_site_does_not_take_the_run_down(tmp_path):
+    """200 graphs of which three are outside the packed kernels' envelope -- a 600 bp read over one site, a 5 000-node graph, a
+    70 000-column graph; the reference has no such bounds (gssw.c:527-786, GraphAligner.cpp:110-167).  The long read and the
+    long graph go through the general path (pg_general.hip; parity with the reference's gssw.c: tests/test_gpu_general.py)
+    and come out as ordinary documents; the 5 000-node graph says why it was skipped under "error"; the 197 other genotype
+    documents equal those of a run over the 197 alone."""
+    import sys
+    from paragraph_amd import workflow
+    data = tmp_path / "sites"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e", "make_sites.py"), str(data), "198", "20", "7", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    graphs = [l.strip() for l in open(data / "graphs.txt") if l.strip()]
+    extra = [l.strip() for l in open(data / "extra_graphs.txt") if l.strip()]
+    assert len(graphs) == 198 and len(extra) == 2
+    ref, manifest = str(data / "ref.fa"), str(data / "manifest.txt")
+    everything = graphs[:50] + [extra[0]] + graphs[50:120] + [extra[1]] + graphs[120:]  # the odd ones in the middle of batches
+    docs = workflow.genotype_graphs(ref, manifest, everything, threads=4, lanes=2, sites_per_batch=32)
+    assert len(docs) == 200
+    by_id = {d["graphinfo"]["ID"]: d for d in docs}
+    bad = {"many_nodes": "4095 nodes"}
+    for gid, why in bad.items():
+        assert "error" in by_id[gid] and why in by_id[gid]["error"], (gid, by_id[gid].get("error"))
+    for gid in ("site_197", "many_columns"):  # the general path: ordinary documents with reads counted
+        assert "error" not in by_id[gid], by_id[gid].get("error")
+        assert by_id[gid]["samples"]["SYN"]["gt"]["num_reads"] > 0, by_id[gid]["samples"]["SYN"]["gt"]
+    good = workflow.genotype_graphs(ref, manifest, graphs[:197], threads=4, lanes=2, sites_per_batch=32)
+    assert len(good) == 197 and not any("error" in d for d in good)
+    for d in good:
+        assert by_id[d["graphinfo"]["ID"]] == d, d["graphinfo"]["ID"]
+    # the object form isolates the same way
+    objects = workflow.genotype_graphs(ref, manifest, everything[45:60], threads=2, lanes=1, sites_per_batch=15, packed_reads=False)
+    assert [("error" in d) for d in objects] == [d["graphinfo"]["ID"] in bad for d in objects] and sum("error" in d for d in objects) == 1
+    for d in objects:
+        if "error" not in d:
+            assert by_id[d["graphinfo"]["ID"]] == d

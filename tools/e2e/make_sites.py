@@ -2,7 +2,10 @@
 along it (graphs as JSON descriptions with reference-interval nodes), and ONE coordinate-sorted BAM of paired 150 bp reads
 sampled around every site from a diploid genome that carries each alternate allele with genotype 0/0, 0/1 or 1/1.
 
-    python tools/e2e/make_sites.py <outdir> [n_sites] [depth] [seed]
+    python tools/e2e/make_sites.py <outdir> [n_sites] [depth] [seed] [extras]
+
+extras = 1 adds what the device kernels' envelope does not hold (the reference has no such bounds): one 600 bp read over
+the last site, and two more graphs -- 5 000 nodes, 70 000 columns -- listed in extra_graphs.txt.
 
 Writes ref.fa(.fai), reads.bam(.bai), graphs/site_<i>.json, graphs.txt, manifest.txt, truth.json.
 """
@@ -22,6 +25,7 @@ def main():
     n_sites = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
     depth = float(sys.argv[3]) if len(sys.argv) > 3 else 30.0
     rng = random.Random(int(sys.argv[4]) if len(sys.argv) > 4 else 1)
+    extras = len(sys.argv) > 5 and sys.argv[5] == "1"
     os.makedirs(os.path.join(out, "graphs"), exist_ok=True)
     spacing, flank, read_len, frag_mean = 3000, 150, 150, 400
     glen = spacing * (n_sites + 1)
@@ -96,6 +100,25 @@ def main():
             name = "s%d_f%d" % (i, k)
             records.append(dict(name=name, tid=0, pos=p1, seq=err(r1), flag=0x63, mtid=0, mpos=p2, mapq=60))
             records.append(dict(name=name, tid=0, pos=p2, seq=err(r2.translate(COMP)[::-1]).translate(COMP)[::-1], flag=0x93, mtid=0, mpos=p1, mapq=60))
+    if extras:
+        start = spacing * n_sites  # the last site
+        records.append(dict(name="long_read", tid=0, pos=start - 300, seq=ref[start - 300:start + 300], flag=0, mtid=-1, mpos=-1, mapq=60))
+        erng = random.Random(12345)
+        chain = [{"name": "source", "sequence": "NNNNNNNNNN"}] + [{"name": "n%d" % k, "sequence": "".join(erng.choice("ACGT") for _ in range(4))} for k in range(5000)]
+        cedges = [{"from": chain[k]["name"], "to": chain[k + 1]["name"]} for k in range(len(chain) - 1)]
+        cedges[10]["sequences"] = ["REF"]
+        cedges.append({"from": "n9", "to": "n11", "sequences": ["ALT"]})
+        wide = [{"name": "LF", "reference": "chr1:%d-%d" % (spacing * 2 - flank + 1, spacing * 2)},
+                {"name": "MID", "sequence": "".join(erng.choice("ACGT") for _ in range(70000))},
+                {"name": "RF", "reference": "chr1:%d-%d" % (spacing * 2 + 1, spacing * 2 + flank)}]
+        wedges = [{"from": "LF", "to": "MID", "sequences": ["ALT"]}, {"from": "LF", "to": "RF", "sequences": ["REF"]}, {"from": "MID", "to": "RF", "sequences": ["ALT"]}]
+        with open(os.path.join(out, "extra_graphs.txt"), "w") as xf:
+            for name, nodes_x, edges_x, site in (("many_nodes", chain, cedges, 1), ("many_columns", wide, wedges, 2)):
+                gp = os.path.join(out, "graphs", name + ".json")
+                with open(gp, "w") as f:
+                    json.dump({"ID": name, "nodes": nodes_x, "edges": edges_x, "sequencenames": ["ALT", "REF"],
+                               "target_regions": ["chr1:%d-%d" % (spacing * site - flank + 1, spacing * site + flank)]}, f)
+                xf.write(gp + "\n")
     records.sort(key=lambda r: r["pos"])
     bamwriter.write_bam(os.path.join(out, "reads.bam"), [("chr1", glen)], records)
     with open(os.path.join(out, "graphs.txt"), "w") as f:

@@ -472,7 +472,11 @@ def run_sites_leg(args, env, ctx, capi, synth, sset, steps, warmup, timed_events
            "shard_imbalance": float(max(sset.rank_weight(r) for r in range(world)) * world / max(1, sset.weights.sum())),
            "hot_sites_split_by_fragment": [{"site": i, "reads": int(sset.n_reads_site[i]),
                                             "reads_per_rank": [len(x) for x in sset.hot_reads[i]]} for i in sset.hot],
-           "counters": n_counters, "reduce_equals_single": None}
+           "counters": n_counters, "reduce_equals_single": None,
+           # reads/s of two workloads only compare at equal graph length: a read costs 4 x L x G cell updates, and this set's
+           # graphs are longer than config 2's 502 columns (insertions up to 1 000 bp, 6-node long deletions)
+           "mean_graph_len_per_read": float((sset.n_reads_site * sset.g_len).sum() / max(1, n_reads)),
+           "cell_updates_per_s": float(4.0 * sset.L * (sset.n_reads_site * sset.g_len).sum() * steps / elapsed)}
     got = table.cpu().numpy().view(np.uint32).copy()
     tall = got[int(graphs.layout.tally_base):].reshape(-1, 4)
     out["tallies"] = {"aligned": int((tall[:, 0] & 0x7FFFFFFF).sum()), "mapped": int(tall[:, 1].sum()),
@@ -829,6 +833,7 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
                         % (args.reads, L, " + 1 all-reduce of the counter table per step" if world > 1 else ""),
             "reads_per_gpu": args.reads, "read_len": L, "graph_len": G, "parallelism": "reads x%d" % world,
         },
+        "cell_updates_per_s": 4.0 * L * G * reads_total / elapsed,  # whole step (fill + traceback + count), all ranks
         "roofline": {
             "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": roof_extra.pop("traffic"),

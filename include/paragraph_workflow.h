@@ -27,8 +27,9 @@ extern "C" {
  *                          variable -- "0,1,2,3" or "all" -- else device 0; sites are independent, the devices
  *                          exchange nothing)
  *                          (grmpy's option names and defaults, grmpy/Parameters.hh:30-74; "sites_per_batch" = (graph,
- *                          sample) pairs per device batch, default 512; "lanes" = batches in flight, default one per
- *                          four threads, at most 8)
+ *                          sample) pairs per device batch, default 128; "lanes" = batches in flight, default about 1.5 per
+ *                          host thread, at most 32 per device and at least one per device -- it grows with the device
+ *                          list; a lane sleeps while its batch is on the device)
  *   error/error_cap        receives the message when the call fails (may be NULL)
  *
  * Returns 0 on success, 1 on failure (nothing usable is written then).

@@ -168,6 +168,83 @@ extern "C" const char* pg_strerror(pg_status st)
 
 extern "C" const char* pg_last_error(const pg_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
 
+// ---- page-locked staging blocks, cached by power-of-two size class ------------------------------------------------
+namespace
+{
+std::mutex g_pinned_mutex;
+std::unordered_map<size_t, std::vector<void*>> g_pinned_idle;
+}  // namespace
+
+hipError_t pg_pinned_get(size_t bytes, void** p, size_t* cap)
+{
+    size_t c = 65536;
+    while (c < bytes)
+        c <<= 1;
+    *cap = c;
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        auto& idle = g_pinned_idle[c];
+        if (!idle.empty())
+        {
+            *p = idle.back();
+            idle.pop_back();
+            return hipSuccess;
+        }
+    }
+    return hipHostMalloc(p, c, hipHostMallocPortable);
+}
+
+void pg_pinned_put(void* p, size_t cap)
+{
+    if (!p)
+        return;
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    auto& idle = g_pinned_idle[cap];
+    if (idle.size() < 64)
+        idle.push_back(p);
+    else
+        (void)hipHostFree(p);
+}
+
+hipError_t PgStagedUpload::commit(hipStream_t stream, void** device_block)
+{
+    *device_block = nullptr;
+    size_t total = 0;
+    for (Item const& it : items)
+        total += (std::max<size_t>(it.bytes, 1) + 255) & ~(size_t)255;
+    void* host = nullptr;
+    size_t cap = 0;
+    hipError_t e = pg_pinned_get(total, &host, &cap);
+    if (e != hipSuccess)
+        return e;
+    void* dev = nullptr;
+    e = pg_dev_alloc(&dev, total);
+    if (e == hipSuccess)
+    {
+        size_t at = 0;
+        for (Item const& it : items)
+        {
+            if (it.bytes)
+                memcpy((char*)host + at, it.src, it.bytes);
+            *it.dst = (char*)dev + at;
+            at += (std::max<size_t>(it.bytes, 1) + 255) & ~(size_t)255;
+        }
+        e = hipMemcpyAsync(dev, host, total, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(stream);
+    }
+    pg_pinned_put(host, cap);
+    if (e != hipSuccess)
+    {
+        (void)pg_dev_free(dev);
+        for (Item const& it : items)
+            *it.dst = nullptr;
+        return e;
+    }
+    *device_block = dev;
+    return hipSuccess;
+}
+
 extern "C" pg_status pg_device_prefer_blocking_waits(int device)
 {
     int n = 0;
@@ -704,25 +781,15 @@ extern "C" pg_status pg_graphs_upload(
         for (uint32_t i = 0; i < total_nodes; ++i)
             G->h_node_len[i] = seq_off[i + 1] - seq_off[i];
     }
-    auto up_vec = [&](auto& vec, auto** dptr) -> hipError_t {
-        using T = typename std::remove_reference<decltype(vec)>::type::value_type;
-        hipError_t e = pg_dev_alloc((void**)dptr, vec.size() * sizeof(T));
-        if (e != hipSuccess)
-            return e;
-        return hipMemcpyAsync(*dptr, vec.data(), vec.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream_copy);
-    };
-    // on the copy stream: a graph set can be prepared while another thread's batch occupies the compute stream
-    hipError_t e = up_vec(gdev, &G->d_graphs);
-    if (e == hipSuccess)
-        e = up_vec(nodes, &G->d_nodes);
-    if (e == hipSuccess)
-        e = up_vec(preds, &G->d_preds);
-    if (e == hipSuccess)
-        e = up_vec(colmeta, &G->d_colmeta);
-    if (e == hipSuccess)
-        e = up_vec(seqchars, &G->d_seqchars);
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(ctx->stream_copy);
+    // one staging block, one copy, one device block for the five tables -- on the copy stream: a graph set can be prepared
+    // while another thread's batch occupies the compute stream
+    PgStagedUpload up;
+    up.add(gdev, &G->d_graphs);
+    up.add(nodes, &G->d_nodes);
+    up.add(preds, &G->d_preds);
+    up.add(colmeta, &G->d_colmeta);
+    up.add(seqchars, &G->d_seqchars);
+    hipError_t e = up.commit(ctx->stream_copy, &G->d_layout_block);
     if (e != hipSuccess)
     {
         pg_graphs_destroy(ctx, G);
@@ -746,18 +813,8 @@ extern "C" void pg_graphs_destroy(pg_ctx* ctx, pg_graphs* G)
         if (G->ev_use[w])
             (void)hipEventDestroy(G->ev_use[w]);
     }
-    (void)pg_dev_free(G->d_graphs);
-    (void)pg_dev_free(G->d_nodes);
-    (void)pg_dev_free(G->d_preds);
-    (void)pg_dev_free(G->d_colmeta);
-    (void)pg_dev_free(G->d_seqchars);
-    (void)pg_dev_free(G->d_cnt_graphs);
-    (void)pg_dev_free(G->d_cnt_pred_off);
-    (void)pg_dev_free(G->d_cnt_pred);
-    (void)pg_dev_free(G->d_cnt_node_len);
-    (void)pg_dev_free(G->d_label_mask);
-    (void)pg_dev_free(G->d_out_mask);
-    (void)pg_dev_free(G->d_in_mask);
+    (void)pg_dev_free(G->d_layout_block);  // d_graphs .. d_seqchars live in it
+    (void)pg_dev_free(G->d_count_block);   // d_cnt_graphs .. d_in_mask
     pg_path_index_free(G->path_index);
     pg_path_index_free(G->filter_index);
     pg_kmer_index_free(G->kmer_index);

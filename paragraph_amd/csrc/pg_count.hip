@@ -478,13 +478,6 @@ __global__ __launch_bounds__(FRAG_BLOCK) void pg_fragment_kernel(CountArgs a)
     }
 }
 
-template <typename T> hipError_t dev_upload(const std::vector<T>& v, T** d, hipStream_t s)
-{
-    hipError_t e = pg_dev_alloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(T));
-    if (e != hipSuccess || v.empty())
-        return e;
-    return hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
-}
 }  // namespace
 
 static void layout_of(const pg_graphs* G, pg_count_layout* lay)
@@ -541,21 +534,17 @@ extern "C" pg_status pg_graphs_set_labels(
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     }
-    (void)pg_dev_free(G->d_cnt_graphs);
-    (void)pg_dev_free(G->d_cnt_pred_off);
-    (void)pg_dev_free(G->d_cnt_pred);
-    (void)pg_dev_free(G->d_cnt_node_len);
-    (void)pg_dev_free(G->d_label_mask);
-    (void)pg_dev_free(G->d_out_mask);
-    (void)pg_dev_free(G->d_in_mask);
-    HIP_TRY(ctx, dev_upload(cg, &G->d_cnt_graphs, ctx->stream_copy));
-    HIP_TRY(ctx, dev_upload(G->h_pred_off, &G->d_cnt_pred_off, ctx->stream_copy));
-    HIP_TRY(ctx, dev_upload(G->h_pred, &G->d_cnt_pred, ctx->stream_copy));
-    HIP_TRY(ctx, dev_upload(G->h_node_len, &G->d_cnt_node_len, ctx->stream_copy));
-    HIP_TRY(ctx, dev_upload(lm, &G->d_label_mask, ctx->stream_copy));
-    HIP_TRY(ctx, dev_upload(outm, &G->d_out_mask, ctx->stream_copy));
-    HIP_TRY(ctx, dev_upload(inm, &G->d_in_mask, ctx->stream_copy));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
+    (void)pg_dev_free(G->d_count_block);
+    G->d_count_block = nullptr;
+    PgStagedUpload up;  // seven tables, one copy
+    up.add(cg, &G->d_cnt_graphs);
+    up.add(G->h_pred_off, &G->d_cnt_pred_off);
+    up.add(G->h_pred, &G->d_cnt_pred);
+    up.add(G->h_node_len, &G->d_cnt_node_len);
+    up.add(lm, &G->d_label_mask);
+    up.add(outm, &G->d_out_mask);
+    up.add(inm, &G->d_in_mask);
+    HIP_TRY(ctx, up.commit(ctx->stream_copy, &G->d_count_block));
     G->labels_set = true;
     return PG_OK;
 }

@@ -72,6 +72,8 @@ struct pg_graphs
     mutable hipEvent_t ev_use[2] = { nullptr, nullptr };
     mutable bool use_recorded[2] = { false, false };
     std::vector<HostGraph> host;
+    void* d_layout_block = nullptr;  // one allocation behind d_graphs .. d_seqchars (PgStagedUpload)
+    void* d_count_block = nullptr;   // one allocation behind d_cnt_graphs .. d_in_mask
     PgGraphDev* d_graphs = nullptr;
     PgNode* d_nodes = nullptr;
     uint32_t* d_preds = nullptr;
@@ -168,6 +170,27 @@ hipError_t pg_batch_wait(pg_ctx* ctx, pg_batch* b);
 hipError_t pg_dev_alloc(void** p, size_t bytes);
 hipError_t pg_dev_free(void* p);
 void pg_dev_cache_release();  // hipFree of every idle block of the current device
+
+// Several small tables -> ONE device block through ONE page-locked staging block and ONE copy.  A graph set is a dozen tables of
+// a few KB each; from pageable vectors every one of them was its own blocking hipMemcpyAsync (150 us of host time apiece,
+// 6 888 calls per two passes of the 10 000-site workflow).  add() notes a table and where its device pointer goes; commit()
+// packs them 256-byte aligned, uploads on `stream`, sets the pointers and hands back the device block (pg_dev_free it when
+// the tables go); it waits for the copy, so the staging block returns to its cache before commit() does.
+struct PgStagedUpload
+{
+    struct Item
+    {
+        const void* src;
+        size_t bytes;
+        void** dst;
+    };
+    std::vector<Item> items;
+    template <typename T> void add(const std::vector<T>& v, T** dst) { items.push_back(Item{ v.data(), v.size() * sizeof(T), (void**)dst }); }
+    hipError_t commit(hipStream_t stream, void** device_block);
+};
+// page-locked host blocks by size class (hipHostMalloc takes milliseconds)
+hipError_t pg_pinned_get(size_t bytes, void** p, size_t* cap);
+void pg_pinned_put(void* p, size_t cap);
 
 pg_status pg_fail(pg_ctx* ctx, pg_status st, const std::string& msg);
 

@@ -916,6 +916,19 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     const int R = std::max(1, (int)((max_len + 63) / 64));
     const uint64_t n_items = (uint64_t)b->n_reads * 2u * ix->max_paths;
     HIP_TRY(ctx, pg_stage_begin(ctx, b));
+    // every way out of this call from here on records the end of the stage: pg_graphs_destroy / pg_dev_free trust those events
+    // (an early return that skipped it could hand buffers the queued kernels still read to another lane)
+    struct StageEnd
+    {
+        pg_ctx* c;
+        pg_batch* b;
+        bool done;
+        ~StageEnd()
+        {
+            if (!done)
+                (void)pg_stage_end(c, b);
+        }
+    } stage_end{ ctx, b, false };
     if (!(flags & PG_AF_KEEP_RESULTS) || flags == PG_AF_ALL)
         HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
     if (b->n_reads == 0 || n_items == 0)
@@ -1022,6 +1035,7 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     }
     hipLaunchKernelGGL(pg_klib_pick_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
+    stage_end.done = true;
     HIP_TRY(ctx, pg_stage_end(ctx, b));
     return PG_OK;
 }

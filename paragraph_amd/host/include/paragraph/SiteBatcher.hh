@@ -60,6 +60,8 @@ struct BatchParameters
     // (CompositeAligner.cpp:105-150).  Both need the sites' paths (addSite's `paths`).
     bool kmer_sequence_matching = false;
     bool klib_sequence_matching = false;
+    // which of SiteCounts' keyed tables to fill (the edge table always is): a caller that only genotypes needs neither
+    bool node_counts = true, sequence_counts = true;
     unsigned alignment_flags = (unsigned)-1;
     int threads = 1;  // host threads for packing the reads and fanning the results back into them
     int device = 0;   // slot of the device list (setDevices / PG_DEVICES) this batch runs on

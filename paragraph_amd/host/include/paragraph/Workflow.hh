@@ -56,6 +56,11 @@ struct Parameters
     int threads = 1;  // host threads for read extraction and document assembly
     int device = 0;   // slot of the device list (paragraph::setDevices / PG_DEVICES) the batch runs on
     Timings* timings = nullptr;
+    // false: a count document holds only what the site's OWN analysis produced (statistics + the enabled tables), not a copy of
+    // the graph description.  grmpy::genotypeGraphs runs that way: its count documents never leave the process -- the genotyper
+    // takes the edge table and the statistics from them and the description from the loaded graph (as the reference's
+    // countAndGenotype does from the graph file, lib/grmpy/CountAndGenotype.cpp:46-88).
+    bool description_in_document = true;
     bool output_enabled(output_options o) const { return (output_options_ & o) != 0; }
 };
 

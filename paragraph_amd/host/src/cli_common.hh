@@ -27,7 +27,21 @@ inline std::vector<int> deviceList(std::string const& value)
     std::string item;
     while (std::getline(ss, item, ','))
         if (!item.empty())
-            out.push_back(std::stoi(item));
+        {
+            size_t used = 0;
+            int ordinal = -1;
+            try
+            {
+                ordinal = std::stoi(item, &used);
+            }
+            catch (std::exception const&)
+            {
+                used = 0;
+            }
+            if (used != item.size() || ordinal < 0)
+                throw std::runtime_error("--devices: '" + item + "' is not a device ordinal (expected e.g. 0,1,2,3 or 'all')");
+            out.push_back(ordinal);
+        }
     if (out.empty())
         throw std::runtime_error("--devices expects a comma-separated list of device ordinals or 'all'");
     return out;

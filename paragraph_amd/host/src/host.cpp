@@ -1513,9 +1513,12 @@ void SiteBatcher::Impl::Run::siteTables()
             const uint32_t nb = csr.node_off[s];
             for (NodeId nd = 0; nd != g.numNodes(); ++nd)
             {
-                CountEntry e = entry(lay.node_base + 4ull * (nb + nd));
-                if (e.count)
-                    sc.by_node[g.nodeName(nd)] = e;
+                if (prm.node_counts)
+                {
+                    CountEntry e = entry(lay.node_base + 4ull * (nb + nd));
+                    if (e.count)
+                        sc.by_node[g.nodeName(nd)] = e;
+                }
                 for (uint32_t q = csr.pred_off[nb + nd]; q < csr.pred_off[nb + nd + 1]; ++q)
                 {
                     CountEntry ee = entry(lay.edge_base + 4ull * q);
@@ -1524,7 +1527,7 @@ void SiteBatcher::Impl::Run::siteTables()
                 }
             }
             const auto& names = csr.label_names[s];
-            for (uint64_t m = 1; m < seq_off[s + 1] - seq_off[s]; ++m)
+            for (uint64_t m = 1; prm.sequence_counts && m < seq_off[s + 1] - seq_off[s]; ++m)
             {
                 CountEntry e = entry(lay.seq_base + 4ull * (seq_off[s] + m));
                 if (!e.count)
@@ -1540,7 +1543,7 @@ void SiteBatcher::Impl::Run::siteTables()
             sc.mapped = table[t + 1];
             sc.bad_align = table[t + 2];
             sc.nonuniq = table[t + 3];
-            if (names.size() > PG_MAX_SEQ_TABLE_LABELS)
+            if (prm.sequence_counts && names.size() > PG_MAX_SEQ_TABLE_LABELS)
             {
                 // the device keeps a dense sequence-set table only for graphs with <= 8 labels (2^labels slots); for the others the
                 // totals of countPathFamilies (ReadCounting.cpp:96-127) are summed here from the per-read label sets: a fragment

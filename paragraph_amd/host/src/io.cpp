@@ -27,6 +27,8 @@
 #include "common/Region.hh"
 #include "paragraph/PackedReads.hh"
 
+#include "inflate.hh"
+
 namespace common
 {
 // ------------------------------------------------------------------------------------------------------------------
@@ -301,6 +303,66 @@ static uint32_t crc32Fast(const unsigned char* p, size_t n)
     return n ? (uint32_t)crc32(crc, p, (uInt)n) : crc;
 }
 
+// BAM's 4-bit base codes -> characters, 32 bases per step where the CPU has byte shuffles (two table look-ups by pshufb and an
+// interleave), two per step otherwise
+__attribute__((target("ssse3"))) static void unpackBasesSsse3(const unsigned char* packed, uint32_t n, char* out)
+{
+    const __m128i table = _mm_setr_epi8('=', 'A', 'C', 'M', 'G', 'R', 'S', 'V', 'T', 'W', 'Y', 'H', 'K', 'D', 'B', 'N');
+    const __m128i low = _mm_set1_epi8(0x0F);
+    uint32_t i = 0;
+    for (; i + 32 <= n; i += 32)
+    {
+        const __m128i v = _mm_loadu_si128((const __m128i*)(packed + i / 2));
+        const __m128i hi = _mm_shuffle_epi8(table, _mm_and_si128(_mm_srli_epi16(v, 4), low));
+        const __m128i lo = _mm_shuffle_epi8(table, _mm_and_si128(v, low));
+        _mm_storeu_si128((__m128i*)(out + i), _mm_unpacklo_epi8(hi, lo));
+        _mm_storeu_si128((__m128i*)(out + i + 16), _mm_unpackhi_epi8(hi, lo));
+    }
+    static const char kBases[] = "=ACMGRSVTWYHKDBN";
+    for (; i < n; ++i)
+        out[i] = kBases[(i & 1) ? packed[i / 2] & 0xF : packed[i / 2] >> 4];
+}
+
+static void unpackBases(const unsigned char* packed, uint32_t n, char* out)
+{
+    static const bool ssse3 = __builtin_cpu_supports("ssse3");
+    if (ssse3)
+    {
+        unpackBasesSsse3(packed, n, out);
+        return;
+    }
+    static const char kBases[] = "=ACMGRSVTWYHKDBN";
+    for (uint32_t i = 0; i < n; ++i)
+        out[i] = kBases[(i & 1) ? packed[i / 2] & 0xF : packed[i / 2] >> 4];
+}
+
+// a byte buffer that is never zero-filled and keeps slack behind its logical size (the block decoder stores whole words)
+struct BlockBuffer
+{
+    std::unique_ptr<unsigned char[]> p;
+    size_t cap = 0, n = 0;
+    unsigned char* data() { return p.get(); }
+    const unsigned char* data() const { return p.get(); }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void clear() { n = 0; }
+    void resize(size_t want, size_t slack)
+    {
+        if (want + slack > cap)
+        {
+            cap = std::max<size_t>(want + slack, 65536 + 64);
+            p.reset(new unsigned char[cap]);
+        }
+        n = want;
+    }
+    void swap(BlockBuffer& o)
+    {
+        p.swap(o.p);
+        std::swap(cap, o.cap);
+        std::swap(n, o.n);
+    }
+};
+
 class Bgzf
 {
 public:
@@ -331,13 +393,21 @@ public:
     }
     uint64_t tell()
     {
-        // a position at the very end of a block is the start of the next one (as bgzf_tell reports after a read)
+        // a position at the very end of a block is the start of the next one (as bgzf_tell reports after a read); the next
+        // block is NOT loaded for that -- pointers handed out by take() stay on the current block
         if (have_block_ && within_ == data_.size() && !eof_)
-        {
-            loadBlock(block_start_ + block_csize_);
-            within_ = 0;
-        }
+            return (block_start_ + block_csize_) << 16;
         return (block_start_ << 16) | (uint64_t)within_;
+    }
+    // n contiguous bytes of the current block without a copy (nullptr when they are not all in it: read() then); the pointer
+    // is good until the block after the next one is loaded
+    const unsigned char* take(size_t n)
+    {
+        if (!have_block_ || eof_ || within_ + n > data_.size())
+            return nullptr;
+        const unsigned char* p = data_.data() + within_;
+        within_ += n;
+        return p;
     }
     // returns the number of bytes read (< n only at end of file)
     size_t read(void* dst, size_t n)
@@ -438,30 +508,40 @@ private:
         if (block_csize_ < 12 + (uint64_t)xlen + 8)
             throw std::runtime_error("BGZF: bad block size in " + path_);
         const size_t cdata_len = block_csize_ - 12 - xlen - 8;
-        cdata_.resize(cdata_len + 8);
-        if (fread(cdata_.data(), 1, cdata_.size(), fp_) != cdata_.size())
+        cdata_.resize(cdata_len + 8, 0);  // the 8 trailer bytes (CRC32, ISIZE) double as the decoder's read slack
+        if (fread(cdata_.data(), 1, cdata_len + 8, fp_) != cdata_len + 8)
             throw std::runtime_error("BGZF: truncated block in " + path_);
         const unsigned char* tail = cdata_.data() + cdata_len;
         const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
-        data_.resize(isize);
+        data_.resize(isize, 16);
         if (isize)
         {
-            if (!zs_ready_)
+            // own block decoder (inflate.hh); PG_BGZF_ZLIB=1 switches back to zlib's inflate for A/B timing
+            static const bool use_zlib = std::getenv("PG_BGZF_ZLIB") != nullptr;
+            if (!use_zlib)
             {
-                memset(&zs_, 0, sizeof zs_);
-                if (inflateInit2(&zs_, -15) != Z_OK)
-                    throw std::runtime_error("BGZF: inflateInit2 failed");
-                zs_ready_ = true;
+                if (pginflate::inflateBlock(cdata_.data(), cdata_len, data_.data(), isize) != pginflate::kOk)
+                    throw std::runtime_error("BGZF: inflate failed in " + path_);
             }
             else
-                inflateReset(&zs_);
-            zs_.next_in = cdata_.data();
-            zs_.avail_in = (uInt)cdata_len;
-            zs_.next_out = data_.data();
-            zs_.avail_out = (uInt)isize;
-            const int rc = inflate(&zs_, Z_FINISH);
-            if (rc != Z_STREAM_END || zs_.avail_out != 0)
-                throw std::runtime_error("BGZF: inflate failed in " + path_);
+            {
+                if (!zs_ready_)
+                {
+                    memset(&zs_, 0, sizeof zs_);
+                    if (inflateInit2(&zs_, -15) != Z_OK)
+                        throw std::runtime_error("BGZF: inflateInit2 failed");
+                    zs_ready_ = true;
+                }
+                else
+                    inflateReset(&zs_);
+                zs_.next_in = cdata_.data();
+                zs_.avail_in = (uInt)cdata_len;
+                zs_.next_out = data_.data();
+                zs_.avail_out = (uInt)isize;
+                const int rc = inflate(&zs_, Z_FINISH);
+                if (rc != Z_STREAM_END || zs_.avail_out != 0)
+                    throw std::runtime_error("BGZF: inflate failed in " + path_);
+            }
             const uint32_t want_crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
             if (crc32Fast(data_.data(), isize) != want_crc)
                 throw std::runtime_error("BGZF: CRC mismatch in " + path_);
@@ -474,7 +554,7 @@ private:
     {
         bool valid = false;
         uint64_t start = 0, csize = 0;
-        std::vector<unsigned char> data;
+        BlockBuffer data;
     };
     Cached ring_[kRing];
     size_t ring_next_ = 0;
@@ -485,7 +565,7 @@ private:
     FILE* fp_ = nullptr;
     bool have_block_ = false, eof_ = false;
     uint64_t block_start_ = 0, block_csize_ = 0;
-    std::vector<unsigned char> data_;
+    BlockBuffer data_;
     size_t within_ = 0;
 };
 
@@ -558,6 +638,7 @@ struct BamReader::Impl
     std::shared_ptr<const BamMeta> meta;
     RegionCursor cursor;
     std::vector<unsigned char> scratch;
+    const unsigned char* record = nullptr;  // the bytes of the record readRecord parsed last (in the current block, or in `scratch`)
 
     void open();
     void parseHeader(BamMeta& m);
@@ -710,18 +791,29 @@ void BamReader::Impl::loadIndex(BamMeta& m)
 
 bool BamReader::Impl::readRecord(BamRecord& rec)
 {
+    // a record that lies inside the current block is used where it is; one that straddles blocks is put together in `scratch`
     unsigned char b4[4];
-    const size_t got = bgzf->read(b4, 4);
-    if (got == 0)
-        return false;
-    if (got != 4)
-        throw std::runtime_error("Truncated BAM (record length) in " + path);
-    const uint32_t block_size = le32(b4);
+    const unsigned char* hdr = bgzf->take(4);
+    if (!hdr)
+    {
+        const size_t got = bgzf->read(b4, 4);
+        if (got == 0)
+            return false;
+        if (got != 4)
+            throw std::runtime_error("Truncated BAM (record length) in " + path);
+        hdr = b4;
+    }
+    const uint32_t block_size = le32(hdr);
     if (block_size < 32 || block_size > (1u << 29))
         throw std::runtime_error("Corrupt BAM record in " + path);
-    scratch.resize(block_size);
-    bgzf->readExact(scratch.data(), block_size, "record");
-    const unsigned char* p = scratch.data();
+    const unsigned char* p = bgzf->take(block_size);
+    if (!p)
+    {
+        scratch.resize(block_size);
+        bgzf->readExact(scratch.data(), block_size, "record");
+        p = scratch.data();
+    }
+    record = p;
     rec.tid = (int32_t)le32(p);
     rec.pos = (int32_t)le32(p + 4);
     const uint32_t l_name = p[8];
@@ -756,33 +848,13 @@ bool BamReader::Impl::readRecord(BamRecord& rec)
 
 void BamReader::Impl::decodeText(BamRecord& rec) const
 {
-    // two bases per packed byte, looked up as a pair
-    static const struct Pairs
-    {
-        char text[256][2];
-        Pairs()
-        {
-            static const char kBases[] = "=ACMGRSVTWYHKDBN";
-            for (int b = 0; b < 256; ++b)
-            {
-                text[b][0] = kBases[b >> 4];
-                text[b][1] = kBases[b & 0xF];
-            }
-        }
-    } pairs;
-    const unsigned char* p = scratch.data();
+    const unsigned char* p = record;
     rec.name.assign((const char*)p + rec.name_at, rec.name_len);
     const uint32_t l_seq = rec.seq_len;
     rec.bases.resize(l_seq);
     const unsigned char* packed = p + rec.seq_at;
-    char* out = l_seq ? &rec.bases[0] : nullptr;
-    for (uint32_t i = 0; i + 1 < l_seq; i += 2)
-    {
-        out[i] = pairs.text[packed[i / 2]][0];
-        out[i + 1] = pairs.text[packed[i / 2]][1];
-    }
-    if (l_seq & 1)
-        out[l_seq - 1] = pairs.text[packed[l_seq / 2]][0];
+    if (l_seq)
+        unpackBases(packed, l_seq, &rec.bases[0]);
     const unsigned char* q = packed + (l_seq + 1) / 2;
     rec.quals.resize(l_seq);
     for (uint32_t i = 0; i < l_seq; ++i)
@@ -960,7 +1032,7 @@ bool BamReader::getAlignLean(LeanAlign& out)
     {
         if (rec.flag & (samflag::kSupplementary | samflag::kSecondary))
             continue;
-        const unsigned char* p = impl_->scratch.data();
+        const unsigned char* p = impl_->record;
         out.name = (const char*)p + rec.name_at;
         out.name_len = rec.name_len;
         out.n_bases = rec.seq_len;
@@ -1009,29 +1081,10 @@ void LeanAlign::appendBasesTo(std::string& out) const
         out.append(text_bases, n_bases);
         return;
     }
-    static const struct Pairs
-    {
-        char text[256][2];
-        Pairs()
-        {
-            static const char kBases[] = "=ACMGRSVTWYHKDBN";
-            for (int b = 0; b < 256; ++b)
-            {
-                text[b][0] = kBases[b >> 4];
-                text[b][1] = kBases[b & 0xF];
-            }
-        }
-    } pairs;
     const size_t at = out.size();
     out.resize(at + n_bases);
-    char* dst = n_bases ? &out[at] : nullptr;
-    for (uint32_t i = 0; i + 1 < n_bases; i += 2)
-    {
-        dst[i] = pairs.text[packed_bases[i / 2]][0];
-        dst[i + 1] = pairs.text[packed_bases[i / 2]][1];
-    }
-    if (n_bases & 1)
-        dst[n_bases - 1] = pairs.text[packed_bases[n_bases / 2]][0];
+    if (n_bases)
+        unpackBases(packed_bases, n_bases, &out[at]);
 }
 
 bool BamReader::getAlignedMate(const Read& read, Read& mate)

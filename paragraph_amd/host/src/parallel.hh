@@ -11,11 +11,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <sched.h>
+#include <string>
 
 namespace pghost
 {
 // CPUs this process can really run on at once: the hardware threads, its affinity mask and -- in a container -- the CPU
-// bandwidth of its cgroup (cpu.max: a box may show 256 CPUs and allow 16).  The command lines default their host threads to it.
+// bandwidth of its cgroup (v2: cpu.max, v1: cpu.cfs_quota_us / cpu.cfs_period_us: a box may show 256 CPUs and allow 16).  The command lines default their host threads to it.
 inline int usableCpus()
 {
     int n = (int)std::thread::hardware_concurrency();
@@ -24,7 +25,8 @@ inline int usableCpus()
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0)
         n = std::min(n, (int)CPU_COUNT(&set));
-    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r"))
+    bool quota_seen = false;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r"))  // cgroup v2
     {
         char quota[32];
         long period = 0;
@@ -32,9 +34,33 @@ inline int usableCpus()
         {
             const long q = atol(quota);
             if (q > 0)
+            {
                 n = std::min(n, (int)std::max(1L, (q + period / 2) / period));
+                quota_seen = true;
+            }
         }
         fclose(f);
+    }
+    if (!quota_seen)  // cgroup v1: cpu.cfs_quota_us / cpu.cfs_period_us of the cpu controller (-1 = no limit)
+    {
+        auto read_long = [](const char* path, long& v) {
+            FILE* f = fopen(path, "r");
+            if (!f)
+                return false;
+            const bool ok = fscanf(f, "%ld", &v) == 1;
+            fclose(f);
+            return ok;
+        };
+        long q = -1, period = 0;
+        for (const char* dir : { "/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct" })
+        {
+            const std::string base(dir);
+            if (read_long((base + "/cpu.cfs_quota_us").c_str(), q) && read_long((base + "/cpu.cfs_period_us").c_str(), period))
+                break;
+            q = -1;
+        }
+        if (q > 0 && period > 0)
+            n = std::min(n, (int)std::max(1L, (q + period / 2) / period));
     }
     return std::max(1, n);
 }

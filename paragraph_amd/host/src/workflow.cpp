@@ -277,8 +277,9 @@ Json countDocument(
     Parameters const& parameters, GraphDescription const& d, SiteCounts const& counts, SiteReadViews const& views, size_t reads_in,
     common::ReadBuffer const* reads)
 {
-    Json out = d.description;
-    out["reference"] = d.reference_path;
+    Json out = parameters.description_in_document ? d.description : Json::object();
+    if (parameters.description_in_document)
+        out["reference"] = d.reference_path;
     out["fragment_statistics"] = fragmentStatistics(*d.graph, views);
     if (parameters.output_enabled(Parameters::NODE_READ_COUNTS))
         out["read_counts_by_node"] = countsToJson(counts.by_node);
@@ -348,6 +349,8 @@ BatchParameters batchParameters(Parameters const& parameters)
     bp.klib_sequence_matching = parameters.klib_sequence_matching;
     bp.threads = parameters.threads;
     bp.device = parameters.device;
+    bp.node_counts = parameters.output_enabled(Parameters::NODE_READ_COUNTS);
+    bp.sequence_counts = parameters.output_enabled(Parameters::PATH_READ_COUNTS);
     return bp;
 }
 }  // namespace
@@ -660,9 +663,12 @@ Json genotypeDocument(
     for (size_t i = 0; i < samples.size(); ++i)
     {
         genotyping::SampleInfo const& sample = *samples[i];
-        Json const& doc = *documents[i];
+        Json const& counted = *documents[i];
+        // a count document normally repeats the graph description (the reference's do); the batched workflow's do not, the
+        // description then comes from the loaded graph itself
+        Json const& doc = counted.isMember("nodes") ? counted : root;
         genotyper.addSample(
-            sample.sample_name(), edgeCounts(doc), sample.autosome_depth(), (int)sample.read_length(), sample.depth_sd(), sample.sex());
+            sample.sample_name(), edgeCounts(counted), sample.autosome_depth(), (int)sample.read_length(), sample.depth_sd(), sample.sex());
         if (doc.isMember("eventinfo"))
         {
             if (result.isMember("eventinfo") && result["eventinfo"] != doc["eventinfo"])
@@ -719,8 +725,8 @@ Json genotypeDocument(
             }
             result["graphinfo"] = info;
         }
-        Json per_sample = doc["alignment_statistics"];
-        for (auto const& kv : doc["fragment_statistics"].members())
+        Json per_sample = counted["alignment_statistics"];
+        for (auto const& kv : counted["fragment_statistics"].members())
             if (kv.first != "linear_histogram" && kv.first != "graph_histogram")
                 per_sample[kv.first] = kv.second;
         result["samples"][sample.sample_name()] = per_sample;
@@ -940,6 +946,13 @@ std::vector<Json> genotypeGraphs(
         };
         paragraph::Timings mine;
         paragraph::Parameters site_parameters = siteParameters(parameters);
+        if (!parameters.output_alignments)
+        {
+            // the count documents of this workflow are read by the genotyper and dropped: only the table it reads, no copy of
+            // the description (node / sequence tables and the per-family breakdown are what `paragraph` writes, not grmpy)
+            site_parameters.output_options_ = paragraph::Parameters::EDGE_READ_COUNTS;
+            site_parameters.description_in_document = false;
+        }
         site_parameters.threads = lane_threads;
         site_parameters.timings = parameters.timings ? &mine : nullptr;
         site_parameters.device = (int)((size_t)lane_id % n_devices);

@@ -28,6 +28,9 @@
 #include "paragraph/Statistics.hh"
 #include "paragraph/Workflow.hh"
 
+#include <zlib.h>
+#include "../../paragraph_amd/host/src/inflate.hh"
+
 using namespace common;
 
 static int g_failures = 0;
@@ -723,6 +726,127 @@ static void testChunkSchedule()
     CHECK(ten_k[0].second == 64 && ten_k[7].second - ten_k[7].first == 512);
 }
 
+// The BGZF block decoder (host/src/inflate.hh) against zlib: streams of every block type (stored, fixed, dynamic), sizes from
+// empty to 64 KiB, texts from one repeated byte over BAM-like records to noise, several compression levels and strategies,
+// concatenated blocks (Z_FULL_FLUSH) -- and corrupted / truncated streams, which must be refused, never overrun a buffer.
+static void testInflate()
+{
+    std::mt19937_64 rng(20260927);
+    auto deflateRaw = [](std::vector<unsigned char> const& text, int level, int strategy, bool flush_blocks) {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        CHECK(deflateInit2(&zs, level, Z_DEFLATED, -15, 8, strategy) == Z_OK);
+        std::vector<unsigned char> out(deflateBound(&zs, (uLong)text.size()) + 64 + text.size() / 100);
+        zs.next_out = out.data();
+        zs.avail_out = (uInt)out.size();
+        size_t at = 0;
+        while (flush_blocks && at + 5000 < text.size())
+        {
+            zs.next_in = const_cast<unsigned char*>(text.data() + at);
+            zs.avail_in = 5000;
+            CHECK(deflate(&zs, Z_FULL_FLUSH) == Z_OK);
+            at += 5000;
+        }
+        zs.next_in = const_cast<unsigned char*>(text.data() + at);
+        zs.avail_in = (uInt)(text.size() - at);
+        CHECK(deflate(&zs, Z_FINISH) == Z_STREAM_END);
+        out.resize(zs.total_out);
+        deflateEnd(&zs);
+        return out;
+    };
+    auto makeText = [&](int kind, size_t n) {
+        std::vector<unsigned char> t(n);
+        switch (kind)
+        {
+        case 0:  // one byte
+            std::fill(t.begin(), t.end(), (unsigned char)'A');
+            break;
+        case 1:  // noise
+            for (auto& c : t)
+                c = (unsigned char)rng();
+            break;
+        case 2:  // BAM-like: short binary headers, names, 4-bit bases, qualities from a small alphabet
+            for (size_t i = 0; i < n; ++i)
+            {
+                const size_t r = i % 280;
+                t[i] = r < 36 ? (unsigned char)((i / 280) >> (r % 3)) : r < 50 ? (unsigned char)("s123_f4567890"[r % 13]) : r < 125
+                        ? (unsigned char)(((rng() & 3) == 0 ? 1 : (rng() & 3) == 1 ? 2 : (rng() & 1) ? 4 : 8) * 17)
+                        : (unsigned char)(30 + rng() % 12);
+            }
+            break;
+        case 3:  // short period (offsets < 8: the overlapping-copy path)
+            for (size_t i = 0; i < n; ++i)
+                t[i] = (unsigned char)("ACGTTGA"[i % (1 + (i / 997) % 7)]);
+            break;
+        default:  // text with long-range repeats
+            for (size_t i = 0; i < n; ++i)
+                t[i] = i >= 3000 && (rng() % 8) ? t[i - 3000 + (i % 7 == 0)] : (unsigned char)("ACGTN"[rng() % 5]);
+        }
+        return t;
+    };
+    size_t streams = 0, kinds_seen[3] = { 0, 0, 0 };
+    for (size_t n : { (size_t)0, (size_t)1, (size_t)2, (size_t)7, (size_t)63, (size_t)300, (size_t)301, (size_t)4096, (size_t)20000, (size_t)65280, (size_t)65536 })
+        for (int kind = 0; kind < 5; ++kind)
+            for (int cfg = 0; cfg < 6; ++cfg)
+            {
+                static const int levels[6] = { 0, 1, 6, 9, 6, 6 };
+                static const int strategies[6] = { Z_DEFAULT_STRATEGY, Z_DEFAULT_STRATEGY, Z_DEFAULT_STRATEGY, Z_DEFAULT_STRATEGY, Z_FIXED, Z_HUFFMAN_ONLY };
+                const std::vector<unsigned char> text = makeText(kind, n);
+                std::vector<unsigned char> comp = deflateRaw(text, levels[cfg], strategies[cfg], kind == 4 && cfg == 2);
+                if (!comp.empty())
+                    ++kinds_seen[(comp[0] >> 1) & 3 ? ((comp[0] >> 1) & 3) - 0 > 2 ? 0 : (comp[0] >> 1) & 3 : 0];
+                const size_t clen = comp.size();
+                comp.resize(clen + 8, 0xAB);
+                std::vector<unsigned char> out(n + 16, 0xCD);
+                const int rc = pginflate::inflateBlock(comp.data(), clen, out.data(), n);
+                CHECK(rc == pginflate::kOk);
+                CHECK(memcmp(out.data(), text.data(), n) == 0);
+                ++streams;
+                if (n == 0)
+                    continue;
+                // wrong expected size: one byte short / one byte long must be reported, not written past
+                std::vector<unsigned char> small(n - 1 + 16, 0xCD);
+                CHECK(pginflate::inflateBlock(comp.data(), clen, small.data(), n - 1) != pginflate::kOk);
+                for (size_t k = n - 1 + 16; k-- > n - 1 + 0 && k >= n - 1 + 16;)
+                    CHECK(small[k] == 0xCD);
+                std::vector<unsigned char> large(n + 1 + 16, 0xCD);
+                CHECK(pginflate::inflateBlock(comp.data(), clen, large.data(), n + 1) != pginflate::kOk);
+                // truncated and bit-flipped streams: any answer but a crash / an overrun; "ok" only with the right bytes
+                for (int trial = 0; trial < 6; ++trial)
+                {
+                    std::vector<unsigned char> bad(comp.begin(), comp.begin() + (std::ptrdiff_t)clen);
+                    size_t blen = clen;
+                    if (trial < 2)
+                        blen = clen > 1 ? (size_t)(rng() % clen) : 0;
+                    else
+                        bad[rng() % clen] ^= (unsigned char)(1u << (rng() % 8));
+                    bad.resize(blen);
+                    bad.resize(blen + 8, 0xEE);
+                    std::vector<unsigned char> o2(n + 16, 0xCD);
+                    const int r2 = pginflate::inflateBlock(bad.data(), blen, o2.data(), n);
+                    // the reference decoder on the same input
+                    std::vector<unsigned char> oz(n + 1);
+                    z_stream zi;
+                    memset(&zi, 0, sizeof zi);
+                    inflateInit2(&zi, -15);
+                    zi.next_in = bad.data();
+                    zi.avail_in = (uInt)blen;
+                    zi.next_out = oz.data();
+                    zi.avail_out = (uInt)(n + 1);
+                    const int rz = inflate(&zi, Z_FINISH);
+                    const bool z_ok = rz == Z_STREAM_END && zi.total_out == n && zi.avail_in == 0;
+                    inflateEnd(&zi);
+                    if (z_ok)
+                        CHECK(r2 == pginflate::kOk && memcmp(o2.data(), oz.data(), n) == 0);
+                    else if (r2 == pginflate::kOk)  // zlib also insists that no input is left over; otherwise the bytes must agree
+                        CHECK(rz == Z_STREAM_END && zi.total_out == n && memcmp(o2.data(), oz.data(), n) == 0);
+                    for (size_t k = n; k < n + 16; ++k)
+                        CHECK(o2[k] == 0xCD);
+                }
+            }
+    CHECK(streams == 11 * 5 * 6);
+}
+
 int main(int argc, char** argv)
 {
     if (argc == 4 && std::string(argv[1]) == "--dump-bam")
@@ -770,6 +894,7 @@ int main(int argc, char** argv)
     const std::string dir = argv[1];
     const std::pair<const char*, std::function<void()>> tests[] = {
         { "json", testJson },
+        { "inflate", testInflate },
         { "coordinates", testCoordinates },
         { "fasta", [&] { testFasta(dir); } },
         { "bam-vs-sam", [&] { testBamAgainstSam(dir); } },

@@ -449,3 +449,90 @@ def test_one_oversize_site_does_not_take_the_run_down(tmp_path):
     for d in objects:
         if "error" not in d:
             assert by_id[d["graphinfo"]["ID"]] == d
+
+
+def _graphs_of_expected_genotypes(expected, folder):
+    """The graphs the reference's expected-genotypes.json was computed on, rebuilt from its own `graphinfo`: node names say what
+    a node is ("ref-<chrom>:<a>-<b>" = that reference interval, "<chrom>:<a>-<b>:<SEQ>" = inline sequence, source / sink = N x 10),
+    edge names are "<from>_<to>" and carry the sequence labels."""
+    import json
+    paths = []
+    for k, doc in enumerate(expected):
+        info = doc["graphinfo"]
+        nodes = []
+        for n in info["nodes"]:
+            name = n["name"]
+            if name in ("source", "sink"):
+                nodes.append({"name": name, "sequence": "N" * 10})
+            elif name.startswith("ref-"):
+                nodes.append({"name": name, "reference": name[4:]})
+            else:
+                nodes.append({"name": name, "sequence": name.rsplit(":", 1)[1]})
+        edges = []
+        for e in info["edges"]:
+            a, b = e["name"].split("_")
+            edge = {"from": a, "to": b}
+            if "sequences" in e:
+                edge["sequences"] = e["sequences"]
+            edges.append(edge)
+        path = os.path.join(str(folder), "expected_graph_%d.json" % k)
+        with open(path, "w") as f:
+            json.dump({"ID": info["ID"], "nodes": nodes, "edges": edges, "sequencenames": info["sequencenames"],
+                       "target_regions": info["target_regions"]}, f)
+        paths.append(path)
+    return paths
+
+
+def test_swaps_statistics_equal_the_references_expected_genotypes(tmp_path):
+    """share/test-data/genotyping_test_2/expected-genotypes.json is a genotype document the REFERENCE wrote for swaps.bam (three
+    swaps at 600x): besides GT / GL it holds, per sample, `alignment_statistics` (per node / edge / allele: reads by strand,
+    match-base depth, mismatch / gap / clip rates, average score, contig length) and `fragment_statistics` -- the only values
+    of src/c++/lib/paragraph/AlignmentStatistics.cpp the reference's data holds.  Same graphs (rebuilt from the file's own
+    graphinfo), same BAM -> every number equal at the 5 significant digits the file was written with."""
+    import json
+    import math
+    from paragraph_amd import workflow
+    d = os.path.join(ROOT, "tests", "golden", "sites", "swaps")
+    expected = json.load(open(os.path.join(d, "expected-genotypes.json")))
+    graphs = _graphs_of_expected_genotypes(expected, tmp_path)
+    docs = workflow.genotype_graphs(os.path.join(d, "swaps.fa"), os.path.join(d, "samples.txt"), graphs, threads=2)
+    assert len(docs) == 3
+
+    def same(a, b, where):
+        if isinstance(a, dict):
+            assert isinstance(b, dict) and set(a) == set(b), (where, sorted(a), sorted(b) if isinstance(b, dict) else b)
+            for k in a:
+                same(a[k], b[k], where + "/" + k)
+        elif isinstance(a, list):
+            assert isinstance(b, list) and len(a) == len(b), (where, a, b)
+            for i, (x, y) in enumerate(zip(a, b)):
+                same(x, y, "%s[%d]" % (where, i))
+        elif isinstance(a, float) or isinstance(b, float):
+            if a is None or b is None:
+                assert a is None and b is None, (where, a, b)
+            elif math.isinf(a) or math.isinf(b):
+                assert a == b, (where, a, b)
+            else:
+                assert math.isclose(a, b, rel_tol=6e-5, abs_tol=1e-12), (where, a, b)  # 5 significant digits in the file
+        else:
+            assert a == b, (where, a, b)
+
+    checked = 0
+    for want, got in zip(expected, docs):
+        assert got["graphinfo"]["ID"] == want["graphinfo"]["ID"]
+        w, g = want["samples"]["SWAPS"], got["samples"]["SWAPS"]
+        for block in ("alleles", "edges", "nodes"):  # alignment_statistics
+            same(w[block], g[block], "%s/%s" % (want["graphinfo"]["ID"], block))
+            checked += len(w[block])
+        for key in ("bad_alignment_pct", "mean_graph", "mean_linear", "median_graph", "median_linear", "multi_read", "paired_read",
+                    "problematic_graph", "problematic_linear", "single_read", "variance_graph", "variance_linear"):
+            same(w[key], g[key], "%s/%s" % (want["graphinfo"]["ID"], key))
+        for name, bp in w["breakpoints"].items():  # edge / allele counts and the likelihoods of every breakpoint
+            same(bp["counts"], g["breakpoints"][name]["counts"], name + "/counts")
+            for key in ("GL", "GT", "allele_fractions", "num_reads", "coverage_test_pvalue"):
+                if key in bp["gt"]:
+                    same(bp["gt"][key], g["breakpoints"][name]["gt"][key], name + "/gt/" + key)
+        for key in ("GL", "GT", "allele_fractions", "num_reads"):
+            same(w["gt"][key], g["gt"][key], "gt/" + key)
+        assert want["breakpointinfo"] == got["breakpointinfo"]
+    assert checked > 40

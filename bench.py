@@ -639,7 +639,7 @@ def main_rank(args):
                            "sites_per_s": sites_out["sites_per_s"]},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                             "kernel": "pg_fill_kernel<%d, false>" % (2 * ((L + 31) // 32)),
+                             "kernel": "pg_fill_kernel<%d, false, 16>" % (2 * ((L + 31) // 32)),
                              "launches": int(tim["fill_launches"]),
                              "avg_launch_ms": tim["fill_ms"] / max(1, tim["fill_launches"]),
                              "alg_bytes_per_launch": b_alg_mine * args.steps / max(1, tim["fill_launches"]),
@@ -837,7 +837,7 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
         "roofline": {
             "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": roof_extra.pop("traffic"),
-            "kernel": "pg_fill_kernel<%d, false>" % (2 * ((L + 31) // 32)),
+            "kernel": "pg_fill_kernel<%d, false, 16>" % (2 * ((L + 31) // 32)),
             "launches": int(tim["fill_launches"]),
             "avg_launch_ms": tim["fill_ms"] / max(1, tim["fill_launches"]),
             **roof_extra,

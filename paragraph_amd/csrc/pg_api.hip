@@ -278,6 +278,8 @@ extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
     int prio_least = 0, prio_greatest = 0;
     if (hipSetDevice(device) == hipSuccess)
         (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    // reads of 251..512 bases: 32 lanes per read (two wavefronts per work item); PG_WIDE16=1 = the 16-lane kernels, for A/B timing
+    ctx->wide32 = getenv("PG_WIDE16") == nullptr;
     const char* pe = getenv("PG_STREAM_PRIORITY");
     const int side_prio = (pe && pe[0] == '0') ? 0 : prio_greatest;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess
@@ -968,7 +970,8 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
             ++q;
         const int C = (int)keys[p].c;
         const HostGraph& hg = G->host[keys[p].graph];
-        const uint64_t nsteps = pg_fill_steps(hg.ncols);
+        // (the wide variants' sweeps run 32 lanes per read: 16 steps more; sized for that whichever kernel set runs)
+        const uint64_t nsteps = pg_fill_steps_lanes(hg.ncols, pg_var_wide(C) ? PG_WIDE_LANES : PG_GROUP_LANES);
         const uint64_t trace_bytes = align_up(nsteps * 64 * pg_trace_lane_bytes(C), 256);
         const uint64_t seed_bytes = pg_seed_region_bytes(C, hg.n_nodes) + pg_key_region_bytes(hg.n_nodes);
         // + the traceback's CIGAR scratch of the pair's four reads (reversed-graph item's trace_off, which has no trace)
@@ -1307,7 +1310,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             ev.kind = 0;
             HIP_TRY(ctx, hipEventRecord(ev.a, ctx->stream));
         }
-        HIP_TRY(ctx, pg_launch_fill(ch.C, fa, n_pairs, revg, ch.max_nodes, ctx->stream));
+        HIP_TRY(ctx, pg_launch_fill(ch.C, fa, n_pairs, revg, ctx->wide32, ctx->stream));
         if (ctx->timing)
         {
             HIP_TRY(ctx, hipEventRecord(ev.b, ctx->stream));
@@ -1326,6 +1329,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         ta.pair_begin = ch.pair_begin;
         ta.n_pairs = n_pairs;
         ta.C = ch.C;
+        ta.wide32 = ctx->wide32 ? 1u : 0u;
         ta.flags = flags;
         ta.graphs = G->d_graphs;
         ta.nodes = G->d_nodes;

@@ -40,6 +40,12 @@
 // pipeline steps of one sweep: the 16 lanes of a read are skewed by one column each (ncols + 15 steps); rounded up to an
 // even count because the step loop is unrolled twice with ping-pong register naming (the extra step runs on an idle column)
 static inline __host__ __device__ uint32_t pg_fill_steps(uint32_t ncols) { return (ncols + PG_GROUP_LANES) & ~1u; }
+// ... and of a sweep whose reads take `lanes` lanes each.  The WIDE variants (reads of 251..512 bases) run 32 lanes per read:
+// a work item's four reads are swept by TWO wavefronts (reads 0-1 and 2-3, PG_WIDE_HALVES), each with half the rows per lane --
+// half the LDS profile and far fewer registers per wavefront than four reads x 16 lanes x up to 32 rows.
+#define PG_WIDE_LANES 32
+#define PG_WIDE_HALVES 2
+static inline __host__ __device__ uint32_t pg_fill_steps_lanes(uint32_t ncols, uint32_t lanes) { return (ncols + lanes) & ~1u; }
 
 // The fill kernel keeps scores in a frame that moves by one per pipeline step (pg_fill.hip): the H trace holds
 // (score + PG_TAU0 + (step & 255)) & 0xFF per cell, step = column + lane of the row.

@@ -78,9 +78,12 @@ __device__ __forceinline__ int sub_score(uint32_t a, uint32_t b)
     return (a == 4u || b == 4u) ? 0 : (a == b ? 1 : -4);
 }
 
-template <int C, int DIR, bool WIDE>
-__device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair, uint32_t* lds)
+template <int C, int DIR, bool WIDE, int GL = PG_GROUP_LANES>
+__device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair, uint32_t* lds, uint32_t half = 0)
 {
+    // GL lanes per read: 16 = the four reads of a work item in one wavefront; 32 (wide variants) = two reads per wavefront,
+    // wavefront `half` of the item takes reads 2 * half, 2 * half + 1 and its own half of the item's trace / seed regions
+    constexpr int GROUPS = 64 / GL;
     constexpr int PAD = WIDE ? PG_PAD_SCORE_WIDE : PG_PAD_SCORE;
     // Register / LDS budget.  The byte variants keep the next column's profile rows (fetched one step ahead) and the lane's
     // last seed in registers: 128 VGPRs or fewer up to C = 12 (4 wavefronts per SIMD; the 4 KB x C / 4 of LDS profile allow
@@ -91,8 +94,8 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     constexpr bool SEEDCACHE = !WIDE;
     constexpr int TRACE_DW = C / 2;             // dwords of H trace per lane per step: one byte per cell, two strands
     constexpr int SEED_DW = WIDE ? 2 * C : C;   // dwords of seed per lane per node
-    constexpr int ROWS = PG_GROUP_LANES * C;
-    // LDS holds the profiles of the four real reference codes only: [4 reads][4 codes][ROWS] packed (strand A | strand B << 16)
+    constexpr int ROWS = GL * C;
+    // LDS holds the profiles of the four real reference codes only: [GROUPS reads][4 codes][ROWS] packed (strand A | strand B << 16)
     // = 10 240 B at C = 10, i.e. 16 wavefronts per CU (the kernel is latency-sensitive: 12 -> 16 waves is worth ~8 %).  Code 4
     // (N / idle column) scores 0 on real rows and PAD on padding rows: synthesised in registers on the rare columns that
     // carry it.  The per-node maxima keys live in the workspace behind this item's seed region (global atomics, 3 per lane
@@ -100,8 +103,9 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     uint32_t* prof = lds;
 
     const int lane = threadIdx.x;
-    const int grp = lane >> 4;
-    const int k = lane & 15;
+    const int lgrp = lane / GL;                    // read of this wavefront the lane works for
+    const int grp = (int)half * GROUPS + lgrp;     // ... = read slot of the work item
+    const int k = lane % GL;
 
     // items come in (forward graph, reversed graph) pairs: this instantiation takes the DIR member
     const uint32_t item_idx = a.item_begin + 2 * pair + DIR;
@@ -111,7 +115,8 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     const uint32_t* __restrict__ smeta = a.colmeta + gd.meta_off;
     const PgNode* __restrict__ nodes = a.nodes + gd.node_off;
     const uint32_t n_nodes = gd.n_nodes;
-    uint32_t* nodekey = (uint32_t*)(a.workspace + itp->seed_off + pg_seed_region_bytes(WIDE ? PG_VAR_WIDE + C : C, n_nodes));
+    // (the item's seed region holds both halves' seeds: GROUPS * GL * C = 64 x the 16-lane variant's rows either way)
+    uint32_t* nodekey = (uint32_t*)(a.workspace + itp->seed_off + pg_seed_region_bytes(WIDE ? PG_VAR_WIDE + C * (GL / 16) : C, n_nodes));
     unsigned long long* nodekey64 = (unsigned long long*)nodekey;  // [n_nodes][4 reads][2 strands] 64-bit slots
 
     // ---- the moving frame ----------------------------------------------------------------------------------------------------
@@ -131,9 +136,9 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // ---- query profiles of the 8 fills into LDS (gssw_qP_byte), shifted by the frame step ------------------------------
     // (read index, offset and length are uniform per read: loaded once, not per profile entry)
 #pragma unroll
-    for (int g = 0; g < PG_GROUPS; ++g)
+    for (int g = 0; g < GROUPS; ++g)
     {
-        const uint32_t ridx = itp->read[g];
+        const uint32_t ridx = itp->read[(int)half * GROUPS + g];
         uint32_t off = 0, L = 0;
         if (ridx != PG_NONE)
         {
@@ -167,8 +172,9 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     }
     // (device-scope stores / loads on the keys, but only a workgroup-scope fence: an agent-scope fence would write the
     // whole L2 back, trace stores included)
-    for (uint32_t e = lane; e < n_nodes * 16; e += 64)
-        __hip_atomic_store(&nodekey[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // this wavefront's key slots only ([node][4 reads][2 strands] 64-bit slots: 4 * GROUPS dwords per node from its first read)
+    for (uint32_t e = lane; e < n_nodes * 4 * GROUPS; e += 64)
+        __hip_atomic_store(&nodekey[(e / (4 * GROUPS)) * 16 + half * 4 * GROUPS + e % (4 * GROUPS)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence_block();
     __syncthreads();
     // rows of this lane that exist in its read (the others are padding rows)
@@ -179,8 +185,11 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         real_rows = Lg > (uint32_t)(k * C) ? Lg - (uint32_t)(k * C) : 0u;
     }
 
-    uint32_t* __restrict__ seed = (uint32_t*)(a.workspace + itp->seed_off);    // [node][lane][SEED_DW]
-    uint32_t* __restrict__ trace = (uint32_t*)(a.workspace + itp->trace_off);  // [step][TRACE_DW][lane]: one store instruction = 256 contiguous bytes
+    const uint32_t nsteps = pg_fill_steps_lanes(gd.ncols, GL);  // even
+    // [node][lane][SEED_DW] / [step][TRACE_DW][lane] (one store instruction = 256 contiguous bytes); wavefront `half` of a wide
+    // item owns the second n_nodes * 64 * SEED_DW / nsteps * 64 * TRACE_DW dwords
+    uint32_t* __restrict__ seed = (uint32_t*)(a.workspace + itp->seed_off) + (size_t)half * n_nodes * 64 * SEED_DW;
+    uint32_t* __restrict__ trace = (uint32_t*)(a.workspace + itp->trace_off) + (size_t)half * nsteps * 64 * TRACE_DW;
 
     // H of the previous column lives in one of two register sets (HA / HB): a step reads one and writes the other, and the
     // step loop is unrolled twice with the roles swapped -- no register-to-register copies at the loop edge (the same for the
@@ -208,8 +217,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     uint32_t FR = 0;  // WIDE: smallest row (within the lane) holding the lane's maximum in column FC, per strand
     const uint32_t NEG5 = 0xC500C500u;    // (-5.0, -5.0): gap extend - gap open
     const uint32_t NEG256 = 0xDC00DC00u;  // (-256.0, -256.0)
-    const uint32_t nsteps = pg_fill_steps(gd.ncols);  // even
-    const uint32_t* profl = prof + grp * 4 * ROWS + k * C;
+    const uint32_t* profl = prof + lgrp * 4 * ROWS + k * C;
     const uint32_t trace_lane_off = (uint32_t)lane * 4u;
 
     // Column meta words: the word of step t is the same for the whole wavefront, so it is read with SCALAR loads through
@@ -220,7 +228,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     const const_u32_ptr cmeta = (const_u32_ptr)(uintptr_t)smeta;
     uint32_t mw1 = cmeta[1], mw2 = cmeta[2];
     // software pipeline: `meta` and the current profile rows always belong to the step about to be computed
-    uint32_t meta = row_shr1_keep(cmeta[0], PG_META_IDLE);
+    uint32_t meta = group_shr1_keep<GL>(cmeta[0], PG_META_IDLE);
     // code 4 (N / idle column: score 0 on real rows) in the profile's shifted form
     auto code4_rows = [&](uint32_t (&rows)[C]) __attribute__((always_inline)) {
 #pragma unroll
@@ -293,11 +301,15 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 // node's cells (epilogue).  A maximum passes through each of those five values at most once, so the row search
                 // runs a handful of times per node instead of at every growth step.  (The traceback's start row is found from
                 // the H trace in the epilogue, like in the byte variants.)
-                const uint32_t mnA = Mn & 0xFFFFu, mnB = Mn >> 16;  // bit patterns: 0x6400 + score + tau
-                const bool needA = (grew & 0xFFFFu) && ((mnA & 0x3FFu) - tau - 251u) <= 4u;
-                const bool needB = (grew >> 16) && ((mnB & 0x3FFu) - tau - 251u) <= 4u;
-                if (needA || needB)
+                // the test itself runs at every step, so it is kept to five packed instructions: score - 251 per strand by one
+                // subtraction of the wave-uniform pattern of 251 in this step's frame, clamped at 5 (anything below the window
+                // wraps around to a large unsigned value and is clamped too), in the window where the result is not 5
+                const uint32_t inwin = pk_minu(pk_sub(Mn, BIAS2 + (tau + 251u) * ONE2), 5u * ONE2) ^ (5u * ONE2);
+                const uint32_t need = inwin & grew;
+                if (need)
                 {
+                    const uint32_t mnA = Mn & 0xFFFFu, mnB = Mn >> 16;  // bit patterns: 0x6400 + score + tau
+                    const bool needA = (need & 0xFFFFu) != 0u, needB = (need >> 16) != 0u;
                     uint32_t frA = FR & 0xFFFFu, frB = FR >> 16;
 #pragma unroll
                     for (int r = C - 1; r >= 0; --r)
@@ -464,11 +476,11 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         // input one step later (lane k + 1 works one column behind lane k).  The row's first lane has no lane above: it keeps
         // its own register, which follows the frame by one per step.
         dHin = pk_add(dHin, ONE2);
-        dHin = row_shr1_keep(dHin, Hout[C - 1]);
-        Fin = row_shr1_keep(Fin, Fsend);
+        dHin = group_shr1_keep<GL>(dHin, Hout[C - 1]);
+        Fin = group_shr1_keep<GL>(Fin, Fsend);
         const uint32_t dH = dHin, F = Fin;
         // the next step's meta word; the profile rows of the next column (PREFETCH) or of this one
-        meta = row_shr1_keep(mw1, meta_cur);
+        meta = group_shr1_keep<GL>(mw1, meta_cur);
         mw1 = mw2;
         mw2 = cmeta[t + 3];
         const uint32_t meta_rows = PREFETCH ? meta : meta_cur;
@@ -594,7 +606,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             const uint32_t kk = (0xFFFFu - (uint32_t)(bestkey & 0xFFFFu)) / (uint32_t)C;
             // (bytes = (score + tau) mod 256: within one lane's C <= 32 rows of a column the scores differ by far less than 256,
             // so comparing modulo 256 finds the same first row)
-            const uint32_t* tp = trace + (size_t)(col + kk) * 64 * TRACE_DW + (grp * 16 + kk);
+            const uint32_t* tp = trace + (size_t)(col + kk) * 64 * TRACE_DW + (lgrp * GL + kk);
             const uint32_t tau = PG_TAU0 + ((col + kk) & 255u);
             int rr = 0;
             bool found = false;
@@ -651,7 +663,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         {
             const uint32_t col = 0xFFFFu - ((bestkey >> 4) & 0xFFFFu);
             const uint32_t kk = 15u - (bestkey & 15u);
-            const uint32_t* tp = trace + (size_t)(col + kk) * 64 * TRACE_DW + (grp * 16 + kk);
+            const uint32_t* tp = trace + (size_t)(col + kk) * 64 * TRACE_DW + (lgrp * GL + kk);
             int rr = 0;
             bool found = false;
 #pragma unroll
@@ -686,35 +698,33 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 // the launch would last as long as the heavier half.  Instead the direction changes every EIGHT workgroups: XCD x gets
 // workgroups x, x + 8, x + 16, ... = pair p forward, pair p reversed, pair p + 8 forward, ... -- the same mix on every XCD.
 // With AF_REVERSE_GRAPH off (both_dirs == 0) every workgroup is a forward-graph one.
-template <int C, bool WIDE>
+template <int C, bool WIDE, int GL = PG_GROUP_LANES>
 __global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // GL = 32: two wavefronts (workgroups) per work item, unit = 2 * pair + half
+    constexpr uint32_t HALVES = GL / PG_GROUP_LANES;
+    const uint32_t n_units = a.n_pairs * HALVES;
     if (a.both_dirs)
     {
         const uint32_t j = blockIdx.x >> 3;
-        const uint32_t pair = (j >> 1) * 8u + (blockIdx.x & 7u);
-        if (pair >= a.n_pairs)
+        const uint32_t unit = (j >> 1) * 8u + (blockIdx.x & 7u);
+        if (unit >= n_units)
             return;  // the grid is rounded up to whole runs of eight
         if (j & 1u)
-            pg_fill_body<C, 1, WIDE>(a, pair, lds);
+            pg_fill_body<C, 1, WIDE, GL>(a, unit / HALVES, lds, unit % HALVES);
         else
-            pg_fill_body<C, 0, WIDE>(a, pair, lds);
+            pg_fill_body<C, 0, WIDE, GL>(a, unit / HALVES, lds, unit % HALVES);
     }
     else
-        pg_fill_body<C, 0, WIDE>(a, blockIdx.x, lds);
+        pg_fill_body<C, 0, WIDE, GL>(a, blockIdx.x / HALVES, lds, blockIdx.x % HALVES);
 }
 
-size_t pg_fill_lds_bytes(int V, uint32_t max_nodes)
+template <int C, bool WIDE = false, int GL = PG_GROUP_LANES>
+static hipError_t launch_c(PgFillArgs args, uint32_t n_pairs, bool revg, hipStream_t stream)
 {
-    (void)max_nodes;
-    return (size_t)(PG_GROUPS * 4 * PG_GROUP_LANES * pg_var_c(V)) * sizeof(uint32_t);
-}
-
-template <int C, bool WIDE = false>
-static hipError_t launch_c(PgFillArgs args, uint32_t n_pairs, bool revg, size_t lds, hipStream_t stream)
-{
-    void (*fn)(PgFillArgs) = pg_fill_kernel<C, WIDE>;
+    void (*fn)(PgFillArgs) = pg_fill_kernel<C, WIDE, GL>;
+    const size_t lds = (size_t)(64 * 4 * C) * sizeof(uint32_t);  // [64 / GL reads][4 codes][GL * C rows]
     if (lds > 48 * 1024)
     {
         hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -723,31 +733,44 @@ static hipError_t launch_c(PgFillArgs args, uint32_t n_pairs, bool revg, size_t 
     }
     args.both_dirs = revg ? 1u : 0u;
     args.n_pairs = n_pairs;
-    hipLaunchKernelGGL(fn, dim3(revg ? (n_pairs + 7u) / 8u * 16u : n_pairs), dim3(64), lds, stream, args);
+    const uint32_t n_units = n_pairs * (uint32_t)(GL / PG_GROUP_LANES);
+    hipLaunchKernelGGL(fn, dim3(revg ? (n_units + 7u) / 8u * 16u : n_units), dim3(64), lds, stream, args);
     return hipGetLastError();
 }
 
-// Launches the forward-graph fills of n_pairs item pairs and (revg) their reversed-graph fills.
-hipError_t pg_launch_fill(int C, const PgFillArgs& args, uint32_t n_pairs, bool revg, uint32_t max_nodes, hipStream_t stream)
+// Launches the forward-graph fills of n_pairs item pairs and (revg) their reversed-graph fills.  V = the chunk's variant code;
+// wide32: the wide variants with 32 lanes per read (two wavefronts per item, half the rows per lane).
+hipError_t pg_launch_fill(int V, const PgFillArgs& args, uint32_t n_pairs, bool revg, bool wide32, hipStream_t stream)
 {
     if (n_pairs == 0)
         return hipSuccess;
-    const size_t lds = pg_fill_lds_bytes(C, max_nodes);
-    switch (C)
+    if (pg_var_wide(V) && wide32)
     {
-    case 2: return launch_c<2>(args, n_pairs, revg, lds, stream);
-    case 4: return launch_c<4>(args, n_pairs, revg, lds, stream);
-    case 6: return launch_c<6>(args, n_pairs, revg, lds, stream);
-    case 8: return launch_c<8>(args, n_pairs, revg, lds, stream);
-    case 10: return launch_c<10>(args, n_pairs, revg, lds, stream);
-    case 12: return launch_c<12>(args, n_pairs, revg, lds, stream);
-    case 14: return launch_c<14>(args, n_pairs, revg, lds, stream);
-    case 16: return launch_c<16>(args, n_pairs, revg, lds, stream);
-    case PG_VAR_WIDE + 16: return launch_c<16, true>(args, n_pairs, revg, lds, stream);
-    case PG_VAR_WIDE + 20: return launch_c<20, true>(args, n_pairs, revg, lds, stream);
-    case PG_VAR_WIDE + 24: return launch_c<24, true>(args, n_pairs, revg, lds, stream);
-    case PG_VAR_WIDE + 28: return launch_c<28, true>(args, n_pairs, revg, lds, stream);
-    case PG_VAR_WIDE + 32: return launch_c<32, true>(args, n_pairs, revg, lds, stream);
+        switch (pg_var_c(V))
+        {
+        case 16: return launch_c<8, true, 32>(args, n_pairs, revg, stream);
+        case 20: return launch_c<10, true, 32>(args, n_pairs, revg, stream);
+        case 24: return launch_c<12, true, 32>(args, n_pairs, revg, stream);
+        case 28: return launch_c<14, true, 32>(args, n_pairs, revg, stream);
+        case 32: return launch_c<16, true, 32>(args, n_pairs, revg, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    switch (V)
+    {
+    case 2: return launch_c<2>(args, n_pairs, revg, stream);
+    case 4: return launch_c<4>(args, n_pairs, revg, stream);
+    case 6: return launch_c<6>(args, n_pairs, revg, stream);
+    case 8: return launch_c<8>(args, n_pairs, revg, stream);
+    case 10: return launch_c<10>(args, n_pairs, revg, stream);
+    case 12: return launch_c<12>(args, n_pairs, revg, stream);
+    case 14: return launch_c<14>(args, n_pairs, revg, stream);
+    case 16: return launch_c<16>(args, n_pairs, revg, stream);
+    case PG_VAR_WIDE + 16: return launch_c<16, true>(args, n_pairs, revg, stream);
+    case PG_VAR_WIDE + 20: return launch_c<20, true>(args, n_pairs, revg, stream);
+    case PG_VAR_WIDE + 24: return launch_c<24, true>(args, n_pairs, revg, stream);
+    case PG_VAR_WIDE + 28: return launch_c<28, true>(args, n_pairs, revg, stream);
+    case PG_VAR_WIDE + 32: return launch_c<32, true>(args, n_pairs, revg, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -50,6 +50,7 @@ struct pg_ctx
     // workspace of the general path (reads / graphs beyond the packed kernels' envelope); used on stream2 only
     uint8_t* gen_ws = nullptr;
     uint64_t gen_ws_cap = 0;
+    bool wide32 = true;  // wide variants (reads of 251..512 bases) with 32 lanes per read
     bool timing = false;
     std::vector<EventPair> events;
     std::vector<hipEvent_t> event_pool;

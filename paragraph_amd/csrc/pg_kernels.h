@@ -27,7 +27,8 @@ struct PgTraceArgs
     const PgWorkItem* items;
     uint32_t pair_begin;  // first (fwd,rev) item pair of this launch; fwd item = 2*pair, rev = 2*pair+1
     uint32_t n_pairs;
-    int C;
+    int C;           // variant code of the chunk
+    uint32_t wide32; // wide variants: the fill ran 32 lanes per read (two wavefronts per work item, pg_fill.hip)
     uint32_t flags;  // PG_AF_*
     const PgGraphDev* graphs;
     const PgNode* nodes;
@@ -43,6 +44,5 @@ struct PgTraceArgs
     unsigned long long* ops_counter;
 };
 
-size_t pg_fill_lds_bytes(int C, uint32_t max_nodes);
-hipError_t pg_launch_fill(int C, const PgFillArgs& args, uint32_t n_pairs, bool revg, uint32_t max_nodes, hipStream_t stream);
+hipError_t pg_launch_fill(int V, const PgFillArgs& args, uint32_t n_pairs, bool revg, bool wide32, hipStream_t stream);
 hipError_t pg_launch_trace(const PgTraceArgs& args, hipStream_t stream);

@@ -120,3 +120,17 @@ __device__ __forceinline__ uint32_t row_shr1_keep(uint32_t first, uint32_t v)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x111, 0xf, 0xf, false);
 }
+// The same shift for groups of GL lanes (a read = GL lanes): GL = 16 is one DPP row; GL = 32 spans two rows, so lane 16 of a
+// group first takes lane 15 of the row before it (row_bcast:15 into the odd rows), then row_shr:1 moves the rest -- lane 0 of
+// every row keeps what it holds, which is `first` in the group's first lane and the broadcast value in its 17th.
+template <int GL> __device__ __forceinline__ uint32_t group_shr1_keep(uint32_t first, uint32_t v)
+{
+    if constexpr (GL == 16)
+        return row_shr1_keep(first, v);
+    else
+    {
+        static_assert(GL == 32, "a read takes 16 or 32 lanes");
+        const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15, rows 1 and 3
+        return (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)v, 0x111, 0xf, 0xf, false);
+    }
+}

@@ -123,7 +123,9 @@ struct Emitter
 };
 }  // namespace
 
-template <int C, bool WIDE>
+// GL = lanes per read in the FILL that wrote the trace (16, or 32 for the wide variants: two fill wavefronts per work item,
+// reads 0-1 / 2-3, each with its own half of the item's trace and seed regions); this kernel walks with 16 lanes per read either way
+template <int C, bool WIDE, int GL = PG_GROUP_LANES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void pg_trace_kernel(PgTraceArgs a)
 {
     // No LDS and at most 64 VGPRs: this kernel runs on the second stream UNDER the next chunk's fill, whose 16 wavefronts per CU
@@ -196,8 +198,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const PgGraphDev gdev = a.graphs[fw->graph];
     const PgNode* __restrict__ nodes = a.nodes + gdev.dir[0].node_off;
     const char* __restrict__ refc = a.seqchars + gdev.seq_off;
-    const uint8_t* __restrict__ trace = a.workspace + fw->trace_off;
-    const uint32_t* __restrict__ seed = (const uint32_t*)(a.workspace + fw->seed_off);
+    // where this read's lanes sit in the fill wavefront's records, and which half of the item's regions that wavefront owns
+    constexpr uint32_t FILL_GROUPS = 64 / GL;
+    const uint32_t half = grp / FILL_GROUPS, lane0 = (grp % FILL_GROUPS) * GL;
+    const uint8_t* __restrict__ trace = a.workspace + fw->trace_off
+        + (size_t)half * pg_fill_steps_lanes(gdev.dir[0].ncols, GL) * 64 * (2 * C);
+    const uint32_t* __restrict__ seed = (const uint32_t*)(a.workspace + fw->seed_off) + (size_t)half * gdev.dir[0].n_nodes * 64 * (WIDE ? 2 * C : C);
 
     auto qchar = [&](int j) -> uint32_t {
         return s == 0 ? upper_c((uint8_t)bases[j]) : comp_c((uint8_t)bases[L - 1 - j]);
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
         // the fill kernel stores (score + tau) of the step the cell was computed in (PG_TAU0, pg_device.h)
         const uint32_t tau = PG_TAU0 + ((col + kq) & 255u);
-        const size_t dw = ((size_t)(col + kq) * (C / 2) + r / 2) * 64 + (grp * 16 + kq);
+        const size_t dw = ((size_t)(col + kq) * (C / 2) + r / 2) * 64 + (lane0 + kq);
         return (int)(((uint32_t)trace[dw * 4 + (r & 1u) + 2u * (uint32_t)s] - tau) & 0xFFu);
     };
     // The byte is the whole score in the byte variants (reads <= 250 bases).  In the wide ones it is the score modulo 256: the
@@ -232,18 +238,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     auto seedH = [&](uint32_t node, int j) -> int {
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
         if (WIDE)
-            return (int)((seed[((size_t)node * 64 + (grp * 16 + kq)) * (2 * C) + 2 * r] >> (16 * s)) & 0x3FFu);
-        return (int)((seed[((size_t)node * 64 + (grp * 16 + kq)) * C + r] >> (8 * s)) & 0xFFu);
+            return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * (2 * C) + 2 * r] >> (16 * s)) & 0x3FFu);
+        return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * C + r] >> (8 * s)) & 0xFFu);
     };
     auto seedE = [&](uint32_t node, int j) -> int {
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
         if (WIDE)
-            return (int)((seed[((size_t)node * 64 + (grp * 16 + kq)) * (2 * C) + 2 * r + 1] >> (16 * s)) & 0x3FFu);
-        return (int)((seed[((size_t)node * 64 + (grp * 16 + kq)) * C + r] >> (16 + 8 * s)) & 0xFFu);
+            return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * (2 * C) + 2 * r + 1] >> (16 * s)) & 0x3FFu);
+        return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * C + r] >> (16 + 8 * s)) & 0xFFu);
     };
 
     Emitter em;
-    em.cap = pg_ops_cap(WIDE ? PG_VAR_WIDE + C : C);
+    em.cap = pg_ops_cap(WIDE ? PG_VAR_WIDE + C * (GL / 16) : C);
     em.slot = (uint32_t*)(a.workspace_rw + a.items[2 * pair + 1].trace_off) + grp * em.cap;  // [4 reads][pg_ops_cap]
     em.writer = writer;
     em.n = 0;
@@ -545,9 +551,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         a.results[ridx] = res;
 }
 
-template <int C, bool WIDE> static hipError_t launch_trace_c(const PgTraceArgs& args, hipStream_t stream)
+template <int C, bool WIDE, int GL = PG_GROUP_LANES> static hipError_t launch_trace_c(const PgTraceArgs& args, hipStream_t stream)
 {
-    hipLaunchKernelGGL((pg_trace_kernel<C, WIDE>), dim3(args.n_pairs), dim3(64), 0, stream, args);
+    hipLaunchKernelGGL((pg_trace_kernel<C, WIDE, GL>), dim3(args.n_pairs), dim3(64), 0, stream, args);
     return hipGetLastError();
 }
 
@@ -555,6 +561,18 @@ hipError_t pg_launch_trace(const PgTraceArgs& args, hipStream_t stream)
 {
     if (args.n_pairs == 0)
         return hipSuccess;
+    if (pg_var_wide(args.C) && args.wide32)
+    {
+        switch (pg_var_c(args.C))
+        {
+        case 16: return launch_trace_c<8, true, 32>(args, stream);
+        case 20: return launch_trace_c<10, true, 32>(args, stream);
+        case 24: return launch_trace_c<12, true, 32>(args, stream);
+        case 28: return launch_trace_c<14, true, 32>(args, stream);
+        case 32: return launch_trace_c<16, true, 32>(args, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
     switch (args.C)
     {
     case 2: return launch_trace_c<2, false>(args, stream);

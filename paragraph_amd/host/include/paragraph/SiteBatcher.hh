@@ -62,6 +62,10 @@ struct BatchParameters
     bool klib_sequence_matching = false;
     // which of SiteCounts' keyed tables to fill (the edge table always is): a caller that only genotypes needs neither
     bool node_counts = true, sequence_counts = true;
+    // grm::ValidationAligner's bookkeeping for simulated reads (lib/grm/ValidationAligner.cpp:59-125) read by read after the
+    // batch: total / MAPPED / MAPPED off the simulated path / non-unique BAD_ALIGN; object sites with paths only.  The totals
+    // are the process-wide ones grm::ValidationAligner<CompositeAligner>::total() ... report (validationLogLines()).
+    bool validate_alignments = false;
     unsigned alignment_flags = (unsigned)-1;
     int threads = 1;  // host threads for packing the reads and fanning the results back into them
     int device = 0;   // slot of the device list (setDevices / PG_DEVICES) this batch runs on
@@ -78,6 +82,8 @@ size_t pinnedStagingBytes();
 // CPUs this process may use at once (hardware threads, affinity mask, cgroup CPU bandwidth): the command lines' default for
 // their host threads (the reference defaults to std::thread::hardware_concurrency(), grmpy.cpp:66)
 int usableCpus();
+// the [VALIDATION] lines logAlignerStats writes (lib/grm/Align.cpp:42-55) from the counters accumulated so far
+std::vector<std::string> validationLogLines();
 
 class SiteBatcher
 {

@@ -61,6 +61,9 @@ struct Parameters
     // takes the edge table and the statistics from them and the description from the loaded graph (as the reference's
     // countAndGenotype does from the graph file, lib/grmpy/CountAndGenotype.cpp:46-88).
     bool description_in_document = true;
+    // `paragraph --validate-alignments`: grm::ValidationAligner's bookkeeping for simulated reads (fragment ids "<path id>_...");
+    // read objects instead of packed reads, the sites need their paths
+    bool validate_alignments = false;
     bool output_enabled(output_options o) const { return (output_options_ & o) != 0; }
 };
 

@@ -3,6 +3,7 @@
 // No alignment arithmetic happens on the host and there is no CPU fallback: without a device every call throws.
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cctype>
 #include <chrono>
 #include <cstdio>
@@ -943,6 +944,67 @@ ValidationAligner<AlignerT>::ValidationAligner(AlignerT&& aligner, const graphto
             nodes += (nodes.empty() ? "" : "->") + std::to_string(n);
     }
 }
+}  // namespace grm
+
+namespace paragraph
+{
+// the same bookkeeping for the batched workflow (SiteBatcher with BatchParameters::validate_alignments)
+void validationAccount(common::Read& read, std::unordered_map<std::string, std::string> const& path_nodes)
+{
+    ++grm::validation_total;
+    if (read.graph_mapping_status() == common::Read::MAPPED)
+    {
+        ++grm::validation_aligned;
+        std::string cigar_nodes;
+        bool in_cigar = false;
+        for (const char c : read.graph_cigar())
+        {
+            if (c == '[')
+                in_cigar = true;
+            else if (c == ']')
+                in_cigar = false;
+            else if (!in_cigar)
+            {
+                if (!cigar_nodes.empty())
+                    cigar_nodes += "->";
+                cigar_nodes += c;
+            }
+        }
+        auto it = path_nodes.find(read.fragment_id().substr(0, read.fragment_id().find('_')));
+        const std::string none;
+        const bool supports_path = std::string::npos != (it == path_nodes.end() ? none : it->second).find(cigar_nodes);
+        grm::validation_mismapped += !supports_path;
+        // the reference logs every misplaced read at debug level (ValidationAligner.cpp:84-90); PG_VALIDATE_DEBUG shows the first few
+        static const bool debug = std::getenv("PG_VALIDATE_DEBUG") != nullptr;
+        static std::atomic<int> shown(0);
+        if (debug && !supports_path && shown.fetch_add(1) < 8)
+            fprintf(stderr, "misplaced:%s:pn'%s' cn'%s' cigar %s (%zu paths)\n", read.fragment_id().c_str(),
+                    it == path_nodes.end() ? "<unknown path>" : it->second.c_str(), cigar_nodes.c_str(), read.graph_cigar().c_str(), path_nodes.size());
+    }
+    else if (read.graph_mapping_status() == common::Read::BAD_ALIGN && !read.is_graph_alignment_unique())
+        ++grm::validation_repeats;
+}
+
+std::vector<std::string> validationLogLines()
+{
+    const unsigned total = grm::validation_total, aligned = grm::validation_aligned, repeats = grm::validation_repeats,
+                   mismapped = grm::validation_mismapped;
+    char line[160];
+    std::vector<std::string> out;
+    out.push_back("[VALIDATION]\tMAPQ\tEmpMAPQ\tWrong\tTotal");
+    snprintf(line, sizeof line, "[VALIDATION]\tunalgnd\t0\t0\t%u", total - aligned - repeats);
+    out.push_back(line);
+    snprintf(line, sizeof line, "[VALIDATION]\trepeat\t0\t0\t%u", repeats);
+    out.push_back(line);
+    const double emp = !mismapped ? 60.0 : aligned ? -10.0 * std::log10((double)mismapped / (double)aligned) : 0.0;
+    snprintf(line, sizeof line, "[VALIDATION]\t60\t%g\t%u\t%u", emp, mismapped, aligned);
+    out.push_back(line);
+    return out;
+}
+}  // namespace paragraph
+
+namespace grm
+{
 template <typename AlignerT> void ValidationAligner<AlignerT>::account(Read& read)
 {
     ++validation_total;
@@ -999,6 +1061,8 @@ template class ValidationAligner<CompositeAligner>;
 
 namespace paragraph
 {
+void validationAccount(common::Read& read, std::unordered_map<std::string, std::string> const& path_nodes);
+
 struct SiteBatcher::Impl
 {
     std::vector<const Graph*> graphs;
@@ -1367,12 +1431,32 @@ void SiteBatcher::Impl::Run::deviceSection()
 
 void SiteBatcher::Impl::Run::resultsToReads()
 {
+    // --validate-alignments: per site the node lists of its paths, keyed by path id, as ValidationAligner's constructor builds them
+    std::vector<std::unordered_map<std::string, std::string>> validation_paths;
+    if (prm.validate_alignments)
+    {
+        validation_paths.resize(n_sites);
+        for (size_t s = 0; s < n_sites; ++s)
+        {
+            if (!impl.paths[s])
+                throw std::logic_error("SiteBatcher: validate_alignments needs the paths of every site");
+            for (auto const& p : *impl.paths[s])
+            {
+                std::string& nodes = validation_paths[s][p.encode()];
+                nodes.clear();
+                for (auto nd : p.nodeIds())
+                    nodes += (nodes.empty() ? "" : "->") + std::to_string(nd);
+            }
+        }
+    }
     // ---- fan results back into the reads ---------------------------------------------------------------
     const uint32_t n = (uint32_t)gor.size();
     pghost::parallelFor(
         n, prm.threads,
         [&](size_t i) {
             Read& read = *flat[i];
+            if (prm.validate_alignments && !read.bases().empty() && sup[i].status == 0)
+                validationAccount(read, validation_paths[gor[i]]);  // went through the aligner and stayed unmapped: counts in the total
             if (read.bases().empty() || sup[i].status == 0)
                 return;
             if (sup[i].status == 3)
@@ -1394,6 +1478,8 @@ void SiteBatcher::Impl::Run::resultsToReads()
             else  // the k-mer and klib stages replace the bases of a reverse hit but leave the qualities as they are
                 applyResult(read, res[i], ops.data(), true, !(res[i].status & (PG_STATUS_KMER_ALIGNER | PG_STATUS_KLIB_ALIGNER)));
             read.set_graph_mapping_status(sup[i].status == 1 ? Read::MAPPED : Read::BAD_ALIGN);
+            if (prm.validate_alignments)
+                validationAccount(read, validation_paths[gor[i]]);
             read.clear_graph_nodes_supported();
             read.clear_graph_edges_supported();
             read.clear_graph_sequences_supported();

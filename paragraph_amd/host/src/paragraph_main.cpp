@@ -99,10 +99,9 @@ int main(int argc, char** argv)
                 paragraph::setDevices(cli::deviceList(args.value()));
             else if (args.is(nullptr, "--validate-alignments"))
             {
-                // simulated-read bookkeeping (grm::ValidationAligner): available through grm::alignReads(validate_alignments =
-                // true), not in the batched count workflow of this front end -- say so rather than ignore the request
-                if (args.optionalBool())
-                    throw std::runtime_error("option '--validate-alignments' is not available in this front end (use grm::alignReads)");
+                // simulated-read bookkeeping (grm::ValidationAligner, lib/grm/ValidationAligner.cpp:59-125): read objects instead
+                // of packed reads, the [VALIDATION] lines of logAlignerStats (lib/grm/Align.cpp:42-55) on stderr at the end
+                parameters.validate_alignments = args.optionalBool();
             }
             else if (args.is(nullptr, "--progress"))
                 (void)args.optionalBool();
@@ -126,6 +125,9 @@ int main(int argc, char** argv)
             throw std::runtime_error("ERROR: Reference genome is missing.");
 
         const std::vector<common::Json> documents = paragraph::countGraphs(parameters, graphs, reference, bams, bam_indexes, target_regions);
+        if (parameters.validate_alignments)
+            for (std::string const& line : paragraph::validationLogLines())
+                std::cerr << line << "\n";
 
         if (!output_folder.empty())
             for (size_t g = 0; g < graphs.size(); ++g)

@@ -349,6 +349,7 @@ BatchParameters batchParameters(Parameters const& parameters)
     bp.klib_sequence_matching = parameters.klib_sequence_matching;
     bp.threads = parameters.threads;
     bp.device = parameters.device;
+    bp.validate_alignments = parameters.validate_alignments;
     bp.node_counts = parameters.output_enabled(Parameters::NODE_READ_COUNTS);
     bp.sequence_counts = parameters.output_enabled(Parameters::PATH_READ_COUNTS);
     return bp;
@@ -434,7 +435,7 @@ std::vector<Json> countGraphs(
     if (!bam_index_paths.empty() && bam_index_paths.size() != bam_paths.size())
         throw std::runtime_error("ERROR: the number of BAM index files differs from the number of BAM files");
     auto index_of = [&](size_t b) { return bam_index_paths.empty() ? std::string() : bam_index_paths[b]; };
-    const bool packed = bam_paths.size() == 1 && !parameters.output_enabled(Parameters::ALIGNMENTS);
+    const bool packed = bam_paths.size() == 1 && !parameters.output_enabled(Parameters::ALIGNMENTS) && !parameters.validate_alignments;
     const common::FastaFile fasta(reference_path);
     std::vector<std::unique_ptr<common::BamReader>> keep_alive;  // also shares the parsed header / index with the workers
     for (size_t b = 0; b < bam_paths.size(); ++b)

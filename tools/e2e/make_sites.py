@@ -26,6 +26,9 @@ def main():
     depth = float(sys.argv[3]) if len(sys.argv) > 3 else 30.0
     rng = random.Random(int(sys.argv[4]) if len(sys.argv) > 4 else 1)
     extras = len(sys.argv) > 5 and sys.argv[5] == "1"
+    # "paths": fragment names start with the encoded path of the haplotype a fragment was drawn from, "(0@0)-(1)-...-(k@0)_..." (source and sink are one-base nodes "X" once loaded, GraphInput.cpp:86-89)
+    # -- what grm::ValidationAligner reads the simulated path from (lib/grm/ValidationAligner.cpp:122-125)
+    path_names = len(sys.argv) > 6 and sys.argv[6] == "paths"
     os.makedirs(os.path.join(out, "graphs"), exist_ok=True)
     spacing, flank, read_len, frag_mean = 3000, 150, 150, 400
     glen = spacing * (n_sites + 1)
@@ -98,6 +101,10 @@ def main():
                     s = s[:k] + rng.choice("ACGT") + s[k + 1:]
                 return s
             name = "s%d_f%d" % (i, k)
+            if path_names:
+                ids = [order[x] for x in (["source", "LF"] + (mid_alt if gt[h] else mid_ref) + ["RF", "sink"])]
+                enc = "".join(("(%d@0)" % n) if j == 0 else ("-(%d@0)" % n) if j == len(ids) - 1 else ("-(%d)" % n) for j, n in enumerate(ids))
+                name = enc + "_" + name
             records.append(dict(name=name, tid=0, pos=p1, seq=err(r1), flag=0x63, mtid=0, mpos=p2, mapq=60))
             records.append(dict(name=name, tid=0, pos=p2, seq=err(r2.translate(COMP)[::-1]).translate(COMP)[::-1], flag=0x93, mtid=0, mpos=p1, mapq=60))
     if extras:

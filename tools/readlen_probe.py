@@ -1,18 +1,21 @@
 """gssw stage throughput by read length on the config-2 graph (byte variants up to 250 bp, the 16-bit "wide" variants
-251-512 bp): reads/s and DP cell updates/s.  Usage: python tools/readlen_probe.py [n_reads]  (prints one JSON object)"""
+251-512 bp): reads/s and DP cell updates/s.  Usage: python tools/readlen_probe.py [n_reads] [len,len,...]  (prints one JSON object; PG_WIDE16=1 = the 16-lane wide kernels)"""
 import json
 import sys
 import time
 
-sys.path.insert(0, ".")
+import os  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from paragraph_amd import capi, synth  # noqa: E402
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+    lens = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [100, 150, 250, 251, 300, 400, 512]
     ctx = capi.Context(0, workspace_bytes=64 << 30)
     out = {"reads": n, "rows": []}
-    for read_len in (100, 150, 250, 251, 300, 400):
+    for read_len in lens:
         site, arr = synth.config2_reads_packed(n, read_len=read_len, seed=2)
         graphs = ctx.upload_graphs([(site.seqs, site.edges)])
         b = ctx.new_batch()

@@ -46,4 +46,4 @@ def main(src, dst, n_reads, kernel, steps):
 
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 200000,
-         sys.argv[4] if len(sys.argv) > 4 else "pg_fill_kernel<10, false>", int(sys.argv[5]) if len(sys.argv) > 5 else 518)
+         sys.argv[4] if len(sys.argv) > 4 else "pg_fill_kernel<10, false", int(sys.argv[5]) if len(sys.argv) > 5 else 518)

@@ -68,7 +68,7 @@ enum
     PG_ERR_INVALID = 1,     /* bad argument (NULL, non-topological edge, empty node, ...) */
     PG_ERR_NO_DEVICE = 2,   /* no usable HIP device */
     PG_ERR_HIP = 3,         /* a HIP runtime call failed (see pg_last_error) */
-    PG_ERR_UNSUPPORTED = 4, /* outside the supported envelope (read > 512 bp, > 4095 nodes, ...) */
+    PG_ERR_UNSUPPORTED = 4, /* outside the supported envelope (read > 16 000 bp, > 65 535 nodes, > 64 labels, ...) */
     PG_ERR_NOMEM = 5,
     PG_ERR_OVERFLOW = 6     /* an output buffer supplied by the caller is too small */
 };
@@ -87,8 +87,11 @@ enum
 
 enum
 {
-    PG_MAX_READ_LEN = 512, /* <= 250: gssw's byte mode (never overflows, gssw.c:380); 251..512: its 16-bit word mode */
-    PG_MAX_NODES = 4095
+    PG_MAX_READ_LEN = 512, /* the packed kernels: <= 250 gssw's byte mode (never overflows, gssw.c:380); 251..512 its 16-bit
+                              word mode.  Longer reads (up to 16 000 bases) take the general device path, as do graphs of more
+                              than PG_MAX_PACKED_NODES nodes or 65 519 columns: same results, far slower */
+    PG_MAX_PACKED_NODES = 4095,
+    PG_MAX_NODES = 65535   /* node ids are 16-bit fields of pg_op and of the count path's entries */
 };
 
 typedef struct pg_ctx pg_ctx;
@@ -118,11 +121,15 @@ typedef struct pg_result
 #define PG_STATUS_KMER_ALIGNER 0x200u
 #define PG_STATUS_KLIB_ALIGNER 0x400u
 
-/* One run-length CIGAR element inside a node: node id (12 bits) | op (4 bits) | length (16 bits). */
+/* One run-length CIGAR element inside a node: node id (16 bits) | op (4 bits) | length (12 bits).  A run longer than
+ * PG_OP_MAX_LEN (only reads beyond 4 095 bases can have one) comes as several consecutive elements of the same node and op:
+ * add their lengths (pg_render_cigar does). */
 typedef uint32_t pg_op;
-#define PG_OP_NODE(x) ((uint32_t)(x) >> 20)
-#define PG_OP_CODE(x) (((uint32_t)(x) >> 16) & 0xFu)
-#define PG_OP_LEN(x) ((uint32_t)(x) & 0xFFFFu)
+#define PG_OP_MAX_LEN 0xFFFu
+#define PG_OP_MAKE(node, code, len) (((uint32_t)(node) << 16) | ((uint32_t)(code) << 12) | ((uint32_t)(len) & PG_OP_MAX_LEN))
+#define PG_OP_NODE(x) ((uint32_t)(x) >> 16)
+#define PG_OP_CODE(x) (((uint32_t)(x) >> 12) & 0xFu)
+#define PG_OP_LEN(x) ((uint32_t)(x) & PG_OP_MAX_LEN)
 /* op codes -> characters "MXNIDS"; code 6 = "node visited with an empty CIGAR" marker (length 0) */
 enum
 {
@@ -237,7 +244,7 @@ typedef struct pg_read_support
     uint8_t filter;      /* 0 none, 1 nonuniq, 2 bad_align, 3 kmer_tooshort, 4 kmer_uncov (KmerFilter.cpp:88-139) */
 } pg_read_support;
 /* path entry: node id | (node supported) << 30 | (edge from the previous path node supported) << 31 */
-#define PG_PATH_NODE(x) ((uint32_t)(x) & 0xFFFu)
+#define PG_PATH_NODE(x) ((uint32_t)(x) & 0xFFFFu)
 #define PG_PATH_NODE_OK(x) (((uint32_t)(x) >> 30) & 1u)
 #define PG_PATH_EDGE_OK(x) (((uint32_t)(x) >> 31) & 1u)
 

@@ -566,17 +566,22 @@ def render_cigar(res_row, ops):
     o0 = int(res_row["ops_off"])
     for e in range(int(res_row["n_ops"])):
         o = int(ops[o0 + e])
-        node, code, ln = o >> 20, (o >> 16) & 0xF, o & 0xFFFF
+        node, code, ln = o >> 16, (o >> 12) & 0xF, o & 0xFFF
         if node != cur:
             if cur is not None:
                 out.append("]")
             out.append("%d[" % node)
             cur = node
+            last = None
         if code < 6:
-            out.append("%d%s" % (ln, OP_CHARS[code]))
+            if last is not None and last[0] == code:  # pieces of one run (beyond 4 095 bases) print as one element
+                last[1] += ln
+            else:
+                last = [code, ln]
+                out.append(last)
     if cur is not None:
         out.append("]")
-    return "".join(out)
+    return "".join(x if isinstance(x, str) else "%d%s" % (x[1], OP_CHARS[x[0]]) for x in out)
 
 
 def render_cigars(res, ops, stride=128):
@@ -642,7 +647,7 @@ def decode_supports(graphs, graph_of_read, sup, path):
         prev = None
         for k in range(int(s["n_path"])):
             en = int(path[int(s["path_off"]) + k])
-            nd = en & 0xFFF
+            nd = en & 0xFFFF
             if (en >> 30) & 1:
                 nodes.add(nd)
             if k > 0 and (en >> 31) & 1:

@@ -633,7 +633,7 @@ extern "C" pg_status pg_graphs_upload(
             return fail(ctx, PG_ERR_INVALID, "graph without nodes");
         const uint32_t n = ne - nb;
         if (n > PG_MAX_NODES)
-            return fail(ctx, PG_ERR_UNSUPPORTED, "graph with more than 4095 nodes");
+            return fail(ctx, PG_ERR_UNSUPPORTED, "graph with more than 65535 nodes");
         uint64_t total = 0;
         for (uint32_t i = 0; i < n; ++i)
         {
@@ -651,7 +651,8 @@ extern "C" pg_status pg_graphs_upload(
         }
         // beyond 65 519 columns the packed kernels' 16-bit column fields end: the graph's reads take the general path
         // (pg_general.h), which reads nodes / predecessors / characters only -- no column words are built for it
-        const bool wide = total > 65535 - PG_GROUP_LANES;
+        // ... and beyond 4 095 nodes the 12-bit node field of the column words ends
+        const bool wide = total > 65535 - PG_GROUP_LANES || n > PG_MAX_PACKED_NODES;
         if (total > 0x7FFFFFFFull)
             return fail(ctx, PG_ERR_UNSUPPORTED, "graph longer than 2^31 columns");
         host[g].n_nodes = n;
@@ -1459,7 +1460,11 @@ extern "C" size_t pg_render_cigar(const pg_result* r, const pg_op* ops, char* bu
         }
         if (code <= PG_OPC_S)
         {
-            int k = snprintf(tmp, sizeof tmp, "%u%c", PG_OP_LEN(o), OPC[code]);
+            // pieces of one run (same node, same op: a run beyond PG_OP_MAX_LEN) print as one element
+            uint32_t run = PG_OP_LEN(o);
+            while (e + 1 < r->n_ops && PG_OP_NODE(ops[r->ops_off + e + 1]) == node && PG_OP_CODE(ops[r->ops_off + e + 1]) == code)
+                run += PG_OP_LEN(ops[r->ops_off + ++e]);
+            int k = snprintf(tmp, sizeof tmp, "%u%c", run, OPC[code]);
             put(tmp, (size_t)k);
         }
     }

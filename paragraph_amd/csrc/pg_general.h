@@ -55,7 +55,7 @@ struct PgGenArgs
 };
 hipError_t pg_launch_general(const PgGenArgs& args, hipStream_t stream);
 
-static inline __host__ __device__ uint32_t pg_gen_ops_cap(uint32_t L) { return L + 32u; }
+static inline __host__ __device__ uint32_t pg_gen_ops_cap(uint32_t L) { return L + 40u; }  // + pieces of runs beyond PG_OP_MAX_LEN
 static inline __host__ __device__ uint64_t pg_gen_align8(uint64_t x) { return (x + 7u) & ~(uint64_t)7u; }
 // bytes of workspace one read needs on a graph with `ncols` columns and `n_nodes` nodes
 static inline __host__ __device__ uint64_t pg_gen_read_bytes(uint64_t L, uint64_t ncols, uint64_t n_nodes)
@@ -232,10 +232,17 @@ struct Emitter
     {
         if (last_op == 0xFFu)
             return;
-        if (n < cap)
-            slot[cap - 1 - n++] = (last_node << 20) | (last_op << 16) | (last_len & 0xFFFFu);
-        else
-            overflow = true;
+        // a run longer than an element holds goes out as several elements of the same node and op (only reads beyond 4 095 bases)
+        uint32_t left = last_len;
+        do
+        {
+            const uint32_t piece = left > PG_OP_MAX_LEN ? PG_OP_MAX_LEN : left;
+            if (n < cap)
+                slot[cap - 1 - n++] = PG_OP_MAKE(last_node, last_op, piece);
+            else
+                overflow = true;
+            left -= piece;
+        } while (left);
     }
     __host__ __device__ void emit(uint32_t node, uint32_t op, uint32_t len)
     {

@@ -717,7 +717,7 @@ __global__ __launch_bounds__(64) void pg_klib_pick_kernel(KlibArgs a)
         uint32_t nd, op, len, e = 0;
         while (gen.next(nd, op, len))
         {
-            a.ops[base + e++] = (nd << 20) | (op << 16) | (len & 0xFFFFu);
+            a.ops[base + e++] = PG_OP_MAKE(nd, op, len);
             if (op == PG_OPC_M)
                 score += len;
             if (op == PG_OPC_S)

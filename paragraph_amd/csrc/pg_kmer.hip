@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64) void pg_kmer_kernel(KmerArgs a)
                 ++run;
                 continue;
             }
-            a.ops[base + e++] = ((cur >> 4) << 20) | ((cur & 7u) << 16) | (run & 0xFFFFu);
+            a.ops[base + e++] = PG_OP_MAKE(cur >> 4, cur & 7u, run);
             cur = nxt;
             run = 1;
         }

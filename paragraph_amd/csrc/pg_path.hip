@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
             const uint32_t node = ids[i];
             const uint32_t lo = i == 0 ? sp : 0u;
             const uint32_t hi = i == n_nodes - 1 ? ep : w.nlen(node) - 1;
-            ops[i] = (node << 20) | ((uint32_t)PG_OPC_M << 16) | ((hi - lo + 1) & 0xFFFFu);
+            ops[i] = PG_OP_MAKE(node, PG_OPC_M, hi - lo + 1);
         }
     }
     pg_result res;

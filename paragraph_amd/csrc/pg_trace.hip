@@ -100,7 +100,7 @@ struct Emitter
             if (n < cap)
             {
                 if (writer)
-                    slot[cap - 1 - n] = (last_node << 20) | (last_op << 16) | (last_len & 0xFFFFu);
+                    slot[cap - 1 - n] = PG_OP_MAKE(last_node, last_op, last_len);
                 ++n;
             }
             else

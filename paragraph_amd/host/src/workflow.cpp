@@ -201,7 +201,7 @@ void addDetailedCounts(Json& by_sequence, graphtools::Graph const& graph, SiteRe
         uint32_t prev = 0;
         for (uint32_t k = 0; k < read.n_support; ++k)
         {
-            const uint32_t entry = views.support[read.support_off + k], node = entry & 0xFFFu;
+            const uint32_t entry = views.support[read.support_off + k], node = entry & 0xFFFFu;  // PG_PATH_NODE (include/paragraph_amd.h)
             if ((entry >> 30) & 1u)
                 f.nodes.push_back(node);
             if (k > 0 && (entry >> 31))

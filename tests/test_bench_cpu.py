@@ -110,7 +110,7 @@ def test_cpu_leg_and_verification(tmp_path):
         text = bytes(cig[i]).split(b"\0")[0].decode()
         for node, body in re.findall(r"(\d+)\[([^\]]*)\]", text):
             for ln, op in re.findall(r"(\d+)([MXNIDS])", body):
-                ops.append((int(node) << 20) | (codes[op] << 16) | int(ln))
+                ops.append((int(node) << 16) | (codes[op] << 12) | int(ln))
         gres[i]["n_ops"] = len(ops) - gres[i]["ops_off"]
     ops = np.array(ops, dtype=np.uint32)
     v = bench.verify_against_reference(capi, gres, ops, res[:n], cig[:n])

@@ -50,8 +50,8 @@ def test_render_cigar_helper():
     import numpy as np
     from paragraph_amd import capi
     res = np.zeros(1, dtype=capi.RESULT_DTYPE)
-    ops = np.array([(0 << 20) | (5 << 16) | 3, (0 << 20) | (0 << 16) | 8, (1 << 20) | (1 << 16) | 1,
-                    (3 << 20) | (4 << 16) | 2, (3 << 20) | (0 << 16) | 7], dtype=np.uint32)
+    ops = np.array([(0 << 16) | (5 << 12) | 3, (0 << 16) | (0 << 12) | 8, (1 << 16) | (1 << 12) | 1,
+                    (3 << 16) | (4 << 12) | 2, (3 << 16) | (0 << 12) | 7], dtype=np.uint32)
     res[0]["n_ops"] = len(ops)
     assert capi.render_cigar(res[0], ops) == "0[3S8M]1[1X]3[2D7M]"
     lib = capi.load_library()

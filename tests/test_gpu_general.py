@@ -121,3 +121,29 @@ def test_general_reads_are_counted_like_the_others(gpu_ctx, checker):
         for ei, e in enumerate(graphs[gi][1]):
             assert c["edge_counts"][tuple(e)] == [int(x) for x in w["edge_counts"][ei]], (gi, e)
         assert c["seq_counts"] == w["seq_counts"], (gi, c["seq_counts"], w["seq_counts"])
+
+
+def test_graph_beyond_4095_nodes_and_runs_beyond_4095_bases(gpu_ctx, checker):
+    """a 5 000-node chain with skip edges (node ids need more than the 12 bits the packed kernels' column words hold) and reads
+    of 4 500 .. 5 200 bases whose match runs are longer than one CIGAR element holds (PG_OP_MAX_LEN: the pieces print as one)"""
+    rng = random.Random(fuzzgen.salted(5000))
+    seqs = [fuzzgen.rand_seq(rng, rng.randint(1, 6)) for _ in range(5000)]
+    edges = [(i, i + 1) for i in range(4999)] + [(i, i + 2) for i in range(0, 4998, 37)] + [(i, i + 5) for i in range(3, 4990, 211)]
+    path = "".join(seqs)
+    reads = []
+    for k in range(28):
+        L = rng.choice([40, 150, 150, 320, 600])
+        at = rng.randrange(0, len(path) - L)
+        r = fuzzgen.mutate(rng, path[at:at + L], sub=rng.choice([0.0, 0.02]), indel=rng.choice([0.0, 0.01])) or "A"
+        reads.append(r if k % 2 else "".join({"A": "T", "C": "G", "G": "C", "T": "A"}.get(c, "N") for c in reversed(r)))
+    long_nodes = [fuzzgen.rand_seq(rng, 6000), fuzzgen.rand_seq(rng, 300), fuzzgen.rand_seq(rng, 400)]
+    long_edges = [(0, 1), (0, 2), (1, 2)]
+    long_reads = [long_nodes[0][500:5500], long_nodes[0][900:6000] + long_nodes[2][:100],
+                  fuzzgen.mutate(rng, long_nodes[0][100:4700], sub=0.0005, indel=0.0)]
+    want = checker.align_batch(seqs, edges, reads, threads=8, cigar_stride=8192) \\
+        + checker.align_batch(long_nodes, long_edges, long_reads, threads=3, cigar_stride=8192)
+    got = _align(gpu_ctx, [(seqs, edges), (long_nodes, long_edges)], reads + long_reads, [0] * len(reads) + [1] * len(long_reads))
+    bad = [i for i, (a, w) in enumerate(zip(got, want)) if not _same(a, w)]
+    assert not bad, (bad[:5], got[bad[0]], want[bad[0]])
+    assert any(int(n) > 4095 for w in want[:28] for n in __import__("re").findall(r"(\\d+)\\[", w["cigar"]))
+    assert any(int(m) > 4095 for w in want[28:] for m in __import__("re").findall(r"(\\d+)M", w["cigar"]))

@@ -213,15 +213,14 @@ def test_many_tiny_nodes(gpu_ctx, checker):
 
 def test_documented_limits_fail_loudly(gpu_ctx):
     """Every limit of the envelope (include/paragraph_amd.h) answers with PG_ERR_UNSUPPORTED -- never with a wrong result:
-    4096 nodes, 65 labels, 31 klib paths, a 16 001-base read.  (Round 3: a direction longer than 65 519 columns and reads of
-    513..16 000 bases are no longer limits -- they take the general path, tests/test_gpu_general.py.)"""
+    65 536 nodes, 65 labels, 31 klib paths, a 16 001-base read.  (Round 3: more than 4 095 nodes, a direction longer than 65 519
+    columns and reads of 513..16 000 bases are no longer limits -- they take the general path, tests/test_gpu_general.py.)"""
     from paragraph_amd import capi
-    chain = (["ACGT"] * 4096, [(i, i + 1) for i in range(4095)])
+    chain = (["A"] * 65536, [(i, i + 1) for i in range(65535)])
     with pytest.raises(capi.PgError) as e:
         gpu_ctx.upload_graphs([chain])
-    assert e.value.status == 4 and "4095" in str(e.value)
-    ok = gpu_ctx.upload_graphs([(["ACGT"] * 4095, [(i, i + 1) for i in range(4094)])])  # the largest graph that is in
-    ok.close()
+    assert e.value.status == 4 and "65535" in str(e.value)
+    gpu_ctx.upload_graphs([(["ACGT"] * 4096, [(i, i + 1) for i in range(4095)])]).close()  # general path
     gpu_ctx.upload_graphs([(["A" * 40000, "C" * 25600], [(0, 1)])]).close()  # general path
     G = gpu_ctx.upload_graphs([ALIGNS_GRAPH])
     names = ["L%02d" % i for i in range(65)]

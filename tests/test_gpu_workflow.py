@@ -414,11 +414,12 @@ def test_config1_multigrmpy_from_json_events(tmp_path):
 
 
 def test_one_oversize_site_does_not_take_the_run_down(tmp_path):
-    """200 graphs of which three are outside the packed kernels' envelope -- a 600 bp read over one site, a 5 000-node graph, a
-    70 000-column graph; the reference has no such bounds (gssw.c:527-786, GraphAligner.cpp:110-167).  The long read and the
-    long graph go through the general path (pg_general.hip; parity with the reference's gssw.c: tests/test_gpu_general.py)
-    and come out as ordinary documents; the 5 000-node graph says why it was skipped under "error"; the 197 other genotype
-    documents equal those of a run over the 197 alone."""
+    """201 graphs of which four are outside the packed kernels' envelope -- a 600 bp read over one site, a 5 000-node graph, a
+    70 000-column graph, a graph with 65 sequence labels; the reference has no such bounds (gssw.c:527-786,
+    GraphAligner.cpp:110-167, ReadCounting.cpp:96-127).  The long read, the many nodes and the many columns go through the
+    general path (pg_general.hip; parity with the reference's gssw.c: tests/test_gpu_general.py) and come out as ordinary
+    documents; the 65-label graph says why it was skipped under "error"; the 197 other genotype documents equal those of a
+    run over the 197 alone."""
     import sys
     from paragraph_amd import workflow
     data = tmp_path / "sites"
@@ -427,16 +428,16 @@ def test_one_oversize_site_does_not_take_the_run_down(tmp_path):
     assert r.returncode == 0, r.stderr
     graphs = [l.strip() for l in open(data / "graphs.txt") if l.strip()]
     extra = [l.strip() for l in open(data / "extra_graphs.txt") if l.strip()]
-    assert len(graphs) == 198 and len(extra) == 2
+    assert len(graphs) == 198 and len(extra) == 3
     ref, manifest = str(data / "ref.fa"), str(data / "manifest.txt")
-    everything = graphs[:50] + [extra[0]] + graphs[50:120] + [extra[1]] + graphs[120:]  # the odd ones in the middle of batches
+    everything = graphs[:50] + [extra[0]] + graphs[50:120] + [extra[1]] + graphs[120:160] + [extra[2]] + graphs[160:]  # the odd ones in the middle of batches
     docs = workflow.genotype_graphs(ref, manifest, everything, threads=4, lanes=2, sites_per_batch=32)
-    assert len(docs) == 200
+    assert len(docs) == 201
     by_id = {d["graphinfo"]["ID"]: d for d in docs}
-    bad = {"many_nodes": "4095 nodes"}
+    bad = {"many_labels": "64"}
     for gid, why in bad.items():
         assert "error" in by_id[gid] and why in by_id[gid]["error"], (gid, by_id[gid].get("error"))
-    for gid in ("site_197", "many_columns"):  # the general path: ordinary documents with reads counted
+    for gid in ("site_197", "many_columns", "many_nodes"):  # the general path: ordinary documents with reads counted
         assert "error" not in by_id[gid], by_id[gid].get("error")
         assert by_id[gid]["samples"]["SYN"]["gt"]["num_reads"] > 0, by_id[gid]["samples"]["SYN"]["gt"]
     good = workflow.genotype_graphs(ref, manifest, graphs[:197], threads=4, lanes=2, sites_per_batch=32)
@@ -444,7 +445,7 @@ def test_one_oversize_site_does_not_take_the_run_down(tmp_path):
     for d in good:
         assert by_id[d["graphinfo"]["ID"]] == d, d["graphinfo"]["ID"]
     # the object form isolates the same way
-    objects = workflow.genotype_graphs(ref, manifest, everything[45:60], threads=2, lanes=1, sites_per_batch=15, packed_reads=False)
+    objects = workflow.genotype_graphs(ref, manifest, everything[155:170], threads=2, lanes=1, sites_per_batch=15, packed_reads=False)
     assert [("error" in d) for d in objects] == [d["graphinfo"]["ID"] in bad for d in objects] and sum("error" in d for d in objects) == 1
     for d in objects:
         if "error" not in d:

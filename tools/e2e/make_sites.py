@@ -5,7 +5,7 @@ sampled around every site from a diploid genome that carries each alternate alle
     python tools/e2e/make_sites.py <outdir> [n_sites] [depth] [seed] [extras]
 
 extras = 1 adds what the device kernels' envelope does not hold (the reference has no such bounds): one 600 bp read over
-the last site, and two more graphs -- 5 000 nodes, 70 000 columns -- listed in extra_graphs.txt.
+the last site, and three more graphs -- 5 000 nodes, 70 000 columns, 65 sequence labels -- listed in extra_graphs.txt.
 
 Writes ref.fa(.fai), reads.bam(.bai), graphs/site_<i>.json, graphs.txt, manifest.txt, truth.json.
 """
@@ -119,11 +119,18 @@ def main():
                 {"name": "MID", "sequence": "".join(erng.choice("ACGT") for _ in range(70000))},
                 {"name": "RF", "reference": "chr1:%d-%d" % (spacing * 2 + 1, spacing * 2 + flank)}]
         wedges = [{"from": "LF", "to": "MID", "sequences": ["ALT"]}, {"from": "LF", "to": "RF", "sequences": ["REF"]}, {"from": "MID", "to": "RF", "sequences": ["ALT"]}]
+        labels65 = ["L%02d" % k for k in range(65)]
+        lnodes = [{"name": "LF", "reference": "chr1:%d-%d" % (spacing * 3 - flank + 1, spacing * 3)},
+                  {"name": "MID", "sequence": "ACGTTGCAACGTACGT"},
+                  {"name": "RF", "reference": "chr1:%d-%d" % (spacing * 3 + 1, spacing * 3 + flank)}]
+        ledges = [{"from": "LF", "to": "MID", "sequences": labels65[:33]}, {"from": "LF", "to": "RF", "sequences": labels65[33:]},
+                  {"from": "MID", "to": "RF", "sequences": labels65[:33]}]
         with open(os.path.join(out, "extra_graphs.txt"), "w") as xf:
-            for name, nodes_x, edges_x, site in (("many_nodes", chain, cedges, 1), ("many_columns", wide, wedges, 2)):
+            for name, nodes_x, edges_x, site, seqnames in (("many_nodes", chain, cedges, 1, ["ALT", "REF"]), ("many_columns", wide, wedges, 2, ["ALT", "REF"]),
+                                                           ("many_labels", lnodes, ledges, 3, labels65)):
                 gp = os.path.join(out, "graphs", name + ".json")
                 with open(gp, "w") as f:
-                    json.dump({"ID": name, "nodes": nodes_x, "edges": edges_x, "sequencenames": ["ALT", "REF"],
+                    json.dump({"ID": name, "nodes": nodes_x, "edges": edges_x, "sequencenames": seqnames,
                                "target_regions": ["chr1:%d-%d" % (spacing * site - flank + 1, spacing * site + flank)]}, f)
                 xf.write(gp + "\n")
     records.sort(key=lambda r: r["pos"])

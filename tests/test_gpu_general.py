@@ -140,10 +140,11 @@ def test_graph_beyond_4095_nodes_and_runs_beyond_4095_bases(gpu_ctx, checker):
     long_edges = [(0, 1), (0, 2), (1, 2)]
     long_reads = [long_nodes[0][500:5500], long_nodes[0][900:6000] + long_nodes[2][:100],
                   fuzzgen.mutate(rng, long_nodes[0][100:4700], sub=0.0005, indel=0.0)]
-    want = checker.align_batch(seqs, edges, reads, threads=8, cigar_stride=8192) \\
-        + checker.align_batch(long_nodes, long_edges, long_reads, threads=3, cigar_stride=8192)
+    want = (checker.align_batch(seqs, edges, reads, threads=8, cigar_stride=8192)
+            + checker.align_batch(long_nodes, long_edges, long_reads, threads=3, cigar_stride=8192))
     got = _align(gpu_ctx, [(seqs, edges), (long_nodes, long_edges)], reads + long_reads, [0] * len(reads) + [1] * len(long_reads))
     bad = [i for i, (a, w) in enumerate(zip(got, want)) if not _same(a, w)]
     assert not bad, (bad[:5], got[bad[0]], want[bad[0]])
-    assert any(int(n) > 4095 for w in want[:28] for n in __import__("re").findall(r"(\\d+)\\[", w["cigar"]))
-    assert any(int(m) > 4095 for w in want[28:] for m in __import__("re").findall(r"(\\d+)M", w["cigar"]))
+    import re
+    assert any(int(n) > 4095 for w in want[:28] for n in re.findall(r"(\d+)\[", w["cigar"]))
+    assert any(int(m) > 4095 for w in want[28:] for m in re.findall(r"(\d+)M", w["cigar"]))

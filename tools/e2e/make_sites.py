@@ -111,7 +111,8 @@ def main():
         start = spacing * n_sites  # the last site
         records.append(dict(name="long_read", tid=0, pos=start - 300, seq=ref[start - 300:start + 300], flag=0, mtid=-1, mpos=-1, mapq=60))
         erng = random.Random(12345)
-        chain = [{"name": "source", "sequence": "NNNNNNNNNN"}] + [{"name": "n%d" % k, "sequence": "".join(erng.choice("ACGT") for _ in range(4))} for k in range(5000)]
+        c0 = spacing - flank  # 5 000 four-base pieces of the reference from the first site's left flank on
+        chain = [{"name": "source", "sequence": "NNNNNNNNNN"}] + [{"name": "n%d" % k, "reference": "chr1:%d-%d" % (c0 + 4 * k + 1, c0 + 4 * k + 4)} for k in range(5000)]
         cedges = [{"from": chain[k]["name"], "to": chain[k + 1]["name"]} for k in range(len(chain) - 1)]
         cedges[10]["sequences"] = ["REF"]
         cedges.append({"from": "n9", "to": "n11", "sequences": ["ALT"]})

@@ -234,7 +234,42 @@ class RefCounts:
         L.pgrefc_count_site.argtypes = [C.c_void_p, C.c_uint32, i32p, u32p, C.c_char_p, u8p, u8p, u8p, u32p, u32p,
                                         C.POINTER(Params), u8p, u64p, u64p, u64p, u64p, u64p, u32p, u64p, u64p,
                                         C.c_uint32]
+        L.pgrefc_pair_length.restype = C.c_int
+        L.pgrefc_pair_length.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, u64p, u64p]
         self.L = L
+
+    def _graph(self, graph):
+        def P(a, t):
+            return a.ctypes.data_as(C.POINTER(t))
+        n_nodes = len(graph.nodes)
+        seq_off = np.zeros(n_nodes + 1, dtype=np.uint32)
+        seq_off[1:] = np.cumsum([len(s) for s in graph.nodes])
+        frm = np.array([e[0] for e in graph.edges] or [0], dtype=np.uint32)
+        to = np.array([e[1] for e in graph.edges] or [0], dtype=np.uint32)
+        loff = np.zeros(len(graph.edges) + 1, dtype=np.uint32)
+        lids = np.array([0], dtype=np.uint32)
+        names = (C.c_char_p * 1)(b"")
+        g = self.L.pgrefc_graph_create(n_nodes, P(seq_off, C.c_uint32), "".join(graph.nodes).encode(), len(graph.edges),
+                                       P(frm, C.c_uint32), P(to, C.c_uint32), P(loff, C.c_uint32), P(lids, C.c_uint32), 0, names)
+        if not g:
+            raise RuntimeError("pgrefc_graph_create failed")
+        return g
+
+    def pair_lengths(self, graph, pairs):
+        """Graph length of two-read fragments as common::Fragment::addRead computes it on the reference's own
+        graphtools::GraphCoordinates (Fragment.cpp:70-95): pairs = [(pos1, cigar1, pos2, cigar2)] -> [length | None]."""
+        g = self._graph(graph)
+        out = []
+        try:
+            span = (C.c_uint64 * 4)()
+            length = C.c_uint64(0)
+            for pos1, cigar1, pos2, cigar2 in pairs:
+                if self.L.pgrefc_pair_length(g, pos1, cigar1.encode(), pos2, cigar2.encode(), span, C.byref(length)) != 0:
+                    raise RuntimeError("pgrefc_pair_length failed on %r" % ((pos1, cigar1, pos2, cigar2),))
+                out.append(None if length.value == 0xFFFFFFFFFFFFFFFF else int(length.value))
+        finally:
+            self.L.pgrefc_graph_destroy(g)
+        return out
 
     def count_site(self, graph, reads, remove_nonuniq=True, bad_align_frac=0.8, use_support_filters=True):
         def P(a, t):

@@ -18,6 +18,7 @@
  *
  * Interface limits (checker only): <= 64 nodes, <= 64 edges, <= 64 labels per graph.
  */
+#include <limits>
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -31,6 +32,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "graphcore/GraphCoordinates.hh"
 #include "graphalign/GraphAlignment.hh"
 #include "graphalign/GraphAlignmentOperations.hh"
 #include "graphcore/Graph.hh"
@@ -96,6 +98,29 @@ extern "C" pgrefc_graph* pgrefc_graph_create(
 }
 
 extern "C" void pgrefc_graph_destroy(pgrefc_graph* g) { delete g; }
+
+// Graph length of a fragment of two graph-mapped reads exactly as common::Fragment::addRead computes it
+// (src/c++/lib/common/Fragment.cpp:70-95) on the reference's own graphtools::GraphCoordinates (compiled from the tarball):
+// canonical (start, end) of both mappings into span[0..3], the fragment length (all ones = no path) into *length.
+extern "C" int pgrefc_pair_length(
+    pgrefc_graph* g, int32_t pos1, const char* cigar1, int32_t pos2, const char* cigar2, uint64_t* span, uint64_t* length)
+{
+    try
+    {
+        graphtools::GraphCoordinates coordinates(&g->graph);
+        const GraphAlignment m1 = decodeGraphAlignment(pos1, cigar1, &g->graph), m2 = decodeGraphAlignment(pos2, cigar2, &g->graph);
+        const std::pair<uint64_t, uint64_t> p1 = coordinates.canonicalStartAndEnd(m1.path()), p2 = coordinates.canonicalStartAndEnd(m2.path());
+        span[0] = p1.first, span[1] = p1.second, span[2] = p2.first, span[3] = p2.second;
+        const uint64_t d1 = coordinates.distance(p1.second, p2.first), d2 = coordinates.distance(p2.second, p1.first);
+        const uint64_t distance = std::min(d1, d2);
+        *length = distance == std::numeric_limits<uint64_t>::max() ? (uint64_t)-1 : m1.queryLength() + m2.queryLength() + distance;
+        return 0;
+    }
+    catch (std::exception const&)
+    {
+        return 1;
+    }
+}
 
 namespace
 {

@@ -612,7 +612,9 @@ void addToFragment(FragmentShape& f, graphtools::GraphCoordinates const& coords,
         walk.nodes.push_back(nodes[k].node);
         query_length += nodes[k].queryLength();
     }
-    walk.end_position = (int32_t)nodes[read.n_pieces - 1].referenceLength() + (read.n_pieces == 1 ? read.graph_pos : 0);
+    // the LAST aligned base of the last node (inclusive), as decodeGraphAlignment builds the alignment's path
+    // (GT!/src/graphalign/GraphAlignmentOperations.cpp:103-104); canonicalStartAndEnd then treats an end of 0 as "unknown"
+    walk.end_position = (int32_t)nodes[read.n_pieces - 1].referenceLength() + (read.n_pieces == 1 ? read.graph_pos : 0) - 1;
     f.spans.push_back(coords.canonicalStartAndEnd(walk));
     f.lengths.push_back(query_length);
     if (f.spans.size() == 1)

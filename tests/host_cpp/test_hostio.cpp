@@ -565,8 +565,10 @@ static void testStatistics()
     CHECK(fs["paired_read"].asUInt64() == 1 && fs["single_read"].asUInt64() == 1 && fs["multi_read"].asUInt64() == 0);
     CHECK(fs["problematic_linear"].asUInt64() == 1 && fs["problematic_graph"].asUInt64() == 0);
     CHECK(fs["mean_linear"].asDouble() == 210.0);  // |300 - 100| + 10 bases of the read added last
-    // r1 spans canonical [1+0, 11+11), r2 [11+12, 11+20): gap from 22 to 23 is 1 -> 25 + 8 + 1
-    CHECK(fs["mean_graph"].asDouble() == 34.0);
+    // r1 spans canonical 1+0 .. 11+10 (its LAST aligned base: decodeGraphAlignment's path end is inclusive,
+    // GT!/src/graphalign/GraphAlignmentOperations.cpp:103), r2 starts at 11+12: distance 21 -> 23 is 2 -> 25 + 8 + 2
+    // (the arithmetic itself is compared with the reference's compiled GraphCoordinates in tests/test_counts_oracle.py)
+    CHECK(fs["mean_graph"].asDouble() == 35.0);
     CHECK(fs["median_graph"].asDouble() == 0.0 && fs["variance_graph"].asDouble() == 0.0);
     const Json as = paragraph::alignmentStatistics(g, reads);
     CHECK(as["nodes"]["A"]["num_fwd_reads"].asInt64() == 2 && as["nodes"]["B"]["num_rev_reads"].asInt64() == 1);
@@ -878,6 +880,49 @@ int main(int argc, char** argv)
             const auto g = grm::graphFromJson(doc, argv[3]);
             const auto paths = grm::pathsFromJson(&g, (doc.isMember("graph") ? doc["graph"] : doc)["paths"]);
             std::cout << g.numNodes() << " nodes, " << g.numEdges() << " edges, " << paths.size() << " paths\n";
+        }
+        catch (std::exception const& e)
+        {
+            std::cerr << "error: " << e.what() << "\n";
+            return 1;
+        }
+        return 0;
+    }
+    if (argc == 4 && std::string(argv[1]) == "--pair-lengths")
+    {
+        // <graph.json> <reference.fa>; stdin: "pos1 cigar1 pos2 cigar2" per line -> graph length of the two-read fragment as
+        // paragraph::fragmentStatistics sees it ("-" = no path), for the comparison with the reference's Fragment /
+        // GraphCoordinates in tests/test_counts_oracle.py
+        try
+        {
+            const Json doc = Json::parseFile(argv[2]);
+            const auto g = grm::graphFromJson(doc, argv[3]);
+            std::string line;
+            while (std::getline(std::cin, line))
+            {
+                std::istringstream in(line);
+                int pos1 = 0, pos2 = 0;
+                std::string c1, c2;
+                if (!(in >> pos1 >> c1 >> pos2 >> c2))
+                    continue;
+                Read r1("f", "A", "#"), r2("f", "A", "#");
+                r1.set_graph_mapping_status(Read::MAPPED);
+                r2.set_graph_mapping_status(Read::MAPPED);
+                r1.set_graph_pos(pos1);
+                r1.set_graph_cigar(c1);
+                r2.set_graph_pos(pos2);
+                r2.set_graph_cigar(c2);
+                const std::vector<Read const*> reads = { &r1, &r2 };
+                const Json fs = paragraph::fragmentStatistics(g, reads);
+                if (fs["problematic_graph"].asUInt64())
+                    std::cout << "-\n";
+                else
+                {
+                    char text[64];
+                    snprintf(text, sizeof text, "%.17g", fs["mean_graph"].asDouble());
+                    std::cout << text << "\n";
+                }
+            }
         }
         catch (std::exception const& e)
         {

@@ -1,6 +1,7 @@
 """CPU tests of the count-path checkers: the pure-Python restatement (oracle/counts.py) against the
 reference's unit-test expectations and -- where oracle/_ref exists -- against the reference's own
 graph-tools code (oracle/_ref/libpg_refcounts.so) on randomized alignments."""
+import os
 import random
 
 import pytest
@@ -147,3 +148,52 @@ def test_kmer_checker_unit_vectors():
     for g, (st, pos, cigar, score, rev, mapq) in zip(got, want):
         assert (g["status"], g["graph_pos"], g["cigar"], g["score"], g["is_graph_reverse"], g["mapq"]) == \
             (st, pos, cigar, score, rev, mapq)
+
+
+def test_fragment_graph_length_equals_the_references(tmp_path):
+    """The graph length of a read pair -- what `fragment_statistics` is made of -- as the host library computes it
+    (paragraph::fragmentStatistics over the restated graphtools::GraphCoordinates) against common::Fragment::addRead's
+    arithmetic on the reference's OWN GraphCoordinates.cpp (compiled from the graph-tools tarball): random graphs, the
+    alignments the reference's gssw.c gives two reads on them."""
+    import json
+    import random
+    import subprocess
+    from oracle import counts as oc
+    from oracle import oracle as orc
+    from paragraph_amd import build
+    from tests import fuzzgen
+    if not (oc.have_ref() and orc.have_ref()):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    exe = build.build_genotyping_test()
+    exe = os.path.join(os.path.dirname(exe), "test_hostio")
+    ref, gssw = oc.RefCounts(), orc.RefOracle()
+    rng = random.Random(20260927)
+    fasta = tmp_path / "none.fa"
+    fasta.write_text(">x\nACGT\n")
+    (tmp_path / "none.fa.fai").write_text("x\t4\t3\t4\t5\n")
+    checked = with_gap = no_path = 0
+    for it in range(60):
+        seqs, edges = fuzzgen.rand_graph(rng, max_len=rng.choice([8, 40, 90]), max_nodes=8)
+        seqs = [s.replace("X", "A") for s in seqs]
+        reads = [fuzzgen.rand_read(rng, seqs, edges, min_len=6, max_len=60) for _ in range(12)]
+        al = [a for a in gssw.align_batch(seqs, edges, reads) if a["score"] > 0 and a["cigar"]]
+        pairs = [(a["graph_pos"], a["cigar"], b["graph_pos"], b["cigar"]) for a, b in zip(al[0::2], al[1::2])]
+        if not pairs:
+            continue
+        want = ref.pair_lengths(oc.CountGraph(seqs, edges), pairs)
+        graph_json = tmp_path / ("g%d.json" % it)
+        graph_json.write_text(json.dumps({"nodes": [{"name": "n%d" % i, "sequence": s} for i, s in enumerate(seqs)],
+                                          "edges": [{"from": "n%d" % a, "to": "n%d" % b} for a, b in edges],
+                                          "target_regions": ["x:1-2"]}))
+        p = subprocess.run([exe, "--pair-lengths", str(graph_json), str(fasta)], input="".join("%d %s %d %s\n" % q for q in pairs),
+                           capture_output=True, text=True, timeout=60)
+        assert p.returncode == 0, p.stderr
+        # (lengths go through the statistics' doubles; an alignment that ends on the first base of its last node has an
+        # "unknown" end in the reference -- all ones -- and the fragment length it then computes wraps around: kept as it is)
+        got = [None if l == "-" else float(l) for l in p.stdout.split()]
+        want_f = [None if w is None else float(w) for w in want]
+        assert got == want_f, (seqs, edges, [(q, g, w) for q, g, w in zip(pairs, got, want) if g != (None if w is None else float(w))][:3])
+        checked += len(pairs)
+        no_path += sum(w is None for w in want)
+        with_gap += sum(1 for q, w in zip(pairs, want) if w is not None and q[1].split("[")[0] != q[3].split("[")[0])
+    assert checked > 150 and with_gap > 40, (checked, with_gap, no_path)

@@ -888,6 +888,51 @@ int main(int argc, char** argv)
         }
         return 0;
     }
+    if (argc == 4 && std::string(argv[1]) == "--alignment-statistics")
+    {
+        // <graph.json> <reference.fa>; stdin: "pos cigar reverse(0|1) score seq1,seq2|-" per MAPPED read -> the
+        // "alignment_statistics" object as paragraph::alignmentStatistics builds it, for the comparison with the reference's
+        // own summarizeAlignments in tests/test_counts_oracle.py
+        try
+        {
+            const Json doc = Json::parseFile(argv[2]);
+            const auto g = grm::graphFromJson(doc, argv[3]);
+            std::deque<Read> store;
+            std::string line;
+            while (std::getline(std::cin, line))
+            {
+                std::istringstream in(line);
+                int pos = 0, reverse = 0, score = 0;
+                std::string cigar, seqs;
+                if (!(in >> pos >> cigar >> reverse >> score >> seqs))
+                    continue;
+                store.emplace_back("f" + std::to_string(store.size()), "A", "#");
+                Read& r = store.back();
+                r.set_graph_mapping_status(Read::MAPPED);
+                r.set_graph_pos(pos);
+                r.set_graph_cigar(cigar);
+                r.set_is_graph_reverse_strand(reverse != 0);
+                r.set_graph_alignment_score(score);
+                if (seqs != "-")
+                {
+                    std::stringstream ss(seqs);
+                    std::string one;
+                    while (std::getline(ss, one, ','))
+                        r.add_graph_sequences_supported(one);
+                }
+            }
+            std::vector<Read const*> reads;
+            for (Read const& r : store)
+                reads.push_back(&r);
+            std::cout << paragraph::alignmentStatistics(g, reads).dump() << "\n";
+        }
+        catch (std::exception const& e)
+        {
+            std::cerr << "error: " << e.what() << "\n";
+            return 1;
+        }
+        return 0;
+    }
     if (argc == 4 && std::string(argv[1]) == "--pair-lengths")
     {
         // <graph.json> <reference.fa>; stdin: "pos1 cigar1 pos2 cigar2" per line -> graph length of the two-read fragment as

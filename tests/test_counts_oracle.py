@@ -197,3 +197,71 @@ def test_fragment_graph_length_equals_the_references(tmp_path):
         no_path += sum(w is None for w in want)
         with_gap += sum(1 for q, w in zip(pairs, want) if w is not None and q[1].split("[")[0] != q[3].split("[")[0])
     assert checked > 150 and with_gap > 40, (checked, with_gap, no_path)
+
+
+def test_alignment_statistics_equal_the_references_summarize_alignments(tmp_path):
+    """`alignment_statistics` (per node / edge / allele: reads by strand, match-base depth, mismatch / gap / clip rates,
+    average score, contig length) as the host library builds it against the reference's OWN summarizeAlignments +
+    AlignmentStatistics.cpp (compiled as they lie: oracle/_ref/libpg_refstats.so) on random labelled graphs, the alignments the
+    reference's gssw.c gives the reads and the sequence supports its disambiguation gives them."""
+    import json
+    import math
+    import random
+    import subprocess
+    from oracle import counts as oc
+    from oracle import oracle as orc
+    from oracle import stats as ost
+    from paragraph_amd import build
+    from tests import fuzzgen
+    if not (oc.have_ref() and orc.have_ref() and ost.have_ref()):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    exe = os.path.join(os.path.dirname(build.build_genotyping_test()), "test_hostio")
+    counts, gssw = oc.RefCounts(), orc.RefOracle()
+    rng = random.Random(4711)
+    fasta = tmp_path / "none.fa"
+    fasta.write_text(">x\nACGT\n")
+    (tmp_path / "none.fa.fai").write_text("x\t4\t3\t4\t5\n")
+
+    def same(a, b, where):
+        if isinstance(a, dict):
+            assert isinstance(b, dict) and set(a) == set(b), (where, sorted(a), sorted(b) if isinstance(b, dict) else b)
+            for k in a:
+                same(a[k], b[k], where + "/" + k)
+        elif isinstance(a, float) or isinstance(b, float):
+            assert math.isclose(a, b, rel_tol=1e-12, abs_tol=1e-15), (where, a, b)
+        else:
+            assert a == b, (where, a, b)
+
+    n_reads = n_elements = 0
+    for it in range(90):
+        shape = rng.choice([None, None, "longdel", "bubble"])
+        seqs, edges = fuzzgen.rand_graph(rng, max_len=rng.choice([10, 40]), max_nodes=7, shape=shape)
+        terminals = it % 3 == 0 and len(seqs) >= 3
+        names = ["n%d" % i for i in range(len(seqs))]
+        if terminals:  # source / sink: one-base "X" nodes once loaded (GraphInput.cpp:86-89), left out of the statistics
+            names[0], names[-1] = "source", "sink"
+            seqs = ["X"] + list(seqs[1:-1]) + ["X"]
+        labels, label_names = fuzzgen.rand_labels(rng, edges)
+        reads = [fuzzgen.rand_read(rng, seqs, edges, min_len=8, max_len=70) for _ in range(16)]
+        al = gssw.align_batch(seqs, edges, reads)
+        recs = [{"pos": a["graph_pos"], "cigar": a["cigar"], "aligned": a["score"] > 0, "unique": a["unique"], "graph_reverse": rng.random() < 0.5,
+                 "read_len": len(r), "fragment": i} for i, (a, r) in enumerate(zip(al, reads))]
+        sup = counts.count_site(oc.CountGraph(seqs, edges, labels, label_names), recs, remove_nonuniq=False, use_support_filters=True)
+        mapped = [{"pos": rec["pos"], "cigar": rec["cigar"], "reverse": rec["graph_reverse"], "score": a["score"], "sequences": sorted(sup["labels"][i])}
+                  for i, (rec, a) in enumerate(zip(recs, al)) if sup["status"][i] == 1]
+        if not mapped:
+            continue
+        want = ost.alignment_statistics(names, seqs, edges, labels, mapped)
+        graph_json = tmp_path / ("s%d.json" % it)
+        graph_json.write_text(json.dumps({
+            "nodes": [{"name": nm, "sequence": s} for nm, s in zip(names, seqs)],
+            "edges": [dict({"from": names[a], "to": names[b]}, **({"sequences": labels[(a, b)]} if labels.get((a, b)) else {})) for a, b in edges],
+            "sequencenames": label_names, "target_regions": ["x:1-2"]}))
+        lines = "".join("%d %s %d %d %s\n" % (m["pos"], m["cigar"], 1 if m["reverse"] else 0, m["score"], ",".join(m["sequences"]) or "-") for m in mapped)
+        p = subprocess.run([exe, "--alignment-statistics", str(graph_json), str(fasta)], input=lines, capture_output=True, text=True, timeout=60)
+        assert p.returncode == 0, p.stderr
+        got = json.loads(p.stdout)
+        same(want, got, "graph %d" % it)
+        n_reads += len(mapped)
+        n_elements += sum(len(want[k]) for k in ("nodes", "edges", "alleles"))
+    assert n_reads > 250 and n_elements > 300, (n_reads, n_elements)

@@ -105,7 +105,7 @@ def test_general_reads_are_counted_like_the_others(gpu_ctx, checker):
         gor.extend([gi] * len(rs))
         frag.extend(fr)
         isrev.extend(rv)
-    assert sum(len(r) > 512 for r in reads) > 30
+    assert sum(len(r) > 512 for r in reads) > 12
     al, sup, cnt = gpu_counts(gpu_ctx, graphs, labels, names, reads, gor, frag, isrev, **kw)
     k = 0
     for gi, w in enumerate(want):

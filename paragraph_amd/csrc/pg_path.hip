@@ -278,16 +278,18 @@ __global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
     int len;
     w.extend<false>(e, qpos, fn, sp, ep, len, nl, nr, nullptr, nullptr);
     const uint32_t n_nodes = nl + e.n_nodes + nr;
-    const unsigned long long base = atomicAdd(a.ops_counter, (unsigned long long)n_nodes);
+    // one element per node -- except that a match run longer than an element holds (PG_OP_MAX_LEN: only reads beyond 4 095 bases
+    // have one) goes out in pieces: at most L / PG_OP_MAX_LEN more elements, reserved up front
+    const uint32_t extra = (uint32_t)L > PG_OP_MAX_LEN ? (uint32_t)L / PG_OP_MAX_LEN : 0u;
+    const unsigned long long base = atomicAdd(a.ops_counter, (unsigned long long)(n_nodes + extra));
     pg_op* ops = a.ops + base;
+    uint32_t n_ops = 0;
     // prepended nodes are produced closest-first: write them at nl-1-j; seed nodes at nl+i; appended at nl+n_seed+j
     {
-        // record into the ops area itself (node ids first, converted to op words below)
-        uint32_t* ids = (uint32_t*)ops;
-        // use the tail of the region for the "left" list so that nothing overlaps: left[j] -> ids[nl-1-j]
-        // implemented by recording into temporaries placed at the final positions via reversed pointer maths
+        // record into the ops area itself (node ids first -- behind the reserved extra elements, so that the op words written
+        // from the front never overtake the ids still to be read -- converted to op words below)
+        uint32_t* ids = (uint32_t*)ops + extra;
         qpos = first_pos;
-        // rec_l must map j -> ids[nl-1-j]; do it with a small adaptor: record to ids+0.. then reverse
         w.extend<true>(e, qpos, fn, sp, ep, len, nl, nr, ids, ids + nl + e.n_nodes);
         for (uint32_t i = 0, j = nl ? nl - 1 : 0; i < j; ++i, --j)
         {
@@ -302,7 +304,13 @@ __global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
             const uint32_t node = ids[i];
             const uint32_t lo = i == 0 ? sp : 0u;
             const uint32_t hi = i == n_nodes - 1 ? ep : w.nlen(node) - 1;
-            ops[i] = PG_OP_MAKE(node, PG_OPC_M, hi - lo + 1);
+            uint32_t left = hi - lo + 1;
+            do
+            {
+                const uint32_t piece = left > PG_OP_MAX_LEN ? PG_OP_MAX_LEN : left;
+                ops[n_ops++] = PG_OP_MAKE(node, PG_OPC_M, piece);
+                left -= piece;
+            } while (left);
         }
     }
     pg_result res;
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
     res.is_unique = n_full == 1 ? 1 : 0;
     res.returned_reverse = first_strand ? 1 : 0;
     res.multi_mask = 0;
-    res.n_ops = (uint16_t)n_nodes;
+    res.n_ops = (uint16_t)n_ops;
     res.ops_off = (uint32_t)base;
     res.strand_score[0] = first_strand ? -1 : (int16_t)L;
     res.strand_score[1] = first_strand ? (int16_t)L : -1;

@@ -148,3 +148,30 @@ def test_graph_beyond_4095_nodes_and_runs_beyond_4095_bases(gpu_ctx, checker):
     import re
     assert any(int(n) > 4095 for w in want[:28] for n in re.findall(r"(\d+)\[", w["cigar"]))
     assert any(int(m) > 4095 for w in want[28:] for m in re.findall(r"(\d+)M", w["cigar"]))
+
+
+def test_path_stage_takes_a_read_beyond_4095_bases(gpu_ctx):
+    """PathAligner (exact matching, default ON in `paragraph`) on a 5 000-base read that matches a node run exactly: one
+    CIGAR element per node, the 4 600-base run inside the long node in pieces that print as one (PathAligner.cpp:121-161)."""
+    from paragraph_amd import capi
+    rng = random.Random(fuzzgen.salted(4600))
+    nodes = [fuzzgen.rand_seq(rng, 300), fuzzgen.rand_seq(rng, 6000), fuzzgen.rand_seq(rng, 500)]
+    edges = [(0, 1), (0, 2), (1, 2)]
+    read = nodes[0][200:] + nodes[1][:4600]
+    short = nodes[0][100:250]
+    G = gpu_ctx.upload_graphs([(nodes, edges)])
+    G.build_path_index(32)
+    b = gpu_ctx.new_batch()
+    b.upload(G, [read, short])
+    b.path_align()
+    res, ops = b.download()
+    got = capi.results_to_dicts(res, ops)
+    from tests.test_gpu_path import PKEYS, path_checker
+    want = path_checker()(nodes, edges, [read, short], 32)
+    assert want[0]["status"] == 1 and want[0]["cigar"] == "0[100M]1[4600M]" and want[0]["score"] == len(read), want[0]
+    for g, w in zip(got, want):
+        assert g["by_path_aligner"] == bool(w["status"]), (g, w)
+        if w["status"]:
+            assert all(g[key] == w[key] for key in PKEYS) and g["returned_reverse"] == w["is_graph_reverse"], (g, w)
+    b.close()
+    G.close()

@@ -1272,27 +1272,127 @@ void PackedSite::clear()
 
 namespace
 {
-// fragment ids of one site, kept once: the maps below hold views into it (blocks never move)
+// fragment ids of one site, kept once: the tables below hold views into it (blocks never move; reset() keeps them for the
+// next site of the same thread)
 class NameArena
 {
 public:
     std::string_view keep(const char* p, size_t n)
     {
-        if (blocks_.empty() || used_ + n > kBlock)
+        if (current_ == kNone || used_ + n > sizes_[current_])
         {
-            blocks_.emplace_back(new char[std::max<size_t>(kBlock, n)]);
+            const size_t next = current_ == kNone ? 0 : current_ + 1;
+            if (next >= blocks_.size() || sizes_[next] < n)
+            {
+                blocks_.emplace(blocks_.begin() + (ptrdiff_t)next, new char[std::max<size_t>(kBlock, n)]);
+                sizes_.insert(sizes_.begin() + (ptrdiff_t)next, std::max<size_t>(kBlock, n));
+            }
+            current_ = next;
             used_ = 0;
         }
-        char* dst = blocks_.back().get() + used_;
+        char* dst = blocks_[current_].get() + used_;
         memcpy(dst, p, n);
         used_ += n;
         return std::string_view(dst, n);
     }
+    void reset()
+    {
+        current_ = kNone;
+        used_ = 0;
+    }
 
 private:
-    enum : size_t { kBlock = 16384 };
+    enum : size_t { kBlock = 16384, kNone = (size_t)-1 };
     std::vector<std::unique_ptr<char[]>> blocks_;
-    size_t used_ = 0;
+    std::vector<size_t> sizes_;
+    size_t current_ = kNone, used_ = 0;
+};
+
+// fragment id -> value, open addressing over a flat entry list: no node per id, and clear() keeps the storage, so a worker
+// thread allocates while its first sites grow the tables and not afterwards (std::unordered_map: one allocation per id, per site)
+template <class V> class NameTable
+{
+public:
+    struct Entry
+    {
+        std::string_view key;
+        uint64_t hash;
+        V value;
+    };
+    void clear()
+    {
+        entries_.clear();
+        std::fill(index_.begin(), index_.end(), -1);
+    }
+    size_t size() const { return entries_.size(); }
+    std::vector<Entry> const& entries() const { return entries_; }
+    Entry& at(size_t i) { return entries_[i]; }
+    // index of the entry of `key`, or -1
+    int32_t find(std::string_view key, uint64_t h) const
+    {
+        if (index_.empty())
+            return -1;
+        const size_t mask = index_.size() - 1;
+        for (size_t i = (size_t)h & mask;; i = (i + 1) & mask)
+        {
+            const int32_t e = index_[i];
+            if (e < 0)
+                return -1;
+            if (entries_[(size_t)e].hash == h && entries_[(size_t)e].key == key)
+                return e;
+        }
+    }
+    // `key` must outlive the table's contents (a view into the arena)
+    int32_t insert(std::string_view key, uint64_t h, V const& value)
+    {
+        if ((entries_.size() + 1) * 2 > index_.size())
+            grow();
+        entries_.push_back(Entry{ key, h, value });
+        place((int32_t)entries_.size() - 1);
+        return (int32_t)entries_.size() - 1;
+    }
+    static uint64_t hashOf(std::string_view s)
+    {
+        // 8 bytes at a time, multiply-fold (ids are 10-40 characters; the quality bar is "no clustering in a table half full")
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)s.size();
+        const char* p = s.data();
+        size_t n = s.size();
+        while (n >= 8)
+        {
+            uint64_t w;
+            memcpy(&w, p, 8);
+            h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+            h ^= h >> 32;
+            p += 8;
+            n -= 8;
+        }
+        if (n)
+        {
+            uint64_t w = 0;
+            memcpy(&w, p, n);
+            h = (h ^ w) * 0xC4CEB9FE1A85EC53ull;
+            h ^= h >> 29;
+        }
+        return h;
+    }
+
+private:
+    void place(int32_t e)
+    {
+        const size_t mask = index_.size() - 1;
+        size_t i = (size_t)entries_[(size_t)e].hash & mask;
+        while (index_[i] >= 0)
+            i = (i + 1) & mask;
+        index_[i] = e;
+    }
+    void grow()
+    {
+        index_.assign(std::max<size_t>(256, index_.size() * 2), -1);
+        for (int32_t e = 0; e < (int32_t)entries_.size(); ++e)
+            place(e);
+    }
+    std::vector<Entry> entries_;
+    std::vector<int32_t> index_;
 };
 
 // the reads of one target region while it is scanned: one slot pair per fragment id, like common::ReadPairs
@@ -1305,19 +1405,27 @@ struct RegionReads
         uint8_t flags;
     };
     typedef std::array<int32_t, 2> Slots;  // index into `kept` of first / second mate, -1 = empty
-    std::unordered_map<std::string_view, Slots> slots;
+    NameTable<Slots> slots;
     std::vector<Kept> kept;
     std::string bases;
+    std::vector<uint32_t> order;  // scratch of ordered()
     int num_reads = 0;
-    NameArena& names;
-    explicit RegionReads(NameArena& arena) : names(arena) {}
 
-    void add(common::LeanAlign const& r)
+    void clear()
     {
-        auto it = slots.find(std::string_view(r.name, r.name_len));
-        if (it == slots.end())
-            it = slots.emplace(names.keep(r.name, r.name_len), Slots{ -1, -1 }).first;
-        int32_t& slot = it->second[r.is_first_mate ? 0 : 1];
+        slots.clear();
+        kept.clear();
+        bases.clear();
+        num_reads = 0;
+    }
+    void add(common::LeanAlign const& r, NameArena& names)
+    {
+        const std::string_view name(r.name, r.name_len);
+        const uint64_t h = NameTable<Slots>::hashOf(name);
+        int32_t e = slots.find(name, h);
+        if (e < 0)
+            e = slots.insert(names.keep(r.name, r.name_len), h, Slots{ -1, -1 });
+        int32_t& slot = slots.at((size_t)e).value[r.is_first_mate ? 0 : 1];
         Kept k;
         k.base_begin = (uint32_t)bases.size();
         k.base_len = r.n_bases;
@@ -1346,7 +1454,7 @@ struct RegionReads
             kept[(size_t)slot] = k;
         }
     }
-    void add(common::Read const& r)
+    void add(common::Read const& r, NameArena& names)
     {
         common::LeanAlign l;
         l.name = r.fragment_id().data();
@@ -1362,15 +1470,26 @@ struct RegionReads
         l.is_mate_mapped = r.is_mate_mapped();
         l.is_reverse_strand = r.is_reverse_strand();
         l.is_mate_reverse_strand = r.is_mate_reverse_strand();
-        add(l);
+        add(l, names);
     }
-    // (fragment id, slots) in the order common::ReadPairs (a std::map by fragment id) walks them
-    std::vector<std::pair<std::string_view, Slots>> ordered() const
+    // entry indices in the order common::ReadPairs (a std::map by fragment id) walks them
+    std::vector<uint32_t> const& ordered()
     {
-        std::vector<std::pair<std::string_view, Slots>> v(slots.begin(), slots.end());
-        std::sort(v.begin(), v.end(), [](auto const& a, auto const& b) { return a.first < b.first; });
-        return v;
+        order.resize(slots.size());
+        for (uint32_t i = 0; i < (uint32_t)order.size(); ++i)
+            order[i] = i;
+        auto const& e = slots.entries();
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return e[a].key < e[b].key; });
+        return order;
     }
+};
+
+// what extractPacked needs besides the site it fills; one per worker thread, reused from site to site
+struct ExtractScratch
+{
+    NameArena names;
+    NameTable<uint32_t> fragment_of;  // across the regions of one site
+    RegionReads pairs;
 };
 
 // common::isReadOrItsMateInRegion on a lean record
@@ -1390,13 +1509,17 @@ void extractPacked(
 {
     if (!site.fragment.empty())
         throw std::logic_error("extractPacked: the site must be empty (fragment ids are assigned by name)");
-    NameArena names;
-    std::unordered_map<std::string_view, uint32_t> fragment_of;  // across the regions of this site
+    static thread_local ExtractScratch scratch;
+    NameArena& names = scratch.names;
+    NameTable<uint32_t>& fragment_of = scratch.fragment_of;
+    RegionReads& pairs = scratch.pairs;
+    names.reset();
+    fragment_of.clear();
     common::LeanAlign rec;
     for (common::Region const& region : target_regions)
     {
         reader.setRegion(region.getExtendedRegion((int64_t)avr_fragment_length * 3));
-        RegionReads pairs(names);
+        pairs.clear();
         unsigned total_length = 0, counted = 0;
         while (pairs.num_reads != max_num_reads && reader.getAlignLean(rec))
         {
@@ -1406,16 +1529,17 @@ void extractPacked(
                 ++counted;
             }
             if (inRegion(rec, region))
-                pairs.add(rec);
+                pairs.add(rec, names);
         }
         const unsigned read_length = counted ? total_length / counted : 0;
         if (max_num_reads != pairs.num_reads && read_length <= longest_alt_insertion * 2)
         {
             // far-away mates of half-filled fragments (recoverMissingMates): rare, so a temporary Read per lookup is fine
             std::vector<common::Read> lonely;
-            for (auto const& kv : pairs.ordered())
+            for (uint32_t entry : pairs.ordered())
             {
-                const int32_t a = kv.second[0], b = kv.second[1];
+                auto const& kv = pairs.slots.entries()[entry];
+                const int32_t a = kv.value[0], b = kv.value[1];
                 const bool has_a = a >= 0 && pairs.kept[(size_t)a].base_len > 0, has_b = b >= 0 && pairs.kept[(size_t)b].base_len > 0;
                 if (has_a == has_b)
                     continue;  // both there -- or neither, which is not a read at all
@@ -1423,7 +1547,7 @@ void extractPacked(
                 if (k.chrom_id == k.mate_chrom_id && std::abs(k.pos - k.mate_pos) < 1000)
                     continue;
                 common::Read have;
-                have.setCoreInfo(std::string(kv.first), pairs.bases.substr(k.base_begin, k.base_len), "");
+                have.setCoreInfo(std::string(kv.key), pairs.bases.substr(k.base_begin, k.base_len), "");
                 have.set_is_first_mate((k.flags & PackedSite::FIRST_MATE) != 0);
                 have.set_is_mate_mapped((k.flags & PackedSite::MATE_MAPPED) != 0);
                 have.set_chrom_id(k.chrom_id);
@@ -1437,19 +1561,41 @@ void extractPacked(
                 common::Read mate;
                 reader.getAlignedMate(have, mate);
                 if (mate.is_initialized())
-                    pairs.add(mate);
+                    pairs.add(mate, names);
             }
         }
-        for (auto const& kv : pairs.ordered())
         {
-            for (int32_t slot : kv.second)
+            const size_t more = pairs.kept.size();
+            site.bases.reserve(site.bases.size() + pairs.bases.size());
+            site.base_end.reserve(site.base_end.size() + more);
+            site.fragment.reserve(site.fragment.size() + more);
+            site.flags.reserve(site.flags.size() + more);
+            site.chrom_id.reserve(site.chrom_id.size() + more);
+            site.pos.reserve(site.pos.size() + more);
+            site.mate_chrom_id.reserve(site.mate_chrom_id.size() + more);
+            site.mate_pos.reserve(site.mate_pos.size() + more);
+        }
+        for (uint32_t entry : pairs.ordered())
+        {
+            auto const& kv = pairs.slots.entries()[entry];
+            uint32_t fragment = 0;
+            bool fragment_known = false;
+            for (int32_t slot : kv.value)
             {
                 if (slot < 0 || pairs.kept[(size_t)slot].base_len == 0)
                     continue;
                 RegionReads::Kept const& k = pairs.kept[(size_t)slot];
                 site.bases.append(pairs.bases, k.base_begin, k.base_len);
                 site.base_end.push_back((uint32_t)site.bases.size());
-                site.fragment.push_back(fragment_of.emplace(kv.first, (uint32_t)fragment_of.size()).first->second);
+                if (!fragment_known)
+                {
+                    int32_t f = fragment_of.find(kv.key, kv.hash);
+                    if (f < 0)
+                        f = fragment_of.insert(kv.key, kv.hash, (uint32_t)fragment_of.size());
+                    fragment = fragment_of.at((size_t)f).value;
+                    fragment_known = true;
+                }
+                site.fragment.push_back(fragment);
                 site.flags.push_back(k.flags);
                 site.chrom_id.push_back(k.chrom_id);
                 site.pos.push_back(k.pos);

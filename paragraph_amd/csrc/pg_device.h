@@ -94,9 +94,11 @@ struct PgFillSummary
 {
     int32_t score;     // best local score of the fill (gssw max_node->score1)
     int32_t max_node;  // first node (topological) holding it
-    int32_t ref_end;   // node-local column of its first occurrence (ref_end1), -1 if score 0
-    int32_t read_end;  // smallest read index in that column (read_end1)
-    int32_t end_col;   // same column as a graph-global column index
+    // (the packed fill, pg_fill.hip; the general path, pg_general.h, fills in the end cell itself: ref_end, read_end = its row)
+    int32_t ref_end;   // -1 (the node-local column of the end cell is the traceback kernel's: end_col - the node's first column)
+    int32_t read_end;  // first row of the fill lane that holds the score in that column; the row itself (read_end1, the smallest
+                       // read index in the column) is found by the traceback kernel among that lane's rows
+    int32_t end_col;   // graph-global column of the score's first occurrence (ref_end1), -1 if score 0 or a reversed-graph fill
     int32_t multi;     // alignsEndAtMultNodes
     int32_t pad[2];
 };

@@ -78,6 +78,12 @@ __device__ __forceinline__ int sub_score(uint32_t a, uint32_t b)
     return (a == 4u || b == 4u) ? 0 : (a == b ? 1 : -4);
 }
 
+// column meta words are fetched this many steps ahead of their use (scalar loads; a step is ~0.6 us of wall clock with four
+// wavefronts per SIMD, a scalar-cache miss an L2 round trip under the chip's full traffic)
+#ifndef PG_META_AHEAD
+#define PG_META_AHEAD 2
+#endif
+
 template <int C, int DIR, bool WIDE, int GL = PG_GROUP_LANES>
 __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair, uint32_t* lds, uint32_t half = 0)
 {
@@ -213,6 +219,14 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // (LF -> {ALT, RF}: RF's far predecessor is LF) needs no memory round trip -- a load there stalls the whole wavefront
     uint32_t cseed[SEEDCACHE ? C : 1];
     uint32_t cnode = 0xFFFFFFFFu;
+    // ... and a second entry where the registers allow it: entry A holds the last seed of an even node, entry B that of an odd
+    // one.  A seed that has to be LOADED at a node's first column stops the wavefront for a memory round trip behind all of its
+    // outstanding trace stores (one counter, in order) -- at every one of the 16 steps in which a lane of the read reaches that
+    // column: a tenth of the whole fill on the left flank -> allele -> right flank graphs of single events, whose right flank
+    // wants the left flank's seed after the allele's has been stored (and a swap's second allele / right flank likewise).
+    constexpr bool SEEDCACHE2 = SEEDCACHE && C <= 12;
+    uint32_t cseedB[SEEDCACHE ? C : 1];
+    uint32_t cnodeB = 0xFFFFFFFFu;
     uint32_t M = BIAS2 + (PG_TAU0 - 1) * ONE2, FC = 0;  // node maximum (frame of the previous step) / step that first reached it
     uint32_t FR = 0;  // WIDE: smallest row (within the lane) holding the lane's maximum in column FC, per strand
     const uint32_t NEG5 = 0xC500C500u;    // (-5.0, -5.0): gap extend - gap open
@@ -226,7 +240,10 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // PG_META_PAD idle words on the host.
     typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
     const const_u32_ptr cmeta = (const_u32_ptr)(uintptr_t)smeta;
-    uint32_t mw1 = cmeta[1], mw2 = cmeta[2];
+    uint32_t mw[PG_META_AHEAD];  // the words of the next PG_META_AHEAD steps, in scalar registers
+#pragma unroll
+    for (int q = 0; q < PG_META_AHEAD; ++q)
+        mw[q] = cmeta[1 + q];
     // software pipeline: `meta` and the current profile rows always belong to the step about to be computed
     uint32_t meta = group_shr1_keep<GL>(cmeta[0], PG_META_IDLE);
     // code 4 (N / idle column: score 0 on real rows) in the profile's shifted form
@@ -329,11 +346,17 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         if (DIR == 0)
         {
             // one byte per cell: the low byte of the bit pattern = (score + tau) mod 256 (all of the score in the byte variants;
-            // in the wide ones the traceback keeps exact scores by following differences, which are small between neighbours)
+            // in the wide ones the traceback keeps exact scores by following differences, which are small between neighbours).
+            // A dword holds DIAGONAL neighbours: the odd row r + 1 of this column and the even row r of the column before it
+            // (Hin, in its own step's frame) -- the traceback walks diagonals, and every memory read it makes costs a whole
+            // 128-byte line (profiles/r03_sector_probe.json), so two cells of its path per dword halve the lines it pulls from
+            // under the next chunk's fill.  Where a node begins in this column Hin has been turned into the seed by
+            // first_column: the even rows of a node's LAST column are therefore not in the trace; they are in the seed
+            // region, which forward-graph fills store for every node (last_column).
 #pragma unroll
             for (int r = 0; r < C; r += 2)
             {
-                const uint32_t packed = __builtin_amdgcn_perm(Hout[r + 1], Hout[r], 0x06020400u);  // bytes A_r, A_r+1, B_r, B_r+1 (one v_perm)
+                const uint32_t packed = __builtin_amdgcn_perm(Hout[r + 1], Hin[r], 0x06020400u);  // bytes A_r', A_r+1, B_r', B_r+1 (one v_perm)
                 asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(trace_lane_off), "v"(packed), "s"(tbase), "n"((r / 2) * 256) : "memory");
             }
         }
@@ -360,27 +383,32 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             if (meta_cur & PG_META_PRED_ONE)
             {
                 const uint32_t pid = (meta_cur >> PG_META_PRED_SHIFT) & 0x7Fu;
-                uint32_t w[C];
-                if (SEEDCACHE && pid == cnode)
-                {
+                // bytes (H_A, H_B, Enext_A, Enext_B) -> (0x6400 | H_A, 0x6400 | H_B) (the 0x64 bytes come from the constant),
+                // then into the frame with an integer addition on the bit patterns.  Each source has its own copy of this: the
+                // wait for a LOADED seed (all outstanding trace stores drain before it, one in-order counter) must not sit behind
+                // the join where the cached ones would pay it too.
+                auto take = [&](const uint32_t (&w)[SEEDCACHE ? C : 1]) __attribute__((always_inline)) {
 #pragma unroll
                     for (int r = 0; r < C; ++r)
-                        w[r] = cseed[SEEDCACHE ? r : 0];
-                }
+                    {
+                        pk_maxu_into(Hin[r], pk_add(__builtin_amdgcn_perm(BIAS2, w[SEEDCACHE ? r : 0], 0x07010500u), hshift));
+                        E[r] = pk_maxu(E[r], pk_add(__builtin_amdgcn_perm(BIAS2, w[SEEDCACHE ? r : 0], 0x07030502u), eshift));
+                    }
+                };
+                if (SEEDCACHE && pid == cnode)
+                    take(cseed);
+                else if (SEEDCACHE2 && pid == cnodeB)
+                    take(cseedB);
                 else
                 {
                     const uint32_t* sp = seed + ((size_t)pid * 64 + lane) * SEED_DW;
 #pragma unroll
                     for (int r = 0; r < C; ++r)
-                        w[r] = sp[r];
-                }
-#pragma unroll
-                for (int r = 0; r < C; ++r)
-                {
-                    // bytes (H_A, H_B, Enext_A, Enext_B) -> (0x6400 | H_A, 0x6400 | H_B) (the 0x64 bytes come from the constant),
-                    // then into the frame with an integer addition on the bit patterns
-                    pk_maxu_into(Hin[r], pk_add(__builtin_amdgcn_perm(BIAS2, w[r], 0x07010500u), hshift));
-                    E[r] = pk_maxu(E[r], pk_add(__builtin_amdgcn_perm(BIAS2, w[r], 0x07030502u), eshift));
+                    {
+                        const uint32_t w = sp[r];
+                        pk_maxu_into(Hin[r], pk_add(__builtin_amdgcn_perm(BIAS2, w, 0x07010500u), hshift));
+                        E[r] = pk_maxu(E[r], pk_add(__builtin_amdgcn_perm(BIAS2, w, 0x07030502u), eshift));
+                    }
                 }
             }
         }
@@ -418,7 +446,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // (already the next column's) in that of step t + 1.
     auto last_column = [&](const uint32_t (&Hout)[C], uint32_t meta_cur, uint32_t tau) __attribute__((always_inline)) {
         const uint32_t node = PG_META_NODE(meta_cur);
-        if (meta_cur & PG_META_SAVE)
+        if ((meta_cur & PG_META_SAVE) || DIR == 0)  // forward graph: every node (the even rows of its last column, see column())
         {
             uint32_t* sp = seed + ((size_t)node * 64 + lane) * SEED_DW;
             const uint32_t hshift = tau * ONE2, eshift = (tau + 1u) * ONE2;
@@ -435,11 +463,25 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 {
                     const uint32_t w = __builtin_amdgcn_perm(es, hs, 0x06040200u);
                     sp[r] = w;
-                    if (SEEDCACHE)
+                    if (SEEDCACHE2)
+                    {
+                        if (node & 1u)
+                            cseedB[r] = w;
+                        else
+                            cseed[r] = w;
+                    }
+                    else if (SEEDCACHE)
                         cseed[r] = w;
                 }
             }
-            if (SEEDCACHE)
+            if (SEEDCACHE2)
+            {
+                if (node & 1u)
+                    cnodeB = node;
+                else
+                    cnode = node;
+            }
+            else if (SEEDCACHE)
                 cnode = node;
         }
         // key: max (12 bits) | inverted column (16 bits; a direction has <= 65519 columns) | inverted lane (4 bits)
@@ -480,9 +522,11 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         Fin = group_shr1_keep<GL>(Fin, Fsend);
         const uint32_t dH = dHin, F = Fin;
         // the next step's meta word; the profile rows of the next column (PREFETCH) or of this one
-        meta = group_shr1_keep<GL>(mw1, meta_cur);
-        mw1 = mw2;
-        mw2 = cmeta[t + 3];
+        meta = group_shr1_keep<GL>(mw[0], meta_cur);
+#pragma unroll
+        for (int q = 0; q + 1 < PG_META_AHEAD; ++q)
+            mw[q] = mw[q + 1];
+        mw[PG_META_AHEAD - 1] = cmeta[t + 1 + PG_META_AHEAD];
         const uint32_t meta_rows = PREFETCH ? meta : meta_cur;
         uint32_t (&rows)[C] = PREFETCH ? sn : sc;
         {
@@ -540,155 +584,129 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             step(HB, HA, sA, sA, t + 1);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trace stores above are invisible to the compiler's own counters
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the key atomics (and the trace stores) above are invisible to the compiler's own counters
 
-    __threadfence_block();
-    __syncthreads();
-
-    // ---- per fill: max_node (first node with the strictly largest score, gssw.c:4015-4018), multi
-    //      flag, end position --------------------------------------------------------------------------
-    if (k < 2 && WIDE)
+    // ---- per fill: max_node (first node with the strictly largest score, gssw.c:4015-4018), multi flag, end column ------------
+    // A wavefront keeps its place on the SIMD until this is done, and every load here is a round trip to memory under the
+    // traffic of 1 000 other wavefronts (and of the previous chunk's traceback): the key loads of all nodes go out together,
+    // lane k of a read taking nodes k, k + GL, ..., and nothing of the H trace is read back -- the row of the end cell is found by
+    // the traceback kernel, which reads that column anyway (pg_trace.hip).
     {
-        const int strand = k;
-        unsigned long long bestkey = 0;
-        uint32_t best = 0, bestnode = 0, cnt = 0;
-        for (uint32_t n = 0; n < n_nodes; ++n)
+        uint32_t lw[2] = { 0u, 0u };  // (score << 16 | 0xFFFF - node) of the lane's first node with its largest score; 0 = none
+        uint32_t lcnt[2] = { 0u, 0u };  // nodes of this lane with that score
+        unsigned long long lkey[2] = { 0ull, 0ull };
+        for (uint32_t n = (uint32_t)k; n < n_nodes; n += (uint32_t)GL)
         {
-            const unsigned long long key = __hip_atomic_load(&nodekey64[n * 8 + grp * 2 + strand], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t m = (uint32_t)(key >> 32);
-            if (m > best)
-            {
-                best = m;
-                bestkey = key;
-                bestnode = n;
-                cnt = 1;
-            }
-            else if (m == best)
-                ++cnt;
-        }
-        if (best >= 251u)
-        {
-            // gssw redid this fill in its 16-bit word mode (score + bias >= 255, gssw.c:380, 4100-4104), but
-            // alignsEndAtMultNodes scans len * readLen BYTES of each node's matrix through a uint8_t*
-            // (GraphAligner.cpp:180-187): a node only counts if the top score (<= 255) sits in the low byte of one of its
-            // first ceil(len * readLen / 2) cells, in (reference position, read position) order.
-            cnt = 0;
-            if (best <= 255u)
-            {
-                const uint32_t ridx = itp->read[grp];
-                const uint32_t L = ridx == PG_NONE ? 0u : a.base_off[ridx + 1] - a.base_off[ridx];
-                for (uint32_t n = 0; n < n_nodes; ++n)
-                {
-                    const unsigned long long key = __hip_atomic_load(&nodekey64[n * 8 + grp * 2 + strand], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((uint32_t)(key >> 32) != best)
-                        continue;
-                    const uint32_t col = 0xFFFFu - (uint32_t)((key >> 16) & 0xFFFFu);
-                    const uint32_t row = 0xFFFFu - (uint32_t)(key & 0xFFFFu);
-                    const uint64_t cell = (uint64_t)(col - nodes[n].col_start) * L + row;
-                    if (cell < ((uint64_t)nodes[n].len * L + 1) / 2)
-                        ++cnt;
-                }
-            }
-        }
-        PgFillSummary fs;
-        fs.score = (int32_t)best;
-        fs.max_node = (int32_t)bestnode;
-        fs.ref_end = -1;
-        fs.read_end = 0;
-        fs.end_col = -1;
-        fs.multi = cnt > 1 ? 1 : 0;
-        fs.pad[0] = fs.pad[1] = 0;
-        if (best > 0 && DIR == 0)
-        {
-            // the key's row field orders the lanes (lane * C + a row < C that is only exact for maxima of 251..255); the row
-            // itself = the first row of that lane holding `best` in the H trace of column `col`
-            const uint32_t col = 0xFFFFu - (uint32_t)((bestkey >> 16) & 0xFFFFu);
-            const uint32_t kk = (0xFFFFu - (uint32_t)(bestkey & 0xFFFFu)) / (uint32_t)C;
-            // (bytes = (score + tau) mod 256: within one lane's C <= 32 rows of a column the scores differ by far less than 256,
-            // so comparing modulo 256 finds the same first row)
-            const uint32_t* tp = trace + (size_t)(col + kk) * 64 * TRACE_DW + (lgrp * GL + kk);
-            const uint32_t tau = PG_TAU0 + ((col + kk) & 255u);
-            int rr = 0;
-            bool found = false;
 #pragma unroll
-            for (int r = 0; r < C; r += 2)
+            for (int st = 0; st < 2; ++st)
             {
-                const uint32_t w = tp[(r / 2) * 64];
-                const uint32_t b0 = (((w >> (strand * 16)) & 0xFFu) - tau) & 0xFFu;
-                const uint32_t b1 = (((w >> (strand * 16 + 8)) & 0xFFu) - tau) & 0xFFu;
-                if (!found && b0 == (best & 0xFFu))
+                unsigned long long key;
+                uint32_t m;
+                if (WIDE)
                 {
-                    rr = r;
-                    found = true;
+                    key = __hip_atomic_load(&nodekey64[n * 8 + grp * 2 + st], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    m = (uint32_t)(key >> 32);
                 }
-                if (!found && b1 == (best & 0xFFu))
+                else
                 {
-                    rr = r + 1;
-                    found = true;
+                    key = __hip_atomic_load(&nodekey[(n * 8 + grp * 2 + st) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    m = (uint32_t)key >> 20;
                 }
+                if (lcnt[st] == 0u || m > (lw[st] >> 16))
+                {
+                    lw[st] = (m << 16) | (0xFFFFu - n);
+                    lkey[st] = key;
+                    lcnt[st] = 1u;
+                }
+                else if (m == (lw[st] >> 16))
+                    ++lcnt[st];
             }
-            fs.end_col = (int32_t)col;
-            fs.ref_end = (int32_t)(col - nodes[bestnode].col_start);
-            fs.read_end = (int32_t)(kk * C) + rr;
         }
-        a.fillsum[((size_t)item_idx * PG_GROUPS + grp) * 2 + strand] = fs;
-    }
-    if (k < 2 && !WIDE)
-    {
-        const int strand = k;
-        uint32_t best = 0, bestkey = 0, bestnode = 0, cnt = 0;
-        for (uint32_t n = 0; n < n_nodes; ++n)
-        {
-            const uint32_t key = __hip_atomic_load(&nodekey[(n * 8 + grp * 2 + strand) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t m = key >> 20;
-            if (m > best)
-            {
-                best = m;
-                bestkey = key;
-                bestnode = n;
-                cnt = 1;
-            }
-            else if (m == best)
-                ++cnt;
-        }
-        PgFillSummary fs;
-        fs.score = (int32_t)best;
-        fs.max_node = (int32_t)bestnode;
-        fs.ref_end = -1;
-        fs.read_end = 0;
-        fs.end_col = -1;
-        fs.multi = cnt > 1 ? 1 : 0;
-        fs.pad[0] = fs.pad[1] = 0;
-        if (best > 0 && DIR == 0)
-        {
-            const uint32_t col = 0xFFFFu - ((bestkey >> 4) & 0xFFFFu);
-            const uint32_t kk = 15u - (bestkey & 15u);
-            const uint32_t* tp = trace + (size_t)(col + kk) * 64 * TRACE_DW + (lgrp * GL + kk);
-            int rr = 0;
-            bool found = false;
+        // across the read's lanes: the largest (score, smallest node); how many nodes carry that score; the winner's key
+        uint32_t gw[2], gcnt[2];
+        unsigned long long gkey[2];
 #pragma unroll
-            for (int r = 0; r < C; r += 2)
+        for (int st = 0; st < 2; ++st)
+        {
+            uint32_t w = lw[st];
+#pragma unroll
+            for (int off = GL / 2; off >= 1; off >>= 1)
             {
-                const uint32_t w = tp[(r / 2) * 64];
-                const uint32_t tau = PG_TAU0 + ((col + kk) & 255u);  // the trace holds (score + tau) & 0xFF of the step it was written in
-                const uint32_t b0 = (((w >> (strand * 16)) & 0xFFu) - tau) & 0xFFu;
-                const uint32_t b1 = (((w >> (strand * 16 + 8)) & 0xFFu) - tau) & 0xFFu;
-                if (!found && b0 == best)
+                const uint32_t o = (uint32_t)__shfl_xor((int)w, off, GL);
+                w = o > w ? o : w;
+            }
+            gw[st] = w;
+            uint32_t c = (lcnt[st] != 0u && (lw[st] >> 16) == (w >> 16)) ? lcnt[st] : 0u;
+            uint32_t klo = lw[st] == w ? (uint32_t)lkey[st] : 0u, khi = lw[st] == w ? (uint32_t)(lkey[st] >> 32) : 0u;
+            if (w == 0u)
+                klo = khi = 0u;  // no node at all (cannot happen: a graph has nodes)
+#pragma unroll
+            for (int off = GL / 2; off >= 1; off >>= 1)
+            {
+                c += (uint32_t)__shfl_xor((int)c, off, GL);
+                klo |= (uint32_t)__shfl_xor((int)klo, off, GL);
+                if (WIDE)
+                    khi |= (uint32_t)__shfl_xor((int)khi, off, GL);
+            }
+            gcnt[st] = c;
+            gkey[st] = ((unsigned long long)khi << 32) | klo;
+        }
+        if (k < 2)
+        {
+            const int strand = k;
+            const uint32_t best = (strand ? gw[1] : gw[0]) >> 16;
+            const uint32_t bestnode = 0xFFFFu - ((strand ? gw[1] : gw[0]) & 0xFFFFu);
+            const unsigned long long bestkey = strand ? gkey[1] : gkey[0];
+            uint32_t cnt = strand ? gcnt[1] : gcnt[0];
+            if (WIDE && best >= 251u)
+            {
+                // gssw redid this fill in its 16-bit word mode (score + bias >= 255, gssw.c:380, 4100-4104), but
+                // alignsEndAtMultNodes scans len * readLen BYTES of each node's matrix through a uint8_t*
+                // (GraphAligner.cpp:180-187): a node only counts if the top score (<= 255) sits in the low byte of one of its
+                // first ceil(len * readLen / 2) cells, in (reference position, read position) order.
+                cnt = 0;
+                if (best <= 255u)
                 {
-                    rr = r;
-                    found = true;
-                }
-                if (!found && b1 == best)
-                {
-                    rr = r + 1;
-                    found = true;
+                    const uint32_t ridx = itp->read[grp];
+                    const uint32_t L = ridx == PG_NONE ? 0u : a.base_off[ridx + 1] - a.base_off[ridx];
+                    for (uint32_t n = 0; n < n_nodes; ++n)
+                    {
+                        const unsigned long long key = __hip_atomic_load(&nodekey64[n * 8 + grp * 2 + strand], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((uint32_t)(key >> 32) != best)
+                            continue;
+                        const uint32_t col = 0xFFFFu - (uint32_t)((key >> 16) & 0xFFFFu);
+                        const uint32_t row = 0xFFFFu - (uint32_t)(key & 0xFFFFu);
+                        const uint64_t cell = (uint64_t)(col - nodes[n].col_start) * L + row;
+                        if (cell < ((uint64_t)nodes[n].len * L + 1) / 2)
+                            ++cnt;
+                    }
                 }
             }
-            fs.end_col = (int32_t)col;
-            fs.ref_end = (int32_t)(col - nodes[bestnode].col_start);
-            fs.read_end = (int32_t)(kk * C) + rr;
+            PgFillSummary fs;
+            fs.score = (int32_t)best;
+            fs.max_node = (int32_t)bestnode;
+            fs.ref_end = -1;  // node-local column and row of the end cell: the traceback kernel's (from end_col / read_end)
+            fs.read_end = 0;
+            fs.end_col = -1;
+            fs.multi = cnt > 1 ? 1 : 0;
+            fs.pad[0] = fs.pad[1] = 0;
+            if (best > 0 && DIR == 0)
+            {
+                // the column of the first cell holding `best`, and the first row of the lane that holds it there
+                if (WIDE)
+                {
+                    // (the key's row field = lane * C + a row < C that is only exact for maxima of 251..255: it orders the lanes)
+                    fs.end_col = (int32_t)(0xFFFFu - (uint32_t)((bestkey >> 16) & 0xFFFFu));
+                    fs.read_end = (int32_t)((0xFFFFu - (uint32_t)(bestkey & 0xFFFFu)) / (uint32_t)C * (uint32_t)C);
+                }
+                else
+                {
+                    fs.end_col = (int32_t)(0xFFFFu - (((uint32_t)bestkey >> 4) & 0xFFFFu));
+                    fs.read_end = (int32_t)((15u - ((uint32_t)bestkey & 15u)) * (uint32_t)C);
+                }
+            }
+            a.fillsum[((size_t)item_idx * PG_GROUPS + grp) * 2 + strand] = fs;
         }
-        a.fillsum[((size_t)item_idx * PG_GROUPS + grp) * 2 + strand] = fs;
     }
 }
 

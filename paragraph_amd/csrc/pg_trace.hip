@@ -33,9 +33,18 @@
 // The randomized parity tests (tests/test_gpu_parity.py) pin this against the reference's own gssw.c.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pg_device.h"
 #include "pg_kernels.h"
+
+// tuning constants: rounds of diagonal loads in flight together, and the register budget as wavefronts per SIMD
+#ifndef PG_TRACE_BURST
+#define PG_TRACE_BURST 4
+#endif
+#ifndef PG_TRACE_WPE
+#define PG_TRACE_WPE 6
+#endif
 
 namespace
 {
@@ -125,8 +134,7 @@ struct Emitter
 
 // GL = lanes per read in the FILL that wrote the trace (16, or 32 for the wide variants: two fill wavefronts per work item,
 // reads 0-1 / 2-3, each with its own half of the item's trace and seed regions); this kernel walks with 16 lanes per read either way
-template <int C, bool WIDE, int GL = PG_GROUP_LANES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void pg_trace_kernel(PgTraceArgs a)
+template <int C, bool WIDE, int GL> __device__ __forceinline__ void pg_trace_pair(const PgTraceArgs& a, const uint32_t pair)
 {
     // No LDS and at most 64 VGPRs: this kernel runs on the second stream UNDER the next chunk's fill, whose 16 wavefronts per CU
     // take all 160 KB of LDS and 448 of the 512 VGPRs of a SIMD lane -- a traceback wavefront that needs neither takes the
@@ -134,9 +142,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const uint32_t lane = threadIdx.x;
     const uint32_t grp = lane >> 4;  // the read of this 16-lane row
     const uint32_t k = lane & 15u;
-    const uint32_t pair = a.pair_begin + blockIdx.x;
-    const uint32_t tid = blockIdx.x * PG_GROUPS + grp;
-    (void)tid;
     // row-level collectives; the control flow below is uniform within a row, so a lane only ever talks to active lanes
     auto row_ballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> (grp * 16u)) & 0xFFFFu; };
     auto row_get = [&](uint32_t v, uint32_t src) -> uint32_t { return (uint32_t)__shfl((int)v, (int)(grp * 16u + src)); };
@@ -211,11 +216,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // byte variants: trace [step][C/2][lane] dwords of bytes (A_r, A_r+1, B_r, B_r+1), seed [node][lane][C] dwords of
     // bytes (H_A, H_B, Enext_A, Enext_B); wide variants: the same trace, seed [node][lane][2C] dwords (H_A | H_B << 16),
     // (Enext_A | Enext_B << 16), each 16-bit field = 0x6400 | score
-    auto Hcell = [&](uint32_t col, int j) -> int {
+    uint32_t n = (uint32_t)fs.max_node;  // the node being walked
+    auto seedH = [&](uint32_t node, int j) -> int {
+        const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
+        if (WIDE)
+            return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * (2 * C) + 2 * r] >> (16 * s)) & 0x3FFu);
+        return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * C + r] >> (8 * s)) & 0xFFu);
+    };
+    auto seedE = [&](uint32_t node, int j) -> int {
+        const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
+        if (WIDE)
+            return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * (2 * C) + 2 * r + 1] >> (16 * s)) & 0x3FFu);
+        return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * C + r] >> (16 + 8 * s)) & 0xFFu);
+    };
+
+    // A trace dword holds diagonal neighbours (pg_fill.hip, column()): the odd row r of the step it was written in and the even
+    // row r - 1 of the step before -- so an even row is found one step on.  The even rows of a node's LAST column are not in
+    // the trace (the step after it starts another node); they are in that node's seed.  `at_end`: col is the last column of the
+    // node being walked (only the F tests look at the walk's own column; diagonals and E look at the one before it).
+    auto Hcell = [&](uint32_t col, int j, bool at_end) -> int {
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
         // the fill kernel stores (score + tau) of the step the cell was computed in (PG_TAU0, pg_device.h)
         const uint32_t tau = PG_TAU0 + ((col + kq) & 255u);
-        const size_t dw = ((size_t)(col + kq) * (C / 2) + r / 2) * 64 + (lane0 + kq);
+        if (!(r & 1u) && at_end)
+            return seedH(n, j) & (WIDE ? 0xFF : 0x3FF);
+        const size_t dw = ((size_t)(col + kq + ((r & 1u) ^ 1u)) * (C / 2) + r / 2) * 64 + (lane0 + kq);
         return (int)(((uint32_t)trace[dw * 4 + (r & 1u) + 2u * (uint32_t)s] - tau) & 0xFFu);
     };
     // The byte is the whole score in the byte variants (reads <= 250 bases).  In the wide ones it is the score modulo 256: the
@@ -235,19 +260,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
         return v;
     };
-    auto seedH = [&](uint32_t node, int j) -> int {
-        const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
-        if (WIDE)
-            return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * (2 * C) + 2 * r] >> (16 * s)) & 0x3FFu);
-        return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * C + r] >> (8 * s)) & 0xFFu);
-    };
-    auto seedE = [&](uint32_t node, int j) -> int {
-        const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
-        if (WIDE)
-            return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * (2 * C) + 2 * r + 1] >> (16 * s)) & 0x3FFu);
-        return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * C + r] >> (16 + 8 * s)) & 0xFFu);
-    };
-
     Emitter em;
     em.cap = pg_ops_cap(WIDE ? PG_VAR_WIDE + C * (GL / 16) : C);
     em.slot = (uint32_t*)(a.workspace_rw + a.items[2 * pair + 1].trace_off) + grp * em.cap;  // [4 reads][pg_ops_cap]
@@ -259,9 +271,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     em.overflow = false;
     em.node_has_ops = false;
 
-    uint32_t n = (uint32_t)fs.max_node;
-    int i = fs.ref_end;
+    // The fill leaves the end cell as (graph column, first row of the fill lane that holds it): the node-local column follows
+    // from the node, the row = the first of that lane's C rows holding the score in that column (gssw's read_end1, the
+    // smallest read index in the column: lanes are ordered by the key, rows here) -- one round of loads for the row's lanes.
+    PgNode nd = nodes[n];
+    int i = fs.end_col - (int)nd.col_start;
     int j = fs.read_end;
+    {
+        const bool at_end = i == (int)nd.len - 1;
+        uint32_t hit = 0u;  // bit r: row j + r holds the score
+#pragma unroll
+        for (int base = 0; base < C; base += 16)
+        {
+            const int r = base + (int)k;
+            bool eq = false;
+            if (r < C)
+            {
+                const int h = Hcell((uint32_t)fs.end_col, j + r, at_end);
+                eq = WIDE ? ((uint32_t)(h ^ fs.score) & 0xFFu) == 0u : h == fs.score;
+            }
+            hit |= row_ballot(eq) << base;
+        }
+        if (hit)
+            j += (int)__builtin_ctz(hit);
+    }
     int sc = fs.score;
     bool inE = false, inF = false;
     bool skip_probe = false;
@@ -275,7 +308,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
     for (int guard = 0; guard < 0x7fffffff; ++guard)
     {
-        const PgNode nd = nodes[n];
         const uint32_t c0 = nd.col_start;
         // ---- within-node traceback (gssw.c:1214-1808) ---------------------------------------------
         while (sc > 0 && i >= 0 && j >= 0)
@@ -284,7 +316,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             {
                 if (i == 0)
                     break;
-                const int hup = Hcell(c0 + i - 1, j);
+                const int hup = Hcell(c0 + i - 1, j, false);
                 em.emit(n, PG_OPC_D, 1);
                 --i;
                 if (same(sc, hup - PG_GAP_OPEN))
@@ -303,7 +335,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     status = 2;
                     break;
                 }
-                const int hl = Hcell(c0 + i, j - 1);
+                const int hl = Hcell(c0 + i, j - 1, i == (int)nd.len - 1);
                 em.emit(n, PG_OPC_I, 1);
                 --j;
                 if (same(sc, hl - PG_GAP_OPEN))
@@ -318,55 +350,83 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             if (i > 0 && j > 0 && !skip_probe)
             {
                 // ---- diagonal run, 16 cells per round: lane d looks at cell (i - d, j - d) -----------------------------
-                const int ii = i - (int)k, jj = j - (int)k;
-                const bool valid = ii > 0 && jj > 0;
-                int hd = 0, subd = 0;
-                uint32_t opd = PG_OPC_M;
-                if (valid)
+                // The loads of PG_TRACE_BURST rounds go out together (a round's addresses do not depend on the round before it,
+                // only on its being a full run): under the next chunk's fill a dependent load takes microseconds, and the walk is
+                // a chain of them.  A round after a broken run is never looked at; its loads are the price.
+                int hdv[PG_TRACE_BURST];
+                uint32_t rcv[PG_TRACE_BURST], qcv[PG_TRACE_BURST];
+#pragma unroll
+                for (int rd = 0; rd < PG_TRACE_BURST; ++rd)
                 {
-                    hd = Hcell(c0 + ii - 1, jj - 1);
-                    const uint32_t rc = (uint8_t)refc[c0 + ii];
-                    const uint32_t qc = qchar(jj);
-                    subd = sub_score(nt_code(rc), nt_code(qc));
-                    opd = (rc == 'N' || qc == 'N') ? PG_OPC_N : (rc == qc ? PG_OPC_M : PG_OPC_X);
-                }
-                // the score the walk holds when it arrives at depth d: H of depth d - 1 (byte variants), or the exact score minus
-                // the substitution scores of the depths before (wide variants, where H is known modulo 256 only)
-                int cur;
-                int sub_before = 0;
-                if (WIDE)
-                {
-                    sub_before = row_scan(subd) - subd;
-                    cur = sc - sub_before;
-                }
-                else
-                {
-                    const int above = (int)row_get((uint32_t)hd, k == 0u ? 0u : k - 1u);
-                    cur = k == 0u ? sc : above;
-                }
-                const bool ok = valid && cur > 0 && same(cur, hd + subd);
-                const uint32_t fail = ~row_ballot(ok) & 0xFFFFu;
-                const uint32_t run = fail ? (uint32_t)__builtin_ctz(fail) : 16u;
-                if (run > 0u)
-                {
-                    const uint32_t prev_op = row_get(opd, k == 0u ? 0u : k - 1u);
-                    uint32_t starts = row_ballot(k < run && (k == 0u || opd != prev_op));
-                    while (starts)
+                    const int ii = i - (int)k - 16 * rd, jj = j - (int)k - 16 * rd;
+                    hdv[rd] = 0;
+                    rcv[rd] = 0;
+                    qcv[rd] = 0;
+                    if (ii > 0 && jj > 0)
                     {
-                        const uint32_t s0 = (uint32_t)__builtin_ctz(starts);
-                        starts &= starts - 1u;
-                        const uint32_t s1 = starts ? (uint32_t)__builtin_ctz(starts) : run;
-                        em.emit(n, row_get(opd, s0), s1 - s0);
+                        hdv[rd] = Hcell(c0 + ii - 1, jj - 1, false);
+                        rcv[rd] = (uint8_t)refc[c0 + ii];
+                        qcv[rd] = qchar(jj);
                     }
-                    if (WIDE)
-                        sc -= (int)row_get((uint32_t)(sub_before + subd), run - 1u);
-                    else
-                        sc = (int)row_get((uint32_t)hd, run - 1u);
-                    i -= (int)run;
-                    j -= (int)run;
                 }
-                skip_probe = run < 16u;  // the cell the run stopped at is handled by the scalar logic below
-                if (run > 0u)
+                bool progressed = false;
+#pragma unroll
+                for (int rd = 0; rd < PG_TRACE_BURST; ++rd)
+                {
+                    if (rd > 0 && !(sc > 0 && i > 0 && j > 0))
+                        break;  // what the loop head would decide after a full run
+                    const int ii = i - (int)k, jj = j - (int)k;
+                    const bool valid = ii > 0 && jj > 0;
+                    const int hd = hdv[rd];
+                    int subd = 0;
+                    uint32_t opd = PG_OPC_M;
+                    if (valid)
+                    {
+                        const uint32_t rc = rcv[rd], qc = qcv[rd];
+                        subd = sub_score(nt_code(rc), nt_code(qc));
+                        opd = (rc == 'N' || qc == 'N') ? PG_OPC_N : (rc == qc ? PG_OPC_M : PG_OPC_X);
+                    }
+                    // the score the walk holds when it arrives at depth d: H of depth d - 1 (byte variants), or the exact score
+                    // minus the substitution scores of the depths before (wide variants, where H is known modulo 256 only)
+                    int cur;
+                    int sub_before = 0;
+                    if (WIDE)
+                    {
+                        sub_before = row_scan(subd) - subd;
+                        cur = sc - sub_before;
+                    }
+                    else
+                    {
+                        const int above = (int)row_get((uint32_t)hd, k == 0u ? 0u : k - 1u);
+                        cur = k == 0u ? sc : above;
+                    }
+                    const bool ok = valid && cur > 0 && same(cur, hd + subd);
+                    const uint32_t fail = ~row_ballot(ok) & 0xFFFFu;
+                    const uint32_t run = fail ? (uint32_t)__builtin_ctz(fail) : 16u;
+                    if (run > 0u)
+                    {
+                        const uint32_t prev_op = row_get(opd, k == 0u ? 0u : k - 1u);
+                        uint32_t starts = row_ballot(k < run && (k == 0u || opd != prev_op));
+                        while (starts)
+                        {
+                            const uint32_t s0 = (uint32_t)__builtin_ctz(starts);
+                            starts &= starts - 1u;
+                            const uint32_t s1 = starts ? (uint32_t)__builtin_ctz(starts) : run;
+                            em.emit(n, row_get(opd, s0), s1 - s0);
+                        }
+                        if (WIDE)
+                            sc -= (int)row_get((uint32_t)(sub_before + subd), run - 1u);
+                        else
+                            sc = (int)row_get((uint32_t)hd, run - 1u);
+                        i -= (int)run;
+                        j -= (int)run;
+                        progressed = true;
+                    }
+                    skip_probe = run < 16u;  // the cell the run stopped at is handled by the scalar logic below
+                    if (run < 16u)
+                        break;
+                }
+                if (progressed)
                     continue;
             }
             skip_probe = false;
@@ -375,7 +435,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             const int sub = sub_score(nt_code(rch), nt_code(qch));
             if (i > 0 && j > 0)
             {
-                if (same(sc, Hcell(c0 + i - 1, j - 1) + sub))
+                if (same(sc, Hcell(c0 + i - 1, j - 1, false) + sub))
                 {
                     const uint32_t op = (rch == 'N' || qch == 'N') ? PG_OPC_N : (rch == qch ? PG_OPC_M : PG_OPC_X);
                     em.emit(n, op, 1);
@@ -415,7 +475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     const bool in = kk <= lim;
                     int h = 0;
                     if (in)
-                        h = Hcell(c0 + i, j - kk);
+                        h = Hcell(c0 + i, j - kk, i == (int)nd.len - 1);
                     if (WIDE)
                     {
                         // exact values along the column: add up the signed differences of neighbouring bytes
@@ -526,7 +586,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             em.emit(n, PG_OPC_EMPTY, 0);
         em.node_has_ops = false;
         n = (uint32_t)best_prev;
-        i = (int)nodes[n].len - 1;
+        nd = nodes[n];
+        i = (int)nd.len - 1;
         if (sc <= 0)
             break;  // gssw.c:2778: the loop ends before the predecessor is visited
     }
@@ -551,9 +612,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         a.results[ridx] = res;
 }
 
+// One wavefront per workgroup, walking work-item pairs blockIdx.x, blockIdx.x + gridDim.x, ...: the launcher bounds the number
+// of wavefronts in flight (pg_trace_blocks below).
+template <int C, bool WIDE, int GL = PG_GROUP_LANES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_TRACE_WPE, PG_TRACE_WPE))) void pg_trace_kernel(PgTraceArgs a)
+{
+    for (uint32_t p = blockIdx.x; p < a.n_pairs; p += gridDim.x)
+        pg_trace_pair<C, WIDE, GL>(a, a.pair_begin + p);
+}
+
+// Wavefronts of one traceback launch.  The walk is a chain of dependent loads that each pull a whole 128-byte line for a few
+// bytes (profiles/r03_sector_probe.json), and it runs under the next chunk's fill, which writes 3.5 TB/s the whole time.
+// Measured with stand-in kernels in the walk's place (profiles/r03_trace_tax.md): wavefronts that only sit beside the fill
+// cost it nothing; dependent random-line reads cost it in proportion to their bytes, and more when they come as a burst
+// (one wavefront per pair = some 5 000 in flight for a millisecond) than when the same bytes are spread out.  Two per SIMD is
+// also what fits beside the fill's four wavefronts per SIMD without taking registers from them (PG_TRACE_BLOCKS overrides;
+// 0 = one per pair).
+static uint32_t pg_trace_blocks(uint32_t n_pairs)
+{
+    static const long cap = [] {
+        const char* e = getenv("PG_TRACE_BLOCKS");
+        if (e)
+            return atol(e);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess)
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return 8L * cus;
+    }();
+    return cap > 0 && (uint32_t)cap < n_pairs ? (uint32_t)cap : n_pairs;
+}
+
 template <int C, bool WIDE, int GL = PG_GROUP_LANES> static hipError_t launch_trace_c(const PgTraceArgs& args, hipStream_t stream)
 {
-    hipLaunchKernelGGL((pg_trace_kernel<C, WIDE, GL>), dim3(args.n_pairs), dim3(64), 0, stream, args);
+    hipLaunchKernelGGL((pg_trace_kernel<C, WIDE, GL>), dim3(pg_trace_blocks(args.n_pairs)), dim3(64), 0, stream, args);
     return hipGetLastError();
 }
 

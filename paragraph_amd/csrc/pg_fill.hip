@@ -97,7 +97,8 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // wide variants from C = 20 on would fall to one wavefront per SIMD with the prefetch registers; they fetch the rows at
     // the start of the step instead.
     constexpr bool PREFETCH = WIDE ? C <= 16 : true;
-    constexpr bool SEEDCACHE = !WIDE;
+    constexpr bool SEEDCACHE = !WIDE || (GL == 32 && C <= 14);   // (16 rows x 32 lanes: 174 registers, two wavefronts per SIMD)
+    constexpr bool SEEDCACHE2 = SEEDCACHE && (WIDE ? C <= 8 : C <= 12);
     constexpr int TRACE_DW = C / 2;             // dwords of H trace per lane per step: one byte per cell, two strands
     constexpr int SEED_DW = WIDE ? 2 * C : C;   // dwords of seed per lane per node
     constexpr int ROWS = GL * C;
@@ -215,17 +216,20 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // every step), anything not above score 0 for F.  row_shr:1 never writes lane 0 of a row, so that lane keeps these while
     // the other lanes receive their neighbour's values every step.
     uint32_t dHin = BIAS2 + (PG_TAU0 - 3) * ONE2, Fin = BIAS2;
-    // one-entry seed cache (byte variants): the seed this lane stored last stays in registers, so the usual bubble
-    // (LF -> {ALT, RF}: RF's far predecessor is LF) needs no memory round trip -- a load there stalls the whole wavefront
-    uint32_t cseed[SEEDCACHE ? C : 1];
+    // Seed cache: seeds this lane stored for successors that are not its neighbours in the layout stay in registers (SEED_DW
+    // dwords each: entry A the last one of an even node, entry B -- where the registers allow it -- that of an odd node; with
+    // one entry, A takes every node).  A seed that has to be LOADED at a node's first column stops the wavefront for a memory
+    // round trip (behind all of its outstanding trace stores: one counter, in order) at every one of the GL steps in which a
+    // lane of the read reaches that column: a tenth of the whole fill on the left flank -> allele -> right flank graphs of
+    // single events, whose right flank wants the left flank's seed (and a swap's second allele / right flank likewise).  The
+    // wide variants with 32 lanes per read are held to 10-13 wavefronts per CU by their LDS profile, not by registers: they
+    // can afford the entries too.
+    // (byte variants: one dword per row, bytes H_A, H_B, Enext_A, Enext_B; wide variants: H and Enext dwords in arrays of their own)
+    constexpr int CACHE_N = SEEDCACHE ? C : 1, CACHE_NE = SEEDCACHE && WIDE ? C : 1;
+    constexpr int CACHE_NB = SEEDCACHE2 ? C : 1, CACHE_NEB = SEEDCACHE2 && WIDE ? C : 1;
+    uint32_t cseed[CACHE_N], cseedE[CACHE_NE];
     uint32_t cnode = 0xFFFFFFFFu;
-    // ... and a second entry where the registers allow it: entry A holds the last seed of an even node, entry B that of an odd
-    // one.  A seed that has to be LOADED at a node's first column stops the wavefront for a memory round trip behind all of its
-    // outstanding trace stores (one counter, in order) -- at every one of the 16 steps in which a lane of the read reaches that
-    // column: a tenth of the whole fill on the left flank -> allele -> right flank graphs of single events, whose right flank
-    // wants the left flank's seed after the allele's has been stored (and a swap's second allele / right flank likewise).
-    constexpr bool SEEDCACHE2 = SEEDCACHE && C <= 12;
-    uint32_t cseedB[SEEDCACHE ? C : 1];
+    uint32_t cseedB[CACHE_NB], cseedEB[CACHE_NEB];
     uint32_t cnodeB = 0xFFFFFFFFu;
     uint32_t M = BIAS2 + (PG_TAU0 - 1) * ONE2, FC = 0;  // node maximum (frame of the previous step) / step that first reached it
     uint32_t FR = 0;  // WIDE: smallest row (within the lane) holding the lane's maximum in column FC, per strand
@@ -377,37 +381,67 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 E[r] = BIAS2 + eshift;
             }
         }
-        if (!WIDE && !(meta_cur & PG_META_PRED_MANY))
+        if (!(meta_cur & PG_META_PRED_MANY))
         {
             // predecessor summary in the meta word: no table loads
             if (meta_cur & PG_META_PRED_ONE)
             {
                 const uint32_t pid = (meta_cur >> PG_META_PRED_SHIFT) & 0x7Fu;
-                // bytes (H_A, H_B, Enext_A, Enext_B) -> (0x6400 | H_A, 0x6400 | H_B) (the 0x64 bytes come from the constant),
-                // then into the frame with an integer addition on the bit patterns.  Each source has its own copy of this: the
-                // wait for a LOADED seed (all outstanding trace stores drain before it, one in-order counter) must not sit behind
-                // the join where the cached ones would pay it too.
-                auto take = [&](const uint32_t (&w)[SEEDCACHE ? C : 1]) __attribute__((always_inline)) {
+                // byte variants: bytes (H_A, H_B, Enext_A, Enext_B) -> (0x6400 | H_A, 0x6400 | H_B) (the 0x64 bytes come from the
+                // constant); wide variants: dwords (H_A | H_B << 16), (Enext_A | Enext_B << 16), each field = 0x6400 | score; then
+                // into the frame with an integer addition on the bit patterns.  Each source has its own copy of this: the wait
+                // for a LOADED seed must not sit behind the join where the cached ones would pay it too.
+                if (SEEDCACHE && pid == cnode)
+                {
 #pragma unroll
                     for (int r = 0; r < C; ++r)
                     {
-                        pk_maxu_into(Hin[r], pk_add(__builtin_amdgcn_perm(BIAS2, w[SEEDCACHE ? r : 0], 0x07010500u), hshift));
-                        E[r] = pk_maxu(E[r], pk_add(__builtin_amdgcn_perm(BIAS2, w[SEEDCACHE ? r : 0], 0x07030502u), eshift));
+                        if constexpr (WIDE)
+                        {
+                            pk_maxu_into(Hin[r], pk_add(cseed[SEEDCACHE ? r : 0], hshift));
+                            E[r] = pk_maxu(E[r], pk_add(cseedE[SEEDCACHE ? r : 0], eshift));
+                        }
+                        else
+                        {
+                            pk_maxu_into(Hin[r], pk_add(__builtin_amdgcn_perm(BIAS2, cseed[SEEDCACHE ? r : 0], 0x07010500u), hshift));
+                            E[r] = pk_maxu(E[r], pk_add(__builtin_amdgcn_perm(BIAS2, cseed[SEEDCACHE ? r : 0], 0x07030502u), eshift));
+                        }
                     }
-                };
-                if (SEEDCACHE && pid == cnode)
-                    take(cseed);
+                }
                 else if (SEEDCACHE2 && pid == cnodeB)
-                    take(cseedB);
+                {
+#pragma unroll
+                    for (int r = 0; r < C; ++r)
+                    {
+                        if constexpr (WIDE)
+                        {
+                            pk_maxu_into(Hin[r], pk_add(cseedB[SEEDCACHE2 ? r : 0], hshift));
+                            E[r] = pk_maxu(E[r], pk_add(cseedEB[SEEDCACHE2 ? r : 0], eshift));
+                        }
+                        else
+                        {
+                            pk_maxu_into(Hin[r], pk_add(__builtin_amdgcn_perm(BIAS2, cseedB[SEEDCACHE2 ? r : 0], 0x07010500u), hshift));
+                            E[r] = pk_maxu(E[r], pk_add(__builtin_amdgcn_perm(BIAS2, cseedB[SEEDCACHE2 ? r : 0], 0x07030502u), eshift));
+                        }
+                    }
+                }
                 else
                 {
                     const uint32_t* sp = seed + ((size_t)pid * 64 + lane) * SEED_DW;
 #pragma unroll
                     for (int r = 0; r < C; ++r)
                     {
-                        const uint32_t w = sp[r];
-                        pk_maxu_into(Hin[r], pk_add(__builtin_amdgcn_perm(BIAS2, w, 0x07010500u), hshift));
-                        E[r] = pk_maxu(E[r], pk_add(__builtin_amdgcn_perm(BIAS2, w, 0x07030502u), eshift));
+                        if constexpr (WIDE)
+                        {
+                            pk_maxu_into(Hin[r], pk_add(sp[2 * r], hshift));
+                            E[r] = pk_maxu(E[r], pk_add(sp[2 * r + 1], eshift));
+                        }
+                        else
+                        {
+                            const uint32_t w = sp[r];
+                            pk_maxu_into(Hin[r], pk_add(__builtin_amdgcn_perm(BIAS2, w, 0x07010500u), hshift));
+                            E[r] = pk_maxu(E[r], pk_add(__builtin_amdgcn_perm(BIAS2, w, 0x07030502u), eshift));
+                        }
                     }
                 }
             }
@@ -450,39 +484,42 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         {
             uint32_t* sp = seed + ((size_t)node * 64 + lane) * SEED_DW;
             const uint32_t hshift = tau * ONE2, eshift = (tau + 1u) * ONE2;
+            // only a seed that a far successor will want goes into the cache (SAVE; a forward-graph node without one is stored for
+            // the traceback alone)
+            const bool keep = SEEDCACHE && (meta_cur & PG_META_SAVE) != 0u;
+            const bool toB = keep && SEEDCACHE2 && (node & 1u) != 0u, toA = keep && !toB;
 #pragma unroll
             for (int r = 0; r < C; ++r)
             {
                 const uint32_t hs = pk_sub(Hout[r], hshift), es = pk_sub(E[r], eshift);  // 0x6400 | score
-                if (WIDE)
+                if constexpr (WIDE)
                 {
                     sp[2 * r] = hs;
                     sp[2 * r + 1] = es;
+                    // (selects on the values, not branches around the stores: the arrays must stay in registers)
+                    if constexpr (SEEDCACHE2)
+                    {
+                        cseedB[r] = toB ? hs : cseedB[r];
+                        cseedEB[r] = toB ? es : cseedEB[r];
+                    }
+                    if constexpr (SEEDCACHE)
+                    {
+                        cseed[r] = toA ? hs : cseed[r];
+                        cseedE[r] = toA ? es : cseedE[r];
+                    }
                 }
                 else
                 {
                     const uint32_t w = __builtin_amdgcn_perm(es, hs, 0x06040200u);
                     sp[r] = w;
-                    if (SEEDCACHE2)
-                    {
-                        if (node & 1u)
-                            cseedB[r] = w;
-                        else
-                            cseed[r] = w;
-                    }
-                    else if (SEEDCACHE)
-                        cseed[r] = w;
+                    if constexpr (SEEDCACHE2)
+                        cseedB[r] = toB ? w : cseedB[r];
+                    if constexpr (SEEDCACHE)
+                        cseed[r] = toA ? w : cseed[r];
                 }
             }
-            if (SEEDCACHE2)
-            {
-                if (node & 1u)
-                    cnodeB = node;
-                else
-                    cnode = node;
-            }
-            else if (SEEDCACHE)
-                cnode = node;
+            cnodeB = toB ? node : cnodeB;
+            cnode = toA ? node : cnode;
         }
         // key: max (12 bits) | inverted column (16 bits; a direction has <= 65519 columns) | inverted lane (4 bits)
         const uint32_t kinv = (uint32_t)(15 - k);

@@ -836,7 +836,7 @@ Json alignmentStatistics(Graph const& graph, SiteReadViews const& views)
         Json entry = kv.second.toJson();
         const int n = kv.second.fwd + kv.second.rev;
         entry["avr_score"] = n == 0 ? 0.0 : (double)allele_score[kv.first] / n;
-        out["alleles"][kv.first] = entry;
+        out["alleles"][kv.first] = std::move(entry);
     }
     return out;
 }

@@ -295,7 +295,7 @@ Json countDocument(
             total["total:READS"] = kv.second.reads;
             total["total:FWD"] = kv.second.fwd;
             total["total:REV"] = kv.second.rev;
-            families[kv.first] = total;
+            families[kv.first] = std::move(total);
         }
         if (parameters.output_enabled(Parameters::DETAILED_READ_COUNTS))
         {
@@ -304,7 +304,7 @@ Json countDocument(
             else
                 addDetailedCounts(families, *d.graph, views);
         }
-        out["read_counts_by_sequence"] = families;
+        out["read_counts_by_sequence"] = std::move(families);
     }
     Json stats = alignmentStatistics(*d.graph, views);
     // the filter tallies only exist when filtered alignments are asked for (Disambiguation.cpp:177-199, 333-346)
@@ -314,13 +314,13 @@ Json countDocument(
         stats["read_filter_bad_align"] = counts.bad_align;
     if (tally && counts.nonuniq)
         stats["read_filter_nonuniq"] = counts.nonuniq;
-    out["alignment_statistics"] = stats;
+    out["alignment_statistics"] = std::move(stats);
     if (reads && parameters.output_enabled(Parameters::ALIGNMENTS))
     {
         Json alignments = Json::array();
         for (auto const& r : *reads)
             alignments.append(r->toJson());
-        out["alignments"] = alignments;
+        out["alignments"] = std::move(alignments);
     }
     return out;
 }
@@ -607,7 +607,7 @@ Json genotypeToJson(genotyping::Genotype const& g, std::vector<std::string> cons
                 name += (j ? "/" : "") + allele_names[g.gl_name[i][j]];
             gl[name] = g.gl[i];
         }
-        out["GL"] = gl;
+        out["GL"] = std::move(gl);
     }
     if (g.gq != -1)
         out["GQ"] = g.gq;
@@ -616,14 +616,14 @@ Json genotypeToJson(genotyping::Genotype const& g, std::vector<std::string> cons
         Json fractions = Json::object();
         for (size_t a = 0; a < g.allele_fractions.size() && a < allele_names.size(); ++a)
             fractions[allele_names[a]] = g.allele_fractions[a];
-        out["allele_fractions"] = fractions;
+        out["allele_fractions"] = std::move(fractions);
     }
     if (!g.filters.empty())
     {
         Json filters = Json::array();
         for (auto const& f : g.filters)
             filters.append(f);
-        out["filters"] = filters;
+        out["filters"] = std::move(filters);
     }
     if (!g.gt.empty())
     {
@@ -701,9 +701,9 @@ Json genotypeDocument(
                     if (canonical != allele)
                         entry["mapped_alleles"][allele] = canonical;
                 }
-                bp_info.append(entry);
+                bp_info.append(std::move(entry));
             }
-            result["breakpointinfo"] = bp_info;
+            result["breakpointinfo"] = std::move(bp_info);
             info["target_regions"] = doc["target_regions"];
             info["sequencenames"] = doc["sequencenames"];
             info["nodes"] = Json::array();
@@ -713,7 +713,7 @@ Json genotypeDocument(
                 node["name"] = n["name"];
                 if (n.isMember("sequences"))
                     node["sequences"] = n["sequences"];
-                info["nodes"].append(node);
+                info["nodes"].append(std::move(node));
             }
             info["edges"] = Json::array();
             for (Json const& e : doc["edges"].elements())
@@ -722,15 +722,15 @@ Json genotypeDocument(
                 edge["name"] = e["from"].asString() + "_" + e["to"].asString();
                 if (e.isMember("sequences"))
                     edge["sequences"] = e["sequences"];
-                info["edges"].append(edge);
+                info["edges"].append(std::move(edge));
             }
-            result["graphinfo"] = info;
+            result["graphinfo"] = std::move(info);
         }
         Json per_sample = counted["alignment_statistics"];
         for (auto const& kv : counted["fragment_statistics"].members())
             if (kv.first != "linear_histogram" && kv.first != "graph_histogram")
                 per_sample[kv.first] = kv.second;
-        result["samples"][sample.sample_name()] = per_sample;
+        result["samples"][sample.sample_name()] = std::move(per_sample);
     }
     genotyper.runGenotyping();
     auto const& allele_names = genotyper.alleleNames();
@@ -753,8 +753,8 @@ Json genotypeDocument(
                 counts["edges"][edge] = genotyper.getCount(i, bp.first, edge);
             for (auto const& allele : bp.second.canonicalAlleleNames())
                 counts["alleles"][allele] = genotyper.getCount(i, bp.first, allele);
-            bj["counts"] = counts;
-            entry["breakpoints"][bp.first] = bj;
+            bj["counts"] = std::move(counts);
+            entry["breakpoints"][bp.first] = std::move(bj);
         }
         entry["gt"] = genotypeToJson(genotyper.getGenotype(name, ""), allele_names);
     }
@@ -764,7 +764,7 @@ Json genotypeDocument(
         for (auto const& kv : by_breakpoint)
             if (!kv.first.empty())
                 pop["breakpoints"][kv.first] = genotyping::PopulationStatistics(kv.second).toJson();
-        result["population"] = pop;
+        result["population"] = std::move(pop);
     }
     return result;
 }

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <map>
 #include <string>
+#include <string_view>
 #include <vector>
 
 namespace common
@@ -13,7 +14,7 @@ class Json
 {
 public:
     enum Kind { NUL, BOOL, INT, UINT, REAL, STRING, ARRAY, OBJECT };
-    typedef std::map<std::string, Json> Members;
+    typedef std::map<std::string, Json, std::less<>> Members;  // (transparent comparison: looked up by string_view, no temporary)
     typedef std::vector<Json> Elements;
 
     // A value is 16 bytes: its kind and either the scalar itself or a pointer to its string / elements / members (a count
@@ -81,15 +82,25 @@ public:
     std::string const& asString() const;
 
     // objects; a null value silently becomes an object (array) on first write, like Json::Value
-    bool isMember(std::string const& key) const { return kind_ == OBJECT && v_.members->count(key) != 0; }
-    Json& operator[](std::string const& key);
-    Json& operator[](const char* key) { return (*this)[std::string(key)]; }
-    Json const& operator[](std::string const& key) const;  // null value when absent
-    Json const& operator[](const char* key) const { return (*this)[std::string(key)]; }
-    void removeMember(std::string const& key)
+    bool isMember(std::string_view key) const { return kind_ == OBJECT && v_.members->find(key) != v_.members->end(); }
+    bool isMember(std::string const& key) const { return isMember(std::string_view(key)); }
+    bool isMember(const char* key) const { return isMember(std::string_view(key)); }
+    Json& member(std::string_view key);              // finds or inserts (one string is built, and only on insertion)
+    Json& member(std::string&& key);                 // ... taking the key's storage on insertion
+    Json const& member(std::string_view key) const;  // null value when absent
+    Json& operator[](std::string const& key) { return member(std::string_view(key)); }
+    Json& operator[](std::string&& key) { return member(std::move(key)); }
+    Json& operator[](const char* key) { return member(std::string_view(key)); }
+    Json const& operator[](std::string const& key) const { return member(std::string_view(key)); }
+    Json const& operator[](const char* key) const { return member(std::string_view(key)); }
+    void removeMember(std::string_view key)
     {
         if (kind_ == OBJECT)
-            v_.members->erase(key);
+        {
+            auto it = v_.members->find(key);
+            if (it != v_.members->end())
+                v_.members->erase(it);
+        }
     }
     Members const& members() const { return kind_ == OBJECT ? *v_.members : noMembers(); }
     std::vector<std::string> getMemberNames() const;

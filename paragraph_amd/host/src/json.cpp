@@ -206,7 +206,7 @@ struct Reader
                 std::string key = string();
                 if (!take(':'))
                     fail("expected ':'");
-                obj[key] = value(depth + 1);
+                obj[std::move(key)] = value(depth + 1);
                 if (take(','))
                     continue;
                 if (take('}'))
@@ -435,7 +435,22 @@ std::string const& Json::asString() const
     return *v_.s;
 }
 
-Json& Json::operator[](std::string const& key)
+Json& Json::member(std::string_view key)
+{
+    if (kind_ == NUL)
+    {
+        kind_ = OBJECT;
+        v_.members = new Members();
+    }
+    if (kind_ != OBJECT)
+        throw std::runtime_error("JSON value is not an object (member " + std::string(key) + ")");
+    auto it = v_.members->lower_bound(key);
+    if (it != v_.members->end() && it->first == key)
+        return it->second;
+    return v_.members->emplace_hint(it, std::string(key), Json())->second;
+}
+
+Json& Json::member(std::string&& key)
 {
     if (kind_ == NUL)
     {
@@ -444,16 +459,19 @@ Json& Json::operator[](std::string const& key)
     }
     if (kind_ != OBJECT)
         throw std::runtime_error("JSON value is not an object (member " + key + ")");
-    return (*v_.members)[key];
+    auto it = v_.members->lower_bound(std::string_view(key));
+    if (it != v_.members->end() && it->first == key)
+        return it->second;
+    return v_.members->emplace_hint(it, std::move(key), Json())->second;
 }
 
-Json const& Json::operator[](std::string const& key) const
+Json const& Json::member(std::string_view key) const
 {
     static const Json null_value;
     if (kind_ == NUL)
         return null_value;
     if (kind_ != OBJECT)
-        throw std::runtime_error("JSON value is not an object (member " + key + ")");
+        throw std::runtime_error("JSON value is not an object (member " + std::string(key) + ")");
     auto it = v_.members->find(key);
     return it == v_.members->end() ? null_value : it->second;
 }

@@ -648,7 +648,9 @@ std::map<std::string, int32_t> edgeCounts(Json const& doc)
 // GraphGenotyper::addAlignment + getGenotypes (lib/genotyping/GraphGenotyper.cpp:88-337)
 Json genotypeDocument(
     graphtools::Graph const& graph, Json const& root, std::string const& genotyping_parameter_path,
-    std::vector<genotyping::SampleInfo const*> const& samples, std::vector<Json const*> const& documents)
+    std::vector<genotyping::SampleInfo const*> const& samples, std::vector<Json const*> const& documents,
+    std::vector<Json*> const* consumed = nullptr /* the same documents, when the caller drops them afterwards: their
+                                                     alignment_statistics are moved into the result instead of copied */)
 {
     std::vector<std::string> regions;
     for (Json const& r : root["target_regions"].elements())
@@ -726,7 +728,7 @@ Json genotypeDocument(
             }
             result["graphinfo"] = std::move(info);
         }
-        Json per_sample = counted["alignment_statistics"];
+        Json per_sample = consumed ? std::move((*(*consumed)[i])["alignment_statistics"]) : Json(counted["alignment_statistics"]);
         for (auto const& kv : counted["fragment_statistics"].members())
             if (kv.first != "linear_histogram" && kv.first != "graph_histogram")
                 per_sample[kv.first] = kv.second;
@@ -997,13 +999,15 @@ std::vector<Json> genotypeGraphs(
                 parallelFor(n_here, lane_threads, [&](size_t g) {
                     std::vector<genotyping::SampleInfo const*> sample_ptrs;
                     std::vector<Json const*> docs;
+                    std::vector<Json*> dropped_after;  // the count documents end with this chunk
                     for (size_t s = 0; s < n_samples; ++s)
                     {
                         sample_ptrs.push_back(&samples[s]);
                         docs.push_back(&documents[g * n_samples + s]);
+                        dropped_after.push_back(&documents[g * n_samples + s]);
                     }
-                    genotypes[g0 + g]
-                        = genotypeDocument(*chunk->graphs[g].graph, chunk->graphs[g].description, genotyping_parameter_path, sample_ptrs, docs);
+                    genotypes[g0 + g] = genotypeDocument(
+                        *chunk->graphs[g].graph, chunk->graphs[g].description, genotyping_parameter_path, sample_ptrs, docs, &dropped_after);
                     for (Json const* doc : docs)  // a graph the device path could not take: genotyped from no counts, and says so
                         if (doc->isMember("error") && !genotypes[g0 + g].isMember("error"))
                             genotypes[g0 + g]["error"] = (*doc)["error"];

@@ -21,11 +21,16 @@
 //   * the query profile of the 8 fills lives in LDS ([read][ref code][row] packed dwords); each step
 //     costs C/2 ds_read_b64 per lane.
 //   * H of every cell of the forward-graph fills is written to HBM as bytes, laid out by pipeline
-//     step so that one step of one wavefront is a single contiguous 64*2C-byte store; the traceback
+//     step so that one step of one wavefront is a single contiguous 64*2C-byte store (a dword holds
+//     diagonal neighbours: the odd row of this step, the even row of the step before); the traceback
 //     kernel re-derives E/F decisions from H (see pg_trace.hip).
 //   * node boundaries: the last column (H, next-column E) of a node is stored once per lane in a
 //     per-wavefront seed region; a node's first column takes the lane-wise max over its predecessors'
-//     seeds (the predecessor that directly precedes it in the layout stays in registers).
+//     seeds (the predecessor that directly precedes it in the layout stays in registers, the seeds a far
+//     successor wants in a two-entry register cache).
+//   * wherever a wavefront waits for memory it pays the latency of a chip that moves 3.5 TB/s of its
+//     own stores (one in-order counter): no load in the step loop on the usual graphs, one round trip
+//     in the tail (profiles/r03_trace_tax.md).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -319,9 +324,9 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             {
                 // The row of the maximum matters in one case only: a node whose final maximum is 251..255 -- the reference's
                 // alignsEndAtMultNodes reads word-mode matrices through a byte pointer and then only sees the first half of the
-                // node's cells (epilogue).  A maximum passes through each of those five values at most once, so the row search
-                // runs a handful of times per node instead of at every growth step.  (The traceback's start row is found from
-                // the H trace in the epilogue, like in the byte variants.)
+                // node's cells (the tail below).  A maximum passes through each of those five values at most once, so the row
+                // search runs a handful of times per node instead of at every growth step.  (The traceback's start row is found
+                // by the traceback kernel from the H trace, like in the byte variants.)
                 // the test itself runs at every step, so it is kept to five packed instructions: score - 251 per strand by one
                 // subtraction of the wave-uniform pattern of 251 in this step's frame, clamped at 5 (anything below the window
                 // wraps around to a large unsigned value and is clamped too), in the window where the result is not 5

@@ -3,11 +3,12 @@
 // trace; the 16 lanes of a read take that latency 16 cells at a time:
 //   * diagonal runs: lane d loads H(i-1-d, j-1-d) and the two characters of depth d, every lane checks its own step
 //     (H(d-1) == H(d) + s(d)), one ballot gives the length of the run, and the run's M / X / N segments are emitted
-//     run-length encoded -- one round of loads per 16 matched bases instead of 16;
+//     run-length encoded -- one round of loads per 16 matched bases instead of 16, the loads of four rounds in flight together;
 //   * the "score == F(i,j)" scan after a failed diagonal: 16 candidate gap lengths per round;
 //   * everything else (gap steps, node boundaries) is the scalar logic, executed redundantly by the row's lanes (the same
 //     address in every lane: one transaction).
-// CIGAR elements are collected in LDS (written by the row's first lane) and copied out by all 16.
+// CIGAR elements are collected in a scratch slot of the workspace (written by the row's first lane) and copied out by all 16.
+// The fill hands over the end cell as (graph column, lane); its row is found here (one round of loads).
 //
 // Replaces
 //   GraphAligner::alignRead strand/uniqueness logic     src/c++/lib/grm/GraphAligner.cpp:340-401
@@ -136,9 +137,9 @@ struct Emitter
 // reads 0-1 / 2-3, each with its own half of the item's trace and seed regions); this kernel walks with 16 lanes per read either way
 template <int C, bool WIDE, int GL> __device__ __forceinline__ void pg_trace_pair(const PgTraceArgs& a, const uint32_t pair)
 {
-    // No LDS and at most 64 VGPRs: this kernel runs on the second stream UNDER the next chunk's fill, whose 16 wavefronts per CU
-    // take all 160 KB of LDS and 448 of the 512 VGPRs of a SIMD lane -- a traceback wavefront that needs neither takes the
-    // place of no fill wavefront (with 3 KB of LDS and 80 VGPRs it cost the fill 10 % of its time).
+    // No LDS and 80 VGPRs: this kernel runs on the second stream UNDER the next chunk's fill, whose 16 wavefronts per CU take
+    // all 160 KB of LDS and four times 114 of the 512 VGPRs of a SIMD lane -- two traceback wavefronts per SIMD fit beside them
+    // (pg_trace_blocks) and take the place of no fill wavefront.
     const uint32_t lane = threadIdx.x;
     const uint32_t grp = lane >> 4;  // the read of this 16-lane row
     const uint32_t k = lane & 15u;

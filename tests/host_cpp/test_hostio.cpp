@@ -91,6 +91,29 @@ static void testJson()
     CHECK_THROWS(Json::parse("\"abc"));
     CHECK_THROWS(v["b"].asString());
     CHECK_THROWS(Json::parseFile("/nonexistent/file.json"));
+    // members: found without building a key, inserted with the key's own storage when it is handed over; a reference to a member
+    // stays good while other members are added (documents are built that way)
+    {
+        Json o;
+        Json& first = o["a_key_that_is_longer_than_the_small_string_buffer"];
+        first = 1;
+        std::string key = "another_key_that_is_longer_than_the_small_string_buffer";
+        const char* storage = key.data();
+        Json& second = o[std::move(key)];
+        second = 2;
+        CHECK(o.members().find("another_key_that_is_longer_than_the_small_string_buffer")->first.data() == storage);
+        for (int i = 0; i < 100; ++i)
+            o["k" + std::to_string(i)] = i;
+        CHECK(first == Json(1) && second == Json(2) && o.size() == 102);
+        CHECK(o.isMember("k42") && o.isMember(std::string("k42")) && !o.isMember("k420"));
+        CHECK(o["k42"] == Json(42) && static_cast<Json const&>(o)["missing"].isNull() && o.size() == 102);
+        o.removeMember("k42");
+        o.removeMember("not there");
+        CHECK(!o.isMember("k42") && o.size() == 101);
+        Json moved = std::move(o["k7"]);
+        CHECK(moved == Json(7) && o["k7"].isNull());
+        CHECK_THROWS(Json(3)["x"]);
+    }
 }
 
 static void testCoordinates()

@@ -242,3 +242,21 @@ def test_documented_limits_fail_loudly(gpu_ctx):
     assert res[0]["status"] & 0xFF in (0, 1)
     b.close()
     G.close()
+
+
+@pytest.mark.parametrize("env", [{"PG_TRACE_BLOCKS": "0"}, {"PG_TRACE_BLOCKS": "7"}, {"PG_WIDE16": "1"}])
+def test_launch_settings_do_not_change_results(env):
+    """The traceback walks its work-item pairs in a grid-stride loop of a bounded number of wavefronts (PG_TRACE_BLOCKS; 0 = one
+    wavefront per pair), and PG_WIDE16 selects the 16-lane kernels for reads of 251-512 bases: the settings are read once per
+    process, so each one gets a process of its own running the read-length, word-mode and fuzz tests of this file."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-p", "no:cacheprovider", "-k",
+                        "fuzz_many_graphs or fuzz_word_mode_reads or length_boundaries or many_tiny_nodes"],
+                       cwd=root, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

@@ -10,6 +10,10 @@
 #include <sstream>
 #include <stdexcept>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 namespace common
 {
 namespace
@@ -299,12 +303,32 @@ Json Json::parse(std::string const& text)
 
 Json Json::parseFile(std::string const& path)
 {
-    std::ifstream in(path, std::ios::binary);
-    if (!in.good())
+    // open / fstat / read: a graph description is a few KB and the many-site workflow reads one per site -- a stream object with
+    // its locale and buffer, and a second copy through a string stream, cost as much as parsing it
+    const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0)
         throw std::runtime_error("Cannot open JSON file " + path);
-    std::stringstream ss;
-    ss << in.rdbuf();
-    return parse(ss.str());
+    std::string text;
+    struct stat st;
+    if (::fstat(fd, &st) == 0 && st.st_size > 0)
+        text.reserve((size_t)st.st_size);
+    char buffer[16384];
+    for (;;)
+    {
+        const ssize_t n = ::read(fd, buffer, sizeof(buffer));
+        if (n < 0)
+        {
+            if (errno == EINTR)
+                continue;
+            ::close(fd);
+            throw std::runtime_error("Cannot read JSON file " + path);
+        }
+        if (n == 0)
+            break;
+        text.append(buffer, (size_t)n);
+    }
+    ::close(fd);
+    return parse(text);
 }
 
 Json::Json(Json const& o) : kind_(o.kind_), v_(o.v_)

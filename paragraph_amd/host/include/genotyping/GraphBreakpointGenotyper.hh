@@ -39,6 +39,8 @@ public:
     std::vector<std::string> const& alleleNames() const { return allelenames; }
     std::vector<std::string> const& sampleNames() const { return samplenames; }
     std::list<std::string> const& breakpointNames() const { return breakpointnames; }
+    // the graph's breakpoints without counts, as reset() built them (every sample starts from a copy)
+    BreakpointMap const& breakpointsOfGraph() const { return breakpoints_of_graph_; }
 
 private:
     unsigned int samplePloidy(size_t sample_index) const;
@@ -46,6 +48,7 @@ private:
     const graphtools::Graph* graph = nullptr;
     std::vector<std::string> allelenames, samplenames;
     std::list<std::string> breakpointnames;
+    BreakpointMap breakpoints_of_graph_;
     std::vector<BreakpointMap> breakpoint_maps;
     std::vector<std::pair<double, int>> depths;
     std::vector<double> depth_sds;

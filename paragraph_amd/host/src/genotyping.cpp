@@ -654,7 +654,10 @@ void GraphBreakpointGenotyper::reset(graphtools::Graph const* g)
     depth_sds.clear();
     sexes.clear();
     graph_genotypes.clear();
-    const auto bp_map = createBreakpointMap(*graph);
+    // built once per graph: a sample's map is a copy of it (the reference walks the graph again for every sample,
+    // GraphBreakpointGenotyper.cpp:62-75 -- the result is the same map)
+    breakpoints_of_graph_ = createBreakpointMap(*graph);
+    BreakpointMap const& bp_map = breakpoints_of_graph_;
     std::set<string> allele_names;
     for (const auto& bp : bp_map)
     {
@@ -674,7 +677,7 @@ void GraphBreakpointGenotyper::addSample(
     if (!graph)
         error("GraphBreakpointGenotyper::reset has not been called");
     samplenames.push_back(sample_name);
-    breakpoint_maps.push_back(createBreakpointMap(*graph));
+    breakpoint_maps.push_back(breakpoints_of_graph_);
     for (auto& breakpoint : breakpoint_maps.back())
         breakpoint.second.addCounts(read_counts_by_edge);
     depths.emplace_back(autosome_depth, read_length);

@@ -662,7 +662,7 @@ Json genotypeDocument(
         genotyper.parameters().setFromJson(Json::parseFile(genotyping_parameter_path));
 
     Json result = Json::object();
-    const genotyping::BreakpointMap breakpoints = genotyping::createBreakpointMap(graph);
+    genotyping::BreakpointMap const& breakpoints = genotyper.breakpointsOfGraph();
     for (size_t i = 0; i < samples.size(); ++i)
     {
         genotyping::SampleInfo const& sample = *samples[i];

@@ -825,7 +825,7 @@ static void testInflate()
                 std::vector<unsigned char> out(n + 16, 0xCD);
                 const int rc = pginflate::inflateBlock(comp.data(), clen, out.data(), n);
                 CHECK(rc == pginflate::kOk);
-                CHECK(memcmp(out.data(), text.data(), n) == 0);
+                CHECK(n == 0 || memcmp(out.data(), text.data(), n) == 0);
                 ++streams;
                 if (n == 0)
                     continue;

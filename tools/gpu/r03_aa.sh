@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 3, call AA: second seed cache entry -- parity, then fill time against the library before it
+# (tools/variants/lib_*.so are other builds of the same sources made beforehand with tools/build_variant.sh <commit|WORK> <name> [-D...];
+#  they are not tracked -- the script records what was compared, profiles/r03_trace_tax.md the outcome)
 R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
 O=$R/gpurun_out/r03_aa; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -3

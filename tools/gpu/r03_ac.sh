@@ -1,8 +1,8 @@
 #!/bin/bash
 # round 3, call AC: skewed trace layout of the byte variants (four path cells per 128-byte line) -- parity, kernel stats A/B against the
+# commit before it, fetched bytes of the traceback
 # (tools/variants/lib_*.so are other builds of the same sources made beforehand with tools/build_variant.sh <commit|WORK> <name> [-D...];
 #  they are not tracked -- the script records what was compared, profiles/r03_trace_tax.md the outcome)
-# commit before it, fetched bytes of the traceback
 R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
 O=$R/gpurun_out/r03_ac; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_general.py tests/test_gpu_counts.py -m gpu -q -x 2>&1 | tail -3

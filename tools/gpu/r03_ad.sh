@@ -1,8 +1,8 @@
 #!/bin/bash
 # round 3, call AD: seed cache + predecessor summary for the wide variants -- parity (all GPU tests of the fill), read-length probe
+# A/B against the commit before (tools/variants/lib_head.so), headline check
 # (tools/variants/lib_*.so are other builds of the same sources made beforehand with tools/build_variant.sh <commit|WORK> <name> [-D...];
 #  they are not tracked -- the script records what was compared, profiles/r03_trace_tax.md the outcome)
-# A/B against the commit before (tools/variants/lib_head.so), headline check
 R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
 O=$R/gpurun_out/r03_ad; mkdir -p $O
 timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_general.py tests/test_gpu_counts.py -m gpu -q -x 2>&1 | tail -3

@@ -1,8 +1,8 @@
 #!/bin/bash
 # round 3, call AG: column meta words 2 / 4 / 8 steps ahead on the 10 000-site set (every wavefront another graph: its meta words
+# come from HBM, not from a cache the other wavefronts keep warm)
 # (tools/variants/lib_*.so are other builds of the same sources made beforehand with tools/build_variant.sh <commit|WORK> <name> [-D...];
 #  they are not tracked -- the script records what was compared, profiles/r03_trace_tax.md the outcome)
-# come from HBM, not from a cache the other wavefronts keep warm)
 R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
 O=$R/gpurun_out/r03_ag; mkdir -p $O
 for V in tree fa4 fa8 tree fa4 fa8; do

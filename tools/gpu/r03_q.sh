@@ -1,8 +1,8 @@
 #!/bin/bash
 # round 3, call Q: traceback variants (register budget x rounds of diagonal loads in flight) x wavefronts in flight: parity, then
+# kernel stats of the headline loop
 # (tools/variants/lib_*.so are other builds of the same sources made beforehand with tools/build_variant.sh <commit|WORK> <name> [-D...];
 #  they are not tracked -- the script records what was compared, profiles/r03_trace_tax.md the outcome)
-# kernel stats of the headline loop
 R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
 O=$R/gpurun_out/r03_q; mkdir -p $O
 for V in w8b4 w6b4 w5b4; do

@@ -50,8 +50,9 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s pe
 # integer 1024 + score + frame (every integer below 2048 is exact in f16), i.e. integer DP carried by v_pk_*_f16 -- gssw's
 # u8 (reads <= 250 bp) / i16 (251-512 bp) score semantics bit for bit, not a reduced-precision approximation
 DTYPE = "f16x2 packed, exact integers < 2048 (gssw u8 / i16 score semantics)"
-SIMDS, CLOCK_GHZ = 256 * 4, 2.4  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
+SIMDS = 256 * 4  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs (the clock and the cycles per instruction are measured: valu_bound)
 CIGAR_STRIDE = 128
+SITES_CIGAR_STRIDE = 256  # config-3 reads cross insertions of up to 1 000 bases
 
 
 def parse_args():
@@ -78,17 +79,27 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream-batches", type=int, default=16,
                     help="batches of the PCIe-inclusive streaming leg (0 = skip; reported beside the headline value)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_r03.json"),
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_r04.json"),
                     help="PMC-derived HBM bytes per fill launch (written by tools/pmc_traffic.py); used only when the kernel "
                          "sources it was collected on are the ones of this build (kernel_source_sha)")
-    ap.add_argument("--sq-json", default=os.path.join(ROOT, "profiles", "r03_sq_counters.json"),
+    ap.add_argument("--sq-json", default=os.path.join(ROOT, "profiles", "r04_sq_counters.json"),
                     help="SQ counters of one fill launch (tools/sq_collect.sh + tools/sq_summary.py), same rule")
+    ap.add_argument("--isa-mix-json", default=os.path.join(ROOT, "profiles", "r04_fill_isa_mix.json"),
+                    help="static VALU mix of a step by issue class (tools/isa_mix.py), same rule")
+    ap.add_argument("--valu-rate-json", default=os.path.join(ROOT, "profiles", "r04_valu_rate.json"),
+                    help="measured cycles per wave64 instruction (tools/ubench/valu_rate)")
+    ap.add_argument("--clock-json", default=os.path.join(ROOT, "profiles", "r04_clock_probe.json"),
+                    help="engine clock sampled under the fill's load (tools/clock_probe.py)")
     ap.add_argument("--collective", default="auto", choices=["auto", "on", "off"],
                     help="the all-reduce of the counter table inside every step.  auto/on: always -- with ONE rank a world-size-1 "
                          "RCCL communicator is created, so N = 1 runs the code path of N = 8 (auto falls back to off, and says "
                          "so in `dist`, if the communicator cannot be created); off: only with more than one rank")
     # internal: the CPU baseline runs in its own process (it forks workers; the GPU process must not)
+    ap.add_argument("--sites-verify", type=int, default=500,
+                    help="config3 leg: sites of rank 0's shard whose alignments, per-read outcome and count tables are compared "
+                         "with the reference's code in a CPU-leg process (0 = skip); exit status 3 on a mismatch")
     ap.add_argument("--cpu-leg", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--sites-cpu-leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-reads-file", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-out", help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -147,6 +158,132 @@ def _cpu_quota():
         return None if quota == "max" else float(quota) / float(period)
     except (OSError, ValueError):
         return None
+
+
+def _effective_cpus():
+    """CPUs this process can really use at once: its affinity mask, cut to the cgroup's quota (a container on a 256-CPU host
+    may be held to 16: forking one generator per visible CPU in each of 8 ranks would start 2 048 processes on 16 cores)."""
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = _cpu_quota()
+    if quota:
+        ncpu = min(ncpu, max(1, int(quota + 0.5)))
+    return max(1, ncpu)
+
+
+def reference_site_outcome(chk, s, stride=256):
+    """The reference's outcome for ONE config-3 site (TEST INFRASTRUCTURE: runs in the CPU-leg process / tests only): every
+    read aligned by the checker (the reference's gssw.c where oracle/_ref is built), then the reference's filters,
+    disambiguation and counting (graph-tools + Disambiguation.cpp as compiled into oracle/_ref/libpg_refcounts.so, or the
+    restatement): alignments, CIGAR slots, per-read status and label sets, node / edge / sequence tables."""
+    from oracle import counts as oc
+    from oracle import oracle as orc
+    arr = s.reads
+    n, L = arr.shape
+    off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L)).astype(np.uint32)
+    res = np.zeros(n, dtype=orc.RESULT_NP)
+    cig = np.zeros((n, stride), dtype=np.uint8)
+    if n:
+        chk.align_into(s.site.seqs, s.site.edges, off, np.ascontiguousarray(arr).reshape(-1), res, cig, threads=1)
+    recs = [{"pos": int(r["graph_pos"]), "cigar": bytes(c).split(b"\0", 1)[0].decode(), "aligned": int(r["score"]) > 0,
+             "unique": bool(r["unique"]), "graph_reverse": bool(s.is_reverse[k]) != bool(r["returned_reverse"]), "read_len": L,
+             "fragment": int(s.fragment[k])} for k, (r, c) in enumerate(zip(res, cig))]
+    labels = sorted({l for v in s.site.labels.values() for l in v})
+    count = oc.RefCounts().count_site if oc.have_ref() else oc.port_count_site
+    wc = count(oc.CountGraph(s.site.seqs, s.site.edges, s.site.labels, labels), recs, remove_nonuniq=True)
+    lab_idx = {l: k for k, l in enumerate(labels)}
+    return {"res": res, "cig": cig, "status": np.array(wc["status"], dtype=np.uint8),
+            "label_mask": np.array([sum(1 << lab_idx[l] for l in ls) for ls in wc["labels"]], dtype=np.uint64),
+            "nodes": wc["nodes"], "edges": wc["edges"], "node_counts": np.asarray(wc["node_counts"], dtype=np.uint64),
+            "edge_counts": np.asarray(wc["edge_counts"], dtype=np.uint64), "seq_counts": wc["seq_counts"]}
+
+
+_SITES_JOB = None
+
+
+def _sites_job(i):
+    from oracle import oracle as orc
+    chk = orc.RefOracle() if orc.have_ref() else orc.PortOracle()
+    return reference_site_outcome(chk, _SITES_JOB[i], SITES_CIGAR_STRIDE)
+
+
+def sites_cpu_leg_main(args):
+    """CPU-leg process of the config-3 leg: the reference's outcome for a sample of sites (pickled SiteReads in, per-site
+    dicts out), fanned out over the CPUs the cgroup allows."""
+    global _SITES_JOB
+    import multiprocessing as mp
+    import pickle
+    from oracle import counts as oc
+    from oracle import oracle as orc
+    with open(args.cpu_reads_file, "rb") as f:
+        _SITES_JOB = pickle.load(f)
+    procs = max(1, min(_effective_cpus(), len(_SITES_JOB)))
+    t0 = time.perf_counter()
+    if procs == 1:
+        out = [_sites_job(i) for i in range(len(_SITES_JOB))]
+    else:
+        with mp.get_context("fork").Pool(procs) as pool:
+            out = pool.map(_sites_job, range(len(_SITES_JOB)), chunksize=max(1, len(_SITES_JOB) // (4 * procs)))
+    with open(args.cpu_out, "wb") as f:
+        pickle.dump(out, f, protocol=4)
+    print(json.dumps({"sites": len(out), "reads": int(sum(len(o["res"]) for o in out)), "seconds": time.perf_counter() - t0, "workers": procs,
+                      "aligner": "reference gssw.c (oracle/_ref)" if orc.have_ref() else "plain-C restatement (oracle/pg_oracle.c)",
+                      "counting": "reference graph-tools + Disambiguation (oracle/_ref/libpg_refcounts.so)" if oc.have_ref()
+                      else "restatement (oracle/counts.py)"}))
+
+
+def run_sites_cpu_leg(sites):
+    """Runs sites_cpu_leg_main in a fresh interpreter (it forks; this process holds a HIP context): (info, per-site dicts)."""
+    import pickle
+    tmp = tempfile.mkdtemp(prefix="pgbench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    in_file, out_file = os.path.join(tmp, "sites.pkl"), os.path.join(tmp, "ref.pkl")
+    try:
+        with open(in_file, "wb") as f:
+            pickle.dump(sites, f, protocol=4)
+        cmd = [sys.executable, os.path.abspath(__file__), "--sites-cpu-leg", "--cpu-reads-file", in_file, "--cpu-out", out_file]
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(k, None)
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, check=True)
+        info = json.loads(p.stdout.decode().strip().splitlines()[-1])
+        with open(out_file, "rb") as f:
+            return info, pickle.load(f)
+    finally:
+        for f in (in_file, out_file):
+            if os.path.exists(f):
+                os.unlink(f)
+        os.rmdir(tmp)
+
+
+def verify_sites(capi, graphs, sample_sites, sample_idx, res, ops, sup, table, want, info):
+    """The sample sites' GPU outcome (first reads of the rank's batch, in sample order) against the reference's: alignments +
+    CIGARs, per-read status of the count path and label sets of the mapped reads, node / edge / sequence tables per site."""
+    n = int(sum(len(s.reads) for s in sample_sites))
+    ref_res = np.concatenate([w["res"] for w in want]) if want else np.zeros(0)
+    ref_cig = np.concatenate([w["cig"] for w in want]) if want else np.zeros((0, SITES_CIGAR_STRIDE), np.uint8)
+    out = verify_against_reference(capi, res[:n], ops, ref_res, ref_cig)
+    ref_status = np.concatenate([w["status"] for w in want])
+    ref_labels = np.concatenate([w["label_mask"] for w in want])
+    bad_status = sup["status"][:n] != ref_status
+    mapped = ref_status == 1
+    bad_labels = (sup["label_mask"][:n] != ref_labels) & mapped
+    cnt = capi.decode_counts(graphs, table)
+    bad_tables = 0
+    first_bad_site = None
+    for s, si, w in zip(sample_sites, sample_idx, want):
+        c = cnt[int(si)]
+        ok = np.array_equal(c["node_counts"], w["node_counts"]) and c["seq_counts"] == w["seq_counts"] and \
+            all(c["edge_counts"][tuple(e)] == [int(x) for x in w["edge_counts"][ei]] for ei, e in enumerate(s.site.edges))
+        if not ok:
+            bad_tables += 1
+            if first_bad_site is None:
+                first_bad_site = int(si)
+    out.update({"sites": len(sample_sites), "status_mismatches": int(bad_status.sum()), "label_set_mismatches": int(bad_labels.sum()),
+                "site_table_mismatches": int(bad_tables), "first_bad_site": first_bad_site,
+                "mismatches": int(out["mismatches"]) + int(bad_status.sum()) + int(bad_labels.sum()) + int(bad_tables),
+                "fields": out["fields"] + "; count-path status of every read, label sets of the mapped reads; node / edge / sequence "
+                                          "tables of every sampled site (after the all-reduce)",
+                "reference": info})
+    return out
 
 
 def cpu_leg_main(args):
@@ -304,6 +441,62 @@ def _counter_file(path, sha):
     return doc, src
 
 
+def _class_cycles(rate_doc):
+    """cycles per wave64 instruction per SIMD of the two issue classes, from the microbenchmark's rows at 8 wavefronts per SIMD
+    and 8 independent chains (the issue rate) x the clock s_memtime ran at in the same rows"""
+    rows = [r for r in rate_doc["rows"] if r["waves_per_simd"] == 8 and r["chains"] == 8]
+    ghz = {r["op"]: r["memtime_per_memrealtime_median"] * 0.1 for r in rows}  # s_memrealtime counts at 100 MHz
+    cyc = {r["op"]: r["ns_per_wave_inst_per_simd"] * ghz[r["op"]] for r in rows}
+    packed = [cyc[k] for k in ("pk_maximum3_f16", "pk_max_u16", "pk_add_f16", "perm_b32", "bfi_b32", "mov_dpp_row_shr1") if k in cyc]
+    plain = [cyc[k] for k in ("add_u32", "add_u32_literal", "and_b32", "mov_b32") if k in cyc]
+    return sum(packed) / len(packed), sum(plain) / len(plain)
+
+
+def valu_bound(args, sha, reads_per_launch, avg_launch_s):
+    """The share of the SIMDs' VALU issue cycles the fill launches of this run used, from MEASURED constants:
+      cycles per wave64 instruction of the two issue classes   tools/ubench/valu_rate (profiles/r04_valu_rate.json): packed /
+                                                               VOP3 / DPP / SGPR-operand instructions 4.2, plain 32-bit add /
+                                                               logic / mov 2.3
+      sustained engine clock under the fill                    amd-smi samples during a 60-step bench (profiles/r04_clock_probe.json)
+      VALU instructions per wave-step                          SQ_INSTS_VALU of one launch (dynamic, rare paths included)
+      their split by issue class                               static, common path of a step of each graph direction
+                                                               (tools/isa_mix.py); what the dynamic count holds beyond the
+                                                               common path (node boundaries) is priced as four-cycle
+    The counter file and the static mix are used only for the kernel sources they were made on (kernel_source_sha)."""
+    sq, src = _counter_file(args.sq_json, sha)
+    mix, mix_src = _counter_file(args.isa_mix_json, sha)
+    out = {"source": src, "isa_mix_source": mix_src}
+    try:
+        with open(args.valu_rate_json) as f:
+            c4, c2 = _class_cycles(json.load(f))
+        with open(args.clock_json) as f:
+            clock_ghz = json.load(f)["under_fill_load"]["xcd_clock_mhz_median"] / 1e3
+    except Exception as e:  # noqa: BLE001
+        out["why"] = "no measured issue rates / clock: %s" % e
+        return out
+    out.update({"cycles_per_packed_inst": c4, "cycles_per_plain_inst": c2, "clock_ghz": clock_ghz, "simds": SIMDS,
+                "rates_from": os.path.relpath(args.valu_rate_json, ROOT), "clock_from": os.path.relpath(args.clock_json, ROOT)})
+    if not (sq and mix and avg_launch_s > 0):
+        return out
+    n = sq["reads_in_pmc_run"]
+    dyn = sq["per_wave_step"]["SQ_INSTS_VALU"]
+    dirs = mix["directions"]
+    n4 = sum(d["per_step"].get("valu4", 0.0) for d in dirs.values()) / len(dirs)
+    n2 = sum(d["per_step"].get("valu2", 0.0) for d in dirs.values()) / len(dirs)
+    cyc_step = n4 * c4 + n2 * c2 + max(0.0, dyn - n4 - n2) * c4
+    wave_steps = sq["wave_steps"] / n * reads_per_launch
+    floor_s = cyc_step * wave_steps / (SIMDS * clock_ghz * 1e9)
+    out.update({"insts_per_wave_step": dyn, "common_path_packed_per_step": n4, "common_path_plain_per_step": n2,
+                "issue_cycles_per_wave_step": cyc_step, "issue_floor_ms": floor_s * 1e3, "issue_frac": floor_s / avg_launch_s,
+                "note": "issue_frac = VALU issue cycles of the launch / (1 024 SIMDs x the measured clock x the launch's duration).  A "
+                        "two-cycle instruction only costs two when another wavefront's two-cycle instruction pairs with it "
+                        "(profiles/r04_iadd_ab.jsonl: turning 30 of 92 instructions per step from four-cycle into two-cycle ones "
+                        "bought 3.5 %, not 18 %), so the true occupancy of the issue port lies between this figure and the one "
+                        "with every instruction priced at the packed rate: issue_frac_all_packed",
+                "issue_frac_all_packed": dyn * c4 * wave_steps / (SIMDS * clock_ghz * 1e9) / avg_launch_s})
+    return out
+
+
 def measured_bounds(args, reads_per_launch, avg_launch_s):
     """roofline fields beyond the contract's formula: what physically bounds pg_fill_kernel.
       traffic            HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate passes, calibrated)
@@ -319,19 +512,7 @@ def measured_bounds(args, reads_per_launch, avg_launch_s):
         out["traffic"] = doc["hbm_bytes_per_read"] * reads_per_launch
         out["hbm_measured_gbs"] = out["traffic"] / avg_launch_s / 1e9
         out["hbm_measured_frac"] = out["hbm_measured_gbs"] / HBM_PEAK_GBS
-    doc, src = _counter_file(args.sq_json, sha)
-    if doc and avg_launch_s > 0:
-        n = doc["reads_in_pmc_run"]
-        insts = doc["counters"]["SQ_INSTS_VALU"] / n * reads_per_launch
-        cyc = 4.0 * doc["counters"]["SQ_ACTIVE_INST_VALU"] / doc["counters"]["SQ_INSTS_VALU"]  # counter unit: 4 cycles
-        out["valu"] = {"insts_per_wave_step": doc["per_wave_step"]["SQ_INSTS_VALU"], "cycles_per_inst": cyc,
-                       "insts_per_launch": insts, "issue_floor_ms": insts * cyc / (SIMDS * CLOCK_GHZ * 1e9) * 1e3,
-                       "issue_frac": insts * cyc / (SIMDS * CLOCK_GHZ * 1e9) / avg_launch_s,
-                       "simds": SIMDS, "clock_ghz": CLOCK_GHZ, "source": src,
-                       "note": "share of the chip's VALU issue cycles (1 024 SIMDs at 2.4 GHz) the fill launches of THIS run "
-                               "used: the bound that binds (integer DP on packed VALU ops, no MFMA)"}
-    else:
-        out["valu"] = {"source": src}
+    out["valu"] = valu_bound(args, sha, reads_per_launch, avg_launch_s)
     return out
 
 
@@ -435,7 +616,7 @@ def run_sites_leg(args, env, ctx, capi, synth, sset, steps, warmup, timed_events
     torch.cuda.synchronize()  # torch.zeros ran on torch's stream, the library zeroes and counts on its own
     pass_no = [0]
 
-    def one_pass(b):
+    def one_pass(b, red=red):
         # stream-ordered: zero + fills + traceback + count are queued on the library's streams, the reduce behind an event on
         # a stream of torch's, the next pass (other table) right away -- the host waits for nothing until the barrier
         t = tables[pass_no[0] & 1]
@@ -459,11 +640,31 @@ def run_sites_leg(args, env, ctx, capi, synth, sset, steps, warmup, timed_events
     for _ in range(steps):
         table = one_pass(batch)
     env["barrier"]()
-    elapsed = env["max_over_ranks"](time.perf_counter() - t0)
+    elapsed_mine = time.perf_counter() - t0
+    elapsed = env["max_over_ranks"](elapsed_mine)
     tim = None
     if timed_events:
         tim = ctx.timing()
         ctx.timing_enable(False)
+    # every rank's own view (a straggler GPU or an unbalanced shard shows here, not in the max)
+    mine = {"rank": rank, "device": env["device"].index, "reads": int(len(arr)), "ms_per_pass": elapsed_mine / max(1, steps) * 1e3}
+    if tim:
+        mine.update({"fill_ms": tim["fill_ms"], "fill_launches": int(tim["fill_launches"]), "trace_ms": tim["trace_ms"]})
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    got = table.cpu().numpy().view(np.uint32).copy()  # the last REDUCED table (the barrier drained every stream)
+    # the same passes without the collective (each rank's table then stays its own)
+    collective_ab = None
+    if red and steps > 0:
+        env["barrier"]()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_pass(batch, None)
+        env["barrier"]()
+        plain = env["max_over_ranks"](time.perf_counter() - t0)
+        collective_ab = {"ms_per_pass_with": elapsed / steps * 1e3, "ms_per_pass_without": plain / steps * 1e3, "with_vs_without": elapsed / plain}
     n_sites, n_reads = len(sset.sites), int(sset.n_reads_site.sum())
     out = {"config": "configs[2]/[3]: %d mixed DEL / long-DEL / INS sites, 30x paired %dbp reads (%d reads), the same set "
                      "partitioned over %d rank(s) by dist.partition_sites (LPT on reads x graph length); align + count + "
@@ -474,12 +675,11 @@ def run_sites_leg(args, env, ctx, capi, synth, sset, steps, warmup, timed_events
            "shard_imbalance": float(max(sset.rank_weight(r) for r in range(world)) * world / max(1, sset.weights.sum())),
            "hot_sites_split_by_fragment": [{"site": i, "reads": int(sset.n_reads_site[i]),
                                             "reads_per_rank": [len(x) for x in sset.hot_reads[i]]} for i in sset.hot],
-           "counters": n_counters, "reduce_equals_single": None,
+           "counters": n_counters, "reduce_equals_single": None, "per_rank": per_rank, "collective_ab": collective_ab,
            # reads/s of two workloads only compare at equal graph length: a read costs 4 x L x G cell updates, and this set's
            # graphs are longer than config 2's 502 columns (insertions up to 1 000 bp, 6-node long deletions)
            "mean_graph_len_per_read": float((sset.n_reads_site * sset.g_len).sum() / max(1, n_reads)),
            "cell_updates_per_s": float(4.0 * sset.L * (sset.n_reads_site * sset.g_len).sum() * steps / elapsed)}
-    got = table.cpu().numpy().view(np.uint32).copy()
     tall = got[int(graphs.layout.tally_base):].reshape(-1, 4)
     out["tallies"] = {"aligned": int((tall[:, 0] & 0x7FFFFFFF).sum()), "mapped": int(tall[:, 1].sum()),
                       "bad_align": int(tall[:, 2].sum()), "nonuniq": int(tall[:, 3].sum())}
@@ -500,6 +700,16 @@ def run_sites_leg(args, env, ctx, capi, synth, sset, steps, warmup, timed_events
         out["reduce_equals_single"] = bool(np.array_equal(single, got))
         out["single_table_sum"] = int(single.astype(np.uint64).sum())
         b1.close()
+    if rank == 0 and args.sites_verify > 0 and not args.no_cpu_baseline:
+        # a fixed sample of rank 0's whole sites = the first reads of its batch; the table compared is the REDUCED one (the
+        # other ranks contribute zeros to these sites' counters)
+        sample_idx = [int(i) for i in sset.parts[0][:args.sites_verify]]
+        if sample_idx:
+            sample = [sset.sites[i] for i in sample_idx]
+            res_s, ops_s = batch.download()
+            _, sup_s, _ = batch.download_counts(want_table=False)
+            info, want = run_sites_cpu_leg(sample)
+            out["verified"] = verify_sites(capi, graphs, sample, sample_idx, res_s, ops_s, sup_s, got, want, info)
     batch.close()
     graphs.close()
     return out, tim, sset.b_alg(rank), len(arr)
@@ -540,7 +750,7 @@ def main_rank(args):
     want_sites = headline3 or args.sites_steps > 0
 
     # ---- data first: the generators fork workers, which must happen before this process touches HIP ------------
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncpu = _effective_cpus()  # affinity cut to the cgroup's quota, shared by the ranks of this node
     site = arr = None
     if not headline3:
         log("generating config2 reads")
@@ -617,13 +827,22 @@ def main_rank(args):
     if backend:
         dist_info["backend"] = dist.get_backend()
         dist_info["world"] = dist.get_world_size()
-        mine = {"rank": rank, "local_rank": local_rank, "device": dev_index, "name": torch.cuda.get_device_name(dev_index)}
+        prop = torch.cuda.get_device_properties(dev_index)
+        mine = {"rank": rank, "local_rank": local_rank, "device": dev_index, "name": torch.cuda.get_device_name(dev_index),
+                "host": socket.gethostname(), "pci": "%s:%s:%s" % tuple(getattr(prop, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")),
+                "uuid": str(getattr(prop, "uuid", "")) or None}
         if world > 1:
             every = [None] * world
             dist.all_gather_object(every, mine)
             dist_info["ranks"] = every
         else:
             dist_info["ranks"] = [mine]
+        # One process per GPU means just that: with at least as many GPUs as ranks every rank must sit on a device of its own and
+        # the reduce must be RCCL's.  A launch that does not (a wrong LOCAL_RANK, a masked device list) is reported and fails.
+        ids = [(r["host"], r["device"]) for r in dist_info["ranks"]]
+        hw = [(r["host"], r["uuid"] or r["pci"]) for r in dist_info["ranks"]]
+        dist_info["distinct_devices"] = len(set(ids)) == len(ids) and (len(set(hw)) == len(hw) or all(h[1] in (None, "None:None:None") for h in hw))
+        dist_info["placement_ok"] = bool(shared or (dist_info["distinct_devices"] and dist_info["backend"] == "nccl"))
 
     out = None
     if headline3:
@@ -663,6 +882,12 @@ def main_rank(args):
             rc = 3
         if out.get("sites") and out["sites"].get("reduce_equals_single") is False:
             rc = 3
+        if out.get("sites") and out["sites"].get("verified") and out["sites"]["verified"]["mismatches"]:
+            rc = 3
+        if dist_info.get("placement_ok") is False:
+            print("bench.py: %d ranks on %d visible GPUs must each have a device of their own under nccl: %s"
+                  % (world, ndev, json.dumps(dist_info.get("ranks"))), file=sys.stderr)
+            rc = 4
     if backend:
         if world > 1:
             dist.barrier()
@@ -747,13 +972,20 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
 
     # A/B for the collective: the same steps again without it (N = 1 only: there it must cost nothing)
     collective = None
-    if red and world == 1:
+    if red:
         elapsed_plain = timed(None, args.steps)
         collective = {"reduces_in_timed_region": args.steps, "ms_per_step_with": elapsed / args.steps * 1e3,
                       "ms_per_step_without": elapsed_plain / args.steps * 1e3, "with_vs_without": elapsed / elapsed_plain,
-                      "note": "`value` is measured WITH the all-reduce in every step (world-size-1 RCCL communicator = the code "
-                              "path of N = 8); `without` = the same steps right after, no collective"}
+                      "note": "`value` is measured WITH the all-reduce in every step (at N = 1 through a world-size-1 RCCL "
+                              "communicator = the code path of N = 8); `without` = the same steps right after, no collective"}
         log("plain region %.3fs" % elapsed_plain)
+    # every rank's own view of the timed region: a straggler GPU shows here, not in the max
+    mine = {"rank": rank, "device": env["device"].index, "fill_ms_per_launch": tim["fill_ms"] / max(1, tim["fill_launches"]),
+            "fill_launches": int(tim["fill_launches"]), "fill_ms": tim["fill_ms"], "trace_ms": tim["trace_ms"]}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     # PCIe-inclusive leg, streaming form: PINNED host arrays -> device -> results in pinned host arrays, two batch objects
     # and two sets of staging buffers; the upload of batch i+1 and the download of batch i-1 are DMAs on the copy stream
@@ -869,6 +1101,7 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
     }
     if collective:
         out["dist"]["collective_ab"] = collective
+    out["dist"]["per_rank"] = per_rank
     if world == 1 and not args.no_cpu_baseline:
         log("cpu baseline leg")
         base, ref_res, ref_cig = run_cpu_leg(args, arr)
@@ -884,6 +1117,9 @@ def main():
     args = parse_args()
     if args.cpu_leg:
         cpu_leg_main(args)
+        return 0
+    if args.sites_cpu_leg:
+        sites_cpu_leg_main(args)
         return 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         os.environ["PG_BENCH_LAUNCHER"] = "bench.py --gpus %d (self-spawned torch.distributed.run)" % args.gpus

@@ -939,7 +939,13 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
             continue;
         if (L > PG_MAX_READ_LEN || G->host[graph_of_read[i]].general_only)
         {
-            b->gen_idx.push_back(i);  // outside the packed kernels' envelope: the general path (pg_general.h)
+            // outside the packed kernels' envelope: the general path (pg_general.h).  Whether its matrices fit the workspace
+            // budget is decided HERE, before anything of the batch is queued: pg_batch_align must not find out after the
+            // packed chunks' kernels are in flight (the caller drops the site and recycles its device blocks on this error)
+            const HostGraph& hg = G->host[graph_of_read[i]];
+            if (pg_gen_read_bytes(L, hg.ncols, hg.n_nodes) > ctx->ws_limit)
+                return fail(ctx, PG_ERR_UNSUPPORTED, "workspace limit too small for one read of the general path (read length x graph columns)");
+            b->gen_idx.push_back(i);
             continue;
         }
         keys.push_back(Key{ (uint32_t)pg_variant_of(L), graph_of_read[i], i });
@@ -963,6 +969,57 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
             open = false;
         }
     };
+    // workspace bytes of one item pair (its regions are proportional to its pipeline steps, i.e. to its work)
+    struct PairNeed
+    {
+        uint64_t nsteps, trace_bytes, seed_bytes, need;
+    };
+    auto pair_need = [&](int C, const HostGraph& hg) {
+        PairNeed n;
+        // (the wide variants' sweeps run 32 lanes per read: 16 steps more; sized for that whichever kernel set runs)
+        n.nsteps = pg_fill_steps_lanes(hg.ncols, pg_var_wide(C) ? PG_WIDE_LANES : PG_GROUP_LANES);
+        n.trace_bytes = align_up(n.nsteps * 64 * pg_trace_lane_bytes(C), 256);
+        n.seed_bytes = pg_seed_region_bytes(C, hg.n_nodes) + pg_key_region_bytes(hg.n_nodes);
+        // + the traceback's CIGAR scratch of the pair's four reads (reversed-graph item's trace_off, which has no trace)
+        const uint64_t ops_bytes = align_up((uint64_t)PG_GROUPS * pg_ops_cap(C) * sizeof(uint32_t), 256);
+        n.need = n.trace_bytes + 2 * n.seed_bytes + ops_bytes;
+        return n;
+    };
+    // EQUAL chunks: every fill launch ends with a tail in which the chip drains, and a chunk that holds what was left over pays
+    // that tail on a fraction of the work (1 M config-2 reads at 128 GiB went out as 2 full chunks and a small one: launches of
+    // 20.8 / 20.8 / 10.1 ms, profiles/r03_kernel_stats.csv).  The bytes of each variant's run are counted first and cut into
+    // the smallest number of chunks that fit half the budget, all of (nearly) the same size.
+    std::vector<uint64_t> chunk_target(PG_VAR_WIDE + 33, 0);
+    {
+        std::vector<uint64_t> total(chunk_target.size(), 0), largest(chunk_target.size(), 0);
+        size_t p0 = 0;
+        while (p0 < keys.size())
+        {
+            size_t q0 = p0;
+            while (q0 < keys.size() && q0 - p0 < PG_GROUPS && keys[q0].c == keys[p0].c && keys[q0].graph == keys[p0].graph)
+                ++q0;
+            const uint64_t need = pair_need((int)keys[p0].c, G->host[keys[p0].graph]).need;
+            total[keys[p0].c] += need;
+            largest[keys[p0].c] = std::max(largest[keys[p0].c], need);
+            p0 = q0;
+        }
+        const uint64_t cap = ctx->ws_limit / 2;
+        for (size_t c = 0; c < total.size(); ++c)
+        {
+            if (!total[c])
+                continue;
+            if (largest[c] >= cap)
+            {
+                chunk_target[c] = cap;  // (a pair beyond the budget is refused below)
+                continue;
+            }
+            // a chunk closes BEFORE the pair that would exceed its target, so the target carries one pair of slack:
+            // total / n + largest <= cap
+            const uint64_t room = cap - largest[c];
+            const uint64_t n_chunks = std::max<uint64_t>(1, (total[c] + room - 1) / room);
+            chunk_target[c] = std::min(cap, (total[c] + n_chunks - 1) / n_chunks + largest[c]);
+        }
+    }
     size_t p = 0;
     while (p < keys.size())
     {
@@ -971,16 +1028,11 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
             ++q;
         const int C = (int)keys[p].c;
         const HostGraph& hg = G->host[keys[p].graph];
-        // (the wide variants' sweeps run 32 lanes per read: 16 steps more; sized for that whichever kernel set runs)
-        const uint64_t nsteps = pg_fill_steps_lanes(hg.ncols, pg_var_wide(C) ? PG_WIDE_LANES : PG_GROUP_LANES);
-        const uint64_t trace_bytes = align_up(nsteps * 64 * pg_trace_lane_bytes(C), 256);
-        const uint64_t seed_bytes = pg_seed_region_bytes(C, hg.n_nodes) + pg_key_region_bytes(hg.n_nodes);
-        // + the traceback's CIGAR scratch of the pair's four reads (reversed-graph item's trace_off, which has no trace)
-        const uint64_t ops_bytes = align_up((uint64_t)PG_GROUPS * pg_ops_cap(C) * sizeof(uint32_t), 256);
-        const uint64_t need = trace_bytes + 2 * seed_bytes + ops_bytes;
+        const PairNeed pn = pair_need(C, hg);
+        const uint64_t nsteps = pn.nsteps, trace_bytes = pn.trace_bytes, seed_bytes = pn.seed_bytes, need = pn.need;
         if (need > ctx->ws_limit / 2)
             return fail(ctx, PG_ERR_UNSUPPORTED, "workspace limit too small for one wavefront of this graph");
-        if (open && (cur.C != C || cur.ws_bytes + need > ctx->ws_limit / 2))
+        if (open && (cur.C != C || cur.ws_bytes + need > chunk_target[C]))
             close_chunk();
         if (!open)
         {
@@ -1269,6 +1321,29 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
                     cap0 / 1073741824.0, ctx->ws_cap / 1073741824.0, b->chunks.size(), b->max_ws / 1073741824.0, ms);
     }
     HIP_TRY(ctx, pg_stage_begin(ctx, b));
+    // Every way out of this call from here on records the end of the stage: pg_graphs_destroy / pg_dev_free / the next stage of
+    // this batch trust those events.  An error return that skipped it (a failed launch, the general path) would let the caller
+    // hand the batch's and the graph set's device blocks to another lane while the kernels queued so far still read them.
+    // The stage ends on the second stream, which is made to wait for whatever the main stream has been given.
+    struct StageEnd
+    {
+        pg_ctx* c;
+        pg_batch* b;
+        bool done;
+        ~StageEnd()
+        {
+            if (done)
+                return;
+            hipEvent_t e;
+            if (get_sync_event(c, &e) == hipSuccess)
+            {
+                if (hipEventRecord(e, c->stream) == hipSuccess)
+                    (void)hipStreamWaitEvent(c->stream2, e, 0);
+                c->sync_events_in_flight.push_back(e);
+            }
+            (void)pg_stage_end_on(c, b, c->stream2);
+        }
+    } stage_end{ ctx, b, false };
     if (!(flags & PG_AF_KEEP_RESULTS) || (flags == PG_AF_ALL))
         HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
     const bool revg = (flags & PG_AF_REVERSE_GRAPH) != 0;
@@ -1372,6 +1447,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     }
     // the batch is busy until its last traceback is over; later stages of THIS batch wait for that (pg_stage_begin*), other
     // batches' fills do not
+    stage_end.done = true;
     HIP_TRY(ctx, pg_stage_end_on(ctx, b, ctx->stream2));
     return PG_OK;
 }

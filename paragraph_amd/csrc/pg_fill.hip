@@ -142,7 +142,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // integers exactly (range used: 1024 - 300 .. 1024 + 512 + 8 + 256 + 2).  What leaves the registers is converted with
     // integer arithmetic on the bit patterns (0x6400 + n for 1024 + n): seeds and node maxima to plain scores on the rare
     // paths; the H trace keeps the low byte of score + tau, which pg_trace.hip undoes per cell.
-    const uint32_t PADPK = (f16_bits(PAD + 1) | (f16_bits(PAD + 1) << 16));
+    const uint32_t PADPK = pk_delta2(PAD + 1);  // (integer deltas on the bit patterns: pg_pk16.h)
     const uint32_t BIAS2 = PG_F16_BIAS2;  // the score 0 in frame 0
 
     // ---- query profiles of the 8 fills into LDS (gssw_qP_byte), shifted by the frame step ------------------------------
@@ -178,7 +178,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             {
                 const int sA = (cA == 5u ? PAD : sub_score(code, cA)) + shift;
                 const int sB = (cB == 5u ? PAD : sub_score(code, cB)) + shift;
-                prof[(g * 4 + code) * ROWS + row] = f16_bits(sA) | (f16_bits(sB) << 16);
+                prof[(g * 4 + code) * ROWS + row] = pk_delta(sA, sB);
             }
         }
     }
@@ -238,7 +238,8 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     uint32_t cnodeB = 0xFFFFFFFFu;
     uint32_t M = BIAS2 + (PG_TAU0 - 1) * ONE2, FC = 0;  // node maximum (frame of the previous step) / step that first reached it
     uint32_t FR = 0;  // WIDE: smallest row (within the lane) holding the lane's maximum in column FC, per strand
-    const uint32_t NEG5 = 0xC500C500u;    // (-5.0, -5.0): gap extend - gap open
+    const uint32_t NEG5 = pk_delta2(-5);  // gap extend - gap open, per half; NEG1: the vertical gap's extension
+    const uint32_t NEG1 = pk_delta2(-1);
     const uint32_t NEG256 = 0xDC00DC00u;  // (-256.0, -256.0)
     const uint32_t* profl = prof + lgrp * 4 * ROWS + k * C;
     const uint32_t trace_lane_off = (uint32_t)lane * 4u;
@@ -259,7 +260,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     auto code4_rows = [&](uint32_t (&rows)[C]) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < C; ++r)
-            rows[r] = (uint32_t)r < real_rows ? (r == 0 ? 0x40004000u : 0x3C003C00u) : PADPK;  // (2.0, 2.0) / (1.0, 1.0)
+            rows[r] = (uint32_t)r < real_rows ? (r == 0 ? pk_delta2(2) : pk_delta2(1)) : PADPK;
     };
     uint32_t sA[C], sB[C];
     {
@@ -296,11 +297,12 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 #pragma unroll
         for (int r = 0; r < C; ++r)
         {
-            const uint32_t f = r == 0 ? F : pk_dech(F);                      // F of this row in this step's frame
-            const uint32_t h = pk_max3h(pk_addh(diag, sc[r]), E[r], f);      // max(H(i-1,j-1) + s, E, F); E >= 0 is the local-alignment floor
+            // the three additions are 32-bit integer additions on the bit patterns (two cycles where a packed one takes four)
+            const uint32_t f = r == 0 ? F : F + NEG1;                        // F of this row in this step's frame
+            const uint32_t h = pk_max3h(diag + sc[r], E[r], f);              // max(H(i-1,j-1) + s, E, F); E >= 0 is the local-alignment floor
             diag = Hin[r];
             Hout[r] = h;
-            const uint32_t tt = pk_addh_s(h, NEG5);                          // (h - gap open) in the next step's / next row's terms
+            const uint32_t tt = h + NEG5;                                    // (h - gap open) in the next step's / next row's terms
             E[r] = pk_max3h_s(E[r], tt, floorE);                             // no decrement: the frame moves instead
             F = pk_maxu(f, tt);                                              // "F + 1" of the next row
         }
@@ -308,7 +310,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 
         // ---- running node maximum + first step reaching it (gssw.c:369-386) -----------------------
         // three-input maxima: C rows + the running maximum (moved into this step's frame) in (C + 1) / 2 instructions
-        const uint32_t Mprev = pk_add(M, ONE2);  // into this step's frame (integer + 1 on the bit pattern = + 1.0 above 1024)
+        const uint32_t Mprev = M + ONE2;  // into this step's frame (integer + 1 on the bit pattern = + 1.0 above 1024)
         uint32_t cm[C + 1];
 #pragma unroll
         for (int r = 0; r < C; ++r)
@@ -559,7 +561,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         // Hout still holds the column before the previous one: its last row is what the next lane needs as its diagonal
         // input one step later (lane k + 1 works one column behind lane k).  The row's first lane has no lane above: it keeps
         // its own register, which follows the frame by one per step.
-        dHin = pk_add(dHin, ONE2);
+        dHin = dHin + ONE2;
         dHin = group_shr1_keep<GL>(dHin, Hout[C - 1]);
         Fin = group_shr1_keep<GL>(Fin, Fsend);
         const uint32_t dH = dHin, F = Fin;

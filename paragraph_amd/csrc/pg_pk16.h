@@ -81,6 +81,20 @@ __device__ __forceinline__ uint32_t pk_max3h_s(uint32_t a, uint32_t b, uint32_t 
     asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(sconst));
     return d;
 }
+// ---- additions as 32-bit integer additions on the bit patterns ----------------------------------------------------------------
+// gfx950 issues a wave64 v_pk_* (or any VOP3P / v_perm / v_bfi / integer max) instruction over FOUR cycles and v_add_u32,
+// v_add_f32, v_fma_f32, v_mov_b32 over TWO (profiles/r04_valu_rate.json).  Between 1024 and 2048 the f16 pattern of 1024 + n is
+// 0x6400 + n, so adding a small integer d to such a number IS adding d to its bit pattern -- and both halves of a register take
+// their own d in ONE 32-bit addition of the word d_lo + (d_hi << 16) (mod 2^32): the whole-word sum is (hi + d_hi) * 65536 +
+// (lo + d_lo), and as long as each half's result stays within 0 .. 65535 no carry or borrow crosses the boundary (a negative
+// d_lo's "borrow" is already in the word's two's complement).  Every live value of the recurrence is a score >= -6 in a frame
+// >= 8, i.e. a number >= 1024 (that is what PG_TAU0 = 8 is for), so the three additions of a cell pair are exact this way and
+// the three maxima read the same patterns as before.  Padding rows (substitution score PG_PAD_SCORE) drop below 0x6400, where
+// patterns are no longer linear in the value but still ordered like it: they stay below every real cell, which is all that
+// is asked of them.
+__device__ __forceinline__ constexpr uint32_t pk_delta(int lo, int hi) { return (uint32_t)lo + ((uint32_t)hi << 16); }
+__device__ __forceinline__ constexpr uint32_t pk_delta2(int d) { return pk_delta(d, d); }
+
 // in-place forms for the rare paths: the value stays in its register (a tied operand), so the merge after the branch needs no
 // copy on the common path (without them the compiler copied all C registers of the previous column at the top of every step)
 __device__ __forceinline__ void pk_maxu_into(uint32_t& acc, uint32_t x) { asm("v_pk_max_u16 %0, %0, %1" : "+v"(acc) : "v"(x)); }

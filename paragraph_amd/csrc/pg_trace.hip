@@ -242,7 +242,8 @@ template <int C, bool WIDE, int GL> __device__ __forceinline__ void pg_trace_pai
         if (!(r & 1u) && at_end)
             return seedH(n, j) & (WIDE ? 0xFF : 0x3FF);
         const size_t dw = ((size_t)(col + kq + ((r & 1u) ^ 1u)) * (C / 2) + r / 2) * 64 + (lane0 + kq);
-        return (int)(((uint32_t)trace[dw * 4 + (r & 1u) + 2u * (uint32_t)s] - tau) & 0xFFu);
+        // (non-temporal: a trace byte is read once, and what the walk pulls through the L2 competes with the next chunk's fill)
+        return (int)(((uint32_t)__builtin_nontemporal_load(&trace[dw * 4 + (r & 1u) + 2u * (uint32_t)s]) - tau) & 0xFFu);
     };
     // The byte is the whole score in the byte variants (reads <= 250 bases).  In the wide ones it is the score modulo 256: the
     // walk itself carries the exact score (`sc`), and every test below relates the scores of cells that are neighbours or on

@@ -61,23 +61,10 @@ _JOB = None
 
 def _site_job(i):
     kind, payload = _JOB
-    from oracle import counts as oc
     chk = _checker()
     if kind == "config3":
-        s = payload[i]
-        res, cig = _align_site(chk, s.site.seqs, s.site.edges, s.reads, STRIDE)
-        L = s.reads.shape[1]
-        recs = [{"pos": int(r["graph_pos"]), "cigar": bytes(c).split(b"\0", 1)[0].decode(), "aligned": int(r["score"]) > 0,
-                 "unique": bool(r["unique"]), "graph_reverse": bool(s.is_reverse[k]) != bool(r["returned_reverse"]), "read_len": L,
-                 "fragment": int(s.fragment[k])} for k, (r, c) in enumerate(zip(res, cig))]
-        labels = sorted({l for v in s.site.labels.values() for l in v})
-        count = oc.RefCounts().count_site if oc.have_ref() else oc.port_count_site
-        wc = count(oc.CountGraph(s.site.seqs, s.site.edges, s.site.labels, labels), recs, remove_nonuniq=True)
-        lab_idx = {l: k for k, l in enumerate(labels)}
-        return {"res": res, "cig": cig, "status": np.array(wc["status"], dtype=np.uint8),
-                "label_mask": np.array([sum(1 << lab_idx[l] for l in ls) for ls in wc["labels"]], dtype=np.uint64),
-                "nodes": wc["nodes"], "edges": wc["edges"], "node_counts": np.asarray(wc["node_counts"], dtype=np.uint64),
-                "edge_counts": np.asarray(wc["edge_counts"], dtype=np.uint64), "seq_counts": wc["seq_counts"]}
+        import bench
+        return bench.reference_site_outcome(chk, payload[i], STRIDE)  # the same code bench.py's `sites.verified` leg runs
     site, arr = payload[i]
     res, cig = _align_site(chk, site.seqs, site.edges, arr, STRIDE_LONG)
     return {"res": res, "cig": cig}

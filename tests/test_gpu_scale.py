@@ -153,6 +153,39 @@ def test_bench_two_ranks_split_a_hot_site_by_fragment():
     assert out["sites"]["tallies"]["aligned"] == out["sites"]["reads"]
 
 
+def test_bench_eight_ranks_share_the_gpu():
+    """The launch the driver's 8-GPU box will see, on the one GPU: eight ranks (sharing the device, so the reduce hops through
+    the host under gloo -- with eight devices the same code takes the nccl branch and fails unless every rank has its own).
+    configs[3] with a hot site: 8 non-empty balanced shards, the hot site split 8 ways by fragment, reduced table == 1-rank
+    table, a sample of rank 0's sites equal to the reference's code; then the default weak leg (config 2 per rank + the sites
+    leg).  Bounded wall clock on the box's CPU quota (the generators are capped by the cgroup quota, not by the CPUs visible)."""
+    import time
+    t0 = time.perf_counter()
+    out = _run_bench(["--gpus", "8", "--workload", "config3", "--sites", "800", "--hot-site-depth", "1500", "--steps", "2",
+                      "--warmup", "1", "--workspace-gib", "8", "--sites-verify", "100"], timeout=1500)
+    d, s = out["dist"], out["sites"]
+    assert out["n_gpus"] == 8 and d["world"] == 8 and d["shared_device"] is True and d["backend"] == "gloo", d
+    assert d["placement_ok"] is True and len(d["ranks"]) == 8 and sorted(r["rank"] for r in d["ranks"]) == list(range(8))
+    assert s["reduce_equals_single"] is True, s
+    assert len(s["shard_reads"]) == 8 and min(s["shard_reads"]) > 0 and s["shard_imbalance"] < 1.05, s
+    hot = s["hot_sites_split_by_fragment"]
+    assert len(hot) == 1 and len(hot[0]["reads_per_rank"]) == 8 and min(hot[0]["reads_per_rank"]) > 500, hot
+    assert s["verified"]["sites"] == 100 and s["verified"]["mismatches"] == 0 and s["verified"]["reads"] > 10000, s["verified"]
+    assert len(s["per_rank"]) == 8 and all(r["fill_launches"] > 0 for r in s["per_rank"]), s["per_rank"]
+    assert s["collective_ab"]["with_vs_without"] > 0
+    assert s["tallies"]["aligned"] == s["reads"]
+    # the default workload at N = 8: weak scaling of config 2 + the sites leg, per-rank fill times in the line
+    out = _run_bench(["--gpus", "8", "--reads", "100000", "--steps", "2", "--warmup", "1", "--sites", "400", "--sites-steps", "1",
+                      "--sites-verify", "50", "--workspace-gib", "8"], timeout=1500)
+    d = out["dist"]
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and d["world"] == 8 and len(d["per_rank"]) == 8, d
+    assert all(r["fill_launches"] > 0 and r["fill_ms_per_launch"] > 0 for r in d["per_rank"])
+    assert out["counts"]["tallies"]["aligned"] == 8 * 100000, out["counts"]
+    assert out["sites"]["reduce_equals_single"] is True and out["sites"]["verified"]["mismatches"] == 0, out["sites"]
+    assert d["collective_ab"]["with_vs_without"] > 0
+    assert time.perf_counter() - t0 < 900
+
+
 def test_bench_one_rank_runs_the_rccl_reduce_stream_ordered():
     """N = 1 with a world-size-1 RCCL communicator: the all-reduce of the counter table is inside every timed step, ordered
     by events (no host synchronisation), and costs (next to) nothing; the counts are those of the plain path."""

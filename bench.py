@@ -494,6 +494,12 @@ def valu_bound(args, sha, reads_per_launch, avg_launch_s):
                         "bought 3.5 %, not 18 %), so the true occupancy of the issue port lies between this figure and the one "
                         "with every instruction priced at the packed rate: issue_frac_all_packed",
                 "issue_frac_all_packed": dyn * c4 * wave_steps / (SIMDS * clock_ghz * 1e9) / avg_launch_s})
+    pairs = sq["per_wave_step"].get("SQ_ACTIVE_INST_VALU2")
+    if pairs is not None:
+        # SQ_ACTIVE_INST_VALU2 = quad-cycles in which the SIMD issued TWO VALU instructions: every instruction takes one quad-cycle
+        # slot of its SIMD except those pairs, which share one
+        out["dual_issue_quads_per_wave_step"] = pairs
+        out["issue_frac_with_measured_pairing"] = (dyn - pairs) * 4.0 * wave_steps / (SIMDS * clock_ghz * 1e9) / avg_launch_s
     return out
 
 

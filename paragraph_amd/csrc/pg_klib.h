@@ -36,6 +36,7 @@ struct KlibArgs
 {
     uint32_t n_reads;
     uint32_t max_paths;  // items per read = 2 * max_paths
+    uint32_t len_limit;  // reads longer than this are not this stage's: they fall through to the graph aligner
     const uint32_t* base_off;
     const char* bases;
     const uint32_t* graph_of_read;

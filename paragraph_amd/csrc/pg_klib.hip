@@ -594,7 +594,7 @@ __global__ __launch_bounds__(64) void pg_klib_select_kernel(KlibArgs a)
     const uint32_t r = blockIdx.x * 64u + threadIdx.x;
     if (r >= a.n_reads || (a.active && !a.active[r]))
         return;
-    if (a.base_off[r + 1] == a.base_off[r])
+    if (a.base_off[r + 1] == a.base_off[r] || a.base_off[r + 1] - a.base_off[r] > a.len_limit)
         return;
     const LGraphDev g = a.graphs[a.graph_of_read[r]];
     if (g.n_paths == 0 || g.n_paths > MAX_PATHS)
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(64) void pg_klib_pick_kernel(KlibArgs a)
     a.flags[r] = 0;
     const uint32_t off = a.base_off[r];
     const int L = (int)(a.base_off[r + 1] - off);
-    if (L == 0)
+    if (L == 0 || (uint32_t)L > a.len_limit)
         return;
     const LGraphDev g = a.graphs[a.graph_of_read[r]];
     if (g.n_paths == 0 || g.n_paths > MAX_PATHS)
@@ -908,11 +908,16 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
         return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_klib_align: call pg_graphs_build_klib_index first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     pg_klib_index* ix = G->klib_index;
+    // reads beyond the stage's 512 bases are left alone (no result, no flag): in the cascade they fall through to the graph
+    // aligner, whose general path takes them -- one long read must not cost the stage its batch
+    constexpr uint32_t KLIB_LEN_LIMIT = 512;
     uint32_t max_len = 0;
     for (uint32_t r = 0; r < b->n_reads; ++r)
-        max_len = std::max(max_len, b->h_base_off[r + 1] - b->h_base_off[r]);
-    if (max_len > 512)
-        return pg_fail(ctx, PG_ERR_UNSUPPORTED, "pg_batch_klib_align: reads longer than 512 bases are not supported");
+    {
+        const uint32_t L = b->h_base_off[r + 1] - b->h_base_off[r];
+        if (L <= KLIB_LEN_LIMIT)
+            max_len = std::max(max_len, L);
+    }
     const int R = std::max(1, (int)((max_len + 63) / 64));
     const uint64_t n_items = (uint64_t)b->n_reads * 2u * ix->max_paths;
     HIP_TRY(ctx, pg_stage_begin(ctx, b));
@@ -954,6 +959,7 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     a.pathmeta = ix->d_pathmeta;
     a.starts = ix->d_starts;
     a.active = b->has_active ? b->d_active : nullptr;
+    a.len_limit = KLIB_LEN_LIMIT;
     a.cig_cap = cig_cap;
     a.results = b->d_results;
     a.ops = b->d_ops;

@@ -649,11 +649,15 @@ extern "C" pg_status pg_batch_kmer_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     a.ops_counter = b->d_ops_counter;
     a.flags = b->d_path_flags;
     a.active = b->has_active ? b->d_active : nullptr;
+    // reads beyond the stage's 512 bases are left alone (the kernel returns for L > l_max): in the cascade they fall through to
+    // the later stages -- one long read must not cost the stage its batch
     uint32_t max_len = 0;
     for (uint32_t i = 0; i < b->n_reads; ++i)
-        max_len = std::max(max_len, b->h_base_off[i + 1] - b->h_base_off[i]);
-    if (max_len > (uint32_t)KMER_SORT_MAX)
-        return pg_fail(ctx, PG_ERR_UNSUPPORTED, "pg_batch_kmer_align: reads longer than 512 bases are not supported");
+    {
+        const uint32_t L = b->h_base_off[i + 1] - b->h_base_off[i];
+        if (L <= (uint32_t)KMER_SORT_MAX)
+            max_len = std::max(max_len, L);
+    }
     a.l_max = (max_len + 3u) & ~3u;
     a.n_sort = 64;
     while (a.n_sort < max_len)

@@ -151,6 +151,33 @@ def test_klib_stage_150bp_site(gpu_ctx):
     assert n >= 290
 
 
+@pytest.mark.parametrize("general", [False, True])
+def test_a_read_beyond_the_stage_limit_is_left_to_the_later_stages(gpu_ctx, monkeypatch, general):
+    """One 700-base read in the batch (packed and general kernels): the stage aligns the others as if it were not there and
+    leaves it without a result or a flag -- in the cascade it falls through to the graph aligner's general path.  It used to
+    cost the stage the whole batch (and the workflow that site)."""
+    if general:
+        monkeypatch.setenv("PG_KLIB_GENERAL", "1")
+    rng = random.Random(fuzzgen.salted(77))
+    lf = "".join(rng.choice("ACGT") for _ in range(400))
+    rf = "".join(rng.choice("ACGT") for _ in range(400))
+    alt = "".join(rng.choice("ACGT") for _ in range(60))
+    nodes = [lf, alt, rf]
+    ps = [[0, 1, 2], [0, 2]]
+    reads = []
+    for _ in range(40):
+        seq = "".join(nodes[x] for x in rng.choice(ps))
+        st = rng.randrange(len(seq) - 150)
+        reads.append(fuzzgen.mutate(rng, seq[st:st + 150], sub=0.01, indel=0.005)[:200] or "A")
+    long_read = (lf + alt + rf)[:700]
+    f0, g0 = gpu_klib(gpu_ctx, [(nodes, edges_of(ps))], [ps], reads, None)
+    mixed = reads[:7] + [long_read] + reads[7:]
+    f1, g1 = gpu_klib(gpu_ctx, [(nodes, edges_of(ps))], [ps], mixed, None)
+    assert list(f1[:7]) + list(f1[8:]) == list(f0) and g1[:7] + g1[8:] == g0
+    assert f1[7] == 0 and g1[7]["score"] == 0 and g1[7]["cigar"] == ""
+    assert sum(1 for f in f0 if f & 1) >= 35
+
+
 def test_klib_stage_long_reads(gpu_ctx):
     """300..512 bp reads (the general kernels where a path is shorter than a read: R = 5..8 rows per lane, 8 direction bytes
     per lane per step; the packed ones with C = 20..32 rows per lane otherwise)."""

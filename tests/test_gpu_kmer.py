@@ -53,6 +53,19 @@ def test_reference_unit_vectors(gpu_ctx):
     assert ka.port_kmer_align(nodes, paths, reads, 10)[5]["status"] == 2
 
 
+def test_a_read_beyond_the_stage_limit_is_left_to_the_later_stages(gpu_ctx):
+    """One 600-base read in the batch: the stage aligns the others as if it were not there and leaves it without a result or a
+    flag (in the cascade it falls through to the graph aligner's general path) -- it used to cost the stage the batch."""
+    nodes = ["AAAAAAAAAAA", "TTTTTTTT", "GGGGGGGG", "AAAAAAAAAAA"]
+    edges = [(0, 1), (0, 2), (0, 3), (1, 3), (2, 3)]
+    paths = [[0, 1, 3], [0, 2, 3], [0, 3]]
+    reads = ["AAAAAAAATTTTTTTTAAAAAAAA", "AAAAAGGGGGGGGAAAAAA", "AAAAGGGGGGGGAAAAAA"]
+    f0, g0 = gpu_kmer(gpu_ctx, [(nodes, edges)], [paths], reads, None, 10)
+    f1, g1 = gpu_kmer(gpu_ctx, [(nodes, edges)], [paths], reads[:1] + ["ACGT" * 150] + reads[1:], None, 10)
+    assert list(f1[:1]) + list(f1[2:]) == list(f0) and g1[:1] + g1[2:] == g0
+    assert f1[1] == 0 and g1[1]["score"] == 0 and g1[1]["cigar"] == ""
+
+
 def _rand_paths(rng, n_nodes, edges):
     succ = {}
     for f, t in edges:

@@ -1163,18 +1163,29 @@ void SiteBatcher::run(BatchParameters const& prm)
             return;
         }
     }
-    // some site of the batch is outside the envelope: every site on its own, so the others come out as if it were not there
-    for (size_t s = 0; s < n; ++s)
+    // Some site of the batch is outside the envelope.  The batch is cut in two and each half run as a batch of its own (which
+    // cuts itself again if it has to): the offending site ends up alone and reports, every other site comes out as if it were
+    // not there -- after about 2 log2(n) smaller batches, not n one-site ones (a 128-site batch with one 65-label graph used to
+    // become 128 uploads and device round trips, run one after the other).
+    const size_t mid = n / 2;
+    for (size_t part = 0; part < 2; ++part)
     {
-        SiteBatcher one;
-        if (impl_->packed[s])
-            one.addSite(impl_->graphs[s], impl_->packed[s], impl_->paths[s]);
-        else
-            one.addSite(impl_->graphs[s], impl_->reads[s], impl_->paths[s]);
-        one.run(prm);
-        impl_->counts[s] = std::move(one.impl_->counts[0]);
-        impl_->views[s] = std::move(one.impl_->views[0]);
-        impl_->errors[s] = std::move(one.impl_->errors[0]);
+        const size_t lo = part ? mid : 0, hi = part ? n : mid;
+        SiteBatcher half;
+        for (size_t s = lo; s < hi; ++s)
+        {
+            if (impl_->packed[s])
+                half.addSite(impl_->graphs[s], impl_->packed[s], impl_->paths[s]);
+            else
+                half.addSite(impl_->graphs[s], impl_->reads[s], impl_->paths[s]);
+        }
+        half.run(prm);
+        for (size_t s = lo; s < hi; ++s)
+        {
+            impl_->counts[s] = std::move(half.impl_->counts[s - lo]);
+            impl_->views[s] = std::move(half.impl_->views[s - lo]);
+            impl_->errors[s] = std::move(half.impl_->errors[s - lo]);
+        }
     }
 }
 

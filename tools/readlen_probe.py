@@ -12,7 +12,7 @@ from paragraph_amd import capi, synth  # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
-    lens = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [100, 150, 250, 251, 300, 400, 512]
+    lens = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [100, 150, 200, 250, 251, 300, 400, 480]
     ctx = capi.Context(0, workspace_bytes=64 << 30)
     out = {"reads": n, "rows": []}
     for read_len in lens:

@@ -68,7 +68,7 @@ enum
     PG_ERR_INVALID = 1,     /* bad argument (NULL, non-topological edge, empty node, ...) */
     PG_ERR_NO_DEVICE = 2,   /* no usable HIP device */
     PG_ERR_HIP = 3,         /* a HIP runtime call failed (see pg_last_error) */
-    PG_ERR_UNSUPPORTED = 4, /* outside the supported envelope (read > 16 000 bp, > 65 535 nodes, > 64 labels, ...) */
+    PG_ERR_UNSUPPORTED = 4, /* outside the supported envelope (read > 16 000 bp, > 65 535 nodes, > 256 labels, ...) */
     PG_ERR_NOMEM = 5,
     PG_ERR_OVERFLOW = 6     /* an output buffer supplied by the caller is too small */
 };
@@ -237,7 +237,8 @@ typedef struct pg_count_params
 /* Per-read outcome of the count path. */
 typedef struct pg_read_support
 {
-    uint64_t label_mask; /* Read::graph_sequences_supported as a bit set over the graph's labels */
+    uint64_t label_mask; /* Read::graph_sequences_supported as a bit set over the graph's labels: labels 0..63 (the further
+                            words of a graph set with more labels: pg_batch_download_label_ext) */
     uint32_t path_off;   /* first entry in the path array */
     uint16_t n_path;     /* nodes on the read's path */
     uint8_t status;      /* 0 not aligned / skipped, 1 MAPPED, 2 BAD_ALIGN (filtered), 3 invalid alignment */
@@ -250,7 +251,8 @@ typedef struct pg_read_support
 
 enum
 {
-    PG_MAX_LABELS = 64,         /* labels per graph (bit set) */
+    PG_MAX_LABELS = 256,        /* labels per graph (bit set of up to PG_LABEL_WORDS 64-bit words) */
+    PG_LABEL_WORDS = 4,
     PG_MAX_SEQ_TABLE_LABELS = 8 /* graphs with more labels get no dense sequence-set table (slots = 0) */
 };
 
@@ -269,6 +271,14 @@ typedef struct pg_count_layout
  * `pred` array of pg_graphs_upload; n_labels[g] = number of labels of graph g (<= 64). */
 pg_status pg_graphs_set_labels(
     pg_ctx* ctx, pg_graphs* graphs, const uint64_t* label_mask_of_pred, const uint32_t* n_labels);
+/* The same for graph sets with more than 64 labels on a graph (the reference's PathFamily has no bound,
+ * src/c++/lib/paragraph/ReadCounting.cpp:96-127): label_words_of_pred[k * words + w] = word w of the bit set of edge k,
+ * words = 1 .. PG_LABEL_WORDS for the WHOLE set, n_labels[g] <= 64 * words.  pg_read_support.label_mask then holds word 0 of
+ * a read's set and pg_batch_download_label_ext the others. */
+pg_status pg_graphs_set_labels_wide(
+    pg_ctx* ctx, pg_graphs* graphs, const uint64_t* label_words_of_pred, uint32_t words, const uint32_t* n_labels);
+/* words per label set of the graph set (1 unless pg_graphs_set_labels_wide was given more) */
+pg_status pg_graphs_label_words(const pg_graphs* graphs, uint32_t* words);
 pg_status pg_graphs_count_layout(const pg_graphs* graphs, pg_count_layout* out);
 /* seq_off[g] (n_graphs + 1 entries) of the layout above */
 pg_status pg_graphs_seq_offsets(const pg_graphs* graphs, uint64_t* seq_off);
@@ -317,6 +327,9 @@ pg_status pg_ctx_count_wait(pg_ctx* ctx, void* native_event);
 pg_status pg_batch_download_counts(
     pg_ctx* ctx, pg_batch* batch, uint32_t* counts, pg_read_support* supports, uint32_t* path, uint64_t path_cap,
     uint64_t* n_path);
+/* Words 1 .. words-1 of every read's label set, label_ext[r * (words - 1) + (w - 1)] (word 0 is pg_read_support.label_mask);
+ * cap_words = capacity of label_ext in 64-bit words (needs n_reads * (words - 1)).  Nothing to copy when words == 1. */
+pg_status pg_batch_download_label_ext(pg_ctx* ctx, pg_batch* batch, uint64_t* label_ext, uint64_t cap_words);
 
 /* ---------------------------------------------------------------------------------------------------
  * Exact path matching stage (grm::PathAligner, --path-sequence-matching; default ON in `paragraph`, OFF in grmpy)

@@ -304,11 +304,12 @@ class RefCounts:
         fr = np.array([r["fragment"] for r in reads] or [0], dtype=np.uint32)
         prm = Params(1 if remove_nonuniq else 0, bad_align_frac, 1 if use_support_filters else 0)
         st = np.zeros(max(n, 1), dtype=np.uint8)
-        om, oe, ol = (np.zeros(max(n, 1), dtype=np.uint64) for _ in range(3))
+        om, oe = (np.zeros(max(n, 1), dtype=np.uint64) for _ in range(2))
+        ol = np.zeros((max(n, 1), 4), dtype=np.uint64)  # label sets: four words per read (up to 256 labels)
         nc = np.zeros((n_nodes, 4), dtype=np.uint64)
         ec = np.zeros((max(1, len(graph.edges)), 4), dtype=np.uint64)
         nseq = C.c_uint32()
-        smask = np.zeros(256, dtype=np.uint64)
+        smask = np.zeros((256, 4), dtype=np.uint64)
         scnt = np.zeros((256, 4), dtype=np.uint64)
         rc = self.L.pgrefc_count_site(g, n, P(pos, C.c_int32), P(coff, C.c_uint32), cig, P(al, C.c_uint8),
                                       P(un, C.c_uint8), P(rv, C.c_uint8), P(rl, C.c_uint32), P(fr, C.c_uint32),
@@ -318,6 +319,8 @@ class RefCounts:
         self.L.pgrefc_graph_destroy(g)
 
         def bits(m, universe):
+            if isinstance(m, np.ndarray):  # a label set of four words
+                m = sum(int(w) << (64 * k) for k, w in enumerate(m))
             return {universe[k] for k in range(len(universe)) if (int(m) >> k) & 1}
         seqs = {}
         for k in range(nseq.value):

@@ -16,7 +16,7 @@
  *   Fragment::addRead / readsToFragments        src/c++/lib/common/Fragment.cpp:34-69, 141-181
  *   countNodes / countEdges / countPathFamilies src/c++/lib/paragraph/ReadCounting.cpp:52-127
  *
- * Interface limits (checker only): <= 64 nodes, <= 64 edges, <= 64 labels per graph.
+ * Interface limits (checker only): <= 64 nodes, <= 64 edges, <= 256 labels per graph (label sets: 4 words of 64 bits).
  */
 #include <limits>
 #include <algorithm>
@@ -65,7 +65,7 @@ extern "C" pgrefc_graph* pgrefc_graph_create(
     const uint32_t* to, const uint32_t* label_off, const uint32_t* label_ids, uint32_t n_labels,
     const char* const* label_names)
 {
-    if (n_nodes > 64 || n_edges > 64 || n_labels > 64)
+    if (n_nodes > 64 || n_edges > 64 || n_labels > 256)
         return nullptr;
     auto* g = new pgrefc_graph{ Graph(n_nodes, false), {}, {}, {}, {} };  // expansion off as graphFromJson (GraphInput.cpp:62)
     for (uint32_t i = 0; i < n_nodes; ++i)
@@ -319,16 +319,20 @@ extern "C" int pgrefc_count_site(
     {
         const ReadRec& r = reads[i];
         out_status[i] = (uint8_t)r.status;
-        uint64_t nm = 0, em = 0, lm = 0;
+        uint64_t nm = 0, em = 0;
         for (auto n : r.nodes)
             nm |= 1ull << n;
         for (auto const& e : r.edges)
             em |= 1ull << g->edge_index.at(e);
+        uint64_t* lm = out_labels + 4 * (size_t)i;  // four words per read
+        lm[0] = lm[1] = lm[2] = lm[3] = 0;
         for (auto const& l : r.labels)
-            lm |= 1ull << g->label_index.at(l);
+        {
+            const uint32_t b = g->label_index.at(l);
+            lm[b >> 6] |= 1ull << (b & 63);
+        }
         out_nodes[i] = nm;
         out_edges[i] = em;
-        out_labels[i] = lm;
     }
     // readsToFragments over the surviving reads, in read order (Fragment.cpp:165-181)
     std::list<Frag> frags;
@@ -355,7 +359,7 @@ extern "C" int pgrefc_count_site(
     }
     std::fill(node_counts, node_counts + 4 * graph.numNodes(), 0);
     std::fill(edge_counts, edge_counts + 4 * g->edges.size(), 0);
-    std::map<uint64_t, std::array<uint64_t, 4>> seqs;
+    std::map<std::array<uint64_t, 4>, std::array<uint64_t, 4>> seqs;  // label set (four words) -> counters
     for (auto const& f : frags)
     {
         for (auto n : f.nodes)
@@ -364,9 +368,12 @@ extern "C" int pgrefc_count_site(
             add_count(edge_counts + 4 * g->edge_index.at(e), f);
         if (!f.labels.empty())
         {
-            uint64_t lm = 0;
+            std::array<uint64_t, 4> lm{ { 0, 0, 0, 0 } };
             for (auto const& l : f.labels)
-                lm |= 1ull << g->label_index.at(l);
+            {
+                const uint32_t b = g->label_index.at(l);
+                lm[b >> 6] |= 1ull << (b & 63);
+            }
             auto& c = seqs[lm];
             add_count(c.data(), f);
         }
@@ -376,7 +383,7 @@ extern "C" int pgrefc_count_site(
     {
         if (*n_seq >= seq_cap)
             break;
-        seq_masks[*n_seq] = kv.first;
+        std::memcpy(seq_masks + 4 * (*n_seq), kv.first.data(), 4 * sizeof(uint64_t));
         std::memcpy(seq_counts + 4 * (*n_seq), kv.second.data(), 4 * sizeof(uint64_t));
         ++*n_seq;
     }

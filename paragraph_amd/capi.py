@@ -42,7 +42,8 @@ EXPORTS = [
     "pg_device_prefer_blocking_waits", "pg_ctx_create", "pg_ctx_destroy", "pg_strerror", "pg_last_error", "pg_ctx_set_workspace_bytes", "pg_ctx_sync",
     "pg_ctx_timing_enable", "pg_ctx_timing_reset", "pg_ctx_timing_get", "pg_graphs_upload", "pg_graphs_destroy",
     "pg_batch_create", "pg_batch_destroy", "pg_batch_upload", "pg_batch_align", "pg_batch_ops_count",
-    "pg_batch_download", "pg_align_batch", "pg_render_cigar", "pg_graphs_set_labels", "pg_graphs_count_layout",
+    "pg_batch_download", "pg_align_batch", "pg_render_cigar", "pg_graphs_set_labels", "pg_graphs_set_labels_wide", "pg_graphs_label_words",
+    "pg_batch_download_label_ext", "pg_graphs_count_layout",
     "pg_graphs_seq_offsets", "pg_batch_set_fragments", "pg_batch_count", "pg_batch_download_counts", "pg_graphs_build_path_index",
     "pg_batch_path_align", "pg_batch_download_path_flags", "pg_batch_set_active", "pg_graphs_build_kmer_index",
     "pg_batch_kmer_align", "pg_graphs_build_klib_index", "pg_batch_klib_align", "pg_graphs_klib_error", "pg_graphs_klib_last_kernels", "pg_graphs_build_filter_index",
@@ -128,6 +129,12 @@ def load_library():
     u64p = C.POINTER(C.c_uint64)
     L.pg_graphs_set_labels.restype = C.c_int32
     L.pg_graphs_set_labels.argtypes = [vp, vp, u64p, u32p]
+    L.pg_graphs_set_labels_wide.restype = C.c_int32
+    L.pg_graphs_set_labels_wide.argtypes = [vp, vp, u64p, C.c_uint32, u32p]
+    L.pg_graphs_label_words.restype = C.c_int32
+    L.pg_graphs_label_words.argtypes = [vp, u32p]
+    L.pg_batch_download_label_ext.restype = C.c_int32
+    L.pg_batch_download_label_ext.argtypes = [vp, vp, u64p, C.c_uint64]
     L.pg_graphs_count_layout.restype = C.c_int32
     L.pg_graphs_count_layout.argtypes = [vp, C.POINTER(CountLayout)]
     L.pg_graphs_seq_offsets.restype = C.c_int32
@@ -411,7 +418,9 @@ class Graphs:
         if labels is None:
             labels = [sorted({l for v in el.values() for l in v}) for el in edge_labels]
         self.labels = [list(l) for l in labels]
-        mask = np.zeros(max(1, len(self.pred)), dtype=np.uint64)
+        # label sets are bit sets of `words` 64-bit words for the whole graph set (1 unless a graph has more than 64 labels)
+        self.label_words = words = max(1, max((len(l) + 63) // 64 for l in self.labels) if self.labels else 1)
+        mask = np.zeros((max(1, len(self.pred)), words), dtype=np.uint64)
         k = 0
         for g in range(self.n):
             idx = {l: i for i, l in enumerate(self.labels[g])}
@@ -419,11 +428,15 @@ class Graphs:
                 m = 0
                 for l in edge_labels[g].get(e, []):
                     m |= 1 << idx[l]
-                mask[k] = m
+                for w in range(words):
+                    mask[k, w] = (m >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
                 k += 1
         nl = _u32([len(l) for l in self.labels])
-        self.ctx._chk(self.ctx.L.pg_graphs_set_labels(self.ctx.h, self.h, mask.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                                      _p32(nl)))
+        if words == 1:
+            self.ctx._chk(self.ctx.L.pg_graphs_set_labels(self.ctx.h, self.h, mask.ctypes.data_as(C.POINTER(C.c_uint64)), _p32(nl)))
+        else:
+            self.ctx._chk(self.ctx.L.pg_graphs_set_labels_wide(self.ctx.h, self.h, mask.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                           words, _p32(nl)))
         lay = CountLayout()
         self.ctx._chk(self.ctx.L.pg_graphs_count_layout(self.h, C.byref(lay)))
         self.layout = lay
@@ -542,6 +555,19 @@ class Batch:
             len(path), C.byref(npath)))
         return counts, sup[:self.n_reads], path[:int(npath.value)]
 
+    def download_label_sets(self, sup):
+        """The reads' label sets as Python integers (bit i = label i of the read's graph): word 0 from `sup` (download_counts),
+        the further words of a graph set with more than 64 labels on a graph from pg_batch_download_label_ext."""
+        words = getattr(self._graphs, "label_words", 1)
+        out = [int(x) for x in sup["label_mask"]]
+        if words > 1 and self.n_reads:
+            ext = np.zeros((self.n_reads, words - 1), dtype=np.uint64)
+            self.ctx._chk(self.ctx.L.pg_batch_download_label_ext(self.ctx.h, self.h, ext.ctypes.data_as(C.POINTER(C.c_uint64)), ext.size))
+            for i in range(self.n_reads):
+                for w in range(words - 1):
+                    out[i] |= int(ext[i, w]) << (64 * (w + 1))
+        return out
+
     def download(self, into=None):
         """-> (results (RESULT_DTYPE), ops).  into = (results, ops) arrays to fill (e.g. pinned) instead of fresh ones."""
         cnt = C.c_uint64()
@@ -638,8 +664,9 @@ def decode_counts(graphs, counts):
     return out
 
 
-def decode_supports(graphs, graph_of_read, sup, path):
-    """per read: dict(status, filter, nodes {ids}, edges {(from,to)}, labels {names})."""
+def decode_supports(graphs, graph_of_read, sup, path, label_sets=None):
+    """per read: dict(status, filter, nodes {ids}, edges {(from,to)}, labels {names}).  label_sets = Batch.download_label_sets(sup)
+    for graph sets with more than 64 labels on a graph (default: the 64 bits in `sup`)."""
     out = []
     for i, s in enumerate(sup):
         g = int(graph_of_read[i])
@@ -655,5 +682,6 @@ def decode_supports(graphs, graph_of_read, sup, path):
             prev = nd
         labs = graphs.labels[g]
         out.append({"status": int(s["status"]), "filter": int(s["filter"]), "nodes": nodes, "edges": edges,
-                    "labels": {labs[b] for b in range(len(labs)) if (int(s["label_mask"]) >> b) & 1}})
+                    "labels": {labs[b] for b in range(len(labs))
+                               if ((label_sets[i] if label_sets is not None else int(s["label_mask"])) >> b) & 1}})
     return out

@@ -866,6 +866,9 @@ static void batch_free_device(pg_batch* b)
     b->d_active = nullptr;
     b->has_active = false;
     (void)pg_dev_free(b->d_support);
+    (void)pg_dev_free(b->d_label_ext);
+    b->d_label_ext = nullptr;
+    b->cap_label_ext = 0;
     (void)pg_dev_free(b->d_path);
     (void)pg_dev_free(b->d_path_counter);
     (void)pg_dev_free(b->d_frag_off);

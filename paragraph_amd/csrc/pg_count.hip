@@ -43,9 +43,11 @@ struct CountArgs
     const uint32_t* pred_off;   // set-wide node numbering
     const uint32_t* pred;
     const uint32_t* node_len;
-    const uint64_t* label_mask;  // per predecessor entry
-    const uint64_t* out_mask;
+    const uint64_t* label_mask;  // per predecessor entry x label_words
+    const uint64_t* out_mask;    // per node x label_words
     const uint64_t* in_mask;
+    uint32_t label_words;        // 64-bit words per label set (1 unless a graph of the set has more than 64 labels)
+    uint64_t* label_ext;         // [read][label_words - 1]: words 1.. of the reads' sets (word 0 is in pg_read_support)
     pg_read_support* support;
     uint32_t* path;
     unsigned long long* path_counter;
@@ -274,7 +276,9 @@ __global__ __launch_bounds__(64) void pg_support_kernel(CountArgs a)
     NodeAln prev{}, cur{};
     bool have_prev = false, have_cur = false;
     uint32_t k = 0;
-    uint64_t overlapped = 0, matched = 0, failed = 0;
+    // label sets of up to PG_LABEL_WORDS words (W = 1 on all but graph sets with more than 64 labels on a graph)
+    const uint32_t W = a.label_words;
+    uint64_t overlapped[PG_LABEL_WORDS] = {}, matched[PG_LABEL_WORDS] = {}, failed[PG_LABEL_WORDS] = {};
     auto finish_node = [&]() {
         // edge (prev -> cur) and node cur
         uint32_t entry = cur.node;
@@ -282,18 +286,22 @@ __global__ __launch_bounds__(64) void pg_support_kernel(CountArgs a)
         if (have_prev)
         {
             // predecessor entry of the edge prev.node -> cur.node
-            uint64_t emask = 0;
+            uint32_t eq = 0xFFFFFFFFu;
             for (uint32_t q = a.pred_off[gn]; q < a.pred_off[gn + 1]; ++q)
                 if (a.pred[q] == prev.node)
-                    emask = a.label_mask[q];
-            const uint64_t touch = a.out_mask[cg.node_base + prev.node] | a.in_mask[gn];
-            matched |= emask;
-            failed |= (~emask) & touch;
-            if (edge_ok(prev, cur, a.node_len[cg.node_base + prev.node], a.node_len[gn], L, use))
+                    eq = q;
+            const bool eok = edge_ok(prev, cur, a.node_len[cg.node_base + prev.node], a.node_len[gn], L, use);
+            for (uint32_t w = 0; w < W; ++w)
             {
-                entry |= 1u << 31;
-                overlapped |= emask;
+                const uint64_t emask = eq != 0xFFFFFFFFu ? a.label_mask[(size_t)eq * W + w] : 0ull;
+                const uint64_t touch = a.out_mask[(size_t)(cg.node_base + prev.node) * W + w] | a.in_mask[(size_t)gn * W + w];
+                matched[w] |= emask;
+                failed[w] |= (~emask) & touch;
+                if (eok)
+                    overlapped[w] |= emask;
             }
+            if (eok)
+                entry |= 1u << 31;
         }
         if (node_ok(cur, a.node_len[gn], L, use))
             entry |= 1u << 30;
@@ -330,7 +338,9 @@ __global__ __launch_bounds__(64) void pg_support_kernel(CountArgs a)
     if (have_cur)
         finish_node();
     // PathFamily::containsPath for every label overlapped by a supported edge
-    sup.label_mask = overlapped & matched & ~failed;
+    sup.label_mask = overlapped[0] & matched[0] & ~failed[0];
+    for (uint32_t w = 1; w < W; ++w)
+        a.label_ext[(size_t)r * (W - 1) + (w - 1)] = overlapped[w] & matched[w] & ~failed[w];
     sup.path_off = poff;
     sup.n_path = (uint16_t)n_path;
     a.support[r] = sup;
@@ -493,35 +503,40 @@ static void layout_of(const pg_graphs* G, pg_count_layout* lay)
     lay->n_counters = lay->tally_base + 4 * lay->n_graphs;
 }
 
-extern "C" pg_status pg_graphs_set_labels(
-    pg_ctx* ctx, pg_graphs* G, const uint64_t* label_mask_of_pred, const uint32_t* n_labels)
+extern "C" pg_status pg_graphs_set_labels_wide(
+    pg_ctx* ctx, pg_graphs* G, const uint64_t* label_words_of_pred, uint32_t words, const uint32_t* n_labels)
 {
     if (!ctx || !G)
         return PG_ERR_INVALID;
+    if (words < 1 || words > PG_LABEL_WORDS)
+        return pg_fail(ctx, PG_ERR_UNSUPPORTED, "label sets of more than 256 labels (4 words)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t n_nodes = G->h_pred_off.size() - 1, n_pred = G->h_pred.size();
-    std::vector<uint64_t> lm(n_pred, 0), outm(n_nodes, 0), inm(n_nodes, 0);
+    const size_t n_nodes = G->h_pred_off.size() - 1, n_pred = G->h_pred.size(), W = words;
+    std::vector<uint64_t> lm(n_pred * W, 0), outm(n_nodes * W, 0), inm(n_nodes * W, 0);
     G->h_n_labels.assign(G->n_graphs, 0);
     G->h_seq_off.assign(G->n_graphs + 1, 0);
     std::vector<PgCountGraph> cg(G->n_graphs);
     for (uint32_t g = 0; g < G->n_graphs; ++g)
     {
         const uint32_t nl = n_labels ? n_labels[g] : 0;
-        if (nl > PG_MAX_LABELS)
-            return pg_fail(ctx, PG_ERR_UNSUPPORTED, "more than 64 labels on a graph");
+        if (nl > 64u * words)
+            return pg_fail(ctx, PG_ERR_UNSUPPORTED, words == 1 ? "more than 64 labels on a graph (pg_graphs_set_labels_wide takes up to 256)"
+                                                                 : "more labels on a graph than the label words hold");
         G->h_n_labels[g] = nl;
-        const uint64_t valid = nl >= 64 ? ~0ull : ((1ull << nl) - 1);
         const uint32_t nb = G->h_node_off[g], ne = G->h_node_off[g + 1];
         for (uint32_t node = nb; node < ne; ++node)
             for (uint32_t q = G->h_pred_off[node]; q < G->h_pred_off[node + 1]; ++q)
-            {
-                const uint64_t m = label_mask_of_pred ? label_mask_of_pred[q] : 0;
-                if (m & ~valid)
-                    return pg_fail(ctx, PG_ERR_INVALID, "label bit outside n_labels");
-                lm[q] = m;
-                inm[node] |= m;
-                outm[nb + G->h_pred[q]] |= m;
-            }
+                for (uint32_t w = 0; w < words; ++w)
+                {
+                    const uint64_t m = label_words_of_pred ? label_words_of_pred[(size_t)q * W + w] : 0;
+                    // bits of this word that name a label of the graph
+                    const uint64_t valid = nl >= 64u * (w + 1) ? ~0ull : (nl > 64u * w ? ((1ull << (nl - 64u * w)) - 1) : 0ull);
+                    if (m & ~valid)
+                        return pg_fail(ctx, PG_ERR_INVALID, "label bit outside n_labels");
+                    lm[(size_t)q * W + w] = m;
+                    inm[(size_t)node * W + w] |= m;
+                    outm[(size_t)(nb + G->h_pred[q]) * W + w] |= m;
+                }
         cg[g].node_base = nb;
         cg[g].n_nodes = ne - nb;
         cg[g].n_labels = nl;
@@ -536,6 +551,7 @@ extern "C" pg_status pg_graphs_set_labels(
     }
     (void)pg_dev_free(G->d_count_block);
     G->d_count_block = nullptr;
+    G->label_words = words;
     PgStagedUpload up;  // seven tables, one copy
     up.add(cg, &G->d_cnt_graphs);
     up.add(G->h_pred_off, &G->d_cnt_pred_off);
@@ -546,6 +562,20 @@ extern "C" pg_status pg_graphs_set_labels(
     up.add(inm, &G->d_in_mask);
     HIP_TRY(ctx, up.commit(ctx->stream_copy, &G->d_count_block));
     G->labels_set = true;
+    return PG_OK;
+}
+
+extern "C" pg_status pg_graphs_set_labels(
+    pg_ctx* ctx, pg_graphs* G, const uint64_t* label_mask_of_pred, const uint32_t* n_labels)
+{
+    return pg_graphs_set_labels_wide(ctx, G, label_mask_of_pred, 1, n_labels);
+}
+
+extern "C" pg_status pg_graphs_label_words(const pg_graphs* G, uint32_t* words)
+{
+    if (!G || !words || !G->labels_set)
+        return PG_ERR_INVALID;
+    *words = G->label_words;
     return PG_OK;
 }
 
@@ -690,6 +720,23 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     a.label_mask = G->d_label_mask;
     a.out_mask = G->d_out_mask;
     a.in_mask = G->d_in_mask;
+    a.label_words = G->label_words;
+    b->label_ext_words = G->label_words - 1;
+    if (b->label_ext_words)
+    {
+        const size_t need = std::max<size_t>(n, 1) * b->label_ext_words;
+        if (need > b->cap_label_ext)
+        {
+            HIP_TRY(ctx, pg_batch_wait(ctx, b));
+            (void)pg_dev_free(b->d_label_ext);
+            b->d_label_ext = nullptr;
+            b->cap_label_ext = 0;
+            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_label_ext, need * sizeof(uint64_t)));
+            b->cap_label_ext = need;
+        }
+        HIP_TRY(ctx, hipMemsetAsync(b->d_label_ext, 0, need * sizeof(uint64_t), cs));  // reads that are not MAPPED write nothing
+    }
+    a.label_ext = b->d_label_ext;
     a.support = b->d_support;
     a.path = b->d_path;
     a.path_counter = b->d_path_counter;
@@ -719,6 +766,22 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, pg_stage_end_on(ctx, b, cs));
+    return PG_OK;
+}
+
+extern "C" pg_status pg_batch_download_label_ext(pg_ctx* ctx, pg_batch* b, uint64_t* label_ext, uint64_t cap_words)
+{
+    if (!ctx || !b || !b->graphs || !b->d_support)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_download_label_ext: pg_batch_count has not run");
+    const uint64_t need = (uint64_t)b->n_reads * b->label_ext_words;
+    if (need == 0)
+        return PG_OK;
+    if (!label_ext || cap_words < need)
+        return pg_fail(ctx, PG_ERR_OVERFLOW, "label_ext buffer too small (n_reads x (words - 1))");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, pg_batch_wait(ctx, b));
+    HIP_TRY(ctx, hipMemcpyAsync(label_ext, b->d_label_ext, need * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream_copy));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
     return PG_OK;
 }
 

@@ -98,9 +98,10 @@ struct pg_graphs
     uint32_t* d_cnt_pred_off = nullptr;
     uint32_t* d_cnt_pred = nullptr;
     uint32_t* d_cnt_node_len = nullptr;
-    uint64_t* d_label_mask = nullptr;  // per predecessor entry
-    uint64_t* d_out_mask = nullptr;    // per node: labels on outgoing edges
-    uint64_t* d_in_mask = nullptr;     // per node: labels on incoming edges
+    uint32_t label_words = 1;          // 64-bit words per label set (set-wide; pg_graphs_set_labels_wide)
+    uint64_t* d_label_mask = nullptr;  // per predecessor entry x label_words
+    uint64_t* d_out_mask = nullptr;    // per node x label_words: labels on outgoing edges
+    uint64_t* d_in_mask = nullptr;     // per node x label_words: labels on incoming edges
 };
 
 struct pg_batch
@@ -135,6 +136,9 @@ struct pg_batch
     bool has_active = false;
     uint32_t* d_graph_of_read = nullptr;
     pg_read_support* d_support = nullptr;
+    uint64_t* d_label_ext = nullptr;  // [n_reads][label_words - 1]: the label sets' words beyond pg_read_support.label_mask
+    size_t cap_label_ext = 0;
+    uint32_t label_ext_words = 0;     // words - 1 of the last pg_batch_count
     uint32_t* d_path = nullptr;
     unsigned long long* d_path_counter = nullptr;
     uint32_t* d_frag_off = nullptr;

@@ -41,6 +41,34 @@ private:
     double heights_[5] = { 0, 0, 0, 0, 0 }, actual_[5] = { 1, 2, 3, 4, 5 }, desired_[5] = { 1, 2, 3, 4, 5 };
 };
 
+// A set of sequence labels of one graph (bit i = SiteReadViews::label_names[i]).  The reference keeps label NAMES in std::sets
+// and has no bound on their number (src/c++/lib/paragraph/ReadCounting.cpp:96-127); the device keeps bit sets of up to
+// PG_LABEL_WORDS = 4 words (include/paragraph_amd.h), i.e. up to 256 labels on a graph.
+struct LabelSet
+{
+    static constexpr unsigned WORDS = 4;
+    uint64_t w[WORDS] = { 0, 0, 0, 0 };
+    LabelSet() = default;
+    LabelSet(uint64_t w0) { w[0] = w0; }  // (implicit: the ABI's first word)
+    void set(size_t b) { w[b >> 6] |= 1ull << (b & 63); }
+    bool test(size_t b) const { return b < 64 * WORDS && ((w[b >> 6] >> (b & 63)) & 1) != 0; }
+    bool any() const { return (w[0] | w[1] | w[2] | w[3]) != 0; }
+    LabelSet& operator|=(LabelSet const& o)
+    {
+        for (unsigned i = 0; i < WORDS; ++i)
+            w[i] |= o.w[i];
+        return *this;
+    }
+    bool operator==(LabelSet const& o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2] && w[3] == o.w[3]; }
+    bool operator<(LabelSet const& o) const
+    {
+        for (unsigned i = WORDS; i-- > 0;)
+            if (w[i] != o.w[i])
+                return w[i] < o.w[i];
+        return false;
+    }
+};
+
 // What the statistics need of one read that survived alignment + filters, independent of where it is kept (a common::Read
 // with its graph CIGAR string, or the flat device results of a packed batch)
 struct MappedReadView
@@ -52,7 +80,7 @@ struct MappedReadView
     bool is_mapped = false, is_mate_mapped = false, is_reverse_strand = false, is_mate_reverse_strand = false;
     bool is_graph_mapped = false, is_graph_reverse_strand = false;
     uint32_t pieces_off = 0, n_pieces = 0;  // node alignments in SiteReadViews::pieces
-    uint64_t sequences = 0;                 // supported sequence labels, bit i = SiteReadViews::label_names[i]
+    LabelSet sequences;                     // supported sequence labels, bit i = SiteReadViews::label_names[i]
     uint32_t support_off = 0, n_support = 0;  // PG_PATH-coded path entries in SiteReadViews::support (packed batches only)
 };
 

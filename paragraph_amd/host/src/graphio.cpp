@@ -574,7 +574,7 @@ SiteReadViews viewsOfReads(Graph const& graph, std::vector<common::Read const*> 
         {
             const auto it = std::lower_bound(v.label_names.begin(), v.label_names.end(), name);
             if (it != v.label_names.end() && *it == name)
-                m.sequences |= 1ull << (it - v.label_names.begin());
+                m.sequences.set((size_t)(it - v.label_names.begin()));
         }
         v.reads.push_back(m);
     }
@@ -793,7 +793,7 @@ Json alignmentStatistics(Graph const& graph, SiteReadViews const& views)
         }
         for (size_t b = 0; b < views.label_names.size(); ++b)
         {
-            if (!((read.sequences >> b) & 1))
+            if (!read.sequences.test(b))
                 continue;
             if (!allele_seen[b])
             {

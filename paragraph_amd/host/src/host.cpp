@@ -205,9 +205,20 @@ BatchPool batchPool(int slot = 0) { return BatchPool{ deviceSlot(slot) }; }
 struct GraphCsr
 {
     std::vector<uint32_t> node_off{ 0 }, seq_off{ 0 }, pred_off{ 0 }, pred, n_labels;
-    std::vector<uint64_t> label_mask;
+    // label sets of the edges, in predecessor-entry order: bit sets of `label_words` 64-bit words each (one word unless a graph
+    // of the set has more than 64 labels: pg_graphs_set_labels_wide).  Kept as lists of bit indices until the set is complete.
+    std::vector<std::vector<uint16_t>> label_bits;
+    uint32_t label_words = 1;
+    std::vector<uint64_t> label_mask;  // [pred entry][label_words], made by finish()
     std::string seq;
     std::vector<std::vector<std::string>> label_names;  // per graph, sorted
+    void finish()
+    {
+        label_mask.assign(label_bits.size() * (size_t)label_words, 0);
+        for (size_t q = 0; q < label_bits.size(); ++q)
+            for (uint16_t b : label_bits[q])
+                label_mask[q * label_words + (b >> 6)] |= 1ull << (b & 63);
+    }
     void add(const Graph& g)
     {
         std::vector<std::string> names;
@@ -215,8 +226,9 @@ struct GraphCsr
             auto all = g.allLabels();
             names.assign(all.begin(), all.end());
         }
-        if (names.size() > 64)
-            throw OutsideEnvelope("more than 64 sequence labels on one graph (paragraph_amd.h: PG_MAX_LABELS)");
+        if (names.size() > PG_MAX_LABELS)
+            throw OutsideEnvelope("more than 256 sequence labels on one graph (paragraph_amd.h: PG_MAX_LABELS)");
+        label_words = std::max<uint32_t>(label_words, (uint32_t)((names.size() + 63) / 64));
         for (NodeId n = 0; n != g.numNodes(); ++n)
         {
             const std::string& s = g.nodeSeq(n);
@@ -232,10 +244,10 @@ struct GraphCsr
             for (NodeId p : g.predecessors(n))
             {
                 pred.push_back(p);
-                uint64_t m = 0;
+                std::vector<uint16_t> bits;
                 for (auto const& l : g.edgeLabels(p, n))
-                    m |= 1ull << (std::lower_bound(names.begin(), names.end(), l) - names.begin());
-                label_mask.push_back(m);
+                    bits.push_back((uint16_t)(std::lower_bound(names.begin(), names.end(), l) - names.begin()));
+                label_bits.push_back(std::move(bits));
             }
             pred_off.push_back((uint32_t)pred.size());
         }
@@ -1133,6 +1145,14 @@ struct SiteBatcher::Impl::Run
     std::vector<uint64_t> seq_off;
     pghost::PinnedVec<uint32_t> table, path;
     pghost::PinnedVec<pg_read_support> sup;
+    std::vector<uint64_t> label_ext;  // [read][csr.label_words - 1]: the label sets' words beyond pg_read_support.label_mask
+    LabelSet labelSetOf(uint64_t i) const
+    {
+        LabelSet ls(sup[i].label_mask);
+        for (uint32_t w = 1; w < csr.label_words; ++w)
+            ls.w[w] = label_ext[i * (csr.label_words - 1) + (w - 1)];
+        return ls;
+    }
     pg_count_layout lay{};
 };
 
@@ -1222,6 +1242,7 @@ void SiteBatcher::Impl::Run::graphCsr()
 {
     for (const Graph* g : impl.graphs)
         csr.add(*g);
+    csr.finish();
 }
 
 void SiteBatcher::Impl::Run::packReads()
@@ -1331,8 +1352,9 @@ void SiteBatcher::Impl::Run::deviceSection()
                 pg_graphs_destroy(c, g);
         }
     } guard{ ctx, G, nullptr, false, prm.device };
-    check(ctx, pg_graphs_set_labels(ctx, G, csr.label_mask.empty() ? nullptr : csr.label_mask.data(), csr.n_labels.data()),
-          "pg_graphs_set_labels");
+    check(ctx, pg_graphs_set_labels_wide(ctx, G, csr.label_mask.empty() ? nullptr : csr.label_mask.data(), csr.label_words,
+                                         csr.n_labels.data()),
+          "pg_graphs_set_labels_wide");
     // ... and so are the per-graph indexes of the optional stages and of the KmerFilter
     std::vector<uint32_t> path_off{ 0 }, path_node_off{ 0 }, path_nodes;
     if ((prm.kmer_sequence_matching || prm.klib_sequence_matching) && n)
@@ -1436,6 +1458,11 @@ void SiteBatcher::Impl::Run::deviceSection()
     path.resize(n_path + 1);
     check(ctx, pg_batch_download_counts(ctx, guard.b, table.data(), sup.data(), path.data(), path.size(), &n_path),
           "pg_batch_download_counts");
+    if (csr.label_words > 1)
+    {
+        label_ext.assign((size_t)n * (csr.label_words - 1), 0);
+        check(ctx, pg_batch_download_label_ext(ctx, guard.b, label_ext.data(), label_ext.size()), "pg_batch_download_label_ext");
+    }
     guard.finished = true;
     mark("results down");
 }
@@ -1513,8 +1540,9 @@ void SiteBatcher::Impl::Run::resultsToReads()
             for (auto const& e : edges)
                 read.add_graph_edges_supported(e.first + "_" + e.second);
             const auto& names = csr.label_names[gor[i]];
+            const LabelSet labels = labelSetOf(i);
             for (size_t b = 0; b < names.size(); ++b)
-                if ((sup[i].label_mask >> b) & 1)
+                if (labels.test(b))
                     read.add_graph_sequences_supported(names[b]);
         },
         512);
@@ -1580,7 +1608,7 @@ void SiteBatcher::Impl::Run::viewsOfPackedSites()
                     }
                 }
                 m.n_pieces = (uint32_t)v.pieces.size() - m.pieces_off;
-                m.sequences = sup[i].label_mask;
+                m.sequences = labelSetOf(i);
                 m.support_off = (uint32_t)v.support.size();
                 m.n_support = sup[i].n_path;
                 v.support.insert(v.support.end(), path.begin() + sup[i].path_off, path.begin() + sup[i].path_off + sup[i].n_path);
@@ -1647,7 +1675,7 @@ void SiteBatcher::Impl::Run::siteTables()
                 // supports the union of its MAPPED reads' sets
                 struct Agg
                 {
-                    uint64_t labels = 0;
+                    LabelSet labels;
                     uint32_t n = 0, fwd = 0, rev = 0;
                 };
                 std::map<uint32_t, Agg> fragments;
@@ -1656,7 +1684,7 @@ void SiteBatcher::Impl::Run::siteTables()
                     if (sup[i].status != 1)
                         continue;
                     Agg& f = fragments[frag[i]];
-                    f.labels |= sup[i].label_mask;
+                    f.labels |= labelSetOf(i);
                     ++f.n;
                     const bool graph_rev = (res[i].status & PG_STATUS_PATH_ALIGNER) ? res[i].returned_reverse != 0
                                                                                     : (is_rev[i] != 0) != (res[i].returned_reverse != 0);
@@ -1664,11 +1692,11 @@ void SiteBatcher::Impl::Run::siteTables()
                 }
                 for (auto const& kv : fragments)
                 {
-                    if (!kv.second.labels)
+                    if (!kv.second.labels.any())
                         continue;
                     std::string key;
                     for (size_t b = 0; b < names.size(); ++b)
-                        if ((kv.second.labels >> b) & 1)
+                        if (kv.second.labels.test(b))
                             key += (key.empty() ? "" : ",") + names[b];
                     CountEntry& e = sc.by_sequence[key];
                     e.count += 1;

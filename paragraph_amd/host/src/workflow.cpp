@@ -165,7 +165,8 @@ void addDetailedCounts(Json& by_sequence, graphtools::Graph const& graph, SiteRe
     // "<from>_<to>" would be ONE element of the original's name sets, so such graphs take the name-keyed path.
     struct Support
     {
-        uint64_t reads = 0, fwd = 0, rev = 0, sequences = 0;
+        uint64_t reads = 0, fwd = 0, rev = 0;
+        LabelSet sequences;
         std::vector<uint32_t> nodes;
         std::vector<uint64_t> edges;  // from << 32 | to
     };
@@ -215,12 +216,12 @@ void addDetailedCounts(Json& by_sequence, graphtools::Graph const& graph, SiteRe
         c.fwd += f.fwd;
         c.rev += f.rev;
     };
-    std::map<uint64_t, std::pair<std::map<uint32_t, Counter>, std::map<uint64_t, Counter>>> by_family;  // by label bit set
-    std::map<uint64_t, std::map<std::string, Counter>> by_family_named;                                    // ambiguous names
+    std::map<LabelSet, std::pair<std::map<uint32_t, Counter>, std::map<uint64_t, Counter>>> by_family;  // by label bit set
+    std::map<LabelSet, std::map<std::string, Counter>> by_family_named;                                    // ambiguous names
     for (uint32_t id : order)
     {
         Support& f = fragments[id];
-        if (!f.sequences)
+        if (!f.sequences.any())
             continue;
         std::sort(f.nodes.begin(), f.nodes.end());
         f.nodes.erase(std::unique(f.nodes.begin(), f.nodes.end()), f.nodes.end());
@@ -243,10 +244,10 @@ void addDetailedCounts(Json& by_sequence, graphtools::Graph const& graph, SiteRe
         for (uint64_t e : f.edges)
             add(tables.second[e], f);
     }
-    auto family_name = [&](uint64_t mask) {
+    auto family_name = [&](LabelSet const& mask) {
         std::string family;  // label_names are sorted, so this is the sorted join
         for (size_t b = 0; b < views.label_names.size(); ++b)
-            if ((mask >> b) & 1)
+            if (mask.test(b))
                 family += (family.empty() ? "" : ",") + views.label_names[b];
         return family;
     };

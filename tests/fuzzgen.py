@@ -119,6 +119,26 @@ def rand_labels(rng, edges, max_labels=4):
     return out, sorted(names)
 
 
+def rand_path_labels(rng, n_nodes, edges, n_labels):
+    """Many labels the way haplotypes make them: every label names one random source-to-sink walk of the graph and sits on all
+    of its edges.  -> {(from,to): [names]}, sorted name list (names L000, L001, ...)."""
+    succ = {}
+    for f, t in edges:
+        succ.setdefault(f, []).append(t)
+    starts = [n for n in range(n_nodes) if n in succ and not any(t == n for _, t in edges)] or [min(succ)] if succ else []
+    names = ["L%03d" % i for i in range(n_labels)]
+    out = {}
+    for name in names:
+        if not starts:
+            break
+        n = rng.choice(starts)
+        while n in succ:
+            t = rng.choice(succ[n])
+            out.setdefault((n, t), []).append(name)
+            n = t
+    return out, names
+
+
 def rand_fragments(rng, n):
     """Fragment ids: mostly pairs, some singletons, a few fragments with 3 reads."""
     ids = []

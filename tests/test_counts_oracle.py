@@ -96,6 +96,36 @@ def test_port_vs_reference_graphtools_randomized(checker):
     assert n == 1200
 
 
+def test_checkers_with_more_than_64_labels(checker):
+    """Label sets beyond one 64-bit word: the checker built on the reference's own graph-tools / Disambiguation code (whose label
+    sets are std::sets of names: no bound) hands them out as four words; it must agree with the restatement on graphs of
+    65 .. 200 labels."""
+    if not oc.have_ref():
+        pytest.skip("oracle/_ref/libpg_refcounts.so not built")
+    ref = oc.RefCounts()
+    rng = random.Random(6565)
+    n = beyond = 0
+    for _ in range(60):
+        seqs, edges = fuzzgen.rand_graph(rng, max_len=40, max_nodes=6)
+        if not edges:
+            continue
+        lab, names = fuzzgen.rand_path_labels(rng, len(seqs), edges, rng.choice([65, 66, 100, 128, 129, 200]))
+        reads = [fuzzgen.rand_read(rng, seqs, edges, min_len=10, max_len=90) for _ in range(rng.randint(4, 12))]
+        fr = fuzzgen.rand_fragments(rng, len(reads))
+        rv = [rng.random() < 0.5 for _ in reads]
+        al = checker.align_batch(seqs, edges, reads)
+        recs = [{"pos": a["graph_pos"], "cigar": a["cigar"], "aligned": a["score"] > 0, "unique": a["unique"],
+                 "graph_reverse": rv[i] != a["returned_reverse"], "read_len": len(r), "fragment": fr[i]}
+                for i, (a, r) in enumerate(zip(al, reads))]
+        g = oc.CountGraph(seqs, edges, lab, names)
+        x = ref.count_site(g, recs, remove_nonuniq=False)
+        y = oc.port_count_site(g, recs, remove_nonuniq=False)
+        assert x["rc"] == 0 and same(x, y), (seqs, edges, recs)
+        beyond += sum(1 for ls in x["labels"] if any(names.index(l) >= 64 for l in ls))
+        n += 1
+    assert n >= 40 and beyond >= 50
+
+
 def test_path_checker_unit_vectors_and_port_vs_ref():
     """PathAligner checkers: reference unit tests (src/c++/test/test_pathaligner.cpp:37-144, k = 16) and the
     pure-Python port against the harness built on the reference's graph-tools."""

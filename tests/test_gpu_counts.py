@@ -36,7 +36,7 @@ def gpu_counts(ctx, graphs, labels, names, reads, gor, frag, isrev, filter_k=0, 
     b.set_fragments(frag, isrev)
     b.count(**kw)
     table, sup, path = b.download_counts()
-    out = (capi.results_to_dicts(res, ops), capi.decode_supports(G, gor, sup, path), capi.decode_counts(G, table))
+    out = (capi.results_to_dicts(res, ops), capi.decode_supports(G, gor, sup, path, b.download_label_sets(sup)), capi.decode_counts(G, table))
     b.close()
     G.close()
     return out
@@ -97,6 +97,60 @@ def test_counts_fuzz(gpu_ctx, checker):
             for ei, e in enumerate(cg_edges):
                 assert c["edge_counts"][e] == [int(x) for x in w["edge_counts"][ei]], (gi, e)
             assert c["seq_counts"] == w["seq_counts"], (gi, c["seq_counts"], w["seq_counts"])
+
+
+def test_more_than_64_labels_on_a_graph(gpu_ctx, checker):
+    """Label sets beyond one 64-bit word (pg_graphs_set_labels_wide: up to 256 labels on a graph; the reference's path
+    families have no bound, ReadCounting.cpp:96-127): graphs with 65 .. 200 labels beside ordinary ones in ONE graph set --
+    per-read status, supports and label sets, node and edge tables against the reference's code."""
+    from oracle import counts as oc
+    check = count_checker()
+    rng = random.Random(fuzzgen.salted(6565))
+    graphs, labels, names, reads, gor, frag, isrev, want = [], [], [], [], [], [], [], []
+    n_wide = 0
+    for gi in range(60):
+        seqs, edges = fuzzgen.rand_graph(rng, max_len=40, max_nodes=6)
+        if gi % 2 == 0 and edges:
+            lab, nm = fuzzgen.rand_path_labels(rng, len(seqs), edges, rng.choice([65, 66, 100, 128, 129, 200]))
+            n_wide += 1
+        else:
+            lab, nm = fuzzgen.rand_labels(rng, edges)
+        rs = [fuzzgen.rand_read(rng, seqs, edges, min_len=10, max_len=90) for _ in range(rng.randint(4, 14))]
+        fr = fuzzgen.rand_fragments(rng, len(rs))
+        rv = [rng.random() < 0.5 for _ in rs]
+        al = checker.align_batch(seqs, edges, rs)
+        recs = [{"pos": a["graph_pos"], "cigar": a["cigar"], "aligned": a["score"] > 0, "unique": a["unique"],
+                 "graph_reverse": rv[i] != a["returned_reverse"], "read_len": len(r), "fragment": fr[i]}
+                for i, (a, r) in enumerate(zip(al, rs))]
+        want.append(check(oc.CountGraph(seqs, edges, lab, nm), recs, remove_nonuniq=False, use_support_filters=True))
+        graphs.append((seqs, edges))
+        labels.append(lab)
+        names.append(nm)
+        reads.extend(rs)
+        gor.extend([gi] * len(rs))
+        frag.extend(fr)
+        isrev.extend(rv)
+    assert n_wide >= 15
+    al, sup, cnt = gpu_counts(gpu_ctx, graphs, labels, names, reads, gor, frag, isrev, remove_nonuniq=False, use_support_filters=True)
+    k = 0
+    beyond_first_word = 0
+    for gi, w in enumerate(want):
+        n = len(w["status"])
+        for i in range(n):
+            s = sup[k + i]
+            assert s["status"] == w["status"][i], (gi, i, s, w["status"][i])
+            if s["status"] == 1:
+                assert s["nodes"] == w["nodes"][i] and s["edges"] == w["edges"][i] and s["labels"] == set(w["labels"][i]), \
+                    (gi, len(names[gi]), sorted(s["labels"])[:5], sorted(w["labels"][i])[:5])
+                beyond_first_word += any(names[gi].index(l) >= 64 for l in s["labels"])
+        k += n
+        c = cnt[gi]
+        assert (c["node_counts"] == w["node_counts"]).all(), (gi, c["node_counts"], w["node_counts"])
+        for ei, e in enumerate([tuple(e) for e in graphs[gi][1]]):
+            assert c["edge_counts"][e] == [int(x) for x in w["edge_counts"][ei]], (gi, e)
+        if len(names[gi]) <= 8:
+            assert c["seq_counts"] == w["seq_counts"], (gi, c["seq_counts"], w["seq_counts"])
+    assert beyond_first_word >= 20
 
 
 def _rc(s):

@@ -213,7 +213,7 @@ def test_many_tiny_nodes(gpu_ctx, checker):
 
 def test_documented_limits_fail_loudly(gpu_ctx):
     """Every limit of the envelope (include/paragraph_amd.h) answers with PG_ERR_UNSUPPORTED -- never with a wrong result:
-    65 536 nodes, 65 labels, 31 klib paths, a 16 001-base read.  (Round 3: more than 4 095 nodes, a direction longer than 65 519
+    65 536 nodes, 257 labels, 31 klib paths, a 16 001-base read.  (Round 3: more than 4 095 nodes, a direction longer than 65 519
     columns and reads of 513..16 000 bases are no longer limits -- they take the general path, tests/test_gpu_general.py.)"""
     from paragraph_amd import capi
     chain = (["A"] * 65536, [(i, i + 1) for i in range(65535)])
@@ -223,11 +223,12 @@ def test_documented_limits_fail_loudly(gpu_ctx):
     gpu_ctx.upload_graphs([(["ACGT"] * 4096, [(i, i + 1) for i in range(4095)])]).close()  # general path
     gpu_ctx.upload_graphs([(["A" * 40000, "C" * 25600], [(0, 1)])]).close()  # general path
     G = gpu_ctx.upload_graphs([ALIGNS_GRAPH])
-    names = ["L%02d" % i for i in range(65)]
+    names = ["L%03d" % i for i in range(257)]
     with pytest.raises(capi.PgError) as e:
-        G.set_labels([{(0, 1): names[:1]}], [names])  # 65 labels declared
+        G.set_labels([{(0, 1): names[:1]}], [names])  # 257 labels declared
     assert e.value.status == 4
-    G.set_labels([{(0, 1): names[:64]}], [names[:64]])  # 64 labels are in
+    G.set_labels([{(0, 1): names[:256]}], [names[:256]])  # 256 labels are in (four words: tests/test_gpu_counts.py)
+    G.set_labels([{(0, 1): names[:64]}], [names[:64]])
     with pytest.raises(capi.PgError) as e:
         G.build_klib_index([[[0, 1, 3]] * 31])
     assert e.value.status == 4

@@ -414,12 +414,13 @@ def test_config1_multigrmpy_from_json_events(tmp_path):
 
 
 def test_one_oversize_site_does_not_take_the_run_down(tmp_path):
-    """201 graphs of which four are outside the packed kernels' envelope -- a 600 bp read over one site, a 5 000-node graph, a
-    70 000-column graph, a graph with 65 sequence labels; the reference has no such bounds (gssw.c:527-786,
+    """202 graphs of which five are outside the packed kernels' envelope -- a 600 bp read over one site, a 5 000-node graph, a
+    70 000-column graph, a graph with 65 sequence labels, a graph with 257; the reference has no such bounds (gssw.c:527-786,
     GraphAligner.cpp:110-167, ReadCounting.cpp:96-127).  The long read, the many nodes and the many columns go through the
-    general path (pg_general.hip; parity with the reference's gssw.c: tests/test_gpu_general.py) and come out as ordinary
-    documents; the 65-label graph says why it was skipped under "error"; the 197 other genotype documents equal those of a
-    run over the 197 alone."""
+    general path (pg_general.hip; parity with the reference's gssw.c: tests/test_gpu_general.py), the 65 labels through the wide
+    label sets (two words; parity with the reference's counting code: tests/test_gpu_counts.py::
+    test_more_than_64_labels_on_a_graph) and come out as ordinary documents; the 257-label graph says why it was skipped under
+    "error"; the 197 other genotype documents equal those of a run over the 197 alone."""
     import sys
     from paragraph_amd import workflow
     data = tmp_path / "sites"
@@ -428,28 +429,31 @@ def test_one_oversize_site_does_not_take_the_run_down(tmp_path):
     assert r.returncode == 0, r.stderr
     graphs = [l.strip() for l in open(data / "graphs.txt") if l.strip()]
     extra = [l.strip() for l in open(data / "extra_graphs.txt") if l.strip()]
-    assert len(graphs) == 198 and len(extra) == 3
+    assert len(graphs) == 198 and len(extra) == 4
     ref, manifest = str(data / "ref.fa"), str(data / "manifest.txt")
-    everything = graphs[:50] + [extra[0]] + graphs[50:120] + [extra[1]] + graphs[120:160] + [extra[2]] + graphs[160:]  # the odd ones in the middle of batches
+    # the odd ones in the middle of batches
+    everything = graphs[:50] + [extra[0]] + graphs[50:90] + [extra[3]] + graphs[90:120] + [extra[1]] + graphs[120:160] + [extra[2]] + graphs[160:]
     docs = workflow.genotype_graphs(ref, manifest, everything, threads=4, lanes=2, sites_per_batch=32)
-    assert len(docs) == 201
+    assert len(docs) == 202
     by_id = {d["graphinfo"]["ID"]: d for d in docs}
-    bad = {"many_labels": "64"}
+    bad = {"too_many_labels": "256"}
     for gid, why in bad.items():
         assert "error" in by_id[gid] and why in by_id[gid]["error"], (gid, by_id[gid].get("error"))
-    for gid in ("site_197", "many_columns", "many_nodes"):  # the general path: ordinary documents with reads counted
+    for gid in ("site_197", "many_columns", "many_nodes", "many_labels"):  # ordinary documents with reads counted
         assert "error" not in by_id[gid], by_id[gid].get("error")
         assert by_id[gid]["samples"]["SYN"]["gt"]["num_reads"] > 0, by_id[gid]["samples"]["SYN"]["gt"]
+    assert len(by_id["many_labels"]["graphinfo"]["sequencenames"]) == 65
     good = workflow.genotype_graphs(ref, manifest, graphs[:197], threads=4, lanes=2, sites_per_batch=32)
     assert len(good) == 197 and not any("error" in d for d in good)
     for d in good:
         assert by_id[d["graphinfo"]["ID"]] == d, d["graphinfo"]["ID"]
-    # the object form isolates the same way
-    objects = workflow.genotype_graphs(ref, manifest, everything[155:170], threads=2, lanes=1, sites_per_batch=15, packed_reads=False)
+    # the object form isolates the same way, and counts the 65-label graph the same way
+    span = everything[85:100] + [extra[2]]
+    objects = workflow.genotype_graphs(ref, manifest, span, threads=2, lanes=1, sites_per_batch=16, packed_reads=False)
     assert [("error" in d) for d in objects] == [d["graphinfo"]["ID"] in bad for d in objects] and sum("error" in d for d in objects) == 1
     for d in objects:
         if "error" not in d:
-            assert by_id[d["graphinfo"]["ID"]] == d
+            assert by_id[d["graphinfo"]["ID"]] == d, d["graphinfo"]["ID"]
 
 
 def _graphs_of_expected_genotypes(expected, folder):

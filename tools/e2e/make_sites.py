@@ -126,9 +126,16 @@ def main():
                   {"name": "RF", "reference": "chr1:%d-%d" % (spacing * 3 + 1, spacing * 3 + flank)}]
         ledges = [{"from": "LF", "to": "MID", "sequences": labels65[:33]}, {"from": "LF", "to": "RF", "sequences": labels65[33:]},
                   {"from": "MID", "to": "RF", "sequences": labels65[:33]}]
+        # ... and one graph with 257 labels: beyond the device's label sets (4 words of 64 bits), the one site that is reported
+        labels257 = ["M%03d" % k for k in range(257)]
+        xnodes = [{"name": "LF", "reference": "chr1:%d-%d" % (spacing * 4 - flank + 1, spacing * 4)},
+                  {"name": "MID", "sequence": "ACGTTGCAACGTACGT"},
+                  {"name": "RF", "reference": "chr1:%d-%d" % (spacing * 4 + 1, spacing * 4 + flank)}]
+        xedges = [{"from": "LF", "to": "MID", "sequences": labels257[:129]}, {"from": "LF", "to": "RF", "sequences": labels257[129:]},
+                  {"from": "MID", "to": "RF", "sequences": labels257[:129]}]
         with open(os.path.join(out, "extra_graphs.txt"), "w") as xf:
             for name, nodes_x, edges_x, site, seqnames in (("many_nodes", chain, cedges, 1, ["ALT", "REF"]), ("many_columns", wide, wedges, 2, ["ALT", "REF"]),
-                                                           ("many_labels", lnodes, ledges, 3, labels65)):
+                                                           ("many_labels", lnodes, ledges, 3, labels65), ("too_many_labels", xnodes, xedges, 4, labels257)):
                 gp = os.path.join(out, "graphs", name + ".json")
                 with open(gp, "w") as f:
                     json.dump({"ID": name, "nodes": nodes_x, "edges": edges_x, "sequencenames": seqnames,

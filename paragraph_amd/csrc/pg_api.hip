@@ -1140,6 +1140,10 @@ static pg_status run_general(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));  // an earlier launch may still read h_gen_reads / the general workspace (rare path)
     b->h_gen_reads.assign(n, PgGenRead{});
+    // The general workspace comes ON TOP of the packed kernels' (which may hold up to the whole budget): groups are cut at a
+    // budget of its own, 8 GiB or the context's limit if that is smaller -- a single read beyond that (within the limit: checked
+    // by plan_items) is a group by itself.
+    const uint64_t gen_limit = std::min<uint64_t>(ctx->ws_limit, 8ull << 30);
     std::vector<std::pair<size_t, size_t>> groups;
     uint64_t cur = 0, largest = 0;
     size_t begin = 0;
@@ -1151,7 +1155,7 @@ static pg_status run_general(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         const uint64_t need = pg_gen_read_bytes(L, hg.ncols, hg.n_nodes);
         if (need > ctx->ws_limit)
             return fail(ctx, PG_ERR_UNSUPPORTED, "workspace limit too small for one read of the general path (read length x graph columns)");
-        if (cur + need > ctx->ws_limit)
+        if (cur + need > gen_limit && i > begin)
         {
             groups.emplace_back(begin, i);
             begin = i;
@@ -1164,7 +1168,7 @@ static pg_status run_general(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         gr.seed_off = gr.h_off + pg_gen_align8(2 * (uint64_t)hg.ncols * L * 2);
         gr.col_off = gr.seed_off + pg_gen_align8(4 * 2 * (uint64_t)hg.n_nodes * L * 2);
         gr.node_off = gr.col_off + pg_gen_align8(4 * 2 * L * 2);
-        gr.ops_off = gr.node_off + pg_gen_align8(4 * (uint64_t)hg.n_nodes * 2 * 4);
+        gr.ops_off = gr.node_off + pg_gen_align8(4 * (uint64_t)hg.n_nodes * PG_GEN_NODE_BYTES);
         cur += need;
         largest = std::max(largest, cur);
     }
@@ -1191,6 +1195,12 @@ static pg_status run_general(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         ga.reads = b->d_gen_reads + grp.first;
         ga.n = (uint32_t)(grp.second - grp.first);
         ga.flags = flags;
+        ga.max_len = 0;
+        for (size_t i = grp.first; i < grp.second; ++i)
+        {
+            const uint32_t r = b->gen_idx[i];
+            ga.max_len = std::max<uint32_t>(ga.max_len, b->h_base_off[r + 1] - b->h_base_off[r]);
+        }
         ga.graphs = G->d_graphs;
         ga.nodes = G->d_nodes;
         ga.preds = G->d_preds;

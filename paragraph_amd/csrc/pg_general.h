@@ -22,6 +22,7 @@
 #include "pg_device.h"
 
 #define PG_GEN_MAX_READ_LEN 16000  // scores, CIGAR element lengths and n_ops stay inside their 16-bit fields
+#define PG_GEN_NODE_BYTES 16       // per fill and node: the node's key and first-half maximum (PgGenRead::node_off)
 
 // Workspace of one read on the general path (byte offsets from the start of the general workspace).
 struct PgGenRead
@@ -31,7 +32,9 @@ struct PgGenRead
     uint64_t h_off;     // int16 H[strand][column][row] of the two forward-graph fills
     uint64_t seed_off;  // int16 [fill 0..3][2 (H of the last column, E of the next column)][node][row]
     uint64_t col_off;   // int16 [fill][2 (H of the previous column, E of this column)][row]
-    uint64_t node_off;  // int32 [fill][node][2 (maximum over the node, maximum over the first half of its cells)]
+    uint64_t node_off;  // [fill][node] 16 bytes: u64 key of the node's first maximum (score | inverted column | inverted row),
+                        // u32 maximum over the first half of its cells, u32 unused (the scalar fill of the CPU test keeps two
+                        // int32 there: maximum, first-half maximum)
     uint64_t ops_off;   // uint32 CIGAR scratch, pg_gen_ops_cap(L) elements
 };
 
@@ -40,7 +43,8 @@ struct PgGenArgs
 {
     const PgGenRead* reads;
     uint32_t n;
-    uint32_t flags;  // PG_AF_*
+    uint32_t flags;    // PG_AF_*
+    uint32_t max_len;  // longest read of the launch (sizes the fill kernel's LDS columns)
     const PgGraphDev* graphs;
     const PgNode* nodes;
     const uint32_t* preds;
@@ -61,7 +65,7 @@ static inline __host__ __device__ uint64_t pg_gen_align8(uint64_t x) { return (x
 static inline __host__ __device__ uint64_t pg_gen_read_bytes(uint64_t L, uint64_t ncols, uint64_t n_nodes)
 {
     return pg_gen_align8(2 * ncols * L * 2) + pg_gen_align8(4 * 2 * n_nodes * L * 2) + pg_gen_align8(4 * 2 * L * 2)
-        + pg_gen_align8(4 * n_nodes * 2 * 4) + pg_gen_align8((uint64_t)pg_gen_ops_cap((uint32_t)L) * 4);
+        + pg_gen_align8(4 * n_nodes * PG_GEN_NODE_BYTES) + pg_gen_align8((uint64_t)pg_gen_ops_cap((uint32_t)L) * 4);
 }
 
 namespace pggen

@@ -7,7 +7,8 @@
 #include "../../include/paragraph_amd.h"
 #include "pg_device.h"
 
-constexpr int PG_KLIB_MAX_PATHS = 30;
+constexpr int PG_KLIB_MAX_PATHS = 30;        // candidate heaps of paths + 2 entries in registers (select / pick kernels)
+constexpr int PG_KLIB_MAX_PATHS_WIDE = 126;  // graphs with more paths: the same kernels with 128-entry heaps (scratch memory)
 
 struct LPathDev
 {

@@ -35,8 +35,8 @@
 
 namespace
 {
-constexpr int MAX_PATHS = PG_KLIB_MAX_PATHS;
-constexpr int HEAP_CAP = MAX_PATHS + 2;
+constexpr int MAX_PATHS = PG_KLIB_MAX_PATHS_WIDE;  // the envelope; graph sets of up to PG_KLIB_MAX_PATHS paths per graph run the
+                                                   // heap-replaying kernels with their heaps in registers
 // KlibAlignerImpl's scoring (KlibAligner.cpp:134-142): ksw charges gapo + gape for the first gap base
 constexpr int K_MATCH = 1, K_MISMATCH = -4, K_GAPO = 5, K_GAPE = 1, K_GAPOE = K_GAPO + K_GAPE;
 constexpr int K_MINUS_INF = -0x40000000;
@@ -589,7 +589,7 @@ __device__ void kheap_pop(HeapEnt* h, int& n)
 // Replays a read's candidate heap on the scores of the first pass (KlibAligner.cpp:388-442: push, evict the worst beyond
 // paths + 2) and puts the candidates the pick kernel can look at -- those holding the best score -- on the work list of the
 // finish kernel.
-__global__ __launch_bounds__(64) void pg_klib_select_kernel(KlibArgs a)
+template <int HEAP_CAP> __global__ __launch_bounds__(64) void pg_klib_select_kernel(KlibArgs a)
 {
     const uint32_t r = blockIdx.x * 64u + threadIdx.x;
     if (r >= a.n_reads || (a.active && !a.active[r]))
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(64) void pg_klib_select_kernel(KlibArgs a)
     if (a.base_off[r + 1] == a.base_off[r] || a.base_off[r + 1] - a.base_off[r] > a.len_limit)
         return;
     const LGraphDev g = a.graphs[a.graph_of_read[r]];
-    if (g.n_paths == 0 || g.n_paths > MAX_PATHS)
+    if (g.n_paths == 0 || (int)g.n_paths + 2 > HEAP_CAP)
         return;
     const uint32_t per_read = 2u * a.max_paths;
     const uint64_t item0 = (uint64_t)r * per_read;
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(64) void pg_klib_select_kernel(KlibArgs a)
             a.worklist[atomicAdd(a.work_count, 1u)] = (uint32_t)(item0 + heap[i].item);
 }
 
-__global__ __launch_bounds__(64) void pg_klib_pick_kernel(KlibArgs a)
+template <int HEAP_CAP> __global__ __launch_bounds__(64) void pg_klib_pick_kernel(KlibArgs a)
 {
     const uint32_t r = blockIdx.x * 64u + threadIdx.x;
     if (r >= a.n_reads || (a.active && !a.active[r]))
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(64) void pg_klib_pick_kernel(KlibArgs a)
     if (L == 0 || (uint32_t)L > a.len_limit)
         return;
     const LGraphDev g = a.graphs[a.graph_of_read[r]];
-    if (g.n_paths == 0 || g.n_paths > MAX_PATHS)
+    if (g.n_paths == 0 || (int)g.n_paths + 2 > HEAP_CAP)
         return;
     ReadView rv{ a.bases + off, L };
     const uint32_t per_read = 2u * a.max_paths;
@@ -812,7 +812,7 @@ extern "C" pg_status pg_graphs_build_klib_index(
         gd[g].path_off = path_off[g];
         gd[g].n_paths = path_off[g + 1] - path_off[g];
         if (gd[g].n_paths > (uint32_t)MAX_PATHS)
-            return pg_fail(ctx, PG_ERR_UNSUPPORTED, "more than 30 paths on one graph");
+            return pg_fail(ctx, PG_ERR_UNSUPPORTED, "more than 126 paths on one graph");
         max_paths = std::max(max_paths, gd[g].n_paths);
         for (uint32_t p = path_off[g]; p < path_off[g + 1]; ++p)
         {
@@ -986,7 +986,10 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
             a.pair_begin = c.pair_begin;
             HIP_TRY(ctx, pg_klib_launch_local(pg_var_c(c.C), a, c.pair_end - c.pair_begin, ctx->stream));
         }
-        hipLaunchKernelGGL(pg_klib_select_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
+        if (ix->max_paths <= (uint32_t)PG_KLIB_MAX_PATHS)
+            hipLaunchKernelGGL(pg_klib_select_kernel<PG_KLIB_MAX_PATHS + 2>, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(pg_klib_select_kernel<PG_KLIB_MAX_PATHS_WIDE + 2>, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
         HIP_TRY(ctx, hipGetLastError());
         // the size of the second pass is only known now (one small read-back; the stage's caller reads the flags back next anyway)
         uint32_t n_work = 0;
@@ -1039,7 +1042,10 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
         }
         HIP_TRY(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(pg_klib_pick_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
+    if (ix->max_paths <= (uint32_t)PG_KLIB_MAX_PATHS)
+        hipLaunchKernelGGL(pg_klib_pick_kernel<PG_KLIB_MAX_PATHS + 2>, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(pg_klib_pick_kernel<PG_KLIB_MAX_PATHS_WIDE + 2>, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
     stage_end.done = true;
     HIP_TRY(ctx, pg_stage_end(ctx, b));

@@ -26,7 +26,7 @@
 
 namespace
 {
-constexpr int MAX_PATHS = 30;
+constexpr int MAX_PATHS = 126;  // (the candidate heap of paths + 2 entries lives in LDS)
 constexpr int HEAP_CAP = MAX_PATHS + 2;
 
 struct KPathDev
@@ -544,7 +544,7 @@ extern "C" pg_status pg_graphs_build_kmer_index(
         gd[g].path_off = path_off[g];
         gd[g].n_paths = path_off[g + 1] - path_off[g];
         if (gd[g].n_paths > MAX_PATHS)
-            return pg_fail(ctx, PG_ERR_UNSUPPORTED, "more than 30 paths on one graph");
+            return pg_fail(ctx, PG_ERR_UNSUPPORTED, "more than 126 paths on one graph");
         for (uint32_t p = path_off[g]; p < path_off[g + 1]; ++p)
         {
             KPathDev kp{};

@@ -126,6 +126,54 @@ def test_klib_stage_fuzz_dags(gpu_ctx):
     assert n > 500
 
 
+def _bubble_chain(rng, n_bubbles, arm, flank):
+    """flank - (a | b) - link - (a | b) - ... - flank: 2^n_bubbles source-to-sink paths"""
+    seqs = ["".join(rng.choice("ACGT") for _ in range(flank))]
+    edges, layers = [], [[0]]
+    for _ in range(n_bubbles):
+        a, b = len(seqs), len(seqs) + 1
+        seqs += ["".join(rng.choice("ACGT") for _ in range(arm)), "".join(rng.choice("ACGT") for _ in range(arm))]
+        link = len(seqs)
+        seqs.append("".join(rng.choice("ACGT") for _ in range(12)))
+        prev = layers[-1][0]
+        edges += [(prev, a), (prev, b), (a, link), (b, link)]
+        layers.append([link])
+    seqs.append("".join(rng.choice("ACGT") for _ in range(flank)))
+    edges.append((layers[-1][0], len(seqs) - 1))
+    paths = []
+    for m in range(1 << n_bubbles):
+        p = [0]
+        for k in range(n_bubbles):
+            p += [1 + 3 * k + ((m >> k) & 1), 3 + 3 * k]
+        paths.append(p + [len(seqs) - 1])
+    return seqs, sorted(edges), paths
+
+
+@pytest.mark.parametrize("n_paths", [31, 64, 126])
+def test_more_than_30_paths_on_a_graph(gpu_ctx, n_paths):
+    """The stage's candidate heap holds paths + 2 entries (KlibAligner.cpp:388-442): up to 30 paths it lives in registers,
+    beyond that the select / pick kernels run with 128-entry heaps -- a chain of seven bubbles (128 haplotype paths, 31 / 64 / 126
+    of them given) against the reference's ksw.c under the restated KlibAligner."""
+    chk = checker()
+    rng = random.Random(fuzzgen.salted(3100 + n_paths))
+    seqs, edges, all_paths = _bubble_chain(rng, 7, 18, 160)
+    ps = rng.sample(all_paths, n_paths)
+    reads = []
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    for _ in range(60):
+        p = rng.choice(all_paths)  # (also haplotypes that are not among the given paths)
+        pseq = "".join(seqs[n] for n in p)
+        st = rng.randrange(len(pseq) - 150)
+        r = fuzzgen.mutate(rng, pseq[st:st + 150], sub=rng.choice([0.0, 0.01, 0.04]), indel=rng.choice([0.0, 0.0, 0.02]))[:200] or "A"
+        if rng.random() < 0.5:
+            r = "".join(comp[c] for c in reversed(r))
+        reads.append(r)
+    want = chk.align(seqs, ps, reads)
+    flags, got = gpu_klib(gpu_ctx, [(seqs, edges)], [ps], reads, None)
+    n = check(flags, got, want, reads, "klib-%d-paths" % n_paths)
+    assert n >= 50
+
+
 def test_klib_stage_150bp_site(gpu_ctx):
     """Reads of the bench's shape (150 bp, ~500 bp of paths) incl. indel-bearing ones: R = 3 rows per lane."""
     chk = checker()

@@ -66,6 +66,30 @@ def test_a_read_beyond_the_stage_limit_is_left_to_the_later_stages(gpu_ctx):
     assert f1[1] == 0 and g1[1]["score"] == 0 and g1[1]["cigar"] == ""
 
 
+@pytest.mark.parametrize("n_paths", [31, 64, 126])
+def test_more_than_30_paths_on_a_graph(gpu_ctx, n_paths):
+    """The stage's candidate heap holds paths + 2 entries (KmerAligner.cpp:388-442 replayed in LDS): graphs with up to 126
+    paths -- a chain of seven bubbles (128 haplotype paths, 31 / 64 / 126 given) against the restatement."""
+    from oracle import kmeralign as ka
+    from tests.test_gpu_klib import _bubble_chain
+    rng = random.Random(fuzzgen.salted(4100 + n_paths))
+    seqs, edges, all_paths = _bubble_chain(rng, 7, 18, 160)
+    ps = rng.sample(all_paths, n_paths)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    reads = []
+    for _ in range(60):
+        pseq = "".join(seqs[n] for n in rng.choice(all_paths))
+        st = rng.randrange(len(pseq) - 100)
+        r = fuzzgen.mutate(rng, pseq[st:st + 100], sub=rng.choice([0.0, 0.01, 0.02]), indel=0.0) or "A"
+        if rng.random() < 0.5:
+            r = "".join(comp[c] for c in reversed(r))
+        reads.append(r)
+    want = ka.port_kmer_align(seqs, ps, reads, 16)
+    flags, got = gpu_kmer(gpu_ctx, [(seqs, edges)], [ps], reads, None, 16)
+    n = check(flags, got, want, reads, "kmer-%d-paths" % n_paths)
+    assert n >= 25
+
+
 def _rand_paths(rng, n_nodes, edges):
     succ = {}
     for f, t in edges:

@@ -213,7 +213,7 @@ def test_many_tiny_nodes(gpu_ctx, checker):
 
 def test_documented_limits_fail_loudly(gpu_ctx):
     """Every limit of the envelope (include/paragraph_amd.h) answers with PG_ERR_UNSUPPORTED -- never with a wrong result:
-    65 536 nodes, 257 labels, 31 klib paths, a 16 001-base read.  (Round 3: more than 4 095 nodes, a direction longer than 65 519
+    65 536 nodes, 257 labels, 127 klib paths, a 16 001-base read.  (Round 3: more than 4 095 nodes, a direction longer than 65 519
     columns and reads of 513..16 000 bases are no longer limits -- they take the general path, tests/test_gpu_general.py.)"""
     from paragraph_amd import capi
     chain = (["A"] * 65536, [(i, i + 1) for i in range(65535)])
@@ -230,9 +230,9 @@ def test_documented_limits_fail_loudly(gpu_ctx):
     G.set_labels([{(0, 1): names[:256]}], [names[:256]])  # 256 labels are in (four words: tests/test_gpu_counts.py)
     G.set_labels([{(0, 1): names[:64]}], [names[:64]])
     with pytest.raises(capi.PgError) as e:
-        G.build_klib_index([[[0, 1, 3]] * 31])
+        G.build_klib_index([[[0, 1, 3]] * 127])
     assert e.value.status == 4
-    G.build_klib_index([[[0, 1, 3]] * 30])
+    G.build_klib_index([[[0, 1, 3]] * 126])
     b = gpu_ctx.new_batch()
     with pytest.raises(capi.PgError) as e:
         b.upload(G, ["A" * 16001])

@@ -363,7 +363,7 @@ pg_status pg_batch_kmer_align(pg_ctx* ctx, pg_batch* batch, uint32_t flags);
  *   common::KlibAlignment::update (src/c++/lib/common/Klib.cpp:144-164) = ksw_align(KSW_XSTART) + ksw_global
  *   (external/klib/ksw.c:223-355, 457-531) with match 1, mismatch -4, gap open 5 (+1 for its first base), extend 1.
  * ------------------------------------------------------------------------------------------------- */
-/* Paths as for pg_graphs_build_kmer_index (<= 30 per graph, whole nodes, no empty node). */
+/* Paths as for pg_graphs_build_kmer_index (<= 126 per graph, whole nodes, no empty node). */
 pg_status pg_graphs_build_klib_index(
     pg_ctx* ctx, pg_graphs* graphs, const uint32_t* path_off, const uint32_t* path_node_off, const uint32_t* path_nodes);
 /* KlibAligner::alignRead for every ACTIVE read (reads <= 512 bases): per path and strand one local alignment with start

@@ -13,7 +13,7 @@
 
 namespace e2eprof
 {
-enum { kDepth = 10, kMax = 400000 };
+enum { kDepth = 18, kMax = 400000 };
 static void* g_frames[kMax][kDepth];
 static unsigned char g_n[kMax];
 static std::atomic<unsigned> g_next(0);

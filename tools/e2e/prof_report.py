@@ -56,6 +56,20 @@ def main():
     print("\nleaf")
     for k, v in leaf.most_common(30):
         print("%5.1f%%  %s" % (100 * v / n, k))
+    # where the library-side time belongs: the innermost frame of this repo's own code that is not a container / string / Json
+    # helper (so malloc under Json::operator[] under countDocument counts for countDocument)
+    generic = re.compile(r":(std::|common::Json|void std::|__gnu_cxx|operator )")
+    own = collections.Counter()
+    for l in lines:
+        frs = [f for f in l.split(";") if f]
+        if not frs:
+            continue
+        r = [resolve(f) for f in frs]
+        pick = next((x for x in r if x.startswith(("paragraph_host:", "paragraph_amd:", "grmpy_batch:")) and not generic.search(x)), None)
+        own[pick or ("(" + r[0].split(":")[0] + ")")] += 1
+    print("\ninnermost own function (helpers skipped)")
+    for k, v in own.most_common(40):
+        print("%5.1f%%  %s" % (100 * v / n, k))
 
 
 if __name__ == "__main__":

@@ -1138,7 +1138,10 @@ static pg_status run_general(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_gen_reads, n * sizeof(PgGenRead)));
         HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_gen_fsum, n * 4 * sizeof(PgFillSummary)));
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));  // an earlier launch may still read h_gen_reads / the general workspace (rare path)
+    // h_gen_reads is this batch's: its earlier use ended with the batch's last stage (the copy out of it was queued before that
+    // stage's end event).  The general workspace is shared by the batches of the context, but only ever touched by launches on
+    // the second stream, which run in order -- no host wait for the stream itself.
+    HIP_TRY(ctx, pg_batch_wait(ctx, b));
     b->h_gen_reads.assign(n, PgGenRead{});
     // The general workspace comes ON TOP of the packed kernels' (which may hold up to the whole budget): groups are cut at a
     // budget of its own, 8 GiB or the context's limit if that is smaller -- a single read beyond that (within the limit: checked

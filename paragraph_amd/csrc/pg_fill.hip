@@ -588,7 +588,10 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         // of the wavefront in a rare path for 16 steps in a row, and a column inside the branch would then be executed twice,
         // once per side.
         const bool rare = (int32_t)meta_cur < 0;  // PG_META_RARE: node boundary here, or code 4 here / in the next column
-        if (rare)
+        // the lane mask of that test, in scalar registers: both rare blocks (before and after the column) hang off it by scalar
+        // branches, so the common path holds ONE vector compare
+        const unsigned long long rare_lanes = __ballot(rare);
+        if (rare_lanes != 0ull && rare)
         {
             if (meta_rows & 4u)  // N in the graph, or the idle columns behind its end
                 code4_rows(rows);
@@ -596,8 +599,13 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
                 first_column(Hin, meta_cur, tau);
         }
         column(Hin, Hout, sc, dH, F, floorE, tau, tvec);
-        if (meta_cur >= (PG_META_RARE | PG_META_LAST_HI))  // a LAST column (the only words with bits 31 and 30 set): one compare
-            last_column(Hout, meta_cur, tau);
+        if (rare_lanes != 0ull)  // wave-uniform
+        {
+            uint32_t mc = meta_cur;
+            asm volatile("" : "+v"(mc));  // (keeps the compare below inside the branch: the compiler would hoist it onto the common path)
+            if (mc >= (PG_META_RARE | PG_META_LAST_HI))  // a LAST column (the only words with bits 31 and 30 set): one compare
+                last_column(Hout, meta_cur, tau);
+        }
         tbase += TRACE_STEP_BYTES;
     };
 

@@ -6,9 +6,9 @@ wave64 and plain 32-bit add / sub / logic / mov / fp32 add-mul-fma over two (pro
 
 usage: tools/isa_mix.py [C=10] [out.json]      -> profiles/rNN_fill_isa_mix.json (carries the kernel_source_sha it was made at)
 
-The common path: from a loop's header to its back edge, `s_cbranch_execz` taken (the guarded block is a rare path: node
-boundary, code-4 column, seed load), `s_cbranch_execnz` / `s_cbranch_vccnz` not taken unless they close the loop.  The step
-loop is unrolled twice (ping-pong registers): the counts are per step = per loop iteration / 2."""
+The common path: the shortest way from a loop's header back to it (every conditional branch may go either way; the rare
+paths -- node boundary, code-4 column, seed load, frame renormalisation -- only ever add instructions).  The step loop is
+unrolled twice (ping-pong registers): the counts are per step = per loop iteration / 2."""
 import collections
 import json
 import os
@@ -85,37 +85,50 @@ def parse(lines):
 
 
 def common_path(ins, labels, header):
-    """instructions executed from `header` until a branch back to (or before) it, rare guards skipped"""
-    path, pc, steps, seen = [], header, 0, set()
-    while steps < 20000:
-        steps += 1
-        if pc in seen:
-            return path  # around the loop once (the back edge may enter below the header)
-        seen.add(pc)
-        s = ins[pc]
-        path.append(s)
-        m = s.split()[0]
-        if m in ("s_cbranch_execz",):
-            pc = labels[s.split()[1]]  # guarded block skipped
+    """the SHORTEST way round the loop from `header` back to it: every conditional branch may go either way, and the common
+    path is the one with the fewest instructions (a rare path only ever adds work: the guarded blocks of node boundaries,
+    code-4 columns, seed loads, the frame renormalisation every 256 steps; the loop's exit never comes back).  Dijkstra over
+    the instruction graph, cost 1 per instruction."""
+    import heapq
+    cond = ("s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_vccz", "s_cbranch_vccnz", "s_cbranch_execz", "s_cbranch_execnz")
+    dist, prev = {header: 0}, {}
+    heap = [(0, header)]
+    best_end = None
+    while heap:
+        d, pc = heapq.heappop(heap)
+        if d > dist.get(pc, 1 << 60):
             continue
-        if m in ("s_branch", "s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_vccz", "s_cbranch_vccnz", "s_cbranch_execnz"):
-            tgt = labels.get(s.split()[1])
-            if tgt is not None and tgt == header:
-                return path  # the loop's back edge
-            if m == "s_branch" and tgt is not None:
-                if tgt < header:
-                    return path
-                pc = tgt
-                continue
-            # a conditional branch: backward = an inner loop (not taken); a scalar one that skips a short block ahead = a
-            # wave-uniform rare path such as the frame renormalisation every 256 steps (taken); a far one = the loop's exit
-            if m != "s_cbranch_execnz" and tgt is not None and pc < tgt <= pc + 80:
-                pc = tgt
-                continue
-        pc += 1
-        if pc >= len(ins):
+        if d > 4000:
             break
-    return path
+        m = ins[pc].split()[0]
+        nxt = []
+        if m == "s_branch" or m in cond:
+            tgt = labels.get(ins[pc].split()[1])
+            if tgt is not None:
+                nxt.append(tgt)
+            if m in cond:
+                nxt.append(pc + 1)
+        elif m in ("s_endpgm", "s_setpc_b64"):
+            pass
+        else:
+            nxt.append(pc + 1)
+        if header in nxt:  # round the loop (the back edge may land on a latch block that falls into the header): the first
+            best_end = pc  # time this happens is the cheapest way round
+            break
+        for n in nxt:
+            if n < len(ins) and d + 1 < dist.get(n, 1 << 60):
+                dist[n] = d + 1
+                prev[n] = pc
+                heapq.heappush(heap, (d + 1, n))
+    if best_end is None:
+        return []
+    path, pc = [], best_end
+    while True:
+        path.append(ins[pc])
+        if pc == header:
+            break
+        pc = prev[pc]
+    return path[::-1]
 
 
 def main(C, dst):

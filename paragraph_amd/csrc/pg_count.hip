@@ -47,6 +47,7 @@ struct CountArgs
     const uint64_t* out_mask;    // per node x label_words
     const uint64_t* in_mask;
     uint32_t label_words;        // 64-bit words per label set (1 unless a graph of the set has more than 64 labels)
+    uint32_t frag_lds_counters;  // dwords of dynamic LDS a pg_fragment_kernel block has
     uint64_t* label_ext;         // [read][label_words - 1]: words 1.. of the reads' sets (word 0 is in pg_read_support)
     pg_read_support* support;
     uint32_t* path;
@@ -347,14 +348,18 @@ __global__ __launch_bounds__(64) void pg_support_kernel(CountArgs a)
 }
 
 constexpr int FRAG_BLOCK = 256;
-constexpr uint32_t FRAG_LDS_COUNTERS = 4096;
+constexpr uint32_t FRAG_LDS_COUNTERS = 4096;  // at most: a graph that needs more counts with global atomics
 
 // One thread per fragment.  Fragments are sorted by graph, so a block usually works on ONE graph: its
 // counters are then accumulated in LDS and flushed with one global atomic per touched counter per block
 // (a single hot site would otherwise serialise millions of atomics on a handful of addresses).
+// The LDS is dynamic, sized by the launcher to what the largest graph of the set needs (a 3-node deletion graph: 48 counters):
+// this kernel runs on the second stream under the next chunk's fill, whose 16 wavefronts per CU hold all 160 KB of LDS but for
+// what a retiring one frees -- a block that asked for a fixed 16 KB waited for two of them to retire on the same CU while the
+// dispatcher kept handing the freed 10 KB to the next fill wavefront (8 ms under the fill for 62 us of work).
 __global__ __launch_bounds__(FRAG_BLOCK) void pg_fragment_kernel(CountArgs a)
 {
-    __shared__ uint32_t lcnt[FRAG_LDS_COUNTERS];
+    extern __shared__ uint32_t lcnt[];
     const uint32_t f = blockIdx.x * FRAG_BLOCK + threadIdx.x;
     const uint32_t f_first = blockIdx.x * FRAG_BLOCK;
     const uint32_t f_last = min(f_first + FRAG_BLOCK, a.n_frags) - 1;
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(FRAG_BLOCK) void pg_fragment_kernel(CountArgs a)
     const uint32_t n_edges_g = a.pred_off[bg.node_base + bg.n_nodes] - e_base;
     const uint32_t n_seq_g = bg.n_labels <= PG_MAX_SEQ_TABLE_LABELS ? (1u << bg.n_labels) : 0u;
     const uint32_t l_edge = 4 * bg.n_nodes, l_seq = l_edge + 4 * n_edges_g, l_total = l_seq + 4 * n_seq_g;
-    const bool use_lds = g_first == g_last && l_total <= FRAG_LDS_COUNTERS;
+    const bool use_lds = g_first == g_last && l_total <= a.frag_lds_counters;
     if (use_lds)
     {
         for (uint32_t i = threadIdx.x; i < l_total; i += FRAG_BLOCK)
@@ -516,6 +521,7 @@ extern "C" pg_status pg_graphs_set_labels_wide(
     G->h_n_labels.assign(G->n_graphs, 0);
     G->h_seq_off.assign(G->n_graphs + 1, 0);
     std::vector<PgCountGraph> cg(G->n_graphs);
+    uint32_t frag_need = 0;
     for (uint32_t g = 0; g < G->n_graphs; ++g)
     {
         const uint32_t nl = n_labels ? n_labels[g] : 0;
@@ -537,6 +543,12 @@ extern "C" pg_status pg_graphs_set_labels_wide(
                     inm[(size_t)node * W + w] |= m;
                     outm[(size_t)(nb + G->h_pred[q]) * W + w] |= m;
                 }
+        {
+            // what a pg_fragment_kernel block counting this graph in LDS needs: {count, reads, fwd, rev} per node, edge and sequence set
+            const uint64_t need = 4ull * (ne - nb) + 4ull * (G->h_pred_off[ne] - G->h_pred_off[nb]) + 4ull * (nl <= PG_MAX_SEQ_TABLE_LABELS ? (1ull << nl) : 0ull);
+            if (need <= FRAG_LDS_COUNTERS)
+                frag_need = std::max<uint32_t>(frag_need, (uint32_t)need);
+        }
         cg[g].node_base = nb;
         cg[g].n_nodes = ne - nb;
         cg[g].n_labels = nl;
@@ -552,6 +564,7 @@ extern "C" pg_status pg_graphs_set_labels_wide(
     (void)pg_dev_free(G->d_count_block);
     G->d_count_block = nullptr;
     G->label_words = words;
+    G->frag_lds_counters = (frag_need + 63u) & ~63u;
     PgStagedUpload up;  // seven tables, one copy
     up.add(cg, &G->d_cnt_graphs);
     up.add(G->h_pred_off, &G->d_cnt_pred_off);
@@ -721,6 +734,7 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     a.out_mask = G->d_out_mask;
     a.in_mask = G->d_in_mask;
     a.label_words = G->label_words;
+    a.frag_lds_counters = G->frag_lds_counters;
     b->label_ext_words = G->label_words - 1;
     if (b->label_ext_words)
     {
@@ -762,7 +776,8 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     {
         hipLaunchKernelGGL(pg_support_kernel, dim3((n + 63) / 64), dim3(64), 0, cs, a);
         HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(pg_fragment_kernel, dim3((b->n_frags + FRAG_BLOCK - 1) / FRAG_BLOCK), dim3(FRAG_BLOCK), 0, cs, a);
+        hipLaunchKernelGGL(pg_fragment_kernel, dim3((b->n_frags + FRAG_BLOCK - 1) / FRAG_BLOCK), dim3(FRAG_BLOCK),
+                           (size_t)a.frag_lds_counters * sizeof(uint32_t), cs, a);
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, pg_stage_end_on(ctx, b, cs));

@@ -99,6 +99,7 @@ struct pg_graphs
     uint32_t* d_cnt_pred = nullptr;
     uint32_t* d_cnt_node_len = nullptr;
     uint32_t label_words = 1;          // 64-bit words per label set (set-wide; pg_graphs_set_labels_wide)
+    uint32_t frag_lds_counters = 0;    // LDS counters a pg_fragment_kernel block needs for any ONE graph of the set (capped)
     uint64_t* d_label_mask = nullptr;  // per predecessor entry x label_words
     uint64_t* d_out_mask = nullptr;    // per node x label_words: labels on outgoing edges
     uint64_t* d_in_mask = nullptr;     // per node x label_words: labels on incoming edges

@@ -138,8 +138,8 @@ struct Emitter
 template <int C, bool WIDE, int GL> __device__ __forceinline__ void pg_trace_pair(const PgTraceArgs& a, const uint32_t pair)
 {
     // No LDS and 80 VGPRs: this kernel runs on the second stream UNDER the next chunk's fill, whose 16 wavefronts per CU take
-    // all 160 KB of LDS and four times 114 of the 512 VGPRs of a SIMD lane -- two traceback wavefronts per SIMD fit beside them
-    // (pg_trace_blocks) and take the place of no fill wavefront.
+    // all 160 KB of LDS and four times 120 of the 512 VGPRs of a SIMD lane -- a traceback wavefront gets a place when a fill
+    // wavefront retires and holds it for its grid-stride loop (pg_trace_blocks: how many do).
     const uint32_t lane = threadIdx.x;
     const uint32_t grp = lane >> 4;  // the read of this 16-lane row
     const uint32_t k = lane & 15u;
@@ -626,10 +626,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_TRACE_WPE
 // Wavefronts of one traceback launch.  The walk is a chain of dependent loads that each pull a whole 128-byte line for a few
 // bytes (profiles/r03_sector_probe.json), and it runs under the next chunk's fill, which writes 3.5 TB/s the whole time.
 // Measured with stand-in kernels in the walk's place (profiles/r03_trace_tax.md): wavefronts that only sit beside the fill
-// cost it nothing; dependent random-line reads cost it in proportion to their bytes, and more when they come as a burst
-// (one wavefront per pair = some 5 000 in flight for a millisecond) than when the same bytes are spread out.  Two per SIMD is
-// also what fits beside the fill's four wavefronts per SIMD without taking registers from them (PG_TRACE_BLOCKS overrides;
-// 0 = one per pair).
+// cost it little; dependent random-line reads cost it in proportion to their bytes.  A traceback wavefront (80 registers)
+// does take the place of a fill wavefront on its SIMD (4 x 120 of the 512 registers are the fill's), so the number in flight
+// trades the time the traceback holds those places against how many it holds: measured on the round-4 kernels
+// (profiles/r04_trace_blocks_ab.jsonl, three boxes) 4 per CU -6 %, 8 per CU the old default, 11-12 per CU +1.2 ... 1.4 %, 16
+// and more +0.2 ... 0.4 % (PG_TRACE_BLOCKS overrides; 0 = one per pair).
 static uint32_t pg_trace_blocks(uint32_t n_pairs)
 {
     static const long cap = [] {
@@ -639,7 +640,7 @@ static uint32_t pg_trace_blocks(uint32_t n_pairs)
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess)
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return 8L * cus;
+        return 12L * cus;
     }();
     return cap > 0 && (uint32_t)cap < n_pairs ? (uint32_t)cap : n_pairs;
 }

@@ -963,10 +963,34 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
     Chunk cur{};
     bool open = false;
     b->max_ws = 0;
+    std::vector<uint32_t> pair_steps;  // pipeline steps of every item pair (its work)
+    std::vector<uint32_t> order;
+    std::vector<PgWorkItem> sorted;
     auto close_chunk = [&]() {
         if (open)
         {
             cur.pair_end = (uint32_t)(items.size() / 2);
+            // Longest first: a launch ends with a tail in which the chip drains, and the tail is as long as the last wavefront to
+            // start lives -- a 3 000-column graph's lives five times as long as a 600-column one's.  Pairs of one graph have the
+            // same length and stay together (their graph's tables stay hot); regions keep the offsets they were given.
+            const uint32_t pb = cur.pair_begin, pe = cur.pair_end;
+            bool mixed = false;
+            for (uint32_t i = pb + 1; i < pe && !mixed; ++i)
+                mixed = pair_steps[i] != pair_steps[pb];
+            if (mixed)
+            {
+                order.resize(pe - pb);
+                for (uint32_t i = 0; i < pe - pb; ++i)
+                    order[i] = pb + i;
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return pair_steps[x] > pair_steps[y]; });
+                sorted.resize(2 * (size_t)(pe - pb));
+                for (uint32_t i = 0; i < pe - pb; ++i)
+                {
+                    sorted[2 * (size_t)i] = items[2 * (size_t)order[i]];
+                    sorted[2 * (size_t)i + 1] = items[2 * (size_t)order[i] + 1];
+                }
+                std::copy(sorted.begin(), sorted.end(), items.begin() + 2 * (size_t)pb);
+            }
             b->chunks.push_back(cur);
             b->max_ws = std::max(b->max_ws, cur.ws_bytes);
             open = false;
@@ -1068,6 +1092,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
         cur.max_nodes = std::max(cur.max_nodes, hg.n_nodes);
         items.push_back(fw);
         items.push_back(rv);
+        pair_steps.push_back((uint32_t)nsteps);
         p = q;
     }
     close_chunk();

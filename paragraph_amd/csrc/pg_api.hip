@@ -625,6 +625,20 @@ extern "C" pg_status pg_graphs_upload(
     std::vector<uint32_t> colmeta;
     std::vector<char> seqchars;
     std::vector<HostGraph> host(n_graphs);
+    {
+        // (sizes are known up front: one word per column and direction + the idle tail, one character per column)
+        const uint32_t total_nodes = node_off[n_graphs];
+        const uint64_t total_cols = seq_off[total_nodes] >= seq_off[0] ? seq_off[total_nodes] - seq_off[0] : 0;
+        if (total_cols < (1ull << 30))
+        {
+            colmeta.reserve(2 * total_cols + 2ull * n_graphs * PG_META_PAD);
+            seqchars.reserve(total_cols);
+            nodes.reserve(2ull * total_nodes);
+            preds.reserve(2ull * (pred ? pred_off[total_nodes] : 0) + 1);
+        }
+    }
+    std::vector<std::vector<uint32_t>> succ;  // (reused from graph to graph)
+    std::vector<uint32_t> ps;
 
     for (uint32_t g = 0; g < n_graphs; ++g)
     {
@@ -660,7 +674,10 @@ extern "C" pg_status pg_graphs_upload(
         host[g].general_only = wide;
 
         // successors (forward ids)
-        std::vector<std::vector<uint32_t>> succ(n);
+        if (succ.size() < n)
+            succ.resize(n);
+        for (uint32_t i = 0; i < n; ++i)
+            succ[i].clear();
         for (uint32_t i = 0; i < n; ++i)
             for (uint32_t k = pred_off[nb + i]; k < pred_off[nb + i + 1]; ++k)
                 succ[pred[k]].push_back(i);
@@ -697,7 +714,7 @@ extern "C" pg_status pg_graphs_upload(
                 {
                     // predecessors in the reversed graph = successors of src in the original, mapped
                     // s -> n-1-s, ascending
-                    std::vector<uint32_t> ps;
+                    ps.clear();
                     for (uint32_t s : succ[src])
                         ps.push_back(n - 1 - s);
                     std::sort(ps.begin(), ps.end());

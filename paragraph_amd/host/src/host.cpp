@@ -1557,6 +1557,9 @@ void SiteBatcher::Impl::Run::viewsOfPackedSites()
             PackedSite const& p = *impl.packed[s];
             SiteReadViews& v = impl.views[s];
             v.label_names = csr.label_names[s];
+            v.reads.reserve(p.size());  // (most reads of a site map; a read crosses two or three nodes)
+            v.pieces.reserve(2 * p.size() + 8);
+            v.support.reserve(3 * p.size() + 8);
             uint32_t n_fragments = 0;
             for (size_t k = 0; k < p.size(); ++k)
             {

@@ -30,6 +30,11 @@ Prints ONE JSON line (rank 0).  Extra objects:
   verified     -- the GPU results of the last timed step compared field by field and CIGAR by CIGAR with the
                   reference alignments the cpu_baseline leg computed for the same reads (exit status 3 on a mismatch)
   sites        -- the config3 leg (sites/s, strong scaling, reduce_equals_single)
+  e2e          -- "sites genotyped/sec": BAM -> genotypes through the host workflow (pgw_genotype_graphs: BGZF / BAM decode, read
+                  extraction, graph loading, device batches, count documents, genotyping, the JSON array written out), K timed
+                  passes over a synthetic 10 000-site data set written before the timed region; CPU seconds per (site, sample),
+                  genotypes against the simulated truth, a sample of sites' edge counts against the reference's own code on the
+                  reads the reference's extraction policy keeps (exit status 3 on a mismatch)
 """
 import argparse
 import json
@@ -98,6 +103,13 @@ def parse_args():
     ap.add_argument("--sites-verify", type=int, default=500,
                     help="config3 leg: sites of rank 0's shard whose alignments, per-read outcome and count tables are compared "
                          "with the reference's code in a CPU-leg process (0 = skip); exit status 3 on a mismatch")
+    ap.add_argument("--e2e-steps", type=int, default=3,
+                    help="timed passes of the BAM -> genotypes leg (0 = skip): every pass takes ALL sites of the e2e data set from the "
+                         "BAM file to genotype documents written as JSON (with N ranks: rank r takes sites r, r + N, ...)")
+    ap.add_argument("--e2e-sites", type=int, default=10000, help="sites of the e2e data set (one 30x sample; the whole job)")
+    ap.add_argument("--e2e-verify", type=int, default=500,
+                    help="e2e leg: sites of rank 0's shard whose edge counts are compared with the reference's code (0 = skip)")
+    ap.add_argument("--e2e-threads", type=int, default=0, help="host threads of the workflow per rank (0 = usable CPUs / ranks)")
     ap.add_argument("--cpu-leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--sites-cpu-leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-reads-file", help=argparse.SUPPRESS)
@@ -188,7 +200,8 @@ def reference_site_outcome(chk, s, stride=256):
              "unique": bool(r["unique"]), "graph_reverse": bool(s.is_reverse[k]) != bool(r["returned_reverse"]), "read_len": L,
              "fragment": int(s.fragment[k])} for k, (r, c) in enumerate(zip(res, cig))]
     labels = sorted({l for v in s.site.labels.values() for l in v})
-    count = oc.RefCounts().count_site if oc.have_ref() else oc.port_count_site
+    from oracle import select
+    count = select.count_site()
     wc = count(oc.CountGraph(s.site.seqs, s.site.edges, s.site.labels, labels), recs, remove_nonuniq=True)
     lab_idx = {l: k for k, l in enumerate(labels)}
     return {"res": res, "cig": cig, "status": np.array(wc["status"], dtype=np.uint8),
@@ -201,9 +214,8 @@ _SITES_JOB = None
 
 
 def _sites_job(i):
-    from oracle import oracle as orc
-    chk = orc.RefOracle() if orc.have_ref() else orc.PortOracle()
-    return reference_site_outcome(chk, _SITES_JOB[i], SITES_CIGAR_STRIDE)
+    from oracle import select
+    return reference_site_outcome(select.gssw(), _SITES_JOB[i], SITES_CIGAR_STRIDE)
 
 
 def sites_cpu_leg_main(args):
@@ -300,10 +312,9 @@ def cpu_leg_main(args):
     n_all, L = arr.shape
     bases = np.ascontiguousarray(arr).reshape(-1)
     off = (np.arange(n_all + 1, dtype=np.uint64) * np.uint64(L)).astype(np.uint32)
-    if orc.have_ref():
-        chk, kind, label = orc.RefOracle(), "reference", "reference gssw.c (oracle/_ref)"
-    else:
-        chk, kind, label = orc.PortOracle(), "port", "plain-C restatement (oracle/pg_oracle.c)"
+    from oracle import select
+    chk = select.gssw()  # PG_REQUIRE_REF=1: no silent change of checker
+    kind, label = ("reference", "reference gssw.c (oracle/_ref)") if orc.have_ref() else ("port", "plain-C restatement (oracle/pg_oracle.c)")
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     quota = _cpu_quota()  # a container may see every CPU of the host and still be held to a few of them
     res = _shared_array((n_all,), orc.RESULT_NP)
@@ -522,6 +533,34 @@ def measured_bounds(args, reads_per_launch, avg_launch_s):
     return out
 
 
+def roofline_head(extra, formula_gbs):
+    """The contract's six roofline fields for pg_fill_kernel, named after the bound that binds.
+
+    The kernel is VALU-issue-bound: with SQ counters collected on THIS build's kernel sources `bound` is "valu",
+    achieved / peak are wave64 VALU issue slots per second (one slot per SIMD per four cycles; a dual-issued pair shares one) and
+    frac is the share of the issue port the launches held.  The two HBM figures stay beside it under their own names:
+      hbm_formula_frac   SURVEY 8(d)'s B_alg (H, E and F of the two traced fills) / launch time / 8 TB/s.  The kernel keeps H only
+                         and re-derives E / F in the traceback, so it does NOT move these bytes: the figure can exceed 1 and is
+                         void as a fraction of peak -- kept because the contract defines it
+      hbm_measured_frac  PMC bytes per launch / launch time / 8 TB/s: what the kernel really moves
+    Without usable counters (kernel sources changed since they were collected) the line falls back to the HBM formula figure and
+    says so."""
+    valu = extra.get("valu") or {}
+    head = {"traffic": extra.pop("traffic"), "hbm_formula_gbs": formula_gbs, "hbm_formula_frac": formula_gbs / HBM_PEAK_GBS,
+            "hbm_formula_note": "SURVEY 8(d) formula bytes (H + E + F of two fills); void as a fraction for an H-only trace"}
+    frac = valu.get("issue_frac_with_measured_pairing", valu.get("issue_frac"))
+    if frac is not None:
+        peak = SIMDS * valu["clock_ghz"] * 1e9 / 4.0 / 1e9
+        head.update({"bound": "valu", "achieved": frac * peak, "peak": peak, "unit": "G wave64 VALU issue slots/s", "frac": frac,
+                     "bound_note": "share of the 1 024 SIMDs' VALU issue slots (one per four cycles at the measured clock) the fill "
+                                   "launches held; instructions per wave-step and dual-issue pairs from SQ counters of this build"})
+    else:
+        head.update({"bound": "hbm", "achieved": formula_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": formula_gbs / HBM_PEAK_GBS,
+                     "bound_note": "no SQ counters for this build's kernel sources: the contract's HBM formula figure stands in; the "
+                                   "kernel is VALU-issue-bound (see valu / hbm_measured_frac when counters are present)"})
+    return head
+
+
 # ---------------------------------------------------------------------------------------------------
 # launcher
 # ---------------------------------------------------------------------------------------------------
@@ -722,6 +761,193 @@ def run_sites_leg(args, env, ctx, capi, synth, sset, steps, warmup, timed_events
 
 
 # ---------------------------------------------------------------------------------------------------
+# e2e: BAM files -> genotype documents ("sites genotyped/sec")
+# ---------------------------------------------------------------------------------------------------
+def prepare_e2e(args, rank, world, ncpu):
+    """Writes the e2e data set (paragraph_amd/synth_e2e.py: reference, ONE coordinate-sorted BAM + index, one graph description
+    per site, manifest, truth) BEFORE the process touches HIP -- the makers fork.  With N ranks every rank makes the pieces
+    of its N-th of the sites and rank 0 joins them; the others wait for the marker file."""
+    import pickle
+    from paragraph_amd import synth_e2e
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    tag = os.environ.get("MASTER_PORT") if world > 1 else None
+    d = os.path.join(base, "pgbench_e2e_%s" % tag) if tag else tempfile.mkdtemp(prefix="pgbench_e2e_", dir=base)
+    os.makedirs(d, exist_ok=True)
+    n = args.e2e_sites
+    shard0 = list(range(0, n, world))
+    stride = max(1, len(shard0) // max(1, args.e2e_verify))
+    sample_idx = shard0[::stride][:args.e2e_verify] if args.e2e_verify > 0 and not args.no_cpu_baseline else []
+    t0 = time.perf_counter()
+    synth_e2e.make_part(d, rank, world, n_sites=n, depth=30.0, seed=1, read_len=args.read_len, procs=max(1, ncpu // world), keep_sites=sample_idx)
+    ready = os.path.join(d, ".ready")
+    if rank == 0:
+        data = synth_e2e.join(d, world, n_sites=n, depth=30.0, seed=1, read_len=args.read_len, wait_s=900.0)
+        with open(ready + ".tmp", "wb") as f:
+            pickle.dump({"reads": data["reads"], "bam_bytes": data["bam_bytes"]}, f)
+        os.replace(ready + ".tmp", ready)
+    else:
+        deadline = time.time() + 900.0
+        while not os.path.exists(ready):
+            if time.time() > deadline:
+                raise RuntimeError("e2e data set: rank 0 did not finish %s" % d)
+            time.sleep(0.05)
+        with open(ready, "rb") as f:
+            meta = pickle.load(f)
+        data = {"reference": os.path.join(d, "ref.fa"), "manifest": os.path.join(d, "manifest.txt"),
+                "graphs": [os.path.join(d, "graphs", "site_%d.json" % i) for i in range(n)], "sites": synth_e2e.draw_sites(n, 1),
+                "reads": meta["reads"], "bam_bytes": meta["bam_bytes"], "kept": {}, "ref": None}
+        data["truth"] = [s.truth() for s in data["sites"]]
+    data.update({"dir": d, "sample_idx": sample_idx, "make_s": time.perf_counter() - t0})
+    return data
+
+
+def e2e_reference_sites(e2e, read_len):
+    """The sampled sites as the reference's workflow would see them (TEST INFRASTRUCTURE, for reference_site_outcome): the graph
+    as GraphInput.cpp loads it, the reads ReadExtraction.cpp keeps, BAM strand flags, fragments by name."""
+    from paragraph_amd import synth, synth_e2e
+    out = []
+    for i in e2e["sample_idx"]:
+        spec, reads = e2e["sites"][i], e2e["kept"][i]
+        names, seqs, edges, labels = synth_e2e.loaded_graph(spec, e2e["ref"])
+        keep = synth_e2e.extracted(spec, reads, read_len)
+        site = synth.Site(spec.kind, names, seqs, edges, labels, {})
+        out.append(synth.SiteReads(site, np.ascontiguousarray(reads["bases"][keep]), reads["fragment"][keep].astype(np.uint32),
+                                   ((reads["flag"][keep] & 0x10) != 0).astype(np.uint8), spec.gt))
+    return out
+
+
+def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
+    """K timed passes of pgw_genotype_graphs over this rank's sites (r, r + N, ...), barrier + max over ranks around them;
+    then -- outside the timed region -- the documents of the last pass are read back: genotypes against the simulated truth
+    (all ranks), the per-site edge-count table summed over the ranks (the path's one collective, timed on its own), and on
+    rank 0 a sample of sites against the reference's code."""
+    import resource
+    torch, dist = env["torch"], env["dist"]
+    rank, world, device = env["rank"], env["world"], env["device"]
+    from paragraph_amd import workflow
+    n = len(e2e["graphs"])
+    mine = list(range(rank, n, world))
+    graphs = [e2e["graphs"][i] for i in mine]
+    threads = args.e2e_threads or max(1, ncpu // world)
+    out_file = os.path.join(e2e["dir"], "genotypes_rank%d.json" % rank)
+    options = {"threads": threads, "devices": [dev_index]}
+    if shared:  # ranks sharing a GPU (tests on a 1-GPU box): the host library's workspace budget per rank
+        os.environ.setdefault("PG_WORKSPACE_GIB", "%g" % max(4.0, 96.0 / world))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def one_pass():
+        workflow.genotype_graphs_to_file(e2e["reference"], e2e["manifest"], graphs, out_file, **options)
+
+    one_pass()  # warm-up: the host library's own device context, its workspace, the file cache
+    barrier()
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    t0 = time.perf_counter()
+    for _ in range(args.e2e_steps):
+        one_pass()
+    barrier()
+    elapsed_mine = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    elapsed = env["max_over_ranks"](elapsed_mine)
+    cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
+
+    with open(out_file) as f:
+        docs = json.load(f)
+    os.unlink(out_file)
+    assert len(docs) == len(mine)
+    concordant = sum(1 for i, doc in zip(mine, docs) if doc["samples"]["SYN"]["gt"].get("GT") == e2e["truth"][i]["gt"])
+    errors = sum(1 for doc in docs if "error" in doc)
+    # per-site edge-count table in one layout on every rank: a slot per edge of every site's graph, in site order
+    edge_names, offsets, total = [], [], 0
+    for spec in e2e["sites"]:
+        g = spec.graph()
+        edge_names.append(["%s_%s" % (e["from"], e["to"]) for e in g["edges"]])
+        offsets.append(total)
+        total += len(g["edges"])
+    table = np.zeros(total + 2, dtype=np.int32)  # + (concordant genotypes, documents with an error)
+    for i, doc in zip(mine, docs):
+        counts = {}
+        for bp in doc["samples"]["SYN"]["breakpoints"].values():
+            counts.update(bp["counts"]["edges"])
+        for k, name in enumerate(edge_names[i]):
+            table[offsets[i] + k] = counts.get(name, 0)
+    table[total], table[total + 1] = concordant, errors
+    own = table.copy()
+    reduce_ms = None
+    if world > 1 or env["reducer"] is not None:
+        t = torch.from_numpy(table)
+        if not shared:
+            t = t.to(device)
+        barrier()
+        t0 = time.perf_counter()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        barrier()
+        reduce_ms = (time.perf_counter() - t0) * 1e3
+        table = t.cpu().numpy()
+    mine_kept = all(np.array_equal(table[offsets[i]:offsets[i] + len(edge_names[i])], own[offsets[i]:offsets[i] + len(edge_names[i])]) for i in mine)
+    per_rank = [{"rank": rank, "sites": len(mine), "seconds": elapsed_mine, "cpu_s": cpu_s, "threads": threads}]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "sites": len(mine), "seconds": elapsed_mine, "cpu_s": cpu_s, "threads": threads})
+    if rank != 0:
+        return None
+    steps = args.e2e_steps
+    cpu_all = sum(p["cpu_s"] for p in per_rank)
+    out = {"config": "BAM -> genotypes: %d synthetic del / ins / swap sites (graph descriptions with reference-interval nodes), one 30x "
+                     "sample of paired %dbp reads in ONE coordinate-sorted BAM (%d reads, %.0f MB), pgw_genotype_graphs = BGZF + BAM "
+                     "decode, read extraction (ReadExtraction.cpp policy), graph loading, device batches (4 fills + traceback + "
+                     "filters + counts per read), count documents, breakpoint genotyping, the JSON array written to a file; "
+                     "rank r takes sites r, r + %d, ..." % (n, args.read_len, e2e["reads"], e2e["bam_bytes"] / 1e6, world),
+           "sites": n, "samples": 1, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+           "sites_genotyped_per_s": n * steps / elapsed, "reads_in_bam_per_s": e2e["reads"] * steps / elapsed, "scaling": "strong",
+           "host_threads": threads * world, "host_threads_per_rank": threads, "cpu_quota_cores": _cpu_quota(), "host_cpus": ncpu,
+           "cpu_s_per_pass": cpu_all / steps, "cpu_us_per_site_sample": cpu_all / steps / n * 1e6,
+           "cpu_note": "user + system time of the rank processes over the timed passes (getrusage): every host thread of the workflow, "
+                       "the HIP runtime's threads included",
+           "genotypes_equal_truth": int(table[total]), "documents_with_error": int(table[total + 1]),
+           "edge_table": {"entries": total, "sum": int(table[:total].astype(np.int64).sum()), "reduce_ms": reduce_ms,
+                          "reduced_equals_own_on_own_sites": bool(mine_kept),
+                          "note": "one slot per edge of every site (fragment counts of the breakpoint edges), all-reduced over the ranks "
+                                  "AFTER the timed passes: a site's genotype needs only its own counts, the sum only collects them"},
+           "data_make_s": e2e["make_s"], "per_rank": per_rank}
+    # A genotype that differs from the simulated truth is not by itself an error of the path (30x sampling can starve an allele);
+    # a concordance below 99.5 % is.  What must hold exactly: no document with an error, the table checks, the sampled sites.
+    out["genotype_concordance"] = int(table[total]) / max(1, n)
+    bad = (1 if out["genotype_concordance"] < 0.995 else 0) + int(table[total + 1]) + (0 if mine_kept else 1)
+    if e2e["sample_idx"]:
+        sample = e2e_reference_sites(e2e, args.read_len)
+        info, want = run_sites_cpu_leg(sample)
+        wrong, first = 0, None
+        for i, s, w in zip(e2e["sample_idx"], sample, want):
+            ref_counts = {"%s_%s" % (s.site.names[a], s.site.names[b]): int(w["edge_counts"][k][0]) for k, (a, b) in enumerate(s.site.edges)}
+            got = {name: int(table[offsets[i] + k]) for k, name in enumerate(edge_names[i])}
+            # the genotype document reports the edges of its breakpoints (every edge but source -> LF and RF -> sink here)
+            diff = {k: (got[k], ref_counts[k]) for k in got if not k.startswith("source_") and not k.endswith("_sink") and got[k] != ref_counts[k]}
+            if diff:
+                wrong += 1
+                if first is None:
+                    first = {"site": i, "edges (got, reference)": diff}
+        out["verified"] = {"sites": len(sample), "reads": int(sum(len(s.reads) for s in sample)), "site_mismatches": wrong, "first_bad_site": first,
+                           "what": "fragment count of every breakpoint edge of the sampled sites (from the reduced table) = the reference's "
+                                   "gssw.c alignments + graph-tools counting on the reads ReadExtraction.cpp:135-178 keeps",
+                           "reference": info}
+        bad += wrong
+    out["mismatches"] = int(bad)
+    return out
+
+
+def cleanup_e2e(e2e, rank, world, dist):
+    import shutil
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        shutil.rmtree(e2e["dir"], ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------------
 # one rank
 # ---------------------------------------------------------------------------------------------------
 _JSON_FD = None
@@ -768,6 +994,10 @@ def main_rank(args):
         if args.hot_site_depth > 0:  # one deep site on top of the set: split over the ranks by fragment id
             sites = sites + synth.mixed_sites(1, seed=11, read_len=L, depth=args.hot_site_depth, site_streams=True)
         sset = SiteSet(sites, L, world, split_reads=args.split_reads)
+    e2e = None
+    if args.e2e_steps > 0:
+        log("writing the e2e data set")
+        e2e = prepare_e2e(args, rank, world, ncpu)
     log("data ready")
 
     import torch
@@ -881,10 +1111,20 @@ def main_rank(args):
             sites_out, _, _, _ = run_sites_leg(args, env, ctx, capi, synth, sset, args.sites_steps, 1, False)
             if rank == 0:
                 out["sites"] = sites_out
+    if e2e is not None:
+        log("e2e leg")
+        barrier()
+        ctx.close()  # the workflow's host library opens its own context (own workspace budget) on the same device
+        e2e_out = run_e2e_leg(args, env, e2e, dev_index, shared, ncpu)
+        cleanup_e2e(e2e, rank, world, dist)
+        if rank == 0:
+            out["e2e"] = e2e_out
     rc = 0
     if rank == 0:
         print_result_line(out)
         if out.get("verified") and out["verified"]["mismatches"]:
+            rc = 3
+        if out.get("e2e") and out["e2e"]["mismatches"]:
             rc = 3
         if out.get("sites") and out["sites"].get("reduce_equals_single") is False:
             rc = 3
@@ -1075,8 +1315,7 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
         },
         "cell_updates_per_s": 4.0 * L * G * reads_total / elapsed,  # whole step (fill + traceback + count), all ranks
         "roofline": {
-            "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": roof_extra.pop("traffic"),
+            **roofline_head(roof_extra, achieved_gbs),
             "kernel": "pg_fill_kernel<%d, false, 16>" % (2 * ((L + 31) // 32)),
             "launches": int(tim["fill_launches"]),
             "avg_launch_ms": tim["fill_ms"] / max(1, tim["fill_launches"]),

@@ -140,6 +140,12 @@ struct Parameters
     std::vector<int> devices;        // HIP ordinals to spread the lanes over (lane l -> devices[l % n]); empty = the list of
                                      // paragraph::setDevices / PG_DEVICES / PG_DEVICE / {0}
     paragraph::Timings* timings = nullptr;
+    // When set, genotypeGraphs writes every genotype document as JSON text into (*genotype_text)[graph] (resized to the graph
+    // list) right where it is made -- on the lane that made it, beside the other lanes' device batches -- and the returned
+    // documents are left empty: a caller that only writes the documents out (the command line, pgw_genotype_graphs) then does
+    // not serialise 40 MB on one thread after the last lane has finished.
+    std::vector<std::string>* genotype_text = nullptr;
+    int genotype_text_indent = -1;   // Json::dump's indent: < 0 one line
 };
 
 // extraction + alignment + counting of ONE sample against ONE graph; stores the count document in the sample

@@ -96,18 +96,21 @@ int main(int argc, char** argv)
             throw std::runtime_error("Manifest file is missing.");
 
         const genotyping::Samples samples = genotyping::loadManifest(manifest);
-        const std::vector<common::Json> genotypes = grmpy::genotypeGraphs(parameters, graphs, reference, samples, genotyping_parameters);
+        std::vector<std::string> documents;  // serialised by the lanes that made them (Parameters::genotype_text)
+        parameters.genotype_text = &documents;
+        parameters.genotype_text_indent = 1;
+        grmpy::genotypeGraphs(parameters, graphs, reference, samples, genotyping_parameters);
 
         if (!output_folder.empty())
             for (size_t g = 0; g < graphs.size(); ++g)
-                cli::writeOutput(output_folder + "/" + cli::baseName(graphs[g]) + (gzip ? ".gz" : ""), genotypes[g].dump(1) + "\n", gzip);
+                cli::writeOutput(output_folder + "/" + cli::baseName(graphs[g]) + (gzip ? ".gz" : ""), documents[g] + "\n", gzip);
         if (!output_file.empty() || output_folder.empty())
         {
             std::string text;
             if (graphs.size() > 1)
                 text += "[";
-            for (size_t g = 0; g < genotypes.size(); ++g)
-                text += (g ? "," : "") + genotypes[g].dump(1);
+            for (size_t g = 0; g < documents.size(); ++g)
+                text += (g ? "," : "") + documents[g];
             text += graphs.size() > 1 ? "]\n" : "\n";
             cli::writeOutput(output_file, text, gzip);
         }

@@ -893,6 +893,8 @@ std::vector<Json> genotypeGraphs(
 {
     const size_t n_graphs = graph_paths.size(), n_samples = samples.size();
     std::vector<Json> genotypes(n_graphs);
+    if (parameters.genotype_text)
+        parameters.genotype_text->assign(n_graphs, std::string());
     if (n_graphs == 0 || n_samples == 0)
         return genotypes;
     const size_t per_batch = std::max<size_t>(1, parameters.sites_per_batch / n_samples);
@@ -1012,6 +1014,11 @@ std::vector<Json> genotypeGraphs(
                     for (Json const* doc : docs)  // a graph the device path could not take: genotyped from no counts, and says so
                         if (doc->isMember("error") && !genotypes[g0 + g].isMember("error"))
                             genotypes[g0 + g]["error"] = (*doc)["error"];
+                    if (parameters.genotype_text)
+                    {
+                        (*parameters.genotype_text)[g0 + g] = genotypes[g0 + g].dump(parameters.genotype_text_indent);
+                        genotypes[g0 + g] = Json();
+                    }
                 });
                 phase(c, "genotypes");
                 const double t_release = now();
@@ -1133,17 +1140,26 @@ extern "C" int pgw_genotype_graphs(
         }
         std::vector<std::string> graphs(graph_paths, graph_paths + n_graphs);
         const genotyping::Samples samples = genotyping::loadManifest(manifest);
-        const std::vector<Json> genotypes
-            = grmpy::genotypeGraphs(parameters, graphs, reference_fasta, samples, genotyping_parameters ? genotyping_parameters : "");
-        std::ofstream out(output_path, std::ios::binary);
-        if (!out.good())
+        std::vector<std::string> text;  // every document serialised by the lane that made it (Parameters::genotype_text)
+        parameters.genotype_text = &text;
+        grmpy::genotypeGraphs(parameters, graphs, reference_fasta, samples, genotyping_parameters ? genotyping_parameters : "");
+        size_t bytes = 4;
+        for (auto const& t : text)
+            bytes += t.size() + 2;
+        std::string all;
+        all.reserve(bytes);
+        all += "[";
+        for (size_t g = 0; g < text.size(); ++g)
+        {
+            all += g ? ",\n" : "\n";
+            all += text[g];
+        }
+        all += "\n]\n";
+        FILE* out = fopen(output_path, "wb");
+        if (!out)
             return report(std::string("cannot write ") + output_path);
-        out << "[";
-        for (size_t g = 0; g < genotypes.size(); ++g)
-            out << (g ? ",\n" : "\n") << genotypes[g].dump();
-        out << "\n]\n";
-        out.close();
-        if (!out.good())
+        const bool ok = fwrite(all.data(), 1, all.size(), out) == all.size();
+        if (fclose(out) != 0 || !ok)
             return report(std::string("error while writing ") + output_path);
         return 0;
     }

@@ -29,24 +29,30 @@ def load_library():
     return _lib
 
 
+def genotype_graphs_to_file(reference_fasta, manifest, graph_paths, output_path, genotyping_parameters=None, **options):
+    """The call itself: BAM files in, the JSON array of genotype documents in output_path.  Nothing is read back (a caller
+    that times the workflow does not want Python's JSON parser inside the timed region)."""
+    L = load_library()
+    paths = (C.c_char_p * len(graph_paths))(*[os.fsencode(p) for p in graph_paths])
+    err = C.create_string_buffer(4096)
+    rc = L.pgw_genotype_graphs(os.fsencode(reference_fasta), os.fsencode(manifest), paths, len(graph_paths),
+                               os.fsencode(genotyping_parameters) if genotyping_parameters else None,
+                               json.dumps(options).encode() if options else None, os.fsencode(output_path), err, len(err))
+    if rc != 0:
+        raise RuntimeError("pgw_genotype_graphs: " + err.value.decode(errors="replace"))
+
+
 def genotype_graphs(reference_fasta, manifest, graph_paths, genotyping_parameters=None, output_path=None, **options):
     """Genotypes every graph against every sample of the manifest; returns the list of genotype documents (and leaves the
     JSON array in output_path when one is given).  Options: threads, lanes, sites_per_batch, max_reads, bad_align_frac,
     path_sequence_matching, kmer_sequence_matching, klib_sequence_matching, bad_align_uniq_kmer_len, packed_reads,
     devices (list of HIP ordinals the lanes are spread over; default PG_DEVICES, else device 0)."""
-    L = load_library()
-    paths = (C.c_char_p * len(graph_paths))(*[os.fsencode(p) for p in graph_paths])
-    err = C.create_string_buffer(4096)
     keep = output_path is not None
     if not keep:
         fd, output_path = tempfile.mkstemp(suffix=".json")
         os.close(fd)
     try:
-        rc = L.pgw_genotype_graphs(os.fsencode(reference_fasta), os.fsencode(manifest), paths, len(graph_paths),
-                                   os.fsencode(genotyping_parameters) if genotyping_parameters else None,
-                                   json.dumps(options).encode() if options else None, os.fsencode(output_path), err, len(err))
-        if rc != 0:
-            raise RuntimeError("pgw_genotype_graphs: " + err.value.decode(errors="replace"))
+        genotype_graphs_to_file(reference_fasta, manifest, graph_paths, output_path, genotyping_parameters, **options)
         with open(output_path) as f:
             return json.load(f)
     finally:

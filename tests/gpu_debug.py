@@ -6,7 +6,8 @@ from oracle import oracle as orc
 from tests import fuzzgen
 from tests.test_gpu_parity import ALIGNS_GRAPH, ALIGNS_READS, gpu_align, KEYS
 
-chk = orc.RefOracle() if orc.have_ref() else orc.PortOracle()
+from oracle import select
+chk = select.gssw()
 ctx = capi.Context(0)
 
 def report(name, got, want, reads, limit=5):

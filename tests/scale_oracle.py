@@ -28,8 +28,8 @@ def _ncpu():
 
 
 def _checker():
-    from oracle import oracle as orc
-    return orc.RefOracle() if orc.have_ref() else orc.PortOracle()
+    from oracle import select
+    return select.gssw()
 
 
 def _align_site(chk, seqs, edges, arr, stride):

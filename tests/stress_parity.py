@@ -47,7 +47,8 @@ def run(n_graphs, seed, ctx, checker, verbose=True):
 def main():
     n_graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    checker = orc.RefOracle() if orc.have_ref() else orc.PortOracle()
+    from oracle import select
+    checker = select.gssw()
     total = run(n_graphs, seed, capi.Context(0), checker)
     print("stress parity OK: %d graphs, %d reads" % (n_graphs, total))
 

@@ -90,7 +90,8 @@ def test_cpu_leg_and_verification(tmp_path):
     z = np.load(out_file)
     res, cig = z["res"], z["cig"]
     assert len(res) == len(cig) >= 2000 and cig.shape[1] == bench.CIGAR_STRIDE
-    chk = orc.RefOracle() if orc.have_ref() else orc.PortOracle()
+    from oracle import select
+    chk = select.gssw()
     reads = [row.tobytes().decode() for row in arr[:40]]
     for i, w in enumerate(chk.align_batch(site.seqs, site.edges, reads)):
         assert w["cigar"].encode() == bytes(cig[i]).split(b"\0")[0] and w["graph_pos"] == res[i]["graph_pos"] and w["score"] == res[i]["score"]
@@ -133,3 +134,49 @@ def test_bench_spawn_command(monkeypatch):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--workload", "config3"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "PG_BENCH_LAUNCHER" in os.environ
+
+
+def test_e2e_data_set_two_parts_and_reference_view(tmp_path, monkeypatch):
+    """bench.py's e2e leg, the CPU side: two 'ranks' each make the pieces of their half of the sites, rank 0 joins them into the
+    same data set one process makes alone; the sampled sites come out as the reference's workflow would see them (GraphInput's
+    one-base source / sink nodes, the reads ReadExtraction keeps, BAM strand flags) and the reference's counting finds the
+    simulated alleles on them."""
+    import argparse
+    import filecmp
+    import bench
+    from paragraph_amd import synth_e2e
+    one = synth_e2e.make_dataset(str(tmp_path / "one"), n_sites=24, seed=1, procs=2, keep_sites=[0, 8, 16])
+    args = argparse.Namespace(e2e_sites=24, e2e_verify=3, no_cpu_baseline=False, read_len=150)
+    monkeypatch.setenv("MASTER_PORT", "t%d" % os.getpid())
+    monkeypatch.setattr(bench.tempfile, "gettempdir", lambda: str(tmp_path))
+    monkeypatch.setattr(bench.os.path, "isdir", lambda p: False if p == "/dev/shm" else os.path.exists(p) and not os.path.isfile(p))
+    import threading
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault(1, bench.prepare_e2e(args, 1, 2, 2)))
+    t.start()
+    got[0] = bench.prepare_e2e(args, 0, 2, 2)
+    t.join()
+    for name in ("reads.bam", "reads.bam.bai", "ref.fa", "truth.json"):
+        assert filecmp.cmp(os.path.join(got[0]["dir"], name), os.path.join(str(tmp_path / "one"), name), shallow=False), name
+    assert got[0]["reads"] == got[1]["reads"] == one["reads"] and got[0]["sample_idx"] == [0, 8, 16]
+    assert got[1]["truth"] == got[0]["truth"] and got[1]["graphs"] == got[0]["graphs"]
+    sample = bench.e2e_reference_sites(got[0], 150)
+    from oracle import select
+    chk = select.gssw()
+    for i, s in zip(got[0]["sample_idx"], sample):
+        assert s.site.seqs[0] == s.site.seqs[-1] == "X" and 150 < len(s.reads) < len(got[0]["kept"][i]["pos"])
+        w = bench.reference_site_outcome(chk, s, bench.SITES_CIGAR_STRIDE)
+        counts = {(s.site.names[a], s.site.names[b]): int(w["edge_counts"][k][0]) for k, (a, b) in enumerate(s.site.edges)}
+        alt_edges = [e for e, labs in ((e, s.site.labels.get((s.site.names.index(e[0]), s.site.names.index(e[1])), [])) for e in counts) if labs == ["ALT"]]
+        ref_edges = [e for e, labs in ((e, s.site.labels.get((s.site.names.index(e[0]), s.site.names.index(e[1])), [])) for e in counts) if labs == ["REF"]]
+        gt = got[0]["truth"][i]["gt"]
+        assert (sum(counts[e] for e in alt_edges) > 0) == ("ALT" in gt) and (sum(counts[e] for e in ref_edges) > 0) == ("REF" in gt)
+
+
+def test_roofline_head_names_the_bound_that_binds():
+    import bench
+    with_counters = bench.roofline_head({"traffic": 5.0e10, "valu": {"issue_frac_with_measured_pairing": 0.77, "issue_frac": 0.74, "clock_ghz": 2.4}}, 9900.0)
+    assert with_counters["bound"] == "valu" and with_counters["frac"] == 0.77 and with_counters["traffic"] == 5.0e10
+    assert abs(with_counters["achieved"] / with_counters["peak"] - 0.77) < 1e-12 and with_counters["hbm_formula_frac"] > 1.0
+    without = bench.roofline_head({"traffic": None, "valu": {"why": "no counters"}}, 9900.0)
+    assert without["bound"] == "hbm" and without["unit"] == "GB/s" and without["frac"] == without["hbm_formula_frac"]

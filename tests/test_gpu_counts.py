@@ -15,11 +15,8 @@ ALIGNS_READS = ["AAAAAAAATTTTCTTTAAAAAAAA", "TTTTTTAAAGAAAATTTTTTT", "AAAAAGCGGG
 
 
 def count_checker():
-    from oracle import counts as oc
-    if oc.have_ref():
-        ref = oc.RefCounts()
-        return ref.count_site
-    return oc.port_count_site
+    from oracle import select
+    return select.count_site()
 
 
 def gpu_counts(ctx, graphs, labels, names, reads, gor, frag, isrev, filter_k=0, **kw):
@@ -161,10 +158,9 @@ def _rc(s):
 @pytest.mark.parametrize("filter_k", [4, 8, -1])
 def test_kmer_filter_fuzz(gpu_ctx, filter_k):
     """KmerFilter as the third filter of the chain: per-read outcome and the resulting counters."""
-    from oracle import counts as oc
-    from oracle import kmerfilter as kf
+    from oracle import select
     check = count_checker()
-    fcheck = kf.ref_kmer_filter if oc.have_ref() else kf.port_kmer_filter
+    fcheck = select.kmer_filter()
     rng = random.Random(fuzzgen.salted(4040 + filter_k))
     graphs, labels, names, reads, gor, frag, isrev = [], [], [], [], [], [], []
     while len(graphs) < 80:

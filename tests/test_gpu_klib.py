@@ -14,8 +14,8 @@ KEYS = ("graph_pos", "score", "cigar")
 
 
 def checker():
-    from oracle import klibalign as ok
-    return ok.ref_klib() if ok.have_ref() else ok.port_klib()
+    from oracle import select
+    return select.klib()
 
 
 def gpu_klib(ctx, graphs, paths, reads, gor, expect_packed=None, active=None):

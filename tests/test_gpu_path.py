@@ -13,8 +13,8 @@ PKEYS = ("graph_pos", "score", "mapq", "unique", "cigar")
 
 
 def path_checker():
-    from oracle import pathalign as pa
-    return pa.ref_path_align if pa.have_ref() else pa.port_path_align
+    from oracle import select
+    return select.path_align()
 
 
 def gpu_path(ctx, graphs, reads, gor, k):

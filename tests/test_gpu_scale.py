@@ -123,7 +123,8 @@ def test_bench_two_ranks_shard_one_site_set():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "config3", "--sites", "400",
-                        "--steps", "2", "--warmup", "1", "--workspace-gib", "16"], stdout=subprocess.PIPE, env=env, timeout=900)
+                        "--steps", "2", "--warmup", "1", "--workspace-gib", "16", "--e2e-sites", "300", "--e2e-steps", "1", "--e2e-verify", "40"],
+                       stdout=subprocess.PIPE, env=env, timeout=900)
     assert p.returncode == 0, p.stdout.decode()[-2000:]
     line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
@@ -131,6 +132,13 @@ def test_bench_two_ranks_shard_one_site_set():
     assert out["sites"]["reduce_equals_single"] is True, out["sites"]
     assert out["sites"]["sites"] == 400 and len(out["sites"]["shard_reads"]) == 2 and min(out["sites"]["shard_reads"]) > 0
     assert out["sites"]["tallies"]["aligned"] == out["sites"]["reads"]
+    # BAM -> genotypes, two ranks: each genotypes its half of the sites from the one BAM, the edge-count table is summed over gloo
+    e = out["e2e"]
+    assert e["sites"] == 300 and e["mismatches"] == 0 and e["genotypes_equal_truth"] >= 298 and e["documents_with_error"] == 0, e
+    assert len(e["per_rank"]) == 2 and sorted(r["sites"] for r in e["per_rank"]) == [150, 150]
+    assert e["edge_table"]["reduced_equals_own_on_own_sites"] is True and e["edge_table"]["sum"] > 300 * 20
+    assert e["verified"]["sites"] == 40 and e["verified"]["site_mismatches"] == 0 and e["verified"]["reads"] > 40 * 150, e["verified"]
+    assert e["sites_genotyped_per_s"] > 0 and e["cpu_us_per_site_sample"] > 0
 
 
 def _run_bench(argv, timeout=900):
@@ -146,7 +154,7 @@ def test_bench_two_ranks_split_a_hot_site_by_fragment():
     """a hot site (here ~10 000 reads, grmpy's cap) is split over the ranks by FRAGMENT id -- mates stay
     together -- and the all-reduce then really sums that site's counters: reduced table == 1-rank table."""
     out = _run_bench(["--gpus", "2", "--workload", "config3", "--sites", "200", "--hot-site-depth", "1500", "--steps", "2",
-                      "--warmup", "1", "--workspace-gib", "16"])
+                      "--warmup", "1", "--workspace-gib", "16", "--e2e-steps", "0"])
     hot = out["sites"]["hot_sites_split_by_fragment"]
     assert len(hot) == 1 and hot[0]["reads"] >= 5000 and min(hot[0]["reads_per_rank"]) > 1000, hot
     assert out["sites"]["reduce_equals_single"] is True, out["sites"]
@@ -162,7 +170,8 @@ def test_bench_eight_ranks_share_the_gpu():
     import time
     t0 = time.perf_counter()
     out = _run_bench(["--gpus", "8", "--workload", "config3", "--sites", "800", "--hot-site-depth", "1500", "--steps", "2",
-                      "--warmup", "1", "--workspace-gib", "8", "--sites-verify", "100"], timeout=1500)
+                      "--warmup", "1", "--workspace-gib", "8", "--sites-verify", "100", "--e2e-sites", "800", "--e2e-steps", "1",
+                      "--e2e-verify", "50"], timeout=1500)
     d, s = out["dist"], out["sites"]
     assert out["n_gpus"] == 8 and d["world"] == 8 and d["shared_device"] is True and d["backend"] == "gloo", d
     assert d["placement_ok"] is True and len(d["ranks"]) == 8 and sorted(r["rank"] for r in d["ranks"]) == list(range(8))
@@ -174,9 +183,13 @@ def test_bench_eight_ranks_share_the_gpu():
     assert len(s["per_rank"]) == 8 and all(r["fill_launches"] > 0 for r in s["per_rank"]), s["per_rank"]
     assert s["collective_ab"]["with_vs_without"] > 0
     assert s["tallies"]["aligned"] == s["reads"]
+    # the BAM -> genotypes leg with eight ranks: every rank its eighth of the sites from the one BAM the eight made together
+    e = out["e2e"]
+    assert e["sites"] == 800 and e["mismatches"] == 0 and e["genotypes_equal_truth"] >= 796, e
+    assert len(e["per_rank"]) == 8 and all(r["sites"] == 100 for r in e["per_rank"]) and e["verified"]["site_mismatches"] == 0
     # the default workload at N = 8: weak scaling of config 2 + the sites leg, per-rank fill times in the line
     out = _run_bench(["--gpus", "8", "--reads", "100000", "--steps", "2", "--warmup", "1", "--sites", "400", "--sites-steps", "1",
-                      "--sites-verify", "50", "--workspace-gib", "8"], timeout=1500)
+                      "--sites-verify", "50", "--workspace-gib", "8", "--e2e-steps", "0"], timeout=1500)
     d = out["dist"]
     assert out["n_gpus"] == 8 and out["scaling"] == "weak" and d["world"] == 8 and len(d["per_rank"]) == 8, d
     assert all(r["fill_launches"] > 0 and r["fill_ms_per_launch"] > 0 for r in d["per_rank"])
@@ -190,7 +203,7 @@ def test_bench_one_rank_runs_the_rccl_reduce_stream_ordered():
     """N = 1 with a world-size-1 RCCL communicator: the all-reduce of the counter table is inside every timed step, ordered
     by events (no host synchronisation), and costs (next to) nothing; the counts are those of the plain path."""
     out = _run_bench(["--reads", "400000", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--stream-batches", "0",
-                      "--sites", "300", "--sites-steps", "2"])
+                      "--sites", "300", "--sites-steps", "2", "--e2e-sites", "600", "--e2e-steps", "2"])
     d = out["dist"]
     assert d["backend"] == "nccl" and d["world"] == 1 and d["collective_in_step"] is True, d
     assert d["ranks"][0]["device"] == 0
@@ -199,8 +212,11 @@ def test_bench_one_rank_runs_the_rccl_reduce_stream_ordered():
     t = out["counts"]["tallies"]
     assert t["aligned"] == 400000, t
     assert out["sites"]["tallies"]["aligned"] == out["sites"]["reads"]
+    e = out["e2e"]  # one rank, no CPU checker leg (--no-cpu-baseline): genotypes against the truth, the table through RCCL
+    assert e["sites"] == 600 and e["mismatches"] == 0 and e["genotypes_equal_truth"] >= 597 and "verified" not in e, e
+    assert e["edge_table"]["reduce_ms"] is not None and e["host_threads"] >= 1
     plain = _run_bench(["--reads", "400000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--stream-batches", "0",
-                        "--sites-steps", "0", "--collective", "off"])
+                        "--sites-steps", "0", "--collective", "off", "--e2e-steps", "0"])
     assert plain["dist"]["collective_in_step"] is False
     assert plain["counts"] == out["counts"]
 

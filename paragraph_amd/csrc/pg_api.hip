@@ -280,6 +280,11 @@ extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
         (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     // reads of 251..512 bases: 32 lanes per read (two wavefronts per work item); PG_WIDE16=1 = the 16-lane kernels, for A/B timing
     ctx->wide32 = getenv("PG_WIDE16") == nullptr;
+    {
+        int lds = 0;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
+            ctx->max_lds_per_block = (uint64_t)lds;
+    }
     const char* pe = getenv("PG_STREAM_PRIORITY");
     const int side_prio = (pe && pe[0] == '0') ? 0 : prio_greatest;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess
@@ -626,15 +631,24 @@ extern "C" pg_status pg_graphs_upload(
     std::vector<char> seqchars;
     std::vector<HostGraph> host(n_graphs);
     {
-        // (sizes are known up front: one word per column and direction + the idle tail, one character per column)
+        // (sizes are known up front: one word per column and direction + the idle tail, one character per column).  The offsets
+        // have not been validated yet: every size is clamped, and a reservation that fails is only a missed optimisation --
+        // nothing may throw out of an extern "C" function (the per-graph checks below return PG_ERR_INVALID for bad offsets)
         const uint32_t total_nodes = node_off[n_graphs];
         const uint64_t total_cols = seq_off[total_nodes] >= seq_off[0] ? seq_off[total_nodes] - seq_off[0] : 0;
-        if (total_cols < (1ull << 30))
+        const uint64_t total_preds = pred ? pred_off[total_nodes] : 0;
+        if (total_cols < (1ull << 30) && total_nodes < (1u << 28) && total_preds < (1ull << 30) && node_off[0] <= total_nodes)
         {
-            colmeta.reserve(2 * total_cols + 2ull * n_graphs * PG_META_PAD);
-            seqchars.reserve(total_cols);
-            nodes.reserve(2ull * total_nodes);
-            preds.reserve(2ull * (pred ? pred_off[total_nodes] : 0) + 1);
+            try
+            {
+                colmeta.reserve(2 * total_cols + 2ull * n_graphs * PG_META_PAD);
+                seqchars.reserve(total_cols);
+                nodes.reserve(2ull * total_nodes);
+                preds.reserve(2ull * total_preds + 1);
+            }
+            catch (std::exception const&)
+            {
+            }
         }
     }
     std::vector<std::vector<uint32_t>> succ;  // (reused from graph to graph)
@@ -654,6 +668,8 @@ extern "C" pg_status pg_graphs_upload(
             const uint32_t len = seq_off[nb + i + 1] - seq_off[nb + i];
             if (seq_off[nb + i + 1] <= seq_off[nb + i])
                 return fail(ctx, PG_ERR_INVALID, "empty node sequence");
+            if (len >= (1u << 24))  // pg_general.hip's per-node maximum key holds the in-node column in 24 bits
+                return fail(ctx, PG_ERR_UNSUPPORTED, "node of 2^24 columns or more");
             total += len;
             for (uint32_t k = pred_off[nb + i]; k < pred_off[nb + i + 1]; ++k)
             {
@@ -952,6 +968,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
     };
     std::vector<Key> keys;
     keys.reserve(n_reads);
+    uint64_t gen_total = 0, gen_largest = 0;
     for (uint32_t i = 0; i < n_reads; ++i)
     {
         const uint32_t L = base_off[i + 1] - base_off[i];
@@ -963,13 +980,24 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
             // budget is decided HERE, before anything of the batch is queued: pg_batch_align must not find out after the
             // packed chunks' kernels are in flight (the caller drops the site and recycles its device blocks on this error)
             const HostGraph& hg = G->host[graph_of_read[i]];
-            if (pg_gen_read_bytes(L, hg.ncols, hg.n_nodes) > ctx->ws_limit)
+            // the general fill keeps two rolling columns + the query codes of its read in LDS: 5 bytes per base (pg_general.hip)
+            if ((uint64_t)5 * L + 4 > ctx->max_lds_per_block)
+                return fail(ctx, PG_ERR_UNSUPPORTED, "read too long for the general path's LDS columns on this device");
+            const uint64_t gen_need = pg_gen_read_bytes(L, hg.ncols, hg.n_nodes);
+            if (gen_need > ctx->ws_limit)
                 return fail(ctx, PG_ERR_UNSUPPORTED, "workspace limit too small for one read of the general path (read length x graph columns)");
+            gen_total += gen_need;
+            gen_largest = std::max(gen_largest, gen_need);
             b->gen_idx.push_back(i);
             continue;
         }
         keys.push_back(Key{ (uint32_t)pg_variant_of(L), graph_of_read[i], i });
     }
+    // ONE budget (pg_ctx_set_workspace_bytes) for both paths: the general path's share -- all of its reads when they fit 8 GiB or
+    // a quarter of the budget, else groups of that size, and never less than its largest read -- comes out of what the packed
+    // chunks may take, so the context's device memory stays within the budget and a batch that cannot fit is refused HERE.
+    b->gen_reserve = b->gen_idx.empty() ? 0 : std::min<uint64_t>(gen_total, std::max<uint64_t>(gen_largest, std::min<uint64_t>(8ull << 30, ctx->ws_limit / 4)));
+    const uint64_t packed_limit = ctx->ws_limit - b->gen_reserve;
     const auto key_less = [](const Key& x, const Key& y) { return x.c != y.c ? x.c < y.c : x.graph < y.graph; };
     if (!std::is_sorted(keys.begin(), keys.end(), key_less))  // reads of one length, site after site, arrive in order
         std::stable_sort(keys.begin(), keys.end(), key_less);
@@ -1047,7 +1075,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
             largest[keys[p0].c] = std::max(largest[keys[p0].c], need);
             p0 = q0;
         }
-        const uint64_t cap = ctx->ws_limit / 2;
+        const uint64_t cap = packed_limit / 2;
         for (size_t c = 0; c < total.size(); ++c)
         {
             if (!total[c])
@@ -1074,8 +1102,9 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
         const HostGraph& hg = G->host[keys[p].graph];
         const PairNeed pn = pair_need(C, hg);
         const uint64_t nsteps = pn.nsteps, trace_bytes = pn.trace_bytes, seed_bytes = pn.seed_bytes, need = pn.need;
-        if (need > ctx->ws_limit / 2)
-            return fail(ctx, PG_ERR_UNSUPPORTED, "workspace limit too small for one wavefront of this graph");
+        if (need > packed_limit / 2)
+            return fail(ctx, PG_ERR_UNSUPPORTED, b->gen_reserve ? "workspace limit too small for one wavefront of this graph beside the batch's general-path reads"
+                                                               : "workspace limit too small for one wavefront of this graph");
         if (open && (cur.C != C || cur.ws_bytes + need > chunk_target[C]))
             close_chunk();
         if (!open)
@@ -1147,7 +1176,7 @@ static pg_status ensure_ctx_workspace(pg_ctx* ctx, const pg_batch* b)
         ctx->half_free[0] = ctx->half_free[1] = nullptr;  // both streams are idle: nothing reads the old halves
         // batches of one workflow differ by a few percent: one eighth of headroom spares the next, slightly larger one a
         // second multi-GiB allocation (each costs up to a second)
-        uint64_t want = std::min<uint64_t>(need + need / 8, std::max<uint64_t>(ctx->ws_limit, need));
+        uint64_t want = std::min<uint64_t>(need + need / 8, std::max<uint64_t>(ctx->ws_limit - std::min(ctx->ws_limit, b->gen_reserve), need));
         want = align_up(want, 512);
         if (hipMalloc((void**)&ctx->workspace, want) != hipSuccess)
         {
@@ -1185,10 +1214,19 @@ static pg_status run_general(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     // the second stream, which run in order -- no host wait for the stream itself.
     HIP_TRY(ctx, pg_batch_wait(ctx, b));
     b->h_gen_reads.assign(n, PgGenRead{});
-    // The general workspace comes ON TOP of the packed kernels' (which may hold up to the whole budget): groups are cut at a
-    // budget of its own, 8 GiB or the context's limit if that is smaller -- a single read beyond that (within the limit: checked
-    // by plan_items) is a group by itself.
-    const uint64_t gen_limit = std::min<uint64_t>(ctx->ws_limit, 8ull << 30);
+    // The general workspace is the share of the context's budget plan_items set aside for it (gen_reserve: the packed chunks were
+    // cut to what is left, so both together stay within pg_ctx_set_workspace_bytes); groups are cut at that share.
+    const uint64_t gen_limit = std::max<uint64_t>(b->gen_reserve, 1);
+    // A launch's dynamic LDS is sized by its longest read (5 bytes per base, every block of the launch): reads are grouped by
+    // length class, so that 150-base reads on a wide graph do not run with the two-blocks-per-CU occupancy of a 16 000-base one
+    auto length_class = [&](uint32_t r) {
+        const uint32_t L = b->h_base_off[r + 1] - b->h_base_off[r];
+        uint32_t c = 0;
+        while ((512u << c) < L)
+            ++c;
+        return c;  // <= 512, <= 1024, ... <= 16 384 bases
+    };
+    std::stable_sort(b->gen_idx.begin(), b->gen_idx.end(), [&](uint32_t x, uint32_t y) { return length_class(x) < length_class(y); });
     std::vector<std::pair<size_t, size_t>> groups;
     uint64_t cur = 0, largest = 0;
     size_t begin = 0;
@@ -1200,7 +1238,7 @@ static pg_status run_general(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         const uint64_t need = pg_gen_read_bytes(L, hg.ncols, hg.n_nodes);
         if (need > ctx->ws_limit)
             return fail(ctx, PG_ERR_UNSUPPORTED, "workspace limit too small for one read of the general path (read length x graph columns)");
-        if (cur + need > gen_limit && i > begin)
+        if (i > begin && (cur + need > gen_limit || length_class(r) != length_class(b->gen_idx[i - 1])))
         {
             groups.emplace_back(begin, i);
             begin = i;
@@ -1279,6 +1317,8 @@ extern "C" pg_status pg_batch_upload(
     b->has_skipped = false;
     b->fragments_set = false;
     b->has_active = false;
+    b->label_ext_words = 0;  // the label sets of an earlier count belong to the earlier reads
+    b->label_ext_reads = 0;
     b->host_template.clear();  // built only when a read is skipped (rare)
     uint64_t ops_total = 0;
     for (uint32_t i = 0; i < n_reads; ++i)

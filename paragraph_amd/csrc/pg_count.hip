@@ -736,6 +736,7 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     a.label_words = G->label_words;
     a.frag_lds_counters = G->frag_lds_counters;
     b->label_ext_words = G->label_words - 1;
+    b->label_ext_reads = n;
     if (b->label_ext_words)
     {
         const size_t need = std::max<size_t>(n, 1) * b->label_ext_words;
@@ -788,9 +789,15 @@ extern "C" pg_status pg_batch_download_label_ext(pg_ctx* ctx, pg_batch* b, uint6
 {
     if (!ctx || !b || !b->graphs || !b->d_support)
         return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_download_label_ext: pg_batch_count has not run");
+    // the sets on the device are those of the last pg_batch_count: a batch uploaded again since (other reads, another graph set)
+    // has none until it is counted again
+    if (b->label_ext_reads != b->n_reads || b->label_ext_words != b->graphs->label_words - 1)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_download_label_ext: the batch was uploaded again after its last pg_batch_count");
     const uint64_t need = (uint64_t)b->n_reads * b->label_ext_words;
     if (need == 0)
         return PG_OK;
+    if (need > b->cap_label_ext)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_download_label_ext: no label sets of this size on the device");
     if (!label_ext || cap_words < need)
         return pg_fail(ctx, PG_ERR_OVERFLOW, "label_ext buffer too small (n_reads x (words - 1))");
     HIP_TRY(ctx, hipSetDevice(ctx->device));

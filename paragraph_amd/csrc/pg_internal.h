@@ -45,6 +45,7 @@ struct pg_ctx
     uint64_t chunk_seq = 0;
     hipEvent_t half_free[2] = { nullptr, nullptr };
     uint64_t ws_limit = 8ull << 30;
+    uint64_t max_lds_per_block = 64 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock (gfx950: 160 KB)
     uint8_t* workspace = nullptr;
     uint64_t ws_cap = 0;
     // workspace of the general path (reads / graphs beyond the packed kernels' envelope); used on stream2 only
@@ -126,6 +127,7 @@ struct pg_batch
     PgFillSummary* d_gen_fsum = nullptr;
     size_t cap_gen = 0;
     uint64_t max_ws = 0;
+    uint64_t gen_reserve = 0;  // the general path's share of the context's workspace budget (plan_items)
     size_t cap_reads = 0, cap_bases = 0, cap_items = 0;
     std::vector<pg_result> host_template;  // status for reads the device never sees (empty reads)
     bool has_skipped = false;
@@ -140,6 +142,7 @@ struct pg_batch
     uint64_t* d_label_ext = nullptr;  // [n_reads][label_words - 1]: the label sets' words beyond pg_read_support.label_mask
     size_t cap_label_ext = 0;
     uint32_t label_ext_words = 0;     // words - 1 of the last pg_batch_count
+    uint32_t label_ext_reads = 0;     // ... and the reads it counted (a later upload must not be read with this stride)
     uint32_t* d_path = nullptr;
     unsigned long long* d_path_counter = nullptr;
     uint32_t* d_frag_off = nullptr;

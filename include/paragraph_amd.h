@@ -166,6 +166,13 @@ const char* pg_strerror(pg_status st);
 const char* pg_last_error(const pg_ctx* ctx);
 /* bytes of HBM the ctx may use for traceback state per chunk (default 8 GiB) */
 pg_status pg_ctx_set_workspace_bytes(pg_ctx* ctx, uint64_t bytes);
+/* 1 (default): the fills of a batch's chunks run one after the other on the main stream, over two workspace regions.
+ * 2: three regions, the fills alternate between two streams, so that the next chunk's wavefronts take the slots a draining
+ * launch leaves -- for workflows whose launches are short (a 192-site batch fills for ~2 ms, 10 - 15 % of it the tail in
+ * which the chip drains; the reference has no such grain: one site per call, lib/grmpy/AlignSamples.cpp:115-172).  Call it
+ * before batches are uploaded (the chunk plan is cut to the region size); it drains the compute streams.  Results do not
+ * depend on it.  The environment variable PG_FILL_STREAMS=1|2 overrides it (A/B timing). */
+pg_status pg_ctx_set_fill_streams(pg_ctx* ctx, int n);
 pg_status pg_ctx_sync(pg_ctx* ctx);
 /* waits for the compute streams only (stage calls queued so far); uploads / downloads of other batches keep running */
 pg_status pg_ctx_sync_compute(pg_ctx* ctx);

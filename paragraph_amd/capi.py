@@ -48,7 +48,7 @@ EXPORTS = [
     "pg_batch_path_align", "pg_batch_download_path_flags", "pg_batch_set_active", "pg_graphs_build_kmer_index",
     "pg_batch_kmer_align", "pg_graphs_build_klib_index", "pg_batch_klib_align", "pg_graphs_klib_error", "pg_graphs_klib_last_kernels", "pg_graphs_build_filter_index",
     "pg_host_alloc", "pg_host_free", "pg_host_register", "pg_host_unregister", "pg_counts_zero", "pg_ctx_sync_compute",
-    "pg_render_cigars", "pg_ctx_native_stream", "pg_ctx_count_record", "pg_ctx_count_wait",
+    "pg_render_cigars", "pg_ctx_native_stream", "pg_ctx_count_record", "pg_ctx_count_wait", "pg_ctx_set_fill_streams",
 ]
 
 
@@ -99,6 +99,8 @@ def load_library():
     L.pg_last_error.argtypes = [vp]
     L.pg_ctx_set_workspace_bytes.restype = C.c_int32
     L.pg_ctx_set_workspace_bytes.argtypes = [vp, C.c_uint64]
+    L.pg_ctx_set_fill_streams.restype = C.c_int32
+    L.pg_ctx_set_fill_streams.argtypes = [vp, C.c_int]
     L.pg_ctx_sync.restype = C.c_int32
     L.pg_ctx_sync.argtypes = [vp]
     L.pg_ctx_timing_enable.restype = C.c_int32
@@ -273,7 +275,7 @@ def pack_reads(reads):
 class Context:
     """One pg_ctx (one device, one stream)."""
 
-    def __init__(self, device=0, workspace_bytes=None):
+    def __init__(self, device=0, workspace_bytes=None, fill_streams=None):
         self.L = load_library()
         h = C.c_void_p()
         st = self.L.pg_ctx_create(device, C.byref(h))
@@ -282,6 +284,13 @@ class Context:
         self.h = h
         if workspace_bytes:
             self._chk(self.L.pg_ctx_set_workspace_bytes(self.h, workspace_bytes))
+        if fill_streams:
+            self.set_fill_streams(fill_streams)
+
+    def set_fill_streams(self, n):
+        """1: fills one after the other on the main stream (two workspace regions); 2: fills alternate over two streams (three
+        regions) -- short launches then overlap their tails.  Before batches are uploaded; results do not depend on it."""
+        self._chk(self.L.pg_ctx_set_fill_streams(self.h, n))
 
     def _chk(self, st):
         if st != PG_OK:

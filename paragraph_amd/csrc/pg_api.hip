@@ -287,14 +287,38 @@ extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
     }
     const char* pe = getenv("PG_STREAM_PRIORITY");
     const int side_prio = (pe && pe[0] == '0') ? 0 : prio_greatest;
+    // (the second fill stream right after the first: the runtime deals its hardware queues round-robin, so the two land on
+    // different ones)
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess
+        || hipStreamCreateWithFlags(&ctx->stream_fill2, hipStreamNonBlocking) != hipSuccess
         || hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, side_prio) != hipSuccess
         || hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, side_prio) != hipSuccess)
     {
         delete ctx;
         return PG_ERR_HIP;
     }
+    if (const char* fs = getenv("PG_FILL_STREAMS"))  // A/B timing: overrides pg_ctx_set_fill_streams' default of this context
+        ctx->fill_streams = fs[0] == '2' ? 2 : 1;
     *out = ctx;
+    return PG_OK;
+}
+
+extern "C" pg_status pg_ctx_set_fill_streams(pg_ctx* ctx, int n)
+{
+    if (!ctx || (n != 1 && n != 2))
+        return PG_ERR_INVALID;
+    if (getenv("PG_FILL_STREAMS"))
+        return PG_OK;  // the environment decides (A/B runs)
+    if (n == ctx->fill_streams)
+        return PG_OK;
+    // the regions are re-cut: nothing may be in flight on them
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_fill2));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
+    for (auto& e : ctx->region_free)
+        e = nullptr;
+    ctx->fill_streams = n;
     return PG_OK;
 }
 
@@ -305,6 +329,8 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream_fill2)
+        (void)hipStreamSynchronize(ctx->stream_fill2);
     if (ctx->stream2)
         (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream_copy)
@@ -325,6 +351,8 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
         (void)hipFree(ctx->gen_ws);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream_fill2)
+        (void)hipStreamDestroy(ctx->stream_fill2);
     if (ctx->stream2)
         (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream_copy)
@@ -348,6 +376,7 @@ extern "C" pg_status pg_ctx_sync(pg_ctx* ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_fill2));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     recycle_sync_events(ctx);
     return PG_OK;
@@ -410,6 +439,7 @@ extern "C" pg_status pg_ctx_sync_compute(pg_ctx* ctx)
         return PG_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_fill2));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     return PG_OK;
 }
@@ -490,6 +520,7 @@ hipError_t pg_batch_wait(pg_ctx* ctx, pg_batch* b)
 static pg_status drain_events(pg_ctx* ctx)
 {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_fill2));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     for (auto& e : ctx->events)
     {
@@ -562,7 +593,8 @@ static void recycle_sync_events(pg_ctx* ctx)
     for (auto e : ctx->sync_events_in_flight)
         ctx->sync_event_pool.push_back(e);
     ctx->sync_events_in_flight.clear();
-    ctx->half_free[0] = ctx->half_free[1] = nullptr;  // every traceback is over (the caller synchronised both streams)
+    for (auto& e : ctx->region_free)
+        e = nullptr;  // every traceback is over (the caller synchronised the compute streams)
 }
 // A workflow never calls pg_ctx_sync: ordering events whose work is over (they complete in the order they were recorded
 // per stream, so the scan stops at the first one still pending) go back to the pool at the start of every pg_batch_align.
@@ -572,9 +604,9 @@ static void recycle_done_sync_events(pg_ctx* ctx)
     while (done < ctx->sync_events_in_flight.size() && hipEventQuery(ctx->sync_events_in_flight[done]) == hipSuccess)
     {
         const hipEvent_t e = ctx->sync_events_in_flight[done++];
-        for (int h = 0; h < 2; ++h)
-            if (ctx->half_free[h] == e)
-                ctx->half_free[h] = nullptr;  // that traceback is over: the half needs no wait (and the event gets a new job)
+        for (auto& rf : ctx->region_free)
+            if (rf == e)
+                rf = nullptr;  // that traceback is over: the region needs no wait (and the event gets a new job)
         ctx->sync_event_pool.push_back(e);
     }
     if (done)
@@ -1075,7 +1107,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
             largest[keys[p0].c] = std::max(largest[keys[p0].c], need);
             p0 = q0;
         }
-        const uint64_t cap = packed_limit / 2;
+        const uint64_t cap = packed_limit / ctx->regions();
         for (size_t c = 0; c < total.size(); ++c)
         {
             if (!total[c])
@@ -1102,7 +1134,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
         const HostGraph& hg = G->host[keys[p].graph];
         const PairNeed pn = pair_need(C, hg);
         const uint64_t nsteps = pn.nsteps, trace_bytes = pn.trace_bytes, seed_bytes = pn.seed_bytes, need = pn.need;
-        if (need > packed_limit / 2)
+        if (need > packed_limit / ctx->regions())
             return fail(ctx, PG_ERR_UNSUPPORTED, b->gen_reserve ? "workspace limit too small for one wavefront of this graph beside the batch's general-path reads"
                                                                : "workspace limit too small for one wavefront of this graph");
         if (open && (cur.C != C || cur.ws_bytes + need > chunk_target[C]))
@@ -1162,18 +1194,20 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
 // pg_batch_align (never while planning, so that a batch can be uploaded while another one is on the device).
 static pg_status ensure_ctx_workspace(pg_ctx* ctx, const pg_batch* b)
 {
-    // Two halves, used alternately by the chunks of all batches (ctx->chunk_seq): the traceback of a chunk overlaps the fill of
-    // the next chunk -- of the same batch or of the next batch.
-    const uint64_t need = 2 * b->max_ws;
+    // Two (three with two fill streams) regions, used in turn by the chunks of all batches (ctx->chunk_seq): the traceback of a
+    // chunk overlaps the fill of the next chunk -- of the same batch or of the next batch.
+    const uint64_t need = (uint64_t)ctx->regions() * b->max_ws;
     if (need > ctx->ws_cap)
     {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_fill2));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
         if (ctx->workspace)
             HIP_TRY(ctx, hipFree(ctx->workspace));
         ctx->workspace = nullptr;
         ctx->ws_cap = 0;
-        ctx->half_free[0] = ctx->half_free[1] = nullptr;  // both streams are idle: nothing reads the old halves
+        for (auto& e : ctx->region_free)
+            e = nullptr;  // the compute streams are idle: nothing reads the old regions
         // batches of one workflow differ by a few percent: one eighth of headroom spares the next, slightly larger one a
         // second multi-GiB allocation (each costs up to a second)
         uint64_t want = std::min<uint64_t>(need + need / 8, std::max<uint64_t>(ctx->ws_limit - std::min(ctx->ws_limit, b->gen_reserve), need));
@@ -1433,12 +1467,13 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             if (done)
                 return;
             hipEvent_t e;
-            if (get_sync_event(c, &e) == hipSuccess)
-            {
-                if (hipEventRecord(e, c->stream) == hipSuccess)
-                    (void)hipStreamWaitEvent(c->stream2, e, 0);
-                c->sync_events_in_flight.push_back(e);
-            }
+            for (hipStream_t fs : { c->stream, c->stream_fill2 })
+                if (get_sync_event(c, &e) == hipSuccess)
+                {
+                    if (hipEventRecord(e, fs) == hipSuccess)
+                        (void)hipStreamWaitEvent(c->stream2, e, 0);
+                    c->sync_events_in_flight.push_back(e);
+                }
             (void)pg_stage_end_on(c, b, c->stream2);
         }
     } stage_end{ ctx, b, false };
@@ -1449,22 +1484,29 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     // (counted over all batches of the ctx) uses workspace half (chunk_seq & 1), so the latency-bound traceback of a chunk
     // overlaps the VALU-bound fill of the next one -- also across batches: nothing of this call makes the main stream wait
     // for a traceback except the one that still reads the half about to be overwritten.
-    const uint64_t half = (ctx->ws_cap / 2) & ~(uint64_t)255;  // keeps the 256-byte alignment of the trace rows
+    const unsigned regions = ctx->regions();
+    const uint64_t half = (ctx->ws_cap / regions) & ~(uint64_t)255;  // keeps the 256-byte alignment of the trace rows
     {
-        // the trace stream must see everything queued on the main stream so far (memsets, uploads, seed stages)
+        // the trace stream (and the second fill stream) must see everything queued on the main stream so far (memsets, uploads,
+        // seed stages, the waits of pg_stage_begin)
         hipEvent_t e0;
         HIP_TRY(ctx, get_sync_event(ctx, &e0));
         HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, e0, 0));
+        if (ctx->fill_streams == 2)
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_fill2, e0, 0));
         ctx->sync_events_in_flight.push_back(e0);
     }
     for (const Chunk& ch : b->chunks)
     {
         const uint32_t n_pairs = ch.pair_end - ch.pair_begin;
-        const unsigned h = (unsigned)(ctx->chunk_seq & 1u);
+        const unsigned h = (unsigned)(ctx->chunk_seq % regions);
+        // with two fill streams consecutive chunks' fills are on different streams: the later one's wavefronts fill the slots the
+        // earlier one leaves while it drains
+        const hipStream_t fill_stream = (ctx->fill_streams == 2 && (ctx->chunk_seq & 1u)) ? ctx->stream_fill2 : ctx->stream;
         uint8_t* ws = ctx->workspace + h * half;
-        if (ctx->half_free[h])
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->half_free[h], 0));  // the traceback that read this half is done
+        if (ctx->region_free[h])
+            HIP_TRY(ctx, hipStreamWaitEvent(fill_stream, ctx->region_free[h], 0));  // the traceback that read this region is done
         PgFillArgs fa{};
         fa.items = b->d_items;
         fa.item_begin = 2 * ch.pair_begin;
@@ -1482,12 +1524,12 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             HIP_TRY(ctx, get_event(ctx, &ev.a));
             HIP_TRY(ctx, get_event(ctx, &ev.b));
             ev.kind = 0;
-            HIP_TRY(ctx, hipEventRecord(ev.a, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ev.a, fill_stream));
         }
-        HIP_TRY(ctx, pg_launch_fill(ch.C, fa, n_pairs, revg, ctx->wide32, ctx->stream));
+        HIP_TRY(ctx, pg_launch_fill(ch.C, fa, n_pairs, revg, ctx->wide32, fill_stream));
         if (ctx->timing)
         {
-            HIP_TRY(ctx, hipEventRecord(ev.b, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ev.b, fill_stream));
             ctx->events.push_back(ev);
             ctx->acc.fills += revg ? ch.fills : ch.fills / 2;
             ctx->acc.cells += revg ? ch.cells : ch.cells / 2;
@@ -1495,7 +1537,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         }
         hipEvent_t fill_done;
         HIP_TRY(ctx, get_sync_event(ctx, &fill_done));
-        HIP_TRY(ctx, hipEventRecord(fill_done, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(fill_done, fill_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, fill_done, 0));
         ctx->sync_events_in_flight.push_back(fill_done);
         PgTraceArgs ta{};
@@ -1533,7 +1575,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         hipEvent_t td;
         HIP_TRY(ctx, get_sync_event(ctx, &td));
         HIP_TRY(ctx, hipEventRecord(td, ctx->stream2));
-        ctx->half_free[h] = td;
+        ctx->region_free[h] = td;
         ctx->sync_events_in_flight.push_back(td);
         ++ctx->chunk_seq;
     }

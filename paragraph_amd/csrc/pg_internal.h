@@ -39,11 +39,18 @@ struct pg_ctx
     hipStream_t stream2 = nullptr;  // pick + traceback of chunk i overlaps the fill of chunk i + 1
     hipStream_t stream_copy = nullptr;  // uploads of the NEXT batch / downloads of the PREVIOUS one overlap the kernels
     std::vector<hipEvent_t> sync_event_pool, sync_events_in_flight;
-    // The workspace is two halves used alternately by the chunks of ALL batches in the order they are aligned (chunk_seq):
-    // the fill of a chunk (main stream) only waits for the traceback of the chunk two before it (half_free), so the
-    // traceback + count of one batch (second stream) run under the fill of the next batch.
+    // The workspace is `regions` equal regions used in turn by the chunks of ALL batches in the order they are aligned
+    // (chunk_seq): the fill of a chunk only waits for the traceback that last read its region (region_free), so the traceback +
+    // count of one batch (second stream) run under the fill of the next batch.  fill_streams = 1: two regions, fills on the
+    // main stream one after the other.  fill_streams = 2 (pg_ctx_set_fill_streams): THREE regions and the fills alternate
+    // between the main stream and stream_fill2 -- the next chunk's wavefronts take the slots a draining launch leaves (every
+    // launch ends with a tail of one wavefront lifetime, 10 - 15 % of a 2 ms launch), while the traceback of the chunk before
+    // still has its region to itself.
     uint64_t chunk_seq = 0;
-    hipEvent_t half_free[2] = { nullptr, nullptr };
+    hipStream_t stream_fill2 = nullptr;
+    int fill_streams = 1;
+    unsigned regions() const { return fill_streams == 2 ? 3u : 2u; }
+    hipEvent_t region_free[3] = { nullptr, nullptr, nullptr };
     uint64_t ws_limit = 8ull << 30;
     uint64_t max_lds_per_block = 64 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock (gfx950: 160 KB)
     uint8_t* workspace = nullptr;

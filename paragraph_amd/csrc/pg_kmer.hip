@@ -26,8 +26,7 @@
 
 namespace
 {
-constexpr int MAX_PATHS = 126;  // (the candidate heap of paths + 2 entries lives in LDS)
-constexpr int HEAP_CAP = MAX_PATHS + 2;
+constexpr int MAX_PATHS = 126;  // (the candidate heap of paths + 2 entries lives in LDS, sized per launch: KmerArgs::heap_cap)
 
 struct KPathDev
 {
@@ -68,6 +67,7 @@ struct KmerArgs
     uint32_t l_max;     // longest read, padded to a multiple of 4
     uint32_t bm_words;  // candidate-offset bitmap
     uint32_t cache_n;   // path-table entries cached in LDS (paths with more k-mers are searched in global memory)
+    uint32_t heap_cap;  // candidate heap entries: the index's largest path count + 2 (a fixed 128 cost 2 of 17 blocks per CU)
 };
 
 __device__ __forceinline__ uint32_t comp_raw(uint32_t c)
@@ -240,8 +240,8 @@ __global__ __launch_bounds__(64) void pg_kmer_kernel(KmerArgs a)
     uint32_t* sbm = slab0 + 2 * a.l_max;                            // [bm_words]
     uint32_t* spk = sbm + a.bm_words;                               // [cache_n] path k-mers
     uint32_t* spp = spk + a.cache_n;                                // [cache_n] path positions
-    Cand* sheap = (Cand*)(spp + a.cache_n);                         // [HEAP_CAP]
-    int* shn_p = (int*)(sheap + HEAP_CAP);
+    Cand* sheap = (Cand*)(spp + a.cache_n);                         // [heap_cap]
+    int* shn_p = (int*)(sheap + a.heap_cap);
     uint8_t* sread = (uint8_t*)(shn_p + 4);                         // [2][l_max]
     uint32_t* slab[2] = { slab0, slab0 + a.l_max };
     const uint32_t r = blockIdx.x;
@@ -497,6 +497,7 @@ struct pg_kmer_index
     uint32_t k = 0;
     uint32_t max_path_len = 0;
     uint32_t max_path_kmers = 0;
+    uint32_t max_paths = 0;  // largest path count of a graph of the set
     KGraphDev* d_graphs = nullptr;
     KPathDev* d_paths = nullptr;
     char* d_pathseq = nullptr;
@@ -601,6 +602,8 @@ extern "C" pg_status pg_graphs_build_kmer_index(
     ix->k = kmer_len;
     ix->max_path_len = max_len;
     ix->max_path_kmers = max_kmers;
+    for (auto const& g : gd)
+        ix->max_paths = std::max<uint32_t>(ix->max_paths, g.n_paths);
     hipError_t e = upk(gd, &ix->d_graphs, ctx->stream_copy);
     if (e == hipSuccess) e = upk(pd, &ix->d_paths, ctx->stream_copy);
     if (e == hipSuccess) e = upk(pathseq, &ix->d_pathseq, ctx->stream_copy);
@@ -664,8 +667,9 @@ extern "C" pg_status pg_batch_kmer_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
         a.n_sort <<= 1;
     a.bm_words = words;
     a.cache_n = std::min<uint32_t>(ix->max_path_kmers, 2048u);
+    a.heap_cap = (ix->max_paths + 2 + 1u) & ~1u;  // (even: keeps what follows 8-byte aligned whatever sizeof(Cand) is)
     const size_t lds = (size_t)2 * a.n_sort * 8 + (size_t)2 * a.l_max * 4 + (size_t)a.bm_words * 4 + (size_t)2 * a.cache_n * 4
-        + HEAP_CAP * sizeof(Cand) + 16 + (size_t)2 * a.l_max;
+        + (size_t)a.heap_cap * sizeof(Cand) + 16 + (size_t)2 * a.l_max;
     if (b->n_reads)
     {
         if (lds > 48 * 1024)

@@ -261,3 +261,45 @@ def test_launch_settings_do_not_change_results(env):
                        cwd=root, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_two_fill_streams_three_regions(checker):
+    """pg_ctx_set_fill_streams(2): three workspace regions, consecutive chunks' fills on two streams (the next chunk's wavefronts
+    take the slots a draining launch leaves).  A workspace of 96 MiB cuts 24 000 config-2 reads + 3 000 reads of mixed fuzz graphs
+    into many chunks; two batch objects are aligned back to back so that chunks of different batches meet on the regions.
+    Records equal those of the one-stream context field for field, and the reference's on a sample."""
+    import numpy as np
+    from paragraph_amd import capi, synth
+    site, reads = synth.config2_reads(24000, read_len=150, seed=77)
+    graphs, gor = [(site.seqs, site.edges)], [0] * len(reads)
+    reads = list(reads)
+    for gi, (seqs, edges, rs) in enumerate(fuzzgen.cases(909, 300, 10)):
+        graphs.append((seqs, edges))
+        reads.extend(rs)
+        gor.extend([gi + 1] * len(rs))
+    out = {}
+    for streams in (1, 2):
+        ctx = capi.Context(0, workspace_bytes=96 << 20, fill_streams=streams)
+        G = ctx.upload_graphs(graphs)
+        batches = [ctx.new_batch(), ctx.new_batch()]
+        for b in batches:
+            b.upload(G, reads, gor)
+        for _ in range(2):
+            for b in batches:
+                b.align(capi.AF_ALL)
+        got = [b.download() for b in batches]
+        out[streams] = [capi.results_to_dicts(r, o) for r, o in got]
+        for b in batches:
+            b.close()
+        G.close()
+        ctx.close()
+    for k in (0, 1):
+        for a, b in zip(out[1][k], out[2][k]):
+            assert all(a[key] == b[key] for key in KEYS) and a["status"] == b["status"]
+    sample = list(range(0, 24000, 12)) + list(range(24000, len(reads)))
+    want = checker.align_batch(site.seqs, site.edges, [reads[i] for i in sample if i < 24000])
+    compare([out[2][1][i] for i in sample if i < 24000], want, [reads[i] for i in sample if i < 24000], "two fill streams, config 2")
+    at = 24000
+    for gi, (seqs, edges, rs) in enumerate(fuzzgen.cases(909, 300, 10)):
+        compare(out[2][0][at:at + len(rs)], checker.align_batch(seqs, edges, rs), rs, "two fill streams, fuzz graph %d" % gi)
+        at += len(rs)

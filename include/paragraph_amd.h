@@ -329,6 +329,17 @@ enum
 pg_status pg_ctx_native_stream(pg_ctx* ctx, int which, void** out);
 pg_status pg_ctx_count_record(pg_ctx* ctx, void* native_event);
 pg_status pg_ctx_count_wait(pg_ctx* ctx, void* native_event);
+/* Everything a workflow reads back after pg_batch_align + pg_batch_count, with ONE wait for the batch and ONE for the copies
+ * (pg_batch_ops_count + pg_batch_download + two pg_batch_download_counts wait eight times):
+ *   pg_batch_result_sizes   the number of CIGAR elements and path entries of the batch (pg_batch_count sends both to
+ *                           page-locked host memory on its own stream; this call waits for the batch and reads them)
+ *   pg_batch_download_all   results, CIGAR elements, count table (NULL when it lives in caller memory), supports, path entries
+ * The batch's last stage must be pg_batch_count.  (What they replace: the graph_* fields and support lists written into
+ * common::Read, src/c++/include/common/Read.hh:40-264, and countReads' tables, lib/paragraph/ReadCounting.cpp:52-127.) */
+pg_status pg_batch_result_sizes(pg_ctx* ctx, pg_batch* batch, uint64_t* n_ops, uint64_t* n_path);
+pg_status pg_batch_download_all(
+    pg_ctx* ctx, pg_batch* batch, pg_result* results, pg_op* ops, uint64_t ops_cap, uint32_t* counts, pg_read_support* supports,
+    uint32_t* path, uint64_t path_cap);
 /* Copies the count table (if the batch owns it; pass NULL otherwise), per-read supports and path entries
  * (capacity path_cap entries; *n_path receives the number used) to host memory; synchronises. */
 pg_status pg_batch_download_counts(
@@ -391,6 +402,13 @@ pg_status pg_graphs_klib_last_kernels(pg_ctx* ctx, pg_graphs* graphs, uint32_t* 
 /* Restricts the following stage calls (pg_batch_path_align / pg_batch_kmer_align / pg_batch_klib_align / pg_batch_align) to reads with active[i] != 0 (NULL = every read): the next
  * stage of the cascade runs only on reads the previous stage left unmapped / filtered. */
 pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* batch, const uint8_t* active);
+/* The same hand-over decided where the flags are -- on the device (CompositeAligner::alignRead, CompositeAligner.cpp:78-150: a
+ * read the stage mapped and the filter chain accepted is done, the others go on to the next stage).  After a seed stage and
+ * its pg_batch_count: active[i] &= !((stage flag & 1) && count-path status == MAPPED), one thread per read, queued behind the
+ * count pass; no flags, supports or masks cross to the host.  The next stage that runs work items (pg_batch_klib_align,
+ * pg_batch_align) re-makes them from the device's per-(read length class, graph) counts of active reads -- one download of a
+ * few hundred words.  Asynchronous.  Results equal those of pg_batch_set_active with the mask a host loop would build. */
+pg_status pg_batch_retire_mapped(pg_ctx* ctx, pg_batch* batch);
 
 /* Renders "<node>[<len><op>...]..." for one read into buf (NUL-terminated); returns the string length
  * (which may be >= cap, in which case the output was truncated). Host-only helper. */

@@ -49,6 +49,7 @@ EXPORTS = [
     "pg_batch_kmer_align", "pg_graphs_build_klib_index", "pg_batch_klib_align", "pg_graphs_klib_error", "pg_graphs_klib_last_kernels", "pg_graphs_build_filter_index",
     "pg_host_alloc", "pg_host_free", "pg_host_register", "pg_host_unregister", "pg_counts_zero", "pg_ctx_sync_compute",
     "pg_render_cigars", "pg_ctx_native_stream", "pg_ctx_count_record", "pg_ctx_count_wait", "pg_ctx_set_fill_streams",
+    "pg_batch_retire_mapped", "pg_batch_result_sizes", "pg_batch_download_all",
 ]
 
 
@@ -155,6 +156,12 @@ def load_library():
     L.pg_batch_download_path_flags.argtypes = [vp, vp, vp]
     L.pg_batch_set_active.restype = C.c_int32
     L.pg_batch_set_active.argtypes = [vp, vp, vp]
+    L.pg_batch_retire_mapped.restype = C.c_int32
+    L.pg_batch_retire_mapped.argtypes = [vp, vp]
+    L.pg_batch_result_sizes.restype = C.c_int32
+    L.pg_batch_result_sizes.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.pg_batch_download_all.restype = C.c_int32
+    L.pg_batch_download_all.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64]
     L.pg_graphs_build_kmer_index.restype = C.c_int32
     L.pg_graphs_build_kmer_index.argtypes = [vp, vp, C.c_uint32, u32p, u32p, u32p]
     L.pg_batch_kmer_align.restype = C.c_int32
@@ -525,6 +532,25 @@ class Batch:
             if len(a) != self.n_reads:
                 raise ValueError("active length mismatch")
             self.ctx._chk(self.ctx.L.pg_batch_set_active(self.ctx.h, self.h, a.ctypes.data))
+
+    def retire_mapped(self):
+        """The cascade hand-over decided on the device: after a seed stage + count(), reads the stage mapped and the filter chain
+        accepted leave the following stages (pg_batch_retire_mapped); nothing is downloaded."""
+        self.ctx._chk(self.ctx.L.pg_batch_retire_mapped(self.ctx.h, self.h))
+
+    def download_all(self, want_table=True):
+        """-> (results, ops, counts table or None, supports, path entries) with one wait for the batch and one for the copies
+        (pg_batch_result_sizes + pg_batch_download_all); the batch's last stage must be count()."""
+        n_ops, n_path = C.c_uint64(), C.c_uint64()
+        self.ctx._chk(self.ctx.L.pg_batch_result_sizes(self.ctx.h, self.h, C.byref(n_ops), C.byref(n_path)))
+        res = np.zeros(max(self.n_reads, 1), dtype=RESULT_DTYPE)
+        sup = np.zeros(max(self.n_reads, 1), dtype=SUPPORT_DTYPE)
+        ops = np.zeros(max(int(n_ops.value), 1), dtype=np.uint32)
+        path = np.zeros(max(int(n_path.value), 1), dtype=np.uint32)
+        counts = np.zeros(int(self._graphs.layout.n_counters), dtype=np.uint32) if want_table else None
+        self.ctx._chk(self.ctx.L.pg_batch_download_all(self.ctx.h, self.h, res.ctypes.data, ops.ctypes.data, len(ops),
+                                                       counts.ctypes.data if want_table else None, sup.ctypes.data, path.ctypes.data, len(path)))
+        return res[:self.n_reads], ops[:int(n_ops.value)], counts, sup[:self.n_reads], path[:int(n_path.value)]
 
     def align(self, flags=AF_ALL):
         self.ctx._chk(self.ctx.L.pg_batch_align(self.ctx.h, self.h, flags & 0xFFFFFFFF))

@@ -930,6 +930,15 @@ static void batch_free_device(pg_batch* b)
     (void)pg_dev_free(b->d_active);
     b->d_active = nullptr;
     b->has_active = false;
+    (void)pg_dev_free(b->d_group_of_read2);
+    (void)pg_dev_free(b->d_group_base);
+    (void)pg_dev_free(b->d_group_count);
+    (void)pg_dev_free(b->d_active_list);
+    (void)pg_dev_free(b->d_segments);
+    b->d_group_of_read2 = b->d_group_base = b->d_group_count = b->d_active_list = nullptr;
+    b->d_segments = nullptr;
+    b->cap_groups = b->cap_cascade_reads = b->cap_segments = 0;
+    b->cascade_uploaded = false;
     (void)pg_dev_free(b->d_support);
     (void)pg_dev_free(b->d_label_ext);
     b->d_label_ext = nullptr;
@@ -973,6 +982,8 @@ extern "C" void pg_batch_destroy(pg_ctx* ctx, pg_batch* b)
         (void)hipStreamSynchronize(ctx->stream_copy);
     }
     batch_free_device(b);
+    if (b->h_counters)
+        (void)hipHostFree(b->h_counters);
     if (b->ev_upload)
         (void)hipEventDestroy(b->ev_upload);
     if (b->ev_busy)
@@ -981,6 +992,24 @@ extern "C" void pg_batch_destroy(pg_ctx* ctx, pg_batch* b)
 }
 
 static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+// workspace bytes of one item pair (its regions are proportional to its pipeline steps, i.e. to its work)
+struct PairNeed
+{
+    uint64_t nsteps, trace_bytes, seed_bytes, need;
+};
+static PairNeed pair_need_of(int C, const HostGraph& hg)
+{
+    PairNeed n;
+    // (the wide variants' sweeps run 32 lanes per read: 16 steps more; sized for that whichever kernel set runs)
+    n.nsteps = pg_fill_steps_lanes(hg.ncols, pg_var_wide(C) ? PG_WIDE_LANES : PG_GROUP_LANES);
+    n.trace_bytes = align_up(n.nsteps * 64 * pg_trace_lane_bytes(C), 256);
+    n.seed_bytes = pg_seed_region_bytes(C, hg.n_nodes) + pg_key_region_bytes(hg.n_nodes);
+    // + the traceback's CIGAR scratch of the pair's four reads (reversed-graph item's trace_off, which has no trace)
+    const uint64_t ops_bytes = align_up((uint64_t)PG_GROUPS * pg_ops_cap(C) * sizeof(uint32_t), 256);
+    n.need = n.trace_bytes + 2 * n.seed_bytes + ops_bytes;
+    return n;
+}
 
 // Builds the wavefront work items + chunk plan for the reads with active[i] != 0 (all reads when active is
 // NULL) and uploads them.  Items/fill summaries never need more room than the all-reads plan.
@@ -1033,6 +1062,30 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
     const auto key_less = [](const Key& x, const Key& y) { return x.c != y.c ? x.c < y.c : x.graph < y.graph; };
     if (!std::is_sorted(keys.begin(), keys.end(), key_less))  // reads of one length, site after site, arrive in order
         std::stable_sort(keys.begin(), keys.end(), key_less);
+    b->plan_stale = false;
+    if (!active)
+    {
+        // the (variant, graph) runs of the whole batch: what a plan made from the device's per-run counts of ACTIVE reads starts
+        // from (pg_batch_retire_mapped / pg_batch_ensure_plan)
+        b->groups.clear();
+        b->h_group_of_read.assign(n_reads, PG_NONE);
+        b->has_general_reads = !b->gen_idx.empty();
+        b->cascade_uploaded = false;
+        for (size_t p0 = 0; p0 < keys.size();)
+        {
+            size_t q0 = p0;
+            PgReadGroup g{ keys[p0].c, keys[p0].graph, (uint32_t)p0, 0, 0 };
+            while (q0 < keys.size() && keys[q0].c == g.C && keys[q0].graph == g.graph)
+            {
+                b->h_group_of_read[keys[q0].idx] = (uint32_t)b->groups.size();
+                g.sum_len += base_off[keys[q0].idx + 1] - base_off[keys[q0].idx];
+                ++q0;
+            }
+            g.n_reads = (uint32_t)(q0 - p0);
+            b->groups.push_back(g);
+            p0 = q0;
+        }
+    }
 
     // ---- work items (pairs: forward graph, reversed graph) + chunk plan -----------------------------
     std::vector<PgWorkItem> items;
@@ -1073,22 +1126,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
             open = false;
         }
     };
-    // workspace bytes of one item pair (its regions are proportional to its pipeline steps, i.e. to its work)
-    struct PairNeed
-    {
-        uint64_t nsteps, trace_bytes, seed_bytes, need;
-    };
-    auto pair_need = [&](int C, const HostGraph& hg) {
-        PairNeed n;
-        // (the wide variants' sweeps run 32 lanes per read: 16 steps more; sized for that whichever kernel set runs)
-        n.nsteps = pg_fill_steps_lanes(hg.ncols, pg_var_wide(C) ? PG_WIDE_LANES : PG_GROUP_LANES);
-        n.trace_bytes = align_up(n.nsteps * 64 * pg_trace_lane_bytes(C), 256);
-        n.seed_bytes = pg_seed_region_bytes(C, hg.n_nodes) + pg_key_region_bytes(hg.n_nodes);
-        // + the traceback's CIGAR scratch of the pair's four reads (reversed-graph item's trace_off, which has no trace)
-        const uint64_t ops_bytes = align_up((uint64_t)PG_GROUPS * pg_ops_cap(C) * sizeof(uint32_t), 256);
-        n.need = n.trace_bytes + 2 * n.seed_bytes + ops_bytes;
-        return n;
-    };
+    auto pair_need = [&](int C, const HostGraph& hg) { return pair_need_of(C, hg); };
     // EQUAL chunks: every fill launch ends with a tail in which the chip drains, and a chunk that holds what was left over pays
     // that tail on a fraction of the work (1 M config-2 reads at 128 GiB went out as 2 full chunks and a small one: launches of
     // 20.8 / 20.8 / 10.1 ms, profiles/r03_kernel_stats.csv).  The bytes of each variant's run are counted first and cut into
@@ -1351,6 +1389,7 @@ extern "C" pg_status pg_batch_upload(
     b->has_skipped = false;
     b->fragments_set = false;
     b->has_active = false;
+    b->h_counters_valid = false;
     b->label_ext_words = 0;  // the label sets of an earlier count belong to the earlier reads
     b->label_ext_reads = 0;
     b->host_template.clear();  // built only when a read is skipped (rare)
@@ -1431,7 +1470,284 @@ extern "C" pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* b, const uint8_t
     b->has_active = active != nullptr;
     if (active && b->n_reads)
         HIP_TRY(ctx, hipMemcpyAsync(b->d_active, active, b->n_reads, hipMemcpyHostToDevice, ctx->stream));
+    if (!active)
+    {
+        // back to every read: the upload-time groups stay valid, only the items are re-made (plan_items(nullptr) would rebuild the
+        // groups as well, which is harmless)
+    }
     return plan_items(ctx, b, active, ctx->stream);
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// Device-resident hand-over between the stages of the cascade (CompositeAligner::alignRead, src/c++/lib/grm/
+// CompositeAligner.cpp:78-176: a read the stage mapped and the filter accepted is done, everything else goes on).
+// The decision is made where the flags are -- on the device -- and the next stage's work follows it without the reads'
+// flags, supports or an activity mask ever crossing to the host:
+//   pg_batch_retire_mapped   active[i] &= !((stage flag & 1) && count-path status == MAPPED), one thread per read
+//   pg_batch_ensure_plan     (at the next stage that runs work items) active reads listed per (variant, graph) group by
+//                            atomics, the per-GROUP counts downloaded (a few hundred words, one wait), chunks cut from
+//                            the counts by the same rule as plan_items, the work items written by a kernel
+// ----------------------------------------------------------------------------------------------------------------------
+namespace
+{
+__global__ void pg_retire_kernel(uint32_t n, const uint8_t* __restrict__ stage_flags, const pg_read_support* __restrict__ sup, uint8_t* active)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && active[i] && (stage_flags[i] & 1u) && sup[i].status == 1)
+        active[i] = 0;
+}
+
+__global__ void pg_group_list_kernel(
+    uint32_t n, const uint8_t* __restrict__ active, const uint32_t* __restrict__ group_of_read, const uint32_t* __restrict__ group_base,
+    uint32_t* group_count, uint32_t* list)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !active[i])
+        return;
+    const uint32_t g = group_of_read[i];
+    if (g == PG_NONE)
+        return;
+    list[group_base[g] + atomicAdd(&group_count[g], 1u)] = i;
+}
+
+__global__ void pg_build_items_kernel(uint32_t n_pairs, uint32_t n_segments, const PgPlanSegment* __restrict__ seg, const uint32_t* __restrict__ list, PgWorkItem* items)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs)
+        return;
+    uint32_t lo = 0, hi = n_segments;  // last segment whose pair_begin <= p
+    while (hi - lo > 1)
+    {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (seg[mid].pair_begin <= p)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const PgPlanSegment s = seg[lo];
+    const uint32_t k = s.first_pair + (p - s.pair_begin);
+    PgWorkItem fw{}, rv{};
+    fw.graph = rv.graph = s.graph;
+    fw.dir = 0;
+    rv.dir = 1;
+    for (int j = 0; j < PG_GROUPS; ++j)
+    {
+        const uint32_t slot = 4u * k + (uint32_t)j;
+        fw.read[j] = rv.read[j] = slot < s.count ? list[s.list_base + slot] : PG_NONE;
+    }
+    const uint64_t base = s.ws_base + (uint64_t)(p - s.pair_begin) * s.need;
+    fw.trace_off = base;
+    fw.seed_off = base + s.trace_bytes;
+    rv.trace_off = base + s.trace_bytes + 2 * s.seed_bytes;
+    rv.seed_off = base + s.trace_bytes + s.seed_bytes;
+    items[2 * (size_t)p] = fw;
+    items[2 * (size_t)p + 1] = rv;
+}
+}  // namespace
+
+extern "C" pg_status pg_batch_retire_mapped(pg_ctx* ctx, pg_batch* b)
+{
+    if (!ctx || !b || !b->graphs || !b->d_support || !b->d_path_flags)
+        return fail(ctx, PG_ERR_INVALID, "pg_batch_retire_mapped: a seed stage and pg_batch_count must have run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // behind the count pass, on its stream: the next stage (main stream) waits for the batch's event as always
+    hipStream_t cs = ctx->stream2;
+    HIP_TRY(ctx, pg_stage_begin_on(ctx, b, cs));
+    if (!b->has_active && b->n_reads)
+        HIP_TRY(ctx, hipMemsetAsync(b->d_active, 1, b->n_reads, cs));
+    b->has_active = true;
+    if (b->n_reads)
+    {
+        hipLaunchKernelGGL(pg_retire_kernel, dim3((b->n_reads + 255) / 256), dim3(256), 0, cs, b->n_reads, b->d_path_flags, b->d_support, b->d_active);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    b->plan_stale = true;
+    HIP_TRY(ctx, pg_stage_end_on(ctx, b, cs));
+    return PG_OK;
+}
+
+pg_status pg_batch_ensure_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream)
+{
+    if (!b->plan_stale)
+        return PG_OK;
+    const pg_graphs* G = b->graphs;
+    const uint32_t n = b->n_reads;
+    if (b->has_general_reads)
+    {
+        // reads of the general path are planned one by one on the host: this (rare) batch fetches the flags and plans from them
+        std::vector<uint8_t> active(n);
+        HIP_TRY(ctx, hipMemcpyAsync(active.data(), b->d_active, n, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        return plan_items(ctx, b, active.data(), stream);
+    }
+    const size_t n_groups = b->groups.size();
+    b->chunks.clear();
+    b->gen_idx.clear();
+    b->n_pairs = 0;
+    b->plan_stale = false;
+    if (!n || !n_groups)
+        return PG_OK;
+    if (n_groups > b->cap_groups || n > b->cap_cascade_reads)
+    {
+        (void)pg_dev_free(b->d_group_of_read2);
+        (void)pg_dev_free(b->d_group_base);
+        (void)pg_dev_free(b->d_group_count);
+        (void)pg_dev_free(b->d_active_list);
+        b->cap_groups = n_groups;
+        b->cap_cascade_reads = n;
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_group_of_read2, (size_t)n * sizeof(uint32_t)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_active_list, (size_t)n * sizeof(uint32_t)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_group_base, n_groups * sizeof(uint32_t)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_group_count, n_groups * sizeof(uint32_t)));
+        b->cascade_uploaded = false;
+    }
+    std::vector<uint32_t> base(n_groups);
+    if (!b->cascade_uploaded)
+    {
+        for (size_t g = 0; g < n_groups; ++g)
+            base[g] = b->groups[g].list_base;
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_group_of_read2, b->h_group_of_read.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_group_base, base.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        b->cascade_uploaded = true;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(b->d_group_count, 0, n_groups * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(pg_group_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, b->d_active, b->d_group_of_read2, b->d_group_base,
+                       b->d_group_count, b->d_active_list);
+    HIP_TRY(ctx, hipGetLastError());
+    b->h_group_count.resize(n_groups);
+    HIP_TRY(ctx, hipMemcpyAsync(b->h_group_count.data(), b->d_group_count, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));  // the ONE wait of the hand-over: per-group counts (also: `base` may go)
+
+    // ---- chunks and segments from the counts: plan_items' rule (equal chunks per variant, longest graph first inside a chunk)
+    const uint64_t packed_limit = ctx->ws_limit - b->gen_reserve;
+    const uint64_t cap = packed_limit / ctx->regions();
+    std::vector<uint64_t> chunk_target(PG_VAR_WIDE + 33, 0);
+    {
+        std::vector<uint64_t> total(chunk_target.size(), 0), largest(chunk_target.size(), 0);
+        for (size_t g = 0; g < n_groups; ++g)
+        {
+            const uint64_t pairs = (b->h_group_count[g] + PG_GROUPS - 1) / PG_GROUPS;
+            if (!pairs)
+                continue;
+            const uint64_t need = pair_need_of((int)b->groups[g].C, G->host[b->groups[g].graph]).need;
+            total[b->groups[g].C] += pairs * need;
+            largest[b->groups[g].C] = std::max(largest[b->groups[g].C], need);
+        }
+        for (size_t c = 0; c < total.size(); ++c)
+        {
+            if (!total[c])
+                continue;
+            if (largest[c] >= cap)
+            {
+                chunk_target[c] = cap;
+                continue;
+            }
+            const uint64_t room = cap - largest[c];
+            const uint64_t n_chunks = std::max<uint64_t>(1, (total[c] + room - 1) / room);
+            chunk_target[c] = std::min(cap, (total[c] + n_chunks - 1) / n_chunks + largest[c]);
+        }
+    }
+    std::vector<PgPlanSegment>& segs = b->h_segments;
+    segs.clear();
+    std::vector<uint64_t> seg_steps;
+    Chunk cur{};
+    bool open = false;
+    size_t chunk_seg0 = 0;
+    b->max_ws = 0;
+    uint32_t next_pair = 0;
+    auto close_chunk = [&]() {
+        if (!open)
+            return;
+        // longest graph first (what runs in a launch's tail is short); regions keep the offsets they were given
+        std::vector<size_t> order(segs.size() - chunk_seg0);
+        for (size_t i = 0; i < order.size(); ++i)
+            order[i] = chunk_seg0 + i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return seg_steps[x] > seg_steps[y]; });
+        std::vector<PgPlanSegment> sorted;
+        std::vector<uint64_t> sorted_steps;
+        uint32_t at = cur.pair_begin;
+        for (size_t i : order)
+        {
+            PgPlanSegment s = segs[i];
+            s.pair_begin = at;
+            at += s.n_pairs;
+            sorted.push_back(s);
+            sorted_steps.push_back(seg_steps[i]);
+        }
+        std::copy(sorted.begin(), sorted.end(), segs.begin() + (std::ptrdiff_t)chunk_seg0);
+        std::copy(sorted_steps.begin(), sorted_steps.end(), seg_steps.begin() + (std::ptrdiff_t)chunk_seg0);
+        cur.pair_end = at;
+        b->chunks.push_back(cur);
+        b->max_ws = std::max(b->max_ws, cur.ws_bytes);
+        open = false;
+    };
+    for (size_t g = 0; g < n_groups; ++g)
+    {
+        const PgReadGroup& grp = b->groups[g];
+        const uint32_t count = b->h_group_count[g];
+        uint32_t pairs_left = (count + PG_GROUPS - 1) / PG_GROUPS, first_pair = 0;
+        if (!pairs_left)
+            continue;
+        const int C = (int)grp.C;
+        const HostGraph& hg = G->host[grp.graph];
+        const PairNeed pn = pair_need_of(C, hg);
+        if (pn.need > cap)
+            return fail(ctx, PG_ERR_UNSUPPORTED, "workspace limit too small for one wavefront of this graph");
+        const uint64_t mean_len = grp.n_reads ? grp.sum_len / grp.n_reads : 0;
+        while (pairs_left)
+        {
+            if (open && (cur.C != C || cur.ws_bytes + pn.need > chunk_target[C]))
+                close_chunk();
+            if (!open)
+            {
+                cur = Chunk{};
+                cur.C = C;
+                cur.pair_begin = next_pair;
+                chunk_seg0 = segs.size();
+                open = true;
+            }
+            const uint64_t fit = std::max<uint64_t>(1, (chunk_target[C] - cur.ws_bytes) / pn.need);
+            const uint32_t take = (uint32_t)std::min<uint64_t>(pairs_left, fit);
+            PgPlanSegment s{};
+            s.pair_begin = next_pair;  // (re-assigned when the chunk closes)
+            s.n_pairs = take;
+            s.first_pair = first_pair;
+            s.graph = grp.graph;
+            s.list_base = grp.list_base;
+            s.count = count;
+            s.ws_base = cur.ws_bytes;
+            s.need = pn.need;
+            s.trace_bytes = pn.trace_bytes;
+            s.seed_bytes = pn.seed_bytes;
+            segs.push_back(s);
+            seg_steps.push_back(pn.nsteps);
+            const uint64_t reads_here = std::min<uint64_t>((uint64_t)take * PG_GROUPS, count - (uint64_t)first_pair * PG_GROUPS);
+            cur.ws_bytes += (uint64_t)take * pn.need;
+            cur.trace_bytes += (uint64_t)take * pn.nsteps * 64 * pg_trace_lane_bytes(C);
+            cur.max_nodes = std::max(cur.max_nodes, hg.n_nodes);
+            cur.fills += 4 * reads_here;
+            cur.cells += 4 * reads_here * mean_len * hg.ncols;  // (the group's mean read length: a timing figure, not a result)
+            next_pair += take;
+            first_pair += take;
+            pairs_left -= take;
+        }
+    }
+    close_chunk();
+    b->n_pairs = next_pair;
+    if (!next_pair)
+        return PG_OK;
+    if (segs.size() > b->cap_segments)
+    {
+        (void)pg_dev_free(b->d_segments);
+        b->cap_segments = segs.size() + segs.size() / 4 + 16;
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_segments, b->cap_segments * sizeof(PgPlanSegment)));
+    }
+    // (h_segments is the batch's: it stays until the next plan, the copy may run on)
+    HIP_TRY(ctx, hipMemcpyAsync(b->d_segments, segs.data(), segs.size() * sizeof(PgPlanSegment), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(pg_build_items_kernel, dim3((next_pair + 255) / 256), dim3(256), 0, stream, next_pair, (uint32_t)segs.size(), b->d_segments,
+                       b->d_active_list, b->d_items);
+    HIP_TRY(ctx, hipGetLastError());
+    return PG_OK;
 }
 
 extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
@@ -1452,7 +1768,16 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             fprintf(stderr, "[pg_batch_align] workspace %.2f -> %.2f GiB (%zu chunk(s) of up to %.2f GiB) in %.1f ms\n",
                     cap0 / 1073741824.0, ctx->ws_cap / 1073741824.0, b->chunks.size(), b->max_ws / 1073741824.0, ms);
     }
+    b->h_counters_valid = false;
     HIP_TRY(ctx, pg_stage_begin(ctx, b));
+    {
+        const pg_status ps = pg_batch_ensure_plan(ctx, b, ctx->stream);  // work items follow a device-side hand-over (no-op otherwise)
+        if (ps != PG_OK)
+            return ps;
+        const pg_status ws2 = ensure_ctx_workspace(ctx, b);  // (a re-made plan never needs more than the upload-time one; cheap)
+        if (ws2 != PG_OK)
+            return ws2;
+    }
     // Every way out of this call from here on records the end of the stage: pg_graphs_destroy / pg_dev_free / the next stage of
     // this batch trust those events.  An error return that skipped it (a failed launch, the general path) would let the caller
     // hand the batch's and the graph set's device blocks to another lane while the kernels queued so far still read them.

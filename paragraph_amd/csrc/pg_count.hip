@@ -781,7 +781,69 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
                            (size_t)a.frag_lds_counters * sizeof(uint32_t), cs, a);
         HIP_TRY(ctx, hipGetLastError());
     }
+    // the two sizes a caller needs before it can fetch the records, sent to page-locked host memory by this stream: they are there
+    // when the batch's event is (pg_batch_result_sizes)
+    if (!b->h_counters)
+    {
+        void* p = nullptr;
+        HIP_TRY(ctx, hipHostMalloc(&p, 2 * sizeof(unsigned long long), hipHostMallocPortable));
+        b->h_counters = (unsigned long long*)p;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(b->h_counters, b->d_ops_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+    HIP_TRY(ctx, hipMemcpyAsync(b->h_counters + 1, b->d_path_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+    b->h_counters_valid = true;
     HIP_TRY(ctx, pg_stage_end_on(ctx, b, cs));
+    return PG_OK;
+}
+
+extern "C" pg_status pg_batch_result_sizes(pg_ctx* ctx, pg_batch* b, uint64_t* n_ops, uint64_t* n_path)
+{
+    if (!ctx || !b || !b->graphs || !b->d_support || !b->h_counters_valid)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_result_sizes: the batch's last stage must be pg_batch_count");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, pg_batch_wait(ctx, b));
+    if (n_ops)
+        *n_ops = b->h_counters[0];
+    if (n_path)
+        *n_path = b->h_counters[1];
+    return PG_OK;
+}
+
+extern "C" pg_status pg_batch_download_all(
+    pg_ctx* ctx, pg_batch* b, pg_result* results, pg_op* ops, uint64_t ops_cap, uint32_t* counts, pg_read_support* supports,
+    uint32_t* path, uint64_t path_cap)
+{
+    if (!ctx || !b || !b->graphs || !b->d_support || !b->h_counters_valid)
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_download_all: the batch's last stage must be pg_batch_count");
+    if (b->n_reads && (!results || !supports))
+        return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_download_all: null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, pg_batch_wait(ctx, b));
+    const uint64_t n_ops = b->h_counters[0], n_path = b->h_counters[1];
+    if ((n_ops && (!ops || n_ops > ops_cap)) || (n_path && (!path || n_path > path_cap)))
+        return pg_fail(ctx, PG_ERR_OVERFLOW, "pg_batch_download_all: ops / path buffer too small (pg_batch_result_sizes gives the sizes)");
+    hipStream_t cs = ctx->stream_copy;
+    if (b->n_reads)
+    {
+        HIP_TRY(ctx, hipMemcpyAsync(results, b->d_results, b->n_reads * sizeof(pg_result), hipMemcpyDeviceToHost, cs));
+        HIP_TRY(ctx, hipMemcpyAsync(supports, b->d_support, b->n_reads * sizeof(pg_read_support), hipMemcpyDeviceToHost, cs));
+    }
+    if (n_ops)
+        HIP_TRY(ctx, hipMemcpyAsync(ops, b->d_ops, n_ops * sizeof(pg_op), hipMemcpyDeviceToHost, cs));
+    if (n_path)
+        HIP_TRY(ctx, hipMemcpyAsync(path, b->d_path, n_path * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+    if (counts)
+    {
+        if (!b->counts_owned_valid)
+        {
+            HIP_TRY(ctx, hipStreamSynchronize(cs));
+            return pg_fail(ctx, PG_ERR_INVALID, "the count table lives in caller memory (d_counts was given)");
+        }
+        pg_count_layout lay;
+        layout_of(b->graphs, &lay);
+        HIP_TRY(ctx, hipMemcpyAsync(counts, b->d_counts, lay.n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(cs));
     return PG_OK;
 }
 

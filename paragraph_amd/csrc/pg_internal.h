@@ -26,6 +26,23 @@ struct Chunk
     uint64_t fills, cells, trace_bytes;
 };
 
+// Device-resident cascade hand-over (pg_batch_retire_mapped): a run of reads of one (variant, graph) in the sorted order of the
+// upload-time plan, and a piece of such a run inside one chunk of a plan made from the device's per-run counts.
+struct PgReadGroup
+{
+    uint32_t C, graph;
+    uint32_t list_base;  // first slot of the group in the device's active-read list (room for all its reads)
+    uint32_t n_reads;    // reads of the group in the batch
+    uint64_t sum_len;    // their bases (for the cell counts of the timing figures)
+};
+struct PgPlanSegment
+{
+    uint32_t pair_begin, n_pairs;  // item pairs [pair_begin, pair_begin + n_pairs) of the batch
+    uint32_t first_pair;           // ... are pairs first_pair.. of the group's active reads (four reads per pair)
+    uint32_t graph, list_base, count;
+    uint64_t ws_base, need, trace_bytes, seed_bytes;
+};
+
 struct EventPair
 {
     hipEvent_t a, b;
@@ -144,6 +161,20 @@ struct pg_batch
     uint8_t* d_path_flags = nullptr;  // per read: bit0 mapped by the last seed stage, bit1 anchored, bit2 BAD_ALIGN
     uint8_t* d_active = nullptr;      // per read: 0 = skipped by the stage kernels (NULL semantics via has_active)
     bool has_active = false;
+    // ---- device-resident hand-over between cascade stages (pg_batch_retire_mapped -> pg_batch_ensure_plan)
+    std::vector<PgReadGroup> groups;          // the (variant, graph) runs of the upload-time plan
+    std::vector<uint32_t> h_group_of_read;    // per read: its group, PG_NONE for empty reads and reads of the general path
+    bool has_general_reads = false;           // some read of the batch takes the general path (then the host re-plans from the flags)
+    bool plan_stale = false;                  // d_active changed on the device since the work items were made
+    bool cascade_uploaded = false;
+    uint32_t* d_group_of_read2 = nullptr;     // [n_reads] group per read
+    uint32_t* d_group_base = nullptr;         // [n_groups] list_base per group
+    uint32_t* d_group_count = nullptr;        // [n_groups] active reads per group (made by pg_group_list_kernel)
+    uint32_t* d_active_list = nullptr;        // [n_reads] active reads, group after group
+    PgPlanSegment* d_segments = nullptr;
+    size_t cap_groups = 0, cap_cascade_reads = 0, cap_segments = 0;
+    std::vector<uint32_t> h_group_count;
+    std::vector<PgPlanSegment> h_segments;
     uint32_t* d_graph_of_read = nullptr;
     pg_read_support* d_support = nullptr;
     uint64_t* d_label_ext = nullptr;  // [n_reads][label_words - 1]: the label sets' words beyond pg_read_support.label_mask
@@ -159,6 +190,10 @@ struct pg_batch
     size_t cap_count_reads = 0, cap_frags = 0;
     uint64_t cap_counts = 0;
     uint32_t n_frags = 0;
+    // {CIGAR elements, path entries} of the batch as of its last pg_batch_count, copied into page-locked host memory by the count
+    // stream itself (pg_batch_result_sizes reads them after the batch's event: no copy + wait of their own)
+    unsigned long long* h_counters = nullptr;
+    bool h_counters_valid = false;
     bool counts_owned_valid = false;
     bool fragments_set = false;
     // ---- batch pipelining: uploads run on ctx->stream_copy, kernels on ctx->stream
@@ -177,6 +212,9 @@ hipError_t pg_stage_end(pg_ctx* ctx, pg_batch* b);
 hipError_t pg_stage_begin_on(pg_ctx* ctx, pg_batch* b, hipStream_t s);
 hipError_t pg_stage_end_on(pg_ctx* ctx, pg_batch* b, hipStream_t s);
 hipError_t pg_batch_wait(pg_ctx* ctx, pg_batch* b);
+// the work items follow d_active: re-made from the device's per-group counts when pg_batch_retire_mapped changed the flags
+// (called by the stages that run work items: the klib stage and the gssw stage), on `stream`
+pg_status pg_batch_ensure_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream);
 
 
 // Device memory of graph sets and batches comes from a per-device cache of idle blocks (size classes of an eighth of an

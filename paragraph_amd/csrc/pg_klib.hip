@@ -920,6 +920,7 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     }
     const int R = std::max(1, (int)((max_len + 63) / 64));
     const uint64_t n_items = (uint64_t)b->n_reads * 2u * ix->max_paths;
+    b->h_counters_valid = false;
     HIP_TRY(ctx, pg_stage_begin(ctx, b));
     // every way out of this call from here on records the end of the stage: pg_graphs_destroy / pg_dev_free trust those events
     // (an early return that skipped it could hand buffers the queued kernels still read to another lane)
@@ -934,6 +935,11 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
                 (void)pg_stage_end(c, b);
         }
     } stage_end{ ctx, b, false };
+    {
+        const pg_status ps = pg_batch_ensure_plan(ctx, b, ctx->stream);  // the packed kernels run the batch's work items
+        if (ps != PG_OK)
+            return ps;
+    }
     if (!(flags & PG_AF_KEEP_RESULTS) || flags == PG_AF_ALL)
         HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
     if (b->n_reads == 0 || n_items == 0)

@@ -639,6 +639,7 @@ extern "C" pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* b)
         return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_path_align: call pg_graphs_build_path_index first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const pg_path_index* ix = G->path_index;
+    b->h_counters_valid = false;
     HIP_TRY(ctx, pg_stage_begin(ctx, b));
     HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
     if (b->n_reads)

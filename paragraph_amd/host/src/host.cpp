@@ -1407,22 +1407,12 @@ void SiteBatcher::Impl::Run::deviceSection()
     // Seed stages of the cascade (CompositeAligner.cpp:78-150).  After each one the filter chain runs on the device (count
     // pass); a read that is MAPPED and accepted is done, everything else goes on to the next stage with the earlier
     // records kept.
-    std::vector<uint8_t> stage_flags, active;
-    std::vector<pg_read_support> stage_sup;
+    // The hand-over is decided on the device (pg_batch_retire_mapped): neither flags nor supports nor a mask cross to the host,
+    // and the work items of the stages behind it are re-made from per-graph counts of the reads still active.
     uint32_t keep = 0;
     auto hand_over = [&]() {
         check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
-        uint64_t np = 0;
-        stage_flags.resize(n);
-        stage_sup.resize(n);
-        if (active.empty())
-            active.assign(n, 1);
-        check(ctx, pg_batch_download_path_flags(ctx, guard.b, stage_flags.data()), "pg_batch_download_path_flags");
-        check(ctx, pg_batch_download_counts(ctx, guard.b, nullptr, stage_sup.data(), nullptr, 0, &np), "pg_batch_download_counts");
-        for (uint32_t i = 0; i < n; ++i)
-            if (active[i] && (stage_flags[i] & 1) && stage_sup[i].status == 1)
-                active[i] = 0;
-        check(ctx, pg_batch_set_active(ctx, guard.b, active.data()), "pg_batch_set_active");
+        check(ctx, pg_batch_retire_mapped(ctx, guard.b), "pg_batch_retire_mapped");
         keep = PG_AF_KEEP_RESULTS;
     };
     if (prm.path_sequence_matching && n)
@@ -1451,19 +1441,18 @@ void SiteBatcher::Impl::Run::deviceSection()
     lock.unlock();  // the kernels are queued; the next batch may queue its own behind them
     mark("align + count");
 
+    // one wait for the batch (its sizes are in page-locked memory by then), one for the five copies
     uint64_t n_ops = 0, n_path = 0;
-    check(ctx, pg_batch_ops_count(ctx, guard.b, &n_ops), "pg_batch_ops_count");
-    res.resize(n);
-    ops.resize(n_ops + 1);
-    check(ctx, pg_batch_download(ctx, guard.b, res.data(), ops.data(), ops.size(), &n_ops), "pg_batch_download");
     check(ctx, pg_graphs_count_layout(G, &lay), "pg_graphs_count_layout");
     check(ctx, pg_graphs_seq_offsets(G, seq_off.data()), "pg_graphs_seq_offsets");
-    table.resize(lay.n_counters);
+    res.resize(n);
     sup.resize(n);
-    check(ctx, pg_batch_download_counts(ctx, guard.b, nullptr, nullptr, nullptr, 0, &n_path), "pg_batch_download_counts");
+    table.resize(lay.n_counters);
+    check(ctx, pg_batch_result_sizes(ctx, guard.b, &n_ops, &n_path), "pg_batch_result_sizes");
+    ops.resize(n_ops + 1);
     path.resize(n_path + 1);
-    check(ctx, pg_batch_download_counts(ctx, guard.b, table.data(), sup.data(), path.data(), path.size(), &n_path),
-          "pg_batch_download_counts");
+    check(ctx, pg_batch_download_all(ctx, guard.b, res.data(), ops.data(), ops.size(), table.data(), sup.data(), path.data(), path.size()),
+          "pg_batch_download_all");
     if (csr.label_words > 1)
     {
         label_ext.assign((size_t)n * (csr.label_words - 1), 0);

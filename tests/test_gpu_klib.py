@@ -278,6 +278,54 @@ def test_klib_after_kmer_keeps_results(gpu_ctx):
     G.close()
 
 
+def test_klib_after_kmer_hand_over_on_the_device(gpu_ctx):
+    """The same cascade with the hand-over decided on the device (pg_batch_retire_mapped after the k-mer stage's count pass): the
+    klib stage's work items are re-made from the per-graph counts of the reads still active; records equal the host-mask run."""
+    import numpy as np
+    from paragraph_amd import capi
+    reads = (KA_READS + ["AAAAAAAATTTTCTTTAAAAAAAA", "AAAAAGGGGGAAAAAA"]) * 40
+    edges = edges_of(KA_PATHS)
+    out = {}
+    for on_device in (False, True):
+        G = gpu_ctx.upload_graphs([(KA_NODES, edges)])
+        G.set_labels([{e: ["L%d" % (k % 3)] for k, e in enumerate(edges)}])
+        G.build_kmer_index([KA_PATHS], 10)
+        G.build_klib_index([KA_PATHS])
+        b = gpu_ctx.new_batch()
+        b.upload(G, reads, None)
+        b.set_fragments(np.arange(len(reads), dtype=np.uint32))
+        f1 = b.kmer_align()
+        b.count(remove_nonuniq=True, bad_align_frac=0.8)
+        active = np.ones(len(reads), dtype=bool)
+        if on_device:
+            b.retire_mapped()
+        else:
+            _, sup, _ = b.download_counts(want_table=False)
+            active &= ~(((f1 & 1) != 0) & (sup["status"] == 1))
+            b.set_active(active)
+        f2 = b.klib_align(capi.AF_KEEP_RESULTS)
+        b.count(remove_nonuniq=True, bad_align_frac=0.8)
+        if on_device:
+            b.retire_mapped()
+        else:
+            _, sup, _ = b.download_counts(want_table=False)
+            active &= ~(((f2 & 1) != 0) & (sup["status"] == 1))
+            b.set_active(active)
+        b.align(capi.AF_CIGAR | capi.AF_BOTH_STRANDS | capi.AF_REVERSE_GRAPH | capi.AF_KEEP_RESULTS)
+        b.count(remove_nonuniq=True, bad_align_frac=0.8)
+        res, ops, table, sup, _ = b.download_all()
+        out[on_device] = (f1.copy(), f2.copy(), capi.results_to_dicts(res, ops), table, sup, active.copy())
+        b.close()
+        G.close()
+    (a1, a2, ra, ta, sa, act), (b1, b2, rb, tb, sb, _) = out[False], out[True]
+    assert np.array_equal(a1, b1) and np.array_equal(ta, tb) and np.array_equal(sa["status"], sb["status"])
+    ran = (a1 & 1) == 0  # the klib stage's flags agree wherever it ran in both (a read the k-mer stage retired is not touched by it)
+    assert ran.sum() >= 40 and np.array_equal(a2[ran], b2[ran])
+    assert 0 < act.sum() < len(reads)  # something reached the gssw stage, something did not
+    for i in range(len(reads)):
+        assert all(ra[i][k] == rb[i][k] for k in KEYS + ("status",)), (i, ra[i], rb[i])
+
+
 # ---- the packed two-strand kernels (reads <= 250 bases, every path at least as long as the longest read) -------------------
 
 def _site(rng, n_alt, flank):

@@ -124,3 +124,74 @@ def test_cascade_path_then_gssw(gpu_ctx, checker):
     assert 200 < n_path < 1200
     b.close()
     G.close()
+
+
+def _cascade(ctx, graphs, labels, reads, gor, k, on_device):
+    """path stage -> count (filter chain) -> hand-over -> gssw stage on what is left -> count; the hand-over either as a host
+    loop over downloaded flags + supports (pg_batch_set_active) or on the device (pg_batch_retire_mapped)."""
+    from paragraph_amd import capi
+    G = ctx.upload_graphs(graphs)
+    G.set_labels(labels)
+    G.build_path_index(k)
+    b = ctx.new_batch()
+    b.upload(G, reads, gor)
+    b.set_fragments(np.arange(len(reads), dtype=np.uint32))
+    flags = b.path_align()
+    b.count(remove_nonuniq=True, bad_align_frac=0.8)
+    if on_device:
+        b.retire_mapped()
+    else:
+        _, sup, _ = b.download_counts(want_table=False)
+        b.set_active(~(((flags & 1) != 0) & (sup["status"] == 1)))
+    b.align(capi.AF_CIGAR | capi.AF_BOTH_STRANDS | capi.AF_REVERSE_GRAPH | capi.AF_KEEP_RESULTS)
+    b.count(remove_nonuniq=True, bad_align_frac=0.8)
+    res, ops, table, sup, path = b.download_all()
+    res2, ops2 = b.download()
+    table2, sup2, path2 = b.download_counts()
+    # the one-wait download hands back what the separate calls do
+    assert np.array_equal(res, res2) and np.array_equal(ops, ops2) and np.array_equal(table, table2)
+    assert np.array_equal(sup, sup2) and np.array_equal(path, path2)
+    out = capi.results_to_dicts(res, ops)
+    b.close()
+    G.close()
+    return flags, out, sup, table
+
+
+def test_cascade_hand_over_on_the_device(checker):
+    """CompositeAligner's hand-over (CompositeAligner.cpp:78-176) decided on the device: the records, the count-path outcome of
+    every read and the site tables equal those of the host-mediated hand-over -- on one hot graph (most reads retire at the path
+    stage: the gssw stage's work items are re-made from the per-graph counts) and on 300 small graphs, with a workspace small
+    enough that the re-made plan spans many chunks -- and the gssw-stage reads equal the reference's alignments."""
+    from paragraph_amd import capi, synth
+    check = path_checker()
+    site, reads = synth.config2_reads(6000, read_len=150, seed=31)
+    graphs, labels, gor = [(site.seqs, site.edges)], [site.labels], [0] * len(reads)
+    reads = list(reads)
+    rng = random.Random(fuzzgen.salted(77))
+    for gi in range(300):
+        seqs, edges = fuzzgen.rand_graph(rng, max_len=60, max_nodes=6)
+        rs = _path_reads(rng, seqs, edges, 32, 8)
+        graphs.append((seqs, edges))
+        labels.append(fuzzgen.rand_labels(rng, edges)[0])
+        reads.extend(rs)
+        gor.extend([gi + 1] * len(rs))
+    out = {}
+    for on_device in (False, True):
+        ctx = capi.Context(0, workspace_bytes=64 << 20)
+        out[on_device] = _cascade(ctx, graphs, labels, reads, gor, 32, on_device)
+        ctx.close()
+    (f0, r0, s0, t0), (f1, r1, s1, t1) = out[False], out[True]
+    assert np.array_equal(f0, f1) and np.array_equal(t0, t1)
+    assert np.array_equal(s0["status"], s1["status"]) and np.array_equal(s0["label_mask"], s1["label_mask"]) and np.array_equal(s0["n_path"], s1["n_path"])
+    for a, b in zip(r0, r1):
+        assert all(a[key] == b[key] for key in PKEYS + ("returned_reverse", "by_path_aligner", "status")), (a, b)
+    wp = check(site.seqs, site.edges, reads[:6000], 32)
+    wg = checker.align_batch(site.seqs, site.edges, reads[:6000], threads=8)
+    n_path = 0
+    for i, g in enumerate(r1[:6000]):
+        if wp[i]["status"] and wp[i]["unique"]:
+            n_path += 1
+            assert g["by_path_aligner"] and all(g[key] == wp[i][key] for key in PKEYS), (i, g, wp[i])
+        else:
+            assert not g["by_path_aligner"] and all(g[key] == wg[i][key] for key in PKEYS + ("returned_reverse",)), (i, g, wg[i])
+    assert 600 < n_path < 3600

@@ -503,23 +503,30 @@ class Batch:
         del keep
         self.n_reads = n
 
-    def path_align(self):
-        """PathAligner stage for every read; returns flags (bit0 mapped, bit1 anchored)."""
+    def path_align(self, fetch_flags=True):
+        """PathAligner stage for every read; returns flags (bit0 mapped, bit1 anchored) -- or None with fetch_flags=False: the
+        stage is then only queued (the device-resident cascade never reads the flags on the host)."""
         self.ctx._chk(self.ctx.L.pg_batch_path_align(self.ctx.h, self.h))
+        if not fetch_flags:
+            return None
         fl = np.zeros(max(self.n_reads, 1), dtype=np.uint8)
         self.ctx._chk(self.ctx.L.pg_batch_download_path_flags(self.ctx.h, self.h, fl.ctypes.data))
         return fl[:self.n_reads]
 
-    def klib_align(self, flags=AF_ALL):
-        """KlibAligner stage for every active read; returns flags (bit0 mapped, bit2 BAD_ALIGN)."""
+    def klib_align(self, flags=AF_ALL, fetch_flags=True):
+        """KlibAligner stage for every active read; returns flags (bit0 mapped, bit2 BAD_ALIGN), or None with fetch_flags=False."""
         self.ctx._chk(self.ctx.L.pg_batch_klib_align(self.ctx.h, self.h, flags & 0xFFFFFFFF))
+        if not fetch_flags:
+            return None
         fl = np.zeros(max(self.n_reads, 1), dtype=np.uint8)
         self.ctx._chk(self.ctx.L.pg_batch_download_path_flags(self.ctx.h, self.h, fl.ctypes.data))
         return fl[:self.n_reads]
 
-    def kmer_align(self, flags=AF_ALL):
-        """KmerAligner stage for every active read; returns flags (bit0 mapped, bit2 BAD_ALIGN)."""
+    def kmer_align(self, flags=AF_ALL, fetch_flags=True):
+        """KmerAligner stage for every active read; returns flags (bit0 mapped, bit2 BAD_ALIGN), or None with fetch_flags=False."""
         self.ctx._chk(self.ctx.L.pg_batch_kmer_align(self.ctx.h, self.h, flags & 0xFFFFFFFF))
+        if not fetch_flags:
+            return None
         fl = np.zeros(max(self.n_reads, 1), dtype=np.uint8)
         self.ctx._chk(self.ctx.L.pg_batch_download_path_flags(self.ctx.h, self.h, fl.ctypes.data))
         return fl[:self.n_reads]

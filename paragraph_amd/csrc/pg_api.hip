@@ -1465,16 +1465,19 @@ extern "C" pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* b, const uint8_t
     if (!ctx || !b || !b->graphs)
         return fail(ctx, PG_ERR_INVALID, "pg_batch_set_active: batch not uploaded");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, pg_batch_wait(ctx, b));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    b->has_active = active != nullptr;
-    if (active && b->n_reads)
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_active, active, b->n_reads, hipMemcpyHostToDevice, ctx->stream));
     if (!active)
     {
-        // back to every read: the upload-time groups stay valid, only the items are re-made (plan_items(nullptr) would rebuild the
-        // groups as well, which is harmless)
+        // back to every read: nothing to send, and the work items are re-made where the next stage that needs them runs
+        // (pg_batch_ensure_plan: from the upload-time groups, on the device)
+        b->has_active = false;
+        b->plan_stale = true;
+        return PG_OK;
     }
+    HIP_TRY(ctx, pg_batch_wait(ctx, b));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    b->has_active = true;
+    if (b->n_reads)
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_active, active, b->n_reads, hipMemcpyHostToDevice, ctx->stream));
     return plan_items(ctx, b, active, ctx->stream);
 }
 
@@ -1502,7 +1505,7 @@ __global__ void pg_group_list_kernel(
     uint32_t* group_count, uint32_t* list)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !active[i])
+    if (i >= n || (active && !active[i]))  // (no mask: every read is active)
         return;
     const uint32_t g = group_of_read[i];
     if (g == PG_NONE)
@@ -1575,6 +1578,8 @@ pg_status pg_batch_ensure_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream)
     if (b->has_general_reads)
     {
         // reads of the general path are planned one by one on the host: this (rare) batch fetches the flags and plans from them
+        if (!b->has_active)
+            return plan_items(ctx, b, nullptr, stream);
         std::vector<uint8_t> active(n);
         HIP_TRY(ctx, hipMemcpyAsync(active.data(), b->d_active, n, hipMemcpyDeviceToHost, stream));
         HIP_TRY(ctx, hipStreamSynchronize(stream));
@@ -1611,7 +1616,7 @@ pg_status pg_batch_ensure_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream)
         b->cascade_uploaded = true;
     }
     HIP_TRY(ctx, hipMemsetAsync(b->d_group_count, 0, n_groups * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(pg_group_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, b->d_active, b->d_group_of_read2, b->d_group_base,
+    hipLaunchKernelGGL(pg_group_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, b->has_active ? b->d_active : (const uint8_t*)nullptr, b->d_group_of_read2, b->d_group_base,
                        b->d_group_count, b->d_active_list);
     HIP_TRY(ctx, hipGetLastError());
     b->h_group_count.resize(n_groups);

@@ -1,4 +1,7 @@
-"""Throughput of the optional cascade stages (path / k-mer / klib) and of the gssw stage on config-2 reads.
+"""Throughput of the optional cascade stages (path / k-mer / klib) and of the gssw stage on config-2 reads, each alone, and of the
+composed cascades with the filter chain between the stages and the hand-over decided on the device (pg_batch_retire_mapped):
+`paragraph`'s default path + gssw (src/c++/main/paragraph.cpp:60-61) and all four stages.  `predicted_reads_per_s` = what the
+stage rates give for the same split of the reads (every read through the first stage, the rest through the next, ...).
 Usage: python tools/stage_probe.py [n_reads]   (prints one JSON object)"""
 import json
 import sys
@@ -40,6 +43,44 @@ def main():
         out[name] = {"s_per_batch": s, "reads_per_s": n / s,
                      "mapped_frac": None if flags is None else float(np.mean((flags & 1) != 0))}
     assert graphs.klib_error() == 0
+    # ---- composed cascades: stage, count pass (NonUniq + BadAlign), hand-over on the device, next stage on what is left
+    graphs.set_labels([site.labels])
+    b.set_fragments(np.arange(n, dtype=np.uint32) // 2)
+    keep_flags = capi.AF_CIGAR | capi.AF_BOTH_STRANDS | capi.AF_REVERSE_GRAPH | capi.AF_KEEP_RESULTS
+
+    def cascade(stages):
+        def run():
+            b.set_active(None)
+            keep = 0
+            for name in stages:
+                if name == "path":
+                    b.path_align(fetch_flags=False)
+                elif name == "kmer":
+                    b.kmer_align(keep, fetch_flags=False)
+                else:
+                    b.klib_align(keep, fetch_flags=False)
+                b.count(remove_nonuniq=True, bad_align_frac=0.8)
+                b.retire_mapped()
+                keep = capi.AF_KEEP_RESULTS
+            b.align(keep_flags)
+            b.count(remove_nonuniq=True, bad_align_frac=0.8)
+        return run
+
+    for key, stages in (("cascade_path_gssw", ["path"]), ("cascade_all_four", ["path", "kmer", "klib"])):
+        run = cascade(stages)
+        s = timed(ctx, run)
+        # the split of the reads over the stages, from one more pass: a read leaves at the first stage that maps it and passes the filters
+        run()
+        res, _, _, sup, _ = b.download_all(want_table=False)
+        by = {"path": int(((res["status"] & capi.STATUS_PATH_ALIGNER) != 0).sum()), "kmer": int(((res["status"] & capi.STATUS_KMER_ALIGNER) != 0).sum()),
+              "klib": int(((res["status"] & capi.STATUS_KLIB_ALIGNER) != 0).sum())}
+        left, t_pred = n, 0.0
+        for name in stages:
+            t_pred += left / out[name]["reads_per_s"]
+            left -= by[name]
+        t_pred += left / out["gssw"]["reads_per_s"]
+        out[key] = {"s_per_batch": s, "reads_per_s": n / s, "predicted_reads_per_s": n / t_pred, "vs_predicted": t_pred / s,
+                    "reads_by_stage": dict(by, gssw=left), "mapped": int((sup["status"] == 1).sum())}
     print(json.dumps(out))
 
 

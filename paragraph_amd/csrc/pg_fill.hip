@@ -13,8 +13,13 @@
 //     columns node by node in topological order, skewed by one column per lane (anti-diagonal
 //     wavefront): at step t lane k works on column t-k.
 //   * both strands of a read (read and its reverse complement) run in the two 16-bit halves of every
-//     VGPR with packed VOP3P integer ops (v_pk_add_u16, v_pk_max_i16/u16, v_pk_sub_u16 clamp), so one
-//     wavefront performs 8 fills at once.  No MFMA: this is integer DP, not a contraction.
+//     VGPR, so one wavefront performs 8 fills at once.  A score n is held as the f16 number 1024 + n in a
+//     frame that moves by one per step (bit pattern 0x6400 + n + tau: every integer below 2048 is exact
+//     in f16, so this is integer arithmetic in disguise): the three maxima of a cell are
+//     v_pk_maximum3_f16 / v_pk_max_u16 on those patterns (gfx950 has a three-input packed maximum for
+//     f16 and none for integers), the three additions are plain 32-bit v_add_u32 on the patterns of both
+//     halves at once (two issue cycles where a packed add takes four; pg_pk16.h).  Results equal gssw's
+//     saturating u8 / i16 arithmetic bit for bit.  No MFMA: this is integer DP, not a contraction.
 //   * the only cross-lane traffic is (H of the row above on the previous column, running F) handed to
 //     the next lane with two row_shr:1 DPP moves per step; the column's meta word (base code, node
 //     boundary flags) rides the same shift, lane 0 reads it with a scalar load.

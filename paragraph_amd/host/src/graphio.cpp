@@ -586,12 +586,15 @@ namespace
 {
 const uint64_t kNoLength = std::numeric_limits<uint64_t>::max();
 
+// (a fragment is one or two reads: their spans and lengths live in the shape itself -- a list and a vector per fragment were two
+// or three allocations for each of a site's hundred fragments; only a third graph-mapped read spills into `more`)
 struct FragmentShape
 {
-    unsigned n_reads = 0;
+    unsigned n_reads = 0, n_spans = 0;
     uint64_t bam_length = kNoLength, graph_length = kNoLength;
-    std::list<std::pair<uint64_t, uint64_t>> spans;
-    std::vector<uint64_t> lengths;
+    std::pair<uint64_t, uint64_t> span[2];
+    uint64_t length[2] = { 0, 0 };
+    std::vector<std::pair<uint64_t, uint64_t>> more;  // every span, once there are three or more
 };
 
 void addToFragment(FragmentShape& f, graphtools::GraphCoordinates const& coords, SiteReadViews const& views, MappedReadView const& read)
@@ -615,24 +618,35 @@ void addToFragment(FragmentShape& f, graphtools::GraphCoordinates const& coords,
     // the LAST aligned base of the last node (inclusive), as decodeGraphAlignment builds the alignment's path
     // (GT!/src/graphalign/GraphAlignmentOperations.cpp:103-104); canonicalStartAndEnd then treats an end of 0 as "unknown"
     walk.end_position = (int32_t)nodes[read.n_pieces - 1].referenceLength() + (read.n_pieces == 1 ? read.graph_pos : 0) - 1;
-    f.spans.push_back(coords.canonicalStartAndEnd(walk));
-    f.lengths.push_back(query_length);
-    if (f.spans.size() == 1)
-        f.graph_length = f.lengths.front();
-    else if (f.spans.size() == 2)
+    const std::pair<uint64_t, uint64_t> this_span = coords.canonicalStartAndEnd(walk);
+    if (f.n_spans < 2)
     {
-        const uint64_t gap = std::min(
-            coords.distance(f.spans.front().second, f.spans.back().first), coords.distance(f.spans.back().second, f.spans.front().first));
-        f.graph_length = gap == kNoLength ? kNoLength : f.lengths.front() + f.lengths.back() + gap;
+        f.span[f.n_spans] = this_span;
+        f.length[f.n_spans] = query_length;
+    }
+    else
+    {
+        if (f.more.empty())
+            f.more.assign(f.span, f.span + 2);
+        f.more.push_back(this_span);
+    }
+    ++f.n_spans;
+    if (f.n_spans == 1)
+        f.graph_length = f.length[0];
+    else if (f.n_spans == 2)
+    {
+        const uint64_t gap = std::min(coords.distance(f.span[0].second, f.span[1].first), coords.distance(f.span[1].second, f.span[0].first));
+        f.graph_length = gap == kNoLength ? kNoLength : f.length[0] + f.length[1] + gap;
     }
     else
     {
         // three or more graph-mapped reads in one fragment: each step adds the start-to-start distance, twice from the
-        // second read on (kept as the original computes it)
-        f.spans.sort([](std::pair<uint64_t, uint64_t> const& a, std::pair<uint64_t, uint64_t> const& b) { return a.first < b.first; });
+        // second read on (kept as the original computes it); the spans stay sorted from step to step, as the original's list does
+        std::stable_sort(f.more.begin(), f.more.end(),
+                         [](std::pair<uint64_t, uint64_t> const& a, std::pair<uint64_t, uint64_t> const& b) { return a.first < b.first; });
         uint64_t previous = 0, length = 0;
         bool has_previous = false;
-        for (auto const& span : f.spans)
+        for (auto const& span : f.more)
         {
             const uint64_t step = coords.distance(previous, span.first);
             if (step == kNoLength)
@@ -741,18 +755,29 @@ struct Tally
 Json alignmentStatistics(Graph const& graph, SiteReadViews const& views)
 {
     const NodeId n_nodes = (NodeId)graph.numNodes();
-    // an allele's length: the nodes that carry its label on an edge in AND an edge out
-    std::map<std::string, size_t> allele_length;
-    for (NodeId node = 0; node < n_nodes; ++node)
+    // an allele's length: the nodes that carry its label on an edge in AND an edge out (labels as bits of views.label_names,
+    // which holds every label of the graph in sorted order: no string sets per node)
+    std::vector<size_t> allele_length(views.label_names.size(), 0);
     {
-        std::set<std::string> in, out;
-        for (NodeId p : graph.predecessors(node))
-            in.insert(graph.edgeLabels(p, node).begin(), graph.edgeLabels(p, node).end());
-        for (NodeId s : graph.successors(node))
-            out.insert(graph.edgeLabels(node, s).begin(), graph.edgeLabels(node, s).end());
-        for (auto const& label : in)
-            if (out.count(label))
-                allele_length[label] += graph.nodeSeq(node).size();
+        auto bits_of = [&](std::set<std::string> const& labels, LabelSet& into) {
+            for (auto const& label : labels)
+            {
+                const auto it = std::lower_bound(views.label_names.begin(), views.label_names.end(), label);
+                if (it != views.label_names.end() && *it == label)
+                    into.set((size_t)(it - views.label_names.begin()));
+            }
+        };
+        for (NodeId node = 0; node < n_nodes; ++node)
+        {
+            LabelSet in, out;
+            for (NodeId p : graph.predecessors(node))
+                bits_of(graph.edgeLabels(p, node), in);
+            for (NodeId s : graph.successors(node))
+                bits_of(graph.edgeLabels(node, s), out);
+            for (size_t b = 0; b < views.label_names.size(); ++b)
+                if (in.test(b) && out.test(b))
+                    allele_length[b] += graph.nodeSeq(node).size();
+        }
     }
     const bool terminals = n_nodes && (graph.nodeName(0) == "source" || graph.nodeName(n_nodes - 1) == "sink");
     // tallies are kept by id while the reads go by (names only when the document is written)
@@ -798,7 +823,7 @@ Json alignmentStatistics(Graph const& graph, SiteReadViews const& views)
             if (!allele_seen[b])
             {
                 allele_seen[b] = true;
-                allele_tally[b] = Tally(allele_length[views.label_names[b]]);
+                allele_tally[b] = Tally(allele_length[b]);
             }
             for (size_t k = 0; k < read.n_pieces; ++k)
                 allele_tally[b].bases(pieces[k], !(terminals && (pieces[k].node == 0 || pieces[k].node == n_nodes - 1)));

@@ -152,12 +152,9 @@ pg_ctx* deviceContext(int slot = 0)
         // Workspace budget (H trace + seeds of the reads in flight; allocated on demand up to this): the library's default
         // of 8 GiB cuts a 1000-site batch into ~9 chunks of 25 k reads, too few threads for the one-thread-per-read
         // traceback kernel.  An MI355X has 288 GB: 64 GiB (what bench.py uses) keeps such a batch in one or two chunks.
-        // The workflow's batches are small (192 sites: a fill launch of ~2 ms, 10 - 15 % of it the tail in which the chip drains):
-        // fills alternate over two streams and three workspace regions, so the next chunk's wavefronts take the slots the
-        // draining one leaves (PG_FILL_STREAMS=1 in the environment = one stream, for A/B timing).
-        st = pg_ctx_set_fill_streams(ds.ctx, 2);
-        if (st != PG_OK)
-            throw std::runtime_error(std::string("pg_ctx_set_fill_streams: ") + pg_strerror(st));
+        // (pg_ctx_set_fill_streams(ctx, 2) -- fills alternating over two streams and three workspace regions, so that a launch's
+        // draining tail is filled by the next chunk -- was measured here and changes nothing: this workflow is bound by its 16
+        // host CPUs, not by the device, profiles/r05_tail_ab.jsonl.  PG_FILL_STREAMS=2 in the environment switches it on.)
         const char* gib = std::getenv("PG_WORKSPACE_GIB");
         const double budget_gib = gib ? std::atof(gib) : 64.0;
         if (budget_gib > 0)

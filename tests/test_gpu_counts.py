@@ -158,6 +158,7 @@ def _rc(s):
 @pytest.mark.parametrize("filter_k", [4, 8, -1])
 def test_kmer_filter_fuzz(gpu_ctx, filter_k):
     """KmerFilter as the third filter of the chain: per-read outcome and the resulting counters."""
+    from oracle import counts as oc
     from oracle import select
     check = count_checker()
     fcheck = select.kmer_filter()

@@ -84,12 +84,12 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream-batches", type=int, default=16,
                     help="batches of the PCIe-inclusive streaming leg (0 = skip; reported beside the headline value)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_r04.json"),
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_r05.json"),
                     help="PMC-derived HBM bytes per fill launch (written by tools/pmc_traffic.py); used only when the kernel "
                          "sources it was collected on are the ones of this build (kernel_source_sha)")
-    ap.add_argument("--sq-json", default=os.path.join(ROOT, "profiles", "r04_sq_counters.json"),
+    ap.add_argument("--sq-json", default=os.path.join(ROOT, "profiles", "r05_sq_counters.json"),
                     help="SQ counters of one fill launch (tools/sq_collect.sh + tools/sq_summary.py), same rule")
-    ap.add_argument("--isa-mix-json", default=os.path.join(ROOT, "profiles", "r04_fill_isa_mix.json"),
+    ap.add_argument("--isa-mix-json", default=os.path.join(ROOT, "profiles", "r05_fill_isa_mix.json"),
                     help="static VALU mix of a step by issue class (tools/isa_mix.py), same rule")
     ap.add_argument("--valu-rate-json", default=os.path.join(ROOT, "profiles", "r04_valu_rate.json"),
                     help="measured cycles per wave64 instruction (tools/ubench/valu_rate)")

@@ -984,6 +984,10 @@ extern "C" void pg_batch_destroy(pg_ctx* ctx, pg_batch* b)
     batch_free_device(b);
     if (b->h_counters)
         (void)hipHostFree(b->h_counters);
+    if (b->h_group_count)
+        (void)hipHostFree(b->h_group_count);
+    if (b->ev_counts)
+        (void)hipEventDestroy(b->ev_counts);
     if (b->ev_upload)
         (void)hipEventDestroy(b->ev_upload);
     if (b->ev_busy)
@@ -1071,6 +1075,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
         b->h_group_of_read.assign(n_reads, PG_NONE);
         b->has_general_reads = !b->gen_idx.empty();
         b->cascade_uploaded = false;
+        b->counts_pending = false;
         for (size_t p0 = 0; p0 < keys.size();)
         {
             size_t q0 = p0;
@@ -1548,21 +1553,88 @@ __global__ void pg_build_items_kernel(uint32_t n_pairs, uint32_t n_segments, con
 }
 }  // namespace
 
+// The active reads of every (variant, graph) group listed on the device (group after group, in no particular order inside a
+// group), on `stream`; with `want_counts` the per-group counts follow into page-locked host memory and b->ev_counts is recorded
+// behind them.  The group tables go up once per upload.
+static pg_status cascade_lists(pg_ctx* ctx, pg_batch* b, hipStream_t stream, const uint8_t* d_active, bool want_counts)
+{
+    const uint32_t n = b->n_reads;
+    const size_t n_groups = b->groups.size();
+    if (!n || !n_groups)
+        return PG_OK;
+    if (n_groups > b->cap_groups || n > b->cap_cascade_reads)
+    {
+        HIP_TRY(ctx, pg_batch_wait(ctx, b));
+        (void)pg_dev_free(b->d_group_of_read2);
+        (void)pg_dev_free(b->d_group_base);
+        (void)pg_dev_free(b->d_group_count);
+        (void)pg_dev_free(b->d_active_list);
+        b->cap_groups = n_groups;
+        b->cap_cascade_reads = n;
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_group_of_read2, (size_t)n * sizeof(uint32_t)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_active_list, (size_t)n * sizeof(uint32_t)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_group_base, n_groups * sizeof(uint32_t)));
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_group_count, n_groups * sizeof(uint32_t)));
+        b->cascade_uploaded = false;
+    }
+    if (!b->cascade_uploaded)
+    {
+        b->h_group_base.resize(n_groups);
+        for (size_t g = 0; g < n_groups; ++g)
+            b->h_group_base[g] = b->groups[g].list_base;
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_group_of_read2, b->h_group_of_read.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_group_base, b->h_group_base.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        b->cascade_uploaded = true;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(b->d_group_count, 0, n_groups * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(pg_group_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, d_active, b->d_group_of_read2, b->d_group_base,
+                       b->d_group_count, b->d_active_list);
+    HIP_TRY(ctx, hipGetLastError());
+    if (want_counts)
+    {
+        if (n_groups > b->cap_h_group_count)
+        {
+            if (b->h_group_count)
+                (void)hipHostFree(b->h_group_count);
+            b->h_group_count = nullptr;
+            void* p = nullptr;
+            HIP_TRY(ctx, hipHostMalloc(&p, (n_groups + n_groups / 4 + 64) * sizeof(uint32_t), hipHostMallocPortable));
+            b->h_group_count = (uint32_t*)p;
+            b->cap_h_group_count = n_groups + n_groups / 4 + 64;
+        }
+        if (!b->ev_counts)
+            HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_counts, hipEventDisableTiming));
+        HIP_TRY(ctx, hipMemcpyAsync(b->h_group_count, b->d_group_count, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(ctx, hipEventRecord(b->ev_counts, stream));
+    }
+    return PG_OK;
+}
+
 extern "C" pg_status pg_batch_retire_mapped(pg_ctx* ctx, pg_batch* b)
 {
     if (!ctx || !b || !b->graphs || !b->d_support || !b->d_path_flags)
         return fail(ctx, PG_ERR_INVALID, "pg_batch_retire_mapped: a seed stage and pg_batch_count must have run");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // behind the count pass, on its stream: the next stage (main stream) waits for the batch's event as always
+    // behind the count pass, on its stream: the next stage (main stream) waits for the batch's event as always.  The lists and
+    // per-group counts the next plan is made from are produced HERE as well, so that the counts are on the host when this
+    // stream reaches them -- not behind whatever fills of other batches are queued on the main stream.
     hipStream_t cs = ctx->stream2;
     HIP_TRY(ctx, pg_stage_begin_on(ctx, b, cs));
     if (!b->has_active && b->n_reads)
         HIP_TRY(ctx, hipMemsetAsync(b->d_active, 1, b->n_reads, cs));
     b->has_active = true;
+    b->counts_pending = false;
     if (b->n_reads)
     {
         hipLaunchKernelGGL(pg_retire_kernel, dim3((b->n_reads + 255) / 256), dim3(256), 0, cs, b->n_reads, b->d_path_flags, b->d_support, b->d_active);
         HIP_TRY(ctx, hipGetLastError());
+        if (!b->has_general_reads)
+        {
+            const pg_status ls = cascade_lists(ctx, b, cs, b->d_active, true);
+            if (ls != PG_OK)
+                return ls;
+            b->counts_pending = true;
+        }
     }
     b->plan_stale = true;
     HIP_TRY(ctx, pg_stage_end_on(ctx, b, cs));
@@ -1592,36 +1664,26 @@ pg_status pg_batch_ensure_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream)
     b->plan_stale = false;
     if (!n || !n_groups)
         return PG_OK;
-    if (n_groups > b->cap_groups || n > b->cap_cascade_reads)
+    std::vector<uint32_t> all_counts;
+    const uint32_t* counts = nullptr;
+    if (!b->has_active)
     {
-        (void)pg_dev_free(b->d_group_of_read2);
-        (void)pg_dev_free(b->d_group_base);
-        (void)pg_dev_free(b->d_group_count);
-        (void)pg_dev_free(b->d_active_list);
-        b->cap_groups = n_groups;
-        b->cap_cascade_reads = n;
-        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_group_of_read2, (size_t)n * sizeof(uint32_t)));
-        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_active_list, (size_t)n * sizeof(uint32_t)));
-        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_group_base, n_groups * sizeof(uint32_t)));
-        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_group_count, n_groups * sizeof(uint32_t)));
-        b->cascade_uploaded = false;
-    }
-    std::vector<uint32_t> base(n_groups);
-    if (!b->cascade_uploaded)
-    {
+        // every read is active again (pg_batch_set_active(NULL)): the counts are the groups' sizes, only the lists are made
+        const pg_status ls = cascade_lists(ctx, b, stream, nullptr, false);
+        if (ls != PG_OK)
+            return ls;
+        all_counts.resize(n_groups);
         for (size_t g = 0; g < n_groups; ++g)
-            base[g] = b->groups[g].list_base;
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_group_of_read2, b->h_group_of_read.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_group_base, base.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        b->cascade_uploaded = true;
+            all_counts[g] = b->groups[g].n_reads;
+        counts = all_counts.data();
     }
-    HIP_TRY(ctx, hipMemsetAsync(b->d_group_count, 0, n_groups * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(pg_group_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, b->has_active ? b->d_active : (const uint8_t*)nullptr, b->d_group_of_read2, b->d_group_base,
-                       b->d_group_count, b->d_active_list);
-    HIP_TRY(ctx, hipGetLastError());
-    b->h_group_count.resize(n_groups);
-    HIP_TRY(ctx, hipMemcpyAsync(b->h_group_count.data(), b->d_group_count, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(ctx, hipStreamSynchronize(stream));  // the ONE wait of the hand-over: per-group counts (also: `base` may go)
+    else
+    {
+        if (!b->counts_pending)
+            return fail(ctx, PG_ERR_INVALID, "pg_batch_ensure_plan: no counts for the batch's activity flags");
+        HIP_TRY(ctx, hipEventSynchronize(b->ev_counts));  // the ONE wait of the hand-over: a few hundred words, made on the count stream
+        counts = b->h_group_count;
+    }
 
     // ---- chunks and segments from the counts: plan_items' rule (equal chunks per variant, longest graph first inside a chunk)
     const uint64_t packed_limit = ctx->ws_limit - b->gen_reserve;
@@ -1631,7 +1693,7 @@ pg_status pg_batch_ensure_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream)
         std::vector<uint64_t> total(chunk_target.size(), 0), largest(chunk_target.size(), 0);
         for (size_t g = 0; g < n_groups; ++g)
         {
-            const uint64_t pairs = (b->h_group_count[g] + PG_GROUPS - 1) / PG_GROUPS;
+            const uint64_t pairs = (counts[g] + PG_GROUPS - 1) / PG_GROUPS;
             if (!pairs)
                 continue;
             const uint64_t need = pair_need_of((int)b->groups[g].C, G->host[b->groups[g].graph]).need;
@@ -1689,7 +1751,7 @@ pg_status pg_batch_ensure_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream)
     for (size_t g = 0; g < n_groups; ++g)
     {
         const PgReadGroup& grp = b->groups[g];
-        const uint32_t count = b->h_group_count[g];
+        const uint32_t count = counts[g];
         uint32_t pairs_left = (count + PG_GROUPS - 1) / PG_GROUPS, first_pair = 0;
         if (!pairs_left)
             continue;

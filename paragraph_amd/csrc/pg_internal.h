@@ -173,7 +173,11 @@ struct pg_batch
     uint32_t* d_active_list = nullptr;        // [n_reads] active reads, group after group
     PgPlanSegment* d_segments = nullptr;
     size_t cap_groups = 0, cap_cascade_reads = 0, cap_segments = 0;
-    std::vector<uint32_t> h_group_count;
+    std::vector<uint32_t> h_group_base;       // (kept: the upload of the group tables reads it asynchronously)
+    uint32_t* h_group_count = nullptr;        // page-locked [cap_groups]: the counts, sent by the stream that made them
+    size_t cap_h_group_count = 0;
+    hipEvent_t ev_counts = nullptr;           // behind that copy
+    bool counts_pending = false;              // the lists + counts of the CURRENT d_active are made (pg_batch_retire_mapped)
     std::vector<PgPlanSegment> h_segments;
     uint32_t* d_graph_of_read = nullptr;
     pg_read_support* d_support = nullptr;

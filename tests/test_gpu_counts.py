@@ -159,6 +159,7 @@ def _rc(s):
 def test_kmer_filter_fuzz(gpu_ctx, filter_k):
     """KmerFilter as the third filter of the chain: per-read outcome and the resulting counters."""
     from oracle import counts as oc
+    from oracle import kmerfilter as kf
     from oracle import select
     check = count_checker()
     fcheck = select.kmer_filter()

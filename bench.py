@@ -858,6 +858,26 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
         docs = json.load(f)
     os.unlink(out_file)
     assert len(docs) == len(mine)
+    # The same job with `paragraph`'s default cascade (src/c++/main/paragraph.cpp:60-61: exact path matching first, gssw on what it
+    # leaves): path stage -> filter chain -> hand-over on the device -> gssw stage, composed inside the workflow.  Two passes.
+    cascade = None
+    if args.e2e_steps > 0:
+        options_path = dict(options, path_sequence_matching=True)
+        workflow.genotype_graphs_to_file(e2e["reference"], e2e["manifest"], graphs, out_file, **options_path)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            workflow.genotype_graphs_to_file(e2e["reference"], e2e["manifest"], graphs, out_file, **options_path)
+        barrier()
+        t_path = env["max_over_ranks"](time.perf_counter() - t0)
+        with open(out_file) as f:
+            docs_path = json.load(f)
+        os.unlink(out_file)
+        same_gt = sum(1 for a, b2 in zip(docs, docs_path) if a["samples"]["SYN"]["gt"].get("GT") == b2["samples"]["SYN"]["gt"].get("GT"))
+        cascade = {"sites_genotyped_per_s": n * 2 / t_path, "ms_per_step": t_path / 2 * 1e3,
+                   "genotypes_equal_the_gssw_only_run_on_this_rank": same_gt, "sites_on_this_rank": len(mine),
+                   "note": "path_sequence_matching = true (the `paragraph` tool's default): reads the exact path matcher maps and the "
+                           "filters accept keep that alignment, so counts may differ from the gssw-only run by design"}
     concordant = sum(1 for i, doc in zip(mine, docs) if doc["samples"]["SYN"]["gt"].get("GT") == e2e["truth"][i]["gt"])
     errors = sum(1 for doc in docs if "error" in doc)
     # per-site edge-count table in one layout on every rank: a slot per edge of every site's graph, in site order
@@ -912,7 +932,7 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
                           "reduced_equals_own_on_own_sites": bool(mine_kept),
                           "note": "one slot per edge of every site (fragment counts of the breakpoint edges), all-reduced over the ranks "
                                   "AFTER the timed passes: a site's genotype needs only its own counts, the sum only collects them"},
-           "data_make_s": e2e["make_s"], "per_rank": per_rank}
+           "data_make_s": e2e["make_s"], "per_rank": per_rank, "with_path_matching": cascade}
     # A genotype that differs from the simulated truth is not by itself an error of the path (30x sampling can starve an allele);
     # a concordance below 99.5 % is.  What must hold exactly: no document with an error, the table checks, the sampled sites.
     out["genotype_concordance"] = int(table[total]) / max(1, n)

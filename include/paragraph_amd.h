@@ -409,6 +409,11 @@ pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* batch, const uint8_t* activ
  * pg_batch_align) re-makes them from the device's per-(read length class, graph) counts of active reads -- one download of a
  * few hundred words.  Asynchronous.  Results equal those of pg_batch_set_active with the mask a host loop would build. */
 pg_status pg_batch_retire_mapped(pg_ctx* ctx, pg_batch* batch);
+/* Blocks until the per-graph counts of the batch's last pg_batch_retire_mapped are on the host (they are sent by the count
+ * stream right behind the hand-over kernels).  Optional: the next stage that needs them waits for them itself.  Unlike the
+ * stage calls this one may run while OTHER threads queue stages on the same context -- a workflow's lane calls it WITHOUT the
+ * lock that serialises its stage calls, so that other lanes' batches fill the device while this one's counts travel. */
+pg_status pg_batch_await_hand_over(pg_ctx* ctx, pg_batch* batch);
 
 /* Renders "<node>[<len><op>...]..." for one read into buf (NUL-terminated); returns the string length
  * (which may be >= cap, in which case the output was truncated). Host-only helper. */

@@ -1641,6 +1641,18 @@ extern "C" pg_status pg_batch_retire_mapped(pg_ctx* ctx, pg_batch* b)
     return PG_OK;
 }
 
+extern "C" pg_status pg_batch_await_hand_over(pg_ctx* ctx, pg_batch* b)
+{
+    if (!ctx || !b)
+        return PG_ERR_INVALID;
+    if (b->plan_stale && b->has_active && b->counts_pending)
+    {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipEventSynchronize(b->ev_counts));
+    }
+    return PG_OK;
+}
+
 pg_status pg_batch_ensure_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream)
 {
     if (!b->plan_stale)

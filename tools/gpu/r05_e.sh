@@ -21,3 +21,9 @@ import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
 print(json.dumps({'fill_streams': $fs, 'rep': $rep, 'value': d['value'], 'ms_per_step': d['ms_per_step'], 'launches': d['roofline']['launches'], 'avg_launch_ms': d['roofline']['avg_launch_ms']}))" | tee -a $O/headline_fill_streams_ab.jsonl
 done; done
+for ws in 128 165; do
+  python bench.py --steps 10 --warmup 2 --no-cpu-baseline --sites-steps 0 --stream-batches 0 --e2e-steps 0 --workspace-gib $ws 2> /dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print(json.dumps({'workspace_gib': $ws, 'value': d['value'], 'ms_per_step': d['ms_per_step'], 'launches': d['roofline']['launches'], 'avg_launch_ms': d['roofline']['avg_launch_ms']}))" | tee -a $O/headline_workspace_ab.jsonl
+done

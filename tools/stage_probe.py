@@ -52,12 +52,13 @@ def main():
     for x in (b, b2):
         x.set_fragments(np.arange(n, dtype=np.uint32) // 2)
     keep_flags = capi.AF_CIGAR | capi.AF_BOTH_STRANDS | capi.AF_REVERSE_GRAPH | capi.AF_KEEP_RESULTS
-    turn = [0]
 
     def cascade(stages):
-        def run():
-            x = (b, b2)[turn[0] & 1]
-            turn[0] += 1
+        """(start, finish): the seed stages + filter chain + device hand-over of a batch are queued by start(), its gssw stage and
+        final count pass by finish().  The loop below queues start(next batch) BEFORE finish(this batch): by the time the host
+        asks for this batch's per-graph counts (the one wait of the hand-over) they have long arrived, and the device's main
+        stream goes path, fills, path, fills ... without a gap -- what lanes of a workflow do for each other."""
+        def start(x):
             x.set_active(None)
             keep = 0
             for name in stages:
@@ -70,16 +71,31 @@ def main():
                 x.count(remove_nonuniq=True, bad_align_frac=0.8)
                 x.retire_mapped()
                 keep = capi.AF_KEEP_RESULTS
+
+        def finish(x):
             x.align(keep_flags)
             x.count(remove_nonuniq=True, bad_align_frac=0.8)
-            return x
-        return run
+        return start, finish
+
+    def pipelined(start, finish, reps):
+        start(b)
+        ctx.sync()
+        t = time.perf_counter()
+        cur, nxt = b, b2
+        for _ in range(reps):  # steady state: one batch started and not finished at either end of the timed region
+            start(nxt)
+            finish(cur)
+            cur, nxt = nxt, cur
+        ctx.sync()
+        s = (time.perf_counter() - t) / reps
+        finish(cur)
+        ctx.sync()
+        return s, cur
 
     for key, stages in (("cascade_path_gssw", ["path"]), ("cascade_all_four", ["path", "kmer", "klib"])):
-        run = cascade(stages)
-        s = timed(ctx, run, reps=6)
-        # the split of the reads over the stages, from one more pass: a read leaves at the first stage that maps it and passes the filters
-        x = run()
+        start, finish = cascade(stages)
+        pipelined(start, finish, 2)  # warm-up
+        s, x = pipelined(start, finish, 7)
         res, _, _, sup, _ = x.download_all(want_table=False)
         by = {"path": int(((res["status"] & capi.STATUS_PATH_ALIGNER) != 0).sum()), "kmer": int(((res["status"] & capi.STATUS_KMER_ALIGNER) != 0).sum()),
               "klib": int(((res["status"] & capi.STATUS_KLIB_ALIGNER) != 0).sum())}
@@ -90,7 +106,8 @@ def main():
         t_pred += left / out["gssw"]["reads_per_s"]
         out[key] = {"s_per_batch": s, "reads_per_s": n / s, "predicted_reads_per_s": n / t_pred, "vs_predicted": t_pred / s,
                     "reads_by_stage": dict(by, gssw=left), "mapped": int((sup["status"] == 1).sum()),
-                    "note": "two batch objects take turns; predicted = every read through the first stage at its rate, the rest through the next, ..."}
+                    "note": "two batch objects, the next one's seed stages queued before this one's gssw stage; predicted = every read "
+                            "through the first stage at its rate, the rest through the next, ..."}
     print(json.dumps(out))
 
 

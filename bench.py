@@ -76,10 +76,10 @@ def parse_args():
     ap.add_argument("--split-reads", type=int, default=5000,
                     help="config3 with N > 1: a site with this many reads or more is split over all ranks by fragment id")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--workspace-gib", type=float, default=128.0,
-                    help="HBM budget for traceback state (two halves: trace of chunk i overlaps fill of chunk i+1); 128 of the "
-                         "288 GB = 3 fill launches of 333 k reads per 1 M-read step (64: 5 of 200 k, 1.4 %% slower: every launch ends "
-                         "with a tail in which the chip drains)")
+    ap.add_argument("--workspace-gib", type=float, default=165.0,
+                    help="HBM budget for traceback state (two halves: trace of chunk i overlaps fill of chunk i+1); 165 GiB of the "
+                         "288 GB = 2 fill launches of 500 k reads per 1 M-read step (128: 3 of 333 k, 1.2 %% slower; 64: 5 of 200 k, "
+                         "2.6 %% slower: every launch ends with a tail in which the chip drains, profiles/r05_headline_workspace_ab.jsonl)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream-batches", type=int, default=16,

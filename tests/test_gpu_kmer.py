@@ -142,3 +142,43 @@ def test_kmer_stage_fuzz(gpu_ctx, k):
     flags, got = gpu_kmer(gpu_ctx, graphs, paths, reads, gor, k)
     n = check(flags, got, want, reads, "kmer-fuzz-%d" % k)
     assert n > 300
+
+
+def test_reference_vector_through_the_cascade_at_k_10(gpu_ctx, checker):
+    """The reference's one vector for this aligner (src/c++/test/test_kmeraligner.cpp:149-193, K = 10) through the CASCADE the way
+    CompositeAligner runs it (CompositeAligner.cpp:96-118): k-mer stage, filter chain, hand-over on the device, gssw stage on
+    what is left.  The five reads the vector maps keep the vector's record (status MAPPED, by the k-mer aligner); the sixth --
+    BAD_ALIGN in the vector: two equally good candidates -- goes on and comes out as the reference's gssw aligns it."""
+    import numpy as np
+    from paragraph_amd import capi
+    nodes = ["AAAAAAAAAAA", "TTTTTTTT", "GGGGGGGG", "AAAAAAAAAAA"]
+    edges = [(0, 1), (0, 2), (0, 3), (1, 3), (2, 3)]
+    paths = [[0, 1, 3], [0, 2, 3], [0, 3]]
+    reads = ["AAAAAAAATTTTTTTTAAAAAAAA", "TTTTTTAAAAAAAATTTTTTT", "AAAAAGGGGGGGGAAAAAA", "AAAAGGGGGGGGAAAAAA",
+             "TTTTTTCCCCCCCCTTTTT", "AAAAAAAAAAAAAAAAAAA"]
+    want = [(3, "0[8M]1[8M]3[8M]", 24, False), (4, "0[7M]1[8M]3[6M]", 21, True), (6, "0[5M]2[8M]3[6M]", 19, False),
+            (7, "0[4M]2[8M]3[6M]", 18, False), (6, "0[5M]2[8M]3[6M]", 19, True)]
+    G = gpu_ctx.upload_graphs([(nodes, edges)])
+    G.set_labels([{(0, 1): ["P"], (1, 3): ["P"], (0, 2): ["Q"], (2, 3): ["Q"], (0, 3): ["R"]}])
+    G.build_kmer_index([paths], 10)
+    b = gpu_ctx.new_batch()
+    b.upload(G, reads, None)
+    b.set_fragments(np.arange(len(reads), dtype=np.uint32))
+    flags = b.kmer_align()
+    # bad_align_frac 0.8 / remove_nonuniq: none of the five full-length unique matches is filtered
+    b.count(remove_nonuniq=True, bad_align_frac=0.8)
+    b.retire_mapped()
+    b.align(capi.AF_CIGAR | capi.AF_BOTH_STRANDS | capi.AF_REVERSE_GRAPH | capi.AF_KEEP_RESULTS)
+    b.count(remove_nonuniq=True, bad_align_frac=0.8)
+    res, ops, _, sup, _ = b.download_all(want_table=False)
+    got = capi.results_to_dicts(res, ops)
+    assert [1 if f & 1 else (2 if f & 4 else 0) for f in flags] == [1, 1, 1, 1, 1, 2]
+    for g, r, (pos, cigar, score, rev) in zip(got, res, want):
+        assert int(r["status"]) & capi.STATUS_KMER_ALIGNER
+        assert (g["graph_pos"], g["cigar"], g["score"], g["returned_reverse"]) == (pos, cigar, score, rev)
+    assert all(int(s) == 1 for s in sup["status"][:5])
+    w = checker.align_batch(nodes, edges, reads[5:])[0]
+    assert not (int(res[5]["status"]) & capi.STATUS_KMER_ALIGNER)
+    assert all(got[5][k] == w[k] for k in ("graph_pos", "score", "mapq", "unique", "returned_reverse", "cigar")), (got[5], w)
+    b.close()
+    G.close()

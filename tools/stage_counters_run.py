@@ -1,11 +1,12 @@
 """One pass of every kernel north_star names besides the fill / traceback -- the seed stages (path, k-mer), the klib stage's five
 kernels, the count path (support + fragment kernels) and the cascade's hand-over kernels -- on config-2 reads, for a rocprofv3
 --pmc / --kernel-trace collection (tools/stage_counters.sh).  Usage: python tools/stage_counters_run.py [n_reads]"""
+import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from paragraph_amd import capi, synth  # noqa: E402
 
 

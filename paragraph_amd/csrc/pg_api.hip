@@ -1509,13 +1509,28 @@ __global__ void pg_group_list_kernel(
     uint32_t n, const uint8_t* __restrict__ active, const uint32_t* __restrict__ group_of_read, const uint32_t* __restrict__ group_base,
     uint32_t* group_count, uint32_t* list)
 {
+    // One atomic per (wavefront, group), not per read: reads arrive site after site, so the lanes of a wavefront mostly share
+    // ONE group -- a million reads of one graph were a million atomics on one address (1.8 ms per 200 k reads,
+    // profiles/r05_stage_counters.json); the lanes of a group take consecutive slots behind the leader's base.
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || (active && !active[i]))  // (no mask: every read is active)
-        return;
-    const uint32_t g = group_of_read[i];
-    if (g == PG_NONE)
-        return;
-    list[group_base[g] + atomicAdd(&group_count[g], 1u)] = i;
+    uint32_t g = PG_NONE;
+    if (i < n && (!active || active[i]))  // (no mask: every read is active)
+        g = group_of_read[i];
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned long long todo = __ballot(g != PG_NONE);
+    while (todo)
+    {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t g0 = (uint32_t)__shfl((int)g, leader, 64);
+        const unsigned long long same = __ballot(g == g0) & todo;
+        uint32_t base = 0;
+        if ((int)lane == leader)
+            base = atomicAdd(&group_count[g0], (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if ((same >> lane) & 1ull)
+            list[group_base[g0] + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = i;
+        todo &= ~same;
+    }
 }
 
 __global__ void pg_build_items_kernel(uint32_t n_pairs, uint32_t n_segments, const PgPlanSegment* __restrict__ seg, const uint32_t* __restrict__ list, PgWorkItem* items)

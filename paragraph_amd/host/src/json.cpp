@@ -2,6 +2,7 @@
 #include "common/Json.hh"
 
 #include <cerrno>
+#include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -278,16 +279,95 @@ void real(std::string& out, double d)
         out += "null";  // what jsoncpp's writer emits without useSpecialFloats
         return;
     }
-    char buf[40];
-    for (int prec = 15; prec <= 17; ++prec)
+    // The text is printf's "%.{p}g" for the smallest p in 15, 16, 17 that reads back as the same double (what a jsoncpp build
+    // writes), plus ".0" where that leaves a bare integer.  Made without the three snprintf / strtod rounds: the shortest digit
+    // string that reads back (std::to_chars) has n <= 17 digits, the p-digit rounding for n <= p is that string padded with zeros
+    // (which %g strips), so p = max(15, n) and only %g's choice of notation is left: scientific iff the decimal exponent
+    // X < -4 or X >= p.  (A genotype document holds some sixty doubles; this was most of the time of writing it.)
+    if (d != 0.0 && std::fabs(d) < 2.2250738585072014e-308)
     {
-        snprintf(buf, sizeof buf, "%.*g", prec, d);
-        if (strtod(buf, nullptr) == d)
-            break;
+        // subnormal numbers carry fewer than 15 significant digits: the p-digit rounding is then NOT the shortest string padded
+        // with zeros -- these (never seen in a document) take the literal route
+        char slow[40];
+        for (int prec = 15; prec <= 17; ++prec)
+        {
+            snprintf(slow, sizeof slow, "%.*g", prec, d);
+            if (strtod(slow, nullptr) == d)
+                break;
+        }
+        out += slow;
+        return;
     }
-    out += buf;
-    if (!strpbrk(buf, ".eEn"))
-        out += ".0";
+    char sci[40];
+    const auto conv = std::to_chars(sci, sci + sizeof sci, d, std::chars_format::scientific);
+    // "[-]d[.ddd]e[+-]XX"
+    const char* p = sci;
+    const bool negative = *p == '-';
+    if (negative)
+        ++p;
+    char digits[24];
+    int n = 0;
+    for (; p < conv.ptr && *p != 'e'; ++p)
+        if (*p != '.')
+            digits[n++] = *p;
+    int X = 0;
+    {
+        ++p;  // 'e'
+        const bool eneg = *p == '-';
+        ++p;
+        for (; p < conv.ptr; ++p)
+            X = X * 10 + (*p - '0');
+        if (eneg)
+            X = -X;
+    }
+    const int P = n > 15 ? n : 15;
+    char buf[48];
+    char* w = buf;
+    if (negative)
+        *w++ = '-';
+    if (X < -4 || X >= P)
+    {
+        *w++ = digits[0];
+        if (n > 1)
+        {
+            *w++ = '.';
+            for (int i = 1; i < n; ++i)
+                *w++ = digits[i];
+        }
+        *w++ = 'e';
+        *w++ = X < 0 ? '-' : '+';
+        const int ax = X < 0 ? -X : X;
+        if (ax >= 100)
+            *w++ = (char)('0' + ax / 100);
+        *w++ = (char)('0' + (ax / 10) % 10);
+        *w++ = (char)('0' + ax % 10);
+    }
+    else if (X < 0)
+    {
+        *w++ = '0';
+        *w++ = '.';
+        for (int i = -1; i > X; --i)
+            *w++ = '0';
+        for (int i = 0; i < n; ++i)
+            *w++ = digits[i];
+    }
+    else
+    {
+        for (int i = 0; i <= X; ++i)
+            *w++ = i < n ? digits[i] : '0';
+        if (n > X + 1)
+        {
+            *w++ = '.';
+            for (int i = X + 1; i < n; ++i)
+                *w++ = digits[i];
+        }
+        else
+        {
+            *w++ = '.';
+            *w++ = '0';
+        }
+    }
+    out.append(buf, (size_t)(w - buf));
 }
 }  // namespace
 

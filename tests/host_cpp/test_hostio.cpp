@@ -62,6 +62,79 @@ static int g_failures = 0;
         }                                                                            \
     } while (0)
 
+// what the writer's numbers must equal: printf's "%.{p}g" for the smallest p in 15, 16, 17 that reads back, ".0" after a bare integer
+static std::string printfReal(double d)
+{
+    char buf[40];
+    for (int prec = 15; prec <= 17; ++prec)
+    {
+        snprintf(buf, sizeof buf, "%.*g", prec, d);
+        if (strtod(buf, nullptr) == d)
+            break;
+    }
+    std::string out = buf;
+    if (!strpbrk(buf, ".eEn"))
+        out += ".0";
+    return out;
+}
+
+static void testJsonNumbers()
+{
+    // the writer makes its digits with std::to_chars and lays them out by %g's rule: every kind of double against the printf loop
+    uint64_t state = 88172645463325252ull;
+    auto next = [&]() {
+        state ^= state << 13;
+        state ^= state >> 7;
+        state ^= state << 17;
+        return state;
+    };
+    size_t bad = 0, n = 0;
+    auto check = [&](double d) {
+        if (std::isnan(d) || std::isinf(d))
+            return;
+        ++n;
+        if (Json(d).dump() != printfReal(d) && ++bad < 5)
+            std::cerr << "number " << printfReal(d) << " written as " << Json(d).dump() << "\n";
+    };
+    for (int i = 0; i < 300000; ++i)
+    {
+        const uint64_t u = next();
+        double d;
+        memcpy(&d, &u, 8);
+        check(d);  // any bit pattern: every magnitude, subnormals included
+        const double f = std::ldexp((double)(next() >> 11), -53);
+        check(f);
+        check(-1000.0 * f);
+        check(f * 1e-7);
+        check(std::log(f + 1e-300));  // (log-likelihoods)
+        check((double)(int64_t)(next() % 2000000000000ull) / (double)(1 + next() % 100000));
+    }
+    for (int e = -320; e <= 308; ++e)
+    {
+        const double d = std::pow(10.0, e);
+        for (int k = -3; k <= 3; ++k)
+        {
+            double x = d;
+            for (int s = 0; s < std::abs(k); ++s)
+                x = std::nextafter(x, k < 0 ? 0.0 : INFINITY);
+            check(x);
+            check(-x);
+        }
+        check(d * 5);
+        check(d * 9.999999999999999);
+    }
+    for (int64_t v = -20000; v <= 20000; ++v)
+    {
+        check((double)v);
+        check(v / 8.0);
+        check(v / 1000.0);
+    }
+    for (double v : { 0.0, -0.0, 1e15, 1e16, 1e17, 123456789012345678.0, 99999999999999.9, 999999999999999.0, 9999999999999998.0, 0.0001, 0.00001,
+                      0.00012345, 5e-324, 1.7976931348623157e308, 100000.0, 0.1, 1.0 / 3.0 })
+        check(v);
+    CHECK(bad == 0 && n > 1500000);
+}
+
 static void testJson()
 {
     const Json v = Json::parse(R"({"b": [1, -2, 3.5, 1e3, true, false, null], "a": {"s": "x\"\\\né😀", "big": 18446744073709551615}})");
@@ -1007,6 +1080,7 @@ int main(int argc, char** argv)
     const std::string dir = argv[1];
     const std::pair<const char*, std::function<void()>> tests[] = {
         { "json", testJson },
+        { "json numbers", testJsonNumbers },
         { "inflate", testInflate },
         { "coordinates", testCoordinates },
         { "fasta", [&] { testFasta(dir); } },

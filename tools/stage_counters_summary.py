@@ -19,7 +19,7 @@ SIMDS = 1024
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").strip()
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
 
 
 def last_values(path):

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstring>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -364,79 +365,162 @@ template <typename T> static hipError_t up(const std::vector<T>& v, T** d, hipSt
 
 namespace
 {
-struct PathRec
+// One length-k path of a graph, as the enumeration meets it: hash of its characters, where it starts and ends, its nodes
+// (in occ_pool).  No strings, no maps: a site's graph has ~700 of these, and a std::unordered_map<std::string, {count, path}> cost
+// three allocations for each of them -- 100+ us of host time per site, more than everything else `paragraph`'s default cascade
+// adds to a batch (profiles/r05_e2e_phases.json).
+struct KmerOcc
 {
-    uint32_t start, end;
-    std::vector<uint32_t> nodes;
+    uint64_t hash;
+    uint32_t start, end, pool_off, n_nodes;
 };
-typedef std::unordered_map<std::string, std::pair<uint32_t, PathRec>> KmerMap;  // sequence -> (count, first path)
 
-// every length-k path of graph g, depth-first = extendPathEnd (PathOperations.cpp:70-101), KmerIndex.cpp:76-99
-void enumerate_kmers(const pg_graphs* G, const std::vector<uint32_t>& succ_off, const std::vector<uint32_t>& succ, uint32_t g, uint32_t k,
-                     KmerMap& idx)
+struct KmerEnumerator
 {
-    const std::string& raw = G->h_seq_raw;
-    const std::vector<uint32_t>& noff = G->h_nodeseq_off;
-    const uint32_t nb = G->h_node_off[g], ne = G->h_node_off[g + 1];
+    const pg_graphs* G;
+    const std::vector<uint32_t>& succ_off;
+    const std::vector<uint32_t>& succ;
+    uint32_t nb, k;
+    std::vector<KmerOcc>& occ;
+    std::vector<uint32_t>& occ_pool;
     std::vector<uint32_t> nl;
-    std::string seq;
-    struct Rec
+
+    const char* node_chars(uint32_t node) const { return G->h_seq_raw.data() + G->h_nodeseq_off[nb + node]; }
+    static uint64_t extend(uint64_t h, const char* s, uint32_t n)
     {
-        static void go(const pg_graphs* G, const std::vector<uint32_t>& succ_off, const std::vector<uint32_t>& succ,
-                       const std::string& raw, const std::vector<uint32_t>& noff, uint32_t nb, uint32_t k,
-                       std::vector<uint32_t>& nl, std::string& seq, uint32_t start, uint32_t pos, KmerMap& idx)
+        for (uint32_t c = 0; c < n; ++c)
+            h = h * HASH_B + (uint64_t)(uint8_t)s[c] + 1;
+        return h;
+    }
+    void leaf(uint64_t h, uint32_t start, uint32_t end)
+    {
+        occ.push_back(KmerOcc{ h ? h : 1, start, end, (uint32_t)occ_pool.size(), (uint32_t)nl.size() });
+        occ_pool.insert(occ_pool.end(), nl.begin(), nl.end());
+    }
+    // depth-first = extendPathEnd (PathOperations.cpp:70-101): `have` characters hashed into h so far, now at `pos` of nl.back()
+    void go(uint64_t h, uint32_t have, uint32_t start, uint32_t pos)
+    {
+        const uint32_t node = nl.back();
+        const uint32_t room = G->h_node_len[nb + node] - pos, need = k - have;
+        if (need <= room)
         {
-            const uint32_t node = nl.back();
+            leaf(extend(h, node_chars(node) + pos, need), start, pos + need - 1);
+            return;
+        }
+        h = extend(h, node_chars(node) + pos, room);
+        for (uint32_t s = succ_off[nb + node]; s < succ_off[nb + node + 1]; ++s)
+        {
+            nl.push_back(succ[s]);
+            go(h, have + room, start, 0);
+            nl.pop_back();
+        }
+    }
+    // every length-k path of the graph in the reference's order (KmerIndex.cpp:76-99: node by node, position by position).  The
+    // k-mers that lie inside one node -- most of them -- roll: h' = (h - (c_out + 1) B^(k-1)) B + c_in + 1.
+    void run(uint32_t n_nodes)
+    {
+        uint64_t pow_k1 = 1;
+        for (uint32_t i = 1; i < k; ++i)
+            pow_k1 *= HASH_B;
+        for (uint32_t node = 0; node < n_nodes; ++node)
+        {
             const uint32_t len = G->h_node_len[nb + node];
-            const uint32_t need = k - (uint32_t)seq.size();
-            const uint32_t room = len - pos;
-            if (need <= room)
+            const char* s = node_chars(node);
+            uint64_t h = 0;
+            bool rolling = false;
+            for (uint32_t pos = 0; pos < len; ++pos)
             {
-                const size_t before = seq.size();
-                seq.append(raw, noff[nb + node] + pos, need);
-                auto it = idx.find(seq);
-                if (it == idx.end())
-                    idx.emplace(seq, std::make_pair(1u, PathRec{ start, pos + need - 1, nl }));
+                nl.assign(1, node);
+                if (pos + k <= len)
+                {
+                    if (!rolling)
+                    {
+                        h = extend(0, s + pos, k);
+                        rolling = true;
+                    }
+                    else
+                        h = (h - ((uint64_t)(uint8_t)s[pos - 1] + 1) * pow_k1) * HASH_B + (uint64_t)(uint8_t)s[pos + k - 1] + 1;
+                    leaf(h, pos, pos + k - 1);
+                }
                 else
-                    it->second.first++;
-                seq.resize(before);
-                return;
+                    go(0, 0, pos, pos);
             }
-            const size_t before = seq.size();
-            seq.append(raw, noff[nb + node] + pos, room);
-            for (uint32_t s = succ_off[nb + node]; s < succ_off[nb + node + 1]; ++s)
-            {
-                nl.push_back(succ[s]);
-                go(G, succ_off, succ, raw, noff, nb, k, nl, seq, start, 0, idx);
-                nl.pop_back();
-            }
-            seq.resize(before);
         }
-    };
-    for (uint32_t node = 0; node < ne - nb; ++node)
-        for (uint32_t pos = 0; pos < G->h_node_len[nb + node]; ++pos)
-        {
-            nl.assign(1, node);
-            seq.clear();
-            Rec::go(G, succ_off, succ, raw, noff, nb, k, nl, seq, pos, pos, idx);
-        }
+    }
+};
+
+// the k characters of an occurrence (for telling a repeated sequence from a 64-bit hash collision)
+void occ_chars(const pg_graphs* G, uint32_t nb, const KmerOcc& o, const std::vector<uint32_t>& occ_pool, uint32_t k, char* out)
+{
+    uint32_t got = 0;
+    for (uint32_t i = 0; i < o.n_nodes && got < k; ++i)
+    {
+        const uint32_t node = occ_pool[o.pool_off + i];
+        const uint32_t from = i == 0 ? o.start : 0, len = G->h_node_len[nb + node];
+        const uint32_t take = std::min(k - got, len - from);
+        memcpy(out + got, G->h_seq_raw.data() + G->h_nodeseq_off[nb + node] + from, take);
+        got += take;
+    }
 }
 
-// KmerIndex::Impl::updateKmerCounts (KmerIndex.cpp:118-141): unique k-mers per node / per edge of graph g
-void unique_counts(const KmerMap& idx, uint32_t n_nodes, std::vector<uint32_t>& node_cnt, std::unordered_map<uint64_t, uint32_t>& edge_cnt)
+// The graph's table, filled in enumeration order: the first path with a sequence owns the entry (graphtools::KmerIndex keeps
+// every path; only the first and the count are ever read), later ones count up.  false = two different sequences with one hash.
+bool build_table(const pg_graphs* G, uint32_t nb, uint32_t k, const std::vector<KmerOcc>& occ, const std::vector<uint32_t>& occ_pool,
+                 std::vector<KmerEntry>& table, size_t tab_off, uint32_t cap, std::vector<uint32_t>& pool, std::vector<uint32_t>& first_occ)
+{
+    first_occ.assign(cap, 0xFFFFFFFFu);
+    std::vector<char> a(k), b(k);
+    for (uint32_t oi = 0; oi < (uint32_t)occ.size(); ++oi)
+    {
+        const KmerOcc& o = occ[oi];
+        uint32_t slot = (uint32_t)(o.hash >> 20) & (cap - 1);
+        for (;;)
+        {
+            KmerEntry& e = table[tab_off + slot];
+            if (e.hash == 0)
+            {
+                e.hash = o.hash;
+                e.count = 1;
+                e.start_pos = o.start;
+                e.end_pos = o.end;
+                e.n_nodes = o.n_nodes;
+                e.pool_off = (uint32_t)pool.size();
+                pool.insert(pool.end(), occ_pool.begin() + o.pool_off, occ_pool.begin() + o.pool_off + o.n_nodes);
+                first_occ[slot] = oi;
+                break;
+            }
+            if (e.hash == o.hash)
+            {
+                occ_chars(G, nb, occ[first_occ[slot]], occ_pool, k, a.data());
+                occ_chars(G, nb, o, occ_pool, k, b.data());
+                if (memcmp(a.data(), b.data(), k) != 0)
+                    return false;
+                ++e.count;
+                break;
+            }
+            slot = (slot + 1) & (cap - 1);
+        }
+    }
+    return true;
+}
+
+// KmerIndex::Impl::updateKmerCounts (KmerIndex.cpp:118-141): unique k-mers per node / per edge, from the graph's table
+void unique_counts(const std::vector<KmerEntry>& table, size_t tab_off, uint32_t cap, const std::vector<uint32_t>& pool, uint32_t n_nodes,
+                   std::vector<uint32_t>& node_cnt, std::unordered_map<uint64_t, uint32_t>* edge_cnt)
 {
     node_cnt.assign(n_nodes, 0);
-    edge_cnt.clear();
-    for (auto const& kv : idx)
+    if (edge_cnt)
+        edge_cnt->clear();
+    for (uint32_t s = 0; s < cap; ++s)
     {
-        if (kv.second.first != 1)
+        const KmerEntry& e = table[tab_off + s];
+        if (e.hash == 0 || e.count != 1)
             continue;
-        const std::vector<uint32_t>& nodes = kv.second.second.nodes;
-        for (size_t i = 0; i < nodes.size(); ++i)
+        for (uint32_t i = 0; i < e.n_nodes; ++i)
         {
-            node_cnt[nodes[i]] += 1;
-            if (i)
-                edge_cnt[((uint64_t)nodes[i - 1] << 32) | nodes[i]] += 1;
+            node_cnt[pool[e.pool_off + i]] += 1;
+            if (i && edge_cnt)
+                (*edge_cnt)[((uint64_t)pool[e.pool_off + i - 1] << 32) | pool[e.pool_off + i]] += 1;
         }
     }
 }
@@ -471,17 +555,44 @@ pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32
     std::vector<uint32_t> h_k(G->n_graphs, 0);
     const std::string& raw = G->h_seq_raw;
     const std::vector<uint32_t>& noff = G->h_nodeseq_off;
+    std::vector<KmerOcc> occ;
+    std::vector<uint32_t> occ_pool, first_occ;
     for (uint32_t g = 0; g < G->n_graphs; ++g)
     {
         const uint32_t nb = G->h_node_off[g], ne = G->h_node_off[g + 1];
-        KmerMap idx;
         std::vector<uint32_t> node_cnt;
         std::unordered_map<uint64_t, uint32_t> edge_cnt;
+        const size_t tab_off = table.size(), pool_mark = pool.size();
+        uint32_t cap = 0;
+        // the table of graph g for k-mers of length kk, appended to `table` / `pool` (dropped again when the length is only tried)
+        auto make = [&](uint32_t kk, bool want_edges) -> int {
+            table.resize(tab_off);
+            pool.resize(pool_mark);
+            occ.clear();
+            occ_pool.clear();
+            KmerEnumerator en{ G, succ_off, succ, nb, kk, occ, occ_pool, {} };
+            en.run(ne - nb);
+            cap = 4;
+            while (cap < 2 * occ.size())
+                cap *= 2;
+            if (occ.empty())
+            {
+                cap = 0;
+                node_cnt.assign(ne - nb, 0);
+                edge_cnt.clear();
+                return 0;
+            }
+            table.resize(tab_off + cap, KmerEntry{});
+            if (!build_table(G, nb, kk, occ, occ_pool, table, tab_off, cap, pool, first_occ))
+                return -1;
+            unique_counts(table, tab_off, cap, pool, ne - nb, node_cnt, want_edges ? &edge_cnt : nullptr);
+            return 0;
+        };
         int32_t k = k_per_graph[g];
         if (k > 0)
         {
-            enumerate_kmers(G, succ_off, succ, g, (uint32_t)k, idx);
-            unique_counts(idx, ne - nb, node_cnt, edge_cnt);
+            if (make((uint32_t)k, false) != 0)
+                return pg_fail(ctx, PG_ERR_UNSUPPORTED, "64-bit k-mer hash collision inside one graph");
         }
         else
         {
@@ -491,9 +602,8 @@ pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32
             k = -1;
             for (int32_t kk = 10; kk < 64 && k < 0; ++kk)
             {
-                idx.clear();
-                enumerate_kmers(G, succ_off, succ, g, (uint32_t)kk, idx);
-                unique_counts(idx, ne - nb, node_cnt, edge_cnt);
+                if (make((uint32_t)kk, true) != 0)
+                    return pg_fail(ctx, PG_ERR_UNSUPPORTED, "64-bit k-mer hash collision inside one graph");
                 bool any_below = false;
                 for (uint32_t node = 0; node < ne - nb && !any_below; ++node)
                 {
@@ -521,40 +631,8 @@ pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32
         gd[g].pow_k1 = 1;
         for (int32_t i = 1; i < k; ++i)
             gd[g].pow_k1 *= HASH_B;
-        gd[g].tab_off = table.size();
-        if (idx.empty())
-        {
-            gd[g].tab_mask = 0xFFFFFFFFu;
-            continue;
-        }
-        uint32_t cap = 4;
-        while (cap < 2 * idx.size())
-            cap *= 2;
-        gd[g].tab_mask = cap - 1;
-        table.resize(table.size() + cap, KmerEntry{});
-        for (auto const& kv : idx)
-        {
-            const uint64_t h = hash_str(kv.first.data(), (uint32_t)k);
-            uint32_t slot = (uint32_t)(h >> 20) & (cap - 1);
-            for (;;)
-            {
-                KmerEntry& e = table[gd[g].tab_off + slot];
-                if (e.hash == 0)
-                {
-                    e.hash = h;
-                    e.count = kv.second.first;
-                    e.start_pos = kv.second.second.start;
-                    e.end_pos = kv.second.second.end;
-                    e.n_nodes = (uint32_t)kv.second.second.nodes.size();
-                    e.pool_off = (uint32_t)pool.size();
-                    pool.insert(pool.end(), kv.second.second.nodes.begin(), kv.second.second.nodes.end());
-                    break;
-                }
-                if (e.hash == h)
-                    return pg_fail(ctx, PG_ERR_UNSUPPORTED, "64-bit k-mer hash collision inside one graph");
-                slot = (slot + 1) & (cap - 1);
-            }
-        }
+        gd[g].tab_off = tab_off;
+        gd[g].tab_mask = cap ? cap - 1 : 0xFFFFFFFFu;
     }
     pg_path_index* ix = new pg_path_index();
     ix->h_k = h_k;

@@ -43,6 +43,9 @@ def main():
         phases[m.group(1)][0] += float(m.group(2))
         phases[m.group(1)][1] += 1
     out = json.loads(p.stdout.strip().splitlines()[-1]) if p.stdout.strip() else {"error": p.stderr[-2000:]}
+    import resource
+    ru = resource.getrusage(resource.RUSAGE_CHILDREN)
+    out["cpu_s_both_passes_and_startup"] = ru.ru_utime + ru.ru_stime
     out["options"] = opts
     out["phase_lane_ms"] = {k: round(v[0], 1) for k, v in phases.items()}
     out["batches"] = max((v[1] for v in phases.values()), default=0)

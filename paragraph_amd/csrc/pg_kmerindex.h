@@ -52,9 +52,20 @@ struct pg_path_index
     std::vector<uint32_t> h_k;       // per graph
 };
 
+// the tables pg_build_kmer_index makes on the host before they go up
+struct PgKmerIndexHost
+{
+    std::vector<uint32_t> succ_off, succ, pool, h_k;
+    std::vector<PathGraphDev> gd;
+    std::vector<KmerEntry> table;
+    std::vector<uint8_t> node_uniq;
+};
+const char* pg_build_kmer_index_host(const pg_graphs* G, const std::vector<int32_t>& k_per_graph, PgKmerIndexHost& tables, bool want_node_uniq);  // NULL = fine
+
 // k_per_graph[g] > 0: that length; < 0: graphtools::findMinCoveringKmerLength(graph, -k, -k)
 // (GT!/src/graphalign/KmerIndexOperations.cpp:77-113; fails with PG_ERR_UNSUPPORTED when no length 10..63 covers).
-pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32_t>& k_per_graph, pg_path_index** out);
+// want_node_uniq: also mark the nodes that unique k-mers overlap (the KmerFilter reads that; the path stage does not)
+pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32_t>& k_per_graph, pg_path_index** out, bool want_node_uniq);
 
 // Looks the k characters q(pos..pos+k-1) up; true only for a k-mer with EXACTLY ONE path (characters verified, so a
 // 64-bit hash collision cannot fake a hit).  Q: callable int -> uint32_t raw character.

@@ -526,35 +526,45 @@ void unique_counts(const std::vector<KmerEntry>& table, size_t tab_off, uint32_t
 }
 }  // namespace
 
-pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32_t>& k_per_graph, pg_path_index** out)
+// The host half of pg_build_kmer_index (no device call: tools/ubench/kmer_index_host.cpp times it on a CPU)
+const char* pg_build_kmer_index_host(const pg_graphs* G, const std::vector<int32_t>& k_per_graph, PgKmerIndexHost& t, bool want_node_uniq)
 {
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t>& succ_off = t.succ_off;
+    std::vector<uint32_t>& succ = t.succ;
+    std::vector<PathGraphDev>& gd = t.gd;
+    std::vector<KmerEntry>& table = t.table;
+    std::vector<uint32_t>& pool = t.pool;
+    std::vector<uint8_t>& node_uniq = t.node_uniq;
+    std::vector<uint32_t>& h_k = t.h_k;
     const uint32_t n_total = (uint32_t)G->h_node_len.size();
-    // successor CSR (set-wide node numbering, graph-local ids as values, ascending)
-    std::vector<uint32_t> succ_off(n_total + 1, 0), succ;
+    // successor CSR (set-wide node numbering, graph-local ids as values, ascending): counting sort over the predecessor CSR --
+    // a node's successors come out ascending because the nodes are visited in ascending order
+    succ_off.assign(n_total + 1, 0);
+    succ.assign(G->h_pred.size(), 0);
+    for (uint32_t g = 0; g < G->n_graphs; ++g)
     {
-        std::vector<std::vector<uint32_t>> sl(n_total);
+        const uint32_t nb = G->h_node_off[g], ne = G->h_node_off[g + 1];
+        for (uint32_t node = nb; node < ne; ++node)
+            for (uint32_t q = G->h_pred_off[node]; q < G->h_pred_off[node + 1]; ++q)
+                ++succ_off[nb + G->h_pred[q] + 1];
+    }
+    for (uint32_t i = 0; i < n_total; ++i)
+        succ_off[i + 1] += succ_off[i];
+    {
+        std::vector<uint32_t> fill(succ_off.begin(), succ_off.end() - 1);
         for (uint32_t g = 0; g < G->n_graphs; ++g)
         {
             const uint32_t nb = G->h_node_off[g], ne = G->h_node_off[g + 1];
             for (uint32_t node = nb; node < ne; ++node)
                 for (uint32_t q = G->h_pred_off[node]; q < G->h_pred_off[node + 1]; ++q)
-                    sl[nb + G->h_pred[q]].push_back(node - nb);
-        }
-        for (uint32_t i = 0; i < n_total; ++i)
-        {
-            std::sort(sl[i].begin(), sl[i].end());
-            succ.insert(succ.end(), sl[i].begin(), sl[i].end());
-            succ_off[i + 1] = (uint32_t)succ.size();
+                    succ[fill[nb + G->h_pred[q]]++] = node - nb;
         }
     }
-    std::vector<PathGraphDev> gd(G->n_graphs);
-    std::vector<KmerEntry> table;
-    std::vector<uint32_t> pool;
-    std::vector<uint8_t> node_uniq(n_total, 0);
-    std::vector<uint32_t> h_k(G->n_graphs, 0);
-    const std::string& raw = G->h_seq_raw;
-    const std::vector<uint32_t>& noff = G->h_nodeseq_off;
+    gd.assign(G->n_graphs, PathGraphDev{});
+    table.clear();
+    pool.clear();
+    node_uniq.assign(n_total, 0);
+    h_k.assign(G->n_graphs, 0);
     std::vector<KmerOcc> occ;
     std::vector<uint32_t> occ_pool, first_occ;
     for (uint32_t g = 0; g < G->n_graphs; ++g)
@@ -585,14 +595,17 @@ pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32
             table.resize(tab_off + cap, KmerEntry{});
             if (!build_table(G, nb, kk, occ, occ_pool, table, tab_off, cap, pool, first_occ))
                 return -1;
-            unique_counts(table, tab_off, cap, pool, ne - nb, node_cnt, want_edges ? &edge_cnt : nullptr);
+            if (want_node_uniq || want_edges)
+                unique_counts(table, tab_off, cap, pool, ne - nb, node_cnt, want_edges ? &edge_cnt : nullptr);
+            else
+                node_cnt.assign(ne - nb, 0);  // (the path stage never asks which nodes have unique k-mers: that is the KmerFilter's)
             return 0;
         };
         int32_t k = k_per_graph[g];
         if (k > 0)
         {
             if (make((uint32_t)k, false) != 0)
-                return pg_fail(ctx, PG_ERR_UNSUPPORTED, "64-bit k-mer hash collision inside one graph");
+                return "64-bit k-mer hash collision inside one graph";
         }
         else
         {
@@ -603,7 +616,7 @@ pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32
             for (int32_t kk = 10; kk < 64 && k < 0; ++kk)
             {
                 if (make((uint32_t)kk, true) != 0)
-                    return pg_fail(ctx, PG_ERR_UNSUPPORTED, "64-bit k-mer hash collision inside one graph");
+                    return "64-bit k-mer hash collision inside one graph";
                 bool any_below = false;
                 for (uint32_t node = 0; node < ne - nb && !any_below; ++node)
                 {
@@ -620,7 +633,7 @@ pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32
                     k = kk;
             }
             if (k < 0)
-                return pg_fail(ctx, PG_ERR_UNSUPPORTED, "no k-mer length in 10..63 covers every node and edge with unique k-mers");
+                return "no k-mer length in 10..63 covers every node and edge with unique k-mers";
         }
         h_k[g] = (uint32_t)k;
         for (uint32_t node = 0; node < ne - nb; ++node)
@@ -634,6 +647,27 @@ pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32
         gd[g].tab_off = tab_off;
         gd[g].tab_mask = cap ? cap - 1 : 0xFFFFFFFFu;
     }
+    return nullptr;
+}
+
+pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32_t>& k_per_graph, pg_path_index** out, bool want_node_uniq)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // The tables are made in vectors this thread keeps from call to call: a batch's entry table is ~10 MB, and as a fresh vector
+    // it cost 58 us per graph in page faults and regrowth alone -- more than enumerating and hashing the k-mers (12 us) and
+    // filling the table (8 us) together (tools/ubench/kmer_index_host.cpp).  They are uploaded before this call returns.
+    static thread_local PgKmerIndexHost t;
+    if (const char* why = pg_build_kmer_index_host(G, k_per_graph, t, want_node_uniq))
+        return pg_fail(ctx, PG_ERR_UNSUPPORTED, why);
+    std::vector<uint32_t>& succ_off = t.succ_off;
+    std::vector<uint32_t>& succ = t.succ;
+    std::vector<PathGraphDev>& gd = t.gd;
+    std::vector<KmerEntry>& table = t.table;
+    std::vector<uint32_t>& pool = t.pool;
+    std::vector<uint8_t>& node_uniq = t.node_uniq;
+    std::vector<uint32_t>& h_k = t.h_k;
+    const std::string& raw = G->h_seq_raw;
+    const std::vector<uint32_t>& noff = G->h_nodeseq_off;
     pg_path_index* ix = new pg_path_index();
     ix->h_k = h_k;
     ix->k = 0;
@@ -672,7 +706,7 @@ extern "C" pg_status pg_graphs_build_path_index(pg_ctx* ctx, pg_graphs* G, uint3
     if (!ctx || !G || kmer_len == 0 || kmer_len > 250)
         return pg_fail(ctx, PG_ERR_INVALID, "pg_graphs_build_path_index: bad argument");
     pg_path_index* ix = nullptr;
-    const pg_status st = pg_build_kmer_index(ctx, G, std::vector<int32_t>(G->n_graphs, (int32_t)kmer_len), &ix);
+    const pg_status st = pg_build_kmer_index(ctx, G, std::vector<int32_t>(G->n_graphs, (int32_t)kmer_len), &ix, false);
     if (st != PG_OK)
         return st;
     ix->k = kmer_len;
@@ -697,7 +731,7 @@ extern "C" pg_status pg_graphs_build_filter_index(pg_ctx* ctx, pg_graphs* G, int
     if (!ctx || !G || kmer_len == 0 || kmer_len > 250)
         return pg_fail(ctx, PG_ERR_INVALID, "pg_graphs_build_filter_index: bad argument");
     pg_path_index* ix = nullptr;
-    const pg_status st = pg_build_kmer_index(ctx, G, std::vector<int32_t>(G->n_graphs, kmer_len), &ix);
+    const pg_status st = pg_build_kmer_index(ctx, G, std::vector<int32_t>(G->n_graphs, kmer_len), &ix, true);
     if (st != PG_OK)
         return st;
     if (kmer_len_of_graph)

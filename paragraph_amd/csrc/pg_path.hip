@@ -752,10 +752,16 @@ extern "C" pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* b)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const pg_path_index* ix = G->path_index;
     b->h_counters_valid = false;
-    HIP_TRY(ctx, pg_stage_begin(ctx, b));
-    HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
+    // The path stage runs on the SECOND stream (where the tracebacks and the count path run, one priority level up), not behind
+    // the fills queued on the main one: it is 0.2 ms of work per batch whose outcome -- after the count pass and the hand-over,
+    // both on this stream already -- decides what the batch's fills are.  Queued behind two dozen lanes' fills it came back
+    // after 10 ms, and a `paragraph`-default workflow (path + gssw) took two trips through the device queue per batch: 40 k
+    // sites/s against 74 k without the path stage (profiles/r05_e2e_phases.json).
+    const hipStream_t ps = ctx->stream2;
+    HIP_TRY(ctx, pg_stage_begin_on(ctx, b, ps));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ps));
     if (b->n_reads)
-        HIP_TRY(ctx, hipMemsetAsync(b->d_path_flags, 0, b->n_reads, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(b->d_path_flags, 0, b->n_reads, ps));
     PathArgs a{};
     a.n_reads = b->n_reads;
     a.k = ix->k;
@@ -779,10 +785,10 @@ extern "C" pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* b)
     a.active = b->has_active ? b->d_active : nullptr;
     if (b->n_reads)
     {
-        hipLaunchKernelGGL(pg_path_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL(pg_path_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ps, a);
         HIP_TRY(ctx, hipGetLastError());
     }
-    HIP_TRY(ctx, pg_stage_end(ctx, b));
+    HIP_TRY(ctx, pg_stage_end_on(ctx, b, ps));
     return PG_OK;
 }
 

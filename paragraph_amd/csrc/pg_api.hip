@@ -292,6 +292,7 @@ extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess
         || hipStreamCreateWithFlags(&ctx->stream_fill2, hipStreamNonBlocking) != hipSuccess
         || hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, side_prio) != hipSuccess
+        || hipStreamCreateWithPriority(&ctx->stream_seed, hipStreamNonBlocking, side_prio) != hipSuccess
         || hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, side_prio) != hipSuccess)
     {
         delete ctx;
@@ -331,6 +332,8 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
         (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream_fill2)
         (void)hipStreamSynchronize(ctx->stream_fill2);
+    if (ctx->stream_seed)
+        (void)hipStreamSynchronize(ctx->stream_seed);
     if (ctx->stream2)
         (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream_copy)
@@ -353,6 +356,8 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
         (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream_fill2)
         (void)hipStreamDestroy(ctx->stream_fill2);
+    if (ctx->stream_seed)
+        (void)hipStreamDestroy(ctx->stream_seed);
     if (ctx->stream2)
         (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream_copy)
@@ -377,6 +382,7 @@ extern "C" pg_status pg_ctx_sync(pg_ctx* ctx)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_fill2));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_seed));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     recycle_sync_events(ctx);
     return PG_OK;
@@ -440,6 +446,7 @@ extern "C" pg_status pg_ctx_sync_compute(pg_ctx* ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_fill2));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_seed));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     return PG_OK;
 }
@@ -487,7 +494,7 @@ hipError_t pg_stage_end_on(pg_ctx* ctx, pg_batch* b, hipStream_t s)
 {
     if (const pg_graphs* G = b->graphs)
     {
-        const int w = s == ctx->stream ? 0 : 1;
+        const int w = s == ctx->stream ? 0 : s == ctx->stream_seed ? 2 : 1;
         hipError_t e = hipSuccess;
         if (!G->ev_use[w])
             e = hipEventCreateWithFlags(&G->ev_use[w], hipEventDisableTiming);
@@ -874,7 +881,7 @@ extern "C" void pg_graphs_destroy(pg_ctx* ctx, pg_graphs* G)
     if (ctx)
         (void)hipSetDevice(ctx->device);
     // only the stages that used THIS graph set have to be over (other lanes' batches keep the streams busy all the time)
-    for (int w = 0; w < 2; ++w)
+    for (int w = 0; w < 3; ++w)
     {
         if (G->use_recorded[w])
             (void)hipEventSynchronize(G->ev_use[w]);
@@ -1392,6 +1399,7 @@ extern "C" pg_status pg_batch_upload(
     b->graphs = G;
     b->n_reads = n_reads;
     b->has_skipped = false;
+    b->seed_chain = false;
     b->fragments_set = false;
     b->has_active = false;
     b->h_counters_valid = false;
@@ -1633,7 +1641,7 @@ extern "C" pg_status pg_batch_retire_mapped(pg_ctx* ctx, pg_batch* b)
     // behind the count pass, on its stream: the next stage (main stream) waits for the batch's event as always.  The lists and
     // per-group counts the next plan is made from are produced HERE as well, so that the counts are on the host when this
     // stream reaches them -- not behind whatever fills of other batches are queued on the main stream.
-    hipStream_t cs = ctx->stream2;
+    hipStream_t cs = b->seed_chain ? ctx->stream_seed : ctx->stream2;
     HIP_TRY(ctx, pg_stage_begin_on(ctx, b, cs));
     if (!b->has_active && b->n_reads)
         HIP_TRY(ctx, hipMemsetAsync(b->d_active, 1, b->n_reads, cs));
@@ -1863,6 +1871,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
                     cap0 / 1073741824.0, ctx->ws_cap / 1073741824.0, b->chunks.size(), b->max_ws / 1073741824.0, ms);
     }
     b->h_counters_valid = false;
+    b->seed_chain = false;
     HIP_TRY(ctx, pg_stage_begin(ctx, b));
     {
         const pg_status ps = pg_batch_ensure_plan(ctx, b, ctx->stream);  // work items follow a device-side hand-over (no-op otherwise)

@@ -696,8 +696,13 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     if (!b->fragments_set)
         return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_count: call pg_batch_set_fragments first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // the count path runs behind the traceback on the second compute stream: the main stream stays free for the next batch's fill
-    hipStream_t cs = ctx->stream2;
+    // the count path runs behind the traceback on the second compute stream: the main stream stays free for the next batch's fill.
+    // The count pass behind a path stage (the filter chain of the cascade's first hand-over) follows that stage onto the seed
+    // stream -- when it counts into the batch's own table: a caller's table is ordered against the second stream
+    // (pg_ctx_count_record / pg_ctx_count_wait).
+    hipStream_t cs = (b->seed_chain && !d_counts) ? ctx->stream_seed : ctx->stream2;
+    if (cs != ctx->stream_seed)
+        b->seed_chain = false;
     HIP_TRY(ctx, pg_stage_begin_on(ctx, b, cs));
     const uint32_t n = b->n_reads;
     pg_count_layout lay;

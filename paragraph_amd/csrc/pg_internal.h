@@ -65,6 +65,10 @@ struct pg_ctx
     // still has its region to itself.
     uint64_t chunk_seq = 0;
     hipStream_t stream_fill2 = nullptr;
+    // The path stage and the hand-over chain behind it (its count pass, the retire kernel, the lists and counts of the next plan)
+    // run on a stream of their own, one priority level up like the second stream: on the main stream they would wait behind the
+    // fills of every batch queued before them, on the second stream behind tracebacks that wait for those fills.
+    hipStream_t stream_seed = nullptr;
     int fill_streams = 1;
     unsigned regions() const { return fill_streams == 2 ? 3u : 2u; }
     hipEvent_t region_free[3] = { nullptr, nullptr, nullptr };
@@ -95,8 +99,8 @@ struct pg_graphs
     uint32_t n_graphs = 0;
     // last stage queued on this graph set, per compute stream (main, second): pg_graphs_destroy waits for these two events
     // only -- not for whatever other batches have queued on the streams
-    mutable hipEvent_t ev_use[2] = { nullptr, nullptr };
-    mutable bool use_recorded[2] = { false, false };
+    mutable hipEvent_t ev_use[3] = { nullptr, nullptr, nullptr };  // (main stream, second stream, seed stream)
+    mutable bool use_recorded[3] = { false, false, false };
     std::vector<HostGraph> host;
     void* d_layout_block = nullptr;  // one allocation behind d_graphs .. d_seqchars (PgStagedUpload)
     void* d_count_block = nullptr;   // one allocation behind d_cnt_graphs .. d_in_mask
@@ -166,6 +170,8 @@ struct pg_batch
     std::vector<uint32_t> h_group_of_read;    // per read: its group, PG_NONE for empty reads and reads of the general path
     bool has_general_reads = false;           // some read of the batch takes the general path (then the host re-plans from the flags)
     bool plan_stale = false;                  // d_active changed on the device since the work items were made
+    bool seed_chain = false;                  // the batch's last stage ran on the seed stream (pg_batch_path_align): its count pass and
+                                              // hand-over follow it there
     bool cascade_uploaded = false;
     uint32_t* d_group_of_read2 = nullptr;     // [n_reads] group per read
     uint32_t* d_group_base = nullptr;         // [n_groups] list_base per group

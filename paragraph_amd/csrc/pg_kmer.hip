@@ -632,6 +632,7 @@ extern "C" pg_status pg_batch_kmer_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     pg_kmer_index* ix = G->kmer_index;
     const uint32_t words = (ix->max_path_len + 31) / 32 + 1;
     b->h_counters_valid = false;
+    b->seed_chain = false;
     HIP_TRY(ctx, pg_stage_begin(ctx, b));
     if (!(flags & PG_AF_KEEP_RESULTS) || flags == PG_AF_ALL)
         HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));

@@ -752,12 +752,11 @@ extern "C" pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* b)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const pg_path_index* ix = G->path_index;
     b->h_counters_valid = false;
-    // The path stage runs on the SECOND stream (where the tracebacks and the count path run, one priority level up), not behind
-    // the fills queued on the main one: it is 0.2 ms of work per batch whose outcome -- after the count pass and the hand-over,
-    // both on this stream already -- decides what the batch's fills are.  Queued behind two dozen lanes' fills it came back
-    // after 10 ms, and a `paragraph`-default workflow (path + gssw) took two trips through the device queue per batch: 40 k
-    // sites/s against 74 k without the path stage (profiles/r05_e2e_phases.json).
-    const hipStream_t ps = ctx->stream2;
+    // The path stage runs on the SEED stream (one priority level up, like the second stream), not behind the fills queued on the
+    // main one nor behind the tracebacks that wait for them on the second: it is 0.2 ms of work per batch whose outcome -- after
+    // the count pass and the hand-over, which follow it onto this stream -- decides what the batch's fills are.
+    const hipStream_t ps = ctx->stream_seed;
+    b->seed_chain = true;
     HIP_TRY(ctx, pg_stage_begin_on(ctx, b, ps));
     HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ps));
     if (b->n_reads)

@@ -405,15 +405,11 @@ pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* batch, const uint8_t* activ
 /* The same hand-over decided where the flags are -- on the device (CompositeAligner::alignRead, CompositeAligner.cpp:78-150: a
  * read the stage mapped and the filter chain accepted is done, the others go on to the next stage).  After a seed stage and
  * its pg_batch_count: active[i] &= !((stage flag & 1) && count-path status == MAPPED), one thread per read, queued behind the
- * count pass; no flags, supports or masks cross to the host.  The next stage that runs work items (pg_batch_klib_align,
- * pg_batch_align) re-makes them from the device's per-(read length class, graph) counts of active reads -- one download of a
- * few hundred words.  Asynchronous.  Results equal those of pg_batch_set_active with the mask a host loop would build. */
+ * count pass; the wavefront work items of the stages behind it (pg_batch_klib_align, pg_batch_align) are re-written on the
+ * device over the batch's full plan -- a group's active reads first, the pair slots left over EMPTY (their wavefronts return at
+ * once).  Nothing crosses to the host, no call waits.  Asynchronous.  Results equal those of pg_batch_set_active with the
+ * mask a host loop would build. */
 pg_status pg_batch_retire_mapped(pg_ctx* ctx, pg_batch* batch);
-/* Blocks until the per-graph counts of the batch's last pg_batch_retire_mapped are on the host (they are sent by the count
- * stream right behind the hand-over kernels).  Optional: the next stage that needs them waits for them itself.  Unlike the
- * stage calls this one may run while OTHER threads queue stages on the same context -- a workflow's lane calls it WITHOUT the
- * lock that serialises its stage calls, so that other lanes' batches fill the device while this one's counts travel. */
-pg_status pg_batch_await_hand_over(pg_ctx* ctx, pg_batch* batch);
 
 /* Renders "<node>[<len><op>...]..." for one read into buf (NUL-terminated); returns the string length
  * (which may be >= cap, in which case the output was truncated). Host-only helper. */

@@ -49,7 +49,7 @@ EXPORTS = [
     "pg_batch_kmer_align", "pg_graphs_build_klib_index", "pg_batch_klib_align", "pg_graphs_klib_error", "pg_graphs_klib_last_kernels", "pg_graphs_build_filter_index",
     "pg_host_alloc", "pg_host_free", "pg_host_register", "pg_host_unregister", "pg_counts_zero", "pg_ctx_sync_compute",
     "pg_render_cigars", "pg_ctx_native_stream", "pg_ctx_count_record", "pg_ctx_count_wait", "pg_ctx_set_fill_streams",
-    "pg_batch_retire_mapped", "pg_batch_result_sizes", "pg_batch_download_all", "pg_batch_await_hand_over",
+    "pg_batch_retire_mapped", "pg_batch_result_sizes", "pg_batch_download_all",
 ]
 
 
@@ -158,8 +158,6 @@ def load_library():
     L.pg_batch_set_active.argtypes = [vp, vp, vp]
     L.pg_batch_retire_mapped.restype = C.c_int32
     L.pg_batch_retire_mapped.argtypes = [vp, vp]
-    L.pg_batch_await_hand_over.restype = C.c_int32
-    L.pg_batch_await_hand_over.argtypes = [vp, vp]
     L.pg_batch_result_sizes.restype = C.c_int32
     L.pg_batch_result_sizes.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.pg_batch_download_all.restype = C.c_int32

@@ -991,10 +991,6 @@ extern "C" void pg_batch_destroy(pg_ctx* ctx, pg_batch* b)
     batch_free_device(b);
     if (b->h_counters)
         (void)hipHostFree(b->h_counters);
-    if (b->h_group_count)
-        (void)hipHostFree(b->h_group_count);
-    if (b->ev_counts)
-        (void)hipEventDestroy(b->ev_counts);
     if (b->ev_upload)
         (void)hipEventDestroy(b->ev_upload);
     if (b->ev_busy)
@@ -1082,7 +1078,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
         b->h_group_of_read.assign(n_reads, PG_NONE);
         b->has_general_reads = !b->gen_idx.empty();
         b->cascade_uploaded = false;
-        b->counts_pending = false;
+        b->full_plan_ready = false;
         for (size_t p0 = 0; p0 < keys.size();)
         {
             size_t q0 = p0;
@@ -1497,12 +1493,15 @@ extern "C" pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* b, const uint8_t
 // ----------------------------------------------------------------------------------------------------------------------
 // Device-resident hand-over between the stages of the cascade (CompositeAligner::alignRead, src/c++/lib/grm/
 // CompositeAligner.cpp:78-176: a read the stage mapped and the filter accepted is done, everything else goes on).
-// The decision is made where the flags are -- on the device -- and the next stage's work follows it without the reads'
-// flags, supports or an activity mask ever crossing to the host:
-//   pg_batch_retire_mapped   active[i] &= !((stage flag & 1) && count-path status == MAPPED), one thread per read
-//   pg_batch_ensure_plan     (at the next stage that runs work items) active reads listed per (variant, graph) group by
-//                            atomics, the per-GROUP counts downloaded (a few hundred words, one wait), chunks cut from
-//                            the counts by the same rule as plan_items, the work items written by a kernel
+// The decision is made where the flags are -- on the device -- and the next stage's work follows it without ANYTHING
+// crossing to the host, not even a count:
+//   * once per upload the host cuts the batch's FULL plan (every read active) into (group, chunk) segments -- a group is a run of
+//     reads of one (read-length class, graph) -- and uploads them: O(groups), no device information needed;
+//   * pg_batch_retire_mapped: active[i] &= !((stage flag & 1) && count-path status == MAPPED); the reads still active are listed
+//     group by group (one atomic per (wavefront, group)); the work items are re-written over the full plan's pair slots: the
+//     first ceil(count / 4) pairs of a group hold its active reads, the rest are EMPTY (read[0] == PG_NONE) -- the fill, klib
+//     and traceback wavefronts of an empty pair return at once.  The launches keep the full plan's grids and chunk cuts (an empty
+//     workgroup costs a dispatch, not a sweep).
 // ----------------------------------------------------------------------------------------------------------------------
 namespace
 {
@@ -1541,7 +1540,11 @@ __global__ void pg_group_list_kernel(
     }
 }
 
-__global__ void pg_build_items_kernel(uint32_t n_pairs, uint32_t n_segments, const PgPlanSegment* __restrict__ seg, const uint32_t* __restrict__ list, PgWorkItem* items)
+// pair slot p of the full plan: the group's active reads 4k .. 4k + 3 (k = the pair's rank in its group), PG_NONE beyond the
+// group's count of active reads; workspace offsets as the full plan cut them
+__global__ void pg_build_items_kernel(
+    uint32_t n_pairs, uint32_t n_segments, const PgPlanSegment* __restrict__ seg, const uint32_t* __restrict__ list,
+    const uint32_t* __restrict__ group_count, PgWorkItem* items)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs)
@@ -1557,6 +1560,7 @@ __global__ void pg_build_items_kernel(uint32_t n_pairs, uint32_t n_segments, con
     }
     const PgPlanSegment s = seg[lo];
     const uint32_t k = s.first_pair + (p - s.pair_begin);
+    const uint32_t count = group_count[s.group];
     PgWorkItem fw{}, rv{};
     fw.graph = rv.graph = s.graph;
     fw.dir = 0;
@@ -1564,7 +1568,7 @@ __global__ void pg_build_items_kernel(uint32_t n_pairs, uint32_t n_segments, con
     for (int j = 0; j < PG_GROUPS; ++j)
     {
         const uint32_t slot = 4u * k + (uint32_t)j;
-        fw.read[j] = rv.read[j] = slot < s.count ? list[s.list_base + slot] : PG_NONE;
+        fw.read[j] = rv.read[j] = slot < count ? list[s.list_base + slot] : PG_NONE;
     }
     const uint64_t base = s.ws_base + (uint64_t)(p - s.pair_begin) * s.need;
     fw.trace_off = base;
@@ -1576,13 +1580,147 @@ __global__ void pg_build_items_kernel(uint32_t n_pairs, uint32_t n_segments, con
 }
 }  // namespace
 
-// The active reads of every (variant, graph) group listed on the device (group after group, in no particular order inside a
-// group), on `stream`; with `want_counts` the per-group counts follow into page-locked host memory and b->ev_counts is recorded
-// behind them.  The group tables go up once per upload.
-static pg_status cascade_lists(pg_ctx* ctx, pg_batch* b, hipStream_t stream, const uint8_t* d_active, bool want_counts)
+// The batch's full plan (every read active) as (group, chunk) segments on the device, and b->chunks = its chunks: made once per
+// upload, on the host, from the groups' sizes alone -- plan_items' rule: equal chunks per variant, longest graph first in a chunk.
+static pg_status cascade_full_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream)
+{
+    if (b->full_plan_ready)
+        return PG_OK;
+    const pg_graphs* G = b->graphs;
+    const size_t n_groups = b->groups.size();
+    const uint64_t packed_limit = ctx->ws_limit - b->gen_reserve;
+    const uint64_t cap = packed_limit / ctx->regions();
+    std::vector<uint64_t> chunk_target(PG_VAR_WIDE + 33, 0);
+    {
+        std::vector<uint64_t> total(chunk_target.size(), 0), largest(chunk_target.size(), 0);
+        for (size_t g = 0; g < n_groups; ++g)
+        {
+            const uint64_t pairs = (b->groups[g].n_reads + PG_GROUPS - 1) / PG_GROUPS;
+            const uint64_t need = pair_need_of((int)b->groups[g].C, G->host[b->groups[g].graph]).need;
+            total[b->groups[g].C] += pairs * need;
+            largest[b->groups[g].C] = std::max(largest[b->groups[g].C], need);
+        }
+        for (size_t c = 0; c < total.size(); ++c)
+        {
+            if (!total[c])
+                continue;
+            if (largest[c] >= cap)
+            {
+                chunk_target[c] = cap;
+                continue;
+            }
+            const uint64_t room = cap - largest[c];
+            const uint64_t n_chunks = std::max<uint64_t>(1, (total[c] + room - 1) / room);
+            chunk_target[c] = std::min(cap, (total[c] + n_chunks - 1) / n_chunks + largest[c]);
+        }
+    }
+    std::vector<PgPlanSegment>& segs = b->h_segments;
+    segs.clear();
+    b->full_chunks.clear();
+    std::vector<uint64_t> seg_steps;
+    Chunk cur{};
+    bool open = false;
+    size_t chunk_seg0 = 0;
+    uint64_t max_ws = 0;
+    uint32_t next_pair = 0;
+    auto close_chunk = [&]() {
+        if (!open)
+            return;
+        // longest graph first (what runs in a launch's tail is short); regions keep the offsets they were given
+        std::vector<size_t> order(segs.size() - chunk_seg0);
+        for (size_t i = 0; i < order.size(); ++i)
+            order[i] = chunk_seg0 + i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return seg_steps[x] > seg_steps[y]; });
+        std::vector<PgPlanSegment> sorted;
+        std::vector<uint64_t> sorted_steps;
+        uint32_t at = cur.pair_begin;
+        for (size_t i : order)
+        {
+            PgPlanSegment sg = segs[i];
+            sg.pair_begin = at;
+            at += sg.n_pairs;
+            sorted.push_back(sg);
+            sorted_steps.push_back(seg_steps[i]);
+        }
+        std::copy(sorted.begin(), sorted.end(), segs.begin() + (std::ptrdiff_t)chunk_seg0);
+        std::copy(sorted_steps.begin(), sorted_steps.end(), seg_steps.begin() + (std::ptrdiff_t)chunk_seg0);
+        cur.pair_end = at;
+        b->full_chunks.push_back(cur);
+        max_ws = std::max(max_ws, cur.ws_bytes);
+        open = false;
+    };
+    for (size_t g = 0; g < n_groups; ++g)
+    {
+        const PgReadGroup& grp = b->groups[g];
+        uint32_t pairs_left = (grp.n_reads + PG_GROUPS - 1) / PG_GROUPS, first_pair = 0;
+        const int C = (int)grp.C;
+        const HostGraph& hg = G->host[grp.graph];
+        const PairNeed pn = pair_need_of(C, hg);
+        if (pn.need > cap)
+            return fail(ctx, PG_ERR_UNSUPPORTED, "workspace limit too small for one wavefront of this graph");
+        const uint64_t mean_len = grp.n_reads ? grp.sum_len / grp.n_reads : 0;
+        while (pairs_left)
+        {
+            if (open && (cur.C != C || cur.ws_bytes + pn.need > chunk_target[C]))
+                close_chunk();
+            if (!open)
+            {
+                cur = Chunk{};
+                cur.C = C;
+                cur.pair_begin = next_pair;
+                chunk_seg0 = segs.size();
+                open = true;
+            }
+            const uint64_t fit = std::max<uint64_t>(1, (chunk_target[C] - cur.ws_bytes) / pn.need);
+            const uint32_t take = (uint32_t)std::min<uint64_t>(pairs_left, fit);
+            PgPlanSegment sg{};
+            sg.pair_begin = next_pair;  // (re-assigned when the chunk closes)
+            sg.n_pairs = take;
+            sg.first_pair = first_pair;
+            sg.graph = grp.graph;
+            sg.list_base = grp.list_base;
+            sg.group = (uint32_t)g;
+            sg.ws_base = cur.ws_bytes;
+            sg.need = pn.need;
+            sg.trace_bytes = pn.trace_bytes;
+            sg.seed_bytes = pn.seed_bytes;
+            segs.push_back(sg);
+            seg_steps.push_back(pn.nsteps);
+            const uint64_t reads_here = std::min<uint64_t>((uint64_t)take * PG_GROUPS, grp.n_reads - (uint64_t)first_pair * PG_GROUPS);
+            cur.ws_bytes += (uint64_t)take * pn.need;
+            cur.trace_bytes += (uint64_t)take * pn.nsteps * 64 * pg_trace_lane_bytes(C);
+            cur.max_nodes = std::max(cur.max_nodes, hg.n_nodes);
+            cur.fills += 4 * reads_here;  // (of the full plan: what a launch is sized for, not what is left active; timing figures only)
+            cur.cells += 4 * reads_here * mean_len * hg.ncols;
+            next_pair += take;
+            first_pair += take;
+            pairs_left -= take;
+        }
+    }
+    close_chunk();
+    b->full_pairs = next_pair;
+    b->full_max_ws = max_ws;
+    if (segs.size() > b->cap_segments)
+    {
+        HIP_TRY(ctx, pg_batch_wait(ctx, b));
+        (void)pg_dev_free(b->d_segments);
+        b->cap_segments = segs.size() + segs.size() / 4 + 16;
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_segments, b->cap_segments * sizeof(PgPlanSegment)));
+    }
+    // (h_segments is the batch's: it stays until the next upload, the copy may run on)
+    if (!segs.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_segments, segs.data(), segs.size() * sizeof(PgPlanSegment), hipMemcpyHostToDevice, stream));
+    b->full_plan_ready = true;
+    return PG_OK;
+}
+
+// Lists of the active reads + the work items over the full plan's slots, all on `stream` (d_active: NULL = every read).
+static pg_status cascade_rebuild_items(pg_ctx* ctx, pg_batch* b, hipStream_t stream, const uint8_t* d_active)
 {
     const uint32_t n = b->n_reads;
     const size_t n_groups = b->groups.size();
+    b->chunks.clear();
+    b->n_pairs = 0;
     if (!n || !n_groups)
         return PG_OK;
     if (n_groups > b->cap_groups || n > b->cap_cascade_reads)
@@ -1609,27 +1747,23 @@ static pg_status cascade_lists(pg_ctx* ctx, pg_batch* b, hipStream_t stream, con
         HIP_TRY(ctx, hipMemcpyAsync(b->d_group_base, b->h_group_base.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         b->cascade_uploaded = true;
     }
+    const pg_status fp = cascade_full_plan(ctx, b, stream);
+    if (fp != PG_OK)
+        return fp;
     HIP_TRY(ctx, hipMemsetAsync(b->d_group_count, 0, n_groups * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(pg_group_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, d_active, b->d_group_of_read2, b->d_group_base,
                        b->d_group_count, b->d_active_list);
     HIP_TRY(ctx, hipGetLastError());
-    if (want_counts)
+    if (b->full_pairs)
     {
-        if (n_groups > b->cap_h_group_count)
-        {
-            if (b->h_group_count)
-                (void)hipHostFree(b->h_group_count);
-            b->h_group_count = nullptr;
-            void* p = nullptr;
-            HIP_TRY(ctx, hipHostMalloc(&p, (n_groups + n_groups / 4 + 64) * sizeof(uint32_t), hipHostMallocPortable));
-            b->h_group_count = (uint32_t*)p;
-            b->cap_h_group_count = n_groups + n_groups / 4 + 64;
-        }
-        if (!b->ev_counts)
-            HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_counts, hipEventDisableTiming));
-        HIP_TRY(ctx, hipMemcpyAsync(b->h_group_count, b->d_group_count, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(ctx, hipEventRecord(b->ev_counts, stream));
+        hipLaunchKernelGGL(pg_build_items_kernel, dim3((b->full_pairs + 255) / 256), dim3(256), 0, stream, b->full_pairs, (uint32_t)b->h_segments.size(),
+                           b->d_segments, b->d_active_list, b->d_group_count, b->d_items);
+        HIP_TRY(ctx, hipGetLastError());
     }
+    b->chunks = b->full_chunks;
+    b->n_pairs = b->full_pairs;
+    b->max_ws = b->full_max_ws;
+    b->plan_stale = false;
     return PG_OK;
 }
 
@@ -1638,41 +1772,26 @@ extern "C" pg_status pg_batch_retire_mapped(pg_ctx* ctx, pg_batch* b)
     if (!ctx || !b || !b->graphs || !b->d_support || !b->d_path_flags)
         return fail(ctx, PG_ERR_INVALID, "pg_batch_retire_mapped: a seed stage and pg_batch_count must have run");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // behind the count pass, on its stream: the next stage (main stream) waits for the batch's event as always.  The lists and
-    // per-group counts the next plan is made from are produced HERE as well, so that the counts are on the host when this
-    // stream reaches them -- not behind whatever fills of other batches are queued on the main stream.
+    // behind the count pass, on its stream (the seed stream behind a path stage): the next stage waits for the batch's event as
+    // always
     hipStream_t cs = b->seed_chain ? ctx->stream_seed : ctx->stream2;
     HIP_TRY(ctx, pg_stage_begin_on(ctx, b, cs));
     if (!b->has_active && b->n_reads)
         HIP_TRY(ctx, hipMemsetAsync(b->d_active, 1, b->n_reads, cs));
     b->has_active = true;
-    b->counts_pending = false;
+    b->plan_stale = true;
     if (b->n_reads)
     {
         hipLaunchKernelGGL(pg_retire_kernel, dim3((b->n_reads + 255) / 256), dim3(256), 0, cs, b->n_reads, b->d_path_flags, b->d_support, b->d_active);
         HIP_TRY(ctx, hipGetLastError());
-        if (!b->has_general_reads)
+        if (!b->has_general_reads)  // (a batch with general-path reads plans on the host from the downloaded flags: pg_batch_ensure_plan)
         {
-            const pg_status ls = cascade_lists(ctx, b, cs, b->d_active, true);
-            if (ls != PG_OK)
-                return ls;
-            b->counts_pending = true;
+            const pg_status rs = cascade_rebuild_items(ctx, b, cs, b->d_active);
+            if (rs != PG_OK)
+                return rs;
         }
     }
-    b->plan_stale = true;
     HIP_TRY(ctx, pg_stage_end_on(ctx, b, cs));
-    return PG_OK;
-}
-
-extern "C" pg_status pg_batch_await_hand_over(pg_ctx* ctx, pg_batch* b)
-{
-    if (!ctx || !b)
-        return PG_ERR_INVALID;
-    if (b->plan_stale && b->has_active && b->counts_pending)
-    {
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipEventSynchronize(b->ev_counts));
-    }
     return PG_OK;
 }
 
@@ -1680,176 +1799,19 @@ pg_status pg_batch_ensure_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream)
 {
     if (!b->plan_stale)
         return PG_OK;
-    const pg_graphs* G = b->graphs;
-    const uint32_t n = b->n_reads;
     if (b->has_general_reads)
     {
         // reads of the general path are planned one by one on the host: this (rare) batch fetches the flags and plans from them
         if (!b->has_active)
             return plan_items(ctx, b, nullptr, stream);
-        std::vector<uint8_t> active(n);
-        HIP_TRY(ctx, hipMemcpyAsync(active.data(), b->d_active, n, hipMemcpyDeviceToHost, stream));
+        std::vector<uint8_t> active(b->n_reads);
+        HIP_TRY(ctx, hipMemcpyAsync(active.data(), b->d_active, b->n_reads, hipMemcpyDeviceToHost, stream));
         HIP_TRY(ctx, hipStreamSynchronize(stream));
         return plan_items(ctx, b, active.data(), stream);
     }
-    const size_t n_groups = b->groups.size();
-    b->chunks.clear();
+    // pg_batch_set_active(NULL) after a hand-over: every read again, on the stage's own stream
     b->gen_idx.clear();
-    b->n_pairs = 0;
-    b->plan_stale = false;
-    if (!n || !n_groups)
-        return PG_OK;
-    std::vector<uint32_t> all_counts;
-    const uint32_t* counts = nullptr;
-    if (!b->has_active)
-    {
-        // every read is active again (pg_batch_set_active(NULL)): the counts are the groups' sizes, only the lists are made
-        const pg_status ls = cascade_lists(ctx, b, stream, nullptr, false);
-        if (ls != PG_OK)
-            return ls;
-        all_counts.resize(n_groups);
-        for (size_t g = 0; g < n_groups; ++g)
-            all_counts[g] = b->groups[g].n_reads;
-        counts = all_counts.data();
-    }
-    else
-    {
-        if (!b->counts_pending)
-            return fail(ctx, PG_ERR_INVALID, "pg_batch_ensure_plan: no counts for the batch's activity flags");
-        HIP_TRY(ctx, hipEventSynchronize(b->ev_counts));  // the ONE wait of the hand-over: a few hundred words, made on the count stream
-        counts = b->h_group_count;
-    }
-
-    // ---- chunks and segments from the counts: plan_items' rule (equal chunks per variant, longest graph first inside a chunk)
-    const uint64_t packed_limit = ctx->ws_limit - b->gen_reserve;
-    const uint64_t cap = packed_limit / ctx->regions();
-    std::vector<uint64_t> chunk_target(PG_VAR_WIDE + 33, 0);
-    {
-        std::vector<uint64_t> total(chunk_target.size(), 0), largest(chunk_target.size(), 0);
-        for (size_t g = 0; g < n_groups; ++g)
-        {
-            const uint64_t pairs = (counts[g] + PG_GROUPS - 1) / PG_GROUPS;
-            if (!pairs)
-                continue;
-            const uint64_t need = pair_need_of((int)b->groups[g].C, G->host[b->groups[g].graph]).need;
-            total[b->groups[g].C] += pairs * need;
-            largest[b->groups[g].C] = std::max(largest[b->groups[g].C], need);
-        }
-        for (size_t c = 0; c < total.size(); ++c)
-        {
-            if (!total[c])
-                continue;
-            if (largest[c] >= cap)
-            {
-                chunk_target[c] = cap;
-                continue;
-            }
-            const uint64_t room = cap - largest[c];
-            const uint64_t n_chunks = std::max<uint64_t>(1, (total[c] + room - 1) / room);
-            chunk_target[c] = std::min(cap, (total[c] + n_chunks - 1) / n_chunks + largest[c]);
-        }
-    }
-    std::vector<PgPlanSegment>& segs = b->h_segments;
-    segs.clear();
-    std::vector<uint64_t> seg_steps;
-    Chunk cur{};
-    bool open = false;
-    size_t chunk_seg0 = 0;
-    b->max_ws = 0;
-    uint32_t next_pair = 0;
-    auto close_chunk = [&]() {
-        if (!open)
-            return;
-        // longest graph first (what runs in a launch's tail is short); regions keep the offsets they were given
-        std::vector<size_t> order(segs.size() - chunk_seg0);
-        for (size_t i = 0; i < order.size(); ++i)
-            order[i] = chunk_seg0 + i;
-        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return seg_steps[x] > seg_steps[y]; });
-        std::vector<PgPlanSegment> sorted;
-        std::vector<uint64_t> sorted_steps;
-        uint32_t at = cur.pair_begin;
-        for (size_t i : order)
-        {
-            PgPlanSegment s = segs[i];
-            s.pair_begin = at;
-            at += s.n_pairs;
-            sorted.push_back(s);
-            sorted_steps.push_back(seg_steps[i]);
-        }
-        std::copy(sorted.begin(), sorted.end(), segs.begin() + (std::ptrdiff_t)chunk_seg0);
-        std::copy(sorted_steps.begin(), sorted_steps.end(), seg_steps.begin() + (std::ptrdiff_t)chunk_seg0);
-        cur.pair_end = at;
-        b->chunks.push_back(cur);
-        b->max_ws = std::max(b->max_ws, cur.ws_bytes);
-        open = false;
-    };
-    for (size_t g = 0; g < n_groups; ++g)
-    {
-        const PgReadGroup& grp = b->groups[g];
-        const uint32_t count = counts[g];
-        uint32_t pairs_left = (count + PG_GROUPS - 1) / PG_GROUPS, first_pair = 0;
-        if (!pairs_left)
-            continue;
-        const int C = (int)grp.C;
-        const HostGraph& hg = G->host[grp.graph];
-        const PairNeed pn = pair_need_of(C, hg);
-        if (pn.need > cap)
-            return fail(ctx, PG_ERR_UNSUPPORTED, "workspace limit too small for one wavefront of this graph");
-        const uint64_t mean_len = grp.n_reads ? grp.sum_len / grp.n_reads : 0;
-        while (pairs_left)
-        {
-            if (open && (cur.C != C || cur.ws_bytes + pn.need > chunk_target[C]))
-                close_chunk();
-            if (!open)
-            {
-                cur = Chunk{};
-                cur.C = C;
-                cur.pair_begin = next_pair;
-                chunk_seg0 = segs.size();
-                open = true;
-            }
-            const uint64_t fit = std::max<uint64_t>(1, (chunk_target[C] - cur.ws_bytes) / pn.need);
-            const uint32_t take = (uint32_t)std::min<uint64_t>(pairs_left, fit);
-            PgPlanSegment s{};
-            s.pair_begin = next_pair;  // (re-assigned when the chunk closes)
-            s.n_pairs = take;
-            s.first_pair = first_pair;
-            s.graph = grp.graph;
-            s.list_base = grp.list_base;
-            s.count = count;
-            s.ws_base = cur.ws_bytes;
-            s.need = pn.need;
-            s.trace_bytes = pn.trace_bytes;
-            s.seed_bytes = pn.seed_bytes;
-            segs.push_back(s);
-            seg_steps.push_back(pn.nsteps);
-            const uint64_t reads_here = std::min<uint64_t>((uint64_t)take * PG_GROUPS, count - (uint64_t)first_pair * PG_GROUPS);
-            cur.ws_bytes += (uint64_t)take * pn.need;
-            cur.trace_bytes += (uint64_t)take * pn.nsteps * 64 * pg_trace_lane_bytes(C);
-            cur.max_nodes = std::max(cur.max_nodes, hg.n_nodes);
-            cur.fills += 4 * reads_here;
-            cur.cells += 4 * reads_here * mean_len * hg.ncols;  // (the group's mean read length: a timing figure, not a result)
-            next_pair += take;
-            first_pair += take;
-            pairs_left -= take;
-        }
-    }
-    close_chunk();
-    b->n_pairs = next_pair;
-    if (!next_pair)
-        return PG_OK;
-    if (segs.size() > b->cap_segments)
-    {
-        (void)pg_dev_free(b->d_segments);
-        b->cap_segments = segs.size() + segs.size() / 4 + 16;
-        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_segments, b->cap_segments * sizeof(PgPlanSegment)));
-    }
-    // (h_segments is the batch's: it stays until the next plan, the copy may run on)
-    HIP_TRY(ctx, hipMemcpyAsync(b->d_segments, segs.data(), segs.size() * sizeof(PgPlanSegment), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(pg_build_items_kernel, dim3((next_pair + 255) / 256), dim3(256), 0, stream, next_pair, (uint32_t)segs.size(), b->d_segments,
-                       b->d_active_list, b->d_items);
-    HIP_TRY(ctx, hipGetLastError());
-    return PG_OK;
+    return cascade_rebuild_items(ctx, b, stream, b->has_active ? b->d_active : nullptr);
 }
 
 extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)

@@ -127,6 +127,10 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // items come in (forward graph, reversed graph) pairs: this instantiation takes the DIR member
     const uint32_t item_idx = a.item_begin + 2 * pair + DIR;
     const PgWorkItem* itp = a.items + item_idx;
+    // an EMPTY slot of a plan re-written by the cascade's hand-over (pg_batch_retire_mapped: a group's active reads come first,
+    // so the wavefront's first read says it all): nothing to fill, nothing the traceback will look at
+    if (itp->read[(int)half * GROUPS] == PG_NONE)
+        return;
     const uint32_t graph = itp->graph;
     const PgGraphDir gd = a.graphs[graph].dir[DIR];
     const uint32_t* __restrict__ smeta = a.colmeta + gd.meta_off;

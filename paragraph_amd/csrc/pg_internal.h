@@ -37,9 +37,9 @@ struct PgReadGroup
 };
 struct PgPlanSegment
 {
-    uint32_t pair_begin, n_pairs;  // item pairs [pair_begin, pair_begin + n_pairs) of the batch
-    uint32_t first_pair;           // ... are pairs first_pair.. of the group's active reads (four reads per pair)
-    uint32_t graph, list_base, count;
+    uint32_t pair_begin, n_pairs;  // pair slots [pair_begin, pair_begin + n_pairs) of the batch's full plan
+    uint32_t first_pair;           // ... are pairs first_pair.. of the group (four reads per pair, active reads first)
+    uint32_t graph, list_base, group;
     uint64_t ws_base, need, trace_bytes, seed_bytes;
 };
 
@@ -180,10 +180,10 @@ struct pg_batch
     PgPlanSegment* d_segments = nullptr;
     size_t cap_groups = 0, cap_cascade_reads = 0, cap_segments = 0;
     std::vector<uint32_t> h_group_base;       // (kept: the upload of the group tables reads it asynchronously)
-    uint32_t* h_group_count = nullptr;        // page-locked [cap_groups]: the counts, sent by the stream that made them
-    size_t cap_h_group_count = 0;
-    hipEvent_t ev_counts = nullptr;           // behind that copy
-    bool counts_pending = false;              // the lists + counts of the CURRENT d_active are made (pg_batch_retire_mapped)
+    bool full_plan_ready = false;             // the full plan's segments are on the device, full_chunks / full_pairs hold it
+    std::vector<Chunk> full_chunks;
+    uint32_t full_pairs = 0;
+    uint64_t full_max_ws = 0;
     std::vector<PgPlanSegment> h_segments;
     uint32_t* d_graph_of_read = nullptr;
     pg_read_support* d_support = nullptr;
@@ -222,8 +222,8 @@ hipError_t pg_stage_end(pg_ctx* ctx, pg_batch* b);
 hipError_t pg_stage_begin_on(pg_ctx* ctx, pg_batch* b, hipStream_t s);
 hipError_t pg_stage_end_on(pg_ctx* ctx, pg_batch* b, hipStream_t s);
 hipError_t pg_batch_wait(pg_ctx* ctx, pg_batch* b);
-// the work items follow d_active: re-made from the device's per-group counts when pg_batch_retire_mapped changed the flags
-// (called by the stages that run work items: the klib stage and the gssw stage), on `stream`
+// the work items follow d_active: pg_batch_retire_mapped re-writes them on the device; this is for the cases it leaves (a batch with
+// general-path reads, pg_batch_set_active(NULL) after a hand-over) -- called by the stages that run work items, on `stream`
 pg_status pg_batch_ensure_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream);
 
 

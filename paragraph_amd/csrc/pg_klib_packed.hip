@@ -210,6 +210,8 @@ __global__ __launch_bounds__(64) void pg_klib_local_kernel(KlibArgs a)
     const int k = lane & 15;
 
     const PgWorkItem* itp = a.work + 2 * (size_t)(a.pair_begin + blockIdx.x);
+    if (itp->read[0] == PG_NONE)
+        return;  // an empty slot of a plan re-written by the cascade's hand-over (active reads come first in a group)
     const LGraphDev g = a.graphs[itp->graph];
     constexpr int KPAD = kpad(C);
     const uint32_t PADPK = f16_bits(KPAD + 1) | (f16_bits(KPAD + 1) << 16);

@@ -1405,22 +1405,14 @@ void SiteBatcher::Impl::Run::deviceSection()
     // pass); a read that is MAPPED and accepted is done, everything else goes on to the next stage with the earlier
     // records kept.
     // The hand-over is decided on the device (pg_batch_retire_mapped): neither flags nor supports nor a mask cross to the host,
-    // and the work items of the stages behind it are re-made from per-graph counts of the reads still active.
+    // the work items of the stages behind it are re-written there, and the whole cascade is queued without a wait.
     uint32_t keep = 0;
     auto hand_over = [&]() {
         check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
         check(ctx, pg_batch_retire_mapped(ctx, guard.b), "pg_batch_retire_mapped");
         keep = PG_AF_KEEP_RESULTS;
     };
-    // before a stage that re-makes its work items from the hand-over's counts: the wait for them (a few hundred words behind the
-    // count pass) happens WITHOUT the device mutex, so that other lanes queue their batches' stages meanwhile
-    auto await_counts = [&]() {
-        if (!keep)
-            return;
-        lock.unlock();
-        check(ctx, pg_batch_await_hand_over(ctx, guard.b), "pg_batch_await_hand_over");
-        lock.lock();
-    };
+
     if (prm.path_sequence_matching && n)
     {
         check(ctx, pg_batch_path_align(ctx, guard.b), "pg_batch_path_align");
@@ -1433,7 +1425,6 @@ void SiteBatcher::Impl::Run::deviceSection()
     }
     if (prm.klib_sequence_matching && n)
     {
-        await_counts();
         check(ctx, pg_batch_klib_align(ctx, guard.b, keep), "pg_batch_klib_align");
         hand_over();
         uint32_t overflow = 0;
@@ -1441,7 +1432,6 @@ void SiteBatcher::Impl::Run::deviceSection()
         if (overflow)
             throw std::runtime_error("klib stage: CIGAR buffer overflow on the device");
     }
-    await_counts();
     if (keep)  // (the extension flag is ignored when flags == PG_AF_ALL)
         align_flags = (align_flags & (PG_AF_CIGAR | PG_AF_BOTH_STRANDS | PG_AF_REVERSE_GRAPH)) | PG_AF_KEEP_RESULTS;
     check(ctx, pg_batch_align(ctx, guard.b, align_flags), "pg_batch_align");

@@ -1376,8 +1376,10 @@ void SiteBatcher::Impl::Run::deviceSection()
         if (path_nodes.empty())
             path_nodes.push_back(0);
     }
+    mark("graph set up");
     if (prm.path_sequence_matching && n)
         check(ctx, pg_graphs_build_path_index(ctx, G, 32), "pg_graphs_build_path_index");
+    mark("path index");
     if (prm.kmer_sequence_matching && n)
         check(ctx, pg_graphs_build_kmer_index(ctx, G, 16, path_off.data(), path_node_off.data(), path_nodes.data()),
               "pg_graphs_build_kmer_index");
@@ -1388,6 +1390,7 @@ void SiteBatcher::Impl::Run::deviceSection()
     mark("graphs up");
     guard.b = batchPool(prm.device).take(ctx);
     check(ctx, pg_batch_upload(ctx, guard.b, G, n, gor.data(), base_off.data(), bases.data()), "pg_batch_upload");
+    mark("batch upload");
     check(ctx, pg_batch_set_fragments(ctx, guard.b, frag.data(), is_rev.data()), "pg_batch_set_fragments");
     mark("reads up");
     std::unique_lock<std::mutex> lock(deviceMutex(prm.device));
@@ -1447,6 +1450,7 @@ void SiteBatcher::Impl::Run::deviceSection()
     sup.resize(n);
     table.resize(lay.n_counters);
     check(ctx, pg_batch_result_sizes(ctx, guard.b, &n_ops, &n_path), "pg_batch_result_sizes");
+    mark("batch done");
     ops.resize(n_ops + 1);
     path.resize(n_path + 1);
     check(ctx, pg_batch_download_all(ctx, guard.b, res.data(), ops.data(), ops.size(), table.data(), sup.data(), path.data(), path.size()),

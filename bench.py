@@ -770,7 +770,9 @@ def prepare_e2e(args, rank, world, ncpu):
     import pickle
     from paragraph_amd import synth_e2e
     base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
-    tag = os.environ.get("MASTER_PORT") if world > 1 else None
+    # one directory per LAUNCH: the ranks of a launch share the rendezvous port and their parent (the torch.distributed.run agent);
+    # a directory a crashed earlier launch left behind under the same port is then never mistaken for this one's
+    tag = "%s_%d" % (os.environ.get("MASTER_PORT"), os.getppid()) if world > 1 else None
     d = os.path.join(base, "pgbench_e2e_%s" % tag) if tag else tempfile.mkdtemp(prefix="pgbench_e2e_", dir=base)
     os.makedirs(d, exist_ok=True)
     n = args.e2e_sites

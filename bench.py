@@ -110,6 +110,8 @@ def parse_args():
     ap.add_argument("--e2e-verify", type=int, default=500,
                     help="e2e leg: sites of rank 0's shard whose edge counts are compared with the reference's code (0 = skip)")
     ap.add_argument("--e2e-threads", type=int, default=0, help="host threads of the workflow per rank (0 = usable CPUs / ranks)")
+    ap.add_argument("--e2e-options", default="", help="JSON object of further pgw_genotype_graphs options for the e2e leg (A/B runs: "
+                                                       "sites_per_batch, lanes, ...)")
     ap.add_argument("--cpu-leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--sites-cpu-leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-reads-file", help=argparse.SUPPRESS)
@@ -833,6 +835,8 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
     threads = args.e2e_threads or max(1, ncpu // world)
     out_file = os.path.join(e2e["dir"], "genotypes_rank%d.json" % rank)
     options = {"threads": threads, "devices": [dev_index]}
+    if args.e2e_options:
+        options.update(json.loads(args.e2e_options))
     if shared:  # ranks sharing a GPU (tests on a 1-GPU box): the host library's workspace budget per rank
         os.environ.setdefault("PG_WORKSPACE_GIB", "%g" % max(4.0, 96.0 / world))
 

@@ -133,7 +133,10 @@ struct Parameters
     // keep the reads of a site as flat arrays instead of common::Read objects (several times less host work); switched off
     // automatically when output_alignments needs the per-read records
     bool packed_reads = true;
-    size_t sites_per_batch = 192;    // (graph, sample) pairs per device batch; bounds host memory and sets the pipeline grain (10 000 sites, 16 threads: 128 74.8 k sites/s, 192 78.6 k, 256 75.5 k, 384 59.6 k)
+    size_t sites_per_batch = 0;      // (graph, sample) pairs per device batch; bounds host memory and sets the pipeline grain.  0 = 192, or
+                                     // 384 when a seed stage runs before the graph aligner (10 000 sites, 16 threads, profiles/
+                                     // r05_e2e_batch_ab.jsonl: gssw only 128 72.5 k sites/s, 192 74.5 k, 256 74.4 k, 384 70.5 k; with the
+                                     // path stage 192 46 k, 256 49.7 k, 384 56.5 k -- every batch's cascade is a chain of dependent stages)
                                      // (10 000 sites on one MI355X / 16 CPUs: 128 -> 57 k sites/s, 512 -> 51 k)
     int lanes = 0;                   // chunks in flight: each lane carries one chunk through all stages with threads / lanes
                                      // workers; 0 = one lane per four threads, at most eight per device, at least one per device

@@ -897,7 +897,9 @@ std::vector<Json> genotypeGraphs(
         parameters.genotype_text->assign(n_graphs, std::string());
     if (n_graphs == 0 || n_samples == 0)
         return genotypes;
-    const size_t per_batch = std::max<size_t>(1, parameters.sites_per_batch / n_samples);
+    const bool seed_stages = parameters.path_sequence_matching || parameters.kmer_sequence_matching || parameters.klib_sequence_matching;
+    const size_t pairs_per_batch = parameters.sites_per_batch ? parameters.sites_per_batch : (seed_stages ? 384 : 192);
+    const size_t per_batch = std::max<size_t>(1, pairs_per_batch / n_samples);
     const size_t n_even_chunks = (n_graphs + per_batch - 1) / per_batch;
     // Lanes: each lane takes the next chunk and carries it through every stage (load + extract, device batch, documents,
     // genotypes) with its share of the host threads.  The device part of SiteBatcher::run() is serialised by the device

@@ -111,7 +111,7 @@ std::vector<common::Json> alignAndDisambiguateBatch(Parameters const& parameters
 std::vector<common::Json> countGraphs(
     Parameters const& parameters, std::vector<std::string> const& graph_paths, std::string const& reference_path,
     std::vector<std::string> const& bam_paths, std::vector<std::string> const& bam_index_paths = {},
-    std::string const& target_regions = "", size_t sites_per_batch = 192);
+    std::string const& target_regions = "", size_t sites_per_batch = 0 /* 0 = 192, 384 with a seed stage before the graph aligner */);
 // single-site convenience with the reference's shape
 common::Json alignAndDisambiguate(Parameters const& parameters, GraphDescription const& description, common::ReadBuffer& all_reads);
 }  // namespace paragraph

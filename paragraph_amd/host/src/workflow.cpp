@@ -447,7 +447,8 @@ std::vector<Json> countGraphs(
             bam_value.append(b);
 
     std::vector<Json> documents(graph_paths.size());
-    sites_per_batch = std::max<size_t>(1, sites_per_batch);
+    if (sites_per_batch == 0)
+        sites_per_batch = (parameters.path_sequence_matching || parameters.kmer_sequence_matching || parameters.klib_sequence_matching) ? 384 : 192;
     // one chunk of graphs: load + extract, ONE device batch, documents -- with `lane.threads` workers
     auto processChunk = [&](size_t g0, Parameters const& lane) {
         const size_t n_here = std::min(sites_per_batch, graph_paths.size() - g0);

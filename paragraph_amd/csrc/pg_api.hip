@@ -1722,7 +1722,10 @@ static pg_status cascade_rebuild_items(pg_ctx* ctx, pg_batch* b, hipStream_t str
     b->chunks.clear();
     b->n_pairs = 0;
     if (!n || !n_groups)
+    {
+        b->plan_stale = false;  // nothing the packed kernels could run
         return PG_OK;
+    }
     if (n_groups > b->cap_groups || n > b->cap_cascade_reads)
     {
         HIP_TRY(ctx, pg_batch_wait(ctx, b));

@@ -289,8 +289,11 @@ extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
     const int side_prio = (pe && pe[0] == '0') ? 0 : prio_greatest;
     // (the second fill stream right after the first: the runtime deals its hardware queues round-robin, so the two land on
     // different ones)
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess
-        || hipStreamCreateWithFlags(&ctx->stream_fill2, hipStreamNonBlocking) != hipSuccess
+    const bool fills_low = getenv("PG_FILLS_LOW") != nullptr;  // (A/B: both fill streams one level DOWN, a pool nobody else uses)
+    if (hipSetDevice(device) != hipSuccess
+        || (fills_low ? hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_least) : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess
+        || ((getenv("PG_FILL2_LOW") || fills_low) ? hipStreamCreateWithPriority(&ctx->stream_fill2, hipStreamNonBlocking, prio_least)  // (A/B: a pool of its own)
+                                                  : hipStreamCreateWithFlags(&ctx->stream_fill2, hipStreamNonBlocking)) != hipSuccess
         || hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, side_prio) != hipSuccess
         || hipStreamCreateWithPriority(&ctx->stream_seed, hipStreamNonBlocking, side_prio) != hipSuccess
         || hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, side_prio) != hipSuccess)

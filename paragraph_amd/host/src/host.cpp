@@ -153,8 +153,10 @@ pg_ctx* deviceContext(int slot = 0)
         // of 8 GiB cuts a 1000-site batch into ~9 chunks of 25 k reads, too few threads for the one-thread-per-read
         // traceback kernel.  An MI355X has 288 GB: 64 GiB (what bench.py uses) keeps such a batch in one or two chunks.
         // (pg_ctx_set_fill_streams(ctx, 2) -- fills alternating over two streams and three workspace regions, so that a launch's
-        // draining tail is filled by the next chunk -- was measured here and changes nothing: this workflow is bound by its 16
-        // host CPUs, not by the device, profiles/r05_tail_ab.jsonl.  PG_FILL_STREAMS=2 in the environment switches it on.)
+        // draining tail is filled by the next chunk -- was measured here: with the two streams on two hardware queues
+        // (PG_FILLS_LOW=1) the fills do overlap, and this workflow loses 3.5 %: two batches that share the chip both finish late,
+        // and a lane waiting for its batch prepares nothing (profiles/r05_fill_streams_queues_ab.jsonl).  PG_FILL_STREAMS=2
+        // PG_FILLS_LOW=1 in the environment switches it on.)
         const char* gib = std::getenv("PG_WORKSPACE_GIB");
         const double budget_gib = gib ? std::atof(gib) : 64.0;
         if (budget_gib > 0)

@@ -99,6 +99,13 @@ public:
     // Aligns and counts every site added so far.  Afterwards each site's read vector holds only the MAPPED
     // reads (as grm::alignReads leaves it, Align.cpp:155) with their supports filled in.
     void run(BatchParameters const& parameters = BatchParameters());
+    // run() in two halves, for a caller that has other work while the device has this batch: submit() packs and uploads the sites
+    // and queues every device stage, then returns (nothing waits for the device); collect() waits for the batch, fetches its
+    // records and makes views / reads and the site tables.  submit() returns false -- with nothing of the attempt left -- when the
+    // batch holds a site outside the device's envelope: call run(), which isolates that site.  The sites (graphs, reads, paths)
+    // must stay alive and untouched until collect() returns.
+    bool submit(BatchParameters const& parameters = BatchParameters());
+    void collect();
     size_t numSites() const;
     SiteCounts const& counts(size_t site) const;
     SiteReadViews const& views(size_t site) const;  // packed sites only

@@ -192,7 +192,7 @@ struct BatchPool
     }
     void giveBack(pg_ctx* ctx, pg_batch* b, bool reusable)
     {
-        static const size_t keep = 16;
+        static const size_t keep = 64;  // (a workflow's lanes keep two batches in flight each)
         if (reusable)
         {
             std::lock_guard<std::mutex> lock(ds.pool_mutex);
@@ -1091,10 +1091,13 @@ struct SiteBatcher::Impl
     std::vector<std::string> errors;  // per site: why the device path could not take it ("" = fine)
     struct Run;
     void runAll(BatchParameters const& prm);
+    void finish(Run& run);
+    std::unique_ptr<Run> pending;  // between submit() and collect()
+    ~Impl();
 };
 
 SiteBatcher::SiteBatcher() : impl_(new Impl()) {}
-SiteBatcher::~SiteBatcher() = default;
+SiteBatcher::~SiteBatcher() = default;  // (Impl::~Impl is defined behind Impl::Run)
 size_t SiteBatcher::numSites() const { return impl_->graphs.size(); }
 SiteCounts const& SiteBatcher::counts(size_t site) const { return impl_->counts.at(site); }
 
@@ -1124,16 +1127,29 @@ size_t SiteBatcher::addSite(const Graph* graph, PackedSite const* reads, std::li
 struct SiteBatcher::Impl::Run
 {
     Run(Impl& impl_, BatchParameters const& prm_) : impl(impl_), prm(prm_), n_sites(impl_.graphs.size()) {}
+    ~Run()
+    {
+        // the batch object returns to the pool (with its device buffers when the run went through), the graph set goes
+        if (batch)
+            batchPool(prm.device).giveBack(ctx, batch, finished);
+        if (G)
+            pg_graphs_destroy(ctx, G);
+    }
     void graphCsr();
     void packReads();
-    void deviceSection();
+    void deviceSubmit();   // graphs + reads up, every stage queued: returns while the device works
+    void deviceCollect();  // waits for the batch, fetches its records
     void resultsToReads();
     void viewsOfPackedSites();
     void siteTables();
 
     Impl& impl;
-    BatchParameters const& prm;
+    const BatchParameters prm;  // (a copy: a submitted run outlives the call that made it)
     const size_t n_sites;
+    pg_ctx* ctx = nullptr;
+    pg_graphs* G = nullptr;
+    pg_batch* batch = nullptr;
+    bool finished = false;
     bool packed_mode = false;
     GraphCsr csr;
     // inputs of pg_batch_upload / pg_batch_set_fragments, all sites back to back
@@ -1214,26 +1230,45 @@ void SiteBatcher::run(BatchParameters const& prm)
     }
 }
 
-void SiteBatcher::Impl::runAll(BatchParameters const& prm)
+SiteBatcher::Impl::~Impl() = default;
+
+namespace
 {
-    Impl* impl_ = this;
-    // PG_BATCH_TIMING=1: wall-clock of the phases of this call on stderr
+// PG_BATCH_TIMING=1: wall-clock of the phases of a run on stderr
+struct PhaseMarks
+{
     const bool timing = std::getenv("PG_BATCH_TIMING") != nullptr;
-    auto t_prev = std::chrono::steady_clock::now();
-    auto mark = [&](const char* what) {
+    std::chrono::steady_clock::time_point t_prev = std::chrono::steady_clock::now();
+    void operator()(const char* what)
+    {
         if (!timing)
             return;
         const auto t = std::chrono::steady_clock::now();
         fprintf(stderr, "[SiteBatcher] %-18s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
         t_prev = t;
-    };
-    Impl::Run run(*impl_, prm);
+    }
+};
+}  // namespace
+
+void SiteBatcher::Impl::runAll(BatchParameters const& prm)
+{
+    PhaseMarks mark;
+    Impl::Run run(*this, prm);
     run.graphCsr();
     mark("graph csr");
     run.packReads();
     mark("pack reads");
-    run.deviceSection();  // the only part under the device mutex
-    mark("device");
+    run.deviceSubmit();  // the only part under the device mutex
+    mark("device submit");
+    finish(run);
+}
+
+// what follows the queued stages: the records come down, the reads / views and the site tables are made
+void SiteBatcher::Impl::finish(Run& run)
+{
+    PhaseMarks mark;
+    run.deviceCollect();
+    mark("device collect");
     if (run.packed_mode)
         run.viewsOfPackedSites();
     else
@@ -1241,6 +1276,38 @@ void SiteBatcher::Impl::runAll(BatchParameters const& prm)
     mark("results -> reads");
     run.siteTables();
     mark("site tables");
+}
+
+bool SiteBatcher::submit(BatchParameters const& prm)
+{
+    const size_t n = impl_->graphs.size();
+    impl_->counts.assign(n, SiteCounts());
+    impl_->views.assign(n, SiteReadViews());
+    impl_->errors.assign(n, std::string());
+    impl_->pending.reset();
+    if (n == 0)
+        return true;
+    try
+    {
+        std::unique_ptr<Impl::Run> run(new Impl::Run(*impl_, prm));
+        run->graphCsr();
+        run->packReads();
+        run->deviceSubmit();
+        impl_->pending = std::move(run);
+        return true;
+    }
+    catch (OutsideEnvelope const&)
+    {
+        return false;  // nothing of the attempt is left (the run released its device objects): run() isolates the site
+    }
+}
+
+void SiteBatcher::collect()
+{
+    if (!impl_->pending)
+        return;
+    std::unique_ptr<Impl::Run> run = std::move(impl_->pending);
+    impl_->finish(*run);
 }
 
 void SiteBatcher::Impl::Run::graphCsr()
@@ -1319,10 +1386,10 @@ void SiteBatcher::Impl::Run::packReads()
         8);
 }
 
-void SiteBatcher::Impl::Run::deviceSection()
+void SiteBatcher::Impl::Run::deviceSubmit()
 {
     // ---- device section: calls on one context are serialised; everything before and after overlaps across threads ------
-    pg_ctx* ctx = deviceContext(prm.device);
+    ctx = deviceContext(prm.device);
     const uint32_t n = (uint32_t)gor.size();
     seq_off.assign(n_sites + 1, 0);
     const bool timing = std::getenv("PG_BATCH_TIMING") != nullptr;
@@ -1338,25 +1405,9 @@ void SiteBatcher::Impl::Run::deviceSection()
     //   1. graph set + indexes and then the reads go up the copy stream (work items and fragment tables are host work),
     //   2. the stage calls, which share the context's workspace (deviceMutex),
     //   3. the results come down; the batch object returns to the pool with its device buffers.
-    pg_graphs* G = nullptr;
     check(ctx, pg_graphs_upload(ctx, (uint32_t)n_sites, csr.node_off.data(), csr.seq_off.data(), csr.seq.data(),
                                 csr.pred_off.data(), csr.pred.empty() ? nullptr : csr.pred.data(), &G),
           "pg_graphs_upload");
-    struct Guard
-    {
-        pg_ctx* c;
-        pg_graphs* g;
-        pg_batch* b;
-        bool finished;
-        int slot;
-        ~Guard()
-        {
-            if (b)
-                batchPool(slot).giveBack(c, b, finished);
-            if (g)
-                pg_graphs_destroy(c, g);
-        }
-    } guard{ ctx, G, nullptr, false, prm.device };
     check(ctx, pg_graphs_set_labels_wide(ctx, G, csr.label_mask.empty() ? nullptr : csr.label_mask.data(), csr.label_words,
                                          csr.n_labels.data()),
           "pg_graphs_set_labels_wide");
@@ -1390,10 +1441,10 @@ void SiteBatcher::Impl::Run::deviceSection()
     if (prm.kmer_len != 0)  // createReadFilter(graph, nonuniq, frac, kmer_len): NonUniq -> BadAlign -> KmerFilter (ReadFilter.cpp:74-90)
         check(ctx, pg_graphs_build_filter_index(ctx, G, prm.kmer_len, nullptr), "pg_graphs_build_filter_index");
     mark("graphs up");
-    guard.b = batchPool(prm.device).take(ctx);
-    check(ctx, pg_batch_upload(ctx, guard.b, G, n, gor.data(), base_off.data(), bases.data()), "pg_batch_upload");
+    batch = batchPool(prm.device).take(ctx);
+    check(ctx, pg_batch_upload(ctx, batch, G, n, gor.data(), base_off.data(), bases.data()), "pg_batch_upload");
     mark("batch upload");
-    check(ctx, pg_batch_set_fragments(ctx, guard.b, frag.data(), is_rev.data()), "pg_batch_set_fragments");
+    check(ctx, pg_batch_set_fragments(ctx, batch, frag.data(), is_rev.data()), "pg_batch_set_fragments");
     mark("reads up");
     std::unique_lock<std::mutex> lock(deviceMutex(prm.device));
     mark("wait for device");
@@ -1413,24 +1464,24 @@ void SiteBatcher::Impl::Run::deviceSection()
     // the work items of the stages behind it are re-written there, and the whole cascade is queued without a wait.
     uint32_t keep = 0;
     auto hand_over = [&]() {
-        check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
-        check(ctx, pg_batch_retire_mapped(ctx, guard.b), "pg_batch_retire_mapped");
+        check(ctx, pg_batch_count(ctx, batch, &cp, nullptr), "pg_batch_count");
+        check(ctx, pg_batch_retire_mapped(ctx, batch), "pg_batch_retire_mapped");
         keep = PG_AF_KEEP_RESULTS;
     };
 
     if (prm.path_sequence_matching && n)
     {
-        check(ctx, pg_batch_path_align(ctx, guard.b), "pg_batch_path_align");
+        check(ctx, pg_batch_path_align(ctx, batch), "pg_batch_path_align");
         hand_over();
     }
     if (prm.kmer_sequence_matching && n)
     {
-        check(ctx, pg_batch_kmer_align(ctx, guard.b, keep), "pg_batch_kmer_align");
+        check(ctx, pg_batch_kmer_align(ctx, batch, keep), "pg_batch_kmer_align");
         hand_over();
     }
     if (prm.klib_sequence_matching && n)
     {
-        check(ctx, pg_batch_klib_align(ctx, guard.b, keep), "pg_batch_klib_align");
+        check(ctx, pg_batch_klib_align(ctx, batch, keep), "pg_batch_klib_align");
         hand_over();
         uint32_t overflow = 0;
         check(ctx, pg_graphs_klib_error(ctx, G, &overflow), "pg_graphs_klib_error");
@@ -1439,10 +1490,24 @@ void SiteBatcher::Impl::Run::deviceSection()
     }
     if (keep)  // (the extension flag is ignored when flags == PG_AF_ALL)
         align_flags = (align_flags & (PG_AF_CIGAR | PG_AF_BOTH_STRANDS | PG_AF_REVERSE_GRAPH)) | PG_AF_KEEP_RESULTS;
-    check(ctx, pg_batch_align(ctx, guard.b, align_flags), "pg_batch_align");
-    check(ctx, pg_batch_count(ctx, guard.b, &cp, nullptr), "pg_batch_count");
+    check(ctx, pg_batch_align(ctx, batch, align_flags), "pg_batch_align");
+    check(ctx, pg_batch_count(ctx, batch, &cp, nullptr), "pg_batch_count");
     lock.unlock();  // the kernels are queued; the next batch may queue its own behind them
     mark("align + count");
+}
+
+void SiteBatcher::Impl::Run::deviceCollect()
+{
+    const uint32_t n = (uint32_t)gor.size();
+    const bool timing = std::getenv("PG_BATCH_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!timing)
+            return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[SiteBatcher]   %-16s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
 
     // one wait for the batch (its sizes are in page-locked memory by then), one for the five copies
     uint64_t n_ops = 0, n_path = 0;
@@ -1451,18 +1516,18 @@ void SiteBatcher::Impl::Run::deviceSection()
     res.resize(n);
     sup.resize(n);
     table.resize(lay.n_counters);
-    check(ctx, pg_batch_result_sizes(ctx, guard.b, &n_ops, &n_path), "pg_batch_result_sizes");
+    check(ctx, pg_batch_result_sizes(ctx, batch, &n_ops, &n_path), "pg_batch_result_sizes");
     mark("batch done");
     ops.resize(n_ops + 1);
     path.resize(n_path + 1);
-    check(ctx, pg_batch_download_all(ctx, guard.b, res.data(), ops.data(), ops.size(), table.data(), sup.data(), path.data(), path.size()),
+    check(ctx, pg_batch_download_all(ctx, batch, res.data(), ops.data(), ops.size(), table.data(), sup.data(), path.data(), path.size()),
           "pg_batch_download_all");
     if (csr.label_words > 1)
     {
         label_ext.assign((size_t)n * (csr.label_words - 1), 0);
-        check(ctx, pg_batch_download_label_ext(ctx, guard.b, label_ext.data(), label_ext.size()), "pg_batch_download_label_ext");
+        check(ctx, pg_batch_download_label_ext(ctx, batch, label_ext.data(), label_ext.size()), "pg_batch_download_label_ext");
     }
-    guard.finished = true;
+    finished = true;
     mark("results down");
 }
 

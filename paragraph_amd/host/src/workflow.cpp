@@ -426,6 +426,64 @@ std::vector<Json> alignAndDisambiguateBatch(Parameters const& parameters, std::v
     return documents;
 }
 
+// alignAndDisambiguateBatch (packed form) in two halves: beginPackedBatch packs, uploads and queues the batch on the device and
+// returns; finishPackedBatch waits for it and writes the documents.  Between the two the caller does other work (a lane of
+// grmpy::genotypeGraphs prepares its next chunk).
+struct PackedBatchInFlight
+{
+    Parameters parameters;
+    std::vector<PackedSiteInput> sites;
+    SiteBatcher batcher;
+    bool submitted = false;
+    double begin_s = 0;
+};
+
+std::unique_ptr<PackedBatchInFlight> beginPackedBatch(Parameters const& parameters, std::vector<PackedSiteInput> sites)
+{
+    if (parameters.output_enabled(Parameters::ALIGNMENTS))
+        throw std::runtime_error("alignAndDisambiguateBatch: packed sites keep no per-read records; use the object form for \"alignments\"");
+    std::unique_ptr<PackedBatchInFlight> f(new PackedBatchInFlight);
+    f->parameters = parameters;
+    f->sites = std::move(sites);
+    for (auto const& site : f->sites)
+    {
+        if (!site.description || !site.reads)
+            throw std::runtime_error("alignAndDisambiguateBatch: site without description or reads");
+        f->batcher.addSite(site.description->graph.get(), site.reads, &site.description->paths);
+    }
+    const double t0 = now();
+    f->submitted = f->sites.empty() || f->batcher.submit(batchParameters(parameters));
+    f->begin_s = now() - t0;
+    return f;
+}
+
+std::vector<Json> finishPackedBatch(PackedBatchInFlight& f)
+{
+    const double t_batch = now();
+    if (!f.sites.empty())
+    {
+        if (f.submitted)
+            f.batcher.collect();
+        else
+            f.batcher.run(batchParameters(f.parameters));  // a site outside the envelope: run() isolates it
+    }
+    const double t_documents = now();
+    std::vector<Json> documents(f.sites.size());
+    parallelFor(f.sites.size(), f.parameters.threads, [&](size_t s) {
+        documents[s] = countDocument(f.parameters, *f.sites[s].description, f.batcher.counts(s), f.batcher.views(s), f.sites[s].reads->size(), nullptr);
+        noteSiteError(documents[s], *f.sites[s].description, f.batcher.error(s));
+    });
+    if (f.parameters.timings)
+    {
+        f.parameters.timings->device_batch += f.begin_s + (t_documents - t_batch);
+        f.parameters.timings->documents += now() - t_documents;
+        f.parameters.timings->sites += f.sites.size();
+        for (auto const& site : f.sites)
+            f.parameters.timings->reads += site.reads->size();
+    }
+    return documents;
+}
+
 std::vector<Json> countGraphs(
     Parameters const& parameters, std::vector<std::string> const& graph_paths, std::string const& reference_path,
     std::vector<std::string> const& bam_paths, std::vector<std::string> const& bam_index_paths, std::string const& target_regions,
@@ -967,42 +1025,40 @@ std::vector<Json> genotypeGraphs(
         site_parameters.device = (int)((size_t)lane_id % n_devices);
         try
         {
-            for (;;)
+            // A lane keeps TWO chunks going: while one is on the device it prepares the next (graph loading + read extraction),
+            // queues it, and only then waits for the first one's records and writes its documents and genotypes.  The device
+            // always has this lane's next batch behind the current one, and the lane's thread is busy instead of asleep --
+            // as many lanes as host threads are then enough (no oversubscribed CPUs, no descheduled lock holders).
+            struct InFlight
             {
-                const size_t c = next_chunk.fetch_add(1);
-                if (c >= n_chunks || failed.load())
-                    break;
-                const size_t g0 = chunk_ranges[c].first, g1 = chunk_ranges[c].second, n_here = g1 - g0;
-                t_mark = now();
-                std::unique_ptr<Chunk> chunk = prepareChunk(parameters, graph_paths, reference_path, samples, g0, g1, lane_threads, &fasta);
-                phase(c, "prepare");
+                size_t c = 0, g0 = 0, n_here = 0;
+                std::unique_ptr<Chunk> chunk;
+                std::unique_ptr<paragraph::PackedBatchInFlight> batch;
+            };
+            auto finish = [&](InFlight& f) {
+                if (!f.chunk)
+                    return;
                 std::vector<Json> documents;
-                if (!chunk->packed.empty())
-                {
-                    std::vector<paragraph::PackedSiteInput> sites(n_here * n_samples);
-                    for (size_t i = 0; i < sites.size(); ++i)
-                    {
-                        sites[i].description = &chunk->graphs[i / n_samples];
-                        sites[i].reads = &chunk->packed[i];
-                    }
-                    documents = paragraph::alignAndDisambiguateBatch(site_parameters, sites);
-                }
+                if (f.batch)
+                    documents = paragraph::finishPackedBatch(*f.batch);
                 else
                 {
-                    std::vector<paragraph::SiteInput> sites(n_here * n_samples);
+                    std::vector<paragraph::SiteInput> sites(f.n_here * n_samples);
                     for (size_t i = 0; i < sites.size(); ++i)
                     {
-                        sites[i].description = &chunk->graphs[i / n_samples];
-                        sites[i].reads = &chunk->reads[i];
+                        sites[i].description = &f.chunk->graphs[i / n_samples];
+                        sites[i].reads = &f.chunk->reads[i];
                     }
                     documents = paragraph::alignAndDisambiguateBatch(site_parameters, sites);
                 }
                 for (size_t i = 0; i < documents.size(); ++i)
                     finishSampleDocument(documents[i], samples[i % n_samples].filename(), parameters.output_alignments);
-                phase(c, "batch+documents");
+                phase(f.c, "batch+documents");
 
                 const double t_genotype = now();
-                parallelFor(n_here, lane_threads, [&](size_t g) {
+                const size_t g0 = f.g0;
+                Chunk* chunk = f.chunk.get();
+                parallelFor(f.n_here, lane_threads, [&](size_t g) {
                     std::vector<genotyping::SampleInfo const*> sample_ptrs;
                     std::vector<Json const*> docs;
                     std::vector<Json*> dropped_after;  // the count documents end with this chunk
@@ -1023,18 +1079,47 @@ std::vector<Json> genotypeGraphs(
                         genotypes[g0 + g] = Json();
                     }
                 });
-                phase(c, "genotypes");
+                phase(f.c, "genotypes");
                 const double t_release = now();
                 // the lane frees what it allocated itself (a helper thread doing it met the lanes in the allocator's arena locks)
-                mine.load_graphs += chunk->load_s;
-                mine.extract_reads += chunk->extract_s;
+                mine.load_graphs += f.chunk->load_s;
+                mine.extract_reads += f.chunk->extract_s;
                 std::vector<Json>().swap(documents);
-                chunk.reset();
-                phase(c, "release");
+                f.batch.reset();
+                f.chunk.reset();
+                phase(f.c, "release");
                 mine.genotypes += t_release - t_genotype;
                 mine.release += now() - t_release;
                 mine.batches += 1;
+            };
+            InFlight current;
+            for (;;)
+            {
+                const size_t c = next_chunk.fetch_add(1);
+                if (c >= n_chunks || failed.load())
+                    break;
+                InFlight next;
+                next.c = c;
+                next.g0 = chunk_ranges[c].first;
+                next.n_here = chunk_ranges[c].second - next.g0;
+                t_mark = now();
+                next.chunk = prepareChunk(parameters, graph_paths, reference_path, samples, next.g0, chunk_ranges[c].second, lane_threads, &fasta);
+                phase(c, "prepare");
+                if (!next.chunk->packed.empty())
+                {
+                    std::vector<paragraph::PackedSiteInput> sites(next.n_here * n_samples);
+                    for (size_t i = 0; i < sites.size(); ++i)
+                    {
+                        sites[i].description = &next.chunk->graphs[i / n_samples];
+                        sites[i].reads = &next.chunk->packed[i];
+                    }
+                    next.batch = paragraph::beginPackedBatch(site_parameters, std::move(sites));  // queued: the device works on
+                    phase(c, "submit");
+                }
+                finish(current);  // the chunk before: on the device while this one was prepared
+                current = std::move(next);
             }
+            finish(current);
         }
         catch (...)
         {

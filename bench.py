@@ -865,14 +865,15 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
     os.unlink(out_file)
     assert len(docs) == len(mine)
     # The same job with `paragraph`'s default cascade (src/c++/main/paragraph.cpp:60-61: exact path matching first, gssw on what it
-    # leaves): path stage -> filter chain -> hand-over on the device -> gssw stage, composed inside the workflow.  Two passes.
+    # leaves): path stage -> filter chain -> hand-over on the device -> gssw stage, composed inside the workflow.  As many passes (two at least).
     cascade = None
     if args.e2e_steps > 0:
         options_path = dict(options, path_sequence_matching=True)
         workflow.genotype_graphs_to_file(e2e["reference"], e2e["manifest"], graphs, out_file, **options_path)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(2):
+        path_steps = max(2, args.e2e_steps)
+        for _ in range(path_steps):
             workflow.genotype_graphs_to_file(e2e["reference"], e2e["manifest"], graphs, out_file, **options_path)
         barrier()
         t_path = env["max_over_ranks"](time.perf_counter() - t0)
@@ -880,7 +881,7 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
             docs_path = json.load(f)
         os.unlink(out_file)
         same_gt = sum(1 for a, b2 in zip(docs, docs_path) if a["samples"]["SYN"]["gt"].get("GT") == b2["samples"]["SYN"]["gt"].get("GT"))
-        cascade = {"sites_genotyped_per_s": n * 2 / t_path, "ms_per_step": t_path / 2 * 1e3,
+        cascade = {"sites_genotyped_per_s": n * path_steps / t_path, "ms_per_step": t_path / path_steps * 1e3, "steps": path_steps,
                    "genotypes_equal_the_gssw_only_run_on_this_rank": same_gt, "sites_on_this_rank": len(mine),
                    "note": "path_sequence_matching = true (the `paragraph` tool's default): reads the exact path matcher maps and the "
                            "filters accept keep that alignment, so counts may differ from the gssw-only run by design"}

@@ -301,6 +301,9 @@ extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
         delete ctx;
         return PG_ERR_HIP;
     }
+    ctx->side_priority = side_prio;
+    if (const char* ss = getenv("PG_SEED_STREAMS"))  // (A/B; the streams beyond the first are made by the first path stage)
+        ctx->seed_streams = std::min(4, std::max(1, atoi(ss)));
     if (const char* fs = getenv("PG_FILL_STREAMS"))  // A/B timing: overrides pg_ctx_set_fill_streams' default of this context
         ctx->fill_streams = fs[0] == '2' ? 2 : 1;
     *out = ctx;
@@ -337,6 +340,9 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
         (void)hipStreamSynchronize(ctx->stream_fill2);
     if (ctx->stream_seed)
         (void)hipStreamSynchronize(ctx->stream_seed);
+    for (hipStream_t s : ctx->stream_seed_more)
+        if (s)
+            (void)hipStreamSynchronize(s);
     if (ctx->stream2)
         (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream_copy)
@@ -361,6 +367,9 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
         (void)hipStreamDestroy(ctx->stream_fill2);
     if (ctx->stream_seed)
         (void)hipStreamDestroy(ctx->stream_seed);
+    for (hipStream_t s : ctx->stream_seed_more)
+        if (s)
+            (void)hipStreamDestroy(s);
     if (ctx->stream2)
         (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream_copy)
@@ -386,6 +395,9 @@ extern "C" pg_status pg_ctx_sync(pg_ctx* ctx)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_fill2));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_seed));
+    for (hipStream_t s : ctx->stream_seed_more)
+        if (s)
+            HIP_TRY(ctx, hipStreamSynchronize(s));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     recycle_sync_events(ctx);
     return PG_OK;
@@ -450,6 +462,9 @@ extern "C" pg_status pg_ctx_sync_compute(pg_ctx* ctx)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_fill2));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_seed));
+    for (hipStream_t s : ctx->stream_seed_more)
+        if (s)
+            HIP_TRY(ctx, hipStreamSynchronize(s));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     return PG_OK;
 }
@@ -497,7 +512,7 @@ hipError_t pg_stage_end_on(pg_ctx* ctx, pg_batch* b, hipStream_t s)
 {
     if (const pg_graphs* G = b->graphs)
     {
-        const int w = s == ctx->stream ? 0 : s == ctx->stream_seed ? 2 : 1;
+        const int w = s == ctx->stream ? 0 : ctx->is_seed_stream(s) ? 2 : 1;
         hipError_t e = hipSuccess;
         if (!G->ev_use[w])
             e = hipEventCreateWithFlags(&G->ev_use[w], hipEventDisableTiming);
@@ -924,6 +939,9 @@ static void batch_free_device(pg_batch* b)
 {
     (void)pg_dev_free(b->d_base_off);
     (void)pg_dev_free(b->d_bases);
+    (void)pg_dev_free(b->d_bases_rc);
+    b->d_bases_rc = nullptr;
+    b->cap_bases_rc = 0;
     (void)pg_dev_free(b->d_items);
     (void)pg_dev_free(b->d_fillsum);
     (void)pg_dev_free(b->d_gen_reads);
@@ -1780,7 +1798,7 @@ extern "C" pg_status pg_batch_retire_mapped(pg_ctx* ctx, pg_batch* b)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // behind the count pass, on its stream (the seed stream behind a path stage): the next stage waits for the batch's event as
     // always
-    hipStream_t cs = b->seed_chain ? ctx->stream_seed : ctx->stream2;
+    hipStream_t cs = b->seed_chain ? b->seed_stream : ctx->stream2;
     HIP_TRY(ctx, pg_stage_begin_on(ctx, b, cs));
     if (!b->has_active && b->n_reads)
         HIP_TRY(ctx, hipMemsetAsync(b->d_active, 1, b->n_reads, cs));

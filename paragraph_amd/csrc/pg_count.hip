@@ -700,8 +700,8 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     // The count pass behind a path stage (the filter chain of the cascade's first hand-over) follows that stage onto the seed
     // stream -- when it counts into the batch's own table: a caller's table is ordered against the second stream
     // (pg_ctx_count_record / pg_ctx_count_wait).
-    hipStream_t cs = (b->seed_chain && !d_counts) ? ctx->stream_seed : ctx->stream2;
-    if (cs != ctx->stream_seed)
+    hipStream_t cs = (b->seed_chain && !d_counts) ? b->seed_stream : ctx->stream2;
+    if (cs == ctx->stream2)
         b->seed_chain = false;
     HIP_TRY(ctx, pg_stage_begin_on(ctx, b, cs));
     const uint32_t n = b->n_reads;

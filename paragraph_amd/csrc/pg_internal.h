@@ -69,6 +69,21 @@ struct pg_ctx
     // run on a stream of their own, one priority level up like the second stream: on the main stream they would wait behind the
     // fills of every batch queued before them, on the second stream behind tracebacks that wait for those fills.
     hipStream_t stream_seed = nullptr;
+    // Seed streams beyond the first, dealt to the batches' path stages in turn (each batch's seed chain stays on one).  A path stage
+    // beside the fills is latency: it waits for wavefront slots the fills hold (0.6 ms) and then walks chains of dependent loads
+    // (0.7 ms for the 50 wavefronts of a workflow batch with the device to itself, 1.5 ms beside a fill), and on ONE stream the
+    // batches of all the lanes queue behind each other for it -- 68 x 2 ms per pass of the 10 000-site job.  Two streams halve that
+    // (profiles/r05_e2e_seed_streams_ab.jsonl: 61-66k -> 71-72k sites/s); four share hardware queues with the count stream and
+    // lose again.  Made by the first path stage, not with the context: one more high-priority stream in a process that never
+    // runs a path stage cost the gssw-only workflow 5 %.
+    hipStream_t stream_seed_more[3] = { nullptr, nullptr, nullptr };
+    int seed_streams = 2;
+    int side_priority = 0;
+    unsigned seed_turn = 0;
+    bool is_seed_stream(hipStream_t s) const
+    {
+        return s == stream_seed || (s && (s == stream_seed_more[0] || s == stream_seed_more[1] || s == stream_seed_more[2]));
+    }
     int fill_streams = 1;
     unsigned regions() const { return fill_streams == 2 ? 3u : 2u; }
     hipEvent_t region_free[3] = { nullptr, nullptr, nullptr };
@@ -141,6 +156,8 @@ struct pg_batch
     uint32_t n_pairs = 0;
     uint32_t* d_base_off = nullptr;
     char* d_bases = nullptr;
+    char* d_bases_rc = nullptr;  // the reads reverse-complemented, at the same offsets (written by the path kernel, each thread its own read)
+    size_t cap_bases_rc = 0;
     PgWorkItem* d_items = nullptr;
     PgFillSummary* d_fillsum = nullptr;
     pg_result* d_results = nullptr;
@@ -170,6 +187,7 @@ struct pg_batch
     std::vector<uint32_t> h_group_of_read;    // per read: its group, PG_NONE for empty reads and reads of the general path
     bool has_general_reads = false;           // some read of the batch takes the general path (then the host re-plans from the flags)
     bool plan_stale = false;                  // d_active changed on the device since the work items were made
+    hipStream_t seed_stream = nullptr;        // the seed stream this batch's path stage ran on
     bool seed_chain = false;                  // the batch's last stage ran on the seed stream (pg_batch_path_align): its count pass and
                                               // hand-over follow it there
     bool cascade_uploaded = false;

@@ -12,8 +12,8 @@
 // key = 64-bit polynomial hash of the k raw characters, value = (number of paths with that sequence, first path).
 // Device: one thread per read; both strands; rolling hash over the read; for k-mers with exactly one path the
 // reference's greedy exact extension (right, then left; at a node end the neighbour with the UNIQUE longest
-// common prefix over the shortest neighbour's length) is replayed character by character on the raw node
-// sequences.  A read is MAPPED when a match covers the whole read; more than one such match makes it
+// common prefix over the shortest neighbour's length) is replayed on the raw node sequences, eight characters
+// at a time (the reverse strand on a reverse-complemented copy of the reads made once per upload).  A read is MAPPED when a match covers the whole read; more than one such match makes it
 // non-unique (MAPQ 0).  HBM-bound byte work: no LDS staging is needed (a read touches <= 2L graph bytes).
 #include <hip/hip_runtime.h>
 
@@ -39,6 +39,7 @@ struct PathArgs
     uint64_t pow_k1;  // HASH_B^(k-1)
     const uint32_t* base_off;
     const char* bases;
+    char* bases_rc;  // the reads as the reverse strand sees them, at the same offsets: written by the kernel
     const uint32_t* graph_of_read;
     const PathGraphDev* graphs;
     const KmerEntry* table;
@@ -68,17 +69,79 @@ __device__ __forceinline__ uint32_t comp_raw(uint32_t c)
     }
 }
 
+// Eight characters at a time: the reference's character loops (PathOperations.cpp:128-136, 150-159, 202-210, 225-235) are runs of
+// equal characters of two byte strings, forwards or backwards.  One thread owns one read and the 64 threads of a wavefront are at
+// different places of their reads, so a wavefront pays for the LONGEST loop any of its threads is in at every step: with one
+// character per trip the stage spent 430 000 VALU instructions per wavefront (profiles/r05_stage_counters.json: 2.8 ms, the
+// lifetime of one wavefront however few there are).  Wide loads only where eight characters remain on both sides: nothing is read
+// outside the two strings.
+__device__ __forceinline__ uint64_t load8(const char* p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+// number of leading characters x[0..n) and y[0..n) have in common
+__device__ __forceinline__ uint32_t common_prefix(const char* x, const char* y, uint32_t n)
+{
+    uint32_t i = 0;
+    while (i + 16 <= n)  // (four loads in flight: the loop is a chain of round trips, one per trip)
+    {
+        const uint64_t d0 = load8(x + i) ^ load8(y + i), d1 = load8(x + i + 8) ^ load8(y + i + 8);
+        if (d0)
+            return i + ((uint32_t)__builtin_ctzll(d0) >> 3);
+        if (d1)
+            return i + 8 + ((uint32_t)__builtin_ctzll(d1) >> 3);
+        i += 16;
+    }
+    while (i + 8 <= n)
+    {
+        const uint64_t d = load8(x + i) ^ load8(y + i);
+        if (d)
+            return i + ((uint32_t)__builtin_ctzll(d) >> 3);
+        i += 8;
+    }
+    while (i < n && x[i] == y[i])
+        ++i;
+    return i;
+}
+
+// number of trailing characters the strings ENDING at xe and ye (exclusive) have in common, at most n
+__device__ __forceinline__ uint32_t common_suffix(const char* xe, const char* ye, uint32_t n)
+{
+    uint32_t i = 0;
+    while (i + 16 <= n)
+    {
+        const uint64_t d0 = load8(xe - i - 8) ^ load8(ye - i - 8), d1 = load8(xe - i - 16) ^ load8(ye - i - 16);
+        if (d0)
+            return i + ((uint32_t)__builtin_clzll(d0) >> 3);
+        if (d1)
+            return i + 8 + ((uint32_t)__builtin_clzll(d1) >> 3);
+        i += 16;
+    }
+    while (i + 8 <= n)
+    {
+        const uint64_t d = load8(xe - i - 8) ^ load8(ye - i - 8);
+        if (d)
+            return i + ((uint32_t)__builtin_clzll(d) >> 3);
+        i += 8;
+    }
+    while (i < n && xe[-1 - (int)i] == ye[-1 - (int)i])
+        ++i;
+    return i;
+}
+
 struct Walker
 {
     const PathArgs& a;
     const PathGraphDev g;
-    const char* bases;
+    const char* qp;  // the read as this strand sees it (the reverse strand: pg_revcomp_kernel's copy)
     int L;
-    int strand;
 
-    __device__ uint32_t q(int j) const { return strand == 0 ? (uint8_t)bases[j] : comp_raw((uint8_t)bases[L - 1 - j]); }
+    __device__ uint32_t q(int j) const { return (uint8_t)qp[j]; }
     __device__ uint32_t nlen(uint32_t node) const { return a.node_off[g.node_base + node + 1] - a.node_off[g.node_base + node]; }
-    __device__ uint32_t nch(uint32_t node, uint32_t pos) const { return (uint8_t)a.raw[a.node_off[g.node_base + node] + pos]; }
+    __device__ const char* nptr(uint32_t node) const { return a.raw + a.node_off[g.node_base + node]; }
 
     // Extends the seed path `e` anchored at read position qpos (extendPathMatching).  Outputs the final path as
     // (first node, start_pos, last node, end_pos, length, #nodes prepended, #nodes appended) and the new qpos.
@@ -97,11 +160,12 @@ struct Walker
         {
             moved = false;
             const uint32_t len = nlen(node);
-            while (pos_in_query < L && pos_in_node < len && q(pos_in_query) == nch(node, pos_in_node))
+            if (pos_in_query < L && pos_in_node < len)
             {
-                moved = true;
-                ++pos_in_node;
-                ++pos_in_query;
+                const uint32_t m = common_prefix(qp + pos_in_query, nptr(node) + pos_in_node, min((uint32_t)(L - pos_in_query), len - pos_in_node));
+                moved = m != 0;
+                pos_in_node += m;
+                pos_in_query += (int)m;
             }
             if (pos_in_node >= len)
             {
@@ -113,9 +177,7 @@ struct Walker
                 for (uint32_t s = sb; s < se; ++s)
                 {
                     const uint32_t sn = a.succ[s];
-                    uint32_t p = 0;
-                    while (p < min_size && pos_in_query + (int)p < L && nch(sn, p) == q(pos_in_query + (int)p))
-                        ++p;
+                    const uint32_t p = common_prefix(nptr(sn), qp + pos_in_query, min(min_size, (uint32_t)(L - pos_in_query)));
                     if (p > longest)
                     {
                         longest = p;
@@ -147,11 +209,12 @@ struct Walker
         while (moved)
         {
             moved = false;
-            while (pos_in_query > 0 && pos_in_node > 0 && q(pos_in_query - 1) == nch(node, pos_in_node - 1))
+            if (pos_in_query > 0 && pos_in_node > 0)
             {
-                moved = true;
-                --pos_in_node;
-                --pos_in_query;
+                const uint32_t m = common_suffix(qp + pos_in_query, nptr(node) + pos_in_node, min((uint32_t)pos_in_query, pos_in_node));
+                moved = m != 0;
+                pos_in_node -= m;
+                pos_in_query -= (int)m;
             }
             if (pos_in_node == 0)
             {
@@ -163,13 +226,7 @@ struct Walker
                 for (uint32_t s = pb; s < pe; ++s)
                 {
                     const uint32_t pn = a.pred[s];
-                    const uint32_t plen = nlen(pn);
-                    uint32_t pp = plen, ml = 0;
-                    while (pp > plen - min_size && pos_in_query - (int)ml > 0 && nch(pn, pp - 1) == q(pos_in_query - (int)ml - 1))
-                    {
-                        --pp;
-                        ++ml;
-                    }
+                    const uint32_t ml = common_suffix(nptr(pn) + nlen(pn), qp + pos_in_query, min(min_size, (uint32_t)pos_in_query));
                     if (ml > longest)
                     {
                         longest = ml;
@@ -196,11 +253,89 @@ struct Walker
         length = end_query - pos_in_query;
     }
 
+    // hash of q[p .. p + k)
+    __device__ uint64_t hash_at(int p) const
+    {
+        uint64_t h = 0;
+        uint32_t c = 0;
+        for (; c + 8 <= a.k; c += 8)
+        {
+            const uint64_t v = load8(qp + p + (int)c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                h = h * HASH_B + ((v >> (8 * i)) & 0xFFu) + 1;
+        }
+        for (; c < a.k; ++c)
+            h = h * HASH_B + (uint64_t)q(p + (int)c) + 1;
+        return h;
+    }
+
+    // the hash stored in the slot the k-mer with hash h goes to first: 0 = empty, the k-mer is in no path of the graph
+    __device__ uint64_t first_slot_hash(uint64_t h) const
+    {
+        if (h == 0)
+            h = 1;
+        return a.table[g.tab_off + ((uint32_t)(h >> 20) & g.tab_mask)].hash;
+    }
+
+    // pg_kmer_lookup_unique (pg_kmerindex.h) with the k characters compared node by node in runs
     __device__ bool lookup(uint64_t h, int pos, KmerEntry& out) const
     {
-        return pg_kmer_lookup_unique(g, a.table, a.pool, a.node_off, a.raw, h, pos, [&](int j) { return q(j); }, out);
+        if (g.tab_mask == 0xFFFFFFFFu)
+            return false;
+        if (h == 0)
+            h = 1;
+        uint32_t slot = (uint32_t)(h >> 20) & g.tab_mask;
+        for (;;)
+        {
+            const KmerEntry* ep = a.table + g.tab_off + slot;
+            const uint64_t eh = ep->hash;
+            if (eh == 0)
+                return false;
+            if (eh == h)
+            {
+                const KmerEntry e = *ep;
+                if (e.count != 1)
+                    return false;
+                uint32_t ni = 0, p = e.start_pos, c = 0;
+                for (;;)
+                {
+                    const uint32_t node = a.pool[e.pool_off + ni];
+                    const uint32_t seg = min(g.k - c, nlen(node) - p);
+                    if (common_prefix(nptr(node) + p, qp + pos + (int)c, seg) != seg)
+                        return false;
+                    c += seg;
+                    if (c >= g.k)
+                        break;
+                    if (++ni >= e.n_nodes)
+                        return false;
+                    p = 0;
+                }
+                out = e;
+                return true;
+            }
+            slot = (slot + 1) & g.tab_mask;
+        }
     }
 };
+
+// The read as the reverse strand sees it, written at the read's own offset of the second buffer by the thread that goes on to read
+// it (a kernel of its own for this waited for a free slot beside the fills like any kernel does: 0.6 ms, profiles/r05_e2e_modes.json).
+__device__ __forceinline__ void reverse_complement(const char* __restrict__ src, char* __restrict__ dst, int L)
+{
+    int j = 0;
+    for (; j + 8 <= L; j += 8)
+    {
+        const uint64_t v = load8(src + L - 8 - j);
+        uint64_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            o |= (uint64_t)comp_raw((uint32_t)(v >> (8 * (7 - i))) & 0xFFu) << (8 * i);
+        __builtin_memcpy(dst + j, &o, 8);
+    }
+    for (; j < L; ++j)
+        dst[j] = (char)comp_raw((uint8_t)src[L - 1 - j]);
+}
 
 __global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
 {
@@ -218,20 +353,74 @@ __global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
     const PathGraphDev g = a.graphs[a.graph_of_read[r]];
     int n_full = 0, n_matches = 0;
     int first_strand = 0, first_pos = 0;
-    for (int strand = 0; strand < 2; ++strand)
+    const int last = L - (int)a.k;  // the last position a k-mer starts at
+    if (g.tab_mask != 0xFFFFFFFFu)
+        reverse_complement(a.bases + off, a.bases_rc + off, L);
+    for (int strand = 0; strand < 2 && g.tab_mask != 0xFFFFFFFFu; ++strand)
     {
-        Walker w{ a, g, a.bases + off, L, strand };
-        uint64_t h = 0;
-        for (uint32_t c = 0; c < a.k; ++c)
-            h = h * HASH_B + (uint64_t)w.q((int)c) + 1;
+        Walker w{ a, g, (strand == 0 ? a.bases : a.bases_rc) + off, L };
+        uint64_t h = w.hash_at(0);
         int pos = 0;
+        // PathAligner.cpp:92-106 walks the read one position at a time and nearly every position is a miss (the slot its hash goes
+        // to is empty).  Each step was a chain of dependent loads -- two characters for the rolling hash, then the slot -- and the
+        // 64 threads of the wavefront walk in lockstep.  Eight positions per trip: their characters in two loads, their eight slots
+        // probed together; the first one that is not empty gets the full lookup, the ones before it are misses, the ones behind it
+        // are probed again from wherever the walk goes next.  The scan is a loop of its own, so that the threads meet at the lookup
+        // each with a candidate: a wavefront pays for an extension (20 - 60 dependent loads) once per candidate of its busiest
+        // thread, not once per scan step in which any of its threads had one.
         for (;;)
         {
-            KmerEntry e;
-            int next = pos + 1;
-            if (w.lookup(h, pos, e))
+            int at = -1;
+            uint64_t h_first = 0, h_after = 0;
+            while (pos <= last)
             {
-                int qpos = pos;
+                const int nb = min(8, last - pos + 1);
+                uint64_t qo = 0, qi = 0;  // characters leaving / entering the window at pos, pos + 1, ...
+                if (pos + 8 <= last)
+                {
+                    qo = load8(w.qp + pos);
+                    qi = load8(w.qp + pos + (int)a.k);
+                }
+                else
+                    for (int i = 0; i + 1 < nb; ++i)
+                    {
+                        qo |= (uint64_t)w.q(pos + i) << (8 * i);
+                        qi |= (uint64_t)w.q(pos + (int)a.k + i) << (8 * i);
+                    }
+                uint64_t hs[9];
+                hs[0] = h;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    hs[i + 1] = (hs[i] - (((qo >> (8 * i)) & 0xFFu) + 1) * a.pow_k1) * HASH_B + ((qi >> (8 * i)) & 0xFFu) + 1;
+                uint64_t eh[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    eh[i] = w.first_slot_hash(hs[i < nb ? i : 0]);  // (every load unconditional: eight in flight, not eight round trips)
+                int first = nb;
+                h_after = hs[8];  // (all eight miss: nb == 8 and the next window's hash comes from all eight characters of the loads)
+#pragma unroll
+                for (int i = 7; i >= 0; --i)
+                    if (i < nb && eh[i] != 0)
+                    {
+                        first = i;
+                        h_first = hs[i];
+                        h_after = hs[i + 1];
+                    }
+                if (first < nb)
+                {
+                    at = pos + first;
+                    break;
+                }
+                pos += nb;
+                h = h_after;
+            }
+            if (at < 0)
+                break;
+            KmerEntry e;
+            int next = at + 1;
+            if (w.lookup(h_first, at, e))
+            {
+                int qpos = at;
                 uint32_t fn, sp, ep, nl, nr;
                 int len;
                 w.extend<false>(e, qpos, fn, sp, ep, len, nl, nr, nullptr, nullptr);
@@ -241,22 +430,15 @@ __global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
                     if (n_full == 0)
                     {
                         first_strand = strand;
-                        first_pos = pos;
+                        first_pos = at;
                     }
                     ++n_full;
                 }
                 next = qpos + len + 1;  // PathAligner.cpp:104 + the loop increment
             }
-            if (next + (int)a.k > L)
+            if (next > last)
                 break;
-            if (next == pos + 1)
-                h = (h - ((uint64_t)w.q(pos) + 1) * a.pow_k1) * HASH_B + (uint64_t)w.q(pos + (int)a.k) + 1;
-            else
-            {
-                h = 0;
-                for (uint32_t c = 0; c < a.k; ++c)
-                    h = h * HASH_B + (uint64_t)w.q(next + (int)c) + 1;
-            }
+            h = next == at + 1 ? h_after : w.hash_at(next);
             pos = next;
         }
     }
@@ -268,12 +450,9 @@ __global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
         return;
     }
     // ---- second pass over the first full-length match: count nodes, allocate ops, record, emit ----------
-    Walker w{ a, g, a.bases + off, L, first_strand };
-    uint64_t h = 0;
-    for (uint32_t c = 0; c < a.k; ++c)
-        h = h * HASH_B + (uint64_t)w.q(first_pos + (int)c) + 1;
+    Walker w{ a, g, (first_strand == 0 ? a.bases : a.bases_rc) + off, L };
     KmerEntry e;
-    w.lookup(h, first_pos, e);
+    w.lookup(w.hash_at(first_pos), first_pos, e);
     int qpos = first_pos;
     uint32_t fn, sp, ep, nl, nr;
     int len;
@@ -755,14 +934,28 @@ extern "C" pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* b)
     // The path stage runs on the SEED stream (one priority level up, like the second stream), not behind the fills queued on the
     // main one nor behind the tracebacks that wait for them on the second: it is 0.2 ms of work per batch whose outcome -- after
     // the count pass and the hand-over, which follow it onto this stream -- decides what the batch's fills are.
-    const hipStream_t ps = ctx->stream_seed;
+    const unsigned turn = ctx->seed_streams > 1 ? ctx->seed_turn++ % (unsigned)ctx->seed_streams : 0u;
+    if (turn && !ctx->stream_seed_more[turn - 1])
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream_seed_more[turn - 1], hipStreamNonBlocking, ctx->side_priority));
+    const hipStream_t ps = turn ? ctx->stream_seed_more[turn - 1] : ctx->stream_seed;
+    b->seed_stream = ps;
     b->seed_chain = true;
     HIP_TRY(ctx, pg_stage_begin_on(ctx, b, ps));
     HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ps));
     if (b->n_reads)
         HIP_TRY(ctx, hipMemsetAsync(b->d_path_flags, 0, b->n_reads, ps));
+    if (b->cap_bases_rc < b->cap_bases)  // (the reverse strand's copy of the reads: each thread of the kernel writes its own)
+    {
+        HIP_TRY(ctx, pg_batch_wait(ctx, b));
+        (void)pg_dev_free(b->d_bases_rc);
+        b->d_bases_rc = nullptr;
+        b->cap_bases_rc = 0;
+        HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_bases_rc, b->cap_bases));
+        b->cap_bases_rc = b->cap_bases;
+    }
     PathArgs a{};
     a.n_reads = b->n_reads;
+    a.bases_rc = b->d_bases_rc;
     a.k = ix->k;
     a.pow_k1 = ix->pow_k1;
     a.base_off = b->d_base_off;

@@ -63,7 +63,7 @@ struct KmerArgs
     uint8_t* flags;
     const uint8_t* active;  // nullptr = every read
     // dynamic LDS layout (sized by the batch's longest read and the index's longest path)
-    uint32_t n_sort;    // k-mer windows per strand, padded to a power of two
+    uint32_t n_tab;     // slots of a strand's k-mer table: a power of two, at least 4/3 of the longest read's windows
     uint32_t l_max;     // longest read, padded to a multiple of 4
     uint32_t bm_words;  // candidate-offset bitmap
     uint32_t cache_n;   // path-table entries cached in LDS (paths with more k-mers are searched in global memory)
@@ -224,19 +224,18 @@ __device__ void heap_pop(Cand* h, int& n)
     n = len;
 }
 
-constexpr int KMER_SORT_MAX = 512;  // windows per strand (reads <= 512 bp)
+constexpr int KMER_READ_MAX = 512;  // reads beyond 512 bases are left to the later stages
 
-// One WAVEFRONT per read.  The read and its reverse complement are staged in LDS; per strand the (k-mer, position) pairs are
-// produced by the 64 lanes and sorted in LDS (bitonic, 64-bit keys, both strands in the same passes); each path's sorted
-// table is cached in LDS and joined in parallel: lane j takes sorted entry j, and -- this is the reference's single-cursor
-// merge (KmerAligner.cpp:246-276) -- only the FIRST read occurrence of a k-mer value joins, with every path entry of that
-// value.  Candidate diagonals go into an LDS bitmap, are visited in ascending offset, scored by a wave-wide Hamming
+// One WAVEFRONT per read.  The read and its reverse complement are staged in LDS; per strand the 64 lanes put the read's k-mers
+// into an LDS table (k-mer value -> first position); each path's sorted table is cached in LDS and joined in parallel: lane j
+// takes table entries j, j + 64, ... and -- this is the reference's single-cursor merge (KmerAligner.cpp:246-276) -- only the
+// FIRST read occurrence of a k-mer value joins, with every path entry of that value.  Candidate diagonals go into an LDS bitmap, are visited in ascending offset, scored by a wave-wide Hamming
 // distance and pushed into the bounded heap by lane 0 (libstdc++ element order).
 __global__ __launch_bounds__(64) void pg_kmer_kernel(KmerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char kmer_lds[];
-    unsigned long long* skey0 = (unsigned long long*)kmer_lds;       // [2][n_sort] sorted (k-mer << 32 | position)
-    uint32_t* slab0 = (uint32_t*)(skey0 + 2 * a.n_sort);            // [2][l_max] per-position labels (best / rival)
+    unsigned long long* skey0 = (unsigned long long*)kmer_lds;       // [2][n_tab] (k-mer << 32 | first position), ~0 = empty
+    uint32_t* slab0 = (uint32_t*)(skey0 + 2 * a.n_tab);             // [2][l_max] per-position labels (best / rival)
     uint32_t* sbm = slab0 + 2 * a.l_max;                            // [bm_words]
     uint32_t* spk = sbm + a.bm_words;                               // [cache_n] path k-mers
     uint32_t* spp = spk + a.cache_n;                                // [cache_n] path positions
@@ -272,51 +271,66 @@ __global__ __launch_bounds__(64) void pg_kmer_kernel(KmerArgs a)
     __syncthreads();
 
     const int n_win = L >= K ? L - K + 1 : 0;
-    int N = 64;
-    while (N < n_win)
-        N <<= 1;
-    // ---- sorted (k-mer, position) pairs of both strands (KmerAligner.cpp:120-133) ------------------------------------
-    for (int i2 = lane; i2 < 2 * N; i2 += 64)
-    {
-        const int strand = i2 >= N ? 1 : 0, i = i2 - strand * N;
-        unsigned long long key = ~0ull;
-        if (i < n_win)
-        {
-            uint32_t val = 0;
-            bool ok = true;
-            for (int c = 0; c < K; ++c)
-            {
-                const uint32_t bb = base2(rv.at(i + c, strand != 0));
-                ok = ok && bb <= 3;
-                val = (val << 2) | (bb & 3u);
-            }
-            if (ok)
-                key = ((unsigned long long)val << 32) | (uint32_t)i;
-        }
-        skey0[strand * a.n_sort + i] = key;
-    }
+    // ---- the read's k-mers (KmerAligner.cpp:120-133), one table per strand: k-mer value -> its FIRST position ---------------
+    // The reference sorts (k-mer, position) pairs and walks them beside the path's sorted table with one cursor (:246-276): of
+    // the read's occurrences of a k-mer value only the first one in that order -- the smallest position -- meets the path's
+    // entries.  That is all the order is used for, so the pairs are not sorted here (a bitonic sort of 2 x 256 keys in LDS was
+    // 36 passes, four fifths of the kernel's instructions): each strand's windows go into an open-addressing table keyed by the
+    // k-mer value, equal values keep the smaller position (64-bit minimum on value << 32 | position), and the join below takes
+    // the table's entries in whatever order they sit -- it only sets bits.
+    const int T = (int)a.n_tab;
+    const uint32_t tshift = 32u - (uint32_t)__builtin_ctz((uint32_t)T);
+    for (int i = lane; i < 2 * T; i += 64)
+        skey0[i] = ~0ull;
     __syncthreads();
-    for (int k2 = 2; k2 <= N; k2 <<= 1)
-        for (int j = k2 >> 1; j > 0; j >>= 1)
+    {
+        // a lane takes a run of consecutive windows: the value rolls on by one base per window
+        const int per_lane = (n_win + 63) / 64;
+        const int s = lane * per_lane, e = min(s + per_lane, n_win);
+        const uint32_t vmask = K < 16 ? (1u << (2 * K)) - 1u : 0xFFFFFFFFu;
+        for (int strand = 0; strand < 2 && s < e; ++strand)
         {
-            for (int i2 = lane; i2 < 2 * N; i2 += 64)
+            unsigned long long* tab = skey0 + strand * T;
+            uint32_t val = 0;
+            int run = 0;  // consecutive bases of ACGT ending at the last one taken
+            for (int j = s; j < e + K - 1; ++j)
             {
-                const int strand = i2 >= N ? 1 : 0, i = i2 - strand * N;
-                unsigned long long* skey = skey0 + strand * a.n_sort;
-                const int ixj = i ^ j;
-                if (ixj > i)
+                const uint32_t bb = base2(rv.at(j, strand != 0));
+                if (bb <= 3u)
                 {
-                    const unsigned long long x = skey[i], y = skey[ixj];
-                    const bool asc = (i & k2) == 0;
-                    if ((x > y) == asc)
+                    val = ((val << 2) | bb) & vmask;
+                    ++run;
+                }
+                else
+                {
+                    val = 0;
+                    run = 0;
+                }
+                const int i = j - (K - 1);  // the window that ends here
+                if (i < s || run < K)
+                    continue;
+                const unsigned long long key = ((unsigned long long)val << 32) | (uint32_t)i;
+                uint32_t slot = (val * 0x9E3779B1u) >> tshift;
+                for (;;)
+                {
+                    unsigned long long cur = tab[slot];
+                    if (cur == ~0ull)
                     {
-                        skey[i] = y;
-                        skey[ixj] = x;
+                        cur = atomicCAS(&tab[slot], ~0ull, key);
+                        if (cur == ~0ull)
+                            break;
                     }
+                    if ((uint32_t)(cur >> 32) == val)
+                    {
+                        atomicMin(&tab[slot], key);
+                        break;
+                    }
+                    slot = (slot + 1u) & (uint32_t)(T - 1);
                 }
             }
-            __syncthreads();
         }
+    }
+    __syncthreads();
     // candidates are pushed path by path, forward strand first (KmerAligner.cpp:524-531): the heap's element order depends on it
     for (uint32_t pi = 0; pi < g.n_paths; ++pi)
     {
@@ -340,19 +354,17 @@ __global__ __launch_bounds__(64) void pg_kmer_kernel(KmerArgs a)
         for (int strand = 0; strand < 2; ++strand)
         {
             const bool reverse = strand != 0;
-            const unsigned long long* skey = skey0 + strand * a.n_sort;
+            const unsigned long long* skey = skey0 + strand * T;
             for (uint32_t w = lane; w < words; w += 64)
                 bm[w] = 0;
             __syncthreads();
             // ---- merge-join ---------------------------------------------------------------------------------------
-            for (int j = lane; j < N; j += 64)
+            for (int j = lane; j < T; j += 64)
             {
                 const unsigned long long key = skey[j];
                 if (key == ~0ull)
                     continue;
-                const uint32_t km = (uint32_t)(key >> 32), sp = (uint32_t)key;
-                if (j > 0 && (uint32_t)(skey[j - 1] >> 32) == km)
-                    continue;  // a later read occurrence of the same k-mer: the reference's cursor is already past it
+                const uint32_t km = (uint32_t)(key >> 32), sp = (uint32_t)key;  // (sp: the read's first occurrence of this k-mer)
                 uint32_t lo = 0, hi = p.n_kmers;
                 while (lo < hi)
                 {
@@ -660,17 +672,18 @@ extern "C" pg_status pg_batch_kmer_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     for (uint32_t i = 0; i < b->n_reads; ++i)
     {
         const uint32_t L = b->h_base_off[i + 1] - b->h_base_off[i];
-        if (L <= (uint32_t)KMER_SORT_MAX)
+        if (L <= (uint32_t)KMER_READ_MAX)
             max_len = std::max(max_len, L);
     }
     a.l_max = (max_len + 3u) & ~3u;
-    a.n_sort = 64;
-    while (a.n_sort < max_len)
-        a.n_sort <<= 1;
+    const uint32_t n_win_max = max_len >= ix->k ? max_len - ix->k + 1 : 0;
+    a.n_tab = 64;
+    while (a.n_tab * 3 < n_win_max * 4)
+        a.n_tab <<= 1;
     a.bm_words = words;
     a.cache_n = std::min<uint32_t>(ix->max_path_kmers, 2048u);
     a.heap_cap = (ix->max_paths + 2 + 1u) & ~1u;  // (even: keeps what follows 8-byte aligned whatever sizeof(Cand) is)
-    const size_t lds = (size_t)2 * a.n_sort * 8 + (size_t)2 * a.l_max * 4 + (size_t)a.bm_words * 4 + (size_t)2 * a.cache_n * 4
+    const size_t lds = (size_t)2 * a.n_tab * 8 + (size_t)2 * a.l_max * 4 + (size_t)a.bm_words * 4 + (size_t)2 * a.cache_n * 4
         + (size_t)a.heap_cap * sizeof(Cand) + 16 + (size_t)2 * a.l_max;
     if (b->n_reads)
     {

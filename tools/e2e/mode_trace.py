@@ -64,7 +64,7 @@ def summary():
                 continue
             b, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
             ov = sum(max(0, min(e, fe) - max(b, fb)) for fb, fe in fills if fe > b and fb < e)
-            rows.append(((e - b) / 1e3, min(1.0, ov / max(1, e - b)), int(r.get("Grid_Size", 0) or 0)))
+            rows.append(((e - b) / 1e3, min(1.0, ov / max(1, e - b)), int(r.get("Grid_Size_X", 0) or 0)))
         if rows:
             alone = sorted(d for d, o, g in rows if o < 0.05)
             under = sorted(d for d, o, g in rows if o > 0.95)
@@ -72,7 +72,18 @@ def summary():
             beside[want] = {"launches": len(rows), "no_fill_running": {"n": len(alone), "median_us": med(alone)},
                             "a_fill_running_throughout": {"n": len(under), "median_us": med(under)},
                             "median_grid_threads": sorted(g for d, o, g in rows)[len(rows) // 2]}
-    print(json.dumps({"ms_per_pass_wall": s_per_pass * 1e3, "ms_per_pass_with_a_kernel_running": busy / 1e6 / passes,
+    # the fill launches: wavefronts (= workgroups) per launch against the 4 096 the device holds at once (256 CUs x 4 SIMDs x 4)
+    fl = [((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, int(r.get("Grid_Size_X", 0) or 0) // 64)
+          for r in csv.DictReader(open(f)) if "pg_fill_kernel" in r["Kernel_Name"]]
+    fill_launches = None
+    if fl:
+        w = sorted(g for d, g in fl)
+        d = sorted(d for d, g in fl)
+        q = lambda v, f: v[min(len(v) - 1, int(f * len(v)))]
+        fill_launches = {"launches": len(fl), "wavefronts": {"p10": q(w, 0.1), "median": q(w, 0.5), "p90": q(w, 0.9), "sum_per_pass": sum(w) / passes},
+                         "us": {"p10": round(q(d, 0.1), 1), "median": round(q(d, 0.5), 1), "p90": round(q(d, 0.9), 1)},
+                         "wavefront_slots": 4096}
+    print(json.dumps({"fill_launches": fill_launches, "ms_per_pass_wall": s_per_pass * 1e3, "ms_per_pass_with_a_kernel_running": busy / 1e6 / passes,
                       "kernel_ms_per_pass": {k: round(tot[k] / passes, 2) for k in top},
                       "launches_per_pass": {k: round(cnt[k] / passes, 1) for k in top},
                       "avg_us": {k: round(tot[k] / cnt[k] * 1e3, 1) for k in top}, "beside_the_fills": beside}, indent=1))

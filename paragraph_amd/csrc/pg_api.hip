@@ -515,7 +515,7 @@ hipError_t pg_stage_end_on(pg_ctx* ctx, pg_batch* b, hipStream_t s)
         const int w = s == ctx->stream ? 0 : ctx->is_seed_stream(s) ? 2 : 1;
         hipError_t e = hipSuccess;
         if (!G->ev_use[w])
-            e = hipEventCreateWithFlags(&G->ev_use[w], hipEventDisableTiming);
+            e = hipEventCreateWithFlags(&G->ev_use[w], pg_wait_event_flags());
         if (e == hipSuccess)
             e = hipEventRecord(G->ev_use[w], s);
         if (e != hipSuccess)
@@ -530,6 +530,20 @@ hipError_t pg_stage_end_on(pg_ctx* ctx, pg_batch* b, hipStream_t s)
 
 hipError_t pg_stage_begin(pg_ctx* ctx, pg_batch* b) { return pg_stage_begin_on(ctx, b, ctx->stream); }
 hipError_t pg_stage_end(pg_ctx* ctx, pg_batch* b) { return pg_stage_end_on(ctx, b, ctx->stream); }
+
+unsigned pg_wait_event_flags()
+{
+    static const bool spin = getenv("PG_SPIN_WAITS") != nullptr;
+    return hipEventDisableTiming | (spin ? 0u : (unsigned)hipEventBlockingSync);
+}
+
+hipError_t pg_wait_stream(pg_batch* b, hipStream_t s)
+{
+    if (!b || !b->ev_host)
+        return hipStreamSynchronize(s);
+    const hipError_t e = hipEventRecord(b->ev_host, s);
+    return e != hipSuccess ? e : hipEventSynchronize(b->ev_host);
+}
 
 hipError_t pg_batch_wait(pg_ctx* ctx, pg_batch* b)
 {
@@ -925,8 +939,9 @@ extern "C" pg_status pg_batch_create(pg_ctx* ctx, pg_batch** out)
     *out = new (std::nothrow) pg_batch();
     if (!*out)
         return PG_ERR_NOMEM;
-    if (hipSetDevice(ctx->device) != hipSuccess || hipEventCreateWithFlags(&(*out)->ev_upload, hipEventDisableTiming) != hipSuccess
-        || hipEventCreateWithFlags(&(*out)->ev_busy, hipEventDisableTiming) != hipSuccess)
+    if (hipSetDevice(ctx->device) != hipSuccess || hipEventCreateWithFlags(&(*out)->ev_upload, pg_wait_event_flags()) != hipSuccess
+        || hipEventCreateWithFlags(&(*out)->ev_busy, pg_wait_event_flags()) != hipSuccess
+        || hipEventCreateWithFlags(&(*out)->ev_host, pg_wait_event_flags()) != hipSuccess)
     {
         delete *out;
         *out = nullptr;
@@ -1014,6 +1029,8 @@ extern "C" void pg_batch_destroy(pg_ctx* ctx, pg_batch* b)
         (void)hipHostFree(b->h_counters);
     if (b->ev_upload)
         (void)hipEventDestroy(b->ev_upload);
+    if (b->ev_host)
+        (void)hipEventDestroy(b->ev_host);
     if (b->ev_busy)
         (void)hipEventDestroy(b->ev_busy);
     delete b;
@@ -1253,7 +1270,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
     }
     if (!items.empty())
         HIP_TRY(ctx, hipMemcpyAsync(b->d_items, items.data(), items.size() * sizeof(PgWorkItem), hipMemcpyHostToDevice, cs));
-    HIP_TRY(ctx, hipStreamSynchronize(cs));  // `items` goes out of scope
+    HIP_TRY(ctx, pg_wait_stream(b, cs));  // `items` goes out of scope
     return PG_OK;
 }
 

@@ -676,7 +676,7 @@ extern "C" pg_status pg_batch_set_fragments(
         else
             HIP_TRY(ctx, hipMemsetAsync(b->d_is_rev, 0, n, ctx->stream_copy));
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));  // `order` / `frag_off` are host temporaries
+    HIP_TRY(ctx, pg_wait_stream(b, ctx->stream_copy));  // `order` / `frag_off` are host temporaries
     if (b->ev_upload)
     {
         HIP_TRY(ctx, hipEventRecord(b->ev_upload, ctx->stream_copy));
@@ -848,7 +848,7 @@ extern "C" pg_status pg_batch_download_all(
         layout_of(b->graphs, &lay);
         HIP_TRY(ctx, hipMemcpyAsync(counts, b->d_counts, lay.n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
     }
-    HIP_TRY(ctx, hipStreamSynchronize(cs));
+    HIP_TRY(ctx, pg_wait_stream(b, cs));
     return PG_OK;
 }
 

@@ -227,6 +227,7 @@ struct pg_batch
     // ---- batch pipelining: uploads run on ctx->stream_copy, kernels on ctx->stream
     hipEvent_t ev_upload = nullptr;  // recorded on stream_copy when the batch's inputs are resident
     hipEvent_t ev_busy = nullptr;    // recorded on stream after the last stage queued for this batch
+    hipEvent_t ev_host = nullptr;    // what the host waits on where it used to synchronise a stream (pg_wait_stream)
     bool upload_recorded = false, busy_recorded = false;
 };
 
@@ -240,6 +241,12 @@ hipError_t pg_stage_end(pg_ctx* ctx, pg_batch* b);
 hipError_t pg_stage_begin_on(pg_ctx* ctx, pg_batch* b, hipStream_t s);
 hipError_t pg_stage_end_on(pg_ctx* ctx, pg_batch* b, hipStream_t s);
 hipError_t pg_batch_wait(pg_ctx* ctx, pg_batch* b);
+// Host waits.  A lane waits for its batch for milliseconds while the other lanes need its CPU: the events a host thread waits on
+// are made with hipEventBlockingSync (the thread sleeps until the completion interrupt) unless PG_SPIN_WAITS is set -- the
+// device-wide hipDeviceScheduleBlockingSync (pg_device_prefer_blocking_waits) is refused once the device is in use, which it
+// always is in a process that imported torch before it came here.  pg_wait_stream: hipStreamSynchronize by the same rule.
+unsigned pg_wait_event_flags();
+hipError_t pg_wait_stream(pg_batch* b, hipStream_t s);
 // the work items follow d_active: pg_batch_retire_mapped re-writes them on the device; this is for the cases it leaves (a batch with
 // general-path reads, pg_batch_set_active(NULL) after a hand-over) -- called by the stages that run work items, on `stream`
 pg_status pg_batch_ensure_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream);

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <new>
 #include <chrono>
+#include <map>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -531,6 +532,48 @@ hipError_t pg_stage_end_on(pg_ctx* ctx, pg_batch* b, hipStream_t s)
 hipError_t pg_stage_begin(pg_ctx* ctx, pg_batch* b) { return pg_stage_begin_on(ctx, b, ctx->stream); }
 hipError_t pg_stage_end(pg_ctx* ctx, pg_batch* b) { return pg_stage_end_on(ctx, b, ctx->stream); }
 
+bool pg_api_timing = getenv("PG_API_TIMING") != nullptr;
+uint64_t pg_now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+namespace
+{
+struct ApiTimes
+{
+    std::mutex m;
+    std::unordered_map<const char*, std::pair<uint64_t, uint64_t>> by_site;  // call text (a literal: its address is the key) -> (ns, calls)
+    ~ApiTimes()
+    {
+        if (by_site.empty())
+            return;
+        std::map<std::string, std::pair<uint64_t, uint64_t>> merged;
+        for (auto const& kv : by_site)
+        {
+            merged[kv.first].first += kv.second.first;
+            merged[kv.first].second += kv.second.second;
+        }
+        std::vector<std::pair<std::string, std::pair<uint64_t, uint64_t>>> rows(merged.begin(), merged.end());
+        std::sort(rows.begin(), rows.end(), [](auto const& a, auto const& b) { return a.second.first > b.second.first; });
+        fprintf(stderr, "[PG_API_TIMING] host time per call site (ms total, calls, us per call)\n");
+        for (auto const& r : rows)
+            fprintf(stderr, "[PG_API_TIMING] %10.2f %8llu %9.1f  %s\n", r.second.first / 1e6, (unsigned long long)r.second.second,
+                    r.second.first / 1e3 / (double)std::max<uint64_t>(1, r.second.second), r.first.c_str());
+    }
+};
+ApiTimes& apiTimes()
+{
+    static ApiTimes t;
+    return t;
+}
+}  // namespace
+void pg_api_time_add(const char* what, uint64_t t0_ns)
+{
+    const uint64_t dt = pg_now_ns() - t0_ns;
+    ApiTimes& t = apiTimes();
+    std::lock_guard<std::mutex> lock(t.m);
+    auto& e = t.by_site[what];
+    e.first += dt;
+    e.second += 1;
+}
+
 unsigned pg_wait_event_flags()
 {
     static const bool spin = getenv("PG_SPIN_WAITS") != nullptr;
@@ -952,6 +995,9 @@ extern "C" pg_status pg_batch_create(pg_ctx* ctx, pg_batch** out)
 
 static void batch_free_device(pg_batch* b)
 {
+    for (void* p : b->parked_blocks)
+        (void)pg_dev_free(p);
+    b->parked_blocks.clear();
     (void)pg_dev_free(b->d_base_off);
     (void)pg_dev_free(b->d_bases);
     (void)pg_dev_free(b->d_bases_rc);
@@ -1430,6 +1476,13 @@ extern "C" pg_status pg_batch_upload(
     hipStream_t cs = ctx->stream_copy;
     if (b->busy_recorded)
         HIP_TRY(ctx, hipStreamWaitEvent(cs, b->ev_busy, 0));
+    if (!b->parked_blocks.empty())  // what the stages of the last use outgrew (the batch is idle by now: the wait returns at once)
+    {
+        HIP_TRY(ctx, pg_batch_wait(ctx, b));
+        for (void* p : b->parked_blocks)
+            (void)pg_dev_free(p);
+        b->parked_blocks.clear();
+    }
     b->graphs = G;
     b->n_reads = n_reads;
     b->has_skipped = false;
@@ -1740,8 +1793,8 @@ static pg_status cascade_full_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream)
     b->full_max_ws = max_ws;
     if (segs.size() > b->cap_segments)
     {
-        HIP_TRY(ctx, pg_batch_wait(ctx, b));
-        (void)pg_dev_free(b->d_segments);
+        b->park(b->d_segments);  // (no wait under the caller's device lock: pg_internal.h, parked_blocks)
+        b->d_segments = nullptr;
         b->cap_segments = segs.size() + segs.size() / 4 + 16;
         HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_segments, b->cap_segments * sizeof(PgPlanSegment)));
     }
@@ -1766,11 +1819,11 @@ static pg_status cascade_rebuild_items(pg_ctx* ctx, pg_batch* b, hipStream_t str
     }
     if (n_groups > b->cap_groups || n > b->cap_cascade_reads)
     {
-        HIP_TRY(ctx, pg_batch_wait(ctx, b));
-        (void)pg_dev_free(b->d_group_of_read2);
-        (void)pg_dev_free(b->d_group_base);
-        (void)pg_dev_free(b->d_group_count);
-        (void)pg_dev_free(b->d_active_list);
+        b->park(b->d_group_of_read2);
+        b->park(b->d_group_base);
+        b->park(b->d_group_count);
+        b->park(b->d_active_list);
+        b->d_group_of_read2 = b->d_group_base = b->d_group_count = b->d_active_list = nullptr;
         b->cap_groups = n_groups;
         b->cap_cascade_reads = n;
         HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_group_of_read2, (size_t)n * sizeof(uint32_t)));
@@ -1857,10 +1910,14 @@ pg_status pg_batch_ensure_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream)
 
 extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
 {
+    PG_TIMED("pg_batch_align (whole call)");
     if (!ctx || !b || !b->graphs)
         return fail(ctx, PG_ERR_INVALID, "pg_batch_align: batch not uploaded");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    recycle_done_sync_events(ctx);
+    {
+        PG_TIMED("recycle_done_sync_events");
+        recycle_done_sync_events(ctx);
+    }
     const pg_graphs* G = b->graphs;
     {
         const auto t0 = std::chrono::steady_clock::now();

@@ -688,6 +688,7 @@ extern "C" pg_status pg_batch_set_fragments(
 
 extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_params* params, uint32_t* d_counts)
 {
+    PG_TIMED("pg_batch_count (whole call)");
     if (!ctx || !b || !b->graphs || !params)
         return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_count: null argument");
     const pg_graphs* G = b->graphs;
@@ -713,8 +714,8 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     {
         if (lay.n_counters > b->cap_counts)
         {
-            HIP_TRY(ctx, pg_batch_wait(ctx, b));
-            (void)pg_dev_free(b->d_counts);
+            b->park(b->d_counts);  // (no wait: pg_internal.h, parked_blocks)
+            b->d_counts = nullptr;
             b->cap_counts = lay.n_counters;
             HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_counts, lay.n_counters * sizeof(uint32_t)));
         }
@@ -747,8 +748,7 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
         const size_t need = std::max<size_t>(n, 1) * b->label_ext_words;
         if (need > b->cap_label_ext)
         {
-            HIP_TRY(ctx, pg_batch_wait(ctx, b));
-            (void)pg_dev_free(b->d_label_ext);
+            b->park(b->d_label_ext);
             b->d_label_ext = nullptr;
             b->cap_label_ext = 0;
             HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_label_ext, need * sizeof(uint64_t)));
@@ -780,6 +780,7 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     }
     if (n)
     {
+        PG_TIMED("launch pg_support_kernel + pg_fragment_kernel");
         hipLaunchKernelGGL(pg_support_kernel, dim3((n + 63) / 64), dim3(64), 0, cs, a);
         HIP_TRY(ctx, hipGetLastError());
         hipLaunchKernelGGL(pg_fragment_kernel, dim3((b->n_frags + FRAG_BLOCK - 1) / FRAG_BLOCK), dim3(FRAG_BLOCK),

@@ -227,6 +227,17 @@ struct pg_batch
     // ---- batch pipelining: uploads run on ctx->stream_copy, kernels on ctx->stream
     hipEvent_t ev_upload = nullptr;  // recorded on stream_copy when the batch's inputs are resident
     hipEvent_t ev_busy = nullptr;    // recorded on stream after the last stage queued for this batch
+    // Device blocks a STAGE call outgrew (count table, label sets, the cascade's lists): a stage runs under the caller's device lock
+    // with the batch's earlier stages still on the device, so it must not wait for them before it frees -- it parks the old block
+    // here and takes a new one; pg_batch_upload (the batch is idle then) and pg_batch_destroy free what is parked.  (The wait that
+    // used to stand there held the lock of a 24-lane workflow for the length of the batch's fills: 27 % of its batches, 87 ms of a
+    // 145 ms pass, PG_API_TIMING.)
+    std::vector<void*> parked_blocks;
+    void park(void* p)
+    {
+        if (p)
+            parked_blocks.push_back(p);
+    }
     hipEvent_t ev_host = nullptr;    // what the host waits on where it used to synchronise a stream (pg_wait_stream)
     bool upload_recorded = false, busy_recorded = false;
 };
@@ -283,10 +294,31 @@ void pg_pinned_put(void* p, size_t cap);
 
 pg_status pg_fail(pg_ctx* ctx, pg_status st, const std::string& msg);
 
+// PG_API_TIMING=1: host time of every runtime call made through HIP_TRY (and of the scopes marked PG_TIMED), summed per call site
+// text and printed when the process ends -- what a lane's device section costs the host, call by call
+extern bool pg_api_timing;
+uint64_t pg_now_ns();
+void pg_api_time_add(const char* what, uint64_t t0_ns);
+struct PgTimedScope
+{
+    const char* what;
+    uint64_t t0;
+    explicit PgTimedScope(const char* w) : what(w), t0(pg_api_timing ? pg_now_ns() : 0) {}
+    ~PgTimedScope()
+    {
+        if (pg_api_timing)
+            pg_api_time_add(what, t0);
+    }
+};
+#define PG_TIMED(label) PgTimedScope pg_timed_scope__(label)
+
 #define HIP_TRY(ctx, call)                                                                                     \
     do                                                                                                         \
     {                                                                                                          \
+        const uint64_t t0__ = pg_api_timing ? pg_now_ns() : 0;                                                 \
         hipError_t e__ = (call);                                                                               \
+        if (pg_api_timing)                                                                                     \
+            pg_api_time_add(#call, t0__);                                                                      \
         if (e__ != hipSuccess)                                                                                 \
             return pg_fail(ctx, e__ == hipErrorOutOfMemory ? PG_ERR_NOMEM : PG_ERR_HIP,                          \
                            std::string(#call) + ": " + hipGetErrorString(e__));                                \

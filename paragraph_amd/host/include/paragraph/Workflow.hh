@@ -9,6 +9,7 @@
 #pragma once
 #include <list>
 #include <memory>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -149,6 +150,9 @@ struct Parameters
     // not serialise 40 MB on one thread after the last lane has finished.
     std::vector<std::string>* genotype_text = nullptr;
     int genotype_text_indent = -1;   // Json::dump's indent: < 0 one line
+    // called by a lane when the texts of graphs [first, last) are in *genotype_text (any order of ranges, from any lane's thread):
+    // a caller that writes the documents out in order can do so while the other lanes work (pgw_genotype_graphs does)
+    std::function<void(size_t first, size_t last)> genotype_text_ready;
 };
 
 // extraction + alignment + counting of ONE sample against ONE graph; stores the count document in the sample

@@ -1079,6 +1079,8 @@ std::vector<Json> genotypeGraphs(
                         genotypes[g0 + g] = Json();
                     }
                 });
+                if (parameters.genotype_text && parameters.genotype_text_ready)
+                    parameters.genotype_text_ready(g0, g0 + f.n_here);
                 phase(f.c, "genotypes");
                 const double t_release = now();
                 // the lane frees what it allocated itself (a helper thread doing it met the lanes in the allocator's arena locks)
@@ -1228,26 +1230,52 @@ extern "C" int pgw_genotype_graphs(
         }
         std::vector<std::string> graphs(graph_paths, graph_paths + n_graphs);
         const genotyping::Samples samples = genotyping::loadManifest(manifest);
-        std::vector<std::string> text;  // every document serialised by the lane that made it (Parameters::genotype_text)
+        // Every document is serialised by the lane that made it (Parameters::genotype_text) and written out -- in graph order -- by
+        // whichever lane completes the next stretch of the order, while the other lanes work: joining 10 000 texts into one string
+        // and writing it after the last lane had finished was 40 ms of one thread at the end of a 135 ms job.
+        std::vector<std::string> text;
         parameters.genotype_text = &text;
-        grmpy::genotypeGraphs(parameters, graphs, reference_fasta, samples, genotyping_parameters ? genotyping_parameters : "");
-        size_t bytes = 4;
-        for (auto const& t : text)
-            bytes += t.size() + 2;
-        std::string all;
-        all.reserve(bytes);
-        all += "[";
-        for (size_t g = 0; g < text.size(); ++g)
-        {
-            all += g ? ",\n" : "\n";
-            all += text[g];
-        }
-        all += "\n]\n";
         FILE* out = fopen(output_path, "wb");
         if (!out)
             return report(std::string("cannot write ") + output_path);
-        const bool ok = fwrite(all.data(), 1, all.size(), out) == all.size();
-        if (fclose(out) != 0 || !ok)
+        std::vector<char> buffer(1 << 20);
+        setvbuf(out, buffer.data(), _IOFBF, buffer.size());
+        struct Ordered
+        {
+            std::mutex m;
+            std::vector<char> ready;
+            size_t next = 0;
+            bool ok = true;
+        } ordered;
+        ordered.ready.assign(n_graphs, 0);
+        ordered.ok = fputc('[', out) != EOF;
+        auto flush = [&](size_t first, size_t last) {
+            std::lock_guard<std::mutex> lock(ordered.m);
+            for (size_t g = first; g < last && g < ordered.ready.size(); ++g)
+                ordered.ready[g] = 1;
+            while (ordered.next < text.size() && ordered.ready[ordered.next])
+            {
+                std::string& t = text[ordered.next];
+                const char* sep = ordered.next ? ",\n" : "\n";
+                ordered.ok = ordered.ok && fputs(sep, out) != EOF && fwrite(t.data(), 1, t.size(), out) == t.size();
+                std::string().swap(t);
+                ++ordered.next;
+            }
+        };
+        parameters.genotype_text_ready = flush;
+        try
+        {
+            grmpy::genotypeGraphs(parameters, graphs, reference_fasta, samples, genotyping_parameters ? genotyping_parameters : "");
+        }
+        catch (...)
+        {
+            fclose(out);
+            remove(output_path);  // (half a document array is worse than none)
+            throw;
+        }
+        flush(0, n_graphs);  // (whatever a path without lanes left: a single chunk, no graphs at all)
+        ordered.ok = ordered.ok && fputs("\n]\n", out) != EOF;
+        if (fclose(out) != 0 || !ordered.ok)
             return report(std::string("error while writing ") + output_path);
         return 0;
     }

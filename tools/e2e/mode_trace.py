@@ -83,7 +83,28 @@ def summary():
         fill_launches = {"launches": len(fl), "wavefronts": {"p10": q(w, 0.1), "median": q(w, 0.5), "p90": q(w, 0.9), "sum_per_pass": sum(w) / passes},
                          "us": {"p10": round(q(d, 0.1), 1), "median": round(q(d, 0.5), 1), "p90": round(q(d, 0.9), 1)},
                          "wavefront_slots": 4096}
-    print(json.dumps({"fill_launches": fill_launches, "ms_per_pass_wall": s_per_pass * 1e3, "ms_per_pass_with_a_kernel_running": busy / 1e6 / passes,
+    # between two fills: how long, and what ran meanwhile (the fill stream is in order: the next fill was either not queued yet, or
+    # waiting for its batch's upload / for a workspace region a traceback still reads)
+    allk = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f)))
+    fk = [k for k in allk if "pg_fill_kernel" in k[2]]
+    gaps = []
+    for (b0, e0, _), (b1, e1, _) in zip(fk, fk[1:]):
+        if b1 > e0 and b1 - e0 < 20e6:  # (not the pause between passes)
+            inside = collections.Counter()
+            for b, e, n in allk:
+                if e > e0 and b < b1 and "pg_fill_kernel" not in n:
+                    inside[n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]] += min(e, b1) - max(b, e0)
+            gaps.append((b1 - e0, inside))
+    gap_summary = None
+    if gaps:
+        g = sorted(x for x, _ in gaps)
+        tot_busy = collections.Counter()
+        for _, bz in gaps:
+            tot_busy.update(bz)
+        gap_summary = {"gaps": len(g), "sum_ms_per_pass": sum(g) / 1e6 / passes, "median_us": g[len(g) // 2] / 1e3, "p90_us": g[int(0.9 * len(g))] / 1e3,
+                       "overlapping_fills": sum(1 for (b0, e0, _), (b1, e1, _) in zip(fk, fk[1:]) if b1 <= e0),
+                       "kernel_ms_inside_gaps_per_pass": {k: round(v / 1e6 / passes, 2) for k, v in tot_busy.most_common(6)}}
+    print(json.dumps({"fill_launches": fill_launches, "between_fills": gap_summary, "ms_per_pass_wall": s_per_pass * 1e3, "ms_per_pass_with_a_kernel_running": busy / 1e6 / passes,
                       "kernel_ms_per_pass": {k: round(tot[k] / passes, 2) for k in top},
                       "launches_per_pass": {k: round(cnt[k] / passes, 1) for k in top},
                       "avg_us": {k: round(tot[k] / cnt[k] * 1e3, 1) for k in top}, "beside_the_fills": beside}, indent=1))

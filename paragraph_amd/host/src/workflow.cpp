@@ -1258,8 +1258,7 @@ extern "C" int pgw_genotype_graphs(
                 std::string& t = text[ordered.next];
                 const char* sep = ordered.next ? ",\n" : "\n";
                 ordered.ok = ordered.ok && fputs(sep, out) != EOF && fwrite(t.data(), 1, t.size(), out) == t.size();
-                std::string().swap(t);
-                ++ordered.next;
+                ++ordered.next;  // (the text is freed with the others at the end: freed here it would go back to ANOTHER lane's arena)
             }
         };
         parameters.genotype_text_ready = flush;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # stage calls that park the blocks they outgrow instead of waiting for the batch under the device lock: tests, e2e leg, call timing
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; O=$R/gpurun_out/r5k2; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; O=$R/gpurun_out/r5k3; mkdir -p $O
 (time timeout 1200 python -m pytest tests -m gpu -x -q -p no:cacheprovider -k "test_gpu_workflow or host_cpp or test_gpu_counts or test_gpu_path or test_gpu_klib or test_gpu_kmer") > $O/tests.log 2>&1; echo "tests rc=$? $(grep -E 'passed|failed' $O/tests.log | tail -1)"
 for i in 1 2 3; do
 python bench.py --reads 20000 --steps 1 --warmup 0 --sites-steps 0 --no-cpu-baseline --stream-batches 0 --e2e-steps 4 --e2e-options '{}' 2> /dev/null | python -c "

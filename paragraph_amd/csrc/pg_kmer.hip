@@ -459,33 +459,35 @@ __global__ __launch_bounds__(64) void pg_kmer_kernel(KmerArgs a)
             i = si + 1;
         }
     }
+    // ---- emit the best alignment: run-length encode the labels, all lanes (one lane walking the read twice was a fifth of the
+    // kernel): the positions where a run starts go into LDS (the rival's label array is free by now) by ballot + prefix count,
+    // element i of the CIGAR is then (label at start i, start i + 1 - start i)
+    uint32_t n_ops = 0;
+    uint32_t* starts = slab[1];
+    __syncthreads();  // (the last comparison's reads of slab[1])
+    if (has_ops)
+        for (int c0 = 0; c0 < L; c0 += 64)
+        {
+            const int j = c0 + lane;
+            const bool st = j < L && (j == 0 || slab[0][j] != slab[0][j - 1]);
+            const unsigned long long m = __ballot(st);
+            if (st)
+                starts[n_ops + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)j;
+            n_ops += (uint32_t)__popcll(m);
+        }
+    __syncthreads();
+    unsigned long long base = 0;
+    if (lane == 0)
+        base = atomicAdd(a.ops_counter, (unsigned long long)n_ops);
+    base = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0);
+    for (uint32_t i = (uint32_t)lane; i < n_ops; i += 64u)
+    {
+        const uint32_t s0 = starts[i], s1 = i + 1 < n_ops ? starts[i + 1] : (uint32_t)L;
+        const uint32_t cur = slab[0][s0];
+        a.ops[base + i] = PG_OP_MAKE(cur >> 4, cur & 7u, s1 - s0);
+    }
     if (lane != 0)
         return;
-    // ---- emit the best alignment: run-length encode the labels (two passes over LDS: count, write)
-    uint32_t n_ops = 0;
-    if (has_ops)
-    {
-        n_ops = 1;
-        for (int j = 1; j < L; ++j)
-            n_ops += slab[0][j] != slab[0][j - 1];
-    }
-    const unsigned long long base = atomicAdd(a.ops_counter, (unsigned long long)n_ops);
-    if (has_ops)
-    {
-        uint32_t e = 0, run = 1, cur = slab[0][0];
-        for (int j = 1; j <= L; ++j)
-        {
-            const uint32_t nxt = j < L ? slab[0][j] : 0xFFFFFFFFu;
-            if (nxt == cur)
-            {
-                ++run;
-                continue;
-            }
-            a.ops[base + e++] = PG_OP_MAKE(cur >> 4, cur & 7u, run);
-            cur = nxt;
-            run = 1;
-        }
-    }
     pg_result res;
     res.graph_pos = lb.graph_pos;
     res.score = (int16_t)lb.matches;

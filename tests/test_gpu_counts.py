@@ -217,3 +217,63 @@ def test_kmer_filter_fuzz(gpu_ctx, filter_k):
     assert n4 > 20 and nkeep > 20
     if filter_k == 8:
         assert n3 > 0
+
+
+def test_a_reused_batch_outgrows_its_count_table_without_a_wait(gpu_ctx):
+    """A pooled batch object meets a graph set whose count table is larger than its last one while its own fills are still queued
+    (SiteBatcher: pg_batch_align and pg_batch_count back to back under the device lock): pg_batch_count parks the old block and
+    takes a new one -- no wait for the batch -- and the tables equal those of a batch object that never held anything else."""
+    from paragraph_amd import capi
+    rng = random.Random(fuzzgen.salted(4242))
+
+    def plain(x):  # numpy arrays and scalars as lists and ints: comparable with ==
+        if isinstance(x, dict):
+            return {k: plain(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [plain(v) for v in x]
+        if isinstance(x, np.ndarray):
+            return x.tolist()
+        if isinstance(x, np.generic):
+            return x.item()
+        return x
+
+    def site_set(n_sites, n_reads):
+        graphs, labels, names, reads, gor, frag, isrev = [], [], [], [], [], [], []
+        for gi in range(n_sites):
+            graphs.append((ALIGNS_NODES, ALIGNS_EDGES))
+            labels.append(ALIGNS_LABELS)
+            names.append(["D", "P", "Q"])
+            for r in range(n_reads):
+                reads.append(ALIGNS_READS[rng.randrange(len(ALIGNS_READS))])
+                gor.append(gi)
+                frag.append(r // 2)
+                isrev.append(bool(r & 1))
+        return graphs, labels, names, reads, gor, frag, isrev
+
+    def run(b, s):
+        graphs, labels, names, reads, gor, frag, isrev = s
+        G = gpu_ctx.upload_graphs(graphs)
+        G.set_labels(labels, names)
+        b.upload(G, reads, gor)
+        b.set_fragments(frag, isrev)
+        b.align(capi.AF_ALL)   # queued ...
+        b.count(remove_nonuniq=True, use_support_filters=True)  # ... and counted behind it without a wait in between
+        table, sup, path = b.download_counts()
+        # (supports and path entries decoded: where a read's entries sit in the path array is decided by an atomic counter)
+        return G, plain((capi.decode_supports(G, gor, sup, path, b.download_label_sets(sup)), capi.decode_counts(G, table)))
+
+    small, large = site_set(3, 8), site_set(40, 12)
+    reused = gpu_ctx.new_batch()
+    G1, _ = run(reused, small)
+    G2, got = run(reused, large)     # the count table grows from 3 sites' counters to 40 sites'
+    fresh = gpu_ctx.new_batch()
+    G3, want = run(fresh, large)
+    assert got == want
+    G4, again = run(reused, small)   # and back: the parked block was freed by the upload, the smaller table fits the larger block
+    fresh_small = gpu_ctx.new_batch()
+    G5, want_small = run(fresh_small, small)
+    assert again == want_small
+    for b in (reused, fresh, fresh_small):
+        b.close()
+    for G in (G1, G2, G3, G4, G5):
+        G.close()

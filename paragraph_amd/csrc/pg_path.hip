@@ -946,8 +946,7 @@ extern "C" pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* b)
         HIP_TRY(ctx, hipMemsetAsync(b->d_path_flags, 0, b->n_reads, ps));
     if (b->cap_bases_rc < b->cap_bases)  // (the reverse strand's copy of the reads: each thread of the kernel writes its own)
     {
-        HIP_TRY(ctx, pg_batch_wait(ctx, b));
-        (void)pg_dev_free(b->d_bases_rc);
+        b->park(b->d_bases_rc);  // (a stage call never waits for the batch: pg_internal.h, parked_blocks)
         b->d_bases_rc = nullptr;
         b->cap_bases_rc = 0;
         HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_bases_rc, b->cap_bases));

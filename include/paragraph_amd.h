@@ -47,6 +47,8 @@
  * pg_batch_destroy touch only their own batch and the copy stream: they may overlap the stage calls
  * (pg_batch_path_align / _kmer_align / _klib_align / _align / _count / _set_active, which share the ctx workspace and
  * stay serialised) of OTHER batches -- batch k+1 goes up and batch k-1 comes down while batch k computes.
+ * The stage calls only QUEUE work: none of them waits for the device, whatever the batch object held before (a device block a
+ * stage outgrows is kept until the batch's next upload), so the lock a caller holds around them is held for microseconds.
  * pg_last_error is then whichever call failed last.
  * Scoring is fixed as in the reference: match +1, mismatch -4, gap open 6, gap extend 1,
  * N / non-ACGTU = 0 (GraphAligner.cpp:229-233, gssw.c:4188-4220).

@@ -871,17 +871,21 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
         options_path = dict(options, path_sequence_matching=True)
         workflow.genotype_graphs_to_file(e2e["reference"], e2e["manifest"], graphs, out_file, **options_path)
         barrier()
+        rp0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         path_steps = max(2, args.e2e_steps)
         for _ in range(path_steps):
             workflow.genotype_graphs_to_file(e2e["reference"], e2e["manifest"], graphs, out_file, **options_path)
         barrier()
         t_path = env["max_over_ranks"](time.perf_counter() - t0)
+        rp1 = resource.getrusage(resource.RUSAGE_SELF)
+        cpu_path = (rp1.ru_utime - rp0.ru_utime) + (rp1.ru_stime - rp0.ru_stime)
         with open(out_file) as f:
             docs_path = json.load(f)
         os.unlink(out_file)
         same_gt = sum(1 for a, b2 in zip(docs, docs_path) if a["samples"]["SYN"]["gt"].get("GT") == b2["samples"]["SYN"]["gt"].get("GT"))
         cascade = {"sites_genotyped_per_s": n * path_steps / t_path, "ms_per_step": t_path / path_steps * 1e3, "steps": path_steps,
+                   "cpu_us_per_site_sample_this_rank": cpu_path / path_steps / max(1, len(mine)) * 1e6,
                    "genotypes_equal_the_gssw_only_run_on_this_rank": same_gt, "sites_on_this_rank": len(mine),
                    "note": "path_sequence_matching = true (the `paragraph` tool's default): reads the exact path matcher maps and the "
                            "filters accept keep that alignment, so counts may differ from the gssw-only run by design"}

@@ -1077,6 +1077,8 @@ extern "C" void pg_batch_destroy(pg_ctx* ctx, pg_batch* b)
         (void)hipEventDestroy(b->ev_upload);
     if (b->ev_host)
         (void)hipEventDestroy(b->ev_host);
+    if (b->ev_cascade)
+        (void)hipEventDestroy(b->ev_cascade);
     if (b->ev_busy)
         (void)hipEventDestroy(b->ev_busy);
     delete b;
@@ -1552,6 +1554,8 @@ extern "C" pg_status pg_batch_upload(
         HIP_TRY(ctx, hipMemsetAsync(b->d_path_flags, 0, n_reads, cs));
     }
     HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), cs));
+    b->ops_counter_fresh = true;  // (the first stage behind this upload need not zero it again)
+    b->cascade_recorded = false;
     const pg_status st = plan_items(ctx, b, nullptr, cs);
     if (st != PG_OK)
         return st;
@@ -1596,11 +1600,20 @@ extern "C" pg_status pg_batch_set_active(pg_ctx* ctx, pg_batch* b, const uint8_t
 // ----------------------------------------------------------------------------------------------------------------------
 namespace
 {
-__global__ void pg_retire_kernel(uint32_t n, const uint8_t* __restrict__ stage_flags, const pg_read_support* __restrict__ sup, uint8_t* active)
+// (had_mask == 0: the batch has no mask yet = every read is active -- the kernel writes the first one instead of a memset before it;
+//  group_count: the per-group counters of the list kernel behind this one, zeroed here instead of by a memset between the two.  Every
+//  dispatch of a seed chain waits for a wavefront slot beside the fills: the chain is as long as it has dispatches.)
+__global__ void pg_retire_kernel(uint32_t n, const uint8_t* __restrict__ stage_flags, const pg_read_support* __restrict__ sup, uint8_t* active,
+                                 uint32_t had_mask, uint32_t* group_count, uint32_t n_groups)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && active[i] && (stage_flags[i] & 1u) && sup[i].status == 1)
-        active[i] = 0;
+    if (i < n_groups)
+        group_count[i] = 0;
+    if (i < n)
+    {
+        const bool was = had_mask ? active[i] != 0 : true;
+        active[i] = (was && !((stage_flags[i] & 1u) && sup[i].status == 1)) ? 1 : 0;
+    }
 }
 
 __global__ void pg_group_list_kernel(
@@ -1806,17 +1819,13 @@ static pg_status cascade_full_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream)
 }
 
 // Lists of the active reads + the work items over the full plan's slots, all on `stream` (d_active: NULL = every read).
-static pg_status cascade_rebuild_items(pg_ctx* ctx, pg_batch* b, hipStream_t stream, const uint8_t* d_active)
+// the cascade's device tables (groups, lists, plan segments) for this upload: allocated / uploaded / cut on first use
+static pg_status cascade_prepare(pg_ctx* ctx, pg_batch* b, hipStream_t stream)
 {
     const uint32_t n = b->n_reads;
     const size_t n_groups = b->groups.size();
-    b->chunks.clear();
-    b->n_pairs = 0;
     if (!n || !n_groups)
-    {
-        b->plan_stale = false;  // nothing the packed kernels could run
         return PG_OK;
-    }
     if (n_groups > b->cap_groups || n > b->cap_cascade_reads)
     {
         b->park(b->d_group_of_read2);
@@ -1841,10 +1850,41 @@ static pg_status cascade_rebuild_items(pg_ctx* ctx, pg_batch* b, hipStream_t str
         HIP_TRY(ctx, hipMemcpyAsync(b->d_group_base, b->h_group_base.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         b->cascade_uploaded = true;
     }
-    const pg_status fp = cascade_full_plan(ctx, b, stream);
+    return cascade_full_plan(ctx, b, stream);
+}
+
+pg_status pg_cascade_prepare_early(pg_ctx* ctx, pg_batch* b)
+{
+    if (b->has_general_reads || b->cascade_recorded || !b->n_reads || b->groups.empty())
+        return PG_OK;
+    const pg_status ps = cascade_prepare(ctx, b, ctx->stream_copy);
+    if (ps != PG_OK)
+        return ps;
+    if (!b->ev_cascade)
+        HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_cascade, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(b->ev_cascade, ctx->stream_copy));
+    b->cascade_recorded = true;
+    return PG_OK;
+}
+
+static pg_status cascade_rebuild_items(pg_ctx* ctx, pg_batch* b, hipStream_t stream, const uint8_t* d_active, bool group_counts_zeroed = false)
+{
+    const uint32_t n = b->n_reads;
+    const size_t n_groups = b->groups.size();
+    b->chunks.clear();
+    b->n_pairs = 0;
+    if (!n || !n_groups)
+    {
+        b->plan_stale = false;  // nothing the packed kernels could run
+        return PG_OK;
+    }
+    const pg_status fp = cascade_prepare(ctx, b, stream);
     if (fp != PG_OK)
         return fp;
-    HIP_TRY(ctx, hipMemsetAsync(b->d_group_count, 0, n_groups * sizeof(uint32_t), stream));
+    if (b->cascade_recorded)
+        HIP_TRY(ctx, hipStreamWaitEvent(stream, b->ev_cascade, 0));
+    if (!group_counts_zeroed)
+        HIP_TRY(ctx, hipMemsetAsync(b->d_group_count, 0, n_groups * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(pg_group_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, d_active, b->d_group_of_read2, b->d_group_base,
                        b->d_group_count, b->d_active_list);
     HIP_TRY(ctx, hipGetLastError());
@@ -1870,17 +1910,28 @@ extern "C" pg_status pg_batch_retire_mapped(pg_ctx* ctx, pg_batch* b)
     // always
     hipStream_t cs = b->seed_chain ? b->seed_stream : ctx->stream2;
     HIP_TRY(ctx, pg_stage_begin_on(ctx, b, cs));
-    if (!b->has_active && b->n_reads)
-        HIP_TRY(ctx, hipMemsetAsync(b->d_active, 1, b->n_reads, cs));
+    const uint32_t had_mask = b->has_active ? 1u : 0u;
     b->has_active = true;
     b->plan_stale = true;
     if (b->n_reads)
     {
-        hipLaunchKernelGGL(pg_retire_kernel, dim3((b->n_reads + 255) / 256), dim3(256), 0, cs, b->n_reads, b->d_path_flags, b->d_support, b->d_active);
-        HIP_TRY(ctx, hipGetLastError());
-        if (!b->has_general_reads)  // (a batch with general-path reads plans on the host from the downloaded flags: pg_batch_ensure_plan)
+        // (a batch with general-path reads plans on the host from the downloaded flags: pg_batch_ensure_plan)
+        const bool rebuild = !b->has_general_reads;
+        uint32_t n_groups = 0;
+        if (rebuild)
         {
-            const pg_status rs = cascade_rebuild_items(ctx, b, cs, b->d_active);
+            const pg_status ps = cascade_prepare(ctx, b, cs);
+            if (ps != PG_OK)
+                return ps;
+            n_groups = (uint32_t)b->groups.size();
+        }
+        const uint32_t threads = std::max(b->n_reads, n_groups);
+        hipLaunchKernelGGL(pg_retire_kernel, dim3((threads + 255) / 256), dim3(256), 0, cs, b->n_reads, b->d_path_flags, b->d_support, b->d_active,
+                           had_mask, n_groups ? b->d_group_count : nullptr, n_groups);
+        HIP_TRY(ctx, hipGetLastError());
+        if (rebuild)
+        {
+            const pg_status rs = cascade_rebuild_items(ctx, b, cs, b->d_active, true);
             if (rs != PG_OK)
                 return rs;
         }
@@ -1965,8 +2016,9 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             (void)pg_stage_end_on(c, b, c->stream2);
         }
     } stage_end{ ctx, b, false };
-    if (!(flags & PG_AF_KEEP_RESULTS) || (flags == PG_AF_ALL))
+    if ((!(flags & PG_AF_KEEP_RESULTS) || (flags == PG_AF_ALL)) && !b->ops_counter_fresh)
         HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
+    b->ops_counter_fresh = false;
     const bool revg = (flags & PG_AF_REVERSE_GRAPH) != 0;
     // Chunk pipeline on two streams: fill(c) runs on `stream`, pick + traceback(c) on `stream2`; chunk number ctx->chunk_seq
     // (counted over all batches of the ctx) uses workspace half (chunk_seq & 1), so the latency-bound traceback of a chunk

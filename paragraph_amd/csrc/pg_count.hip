@@ -686,6 +686,25 @@ extern "C" pg_status pg_batch_set_fragments(
     return PG_OK;
 }
 
+namespace
+{
+__global__ void pg_count_zero_kernel(uint32_t* counts, uint32_t n, unsigned long long* path_counter)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        counts[i] = 0;
+    if (i == 0)
+        *path_counter = 0;
+}
+
+__global__ void pg_publish_counters_kernel(const unsigned long long* ops_counter, const unsigned long long* path_counter, unsigned long long* host_words)
+{
+    host_words[0] = *ops_counter;
+    host_words[1] = *path_counter;
+    __threadfence_system();
+}
+}  // namespace
+
 extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_params* params, uint32_t* d_counts)
 {
     PG_TIMED("pg_batch_count (whole call)");
@@ -720,10 +739,14 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
             HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_counts, lay.n_counters * sizeof(uint32_t)));
         }
         counts = b->d_counts;
-        HIP_TRY(ctx, hipMemsetAsync(counts, 0, lay.n_counters * sizeof(uint32_t), cs));
         b->counts_owned_valid = true;
     }
-    HIP_TRY(ctx, hipMemsetAsync(b->d_path_counter, 0, sizeof(unsigned long long), cs));
+    {
+        // the batch's own table and the path-entry counter zeroed by ONE dispatch (a caller's table is the caller's to zero)
+        const uint32_t nz = b->counts_owned_valid ? (uint32_t)lay.n_counters : 0u;
+        hipLaunchKernelGGL(pg_count_zero_kernel, dim3(std::max(1u, (nz + 255u) / 256u)), dim3(256), 0, cs, nz ? counts : nullptr, nz, b->d_path_counter);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     CountArgs a{};
     a.n_reads = n;
     a.prm = *params;
@@ -792,11 +815,15 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     if (!b->h_counters)
     {
         void* p = nullptr;
-        HIP_TRY(ctx, hipHostMalloc(&p, 2 * sizeof(unsigned long long), hipHostMallocPortable));
+        HIP_TRY(ctx, hipHostMalloc(&p, 2 * sizeof(unsigned long long), hipHostMallocPortable | hipHostMallocMapped));
         b->h_counters = (unsigned long long*)p;
+        void* dp = nullptr;
+        HIP_TRY(ctx, hipHostGetDevicePointer(&dp, p, 0));
+        b->d_h_counters = (unsigned long long*)dp;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(b->h_counters, b->d_ops_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
-    HIP_TRY(ctx, hipMemcpyAsync(b->h_counters + 1, b->d_path_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+    // (one single-thread dispatch writes both words into the page-locked block: two 8-byte copies were two dispatches)
+    hipLaunchKernelGGL(pg_publish_counters_kernel, dim3(1), dim3(1), 0, cs, b->d_ops_counter, b->d_path_counter, b->d_h_counters);
+    HIP_TRY(ctx, hipGetLastError());
     b->h_counters_valid = true;
     HIP_TRY(ctx, pg_stage_end_on(ctx, b, cs));
     return PG_OK;

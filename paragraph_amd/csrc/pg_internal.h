@@ -221,6 +221,8 @@ struct pg_batch
     // {CIGAR elements, path entries} of the batch as of its last pg_batch_count, copied into page-locked host memory by the count
     // stream itself (pg_batch_result_sizes reads them after the batch's event: no copy + wait of their own)
     unsigned long long* h_counters = nullptr;
+    unsigned long long* d_h_counters = nullptr;  // the same page-locked words as the device sees them (the count pass writes them itself)
+    bool ops_counter_fresh = false;              // zeroed by pg_batch_upload and not used since
     bool h_counters_valid = false;
     bool counts_owned_valid = false;
     bool fragments_set = false;
@@ -239,6 +241,8 @@ struct pg_batch
             parked_blocks.push_back(p);
     }
     hipEvent_t ev_host = nullptr;    // what the host waits on where it used to synchronise a stream (pg_wait_stream)
+    hipEvent_t ev_cascade = nullptr; // the cascade's tables of this upload are on the device (pg_cascade_prepare_early: copy stream)
+    bool cascade_recorded = false;
     bool upload_recorded = false, busy_recorded = false;
 };
 
@@ -258,6 +262,9 @@ hipError_t pg_batch_wait(pg_ctx* ctx, pg_batch* b);
 // always is in a process that imported torch before it came here.  pg_wait_stream: hipStreamSynchronize by the same rule.
 unsigned pg_wait_event_flags();
 hipError_t pg_wait_stream(pg_batch* b, hipStream_t s);
+// The tables the device-side hand-over needs (group of every read, list bases, plan segments) go up on the COPY stream while the
+// batch's first seed stage runs, not on the seed stream between its count pass and the hand-over kernels.
+pg_status pg_cascade_prepare_early(pg_ctx* ctx, pg_batch* b);
 // the work items follow d_active: pg_batch_retire_mapped re-writes them on the device; this is for the cases it leaves (a batch with
 // general-path reads, pg_batch_set_active(NULL) after a hand-over) -- called by the stages that run work items, on `stream`
 pg_status pg_batch_ensure_plan(pg_ctx* ctx, pg_batch* b, hipStream_t stream);

@@ -942,7 +942,9 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
             return ps;
     }
     if (!(flags & PG_AF_KEEP_RESULTS) || flags == PG_AF_ALL)
-        HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
+        if (!b->ops_counter_fresh)
+            HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
+    b->ops_counter_fresh = false;
     if (b->n_reads == 0 || n_items == 0)
         return PG_OK;
     int n_cu = 256;

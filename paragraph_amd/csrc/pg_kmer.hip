@@ -649,7 +649,9 @@ extern "C" pg_status pg_batch_kmer_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     b->seed_chain = false;
     HIP_TRY(ctx, pg_stage_begin(ctx, b));
     if (!(flags & PG_AF_KEEP_RESULTS) || flags == PG_AF_ALL)
-        HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
+        if (!b->ops_counter_fresh)
+            HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
+    b->ops_counter_fresh = false;
     KmerArgs a{};
     a.n_reads = b->n_reads;
     a.k = ix->k;

@@ -340,8 +340,13 @@ __device__ __forceinline__ void reverse_complement(const char* __restrict__ src,
 __global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
 {
     const uint32_t r = blockIdx.x * 64u + threadIdx.x;
-    if (r >= a.n_reads || (a.active && !a.active[r]))
+    if (r >= a.n_reads)
         return;
+    if (a.active && !a.active[r])
+    {
+        a.flags[r] = 0;  // (every read's flag is written: no memset in front of the kernel)
+        return;
+    }
     const uint32_t off = a.base_off[r];
     const int L = (int)(a.base_off[r + 1] - off);
     uint8_t flags = 0;
@@ -940,10 +945,17 @@ extern "C" pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* b)
     const hipStream_t ps = turn ? ctx->stream_seed_more[turn - 1] : ctx->stream_seed;
     b->seed_stream = ps;
     b->seed_chain = true;
+    {
+        const pg_status cp = pg_cascade_prepare_early(ctx, b);  // (the hand-over's tables go up beside the kernel below)
+        if (cp != PG_OK)
+            return cp;
+    }
     HIP_TRY(ctx, pg_stage_begin_on(ctx, b, ps));
-    HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ps));
-    if (b->n_reads)
-        HIP_TRY(ctx, hipMemsetAsync(b->d_path_flags, 0, b->n_reads, ps));
+    // (no memsets in front of the kernel: it writes the flag of every read, and the counter is still zero from the upload when this is
+    // the batch's first stage -- every dispatch of a seed chain waits for a wavefront slot beside the fills)
+    if (!b->ops_counter_fresh)
+        HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ps));
+    b->ops_counter_fresh = false;
     if (b->cap_bases_rc < b->cap_bases)  // (the reverse strand's copy of the reads: each thread of the kernel writes its own)
     {
         b->park(b->d_bases_rc);  // (a stage call never waits for the batch: pg_internal.h, parked_blocks)

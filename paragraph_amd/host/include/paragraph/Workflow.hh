@@ -112,7 +112,7 @@ std::vector<common::Json> alignAndDisambiguateBatch(Parameters const& parameters
 std::vector<common::Json> countGraphs(
     Parameters const& parameters, std::vector<std::string> const& graph_paths, std::string const& reference_path,
     std::vector<std::string> const& bam_paths, std::vector<std::string> const& bam_index_paths = {},
-    std::string const& target_regions = "", size_t sites_per_batch = 0 /* 0 = 192, 384 with a seed stage before the graph aligner */);
+    std::string const& target_regions = "", size_t sites_per_batch = 0 /* 0 = 192 */);
 // single-site convenience with the reference's shape
 common::Json alignAndDisambiguate(Parameters const& parameters, GraphDescription const& description, common::ReadBuffer& all_reads);
 }  // namespace paragraph
@@ -134,11 +134,11 @@ struct Parameters
     // keep the reads of a site as flat arrays instead of common::Read objects (several times less host work); switched off
     // automatically when output_alignments needs the per-read records
     bool packed_reads = true;
-    size_t sites_per_batch = 0;      // (graph, sample) pairs per device batch; bounds host memory and sets the pipeline grain.  0 = 192, or
-                                     // 384 when a seed stage runs before the graph aligner (10 000 sites, 16 threads, profiles/
-                                     // r05_e2e_batch_ab.jsonl: gssw only 128 72.5 k sites/s, 192 74.5 k, 256 74.4 k, 384 70.5 k; with the
-                                     // path stage 192 46 k, 256 49.7 k, 384 56.5 k -- every batch's cascade is a chain of dependent stages)
-                                     // (10 000 sites on one MI355X / 16 CPUs: 128 -> 57 k sites/s, 512 -> 51 k)
+    size_t sites_per_batch = 0;      // (graph, sample) pairs per device batch; bounds host memory and sets the pipeline grain.  0 = 192
+                                     // (10 000 sites, 16 threads: gssw only 128 78.5 k sites/s, 192 79 k, 256 79 k, 384 70.5 k; with the
+                                     // path stage 192 81 k, 256 79 k, 384 73 - 76 k -- profiles/r05_e2e_lanes_ab2.jsonl,
+                                     // r05_e2e_path_batch_ab.jsonl.  While every batch's seed chain carried its table uploads the
+                                     // path cascade wanted 384: fewer, longer chains.)
     int lanes = 0;                   // chunks in flight: each lane carries one chunk through all stages with threads / lanes
                                      // workers; 0 = one lane per four threads, at most eight per device, at least one per device
     std::vector<int> devices;        // HIP ordinals to spread the lanes over (lane l -> devices[l % n]); empty = the list of

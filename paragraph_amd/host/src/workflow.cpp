@@ -506,7 +506,7 @@ std::vector<Json> countGraphs(
 
     std::vector<Json> documents(graph_paths.size());
     if (sites_per_batch == 0)
-        sites_per_batch = (parameters.path_sequence_matching || parameters.kmer_sequence_matching || parameters.klib_sequence_matching) ? 384 : 192;
+        sites_per_batch = 192;
     // one chunk of graphs: load + extract, ONE device batch, documents -- with `lane.threads` workers
     auto processChunk = [&](size_t g0, Parameters const& lane) {
         const size_t n_here = std::min(sites_per_batch, graph_paths.size() - g0);
@@ -956,8 +956,7 @@ std::vector<Json> genotypeGraphs(
         parameters.genotype_text->assign(n_graphs, std::string());
     if (n_graphs == 0 || n_samples == 0)
         return genotypes;
-    const bool seed_stages = parameters.path_sequence_matching || parameters.kmer_sequence_matching || parameters.klib_sequence_matching;
-    const size_t pairs_per_batch = parameters.sites_per_batch ? parameters.sites_per_batch : (seed_stages ? 384 : 192);
+    const size_t pairs_per_batch = parameters.sites_per_batch ? parameters.sites_per_batch : 192;
     const size_t per_batch = std::max<size_t>(1, pairs_per_batch / n_samples);
     const size_t n_even_chunks = (n_graphs + per_batch - 1) / per_batch;
     // Lanes: each lane takes the next chunk and carries it through every stage (load + extract, device batch, documents,

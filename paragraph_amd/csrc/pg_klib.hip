@@ -922,6 +922,11 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     const uint64_t n_items = (uint64_t)b->n_reads * 2u * ix->max_paths;
     b->h_counters_valid = false;
     b->seed_chain = false;
+    {
+        const pg_status cp = pg_cascade_prepare_early(ctx, b);  // (a hand-over behind this stage finds its tables on the device)
+        if (cp != PG_OK)
+            return cp;
+    }
     HIP_TRY(ctx, pg_stage_begin(ctx, b));
     // every way out of this call from here on records the end of the stage: pg_graphs_destroy / pg_dev_free trust those events
     // (an early return that skipped it could hand buffers the queued kernels still read to another lane)

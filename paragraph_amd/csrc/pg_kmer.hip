@@ -647,6 +647,11 @@ extern "C" pg_status pg_batch_kmer_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     const uint32_t words = (ix->max_path_len + 31) / 32 + 1;
     b->h_counters_valid = false;
     b->seed_chain = false;
+    {
+        const pg_status cp = pg_cascade_prepare_early(ctx, b);  // (a hand-over behind this stage finds its tables on the device)
+        if (cp != PG_OK)
+            return cp;
+    }
     HIP_TRY(ctx, pg_stage_begin(ctx, b));
     if (!(flags & PG_AF_KEEP_RESULTS) || flags == PG_AF_ALL)
         if (!b->ops_counter_fresh)

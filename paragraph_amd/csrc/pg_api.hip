@@ -362,6 +362,8 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
         (void)hipFree(ctx->workspace);
     if (ctx->gen_ws)
         (void)hipFree(ctx->gen_ws);
+    for (void* p : ctx->klib_scratch)
+        (void)pg_dev_free(p);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream_fill2)

@@ -55,6 +55,12 @@ struct pg_ctx
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // pick + traceback of chunk i overlaps the fill of chunk i + 1
     hipStream_t stream_copy = nullptr;  // uploads of the NEXT batch / downloads of the PREVIOUS one overlap the kernels
+    // The klib stage's scratch (candidate records, work list, CIGAR slots, direction bytes): the context's, like the fill's workspace
+    // -- the stage's kernels run one batch after the other on the main stream and nothing of it outlives the stage's last kernel.  (As
+    // blocks of every batch's own index they were a quarter of a gigabyte allocated and freed per batch: 5 ms per hipMalloc, the
+    // workflow with the klib stage at 5 k sites/s.)
+    void* klib_scratch[4] = { nullptr, nullptr, nullptr, nullptr };
+    size_t klib_scratch_bytes[4] = { 0, 0, 0, 0 };
     std::vector<hipEvent_t> sync_event_pool, sync_events_in_flight;
     // The workspace is `regions` equal regions used in turn by the chunks of ALL batches in the order they are aligned
     // (chunk_seq): the fill of a chunk only waits for the traceback that last read its region (region_free), so the traceback +

@@ -886,11 +886,31 @@ extern "C" pg_status pg_graphs_build_klib_index(
     return PG_OK;
 }
 
+// slot of pg_ctx::klib_scratch, grown (never shrunk) to `need` elements; a block in use by an earlier stage call is waited for
+template <typename T> static pg_status scratch(pg_ctx* ctx, int slot, T** d, size_t need)
+{
+    const size_t bytes = std::max<size_t>(need, 1) * sizeof(T);
+    if (bytes > ctx->klib_scratch_bytes[slot])
+    {
+        if (ctx->klib_scratch[slot])
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        (void)pg_dev_free(ctx->klib_scratch[slot]);
+        ctx->klib_scratch[slot] = nullptr;
+        ctx->klib_scratch_bytes[slot] = 0;
+        const size_t cap = bytes + bytes / 4;
+        HIP_TRY(ctx, pg_dev_alloc(&ctx->klib_scratch[slot], cap));
+        ctx->klib_scratch_bytes[slot] = cap;
+    }
+    *d = (T*)ctx->klib_scratch[slot];
+    return PG_OK;
+}
+
 template <typename T> static pg_status grow(pg_ctx* ctx, T** d, size_t* cap, size_t need)
 {
     if (need <= *cap)
         return PG_OK;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (*d)  // (a block of an earlier call may still be read; a fresh index -- every batch of a workflow -- has none and waits for nothing)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     (void)pg_dev_free(*d);
     *d = nullptr;
     *cap = 0;
@@ -981,16 +1001,19 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
     a.ops_cap = b->ops_cap;
     a.flags = b->d_path_flags;
     a.error = ix->d_error;
-    pg_status st = grow(ctx, &ix->d_items, &ix->items_cap, (size_t)n_items);
+    KlibItem* d_items = nullptr;
+    uint32_t *d_worklist = nullptr, *d_cigars = nullptr;
+    uint8_t* d_z = nullptr;
+    pg_status st = scratch(ctx, 0, &d_items, (size_t)n_items);
     if (st != PG_OK)
         return st;
-    a.items = ix->d_items;
+    a.items = d_items;
     if (packed)
     {
-        st = grow(ctx, &ix->d_worklist, &ix->worklist_cap, (size_t)n_items);
+        st = scratch(ctx, 1, &d_worklist, (size_t)n_items);
         if (st != PG_OK)
             return st;
-        a.worklist = ix->d_worklist;
+        a.worklist = d_worklist;
         a.work_count = ix->d_work_count;
         a.work = b->d_items;
         HIP_TRY(ctx, hipMemsetAsync(ix->d_work_count, 0, sizeof(uint32_t), ctx->stream));
@@ -1005,26 +1028,27 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
         else
             hipLaunchKernelGGL(pg_klib_select_kernel<PG_KLIB_MAX_PATHS_WIDE + 2>, dim3((b->n_reads + 63) / 64), dim3(64), 0, ctx->stream, a);
         HIP_TRY(ctx, hipGetLastError());
-        // the size of the second pass is only known now (one small read-back; the stage's caller reads the flags back next anyway)
-        uint32_t n_work = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&n_work, ix->d_work_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        // The size of the second pass is known on the DEVICE only: the finish kernel reads it there, the launch is sized for the
+        // resident wavefronts and the scratch for every candidate.  (A read-back here was a wait for the whole main stream -- the
+        // fills of every batch queued before this one -- under the caller's device lock: the workflow with the klib stage ran at
+        // 5 - 27 k sites/s.)
+        const uint32_t n_work = (uint32_t)std::min<uint64_t>(n_items, 0xFFFFFFFFull);
         if ((uint64_t)n_work * cig_cap >= (1ull << 32))
             return pg_fail(ctx, PG_ERR_UNSUPPORTED, "pg_batch_klib_align: batch too large (CIGAR scratch index)");
         const int C = pg_var_c(pg_variant_of(max_len));
-        const uint32_t waves = (n_work + 7u) / 8u;
+        const uint32_t waves = (n_work + 7u) / 8u;  // (an upper bound: every candidate)
         // resident wavefronts per CU: 10 by LDS for reads up to 250 bases, 4 (one per SIMD, by registers) beyond; each one owns
         // z_bytes of direction scratch
         const uint32_t grid = std::min<uint32_t>(waves, (uint32_t)n_cu * (C > 16 ? 4u : 10u));
         const uint64_t z_bytes = pg_klib_finish_z_bytes(C);
-        st = grow(ctx, &ix->d_cigars, &ix->cigars_cap, std::max<size_t>((size_t)n_work * cig_cap, 1));
-        if (st == PG_OK) st = grow(ctx, &ix->d_z, &ix->z_cap, std::max<size_t>((size_t)grid * z_bytes, 1));
+        st = scratch(ctx, 2, &d_cigars, std::max<size_t>((size_t)n_work * cig_cap, 1));
+        if (st == PG_OK) st = scratch(ctx, 3, &d_z, std::max<size_t>((size_t)grid * z_bytes, 1));
         if (st != PG_OK)
             return st;
-        a.cigars = ix->d_cigars;
-        a.z = ix->d_z;
+        a.cigars = d_cigars;
+        a.z = d_z;
         a.z_bytes = z_bytes;
-        a.n_work = n_work;
+        a.n_work = 0;  // (unused: a.work_count is set)
         HIP_TRY(ctx, pg_klib_launch_finish(C, a, grid, ctx->stream));
     }
     else
@@ -1036,12 +1060,12 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
         // delete more bases than it matches) and never more than the path; + 64 steps of skew
         const uint64_t z_steps = std::min<uint64_t>(2ull * max_len, ix->max_path_len) + 64 + 1;
         const uint64_t z_bytes = z_steps * 64 * z_lane_bytes(R);
-        st = grow(ctx, &ix->d_cigars, &ix->cigars_cap, (size_t)n_items * cig_cap);
-        if (st == PG_OK) st = grow(ctx, &ix->d_z, &ix->z_cap, (size_t)grid * z_bytes);
+        st = scratch(ctx, 2, &d_cigars, (size_t)n_items * cig_cap);
+        if (st == PG_OK) st = scratch(ctx, 3, &d_z, (size_t)grid * z_bytes);
         if (st != PG_OK)
             return st;
-        a.cigars = ix->d_cigars;
-        a.z = ix->d_z;
+        a.cigars = d_cigars;
+        a.z = d_z;
         a.z_bytes = z_bytes;
         switch (R)
         {
@@ -1072,9 +1096,13 @@ extern "C" pg_status pg_graphs_klib_error(pg_ctx* ctx, pg_graphs* G, uint32_t* e
     if (!ctx || !G || !G->klib_index || !error)
         return pg_fail(ctx, PG_ERR_INVALID, "pg_graphs_klib_error: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(error, G->klib_index->d_error, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(G->klib_index->d_error, 0, sizeof(uint32_t), ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // the last stage that used this graph set on the main stream (the klib stage), not everything every batch has queued there;
+    // then the word comes down the copy stream
+    if (G->use_recorded[0])
+        HIP_TRY(ctx, hipEventSynchronize(G->ev_use[0]));
+    HIP_TRY(ctx, hipMemcpyAsync(error, G->klib_index->d_error, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream_copy));
+    HIP_TRY(ctx, hipMemsetAsync(G->klib_index->d_error, 0, sizeof(uint32_t), ctx->stream_copy));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
     return PG_OK;
 }
 

@@ -370,7 +370,9 @@ __global__ __launch_bounds__(64) void pg_klib_finish_kernel(KlibArgs a)
     const uint32_t per_read = 2u * a.max_paths;
     uint32_t* __restrict__ zw = (uint32_t*)(a.z + (size_t)blockIdx.x * a.z_bytes);  // [step][ZDW][64 lanes]
 
-    for (uint32_t base = blockIdx.x * 8u; base < a.n_work; base += gridDim.x * 8u)
+    // (the number of selected candidates is read where the select kernel left it: the host does not wait for it to size this launch)
+    const uint32_t n_work = a.work_count ? *a.work_count : a.n_work;
+    for (uint32_t base = blockIdx.x * 8u; base < n_work; base += gridDim.x * 8u)
     {
         __syncthreads();
         if (lane < 8)
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(64) void pg_klib_finish_kernel(KlibArgs a)
             fi.te = -1;
             fi.qe = -1;
             const uint32_t w = base + (uint32_t)lane;
-            if (w < a.n_work)
+            if (w < n_work)
             {
                 const uint32_t item = a.worklist[w];
                 const uint32_t r = item / per_read, sub = item % per_read;

@@ -1482,11 +1482,7 @@ void SiteBatcher::Impl::Run::deviceSubmit()
     if (prm.klib_sequence_matching && n)
     {
         check(ctx, pg_batch_klib_align(ctx, batch, keep), "pg_batch_klib_align");
-        hand_over();
-        uint32_t overflow = 0;
-        check(ctx, pg_graphs_klib_error(ctx, G, &overflow), "pg_graphs_klib_error");
-        if (overflow)
-            throw std::runtime_error("klib stage: CIGAR buffer overflow on the device");
+        hand_over();  // (the stage's overflow word is read when the batch is back: deviceCollect)
     }
     if (keep)  // (the extension flag is ignored when flags == PG_AF_ALL)
         align_flags = (align_flags & (PG_AF_CIGAR | PG_AF_BOTH_STRANDS | PG_AF_REVERSE_GRAPH)) | PG_AF_KEEP_RESULTS;
@@ -1518,6 +1514,13 @@ void SiteBatcher::Impl::Run::deviceCollect()
     table.resize(lay.n_counters);
     check(ctx, pg_batch_result_sizes(ctx, batch, &n_ops, &n_path), "pg_batch_result_sizes");
     mark("batch done");
+    if (prm.klib_sequence_matching && n)
+    {
+        uint32_t overflow = 0;
+        check(ctx, pg_graphs_klib_error(ctx, G, &overflow), "pg_graphs_klib_error");
+        if (overflow)
+            throw std::runtime_error("klib stage: CIGAR buffer overflow on the device");
+    }
     ops.resize(n_ops + 1);
     path.resize(n_path + 1);
     check(ctx, pg_batch_download_all(ctx, batch, res.data(), ops.data(), ops.size(), table.data(), sup.data(), path.data(), path.size()),

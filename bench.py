@@ -889,6 +889,29 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
                    "genotypes_equal_the_gssw_only_run_on_this_rank": same_gt, "sites_on_this_rank": len(mine),
                    "note": "path_sequence_matching = true (the `paragraph` tool's default): reads the exact path matcher maps and the "
                            "filters accept keep that alignment, so counts may differ from the gssw-only run by design"}
+    # ... and with all four stages of the cascade on (path -> k-mer -> klib -> gssw; `paragraph --kmer-sequence-matching
+    # --klib-sequence-matching`, both default OFF in the reference's tools): two passes, reported only -- a failure here is written
+    # into the line, it does not fail the run
+    all_four = None
+    if args.e2e_steps > 0 and world == 1:  # (N = 1 only: a rank that failed here alone would leave the others at a barrier)
+        try:
+            options_all = dict(options, path_sequence_matching=True, kmer_sequence_matching=True, klib_sequence_matching=True)
+            workflow.genotype_graphs_to_file(e2e["reference"], e2e["manifest"], graphs, out_file, **options_all)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                workflow.genotype_graphs_to_file(e2e["reference"], e2e["manifest"], graphs, out_file, **options_all)
+            barrier()
+            t_all = env["max_over_ranks"](time.perf_counter() - t0)
+            with open(out_file) as f:
+                docs_all = json.load(f)
+            os.unlink(out_file)
+            all_four = {"sites_genotyped_per_s": n * 2 / t_all, "ms_per_step": t_all / 2 * 1e3, "steps": 2,
+                        "genotypes_equal_the_gssw_only_run_on_this_rank": sum(
+                            1 for a, b2 in zip(docs, docs_all) if a["samples"]["SYN"]["gt"].get("GT") == b2["samples"]["SYN"]["gt"].get("GT")),
+                        "sites_on_this_rank": len(mine)}
+        except Exception as exc:  # noqa: BLE001 -- reported, not fatal
+            all_four = {"error": "%s: %s" % (type(exc).__name__, exc)}
     concordant = sum(1 for i, doc in zip(mine, docs) if doc["samples"]["SYN"]["gt"].get("GT") == e2e["truth"][i]["gt"])
     errors = sum(1 for doc in docs if "error" in doc)
     # per-site edge-count table in one layout on every rank: a slot per edge of every site's graph, in site order
@@ -943,7 +966,7 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
                           "reduced_equals_own_on_own_sites": bool(mine_kept),
                           "note": "one slot per edge of every site (fragment counts of the breakpoint edges), all-reduced over the ranks "
                                   "AFTER the timed passes: a site's genotype needs only its own counts, the sum only collects them"},
-           "data_make_s": e2e["make_s"], "per_rank": per_rank, "with_path_matching": cascade}
+           "data_make_s": e2e["make_s"], "per_rank": per_rank, "with_path_matching": cascade, "with_all_four_stages": all_four}
     # A genotype that differs from the simulated truth is not by itself an error of the path (30x sampling can starve an allele);
     # a concordance below 99.5 % is.  What must hold exactly: no document with an error, the table checks, the sampled sites.
     out["genotype_concordance"] = int(table[total]) / max(1, n)

@@ -112,7 +112,14 @@ def parse_args():
     ap.add_argument("--e2e-threads", type=int, default=0, help="host threads of the workflow per rank (0 = usable CPUs / ranks)")
     ap.add_argument("--e2e-options", default="", help="JSON object of further pgw_genotype_graphs options for the e2e leg (A/B runs: "
                                                        "sites_per_batch, lanes, ...)")
+    ap.add_argument("--config5-graphs", type=int, default=100,
+                    help="configs[4] leg of the default run: graphs with one 2-8 kb inline ALT node each (0 = skip)")
+    ap.add_argument("--config5-reads-per-graph", type=int, default=240, help="250 bp reads per graph of that leg")
+    ap.add_argument("--config5-verify-per-graph", type=int, default=8,
+                    help="reads of every graph of that leg compared with the reference's gssw.c in a CPU-leg process (0 = skip)")
+    ap.add_argument("--config5-steps", type=int, default=3, help="timed passes of that leg")
     ap.add_argument("--cpu-leg", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--config5-cpu-leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--sites-cpu-leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-reads-file", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-out", help=argparse.SUPPRESS)
@@ -187,8 +194,8 @@ def _effective_cpus():
 def reference_site_outcome(chk, s, stride=256):
     """The reference's outcome for ONE config-3 site (TEST INFRASTRUCTURE: runs in the CPU-leg process / tests only): every
     read aligned by the checker (the reference's gssw.c where oracle/_ref is built), then the reference's filters,
-    disambiguation and counting (graph-tools + Disambiguation.cpp as compiled into oracle/_ref/libpg_refcounts.so, or the
-    restatement): alignments, CIGAR slots, per-read status and label sets, node / edge / sequence tables."""
+    disambiguation and counting (graph-tools compiled as it lies + the Disambiguation.cpp / ReadCounting.cpp glue RESTATED in
+    oracle/ref_counts.cpp -> oracle/_ref/libpg_refcounts.so, or the Python restatement): alignments, CIGAR slots, per-read status and label sets, node / edge / sequence tables."""
     from oracle import counts as oc
     from oracle import oracle as orc
     arr = s.reads
@@ -241,7 +248,7 @@ def sites_cpu_leg_main(args):
         pickle.dump(out, f, protocol=4)
     print(json.dumps({"sites": len(out), "reads": int(sum(len(o["res"]) for o in out)), "seconds": time.perf_counter() - t0, "workers": procs,
                       "aligner": "reference gssw.c (oracle/_ref)" if orc.have_ref() else "plain-C restatement (oracle/pg_oracle.c)",
-                      "counting": "reference graph-tools + Disambiguation (oracle/_ref/libpg_refcounts.so)" if oc.have_ref()
+                      "counting": "graph-tools compiled + Disambiguation glue restated (oracle/_ref/libpg_refcounts.so)" if oc.have_ref()
                       else "restatement (oracle/counts.py)"}))
 
 
@@ -297,6 +304,146 @@ def verify_sites(capi, graphs, sample_sites, sample_idx, res, ops, sup, table, w
                 "fields": out["fields"] + "; count-path status of every read, label sets of the mapped reads; node / edge / sequence "
                                           "tables of every sampled site (after the all-reduce)",
                 "reference": info})
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# configs[4]: long inline ALT nodes (2-8 kb) + 250 bp reads
+# ---------------------------------------------------------------------------------------------------
+CONFIG5_CIGAR_STRIDE = 256
+CONFIG5_READ_LEN = 250
+
+
+def config5_cases(n_graphs, reads_per_graph, seed=5):
+    """INV / DUP-style graphs LF -> {REF (60 bp), ALT (inline sequence, 2 000 .. 8 000 bp)} -> RF with 300 bp flanks, 250 bp
+    reads from both haplotypes (1 % substitutions, 1 % of the reads with an indel, 0.5 % unrelated sequence)."""
+    from paragraph_amd import synth
+    out = []
+    for gi in range(n_graphs):
+        alt = 2000 + (gi * 6007) % 6001
+        site = synth.long_node_site(seed * 1000 + gi, alt)
+        arr = synth.simulate_reads_packed(site, reads_per_graph, CONFIG5_READ_LEN, seed * 2000 + gi, indel_frac=0.01, random_frac=0.005)
+        out.append((site, arr))
+    return out
+
+
+_C5_JOB = None
+
+
+def _c5_job(i):
+    from oracle import oracle as orc
+    from oracle import select
+    site, arr = _C5_JOB[i]
+    n, L = arr.shape
+    off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L)).astype(np.uint32)
+    res = np.zeros(n, dtype=orc.RESULT_NP)
+    cig = np.zeros((n, CONFIG5_CIGAR_STRIDE), dtype=np.uint8)
+    select.gssw().align_into(site.seqs, site.edges, off, np.ascontiguousarray(arr).reshape(-1), res, cig, threads=1)
+    return res, cig
+
+
+def config5_cpu_leg_main(args):
+    """CPU-leg process of the configs[4] leg (TEST INFRASTRUCTURE): the reference's gssw.c on the sampled reads of every graph."""
+    global _C5_JOB
+    import multiprocessing as mp
+    import pickle
+    from oracle import oracle as orc
+    with open(args.cpu_reads_file, "rb") as f:
+        _C5_JOB = pickle.load(f)
+    procs = max(1, min(_effective_cpus(), len(_C5_JOB)))
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(procs) as pool:
+        out = pool.map(_c5_job, range(len(_C5_JOB)), chunksize=max(1, len(_C5_JOB) // (4 * procs)))
+    spent = time.perf_counter() - t0
+    with open(args.cpu_out, "wb") as f:
+        pickle.dump(out, f, protocol=4)
+    n = int(sum(len(r) for r, _ in out))
+    print(json.dumps({"graphs": len(out), "reads": n, "seconds": spent, "workers": procs, "reads_per_s": n / max(spent, 1e-9),
+                      "aligner": "reference gssw.c (oracle/_ref)" if orc.have_ref() else "plain-C restatement (oracle/pg_oracle.c)"}))
+
+
+def run_config5_leg(args, env, ctx, capi):
+    """configs[4] on the device: every graph's reads aligned (4 fills each over 2.7 - 8.7 k columns, the long node swept in one go:
+    a lane's state crosses a column block boundary in registers) + counted, K timed passes on resident data; a sample of every
+    graph's reads against the reference's gssw.c."""
+    import pickle
+    rank = env["rank"]
+    cases = config5_cases(args.config5_graphs, args.config5_reads_per_graph)
+    L = CONFIG5_READ_LEN
+    graphs = ctx.upload_graphs([(s.seqs, s.edges) for s, _ in cases])
+    graphs.set_labels([s.labels for s, _ in cases])
+    arr = np.concatenate([a for _, a in cases])
+    n = len(arr)
+    gor = np.repeat(np.arange(len(cases), dtype=np.uint32), args.config5_reads_per_graph)
+    g_len = np.array([s.total_len for s, _ in cases], dtype=np.float64)
+    cells = float((4.0 * L * g_len * args.config5_reads_per_graph).sum())
+    b_alg = float(((6.0 * L * g_len + L + 64) * args.config5_reads_per_graph).sum())
+    b_alg_h = float(((2.0 * L * g_len + L + 64) * args.config5_reads_per_graph).sum())
+    off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L)).astype(np.uint32)
+    batches = [ctx.new_batch(), ctx.new_batch()]
+    for b in batches:
+        b.upload(graphs, (off, np.ascontiguousarray(arr).reshape(-1)), gor)
+        b.set_fragments(np.arange(n, dtype=np.uint32) // 2)
+    ctx.sync()
+
+    def one(k):
+        batches[k & 1].align(capi.AF_ALL)
+        batches[k & 1].count(remove_nonuniq=True, bad_align_frac=0.8)
+
+    one(0)
+    one(1)
+    env["barrier"]()
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for k in range(args.config5_steps):
+        one(k)
+    env["barrier"]()
+    elapsed = env["max_over_ranks"](time.perf_counter() - t0)
+    tim = ctx.timing()
+    ctx.timing_enable(False)
+    last = batches[(args.config5_steps - 1) & 1]
+    res, ops = last.download()
+    fill_s = tim["fill_ms"] / 1e3
+    out = {"workload": "configs[4]: %d graphs LF(300) -> {REF(60), ALT(2 000 - 8 000, inline)} -> RF(300), %d synthetic 250 bp reads each, "
+                       "alignRead(AF_ALL) + filters + counts, every rank its own copy" % (len(cases), args.config5_reads_per_graph),
+           "graphs": len(cases), "reads": n, "read_len": L, "mean_graph_len": float(g_len.mean()), "steps": args.config5_steps,
+           "ms_per_step": elapsed / args.config5_steps * 1e3, "reads_per_s": n * env["world"] * args.config5_steps / elapsed,
+           "cell_updates_per_s": cells * env["world"] * args.config5_steps / elapsed,
+           "fill_launches": int(tim["fill_launches"]), "fill_ms": tim["fill_ms"], "trace_ms": tim["trace_ms"],
+           "hbm_formula_frac": (b_alg * args.config5_steps / fill_s / 1e9 / HBM_PEAK_GBS) if fill_s > 0 else None,
+           "hbm_alg_h_only_frac": (b_alg_h * args.config5_steps / fill_s / 1e9 / HBM_PEAK_GBS) if fill_s > 0 else None}
+    v = args.config5_verify_per_graph
+    if rank == 0 and v > 0:
+        sample = [(s, a[:v]) for s, a in cases]
+        tmp = tempfile.mkdtemp(prefix="pgbench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        in_file, out_file = os.path.join(tmp, "c5.pkl"), os.path.join(tmp, "ref.pkl")
+        try:
+            with open(in_file, "wb") as f:
+                pickle.dump(sample, f, protocol=4)
+            cmd = [sys.executable, os.path.abspath(__file__), "--config5-cpu-leg", "--cpu-reads-file", in_file, "--cpu-out", out_file]
+            cenv = dict(os.environ)
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                cenv.pop(k, None)
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, env=cenv, check=True)
+            info = json.loads(p.stdout.decode().strip().splitlines()[-1])
+            with open(out_file, "rb") as f:
+                want = pickle.load(f)
+        finally:
+            for f in (in_file, out_file):
+                if os.path.exists(f):
+                    os.unlink(f)
+            os.rmdir(tmp)
+        idx = (np.arange(len(cases))[:, None] * args.config5_reads_per_graph + np.arange(v)[None, :]).reshape(-1)
+        ref_res = np.concatenate([w[0] for w in want])
+        ref_cig = np.concatenate([w[1] for w in want])
+        ver = verify_against_reference(capi, res[idx], ops, ref_res, ref_cig)
+        ver["reference"] = info
+        ver["sample"] = "the first %d reads of every graph" % v
+        out["verified"] = ver
+    for b in batches:
+        b.close()
+    graphs.close()
     return out
 
 
@@ -1165,6 +1312,11 @@ def main_rank(args):
             sites_out, _, _, _ = run_sites_leg(args, env, ctx, capi, synth, sset, args.sites_steps, 1, False)
             if rank == 0:
                 out["sites"] = sites_out
+        if args.config5_graphs > 0:
+            log("config5 leg")
+            c5 = run_config5_leg(args, env, ctx, capi)
+            if rank == 0:
+                out["config5"] = c5
     if e2e is not None:
         log("e2e leg")
         barrier()
@@ -1179,6 +1331,8 @@ def main_rank(args):
         if out.get("verified") and out["verified"]["mismatches"]:
             rc = 3
         if out.get("e2e") and out["e2e"]["mismatches"]:
+            rc = 3
+        if out.get("config5") and out["config5"].get("verified") and out["config5"]["verified"]["mismatches"]:
             rc = 3
         if out.get("sites") and out["sites"].get("reduce_equals_single") is False:
             rc = 3
@@ -1341,6 +1495,7 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
     reads_total = args.reads * world * args.steps
     value = reads_total / elapsed
     b_alg = b_alg_total / args.reads  # 6*L*G + L + 64 per read
+    b_alg_h = 2 * L * G + L + 64      # the same with H only (the kernel re-derives E / F in the traceback)
     fill_s = tim["fill_ms"] / 1e3
     reads_per_fill_leg = args.reads * args.steps  # this rank's fill launches
     achieved_gbs = reads_per_fill_leg * b_alg / fill_s / 1e9 if fill_s > 0 else 0.0
@@ -1360,6 +1515,8 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
         "vs_baseline": None,
         "dtype": DTYPE,
         "data": "synthetic",
+        # the PCIe-inclusive rate (pinned host arrays in, every result array back on the host, double-buffered): never `value`
+        "value_streaming": (args.reads / t_stream) if t_stream else None,
         "config": {
             "workload": "configs[1]: 1 DEL graph (200bp flanks, nodes 201/100/201), %d synthetic %dbp reads per GPU, "
                         "GraphAligner::alignRead(AF_ALL) = 4 fills + strand pick + traceback per read, then "
@@ -1376,6 +1533,10 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
             **roof_extra,
             "alg_bytes_per_read": b_alg,
             "alg_bytes_per_launch": b_alg * reads_per_fill_leg / max(1, tim["fill_launches"]),
+            # what an H-only trace has to move: one byte of H per cell of the two traced fills + the read in + the record out
+            "hbm_alg_h_only_bytes_per_read": b_alg_h,
+            "hbm_alg_h_only_gbs": reads_per_fill_leg * b_alg_h / fill_s / 1e9 if fill_s > 0 else 0.0,
+            "hbm_alg_h_only_frac": (reads_per_fill_leg * b_alg_h / fill_s / 1e9 / HBM_PEAK_GBS) if fill_s > 0 else 0.0,
             "gcups": tim["cells"] / fill_s / 1e9 if fill_s > 0 else 0.0,
             "trace_bytes_written_per_read": tim["trace_bytes"] / max(1, reads_per_fill_leg),
         },
@@ -1419,6 +1580,9 @@ def main():
         return 0
     if args.sites_cpu_leg:
         sites_cpu_leg_main(args)
+        return 0
+    if args.config5_cpu_leg:
+        config5_cpu_leg_main(args)
         return 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         os.environ["PG_BENCH_LAUNCHER"] = "bench.py --gpus %d (self-spawned torch.distributed.run)" % args.gpus

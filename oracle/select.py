@@ -60,7 +60,7 @@ def count_site():
     """The count path's checker as a function (graph, records, **kw) -> dict."""
     from . import counts as oc
     return choose("counts", oc.have_ref, lambda: oc.RefCounts().count_site, lambda: oc.port_count_site,
-                  "oracle/_ref/libpg_refcounts.so (reference graph-tools + Disambiguation)", "oracle/counts.py (restatement)")
+                  "oracle/_ref/libpg_refcounts.so (graph-tools compiled + Disambiguation glue restated)", "oracle/counts.py (restatement)")
 
 
 def klib():

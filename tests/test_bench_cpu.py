@@ -122,6 +122,30 @@ def test_cpu_leg_and_verification(tmp_path):
     assert v["mismatches"] == 2 and v["first_mismatch"]["read"] == 7
 
 
+def test_config5_cpu_leg(tmp_path):
+    """bench.py --config5-cpu-leg (the checker side of the configs[4] leg) on two small long-node graphs: its records equal
+    per-read checker calls on the same reads."""
+    import pickle
+    import bench
+    from oracle import select
+    cases = bench.config5_cases(2, 3)
+    assert all(a.shape == (3, bench.CONFIG5_READ_LEN) and 2000 <= len(s.seqs[2]) <= 8000 for s, a in cases)
+    in_file, out_file = tmp_path / "c5.pkl", tmp_path / "ref.pkl"
+    with open(in_file, "wb") as f:
+        pickle.dump([(s, a[:2]) for s, a in cases], f, protocol=4)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config5-cpu-leg", "--cpu-reads-file", str(in_file), "--cpu-out",
+                        str(out_file)], stdout=subprocess.PIPE, check=True)
+    info = json.loads(p.stdout.decode().splitlines()[-1])
+    assert info["graphs"] == 2 and info["reads"] == 4
+    with open(out_file, "rb") as f:
+        want = pickle.load(f)
+    chk = select.gssw()
+    for (s, a), (res, cig) in zip(cases, want):
+        assert cig.shape == (2, bench.CONFIG5_CIGAR_STRIDE)
+        for i, w in enumerate(chk.align_batch(s.seqs, s.edges, [row.tobytes().decode() for row in a[:2]])):
+            assert w["cigar"].encode() == bytes(cig[i]).split(b"\0")[0] and w["score"] == res[i]["score"] > 100
+
+
 def test_bench_spawn_command(monkeypatch):
     """--gpus N without WORLD_SIZE: bench.py re-executes itself under torch.distributed.run on 127.0.0.1 with N ranks."""
     import bench

@@ -27,7 +27,7 @@ extern "C" {
  *                          variable -- "0,1,2,3" or "all" -- else device 0; sites are independent, the devices
  *                          exchange nothing)
  *                          (grmpy's option names and defaults, grmpy/Parameters.hh:30-74; "sites_per_batch" = (graph,
- *                          sample) pairs per device batch, default 192 (384 when a seed stage runs before the graph aligner); "lanes" = batches in flight, default about 1.5 per
+ *                          sample) pairs per device batch, default 192 for every cascade; "lanes" = batches in flight, default about 1.5 per
  *                          host thread, at most 32 per device and at least one per device -- it grows with the device
  *                          list; a lane sleeps while its batch is on the device)
  *   error/error_cap        receives the message when the call fails (may be NULL)

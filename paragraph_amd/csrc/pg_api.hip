@@ -327,6 +327,7 @@ extern "C" pg_status pg_ctx_set_fill_streams(pg_ctx* ctx, int n)
     for (auto& e : ctx->region_free)
         e = nullptr;
     ctx->fill_streams = n;
+    ++ctx->plan_epoch;  // chunks cut for the old region size must not meet the new regions (pg_batch_align checks)
     return PG_OK;
 }
 
@@ -519,11 +520,16 @@ hipError_t pg_stage_end_on(pg_ctx* ctx, pg_batch* b, hipStream_t s)
         hipError_t e = hipSuccess;
         if (!G->ev_use[w])
             e = hipEventCreateWithFlags(&G->ev_use[w], pg_wait_event_flags());
+        // ONE event per slot, several seed streams: re-recording it on another stream would drop what it said about the first.
+        // The stream recorded now first waits for the event's previous recording, so the new one covers every earlier use.
+        if (e == hipSuccess && G->use_recorded[w] && G->use_stream[w] != s)
+            e = hipStreamWaitEvent(s, G->ev_use[w], 0);
         if (e == hipSuccess)
             e = hipEventRecord(G->ev_use[w], s);
         if (e != hipSuccess)
             return e;
         G->use_recorded[w] = true;
+        G->use_stream[w] = s;
     }
     if (!b->ev_busy)
         return hipSuccess;
@@ -1158,6 +1164,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
     if (!std::is_sorted(keys.begin(), keys.end(), key_less))  // reads of one length, site after site, arrive in order
         std::stable_sort(keys.begin(), keys.end(), key_less);
     b->plan_stale = false;
+    b->plan_epoch = ctx->plan_epoch;
     if (!active)
     {
         // the (variant, graph) runs of the whole batch: what a plan made from the device's per-run counts of ACTIVE reads starts
@@ -1912,9 +1919,27 @@ extern "C" pg_status pg_batch_retire_mapped(pg_ctx* ctx, pg_batch* b)
     // always
     hipStream_t cs = b->seed_chain ? b->seed_stream : ctx->stream2;
     HIP_TRY(ctx, pg_stage_begin_on(ctx, b, cs));
+    // every way out from here on records the end of the stage on its stream (an error return that skipped it would let the
+    // caller free blocks the kernels queued so far still read); the mask only counts as written once the kernel that writes it
+    // is queued
+    struct StageEnd
+    {
+        pg_ctx* c;
+        pg_batch* b;
+        hipStream_t s;
+        bool done;
+        ~StageEnd()
+        {
+            if (!done)
+                (void)pg_stage_end_on(c, b, s);
+        }
+    } stage_end{ ctx, b, cs, false };
     const uint32_t had_mask = b->has_active ? 1u : 0u;
-    b->has_active = true;
-    b->plan_stale = true;
+    if (!b->n_reads)
+    {
+        b->has_active = true;
+        b->plan_stale = true;
+    }
     if (b->n_reads)
     {
         // (a batch with general-path reads plans on the host from the downloaded flags: pg_batch_ensure_plan)
@@ -1931,6 +1956,8 @@ extern "C" pg_status pg_batch_retire_mapped(pg_ctx* ctx, pg_batch* b)
         hipLaunchKernelGGL(pg_retire_kernel, dim3((threads + 255) / 256), dim3(256), 0, cs, b->n_reads, b->d_path_flags, b->d_support, b->d_active,
                            had_mask, n_groups ? b->d_group_count : nullptr, n_groups);
         HIP_TRY(ctx, hipGetLastError());
+        b->has_active = true;
+        b->plan_stale = true;
         if (rebuild)
         {
             const pg_status rs = cascade_rebuild_items(ctx, b, cs, b->d_active, true);
@@ -1938,6 +1965,7 @@ extern "C" pg_status pg_batch_retire_mapped(pg_ctx* ctx, pg_batch* b)
                 return rs;
         }
     }
+    stage_end.done = true;
     HIP_TRY(ctx, pg_stage_end_on(ctx, b, cs));
     return PG_OK;
 }
@@ -1972,6 +2000,9 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         recycle_done_sync_events(ctx);
     }
     const pg_graphs* G = b->graphs;
+    if (b->plan_epoch != ctx->plan_epoch)
+        return fail(ctx, PG_ERR_INVALID, "pg_batch_align: the batch was uploaded before pg_ctx_set_fill_streams changed the number of "
+                                         "workspace regions (its chunks were cut for the old ones): upload it again");
     {
         const auto t0 = std::chrono::steady_clock::now();
         const uint64_t cap0 = ctx->ws_cap;
@@ -1986,14 +2017,6 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     b->h_counters_valid = false;
     b->seed_chain = false;
     HIP_TRY(ctx, pg_stage_begin(ctx, b));
-    {
-        const pg_status ps = pg_batch_ensure_plan(ctx, b, ctx->stream);  // work items follow a device-side hand-over (no-op otherwise)
-        if (ps != PG_OK)
-            return ps;
-        const pg_status ws2 = ensure_ctx_workspace(ctx, b);  // (a re-made plan never needs more than the upload-time one; cheap)
-        if (ws2 != PG_OK)
-            return ws2;
-    }
     // Every way out of this call from here on records the end of the stage: pg_graphs_destroy / pg_dev_free / the next stage of
     // this batch trust those events.  An error return that skipped it (a failed launch, the general path) would let the caller
     // hand the batch's and the graph set's device blocks to another lane while the kernels queued so far still read them.
@@ -2018,6 +2041,15 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             (void)pg_stage_end_on(c, b, c->stream2);
         }
     } stage_end{ ctx, b, false };
+    {
+        // (inside the guarded region: a plan re-made on the device has queued kernels by the time a later step of it fails)
+        const pg_status ps = pg_batch_ensure_plan(ctx, b, ctx->stream);  // work items follow a device-side hand-over (no-op otherwise)
+        if (ps != PG_OK)
+            return ps;
+        const pg_status ws2 = ensure_ctx_workspace(ctx, b);  // (a re-made plan never needs more than the upload-time one; cheap)
+        if (ws2 != PG_OK)
+            return ws2;
+    }
     if ((!(flags & PG_AF_KEEP_RESULTS) || (flags == PG_AF_ALL)) && !b->ops_counter_fresh)
         HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
     b->ops_counter_fresh = false;

@@ -91,6 +91,7 @@ struct pg_ctx
         return s == stream_seed || (s && (s == stream_seed_more[0] || s == stream_seed_more[1] || s == stream_seed_more[2]));
     }
     int fill_streams = 1;
+    uint32_t plan_epoch = 0;  // counts the changes of the region count: a batch planned under another one is refused (pg_batch_align)
     unsigned regions() const { return fill_streams == 2 ? 3u : 2u; }
     hipEvent_t region_free[3] = { nullptr, nullptr, nullptr };
     uint64_t ws_limit = 8ull << 30;
@@ -122,6 +123,7 @@ struct pg_graphs
     // only -- not for whatever other batches have queued on the streams
     mutable hipEvent_t ev_use[3] = { nullptr, nullptr, nullptr };  // (main stream, second stream, seed stream)
     mutable bool use_recorded[3] = { false, false, false };
+    mutable hipStream_t use_stream[3] = { nullptr, nullptr, nullptr };  // the stream each event was last recorded on (the seed slot is shared by several)
     std::vector<HostGraph> host;
     void* d_layout_block = nullptr;  // one allocation behind d_graphs .. d_seqchars (PgStagedUpload)
     void* d_count_block = nullptr;   // one allocation behind d_cnt_graphs .. d_in_mask
@@ -193,6 +195,7 @@ struct pg_batch
     std::vector<uint32_t> h_group_of_read;    // per read: its group, PG_NONE for empty reads and reads of the general path
     bool has_general_reads = false;           // some read of the batch takes the general path (then the host re-plans from the flags)
     bool plan_stale = false;                  // d_active changed on the device since the work items were made
+    uint32_t plan_epoch = 0;                  // pg_ctx::plan_epoch when the upload-time plan was cut
     hipStream_t seed_stream = nullptr;        // the seed stream this batch's path stage ran on
     bool seed_chain = false;                  // the batch's last stage ran on the seed stream (pg_batch_path_align): its count pass and
                                               // hand-over follow it there

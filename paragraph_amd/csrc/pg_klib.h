@@ -7,6 +7,7 @@
 #include "../../include/paragraph_amd.h"
 #include "pg_device.h"
 
+constexpr uint32_t PG_KLIB_CIG_SMALL = 24;  // entries of a candidate's own CIGAR slot in the packed finish kernel (KlibArgs::cig_small)
 constexpr int PG_KLIB_MAX_PATHS = 30;        // candidate heaps of paths + 2 entries in registers (select / pick kernels)
 constexpr int PG_KLIB_MAX_PATHS_WIDE = 126;  // graphs with more paths: the same kernels with 128-entry heaps (scratch memory)
 
@@ -49,8 +50,15 @@ struct KlibArgs
     const uint32_t* starts;
     const uint8_t* active;
     KlibItem* items;
-    uint32_t* cigars;    // general kernels: [n_items][cig_cap]; packed kernels: [n_work][cig_cap]
+    uint32_t* cigars;    // general kernels: [n_items][cig_cap]; packed kernels: [n_work][cig_small] + a pool of [ovf_cap][cig_cap]
     uint32_t cig_cap;
+    // packed kernels: a candidate's CIGAR goes into its own short slot (cig_small entries: nine in ten have <= 5) and moves to a
+    // full-size slot of the pool (entries from ovf_base on, handed out through ovf_count) when it outgrows it; an exhausted pool
+    // raises error bit 1 like an overflowing slot
+    uint32_t cig_small;
+    uint32_t ovf_cap;
+    uint32_t ovf_base;
+    uint32_t* ovf_count;
     uint8_t* z;          // [gridDim.x][z_bytes]
     uint64_t z_bytes;
     // packed kernels

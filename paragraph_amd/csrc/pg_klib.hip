@@ -872,7 +872,7 @@ extern "C" pg_status pg_graphs_build_klib_index(
     if (e == hipSuccess) e = upl(pathcode, &ix->d_pathcode, ctx->stream_copy);
     if (e == hipSuccess) e = upl(starts, &ix->d_starts, ctx->stream_copy);
     if (e == hipSuccess) e = upl(pathmeta, &ix->d_pathmeta, ctx->stream_copy);
-    if (e == hipSuccess) e = pg_dev_alloc((void**)&ix->d_work_count, sizeof(uint32_t));
+    if (e == hipSuccess) e = pg_dev_alloc((void**)&ix->d_work_count, 2 * sizeof(uint32_t));  // [0] work list, [1] CIGAR pool
     if (e == hipSuccess) e = pg_dev_alloc((void**)&ix->d_error, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(ix->d_error, 0, sizeof(uint32_t), ctx->stream_copy);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream_copy);
@@ -1016,7 +1016,7 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
         a.worklist = d_worklist;
         a.work_count = ix->d_work_count;
         a.work = b->d_items;
-        HIP_TRY(ctx, hipMemsetAsync(ix->d_work_count, 0, sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ix->d_work_count, 0, 2 * sizeof(uint32_t), ctx->stream));
         // first pass: the batch's wavefront work items (4 reads of one graph and one length class each), every path of the graph
         for (const Chunk& c : b->chunks)
         {
@@ -1032,8 +1032,20 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
         // resident wavefronts and the scratch for every candidate.  (A read-back here was a wait for the whole main stream -- the
         // fills of every batch queued before this one -- under the caller's device lock: the workflow with the klib stage ran at
         // 5 - 27 k sites/s.)
-        const uint32_t n_work = (uint32_t)std::min<uint64_t>(n_items, 0xFFFFFFFFull);
-        if ((uint64_t)n_work * cig_cap >= (1ull << 32))
+        // CIGAR scratch: a short slot per candidate (PG_KLIB_CIG_SMALL entries; a CIGAR of the best score is a handful of runs)
+        // + a pool of full-size slots for the ones that outgrow theirs, one per 32 candidates and at least 4 096: 150 bp reads on
+        // ten paths cost 0.13 KB of scratch per candidate, not 1.2 KB, and the 32-bit entry index holds 100 M candidates.
+        // PG_KLIB_CIG_POOL=<slots> sizes the pool for batches of reads with many indels (an exhausted pool is error bit 1 of
+        // pg_graphs_klib_error, never a wrong CIGAR).
+        if (n_items >= (1ull << 32))
+            return pg_fail(ctx, PG_ERR_UNSUPPORTED, "pg_batch_klib_align: batch too large (candidate index)");
+        const uint32_t n_work = (uint32_t)n_items;
+        const uint32_t cig_small = std::min<uint32_t>(cig_cap, PG_KLIB_CIG_SMALL);
+        uint64_t ovf_cap = cig_small == cig_cap ? 0u : std::min<uint64_t>(n_work, std::max<uint64_t>(4096u, n_work / 32u));
+        if (const char* e = std::getenv("PG_KLIB_CIG_POOL"))
+            ovf_cap = cig_small == cig_cap ? 0u : std::min<uint64_t>(n_work, std::strtoull(e, nullptr, 10));
+        const uint64_t cig_entries = (uint64_t)n_work * cig_small + ovf_cap * cig_cap;
+        if (cig_entries >= (1ull << 32))
             return pg_fail(ctx, PG_ERR_UNSUPPORTED, "pg_batch_klib_align: batch too large (CIGAR scratch index)");
         const int C = pg_var_c(pg_variant_of(max_len));
         const uint32_t waves = (n_work + 7u) / 8u;  // (an upper bound: every candidate)
@@ -1041,11 +1053,15 @@ extern "C" pg_status pg_batch_klib_align(pg_ctx* ctx, pg_batch* b, uint32_t flag
         // z_bytes of direction scratch
         const uint32_t grid = std::min<uint32_t>(waves, (uint32_t)n_cu * (C > 16 ? 4u : 10u));
         const uint64_t z_bytes = pg_klib_finish_z_bytes(C);
-        st = scratch(ctx, 2, &d_cigars, std::max<size_t>((size_t)n_work * cig_cap, 1));
+        st = scratch(ctx, 2, &d_cigars, std::max<size_t>((size_t)cig_entries, 1));
         if (st == PG_OK) st = scratch(ctx, 3, &d_z, std::max<size_t>((size_t)grid * z_bytes, 1));
         if (st != PG_OK)
             return st;
         a.cigars = d_cigars;
+        a.cig_small = cig_small;
+        a.ovf_cap = (uint32_t)ovf_cap;
+        a.ovf_base = n_work * cig_small;
+        a.ovf_count = ix->d_work_count + 1;
         a.z = d_z;
         a.z_bytes = z_bytes;
         a.n_work = 0;  // (unused: a.work_count is set)

@@ -644,8 +644,30 @@ __global__ __launch_bounds__(64) void pg_klib_finish_kernel(KlibArgs a)
             const FinishInfo& f = h == 0 ? gA : gB;
             const bool live = f.item != PG_NONE;
             const uint32_t w = base + (uint32_t)(2 * grp + h);
-            const uint32_t slot_base = w * a.cig_cap;
+            // the candidate's short slot; `cap` entries from slot_base on, filled from the end (the walk runs backwards)
+            uint32_t slot_base = w * a.cig_small, cap = a.cig_small;
             uint32_t* slot = a.cigars + slot_base;
+            // the first lane of the eight writes: it moves the CIGAR into a full-size slot of the pool when the short one is full
+            auto room = [&](uint32_t n_have) -> bool {
+                if (n_have < cap)
+                    return true;
+                if (cap == a.cig_cap)
+                    return false;
+                if (d == 0)
+                {
+                    const uint32_t o = atomicAdd(a.ovf_count, 1u);
+                    if (o >= a.ovf_cap)
+                        return false;
+                    const uint32_t nb = a.ovf_base + o * a.cig_cap;
+                    uint32_t* ns = a.cigars + nb;
+                    for (uint32_t e = 0; e < n_have; ++e)
+                        ns[a.cig_cap - 1 - e] = slot[cap - 1 - e];
+                    slot = ns;
+                    slot_base = nb;
+                }
+                cap = a.cig_cap;
+                return true;
+            };
             const uint8_t* zb = (const uint8_t*)zw;
             const int ql = f.qe - f.qb + 1, tl = f.te - f.tb + 1;
             uint32_t n = 0, cur = 0;
@@ -657,10 +679,10 @@ __global__ __launch_bounds__(64) void pg_klib_finish_kernel(KlibArgs a)
                 {
                     if (have)
                     {
-                        if (n < a.cig_cap)
+                        if (!overflow && room(n))
                         {
                             if (d == 0)
-                                slot[a.cig_cap - 1 - n] = cur;
+                                slot[cap - 1 - n] = cur;
                         }
                         else
                             overflow = true;
@@ -743,8 +765,8 @@ __global__ __launch_bounds__(64) void pg_klib_finish_kernel(KlibArgs a)
                     push(1, (uint32_t)(j + 1));
                 if (have)
                 {
-                    if (n < a.cig_cap)
-                        slot[a.cig_cap - 1 - n] = cur;
+                    if (!overflow && room(n))
+                        slot[cap - 1 - n] = cur;
                     else
                         overflow = true;
                     ++n;
@@ -760,7 +782,7 @@ __global__ __launch_bounds__(64) void pg_klib_finish_kernel(KlibArgs a)
                     out.tb = f.tb;
                     out.qb = f.qb;
                     out.n_cigar = n;
-                    out.cig_begin = slot_base + a.cig_cap - n;
+                    out.cig_begin = slot_base + cap - n;
                     out.valid = f.te >= f.tb ? 1u : 0u;
                 }
                 a.items[f.item] = out;

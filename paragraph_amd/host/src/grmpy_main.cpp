@@ -101,6 +101,9 @@ int main(int argc, char** argv)
         parameters.genotype_text_indent = 1;
         grmpy::genotypeGraphs(parameters, graphs, reference, samples, genotyping_parameters);
 
+        for (std::string& d : documents)
+            if (d.empty())
+                d = "null";  // (a graph nothing was written for: the empty document's text, never a hole between the commas)
         if (!output_folder.empty())
             for (size_t g = 0; g < graphs.size(); ++g)
                 cli::writeOutput(output_folder + "/" + cli::baseName(graphs[g]) + (gzip ? ".gz" : ""), documents[g] + "\n", gzip);

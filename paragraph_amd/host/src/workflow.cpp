@@ -1256,7 +1256,9 @@ extern "C" int pgw_genotype_graphs(
             {
                 std::string& t = text[ordered.next];
                 const char* sep = ordered.next ? ",\n" : "\n";
-                ordered.ok = ordered.ok && fputs(sep, out) != EOF && fwrite(t.data(), 1, t.size(), out) == t.size();
+                // (a graph nothing was written for -- no samples -- is `null`, like Json::dump() of the empty document: never a hole)
+                ordered.ok = ordered.ok && fputs(sep, out) != EOF
+                    && (t.empty() ? fputs("null", out) != EOF : fwrite(t.data(), 1, t.size(), out) == t.size());
                 ++ordered.next;  // (the text is freed with the others at the end: freed here it would go back to ANOTHER lane's arena)
             }
         };

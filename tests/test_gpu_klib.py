@@ -449,3 +449,39 @@ def test_klib_config2_8192_reads(gpu_ctx):
     flags, got = gpu_klib(gpu_ctx, [(site.seqs, site.edges)], [ps], reads, None, expect_packed=True)
     mapped = check(flags, got, want, reads, "klib-config2")
     assert mapped > 0.99 * n
+
+
+def test_klib_cigar_pool_is_used_and_its_exhaustion_is_loud(gpu_ctx, monkeypatch):
+    """Packed finish kernel: a candidate's CIGAR starts in a 24-entry slot of its own and moves to a full-size slot of the pool
+    when it outgrows it (reads with a dozen indels).  Results equal the checker's; with the pool taken away (PG_KLIB_CIG_POOL=0)
+    the stage says so through pg_graphs_klib_error (bit 1) instead of returning a cut CIGAR."""
+    from oracle.pathalign import _rc
+    chk = checker()
+    rng = random.Random(fuzzgen.salted(811))
+    nodes, ps = _site(rng, 3, 330)
+    nodes = [n.replace("N", "A") for n in nodes]
+    reads = []
+    for _ in range(120):
+        seq = "".join(nodes[x] for x in rng.choice(ps))
+        st = rng.randrange(max(1, len(seq) - 300))
+        r = list(seq[st:st + 300])
+        for cut in sorted(rng.sample(range(15, len(r) - 15, 16), 14), reverse=True):  # 14 one-base indels, 16+ bases apart
+            if rng.random() < 0.5:
+                del r[cut]
+            else:
+                r.insert(cut, rng.choice("ACGT"))
+        r = "".join(r)[:320]
+        reads.append(_rc(r) if rng.random() < 0.5 else r)
+    want = chk.align(nodes, ps, reads)
+    assert sum(1 for w in want if w["status"] == 1 and w["cigar"].count("I") + w["cigar"].count("D") >= 12) > 20
+    flags, got = gpu_klib(gpu_ctx, [(nodes, edges_of(ps))], [ps], reads, None, expect_packed=True)
+    check(flags, got, want, reads, "klib-pool")
+    monkeypatch.setenv("PG_KLIB_CIG_POOL", "0")
+    G = gpu_ctx.upload_graphs([(nodes, edges_of(ps))])
+    G.build_klib_index([ps])
+    b = gpu_ctx.new_batch()
+    b.upload(G, reads, None)
+    b.klib_align()
+    assert G.klib_error() & 2
+    b.close()
+    G.close()

@@ -24,6 +24,11 @@ struct PathGraphDev
     uint32_t tab_mask;   // capacity - 1 (capacity is a power of two), 0xFFFFFFFF = graph has no k-mers
     uint32_t k;          // k-mer length of this graph's table
     uint64_t pow_k1;     // PG_HASH_B^(k-1)
+    // Presence filter: one bit per (hash >> 32) & filt_mask, set for every k-mer of the graph, 64 bits per k-mer (a k-mer that is
+    // not in the graph meets a clear bit 98 times in 100; one that is never does).  The path stage's scan asks it before the
+    // table: in the table "the slot is not empty" is true for a quarter to a half of all hashes.
+    uint32_t filt_off;   // first 32-bit word in the set's filter array
+    uint32_t filt_mask;  // bits - 1 (a power of two)
 };
 
 struct KmerEntry
@@ -49,6 +54,7 @@ struct pg_path_index
     uint32_t* d_succ_off = nullptr;
     uint32_t* d_succ = nullptr;
     uint8_t* d_node_uniq = nullptr;  // per set-wide node: numUniqueKmersOverlappingNode(node) > 0
+    uint32_t* d_filter = nullptr;    // the graphs' presence filters (PathGraphDev::filt_off)
     std::vector<uint32_t> h_k;       // per graph
 };
 
@@ -59,6 +65,7 @@ struct PgKmerIndexHost
     std::vector<PathGraphDev> gd;
     std::vector<KmerEntry> table;
     std::vector<uint8_t> node_uniq;
+    std::vector<uint32_t> filter;
 };
 const char* pg_build_kmer_index_host(const pg_graphs* G, const std::vector<int32_t>& k_per_graph, PgKmerIndexHost& tables, bool want_node_uniq);  // NULL = fine
 

@@ -10,10 +10,10 @@
 // Host: enumerates every length-k path of every graph (depth-first over successors in ascending id, as
 // extendPathEnd does), groups them by sequence and builds one open-addressing hash table per graph:
 // key = 64-bit polynomial hash of the k raw characters, value = (number of paths with that sequence, first path).
-// Device: one thread per read; both strands; rolling hash over the read; for k-mers with exactly one path the
-// reference's greedy exact extension (right, then left; at a node end the neighbour with the UNIQUE longest
-// common prefix over the shortest neighbour's length) is replayed on the raw node sequences, eight characters
-// at a time (the reverse strand on a reverse-complemented copy of the reads made once per upload).  A read is MAPPED when a match covers the whole read; more than one such match makes it
+// Device: sixteen lanes per read; both strands; all k-mer positions of a 128-position window hashed and probed in one round trip;
+// for k-mers with exactly one path the reference's greedy exact extension (right, then left; at a node end the neighbour with
+// the UNIQUE longest common prefix over the shortest neighbour's length) is replayed on the raw node sequences, 128 characters
+// per trip (the reverse strand on a reverse-complemented copy of the reads the row writes first).  A read is MAPPED when a match covers the whole read; more than one such match makes it
 // non-unique (MAPQ 0).  HBM-bound byte work: no LDS staging is needed (a read touches <= 2L graph bytes).
 #include <hip/hip_runtime.h>
 
@@ -43,6 +43,7 @@ struct PathArgs
     const uint32_t* graph_of_read;
     const PathGraphDev* graphs;
     const KmerEntry* table;
+    const uint32_t* filter;  // presence bits of the graphs' k-mers (PathGraphDev::filt_off / filt_mask)
     const uint32_t* pool;
     const uint32_t* node_off;  // raw char offsets per (set-wide) node, n_total + 1
     const char* raw;
@@ -69,12 +70,21 @@ __device__ __forceinline__ uint32_t comp_raw(uint32_t c)
     }
 }
 
-// Eight characters at a time: the reference's character loops (PathOperations.cpp:128-136, 150-159, 202-210, 225-235) are runs of
-// equal characters of two byte strings, forwards or backwards.  One thread owns one read and the 64 threads of a wavefront are at
-// different places of their reads, so a wavefront pays for the LONGEST loop any of its threads is in at every step: with one
-// character per trip the stage spent 430 000 VALU instructions per wavefront (profiles/r05_stage_counters.json: 2.8 ms, the
-// lifetime of one wavefront however few there are).  Wide loads only where eight characters remain on both sides: nothing is read
-// outside the two strings.
+// Sixteen lanes per read (a 16-lane row of the wavefront = one read, four reads per wavefront).  The stage's time is a chain of
+// dependent memory round trips per read, not arithmetic; with ONE thread per read (rounds 1 - 5) a read paid ~25 of them for its
+// scan (eight k-mer positions probed per trip) and 20 - 60 more per extension, and a workflow batch of 19 200 reads was 300
+// wavefronts on a chip with 1 024 SIMDs: 0.7 ms of pure latency per launch, 1.5 ms beside a fill.  Now
+//   * scan: the sixteen lanes hash and probe 128 k-mer positions of a strand in ONE trip (lane i: positions 8 i .. 8 i + 7 of the
+//     window, hashes rolled in registers, eight probes in flight per lane); the non-empty slots become a 128-bit candidate mask
+//     in LDS that the walk of PathAligner.cpp:92-106 then consumes with bit scans, no further probing;
+//   * the reference's character loops (PathOperations.cpp:128-136, 150-159, 202-210, 225-235: runs of equal characters of two
+//     byte strings, forwards or backwards) compare 128 characters per trip, eight per lane, the first mismatch found by a ballot;
+//   * everything that steers the walk (positions, nodes, lengths) is computed by all sixteen lanes from the same values: control
+//     flow is uniform within a row, the four rows of a wavefront diverge from each other.
+// Wide loads only where eight characters remain on both sides: nothing is read outside the two strings.
+constexpr int PGL = 16;        // lanes per read
+constexpr int PWIN = 8 * PGL;  // k-mer positions per scan window
+
 __device__ __forceinline__ uint64_t load8(const char* p)
 {
     uint64_t v;
@@ -82,73 +92,98 @@ __device__ __forceinline__ uint64_t load8(const char* p)
     return v;
 }
 
-// number of leading characters x[0..n) and y[0..n) have in common
-__device__ __forceinline__ uint32_t common_prefix(const char* x, const char* y, uint32_t n)
+struct Row
 {
-    uint32_t i = 0;
-    while (i + 16 <= n)  // (four loads in flight: the loop is a chain of round trips, one per trip)
+    int grp, kl;  // the wavefront's row (read) this lane works for, lane within the row
+    __device__ uint32_t ballot(bool p) const { return (uint32_t)(__ballot(p) >> (PGL * grp)) & 0xFFFFu; }
+    __device__ uint32_t bcast(uint32_t v, int src_lane) const { return (uint32_t)__shfl((int)v, grp * PGL + src_lane); }
+};
+
+// number of leading characters x[0..n) and y[0..n) have in common (the same value in every lane of the row)
+__device__ __forceinline__ uint32_t common_prefix(const Row& w, const char* x, const char* y, uint32_t n)
+{
+    for (uint32_t base = 0; base < n; base += (uint32_t)PWIN)
     {
-        const uint64_t d0 = load8(x + i) ^ load8(y + i), d1 = load8(x + i + 8) ^ load8(y + i + 8);
-        if (d0)
-            return i + ((uint32_t)__builtin_ctzll(d0) >> 3);
-        if (d1)
-            return i + 8 + ((uint32_t)__builtin_ctzll(d1) >> 3);
-        i += 16;
+        const uint32_t off = base + 8u * (uint32_t)w.kl;
+        uint64_t d = 0;
+        if (off + 8 <= n)
+            d = load8(x + off) ^ load8(y + off);
+        else if (off < n)
+            for (uint32_t i = 0; off + i < n; ++i)
+                d |= (uint64_t)(uint8_t)(x[off + i] ^ y[off + i]) << (8 * i);
+        const uint32_t bal = w.ballot(d != 0);
+        if (bal)
+        {
+            const int fl = __builtin_ctz(bal);
+            return w.bcast(off + ((uint32_t)__builtin_ctzll(d | (1ull << 63)) >> 3), fl);
+        }
     }
-    while (i + 8 <= n)
-    {
-        const uint64_t d = load8(x + i) ^ load8(y + i);
-        if (d)
-            return i + ((uint32_t)__builtin_ctzll(d) >> 3);
-        i += 8;
-    }
-    while (i < n && x[i] == y[i])
-        ++i;
-    return i;
+    return n;
 }
 
 // number of trailing characters the strings ENDING at xe and ye (exclusive) have in common, at most n
-__device__ __forceinline__ uint32_t common_suffix(const char* xe, const char* ye, uint32_t n)
+__device__ __forceinline__ uint32_t common_suffix(const Row& w, const char* xe, const char* ye, uint32_t n)
 {
-    uint32_t i = 0;
-    while (i + 16 <= n)
+    for (uint32_t base = 0; base < n; base += (uint32_t)PWIN)
     {
-        const uint64_t d0 = load8(xe - i - 8) ^ load8(ye - i - 8), d1 = load8(xe - i - 16) ^ load8(ye - i - 16);
-        if (d0)
-            return i + ((uint32_t)__builtin_clzll(d0) >> 3);
-        if (d1)
-            return i + 8 + ((uint32_t)__builtin_clzll(d1) >> 3);
-        i += 16;
+        const uint32_t off = base + 8u * (uint32_t)w.kl;  // characters between this lane's eight and the end
+        uint64_t d = 0;
+        if (off + 8 <= n)
+            d = load8(xe - off - 8) ^ load8(ye - off - 8);
+        else if (off < n)
+            for (uint32_t i = 0; off + i < n; ++i)  // (the i-th character from the end goes to the top: clz counts from there)
+                d |= (uint64_t)(uint8_t)(xe[-1 - (int)(off + i)] ^ ye[-1 - (int)(off + i)]) << (8 * (7 - i));
+        const uint32_t bal = w.ballot(d != 0);
+        if (bal)
+        {
+            const int fl = __builtin_ctz(bal);
+            return w.bcast(off + ((uint32_t)__builtin_clzll(d | 1ull) >> 3), fl);
+        }
     }
-    while (i + 8 <= n)
-    {
-        const uint64_t d = load8(xe - i - 8) ^ load8(ye - i - 8);
-        if (d)
-            return i + ((uint32_t)__builtin_clzll(d) >> 3);
-        i += 8;
-    }
-    while (i < n && xe[-1 - (int)i] == ye[-1 - (int)i])
-        ++i;
-    return i;
+    return n;
 }
 
-struct Walker
+// A row's view of its graph.  SMALL: the graph's node offsets and successor / predecessor lists sit in the row's LDS block (graphs of
+// up to TOPO_N nodes and TOPO_E edges: every site graph the templates make), so the steps of a walk that only ask "how long is this
+// node, who follows it" cost an LDS read, not a memory round trip; larger graphs read the tables where they are.
+constexpr uint32_t TOPO_N = 32, TOPO_E = 64;
+constexpr uint32_t REC_N = 24;  // nodes a walk may add on either side before the record falls back to the two-pass form
+struct RowLds
+{
+    uint64_t hash[PWIN];                  // hashes of the current scan window's k-mers
+    uint8_t mask[PGL] __attribute__((aligned(8)));  // ... and which of them the presence filter lets through
+    uint32_t node_off[TOPO_N + 1];        // raw character offsets (set-wide values)
+    uint32_t succ_off[TOPO_N + 1];        // offsets into succ[] below (graph-local)
+    uint32_t pred_off[TOPO_N + 1];
+    uint32_t succ[TOPO_E];
+    uint32_t pred[TOPO_E];
+    uint32_t rec[2][2][REC_N];            // [buffer][left / right][i]: nodes the walks added (closest first)
+};
+
+template <bool SMALL> struct Walker
 {
     const PathArgs& a;
     const PathGraphDev g;
-    const char* qp;  // the read as this strand sees it (the reverse strand: pg_revcomp_kernel's copy)
+    const Row w;
+    RowLds& t;
+    const char* qp;  // the read as this strand sees it (the reverse strand: the copy the row wrote)
     int L;
 
-    __device__ uint32_t q(int j) const { return (uint8_t)qp[j]; }
-    __device__ uint32_t nlen(uint32_t node) const { return a.node_off[g.node_base + node + 1] - a.node_off[g.node_base + node]; }
-    __device__ const char* nptr(uint32_t node) const { return a.raw + a.node_off[g.node_base + node]; }
+    __device__ __forceinline__ uint32_t q(int j) const { return (uint8_t)qp[j]; }
+    __device__ __forceinline__ uint32_t noff(uint32_t node) const { return SMALL ? t.node_off[node] : a.node_off[g.node_base + node]; }
+    __device__ __forceinline__ uint32_t nlen(uint32_t node) const { return noff(node + 1) - noff(node); }
+    __device__ __forceinline__ const char* nptr(uint32_t node) const { return a.raw + noff(node); }
+    __device__ __forceinline__ uint32_t succ_begin(uint32_t node) const { return SMALL ? t.succ_off[node] : a.succ_off[g.node_base + node]; }
+    __device__ __forceinline__ uint32_t succ_at(uint32_t s) const { return SMALL ? t.succ[s] : a.succ[s]; }
+    __device__ __forceinline__ uint32_t pred_begin(uint32_t node) const { return SMALL ? t.pred_off[node] : a.pred_off[g.node_base + node]; }
+    __device__ __forceinline__ uint32_t pred_at(uint32_t s) const { return SMALL ? t.pred[s] : a.pred[s]; }
 
     // Extends the seed path `e` anchored at read position qpos (extendPathMatching).  Outputs the final path as
     // (first node, start_pos, last node, end_pos, length, #nodes prepended, #nodes appended) and the new qpos.
-    // With REC, prepended / appended node ids are written to rec_l[0..] (closest first) / rec_r[0..].
-    template <bool REC>
-    __device__ void extend(const KmerEntry& e, int& qpos, uint32_t& first_node, uint32_t& start_pos, uint32_t& end_pos,
-                           int& length, uint32_t& n_left, uint32_t& n_right, uint32_t* rec_l, uint32_t* rec_r) const
+    // The prepended / appended node ids go (from the row's first lane) to rec_l[0..] (closest first) / rec_r[0..], at most
+    // rec_cap of each (the counts go on).
+    __device__ __forceinline__ void extend(const KmerEntry& e, int& qpos, uint32_t& first_node, uint32_t& start_pos, uint32_t& end_pos,
+                                           int& length, uint32_t& n_left, uint32_t& n_right, uint32_t* rec_l, uint32_t* rec_r, uint32_t rec_cap) const
     {
         // ---- extendPathEndMatching (PathOperations.cpp:117-189)
         uint32_t node = a.pool[e.pool_off + e.n_nodes - 1];
@@ -162,22 +197,22 @@ struct Walker
             const uint32_t len = nlen(node);
             if (pos_in_query < L && pos_in_node < len)
             {
-                const uint32_t m = common_prefix(qp + pos_in_query, nptr(node) + pos_in_node, min((uint32_t)(L - pos_in_query), len - pos_in_node));
+                const uint32_t m = common_prefix(w, qp + pos_in_query, nptr(node) + pos_in_node, min((uint32_t)(L - pos_in_query), len - pos_in_node));
                 moved = m != 0;
                 pos_in_node += m;
                 pos_in_query += (int)m;
             }
             if (pos_in_node >= len)
             {
-                const uint32_t sb = a.succ_off[g.node_base + node], se = a.succ_off[g.node_base + node + 1];
+                const uint32_t sb = succ_begin(node), se = succ_begin(node + 1);
                 uint32_t min_size = 0xFFFFFFFFu;
                 for (uint32_t s = sb; s < se; ++s)
-                    min_size = min(min_size, nlen(a.succ[s]));
+                    min_size = min(min_size, nlen(succ_at(s)));
                 uint32_t n_longest = 0, longest = 0, cur = 0;
                 for (uint32_t s = sb; s < se; ++s)
                 {
-                    const uint32_t sn = a.succ[s];
-                    const uint32_t p = common_prefix(nptr(sn), qp + pos_in_query, min(min_size, (uint32_t)(L - pos_in_query)));
+                    const uint32_t sn = succ_at(s);
+                    const uint32_t p = common_prefix(w, nptr(sn), qp + pos_in_query, min(min_size, (uint32_t)(L - pos_in_query)));
                     if (p > longest)
                     {
                         longest = p;
@@ -189,7 +224,7 @@ struct Walker
                 }
                 if (longest == 0 || n_longest != 1)
                     break;
-                if (REC)
+                if (w.kl == 0 && n_right < rec_cap)
                     rec_r[n_right] = cur;
                 ++n_right;
                 pos_in_query += (int)longest;
@@ -211,22 +246,22 @@ struct Walker
             moved = false;
             if (pos_in_query > 0 && pos_in_node > 0)
             {
-                const uint32_t m = common_suffix(qp + pos_in_query, nptr(node) + pos_in_node, min((uint32_t)pos_in_query, pos_in_node));
+                const uint32_t m = common_suffix(w, qp + pos_in_query, nptr(node) + pos_in_node, min((uint32_t)pos_in_query, pos_in_node));
                 moved = m != 0;
                 pos_in_node -= m;
                 pos_in_query -= (int)m;
             }
             if (pos_in_node == 0)
             {
-                const uint32_t pb = a.pred_off[g.node_base + node], pe = a.pred_off[g.node_base + node + 1];
+                const uint32_t pb = pred_begin(node), pe = pred_begin(node + 1);
                 uint32_t min_size = 0xFFFFFFFFu;
                 for (uint32_t s = pb; s < pe; ++s)
-                    min_size = min(min_size, nlen(a.pred[s]));
+                    min_size = min(min_size, nlen(pred_at(s)));
                 uint32_t n_longest = 0, longest = 0, cur = 0;
                 for (uint32_t s = pb; s < pe; ++s)
                 {
-                    const uint32_t pn = a.pred[s];
-                    const uint32_t ml = common_suffix(nptr(pn) + nlen(pn), qp + pos_in_query, min(min_size, (uint32_t)pos_in_query));
+                    const uint32_t pn = pred_at(s);
+                    const uint32_t ml = common_suffix(w, nptr(pn) + nlen(pn), qp + pos_in_query, min(min_size, (uint32_t)pos_in_query));
                     if (ml > longest)
                     {
                         longest = ml;
@@ -238,7 +273,7 @@ struct Walker
                 }
                 if (longest == 0 || n_longest != 1)
                     break;
-                if (REC)
+                if (w.kl == 0 && n_left < rec_cap)
                     rec_l[n_left] = cur;
                 ++n_left;
                 pos_in_query -= (int)longest;
@@ -254,7 +289,7 @@ struct Walker
     }
 
     // hash of q[p .. p + k)
-    __device__ uint64_t hash_at(int p) const
+    __device__ __forceinline__ uint64_t hash_at(int p) const
     {
         uint64_t h = 0;
         uint32_t c = 0;
@@ -270,16 +305,17 @@ struct Walker
         return h;
     }
 
-    // the hash stored in the slot the k-mer with hash h goes to first: 0 = empty, the k-mer is in no path of the graph
-    __device__ uint64_t first_slot_hash(uint64_t h) const
+    // the word of the graph's presence filter that holds the bit of the k-mer with hash h (a clear bit: the k-mer is in no path)
+    __device__ __forceinline__ uint32_t filter_word(uint64_t h) const
     {
         if (h == 0)
             h = 1;
-        return a.table[g.tab_off + ((uint32_t)(h >> 20) & g.tab_mask)].hash;
+        return a.filter[g.filt_off + (((uint32_t)(h >> 32) & g.filt_mask) >> 5)];
     }
+    __device__ __forceinline__ static uint32_t filter_bit(uint64_t h) { return (uint32_t)((h ? h : 1ull) >> 32) & 31u; }
 
     // pg_kmer_lookup_unique (pg_kmerindex.h) with the k characters compared node by node in runs
-    __device__ bool lookup(uint64_t h, int pos, KmerEntry& out) const
+    __device__ __forceinline__ bool lookup(uint64_t h, int pos, KmerEntry& out) const
     {
         if (g.tab_mask == 0xFFFFFFFFu)
             return false;
@@ -288,13 +324,11 @@ struct Walker
         uint32_t slot = (uint32_t)(h >> 20) & g.tab_mask;
         for (;;)
         {
-            const KmerEntry* ep = a.table + g.tab_off + slot;
-            const uint64_t eh = ep->hash;
-            if (eh == 0)
+            const KmerEntry e = a.table[g.tab_off + slot];  // (the whole entry in one trip: nearly every probe of a candidate is a hit)
+            if (e.hash == 0)
                 return false;
-            if (eh == h)
+            if (e.hash == h)
             {
-                const KmerEntry e = *ep;
                 if (e.count != 1)
                     return false;
                 uint32_t ni = 0, p = e.start_pos, c = 0;
@@ -302,7 +336,7 @@ struct Walker
                 {
                     const uint32_t node = a.pool[e.pool_off + ni];
                     const uint32_t seg = min(g.k - c, nlen(node) - p);
-                    if (common_prefix(nptr(node) + p, qp + pos + (int)c, seg) != seg)
+                    if (common_prefix(w, nptr(node) + p, qp + pos + (int)c, seg) != seg)
                         return false;
                     c += seg;
                     if (c >= g.k)
@@ -317,118 +351,124 @@ struct Walker
             slot = (slot + 1) & g.tab_mask;
         }
     }
+
+    // One scan window: the k-mers starting at win .. win + 127 (those that exist: <= last).  Lane i hashes and probes positions
+    // win + 8 i .. win + 8 i + 7; hashes go to t.hash[0..127], the "may be a k-mer of the graph" bits (the presence filter's) to t.mask[0..15] (one byte per
+    // lane = eight positions).
+    __device__ __forceinline__ void scan_window(int win, int last) const
+    {
+        const int p0 = win + 8 * w.kl;
+        const int nb = min(8, last - p0 + 1);  // (<= 0: none of this lane's positions exist)
+        uint32_t bits = 0;
+        if (nb > 0)
+        {
+            uint64_t hs[8];
+            hs[0] = hash_at(p0);
+            uint64_t qo = 0, qi = 0;  // characters leaving / entering the window at p0, p0 + 1, ...
+            if (p0 + 8 <= last)
+            {
+                qo = load8(qp + p0);
+                qi = load8(qp + p0 + (int)a.k);
+            }
+            else
+                for (int i = 0; i + 1 < nb; ++i)
+                {
+                    qo |= (uint64_t)q(p0 + i) << (8 * i);
+                    qi |= (uint64_t)q(p0 + (int)a.k + i) << (8 * i);
+                }
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+                hs[i + 1] = (hs[i] - (((qo >> (8 * i)) & 0xFFu) + 1) * a.pow_k1) * HASH_B + ((qi >> (8 * i)) & 0xFFu) + 1;
+            uint32_t fw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                fw[i] = filter_word(hs[i < nb ? i : 0]);  // (every load unconditional: eight in flight, not eight round trips)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+            {
+                if (i < nb && ((fw[i] >> filter_bit(hs[i])) & 1u))
+                    bits |= 1u << i;
+                t.hash[8 * w.kl + i] = hs[i];
+            }
+        }
+        t.mask[w.kl] = (uint8_t)bits;
+    }
 };
 
-// The read as the reverse strand sees it, written at the read's own offset of the second buffer by the thread that goes on to read
-// it (a kernel of its own for this waited for a free slot beside the fills like any kernel does: 0.6 ms, profiles/r05_e2e_modes.json).
-__device__ __forceinline__ void reverse_complement(const char* __restrict__ src, char* __restrict__ dst, int L)
+// The read as the reverse strand sees it, written at the read's own offset of the second buffer by the row that goes on to read
+// it (a kernel of its own for this waited for a free slot beside the fills like any kernel does: 0.6 ms, profiles/r05_e2e_modes.json):
+// lane i writes characters 8 i .. 8 i + 7 of every 128.
+__device__ __forceinline__ void reverse_complement(const Row& w, const char* __restrict__ src, char* __restrict__ dst, int L)
 {
-    int j = 0;
-    for (; j + 8 <= L; j += 8)
+    for (int base = 0; base < L; base += PWIN)
     {
-        const uint64_t v = load8(src + L - 8 - j);
-        uint64_t o = 0;
+        const int j = base + 8 * w.kl;
+        if (j + 8 <= L)
+        {
+            const uint64_t v = load8(src + L - 8 - j);
+            uint64_t o = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            o |= (uint64_t)comp_raw((uint32_t)(v >> (8 * (7 - i))) & 0xFFu) << (8 * i);
-        __builtin_memcpy(dst + j, &o, 8);
+            for (int i = 0; i < 8; ++i)
+                o |= (uint64_t)comp_raw((uint32_t)(v >> (8 * (7 - i))) & 0xFFu) << (8 * i);
+            __builtin_memcpy(dst + j, &o, 8);
+        }
+        else
+            for (int i = j; i < L; ++i)
+                dst[i] = (char)comp_raw((uint8_t)src[L - 1 - i]);
     }
-    for (; j < L; ++j)
-        dst[j] = (char)comp_raw((uint8_t)src[L - 1 - j]);
 }
 
-__global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
+// The walk of one read (PathAligner.cpp:75-164) by its row.
+template <bool SMALL>
+__device__ __forceinline__ void path_row(const PathArgs& a, const Row& w, RowLds& t, uint32_t r, uint32_t off, int L, const PathGraphDev& g)
 {
-    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
-    if (r >= a.n_reads)
-        return;
-    if (a.active && !a.active[r])
-    {
-        a.flags[r] = 0;  // (every read's flag is written: no memset in front of the kernel)
-        return;
-    }
-    const uint32_t off = a.base_off[r];
-    const int L = (int)(a.base_off[r + 1] - off);
     uint8_t flags = 0;
-    if (L < (int)a.k || L == 0)
-    {
-        a.flags[r] = 0;
-        return;
-    }
-    const PathGraphDev g = a.graphs[a.graph_of_read[r]];
     int n_full = 0, n_matches = 0;
-    int first_strand = 0, first_pos = 0;
     const int last = L - (int)a.k;  // the last position a k-mer starts at
-    if (g.tab_mask != 0xFFFFFFFFu)
-        reverse_complement(a.bases + off, a.bases_rc + off, L);
-    for (int strand = 0; strand < 2 && g.tab_mask != 0xFFFFFFFFu; ++strand)
+    // the first full-length match, as the walk that found it left it: seed entry, ends, nodes added (in t.rec[best])
+    KmerEntry best_e{};
+    uint32_t best_sp = 0, best_ep = 0, best_nl = 0, best_nr = 0;
+    int first_strand = 0, first_pos = 0;
+    uint32_t cur = 0;  // the record buffer the next walk writes
+    for (int strand = 0; strand < 2; ++strand)
     {
-        Walker w{ a, g, (strand == 0 ? a.bases : a.bases_rc) + off, L };
-        uint64_t h = w.hash_at(0);
-        int pos = 0;
-        // PathAligner.cpp:92-106 walks the read one position at a time and nearly every position is a miss (the slot its hash goes
-        // to is empty).  Each step was a chain of dependent loads -- two characters for the rolling hash, then the slot -- and the
-        // 64 threads of the wavefront walk in lockstep.  Eight positions per trip: their characters in two loads, their eight slots
-        // probed together; the first one that is not empty gets the full lookup, the ones before it are misses, the ones behind it
-        // are probed again from wherever the walk goes next.  The scan is a loop of its own, so that the threads meet at the lookup
-        // each with a candidate: a wavefront pays for an extension (20 - 60 dependent loads) once per candidate of its busiest
-        // thread, not once per scan step in which any of its threads had one.
-        for (;;)
+        Walker<SMALL> wk{ a, g, w, t, (strand == 0 ? a.bases : a.bases_rc) + off, L };
+        // PathAligner.cpp:92-106 walks the read one position at a time; nearly every position is a miss (its k-mer is in no path).
+        // The window's mask says where the walk has to look at all.
+        int pos = 0, win = -PWIN;
+        while (pos <= last)
         {
-            int at = -1;
-            uint64_t h_first = 0, h_after = 0;
-            while (pos <= last)
+            if (pos >= win + PWIN)
             {
-                const int nb = min(8, last - pos + 1);
-                uint64_t qo = 0, qi = 0;  // characters leaving / entering the window at pos, pos + 1, ...
-                if (pos + 8 <= last)
-                {
-                    qo = load8(w.qp + pos);
-                    qi = load8(w.qp + pos + (int)a.k);
-                }
-                else
-                    for (int i = 0; i + 1 < nb; ++i)
-                    {
-                        qo |= (uint64_t)w.q(pos + i) << (8 * i);
-                        qi |= (uint64_t)w.q(pos + (int)a.k + i) << (8 * i);
-                    }
-                uint64_t hs[9];
-                hs[0] = h;
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    hs[i + 1] = (hs[i] - (((qo >> (8 * i)) & 0xFFu) + 1) * a.pow_k1) * HASH_B + ((qi >> (8 * i)) & 0xFFu) + 1;
-                uint64_t eh[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    eh[i] = w.first_slot_hash(hs[i < nb ? i : 0]);  // (every load unconditional: eight in flight, not eight round trips)
-                int first = nb;
-                h_after = hs[8];  // (all eight miss: nb == 8 and the next window's hash comes from all eight characters of the loads)
-#pragma unroll
-                for (int i = 7; i >= 0; --i)
-                    if (i < nb && eh[i] != 0)
-                    {
-                        first = i;
-                        h_first = hs[i];
-                        h_after = hs[i + 1];
-                    }
-                if (first < nb)
-                {
-                    at = pos + first;
-                    break;
-                }
-                pos += nb;
-                h = h_after;
+                win = pos;
+                wk.scan_window(win, last);
+                __threadfence_block();  // (the row reads what its other lanes wrote)
+            }
+            // first candidate at or behind pos
+            int at = -1;
+            {
+                const int rel = pos - win;
+                const uint64_t m0 = *(const uint64_t*)&t.mask[0], m1 = *(const uint64_t*)&t.mask[8];
+                const uint64_t lo = rel < 64 ? (m0 >> rel) << rel : 0ull;
+                const uint64_t hi = rel < 64 ? m1 : (m1 >> (rel - 64)) << (rel - 64);
+                if (lo)
+                    at = win + __builtin_ctzll(lo);
+                else if (hi)
+                    at = win + 64 + __builtin_ctzll(hi);
             }
             if (at < 0)
-                break;
+            {
+                pos = win + PWIN;
+                continue;
+            }
             KmerEntry e;
             int next = at + 1;
-            if (w.lookup(h_first, at, e))
+            if (wk.lookup(t.hash[at - win], at, e))
             {
                 int qpos = at;
                 uint32_t fn, sp, ep, nl, nr;
                 int len;
-                w.extend<false>(e, qpos, fn, sp, ep, len, nl, nr, nullptr, nullptr);
+                wk.extend(e, qpos, fn, sp, ep, len, nl, nr, t.rec[cur][0], t.rec[cur][1], REC_N);
                 ++n_matches;
                 if (len == L)
                 {
@@ -436,14 +476,17 @@ __global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
                     {
                         first_strand = strand;
                         first_pos = at;
+                        best_e = e;
+                        best_sp = sp;
+                        best_ep = ep;
+                        best_nl = nl;
+                        best_nr = nr;
+                        cur ^= 1u;  // (the later walks write the other buffer)
                     }
                     ++n_full;
                 }
                 next = qpos + len + 1;  // PathAligner.cpp:104 + the loop increment
             }
-            if (next > last)
-                break;
-            h = next == at + 1 ? h_after : w.hash_at(next);
             pos = next;
         }
     }
@@ -451,52 +494,72 @@ __global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
         flags |= 2;
     if (n_full == 0)
     {
-        a.flags[r] = flags;
+        if (w.kl == 0)
+            a.flags[r] = flags;
         return;
     }
-    // ---- second pass over the first full-length match: count nodes, allocate ops, record, emit ----------
-    Walker w{ a, g, (first_strand == 0 ? a.bases : a.bases_rc) + off, L };
-    KmerEntry e;
-    w.lookup(w.hash_at(first_pos), first_pos, e);
-    int qpos = first_pos;
-    uint32_t fn, sp, ep, nl, nr;
-    int len;
-    w.extend<false>(e, qpos, fn, sp, ep, len, nl, nr, nullptr, nullptr);
+    // ---- the first full-length match goes out: one element per node ------------------------------------------------------------
+    Walker<SMALL> wk{ a, g, w, t, (first_strand == 0 ? a.bases : a.bases_rc) + off, L };
+    const KmerEntry e = best_e;
+    const uint32_t nl = best_nl, nr = best_nr, sp = best_sp, ep = best_ep;
     const uint32_t n_nodes = nl + e.n_nodes + nr;
-    // one element per node -- except that a match run longer than an element holds (PG_OP_MAX_LEN: only reads beyond 4 095 bases
-    // have one) goes out in pieces: at most L / PG_OP_MAX_LEN more elements, reserved up front
+    // (a match run longer than an element holds -- PG_OP_MAX_LEN: only reads beyond 4 095 bases have one -- goes out in pieces: at
+    // most L / PG_OP_MAX_LEN more elements, reserved up front)
     const uint32_t extra = (uint32_t)L > PG_OP_MAX_LEN ? (uint32_t)L / PG_OP_MAX_LEN : 0u;
-    const unsigned long long base = atomicAdd(a.ops_counter, (unsigned long long)(n_nodes + extra));
-    pg_op* ops = a.ops + base;
-    uint32_t n_ops = 0;
-    // prepended nodes are produced closest-first: write them at nl-1-j; seed nodes at nl+i; appended at nl+n_seed+j
+    uint32_t base_lo = 0, base_hi = 0;
+    if (w.kl == 0)
     {
-        // record into the ops area itself (node ids first -- behind the reserved extra elements, so that the op words written
-        // from the front never overtake the ids still to be read -- converted to op words below)
-        uint32_t* ids = (uint32_t*)ops + extra;
-        qpos = first_pos;
-        w.extend<true>(e, qpos, fn, sp, ep, len, nl, nr, ids, ids + nl + e.n_nodes);
+        const unsigned long long b0 = atomicAdd(a.ops_counter, (unsigned long long)(n_nodes + extra));
+        base_lo = (uint32_t)b0;
+        base_hi = (uint32_t)(b0 >> 32);
+    }
+    const unsigned long long base = ((unsigned long long)w.bcast(base_hi, 0) << 32) | w.bcast(base_lo, 0);
+    pg_op* ops = a.ops + base;
+    // node ids first (into the ops area itself, behind the reserved extra elements, so that the op words written from the front
+    // never overtake the ids still to be read), converted to op words below by the row's first lane, which wrote them
+    uint32_t* ids = (uint32_t*)ops + extra;
+    if (nl > REC_N || nr > REC_N)
+    {
+        // (a walk over more nodes than the record holds: walked again, recording into the ops area)
+        int qpos = first_pos;
+        uint32_t fn, sp2, ep2, nl2, nr2;
+        int len;
+        wk.extend(e, qpos, fn, sp2, ep2, len, nl2, nr2, ids, ids + nl + e.n_nodes, 0xFFFFFFFFu);
+        if (w.kl != 0)
+            return;
         for (uint32_t i = 0, j = nl ? nl - 1 : 0; i < j; ++i, --j)
         {
-            const uint32_t t = ids[i];
+            const uint32_t x = ids[i];
             ids[i] = ids[j];
-            ids[j] = t;
+            ids[j] = x;
         }
-        for (uint32_t i = 0; i < e.n_nodes; ++i)
-            ids[nl + i] = a.pool[e.pool_off + i];
-        for (uint32_t i = 0; i < n_nodes; ++i)
+    }
+    else
+    {
+        if (w.kl != 0)
+            return;
+        const uint32_t* rl = t.rec[cur ^ 1u][0];
+        const uint32_t* rr = t.rec[cur ^ 1u][1];
+        for (uint32_t i = 0; i < nl; ++i)  // prepended nodes were produced closest-first
+            ids[i] = rl[nl - 1 - i];
+        for (uint32_t i = 0; i < nr; ++i)
+            ids[nl + e.n_nodes + i] = rr[i];
+    }
+    uint32_t n_ops = 0;
+    for (uint32_t i = 0; i < e.n_nodes; ++i)
+        ids[nl + i] = a.pool[e.pool_off + i];
+    for (uint32_t i = 0; i < n_nodes; ++i)
+    {
+        const uint32_t node = ids[i];
+        const uint32_t lo = i == 0 ? sp : 0u;
+        const uint32_t hi = i == n_nodes - 1 ? ep : wk.nlen(node) - 1;
+        uint32_t left = hi - lo + 1;
+        do
         {
-            const uint32_t node = ids[i];
-            const uint32_t lo = i == 0 ? sp : 0u;
-            const uint32_t hi = i == n_nodes - 1 ? ep : w.nlen(node) - 1;
-            uint32_t left = hi - lo + 1;
-            do
-            {
-                const uint32_t piece = left > PG_OP_MAX_LEN ? PG_OP_MAX_LEN : left;
-                ops[n_ops++] = PG_OP_MAKE(node, PG_OPC_M, piece);
-                left -= piece;
-            } while (left);
-        }
+            const uint32_t piece = left > PG_OP_MAX_LEN ? PG_OP_MAX_LEN : left;
+            ops[n_ops++] = PG_OP_MAKE(node, PG_OPC_M, piece);
+            left -= piece;
+        } while (left);
     }
     pg_result res;
     res.graph_pos = (int32_t)sp;
@@ -513,6 +576,54 @@ __global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
     res.status = PG_STATUS_PATH_ALIGNER;
     a.results[r] = res;
     a.flags[r] = flags | 1;
+}
+
+__global__ __launch_bounds__(64) void pg_path_kernel(PathArgs a)
+{
+    __shared__ RowLds lds[64 / PGL];
+    const Row w{ (int)threadIdx.x / PGL, (int)threadIdx.x % PGL };
+    RowLds& t = lds[w.grp];
+    const uint32_t r = blockIdx.x * (64u / PGL) + (uint32_t)w.grp;
+    if (r >= a.n_reads)
+        return;
+    if (a.active && !a.active[r])
+    {
+        if (w.kl == 0)
+            a.flags[r] = 0;  // (every read's flag is written: no memset in front of the kernel)
+        return;
+    }
+    const uint32_t off = a.base_off[r];
+    const int L = (int)(a.base_off[r + 1] - off);
+    const PathGraphDev g = a.graphs[a.graph_of_read[r]];
+    if (L < (int)a.k || L == 0 || g.tab_mask == 0xFFFFFFFFu)
+    {
+        if (w.kl == 0)
+            a.flags[r] = 0;
+        return;
+    }
+    // the graph's tables into the row's LDS block (their loads are in flight beside the read's)
+    const uint32_t sb0 = a.succ_off[g.node_base], pb0 = a.pred_off[g.node_base];
+    const uint32_t n_succ = a.succ_off[g.node_base + g.n_nodes] - sb0, n_pred = a.pred_off[g.node_base + g.n_nodes] - pb0;
+    const bool small = g.n_nodes <= TOPO_N && n_succ <= TOPO_E && n_pred <= TOPO_E;
+    if (small)
+    {
+        for (uint32_t i = (uint32_t)w.kl; i <= g.n_nodes; i += PGL)
+        {
+            t.node_off[i] = a.node_off[g.node_base + i];
+            t.succ_off[i] = a.succ_off[g.node_base + i] - sb0;
+            t.pred_off[i] = a.pred_off[g.node_base + i] - pb0;
+        }
+        for (uint32_t i = (uint32_t)w.kl; i < n_succ; i += PGL)
+            t.succ[i] = a.succ[sb0 + i];
+        for (uint32_t i = (uint32_t)w.kl; i < n_pred; i += PGL)
+            t.pred[i] = a.pred[pb0 + i];
+    }
+    reverse_complement(w, a.bases + off, a.bases_rc + off, L);
+    __threadfence_block();  // (the row reads what its other lanes wrote: the copy and the tables)
+    if (small)
+        path_row<true>(a, w, t, r, off, L, g);
+    else
+        path_row<false>(a, w, t, r, off, L, g);
 }
 
 uint64_t hash_str(const char* s, uint32_t k)
@@ -536,6 +647,7 @@ void pg_path_index_free(pg_path_index* ix)
     (void)pg_dev_free(ix->d_succ_off);
     (void)pg_dev_free(ix->d_succ);
     (void)pg_dev_free(ix->d_node_uniq);
+    (void)pg_dev_free(ix->d_filter);
     delete ix;
 }
 
@@ -720,6 +832,8 @@ const char* pg_build_kmer_index_host(const pg_graphs* G, const std::vector<int32
     std::vector<uint32_t>& pool = t.pool;
     std::vector<uint8_t>& node_uniq = t.node_uniq;
     std::vector<uint32_t>& h_k = t.h_k;
+    std::vector<uint32_t>& filter = t.filter;
+    filter.clear();
     const uint32_t n_total = (uint32_t)G->h_node_len.size();
     // successor CSR (set-wide node numbering, graph-local ids as values, ascending): counting sort over the predecessor CSR --
     // a node's successors come out ascending because the nodes are visited in ascending order
@@ -830,6 +944,19 @@ const char* pg_build_kmer_index_host(const pg_graphs* G, const std::vector<int32
             gd[g].pow_k1 *= HASH_B;
         gd[g].tab_off = tab_off;
         gd[g].tab_mask = cap ? cap - 1 : 0xFFFFFFFFu;
+        // presence filter over the table's keys (the table of the length that was kept)
+        uint32_t bits = 1024;
+        while (bits < 64u * (cap / 2) && bits < (1u << 28))
+            bits *= 2;
+        gd[g].filt_off = (uint32_t)filter.size();
+        gd[g].filt_mask = bits - 1;
+        filter.resize(filter.size() + bits / 32, 0u);
+        for (uint32_t sidx = 0; sidx < cap; ++sidx)
+            if (const uint64_t h = table[tab_off + sidx].hash)
+            {
+                const uint32_t bit = (uint32_t)(h >> 32) & (bits - 1);
+                filter[gd[g].filt_off + (bit >> 5)] |= 1u << (bit & 31u);
+            }
     }
     return nullptr;
 }
@@ -875,6 +1002,7 @@ pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32
     if (e == hipSuccess) e = up(succ_off, &ix->d_succ_off, ctx->stream_copy);
     if (e == hipSuccess) e = up(succ, &ix->d_succ, ctx->stream_copy);
     if (e == hipSuccess) e = up(node_uniq, &ix->d_node_uniq, ctx->stream_copy);
+    if (e == hipSuccess) e = up(t.filter, &ix->d_filter, ctx->stream_copy);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream_copy);
     if (e != hipSuccess)
     {
@@ -974,6 +1102,7 @@ extern "C" pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* b)
     a.graph_of_read = b->d_graph_of_read;
     a.graphs = ix->d_graphs;
     a.table = ix->d_table;
+    a.filter = ix->d_filter;
     a.pool = ix->d_pool;
     a.node_off = ix->d_node_off;
     a.raw = ix->d_raw;
@@ -988,7 +1117,7 @@ extern "C" pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* b)
     a.active = b->has_active ? b->d_active : nullptr;
     if (b->n_reads)
     {
-        hipLaunchKernelGGL(pg_path_kernel, dim3((b->n_reads + 63) / 64), dim3(64), 0, ps, a);
+        hipLaunchKernelGGL(pg_path_kernel, dim3((b->n_reads + 3) / 4), dim3(64), 0, ps, a);  // four reads per wavefront, 16 lanes each
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, pg_stage_end_on(ctx, b, ps));

@@ -21,7 +21,11 @@
 #include <new>
 #include <chrono>
 #include <map>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
+#include <sys/prctl.h>
+#include <time.h>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -232,7 +236,11 @@ hipError_t PgStagedUpload::commit(hipStream_t stream, void** device_block)
         }
         e = hipMemcpyAsync(dev, host, total, hipMemcpyHostToDevice, stream);
         if (e == hipSuccess)
-            e = hipStreamSynchronize(stream);
+        {
+            int device = 0;
+            (void)hipGetDevice(&device);
+            e = pg_stream_wait(device, stream);
+        }
     }
     pg_pinned_put(host, cap);
     if (e != hipSuccess)
@@ -582,6 +590,131 @@ void pg_api_time_add(const char* what, uint64_t t0_ns)
     e.second += 1;
 }
 
+// ---- one thread waits for the device on behalf of all callers -----------------------------------------------------------------
+// A host thread blocked in hipEventSynchronize sleeps in the kernel driver until an interrupt arrives -- ANY completion interrupt
+// of the process: every one of them wakes every sleeper, which looks at its own signal and goes back to sleep.  With 24 lanes of a
+// workflow each waiting for its batch that was 35 000 wait ioctls per pass of 52 batches (profiles/r05_e2e_ioctls.txt), a fifth of
+// the job's CPU together with the runtime's side of them.  Here the callers sleep on a condition variable of their own and ONE
+// thread looks at the pending events (hipEventQuery reads the completion signal in host memory: no system call) every 50 us.
+// PG_WAITER=0: every caller waits in the runtime as before (A/B runs).
+namespace
+{
+struct WaitService
+{
+    struct Req
+    {
+        hipEvent_t ev;
+        int device;
+        bool done = false;
+        hipError_t err = hipSuccess;
+        std::condition_variable cv;
+    };
+    std::mutex m;
+    std::condition_variable cv_new;
+    std::vector<Req*> pending;
+    bool started = false;
+    void run()
+    {
+        int device = -1;
+        std::unique_lock<std::mutex> lock(m);
+        for (;;)
+        {
+            while (pending.empty())
+                cv_new.wait(lock);
+            for (size_t i = 0; i < pending.size();)
+            {
+                Req* r = pending[i];
+                if (r->device != device && hipSetDevice(r->device) == hipSuccess)
+                    device = r->device;
+                const hipError_t e = hipEventQuery(r->ev);
+                if (e == hipErrorNotReady)
+                {
+                    ++i;
+                    continue;
+                }
+                r->err = e;
+                r->done = true;
+                r->cv.notify_one();
+                pending[i] = pending.back();
+                pending.pop_back();
+            }
+            if (!pending.empty())
+            {
+                lock.unlock();
+                struct timespec ts = { 0, 50 * 1000 };
+                nanosleep(&ts, nullptr);
+                lock.lock();
+            }
+        }
+    }
+};
+WaitService& waitService()
+{
+    static WaitService* w = new WaitService();  // (never destroyed: its thread outlives main's statics)
+    return *w;
+}
+}  // namespace
+
+hipError_t pg_event_wait(int device, hipEvent_t ev)
+{
+    static const bool off = [] {
+        const char* e = getenv("PG_WAITER");
+        return (e && e[0] == '0') || getenv("PG_SPIN_WAITS") != nullptr;
+    }();
+    if (off)
+        return hipEventSynchronize(ev);
+    const hipError_t q = hipEventQuery(ev);
+    if (q != hipErrorNotReady)
+        return q;
+    WaitService& w = waitService();
+    WaitService::Req r;
+    r.ev = ev;
+    r.device = device;
+    std::unique_lock<std::mutex> lock(w.m);
+    if (!w.started)
+    {
+        w.started = true;
+        std::thread([&w] {
+            prctl(PR_SET_TIMERSLACK, 1UL, 0UL, 0UL, 0UL);  // (a 50 us sleep that lasts 50 us)
+            w.run();
+        }).detach();
+    }
+    w.pending.push_back(&r);
+    w.cv_new.notify_one();
+    r.cv.wait(lock, [&r] { return r.done; });
+    return r.err;
+}
+
+// hipStreamSynchronize through the wait service: an event from a small pool is recorded on the stream and waited for
+hipError_t pg_stream_wait(int device, hipStream_t s)
+{
+    static std::mutex m;
+    static std::vector<std::pair<int, hipEvent_t>> idle;
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(m);
+        for (size_t i = 0; i < idle.size(); ++i)
+            if (idle[i].first == device)
+            {
+                ev = idle[i].second;
+                idle[i] = idle.back();
+                idle.pop_back();
+                break;
+            }
+    }
+    hipError_t e = hipSuccess;
+    if (!ev)
+        e = hipEventCreateWithFlags(&ev, pg_wait_event_flags());
+    if (e != hipSuccess)
+        return hipStreamSynchronize(s);
+    e = hipEventRecord(ev, s);
+    if (e == hipSuccess)
+        e = pg_event_wait(device, ev);
+    std::lock_guard<std::mutex> lock(m);
+    idle.emplace_back(device, ev);
+    return e;
+}
+
 unsigned pg_wait_event_flags()
 {
     static const bool spin = getenv("PG_SPIN_WAITS") != nullptr;
@@ -593,7 +726,7 @@ hipError_t pg_wait_stream(pg_batch* b, hipStream_t s)
     if (!b || !b->ev_host)
         return hipStreamSynchronize(s);
     const hipError_t e = hipEventRecord(b->ev_host, s);
-    return e != hipSuccess ? e : hipEventSynchronize(b->ev_host);
+    return e != hipSuccess ? e : pg_event_wait(b->device, b->ev_host);
 }
 
 hipError_t pg_batch_wait(pg_ctx* ctx, pg_batch* b)
@@ -601,9 +734,9 @@ hipError_t pg_batch_wait(pg_ctx* ctx, pg_batch* b)
     (void)ctx;
     hipError_t e = hipSuccess;
     if (b->upload_recorded)
-        e = hipEventSynchronize(b->ev_upload);
+        e = pg_event_wait(b->device, b->ev_upload);
     if (e == hipSuccess && b->busy_recorded)
-        e = hipEventSynchronize(b->ev_busy);
+        e = pg_event_wait(b->device, b->ev_busy);
     return e;
 }
 
@@ -998,6 +1131,7 @@ extern "C" pg_status pg_batch_create(pg_ctx* ctx, pg_batch** out)
         *out = nullptr;
         return PG_ERR_HIP;
     }
+    (*out)->device = ctx->device;
     return PG_OK;
 }
 
@@ -2199,12 +2333,12 @@ extern "C" pg_status pg_batch_download(
     {
         if (cnt > ops_cap)
         {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
+            HIP_TRY(ctx, pg_stream_wait(ctx->device, ctx->stream_copy));
             return fail(ctx, PG_ERR_OVERFLOW, "ops buffer too small");
         }
         HIP_TRY(ctx, hipMemcpyAsync(ops, b->d_ops, cnt * sizeof(pg_op), hipMemcpyDeviceToHost, ctx->stream_copy));
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
+    HIP_TRY(ctx, pg_stream_wait(ctx->device, ctx->stream_copy));
     return PG_OK;
 }
 

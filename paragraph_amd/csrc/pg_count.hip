@@ -898,7 +898,7 @@ extern "C" pg_status pg_batch_download_label_ext(pg_ctx* ctx, pg_batch* b, uint6
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, pg_batch_wait(ctx, b));
     HIP_TRY(ctx, hipMemcpyAsync(label_ext, b->d_label_ext, need * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream_copy));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
+    HIP_TRY(ctx, pg_stream_wait(ctx->device, ctx->stream_copy));
     return PG_OK;
 }
 
@@ -912,7 +912,7 @@ extern "C" pg_status pg_batch_download_counts(
     HIP_TRY(ctx, pg_batch_wait(ctx, b));
     unsigned long long np = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&np, b->d_path_counter, sizeof np, hipMemcpyDeviceToHost, ctx->stream_copy));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
+    HIP_TRY(ctx, pg_stream_wait(ctx->device, ctx->stream_copy));
     if (n_path)
         *n_path = np;
     if (counts)
@@ -929,11 +929,11 @@ extern "C" pg_status pg_batch_download_counts(
     {
         if (np > path_cap)
         {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
+            HIP_TRY(ctx, pg_stream_wait(ctx->device, ctx->stream_copy));
             return pg_fail(ctx, PG_ERR_OVERFLOW, "path buffer too small");
         }
         HIP_TRY(ctx, hipMemcpyAsync(path, b->d_path, np * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream_copy));
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
+    HIP_TRY(ctx, pg_stream_wait(ctx->device, ctx->stream_copy));
     return PG_OK;
 }

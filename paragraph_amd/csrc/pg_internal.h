@@ -249,6 +249,7 @@ struct pg_batch
         if (p)
             parked_blocks.push_back(p);
     }
+    int device = 0;                  // the context's device (the wait service asks for events of several devices)
     hipEvent_t ev_host = nullptr;    // what the host waits on where it used to synchronise a stream (pg_wait_stream)
     hipEvent_t ev_cascade = nullptr; // the cascade's tables of this upload are on the device (pg_cascade_prepare_early: copy stream)
     bool cascade_recorded = false;
@@ -271,6 +272,9 @@ hipError_t pg_batch_wait(pg_ctx* ctx, pg_batch* b);
 // always is in a process that imported torch before it came here.  pg_wait_stream: hipStreamSynchronize by the same rule.
 unsigned pg_wait_event_flags();
 hipError_t pg_wait_stream(pg_batch* b, hipStream_t s);
+// the calling thread sleeps until the event is complete; ONE service thread polls the pending events of all callers (pg_api.hip)
+hipError_t pg_event_wait(int device, hipEvent_t ev);
+hipError_t pg_stream_wait(int device, hipStream_t s);  // hipStreamSynchronize by the same route
 // The tables the device-side hand-over needs (group of every read, list bases, plan segments) go up on the COPY stream while the
 // batch's first seed stage runs, not on the seed stream between its count pass and the hand-over kernels.
 pg_status pg_cascade_prepare_early(pg_ctx* ctx, pg_batch* b);

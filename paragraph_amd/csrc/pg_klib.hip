@@ -875,7 +875,7 @@ extern "C" pg_status pg_graphs_build_klib_index(
     if (e == hipSuccess) e = pg_dev_alloc((void**)&ix->d_work_count, 2 * sizeof(uint32_t));  // [0] work list, [1] CIGAR pool
     if (e == hipSuccess) e = pg_dev_alloc((void**)&ix->d_error, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(ix->d_error, 0, sizeof(uint32_t), ctx->stream_copy);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream_copy);
+    if (e == hipSuccess) e = pg_stream_wait(ctx->device, ctx->stream_copy);
     if (e != hipSuccess)
     {
         pg_klib_index_free(ix);
@@ -1118,7 +1118,7 @@ extern "C" pg_status pg_graphs_klib_error(pg_ctx* ctx, pg_graphs* G, uint32_t* e
         HIP_TRY(ctx, hipEventSynchronize(G->ev_use[0]));
     HIP_TRY(ctx, hipMemcpyAsync(error, G->klib_index->d_error, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream_copy));
     HIP_TRY(ctx, hipMemsetAsync(G->klib_index->d_error, 0, sizeof(uint32_t), ctx->stream_copy));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
+    HIP_TRY(ctx, pg_stream_wait(ctx->device, ctx->stream_copy));
     return PG_OK;
 }
 

@@ -624,7 +624,7 @@ extern "C" pg_status pg_graphs_build_kmer_index(
     if (e == hipSuccess) e = upk(starts, &ix->d_starts, ctx->stream_copy);
     if (e == hipSuccess) e = upk(kmers, &ix->d_kmers, ctx->stream_copy);
     if (e == hipSuccess) e = upk(kpos, &ix->d_kpos, ctx->stream_copy);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream_copy);
+    if (e == hipSuccess) e = pg_stream_wait(ctx->device, ctx->stream_copy);
     if (e != hipSuccess)
     {
         pg_kmer_index_free(ix);

@@ -1003,7 +1003,7 @@ pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32
     if (e == hipSuccess) e = up(succ, &ix->d_succ, ctx->stream_copy);
     if (e == hipSuccess) e = up(node_uniq, &ix->d_node_uniq, ctx->stream_copy);
     if (e == hipSuccess) e = up(t.filter, &ix->d_filter, ctx->stream_copy);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream_copy);
+    if (e == hipSuccess) e = pg_stream_wait(ctx->device, ctx->stream_copy);
     if (e != hipSuccess)
     {
         pg_path_index_free(ix);
@@ -1032,7 +1032,7 @@ extern "C" pg_status pg_graphs_build_path_index(pg_ctx* ctx, pg_graphs* G, uint3
     {
         HIP_TRY(ctx, up(G->h_pred_off, &G->d_cnt_pred_off, ctx->stream_copy));
         HIP_TRY(ctx, up(G->h_pred, &G->d_cnt_pred, ctx->stream_copy));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
+        HIP_TRY(ctx, pg_stream_wait(ctx->device, ctx->stream_copy));
     }
     return PG_OK;
 }
@@ -1132,6 +1132,6 @@ extern "C" pg_status pg_batch_download_path_flags(pg_ctx* ctx, pg_batch* b, uint
     HIP_TRY(ctx, pg_batch_wait(ctx, b));
     if (b->n_reads)
         HIP_TRY(ctx, hipMemcpyAsync(flags, b->d_path_flags, b->n_reads, hipMemcpyDeviceToHost, ctx->stream_copy));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
+    HIP_TRY(ctx, pg_stream_wait(ctx->device, ctx->stream_copy));
     return PG_OK;
 }

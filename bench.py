@@ -1114,6 +1114,16 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
                           "note": "one slot per edge of every site (fragment counts of the breakpoint edges), all-reduced over the ranks "
                                   "AFTER the timed passes: a site's genotype needs only its own counts, the sum only collects them"},
            "data_make_s": e2e["make_s"], "per_rank": per_rank, "with_path_matching": cascade, "with_all_four_stages": all_four}
+    # what the host allows: with C usable cores and c CPU-seconds per (site, sample) no more than C / c sites per second leave the
+    # node however many devices it has -- the first thing to read off an N-GPU curve of this leg
+    cores = float(out["cpu_quota_cores"] or ncpu)
+    cpu_per_site = out["cpu_us_per_site_sample"] * 1e-6
+    out["host_bound"] = {"usable_cores": cores, "ceiling_sites_per_s": cores / cpu_per_site if cpu_per_site > 0 else None,
+                         "cores_busy": out["sites_genotyped_per_s"] * cpu_per_site,
+                         "cores_per_rank_at_this_rate": out["sites_genotyped_per_s"] * cpu_per_site / max(1, world),
+                         "threads_per_rank": threads,
+                         "note": "ceiling = usable cores / CPU seconds per (site, sample); a measured rate near it is the host's, not the "
+                                 "devices'"}
     # A genotype that differs from the simulated truth is not by itself an error of the path (30x sampling can starve an allele);
     # a concordance below 99.5 % is.  What must hold exactly: no document with an error, the table checks, the sampled sites.
     out["genotype_concordance"] = int(table[total]) / max(1, n)

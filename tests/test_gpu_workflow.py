@@ -302,6 +302,42 @@ def test_two_device_slots_give_the_same_documents(tmp_path):
     assert r.returncode == 0 and json.loads(r.stdout.splitlines()[-1]) == outs[1], r.stderr[-2000:]
 
 
+def test_eight_device_slots_give_the_same_documents(tmp_path):
+    """The device list of an 8-GPU node on the 1-GPU box: eight slots that all name device 0 = eight contexts (own streams,
+    workspace, batch pool, stage mutex), sixteen lanes spread over them round-robin, 24 copies of the chrX graph in chunks of one
+    graph so that every slot gets batches.  The documents equal the one-slot run's, graph for graph, and every slot was used
+    (PG_BATCH_TIMING names the context a batch ran on)."""
+    import json
+    import sys
+    sites = os.path.join(ROOT, "tests", "golden", "sites", "chrX")
+    bam = os.path.join(sites, "chrX_graph_typing.bam")
+    manifest = tmp_path / "manifest.txt"
+    manifest.write_text("#id\tpath\tdepth\tread length\tdepth sd\tsex\nSAMPLE1\t%s\t44.2\t150\t20\tmale\nSAMPLE2\t%s\t44.2\t150\t20\tfemale\n"
+                        % (bam, bam))
+    graph = os.path.join(sites, "chrX_graph_typing.2sample.json")
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import json, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from paragraph_amd import workflow\n"
+        "opts = json.loads(sys.argv[1])\n"
+        "docs = workflow.genotype_graphs(%r, %r, [%r] * 24, genotyping_parameters=%r, threads=8, sites_per_batch=2, **opts)\n"
+        "print(json.dumps(docs))\n" % (ROOT, os.path.join(sites, "chrX_graph_typing.fa"), str(manifest), graph, os.path.join(sites, "param.json")))
+    env = dict(os.environ)
+    env.pop("PG_DEVICES", None)
+    outs = []
+    for opts in ({"lanes": 16, "devices": [0] * 8}, {"lanes": 1}):
+        r = subprocess.run([sys.executable, str(script), json.dumps(opts)], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.splitlines()[-1]))
+    assert len(outs[0]) == 24 and outs[0] == outs[1]
+    assert outs[0][0]["samples"]["SAMPLE1"]["gt"]["GT"] == "REF" and outs[0][0]["samples"]["SAMPLE2"]["gt"]["GT"] == "REF/REF"
+    # the same through the environment (what bin/grmpy --devices all resolves to on an 8-GPU node)
+    r = subprocess.run([sys.executable, str(script), json.dumps({"lanes": 16})], capture_output=True, text=True, timeout=900,
+                       env=dict(env, PG_DEVICES="0,0,0,0,0,0,0,0"))
+    assert r.returncode == 0 and json.loads(r.stdout.splitlines()[-1]) == outs[1], r.stderr[-2000:]
+
+
 def test_config1_round_trip_from_the_vcf(tmp_path):
     """BASELINE configs[0] with the VCF itself as input, as `multigrmpy.py -i candidates.vcf` takes it: paragraph_amd.vcf2paragraph
     (one allele graph per line, the reference's vcf2paragraph options) -> workflow.genotype_graphs -> the GT / DP / AD of

@@ -35,6 +35,7 @@
 #include "pg_general.h"
 #include "pg_internal.h"
 #include "pg_kernels.h"
+#include "pg_kmerindex.h"
 
 pg_status pg_fail(pg_ctx* ctx, pg_status st, const std::string& msg)
 {
@@ -209,6 +210,47 @@ void pg_pinned_put(void* p, size_t cap)
         idle.push_back(p);
     else
         (void)hipHostFree(p);
+}
+
+hipError_t PgStagedUpload::commit_async(hipStream_t stream, void** device_block, void** staging, size_t* staging_cap)
+{
+    *device_block = nullptr;
+    *staging = nullptr;
+    *staging_cap = 0;
+    size_t total = 0;
+    for (Item const& it : items)
+        total += (std::max<size_t>(it.bytes, 1) + 255) & ~(size_t)255;
+    void* host = nullptr;
+    size_t cap = 0;
+    hipError_t e = pg_pinned_get(total, &host, &cap);
+    if (e != hipSuccess)
+        return e;
+    void* dev = nullptr;
+    e = pg_dev_alloc(&dev, total);
+    if (e == hipSuccess)
+    {
+        size_t at = 0;
+        for (Item const& it : items)
+        {
+            if (it.bytes)
+                memcpy((char*)host + at, it.src, it.bytes);
+            *it.dst = (char*)dev + at;
+            at += (std::max<size_t>(it.bytes, 1) + 255) & ~(size_t)255;
+        }
+        e = hipMemcpyAsync(dev, host, total, hipMemcpyHostToDevice, stream);
+    }
+    if (e != hipSuccess)
+    {
+        pg_pinned_put(host, cap);
+        (void)pg_dev_free(dev);
+        for (Item const& it : items)
+            *it.dst = nullptr;
+        return e;
+    }
+    *device_block = dev;
+    *staging = host;
+    *staging_cap = cap;
+    return hipSuccess;
 }
 
 hipError_t PgStagedUpload::commit(hipStream_t stream, void** device_block)
@@ -2338,8 +2380,7 @@ extern "C" pg_status pg_batch_download(
         }
         HIP_TRY(ctx, hipMemcpyAsync(ops, b->d_ops, cnt * sizeof(pg_op), hipMemcpyDeviceToHost, ctx->stream_copy));
     }
-    HIP_TRY(ctx, pg_stream_wait(ctx->device, ctx->stream_copy));
-    return PG_OK;
+    return pg_path_index_check(ctx, b->graphs);  // (waits for the copy stream; a path index built on the device reports here)
 }
 
 extern "C" pg_status pg_align_batch(

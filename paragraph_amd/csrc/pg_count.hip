@@ -697,10 +697,12 @@ __global__ void pg_count_zero_kernel(uint32_t* counts, uint32_t n, unsigned long
         *path_counter = 0;
 }
 
-__global__ void pg_publish_counters_kernel(const unsigned long long* ops_counter, const unsigned long long* path_counter, unsigned long long* host_words)
+__global__ void pg_publish_counters_kernel(const unsigned long long* ops_counter, const unsigned long long* path_counter, const uint32_t* index_error,
+                                           unsigned long long* host_words)
 {
     host_words[0] = *ops_counter;
     host_words[1] = *path_counter;
+    host_words[2] = index_error ? *index_error : 0u;  // the error word of a path index built on the device (pg_path.hip)
     __threadfence_system();
 }
 }  // namespace
@@ -815,14 +817,15 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     if (!b->h_counters)
     {
         void* p = nullptr;
-        HIP_TRY(ctx, hipHostMalloc(&p, 2 * sizeof(unsigned long long), hipHostMallocPortable | hipHostMallocMapped));
+        HIP_TRY(ctx, hipHostMalloc(&p, 3 * sizeof(unsigned long long), hipHostMallocPortable | hipHostMallocMapped));
         b->h_counters = (unsigned long long*)p;
         void* dp = nullptr;
         HIP_TRY(ctx, hipHostGetDevicePointer(&dp, p, 0));
         b->d_h_counters = (unsigned long long*)dp;
     }
     // (one single-thread dispatch writes both words into the page-locked block: two 8-byte copies were two dispatches)
-    hipLaunchKernelGGL(pg_publish_counters_kernel, dim3(1), dim3(1), 0, cs, b->d_ops_counter, b->d_path_counter, b->d_h_counters);
+    hipLaunchKernelGGL(pg_publish_counters_kernel, dim3(1), dim3(1), 0, cs, b->d_ops_counter, b->d_path_counter,
+                       b->graphs->path_index ? b->graphs->path_index->d_error : nullptr, b->d_h_counters);
     HIP_TRY(ctx, hipGetLastError());
     b->h_counters_valid = true;
     HIP_TRY(ctx, pg_stage_end_on(ctx, b, cs));
@@ -835,6 +838,8 @@ extern "C" pg_status pg_batch_result_sizes(pg_ctx* ctx, pg_batch* b, uint64_t* n
         return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_result_sizes: the batch's last stage must be pg_batch_count");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, pg_batch_wait(ctx, b));
+    if (b->h_counters[2])
+        return pg_fail(ctx, b->h_counters[2] & 1u ? PG_ERR_UNSUPPORTED : PG_ERR_HIP, pg_path_index_error_text((uint32_t)b->h_counters[2]));
     if (n_ops)
         *n_ops = b->h_counters[0];
     if (n_path)
@@ -852,6 +857,8 @@ extern "C" pg_status pg_batch_download_all(
         return pg_fail(ctx, PG_ERR_INVALID, "pg_batch_download_all: null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, pg_batch_wait(ctx, b));
+    if (b->h_counters[2])
+        return pg_fail(ctx, b->h_counters[2] & 1u ? PG_ERR_UNSUPPORTED : PG_ERR_HIP, pg_path_index_error_text((uint32_t)b->h_counters[2]));
     const uint64_t n_ops = b->h_counters[0], n_path = b->h_counters[1];
     if ((n_ops && (!ops || n_ops > ops_cap)) || (n_path && (!path || n_path > path_cap)))
         return pg_fail(ctx, PG_ERR_OVERFLOW, "pg_batch_download_all: ops / path buffer too small (pg_batch_result_sizes gives the sizes)");

@@ -306,7 +306,11 @@ struct PgStagedUpload
     };
     std::vector<Item> items;
     template <typename T> void add(const std::vector<T>& v, T** dst) { items.push_back(Item{ v.data(), v.size() * sizeof(T), (void**)dst }); }
+    void add_raw(const void* src, size_t bytes, void** dst) { items.push_back(Item{ src, bytes, dst }); }
     hipError_t commit(hipStream_t stream, void** device_block);
+    // the same without the wait: the caller queues more work behind the copy, waits once, and then hands the page-locked staging
+    // block back (pg_pinned_put(*staging, *staging_cap))
+    hipError_t commit_async(hipStream_t stream, void** device_block, void** staging, size_t* staging_cap);
 };
 // page-locked host blocks by size class (hipHostMalloc takes milliseconds)
 hipError_t pg_pinned_get(size_t bytes, void** p, size_t* cap);

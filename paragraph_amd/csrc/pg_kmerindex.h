@@ -55,8 +55,18 @@ struct pg_path_index
     uint32_t* d_succ = nullptr;
     uint8_t* d_node_uniq = nullptr;  // per set-wide node: numUniqueKmersOverlappingNode(node) > 0
     uint32_t* d_filter = nullptr;    // the graphs' presence filters (PathGraphDev::filt_off)
+    void* d_block = nullptr;         // device-built index: d_graphs, d_node_off, d_raw, d_succ_off, d_succ live in this ONE block
+    uint32_t* d_error = nullptr;     // device-built index: bit0 = two k-mers of a graph share a hash (the set must be refused), bit1 = internal
+    void* staging = nullptr;         // its page-locked upload block, handed back when the index is freed (the build does not wait)
+    size_t staging_cap = 0;
+    hipEvent_t ev_built = nullptr;   // behind the build's last kernel on the copy stream
     std::vector<uint32_t> h_k;       // per graph
 };
+
+// what the error word of a device-built path index says (pg_path_index::d_error)
+const char* pg_path_index_error_text(uint32_t word);
+// fetches that word for a batch whose stages are complete (synchronises the copy stream): PG_OK, or the build's failure
+pg_status pg_path_index_check(pg_ctx* ctx, const pg_graphs* G);
 
 // the tables pg_build_kmer_index makes on the host before they go up
 struct PgKmerIndexHost

@@ -639,13 +639,24 @@ void pg_path_index_free(pg_path_index* ix)
 {
     if (!ix)
         return;
-    (void)pg_dev_free(ix->d_graphs);
+    if (ix->ev_built)
+    {
+        (void)hipEventSynchronize(ix->ev_built);  // (long complete wherever a batch of the set has come back)
+        (void)hipEventDestroy(ix->ev_built);
+    }
+    pg_pinned_put(ix->staging, ix->staging_cap);
+    if (ix->d_block)
+        (void)pg_dev_free(ix->d_block);  // (d_graphs, d_node_off, d_raw, d_succ_off, d_succ point into it)
+    else
+    {
+        (void)pg_dev_free(ix->d_graphs);
+        (void)pg_dev_free(ix->d_node_off);
+        (void)pg_dev_free(ix->d_raw);
+        (void)pg_dev_free(ix->d_succ_off);
+        (void)pg_dev_free(ix->d_succ);
+    }
     (void)pg_dev_free(ix->d_table);
     (void)pg_dev_free(ix->d_pool);
-    (void)pg_dev_free(ix->d_node_off);
-    (void)pg_dev_free(ix->d_raw);
-    (void)pg_dev_free(ix->d_succ_off);
-    (void)pg_dev_free(ix->d_succ);
     (void)pg_dev_free(ix->d_node_uniq);
     (void)pg_dev_free(ix->d_filter);
     delete ix;
@@ -680,13 +691,19 @@ struct KmerEnumerator
     std::vector<KmerOcc>& occ;
     std::vector<uint32_t>& occ_pool;
     std::vector<uint32_t> nl;
+    // Prefix hashes of every node (P[0] = 0, P[i + 1] = P[i] B + c_i + 1, all mod 2^64) and the powers of B: the hash of the
+    // characters [a, b) of a node is P[b] - P[a] B^(b - a), and a k-mer that runs over several nodes is put together from its
+    // pieces with one multiplication each -- the same value as hashing its k characters one by one, which is what a third of a
+    // site graph's k-mers (the ones that cross a node boundary) used to cost.
+    std::vector<uint64_t> pref, pw;
+    std::vector<uint32_t> pref_off;
 
     const char* node_chars(uint32_t node) const { return G->h_seq_raw.data() + G->h_nodeseq_off[nb + node]; }
-    static uint64_t extend(uint64_t h, const char* s, uint32_t n)
+    // hash of the characters [a, b) of `node`
+    uint64_t piece(uint32_t node, uint32_t a, uint32_t b) const
     {
-        for (uint32_t c = 0; c < n; ++c)
-            h = h * HASH_B + (uint64_t)(uint8_t)s[c] + 1;
-        return h;
+        const uint64_t* P = pref.data() + pref_off[node];
+        return P[b] - P[a] * pw[b - a];
     }
     void leaf(uint64_t h, uint32_t start, uint32_t end)
     {
@@ -700,10 +717,10 @@ struct KmerEnumerator
         const uint32_t room = G->h_node_len[nb + node] - pos, need = k - have;
         if (need <= room)
         {
-            leaf(extend(h, node_chars(node) + pos, need), start, pos + need - 1);
+            leaf(h * pw[need] + piece(node, pos, pos + need), start, pos + need - 1);
             return;
         }
-        h = extend(h, node_chars(node) + pos, room);
+        h = h * pw[room] + piece(node, pos, pos + room);
         for (uint32_t s = succ_off[nb + node]; s < succ_off[nb + node + 1]; ++s)
         {
             nl.push_back(succ[s]);
@@ -711,33 +728,38 @@ struct KmerEnumerator
             nl.pop_back();
         }
     }
-    // every length-k path of the graph in the reference's order (KmerIndex.cpp:76-99: node by node, position by position).  The
-    // k-mers that lie inside one node -- most of them -- roll: h' = (h - (c_out + 1) B^(k-1)) B + c_in + 1.
+    // every length-k path of the graph in the reference's order (KmerIndex.cpp:76-99: node by node, position by position)
     void run(uint32_t n_nodes)
     {
-        uint64_t pow_k1 = 1;
-        for (uint32_t i = 1; i < k; ++i)
-            pow_k1 *= HASH_B;
+        pw.assign(k + 1, 1);
+        for (uint32_t i = 1; i <= k; ++i)
+            pw[i] = pw[i - 1] * HASH_B;
+        pref_off.assign(n_nodes, 0);
+        size_t total = 0;
+        for (uint32_t node = 0; node < n_nodes; ++node)
+        {
+            pref_off[node] = (uint32_t)total;
+            total += G->h_node_len[nb + node] + 1;
+        }
+        pref.resize(total);
+        for (uint32_t node = 0; node < n_nodes; ++node)
+        {
+            uint64_t* P = pref.data() + pref_off[node];
+            const char* s = node_chars(node);
+            const uint32_t len = G->h_node_len[nb + node];
+            uint64_t h = 0;
+            P[0] = 0;
+            for (uint32_t c = 0; c < len; ++c)
+                P[c + 1] = h = h * HASH_B + (uint64_t)(uint8_t)s[c] + 1;
+        }
         for (uint32_t node = 0; node < n_nodes; ++node)
         {
             const uint32_t len = G->h_node_len[nb + node];
-            const char* s = node_chars(node);
-            uint64_t h = 0;
-            bool rolling = false;
             for (uint32_t pos = 0; pos < len; ++pos)
             {
                 nl.assign(1, node);
                 if (pos + k <= len)
-                {
-                    if (!rolling)
-                    {
-                        h = extend(0, s + pos, k);
-                        rolling = true;
-                    }
-                    else
-                        h = (h - ((uint64_t)(uint8_t)s[pos - 1] + 1) * pow_k1) * HASH_B + (uint64_t)(uint8_t)s[pos + k - 1] + 1;
-                    leaf(h, pos, pos + k - 1);
-                }
+                    leaf(piece(node, pos, pos + k), pos, pos + k - 1);
                 else
                     go(0, 0, pos, pos);
             }
@@ -878,7 +900,7 @@ const char* pg_build_kmer_index_host(const pg_graphs* G, const std::vector<int32
             pool.resize(pool_mark);
             occ.clear();
             occ_pool.clear();
-            KmerEnumerator en{ G, succ_off, succ, nb, kk, occ, occ_pool, {} };
+            KmerEnumerator en{ G, succ_off, succ, nb, kk, occ, occ_pool, {}, {}, {}, {} };
             en.run(ne - nb);
             cap = 4;
             while (cap < 2 * occ.size())
@@ -1013,12 +1035,408 @@ pg_status pg_build_kmer_index(pg_ctx* ctx, pg_graphs* G, const std::vector<int32
     return PG_OK;
 }
 
+// ---- the path stage's index made ON THE DEVICE ---------------------------------------------------------------------------------
+// Enumerating a site graph's ~700 k-mers, hashing them, filling a 64 KB table and sending it up cost the host 25 - 30 us per site --
+// a sixth of what a (site, sample) costs it in `paragraph`'s default cascade.  The host now only COUNTS the length-k paths (a
+// dynamic programme over (node, characters left): tens of operations per node) to size the table, the node pool and the presence
+// filter; one thread per start position walks the paths (depth-first over the successors in ascending id, as extendPathEnd does),
+// hashes them and claims slots with a compare-and-swap.  A k-mer that occurs once -- the only kind a lookup accepts -- has one
+// path whoever inserts it; for a repeated one the entry keeps whichever occurrence came first HERE (graphtools::KmerIndex keeps
+// the enumeration's first; nothing reads the path of an entry whose count is not 1).  A second pass compares every occurrence
+// of a repeated hash with the entry's own characters: two different sequences under one 64-bit hash fail the build, as on the
+// host.  The KmerFilter's index (unique-k-mer counts per node and edge, auto-detected lengths) stays with the host builder.
+namespace
+{
+constexpr uint32_t DEV_INDEX_MAX_K = 64;  // depth of a walk's stack (a node has at least one character)
+
+struct IndexBuildArgs
+{
+    uint32_t n_chars;               // characters of the whole set = start positions
+    uint32_t n_total_nodes;
+    uint32_t k;
+    const uint32_t* node_off;       // raw character offsets per set-wide node (n_total + 1)
+    const char* raw;
+    const uint32_t* graph_of_node;  // per set-wide node
+    const PathGraphDev* graphs;
+    const uint32_t* succ_off;
+    const uint32_t* succ;
+    KmerEntry* table;
+    uint32_t* pool;
+    uint32_t* pool_next;            // per graph: next free pool slot (starts at the graph's pool base)
+    uint32_t* filter;
+    uint32_t* error;                // bit0: two sequences with one hash; bit1: internal (table / pool full)
+};
+
+// the characters of the path (nodes ids[0..n), starting at `start` of the first) equal those of (ids2, start2)?  k characters.
+__device__ bool same_kmer(const IndexBuildArgs& a, uint32_t node_base, uint32_t k, const uint32_t* ids, uint32_t start, const uint32_t* ids2, uint32_t start2)
+{
+    uint32_t i1 = 0, p1 = start, i2 = 0, p2 = start2;
+    uint32_t n1 = node_base + ids[0], n2 = node_base + ids2[0];
+    for (uint32_t c = 0; c < k; ++c)
+    {
+        while (p1 >= a.node_off[n1 + 1] - a.node_off[n1])
+        {
+            n1 = node_base + ids[++i1];
+            p1 = 0;
+        }
+        while (p2 >= a.node_off[n2 + 1] - a.node_off[n2])
+        {
+            n2 = node_base + ids2[++i2];
+            p2 = 0;
+        }
+        if (a.raw[a.node_off[n1] + p1] != a.raw[a.node_off[n2] + p2])
+            return false;
+        ++p1;
+        ++p2;
+    }
+    return true;
+}
+
+template <bool VERIFY> __global__ __launch_bounds__(64) void pg_index_build_kernel(IndexBuildArgs a)
+{
+    const uint32_t c0 = blockIdx.x * 64u + threadIdx.x;
+    if (c0 >= a.n_chars)
+        return;
+    // the node that holds character c0 (binary search over the set's node offsets)
+    uint32_t lo = 0, hi = a.n_total_nodes;
+    while (lo + 1 < hi)
+    {
+        const uint32_t mid = (lo + hi) / 2;
+        if (a.node_off[mid] <= c0)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t node0 = lo;
+    const uint32_t gi = a.graph_of_node[node0];
+    const PathGraphDev g = a.graphs[gi];
+    if (g.tab_mask == 0xFFFFFFFFu)
+        return;
+    const uint32_t k = a.k, start = c0 - a.node_off[node0];
+    // depth-first walk: level d holds its node (graph-local), the successor it tries next, and the hash / characters before it
+    uint32_t ids[DEV_INDEX_MAX_K], next_succ[DEV_INDEX_MAX_K], have_before[DEV_INDEX_MAX_K];
+    uint64_t hash_before[DEV_INDEX_MAX_K];
+    int depth = 0;
+    ids[0] = node0 - g.node_base;
+    have_before[0] = 0;
+    hash_before[0] = 0;
+    next_succ[0] = 0xFFFFFFFFu;  // not entered yet
+    while (depth >= 0)
+    {
+        const uint32_t node = g.node_base + ids[depth];
+        const uint32_t len = a.node_off[node + 1] - a.node_off[node];
+        const uint32_t pos = depth == 0 ? start : 0u;
+        const uint32_t room = len - pos, need = k - have_before[depth];
+        if (next_succ[depth] == 0xFFFFFFFFu)
+        {
+            // first visit: hash this node's share of the k-mer
+            const uint32_t take = need <= room ? need : room;
+            uint64_t h = hash_before[depth];
+            const char* s = a.raw + a.node_off[node] + pos;
+            for (uint32_t c = 0; c < take; ++c)
+                h = h * HASH_B + (uint64_t)(uint8_t)s[c] + 1;
+            if (need <= room)
+            {
+                // ---- a complete k-mer: nodes ids[0..depth], from `start` of the first to pos + need - 1 of the last
+                if (h == 0)
+                    h = 1;
+                const uint32_t n_nodes = (uint32_t)depth + 1;
+                uint32_t slot = (uint32_t)(h >> 20) & g.tab_mask;
+                for (uint32_t probes = 0;; ++probes)
+                {
+                    KmerEntry* e = a.table + g.tab_off + slot;
+                    if (!VERIFY)
+                    {
+                        const unsigned long long old = atomicCAS((unsigned long long*)&e->hash, 0ull, (unsigned long long)h);
+                        if (old == 0ull)
+                        {
+                            const uint32_t at = atomicAdd(&a.pool_next[gi], n_nodes);
+                            for (uint32_t i = 0; i < n_nodes; ++i)
+                                a.pool[at + i] = ids[i];
+                            e->start_pos = start;
+                            e->end_pos = pos + need - 1;
+                            e->n_nodes = n_nodes;
+                            e->pool_off = at;
+                            atomicAdd(&e->count, 1u);
+                            const uint32_t bit = (uint32_t)(h >> 32) & g.filt_mask;
+                            atomicOr(&a.filter[g.filt_off + (bit >> 5)], 1u << (bit & 31u));
+                            break;
+                        }
+                        if (old == (unsigned long long)h)
+                        {
+                            atomicAdd(&e->count, 1u);
+                            break;
+                        }
+                    }
+                    else
+                    {
+                        const uint64_t eh = e->hash;
+                        if (eh == h)
+                        {
+                            if (e->count > 1u && !same_kmer(a, g.node_base, k, ids, start, a.pool + e->pool_off, e->start_pos))
+                                atomicOr(a.error, 1u);
+                            break;
+                        }
+                        if (eh == 0)
+                        {
+                            atomicOr(a.error, 2u);  // (an occurrence the first pass did not insert)
+                            break;
+                        }
+                    }
+                    if (probes > g.tab_mask)
+                    {
+                        atomicOr(a.error, 2u);
+                        break;
+                    }
+                    slot = (slot + 1) & g.tab_mask;
+                }
+                --depth;
+                continue;
+            }
+            hash_before[depth + 1] = h;
+            have_before[depth + 1] = have_before[depth] + room;
+            next_succ[depth] = a.succ_off[node];
+        }
+        if (next_succ[depth] < a.succ_off[node + 1] && depth + 1 < (int)DEV_INDEX_MAX_K)
+        {
+            ids[depth + 1] = a.succ[next_succ[depth]++];
+            next_succ[depth + 1] = 0xFFFFFFFFu;
+            ++depth;
+        }
+        else
+            --depth;
+    }
+}
+
+// number of length-k paths of graph g and of the node ids they list together (what the table and the pool must hold): f(node, r) =
+// paths of r more characters that start at the node's first character
+bool count_kmers(const pg_graphs* G, const std::vector<uint32_t>& succ_off, const std::vector<uint32_t>& succ, uint32_t g, uint32_t k, uint64_t& n_occ,
+                 uint64_t& n_pool, std::vector<uint64_t>& f, std::vector<uint64_t>& p)
+{
+    const uint32_t nb = G->h_node_off[g], n = G->h_node_off[g + 1] - nb;
+    f.assign((size_t)n * (k + 1), 0);
+    p.assign((size_t)n * (k + 1), 0);
+    n_occ = n_pool = 0;
+    for (uint32_t node = n; node-- > 0;)
+    {
+        const uint32_t len = G->h_node_len[nb + node];
+        if (len == 0)
+            return false;  // (a walk's depth is bounded by k only when every node holds a character: the host builder takes the set)
+        for (uint32_t r = 1; r <= k; ++r)
+        {
+            uint64_t paths = 0, ids = 0;
+            if (r <= len)
+            {
+                paths = 1;
+                ids = 1;
+            }
+            else
+                for (uint32_t s = succ_off[nb + node]; s < succ_off[nb + node + 1]; ++s)
+                {
+                    if (succ[s] <= node)
+                        return false;  // (not in topological order: the host builder takes the set)
+                    const uint64_t fs = f[(size_t)succ[s] * (k + 1) + (r - len)];
+                    paths += fs;
+                    ids += fs + p[(size_t)succ[s] * (k + 1) + (r - len)];
+                }
+            f[(size_t)node * (k + 1) + r] = paths;
+            p[(size_t)node * (k + 1) + r] = ids;
+        }
+        // start positions inside the node: the first len - k + 1 (if any) stay inside it, the others run on into the successors
+        const uint32_t inside = len >= k ? len - k + 1 : 0;
+        n_occ += inside;
+        n_pool += inside;
+        for (uint32_t pos = inside; pos < len; ++pos)
+        {
+            const uint32_t rem = len - pos;  // < k
+            for (uint32_t s = succ_off[nb + node]; s < succ_off[nb + node + 1]; ++s)
+            {
+                const uint64_t fs = f[(size_t)succ[s] * (k + 1) + (k - rem)];
+                n_occ += fs;
+                n_pool += fs + p[(size_t)succ[s] * (k + 1) + (k - rem)];
+            }
+        }
+    }
+    return true;
+}
+
+// PG_OK with *out == nullptr: this set is not for the device builder (k too long, nodes out of order, sizes beyond 32 bits)
+pg_status build_path_index_on_device(pg_ctx* ctx, pg_graphs* G, uint32_t k, pg_path_index** out)
+{
+    *out = nullptr;
+    // Opt-in (PG_PATH_INDEX_DEVICE=1).  Measured on the e2e leg with `paragraph`'s default cascade (profiles/r06_path_index_device_ab.jsonl):
+    // 169 against 180 us of host CPU per (site, sample), but 77 - 79 k against 82.5 k sites/s -- the two build launches sit on
+    // the one copy stream in front of every lane's uploads.  A host with fewer cores per GPU than this box may prefer it.
+    if (k > DEV_INDEX_MAX_K || !getenv("PG_PATH_INDEX_DEVICE"))
+        return PG_OK;
+    static thread_local PgKmerIndexHost t;  // (kept from call to call: see pg_build_kmer_index)
+    static thread_local std::vector<uint64_t> f, p;
+    static thread_local std::vector<uint32_t> graph_of_node, pool_next;
+    std::vector<uint32_t>& succ_off = t.succ_off;
+    std::vector<uint32_t>& succ = t.succ;
+    const uint32_t n_total = (uint32_t)G->h_node_len.size();
+    succ_off.assign(n_total + 1, 0);
+    succ.assign(G->h_pred.size(), 0);
+    graph_of_node.assign(std::max<uint32_t>(n_total, 1), 0);
+    for (uint32_t g = 0; g < G->n_graphs; ++g)
+    {
+        const uint32_t nb = G->h_node_off[g], ne = G->h_node_off[g + 1];
+        for (uint32_t node = nb; node < ne; ++node)
+        {
+            graph_of_node[node] = g;
+            for (uint32_t q = G->h_pred_off[node]; q < G->h_pred_off[node + 1]; ++q)
+                ++succ_off[nb + G->h_pred[q] + 1];
+        }
+    }
+    for (uint32_t i = 0; i < n_total; ++i)
+        succ_off[i + 1] += succ_off[i];
+    {
+        std::vector<uint32_t> fill(succ_off.begin(), succ_off.end() - 1);
+        for (uint32_t g = 0; g < G->n_graphs; ++g)
+        {
+            const uint32_t nb = G->h_node_off[g], ne = G->h_node_off[g + 1];
+            for (uint32_t node = nb; node < ne; ++node)
+                for (uint32_t q = G->h_pred_off[node]; q < G->h_pred_off[node + 1]; ++q)
+                    succ[fill[nb + G->h_pred[q]]++] = node - nb;
+        }
+    }
+    std::vector<PathGraphDev>& gd = t.gd;
+    gd.assign(G->n_graphs, PathGraphDev{});
+    pool_next.assign(std::max<uint32_t>(G->n_graphs, 1), 0);
+    uint64_t table_entries = 0, pool_entries = 0, filter_words = 0;
+    uint64_t pow_k1 = 1;
+    for (uint32_t i = 1; i < k; ++i)
+        pow_k1 *= HASH_B;
+    for (uint32_t g = 0; g < G->n_graphs; ++g)
+    {
+        uint64_t n_occ = 0, n_pool = 0;
+        if (!count_kmers(G, succ_off, succ, g, k, n_occ, n_pool, f, p))
+            return PG_OK;
+        uint64_t cap = 0;
+        if (n_occ)
+        {
+            cap = 4;
+            while (cap < 2 * n_occ)
+                cap *= 2;
+        }
+        uint64_t bits = 1024;
+        while (bits < 64u * (cap / 2) && bits < (1u << 28))
+            bits *= 2;
+        gd[g].node_base = G->h_node_off[g];
+        gd[g].n_nodes = G->h_node_off[g + 1] - G->h_node_off[g];
+        gd[g].k = k;
+        gd[g].pow_k1 = pow_k1;
+        gd[g].tab_off = table_entries;
+        gd[g].tab_mask = cap ? (uint32_t)(cap - 1) : 0xFFFFFFFFu;
+        gd[g].filt_off = (uint32_t)filter_words;
+        gd[g].filt_mask = (uint32_t)(bits - 1);
+        pool_next[g] = (uint32_t)pool_entries;
+        table_entries += cap;
+        pool_entries += n_pool;
+        filter_words += bits / 32;
+        if (cap > (1ull << 31) || pool_entries >= (1ull << 32) || filter_words >= (1ull << 32))
+            return PG_OK;
+    }
+    if (G->h_seq_raw.size() >= (1ull << 32))
+        return PG_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pg_path_index* ix = new pg_path_index();
+    ix->h_k.assign(G->n_graphs, k);
+    ix->k = k;
+    ix->pow_k1 = pow_k1;
+    // one staged copy for the small tables; the table, the pool and the filter are made on the device
+    std::vector<uint32_t> node_off(G->h_nodeseq_off.begin(), G->h_nodeseq_off.end());
+    uint32_t *d_graph_of_node = nullptr, *d_pool_next = nullptr, *d_error = nullptr;
+    void* staging = nullptr;
+    size_t staging_cap = 0;
+    hipError_t e;
+    {
+        PgStagedUpload up;
+        up.add(gd, &ix->d_graphs);
+        up.add(node_off, &ix->d_node_off);
+        up.add_raw(G->h_seq_raw.data(), G->h_seq_raw.size(), (void**)&ix->d_raw);
+        up.add(succ_off, &ix->d_succ_off);
+        up.add(succ, &ix->d_succ);
+        up.add(graph_of_node, &d_graph_of_node);
+        up.add(pool_next, &d_pool_next);
+        e = up.commit_async(ctx->stream_copy, &ix->d_block, &staging, &staging_cap);
+    }
+    if (e == hipSuccess) e = pg_dev_alloc((void**)&ix->d_table, std::max<uint64_t>(table_entries, 1) * sizeof(KmerEntry));
+    if (e == hipSuccess) e = pg_dev_alloc((void**)&ix->d_pool, std::max<uint64_t>(pool_entries, 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = pg_dev_alloc((void**)&ix->d_filter, (filter_words + 1) * sizeof(uint32_t));  // (+ the error word)
+    if (e == hipSuccess) e = hipMemsetAsync(ix->d_table, 0, std::max<uint64_t>(table_entries, 1) * sizeof(KmerEntry), ctx->stream_copy);
+    if (e == hipSuccess) e = hipMemsetAsync(ix->d_filter, 0, (filter_words + 1) * sizeof(uint32_t), ctx->stream_copy);
+    if (e == hipSuccess)
+    {
+        d_error = ix->d_filter + filter_words;
+        ix->d_error = d_error;
+        IndexBuildArgs a{};
+        a.n_chars = (uint32_t)G->h_seq_raw.size();
+        a.n_total_nodes = n_total;
+        a.k = k;
+        a.node_off = ix->d_node_off;
+        a.raw = ix->d_raw;
+        a.graph_of_node = d_graph_of_node;
+        a.graphs = ix->d_graphs;
+        a.succ_off = ix->d_succ_off;
+        a.succ = ix->d_succ;
+        a.table = ix->d_table;
+        a.pool = ix->d_pool;
+        a.pool_next = d_pool_next;
+        a.filter = ix->d_filter;
+        a.error = d_error;
+        if (a.n_chars)
+        {
+            hipLaunchKernelGGL(pg_index_build_kernel<false>, dim3((a.n_chars + 63) / 64), dim3(64), 0, ctx->stream_copy, a);
+            hipLaunchKernelGGL(pg_index_build_kernel<true>, dim3((a.n_chars + 63) / 64), dim3(64), 0, ctx->stream_copy, a);
+            e = hipGetLastError();
+        }
+    }
+    // Nothing waits here: the batch's upload follows on the same stream and its event orders every stage behind the build; the
+    // error word comes back with the batch's result sizes (pg_batch_count publishes it) or with its records / flags, and the
+    // page-locked block of the upload is handed back when the index is freed.
+    ix->staging = staging;
+    ix->staging_cap = staging_cap;
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_built, pg_wait_event_flags());
+    if (e == hipSuccess) e = hipEventRecord(ix->ev_built, ctx->stream_copy);
+    if (e != hipSuccess)
+    {
+        (void)hipStreamSynchronize(ctx->stream_copy);  // (the copy may still read the block)
+        pg_path_index_free(ix);
+        return pg_fail(ctx, PG_ERR_HIP, std::string("k-mer index build: ") + hipGetErrorString(e));
+    }
+    *out = ix;
+    return PG_OK;
+}
+}  // namespace
+
+const char* pg_path_index_error_text(uint32_t word)
+{
+    return word & 1u ? "64-bit k-mer hash collision inside one graph (path index)" : "k-mer index build: table or pool overflow (internal)";
+}
+
+pg_status pg_path_index_check(pg_ctx* ctx, const pg_graphs* G)
+{
+    if (!G || !G->path_index || !G->path_index->d_error)
+        return PG_OK;
+    uint32_t word = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&word, G->path_index->d_error, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream_copy));
+    HIP_TRY(ctx, pg_stream_wait(ctx->device, ctx->stream_copy));
+    if (word)
+        return pg_fail(ctx, word & 1u ? PG_ERR_UNSUPPORTED : PG_ERR_HIP, pg_path_index_error_text(word));
+    return PG_OK;
+}
+
 extern "C" pg_status pg_graphs_build_path_index(pg_ctx* ctx, pg_graphs* G, uint32_t kmer_len)
 {
     if (!ctx || !G || kmer_len == 0 || kmer_len > 250)
         return pg_fail(ctx, PG_ERR_INVALID, "pg_graphs_build_path_index: bad argument");
     pg_path_index* ix = nullptr;
-    const pg_status st = pg_build_kmer_index(ctx, G, std::vector<int32_t>(G->n_graphs, (int32_t)kmer_len), &ix, false);
+    pg_status st = build_path_index_on_device(ctx, G, kmer_len, &ix);
+    if (st != PG_OK)
+        return st;
+    if (!ix)
+        st = pg_build_kmer_index(ctx, G, std::vector<int32_t>(G->n_graphs, (int32_t)kmer_len), &ix, false);
     if (st != PG_OK)
         return st;
     ix->k = kmer_len;
@@ -1132,6 +1550,5 @@ extern "C" pg_status pg_batch_download_path_flags(pg_ctx* ctx, pg_batch* b, uint
     HIP_TRY(ctx, pg_batch_wait(ctx, b));
     if (b->n_reads)
         HIP_TRY(ctx, hipMemcpyAsync(flags, b->d_path_flags, b->n_reads, hipMemcpyDeviceToHost, ctx->stream_copy));
-    HIP_TRY(ctx, pg_stream_wait(ctx->device, ctx->stream_copy));
-    return PG_OK;
+    return pg_path_index_check(ctx, b->graphs);  // (waits for the copy stream; a path index built on the device reports here)
 }

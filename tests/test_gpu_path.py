@@ -66,8 +66,12 @@ def _path_reads(rng, seqs, edges, k, n):
     return reads
 
 
-@pytest.mark.parametrize("k", [8, 16, 32])
-def test_path_stage_fuzz(gpu_ctx, k):
+@pytest.mark.parametrize("k,index_on_device", [(8, False), (16, False), (32, False), (16, True), (32, True)])
+def test_path_stage_fuzz(gpu_ctx, k, index_on_device, monkeypatch):
+    """index_on_device: the k-mer table, node pool and presence filter made by pg_index_build_kernel (PG_PATH_INDEX_DEVICE=1)
+    instead of the host enumerator -- the same records either way."""
+    if index_on_device:
+        monkeypatch.setenv("PG_PATH_INDEX_DEVICE", "1")
     check = path_checker()
     rng = random.Random(fuzzgen.salted(1000 + k))
     graphs, reads, gor, want = [], [], [], []

@@ -58,6 +58,15 @@ int main(int argc, char** argv)
         best = std::min(best, s);
         entries = t.table.size();
     }
-    printf("{\"graphs\": %u, \"k\": 32, \"fresh_tables\": %s, \"us_per_graph\": %.2f, \"table_entries_per_graph\": %.0f}\n", n, fresh ? "true" : "false", best / n * 1e6, (double)entries / n);
+    // (a checksum of everything the device gets: two builds of the library that print the same one made the same tables)
+    uint64_t sum = 0;
+    for (auto const& e : kept.table)
+        sum = sum * 1000003u + e.hash + e.count * 7u + e.start_pos * 11u + e.end_pos * 13u + e.n_nodes * 17u + e.pool_off * 19u;
+    for (uint32_t v : kept.pool)
+        sum = sum * 1000003u + v;
+    for (uint32_t v : kept.filter)
+        sum = sum * 1000003u + v;
+    printf("{\"graphs\": %u, \"k\": 32, \"fresh_tables\": %s, \"us_per_graph\": %.2f, \"table_entries_per_graph\": %.0f, \"checksum\": \"%016llx\"}\n", n,
+           fresh ? "true" : "false", best / n * 1e6, (double)entries / n, (unsigned long long)sum);
     return 0;
 }

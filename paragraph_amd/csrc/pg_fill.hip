@@ -207,7 +207,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     }
 
     const uint32_t nsteps = pg_fill_steps_lanes(gd.ncols, GL);  // even
-    // [node][lane][SEED_DW] / [step][TRACE_DW][lane] (one store instruction = 256 contiguous bytes); wavefront `half` of a wide
+    // [node][lane][SEED_DW] / [step / 2][TRACE_DW][lane][step & 1] (one store instruction = 512 contiguous bytes); wavefront `half` of a wide
     // item owns the second n_nodes * 64 * SEED_DW / nsteps * 64 * TRACE_DW dwords
     uint32_t* __restrict__ seed = (uint32_t*)(a.workspace + itp->seed_off) + (size_t)half * n_nodes * 64 * SEED_DW;
     uint32_t* __restrict__ trace = (uint32_t*)(a.workspace + itp->trace_off) + (size_t)half * nsteps * 64 * TRACE_DW;
@@ -251,7 +251,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     const uint32_t NEG1 = pk_delta2(-1);
     const uint32_t NEG256 = 0xDC00DC00u;  // (-256.0, -256.0)
     const uint32_t* profl = prof + lgrp * 4 * ROWS + k * C;
-    const uint32_t trace_lane_off = (uint32_t)lane * 4u;
+    const uint32_t trace_lane_off = (uint32_t)lane * 8u;  // (a lane stores the dwords of an even step and of the odd step behind it together)
 
     // Column meta words: the word of step t is the same for the whole wavefront, so it is read with SCALAR loads through
     // the constant address space (the graph tables are never written by a kernel), two steps ahead.  Scalar loads count
@@ -288,19 +288,26 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         for (int r = 0; r < C; ++r)
             sB[r] = 0;
     }
-    // the H trace of one step is [TRACE_DW][64 lanes] dwords behind a wave-uniform base that advances by one step per step:
+    // the H trace of a PAIR of steps (even, odd) is [TRACE_DW][64 lanes][2 steps] dwords behind a wave-uniform base that advances
+    // by two steps every two steps: the dwords of the even step wait in registers for those of the odd one and leave as one
+    // global_store_dwordx2 -- half the store instructions, and the traceback, which walks diagonals (one step per cell), finds
+    // four cells of its path in one 8-byte piece, i.e. half as many 128-byte lines per read (profiles/r06_trace_pairs_ab.jsonl).
     // the stores take the scalar-base form (SGPR pair + 32-bit lane offset + immediate), no per-step vector address arithmetic
     // (readfirstlane: the base is uniform by construction; this makes it so for the compiler, which must keep it in SGPRs;
     // the builtin returns a signed int: without the casts the low half would be sign-extended over the high one)
     uint64_t tbase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)(uintptr_t)trace >> 32)) << 32)
         | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)trace);
     constexpr uint32_t TRACE_STEP_BYTES = 64u * 4u * (uint32_t)TRACE_DW;
+    // (the immediate of a global store is 13 bits, signed: beyond eight dwords per step the base sits 4 096 bytes into the pair)
+    constexpr int TRACE_BIAS = TRACE_DW > 8 ? 4096 : 0;
+    tbase += (uint64_t)TRACE_BIAS;
 
     // ---- one column of the affine-gap recurrence for C rows x 2 strands (Hin: previous column, Hout: this column) -----------
     // floorE = the bit pattern of score 0 in the frame of step t + 1; tau = tau(t); tvec = (t | t << 16), all wave-uniform
+    uint32_t tpack[DIR == 0 ? TRACE_DW : 1];  // the even step's trace dwords
     auto column = [&](uint32_t (&Hin)[C], uint32_t (&Hout)[C], const uint32_t (&sc)[C], uint32_t dH, uint32_t Fabove, uint32_t floorE,
-                      uint32_t tau, uint32_t tvec) __attribute__((always_inline)) {
-        (void)tau;
+                      uint32_t tau, uint32_t tvec, const bool ODD) __attribute__((always_inline)) {
+        (void)tau;  // (ODD is a literal at both call sites: the inlined copies keep one side of the test each)
         uint32_t diag = dH;
         uint32_t F = Fabove;
 #pragma unroll
@@ -377,7 +384,18 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             for (int r = 0; r < C; r += 2)
             {
                 const uint32_t packed = __builtin_amdgcn_perm(Hout[r + 1], Hin[r], 0x06020400u);  // bytes A_r', A_r+1, B_r', B_r+1 (one v_perm)
-                asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(trace_lane_off), "v"(packed), "s"(tbase), "n"((r / 2) * 256) : "memory");
+                if (!ODD)
+                {
+                    tpack[DIR == 0 ? r / 2 : 0] = packed;
+                    // (made HERE: left alone the compiler sinks this v_perm to the store in the next step, and then keeps a second copy
+                    // of the odd rows of this column for it across the next step's first-column block -- five v_mov per pair of steps)
+                    asm volatile("" : "+v"(tpack[DIR == 0 ? r / 2 : 0]));
+                }
+                else
+                {
+                    const uint64_t both = (uint64_t)tpack[DIR == 0 ? r / 2 : 0] | ((uint64_t)packed << 32);
+                    asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 nt" : : "v"(trace_lane_off), "v"(both), "s"(tbase), "n"((r / 2) * 512 - TRACE_BIAS) : "memory");
+                }
             }
         }
     };
@@ -562,7 +580,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     };
 
     // ---- one pipeline step: reads Hin (previous column) / sc (this column's profile rows), writes Hout / sn (next column's) ---
-    auto step = [&](uint32_t (&Hin)[C], uint32_t (&Hout)[C], uint32_t (&sc)[C], uint32_t (&sn)[C], uint32_t t) __attribute__((always_inline)) {
+    auto step = [&](uint32_t (&Hin)[C], uint32_t (&Hout)[C], uint32_t (&sc)[C], uint32_t (&sn)[C], uint32_t t, const bool odd_step) __attribute__((always_inline)) {
         const uint32_t meta_cur = meta;
         const uint32_t tau = PG_TAU0 + (t & 255u);                 // wave-uniform: scalar registers
         const uint32_t floorE = BIAS2 + (tau + 1u) * ONE2;         // score 0 in the next step's frame
@@ -607,7 +625,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             if (meta_cur & PG_META_FIRST)
                 first_column(Hin, meta_cur, tau);
         }
-        column(Hin, Hout, sc, dH, F, floorE, tau, tvec);
+        column(Hin, Hout, sc, dH, F, floorE, tau, tvec, odd_step);
         if (rare_lanes != 0ull)  // wave-uniform
         {
             uint32_t mc = meta_cur;
@@ -615,7 +633,8 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
             if (mc >= (PG_META_RARE | PG_META_LAST_HI))  // a LAST column (the only words with bits 31 and 30 set): one compare
                 last_column(Hout, meta_cur, tau);
         }
-        tbase += TRACE_STEP_BYTES;
+        if (odd_step)
+            tbase += 2u * TRACE_STEP_BYTES;
     };
 
     for (uint32_t t = 0; t < nsteps; t += 2)
@@ -636,13 +655,13 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
         }
         if (PREFETCH)
         {
-            step(HA, HB, sA, sB, t);
-            step(HB, HA, sB, sA, t + 1);
+            step(HA, HB, sA, sB, t, false);
+            step(HB, HA, sB, sA, t + 1, true);
         }
         else
         {
-            step(HA, HB, sA, sA, t);
-            step(HB, HA, sA, sA, t + 1);
+            step(HA, HB, sA, sA, t, false);
+            step(HB, HA, sA, sA, t + 1, true);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the key atomics (and the trace stores) above are invisible to the compiler's own counters

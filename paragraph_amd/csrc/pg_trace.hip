@@ -214,7 +214,7 @@ template <int C, bool WIDE, int GL> __device__ __forceinline__ void pg_trace_pai
     auto qchar = [&](int j) -> uint32_t {
         return s == 0 ? upper_c((uint8_t)bases[j]) : comp_c((uint8_t)bases[L - 1 - j]);
     };
-    // byte variants: trace [step][C/2][lane] dwords of bytes (A_r, A_r+1, B_r, B_r+1), seed [node][lane][C] dwords of
+    // byte variants: trace [step / 2][C/2][lane][step & 1] dwords of bytes (A_r, A_r+1, B_r, B_r+1), seed [node][lane][C] dwords of
     // bytes (H_A, H_B, Enext_A, Enext_B); wide variants: the same trace, seed [node][lane][2C] dwords (H_A | H_B << 16),
     // (Enext_A | Enext_B << 16), each 16-bit field = 0x6400 | score
     uint32_t n = (uint32_t)fs.max_node;  // the node being walked
@@ -241,7 +241,9 @@ template <int C, bool WIDE, int GL> __device__ __forceinline__ void pg_trace_pai
         const uint32_t tau = PG_TAU0 + ((col + kq) & 255u);
         if (!(r & 1u) && at_end)
             return seedH(n, j) & (WIDE ? 0xFF : 0x3FF);
-        const size_t dw = ((size_t)(col + kq + ((r & 1u) ^ 1u)) * (C / 2) + r / 2) * 64 + (lane0 + kq);
+        // ([step / 2][C / 2][lane][step & 1] dwords: the fill stores an even step and the odd one behind it together)
+        const uint32_t step = col + kq + ((r & 1u) ^ 1u);
+        const size_t dw = (((size_t)(step >> 1) * (C / 2) + r / 2) * 64 + (lane0 + kq)) * 2 + (step & 1u);
         // (non-temporal: a trace byte is read once, and what the walk pulls through the L2 competes with the next chunk's fill)
         return (int)(((uint32_t)__builtin_nontemporal_load(&trace[dw * 4 + (r & 1u) + 2u * (uint32_t)s]) - tau) & 0xFFu);
     };

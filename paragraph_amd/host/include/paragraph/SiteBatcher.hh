@@ -66,6 +66,9 @@ struct BatchParameters
     // batch: total / MAPPED / MAPPED off the simulated path / non-unique BAD_ALIGN; object sites with paths only.  The totals
     // are the process-wide ones grm::ValidationAligner<CompositeAligner>::total() ... report (validationLogLines()).
     bool validate_alignments = false;
+    // object sites: keep the reads the filter chain rejected (with the rejecting filter's name) for filtered() instead of
+    // dropping them -- what Disambiguation.cpp:177-199 appends to "alignments" under FILTERED_ALIGNMENTS
+    bool keep_filtered = false;
     unsigned alignment_flags = (unsigned)-1;
     int threads = 1;  // host threads for packing the reads and fanning the results back into them
     int device = 0;   // slot of the device list (setDevices / PG_DEVICES) this batch runs on
@@ -112,6 +115,10 @@ public:
     // "" or why the device path could not take this site (outside its envelope: a read beyond PG_MAX_READ_LEN, more than
     // PG_MAX_NODES nodes, ...).  Such a site has empty counts and no MAPPED reads; the other sites of the batch are unaffected.
     std::string const& error(size_t site) const;
+    // object sites run with keep_filtered: the reads of this site the filter chain rejected (graph_* fields of the rejected
+    // alignment, status BAD_ALIGN) and the filter's message ("nonuniq", "bad_align", "kmer_tooshort", "kmer_uncov"), in input
+    // order.  The caller may move the reads out.
+    std::vector<std::pair<common::p_Read, std::string>>& filtered(size_t site);
 
 private:
     struct Impl;

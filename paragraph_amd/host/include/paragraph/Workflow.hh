@@ -38,7 +38,7 @@ struct Parameters
     enum output_options
     {
         ALIGNMENTS = 0x01,
-        FILTERED_ALIGNMENTS = 0x02,  // accepted; filtered reads are tallied, their records are not re-emitted
+        FILTERED_ALIGNMENTS = 0x02,  // the reads the filter chain rejected, with the filter's message under "error", + the filter tallies
         NODE_READ_COUNTS = 0x08,
         EDGE_READ_COUNTS = 0x10,
         PATH_READ_COUNTS = 0x20,
@@ -131,6 +131,12 @@ struct Parameters
     bool kmer_sequence_matching = false;
     int bad_align_uniq_kmer_len = 0;
     bool output_alignments = false;  // keep "alignments" in the per-sample documents (the original writes them to a folder)
+    // grmpy -A / --alignment-output-folder (lib/grmpy/AlignSamples.cpp:57-109, 120-162): when this names an existing directory,
+    // every (sample, graph) pair's count document WITH the per-read records -- the reads the filters rejected included, and the
+    // filter tallies -- is written there as <sample>-<graph ID>-<target regions>.json.gz; as in the original the folder switches
+    // the filtered records and tallies on for the documents the genotyper reads too.  (Of paragraph::Parameters::ALL the keys
+    // this build produces: no "variants" / "node_coverage" / "path_coverage" / "phasing".)
+    std::string alignment_output_folder;
     // keep the reads of a site as flat arrays instead of common::Read objects (several times less host work); switched off
     // automatically when output_alignments needs the per-read records
     bool packed_reads = true;

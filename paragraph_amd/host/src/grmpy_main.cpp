@@ -2,8 +2,9 @@
 // drivers -- e.g. src/python/bin/multigrmpy.py --grmpy <this binary> -- keep working unchanged.  All it does is parse the
 // options and call grmpy::genotypeGraphs (paragraph/Workflow.hh); output as the original writes it: one document, or a
 // JSON array when several graphs are given, to -o (gzip with -z) or one file per graph under -O.
-// Not carried over: --alignment-output-folder / --infer-read-haplotypes (per-read outputs the batched workflow does not
-// produce); --log-* and --progress are accepted and ignored.
+// -A / --alignment-output-folder writes every (sample, graph) pair's count document with its per-read records into the folder
+// (lib/grmpy/AlignSamples.cpp:57-109).  Not carried over: --infer-read-haplotypes (phasing is outside this build); --log-* and
+// --progress are accepted and ignored.
 #include <algorithm>
 
 #include "cli_common.hh"
@@ -20,6 +21,7 @@ const char* kUsage = "grmpy -r <reference> -g <graphs> -m <manifest> [optional a
                      "  -o, --output-file FILE            output file; stdout if omitted or '-'\n"
                      "  -O, --output-folder DIR           one output file per graph, named like the graph file\n"
                      "  -z, --gzip-output [BOOL]          gzip-compress the output\n"
+                     "  -A, --alignment-output-folder DIR per (sample, graph): count document + per-read alignments, <DIR>/<sample>-<graph>-<regions>.json.gz\n"
                      "  -M, --max-reads-per-event N       (10000)\n"
                      "      --bad-align-frac F            (0.8)\n"
                      "      --path-sequence-matching BOOL (false)   --graph-sequence-matching BOOL (true)\n"
@@ -83,8 +85,10 @@ int main(int argc, char** argv)
                 (void)args.optionalBool();
             else if (args.is(nullptr, "--log-level") || args.is(nullptr, "--log-file") || args.is(nullptr, "--log-async"))
                 (void)args.value();
-            else if (args.is("-A", "--alignment-output-folder") || args.is(nullptr, "--infer-read-haplotypes"))
-                throw std::runtime_error("option '" + args.name() + "' is not available in this build (no per-read outputs)");
+            else if (args.is("-A", "--alignment-output-folder"))
+                parameters.alignment_output_folder = args.value();
+            else if (args.is(nullptr, "--infer-read-haplotypes"))
+                throw std::runtime_error("option '" + args.name() + "' is not available in this build (no phasing output)");
             else
                 throw std::runtime_error("unrecognised option '" + args.name() + "'");
         }

@@ -1089,6 +1089,7 @@ struct SiteBatcher::Impl
     std::vector<SiteCounts> counts;
     std::vector<SiteReadViews> views;
     std::vector<std::string> errors;  // per site: why the device path could not take it ("" = fine)
+    std::vector<std::vector<std::pair<common::p_Read, std::string>>> filtered;  // per site (BatchParameters::keep_filtered)
     struct Run;
     void runAll(BatchParameters const& prm);
     void finish(Run& run);
@@ -1103,6 +1104,12 @@ SiteCounts const& SiteBatcher::counts(size_t site) const { return impl_->counts.
 
 SiteReadViews const& SiteBatcher::views(size_t site) const { return impl_->views.at(site); }
 std::string const& SiteBatcher::error(size_t site) const { return impl_->errors.at(site); }
+std::vector<std::pair<common::p_Read, std::string>>& SiteBatcher::filtered(size_t site)
+{
+    if (impl_->filtered.size() < impl_->graphs.size())
+        impl_->filtered.resize(impl_->graphs.size());
+    return impl_->filtered.at(site);
+}
 
 size_t SiteBatcher::addSite(const Graph* graph, std::vector<common::p_Read>* reads, std::list<graphtools::Path> const* paths)
 {
@@ -1183,6 +1190,8 @@ void SiteBatcher::run(BatchParameters const& prm)
     impl_->counts.assign(n, SiteCounts());
     impl_->views.assign(n, SiteReadViews());
     impl_->errors.assign(n, std::string());
+    impl_->filtered.clear();
+    impl_->filtered.resize(n);
     if (n == 0)
         return;
     try
@@ -1196,6 +1205,8 @@ void SiteBatcher::run(BatchParameters const& prm)
         // ReadCounting.cpp:96-127); the device kernels do.  A site beyond them is reported, the run goes on.
         impl_->counts.assign(n, SiteCounts());
         impl_->views.assign(n, SiteReadViews());
+        impl_->filtered.clear();
+        impl_->filtered.resize(n);
         if (n == 1)
         {
             impl_->errors[0] = e.what();
@@ -1226,6 +1237,8 @@ void SiteBatcher::run(BatchParameters const& prm)
             impl_->counts[s] = std::move(half.impl_->counts[s - lo]);
             impl_->views[s] = std::move(half.impl_->views[s - lo]);
             impl_->errors[s] = std::move(half.impl_->errors[s - lo]);
+            if (s - lo < half.impl_->filtered.size())
+                impl_->filtered[s] = std::move(half.impl_->filtered[s - lo]);
         }
     }
 }
@@ -1284,6 +1297,8 @@ bool SiteBatcher::submit(BatchParameters const& prm)
     impl_->counts.assign(n, SiteCounts());
     impl_->views.assign(n, SiteReadViews());
     impl_->errors.assign(n, std::string());
+    impl_->filtered.clear();
+    impl_->filtered.resize(n);
     impl_->pending.reset();
     if (n == 0)
         return true;
@@ -1777,11 +1792,19 @@ void SiteBatcher::Impl::Run::siteTables()
             }
             if (packed_mode)
                 return;
-            // only MAPPED reads survive (Align.cpp:155)
+            // only MAPPED reads survive (Align.cpp:155); the ones a filter rejected go to filtered() when asked for
+            // (Disambiguation.cpp:183-203: status BAD_ALIGN, the filter's message under "error")
+            static const char* const kFilterName[] = { "", "nonuniq", "bad_align", "kmer_tooshort", "kmer_uncov" };
             std::vector<common::p_Read> kept;
+            uint64_t i = site_read0[s];
             for (auto& r : *impl.reads[s])
+            {
+                const uint64_t at = i++;
                 if (!r->bases().empty() && r->graph_mapping_status() == Read::MAPPED)
                     kept.emplace_back(std::move(r));
+                else if (prm.keep_filtered && !r->bases().empty() && sup[at].status == 2)
+                    impl.filtered[s].emplace_back(std::move(r), kFilterName[sup[at].filter <= 4 ? sup[at].filter : 0]);
+            }
             impl.reads[s]->swap(kept);
         },
         8);

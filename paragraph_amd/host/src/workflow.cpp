@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +26,8 @@
 #include "paragraph/SiteBatcher.hh"
 #include "paragraph/Statistics.hh"
 #include "parallel.hh"
+#include <sys/stat.h>
+#include <zlib.h>
 
 using common::Json;
 
@@ -273,10 +277,12 @@ void addDetailedCounts(Json& by_sequence, graphtools::Graph const& graph, SiteRe
     }
 }
 
-// one site's count document; `reads` is null for packed sites (then `views` is the batcher's)
+// one site's count document; `reads` is null for packed sites (then `views` is the batcher's); `filtered`: the reads the filter
+// chain rejected, with the filter's message (object sites under FILTERED_ALIGNMENTS: moved behind `reads`' own, as
+// alignAndDisambiguate leaves its read buffer, Disambiguation.cpp:348-358)
 Json countDocument(
     Parameters const& parameters, GraphDescription const& d, SiteCounts const& counts, SiteReadViews const& views, size_t reads_in,
-    common::ReadBuffer const* reads)
+    common::ReadBuffer* reads, std::vector<std::pair<common::p_Read, std::string>>* filtered = nullptr)
 {
     Json out = parameters.description_in_document ? d.description : Json::object();
     if (parameters.description_in_document)
@@ -316,12 +322,38 @@ Json countDocument(
     if (tally && counts.nonuniq)
         stats["read_filter_nonuniq"] = counts.nonuniq;
     out["alignment_statistics"] = std::move(stats);
-    if (reads && parameters.output_enabled(Parameters::ALIGNMENTS))
+    if (reads && (parameters.output_enabled(Parameters::ALIGNMENTS) || parameters.output_enabled(Parameters::FILTERED_ALIGNMENTS)))
     {
+        // the rejected reads first, as records of the rejected alignment with the filter's message (Disambiguation.cpp:183-203:
+        // there they are appended while the aligner's threads run, in whatever order those get to them; here in input order),
+        // then the reads that were kept (Disambiguation.cpp:348-356).  One deviation: with a seed stage in front of gssw the
+        // original also emits a read the filter rejected after an EARLIER stage and that a later stage then mapped -- twice, once
+        // per outcome; here a read has the record of its final outcome only.  "kmer_uncov" comes without the node ids the
+        // original appends to it.
         Json alignments = Json::array();
-        for (auto const& r : *reads)
-            alignments.append(r->toJson());
+        if (filtered && parameters.output_enabled(Parameters::FILTERED_ALIGNMENTS))
+            for (auto const& rf : *filtered)
+            {
+                Json r = rf.first->toJson();
+                r["error"] = rf.second;
+                alignments.append(std::move(r));
+            }
+        if (parameters.output_enabled(Parameters::ALIGNMENTS))
+            for (auto const& r : *reads)
+                alignments.append(r->toJson());
         out["alignments"] = std::move(alignments);
+        if (filtered && parameters.output_enabled(Parameters::FILTERED_ALIGNMENTS))
+        {
+            common::ReadBuffer all;
+            all.reserve(filtered->size() + reads->size());
+            for (auto& rf : *filtered)
+                all.emplace_back(std::move(rf.first));
+            if (parameters.output_enabled(Parameters::ALIGNMENTS))
+                for (auto& r : *reads)
+                    all.emplace_back(std::move(r));
+            reads->swap(all);
+            filtered->clear();
+        }
     }
     return out;
 }
@@ -351,6 +383,7 @@ BatchParameters batchParameters(Parameters const& parameters)
     bp.threads = parameters.threads;
     bp.device = parameters.device;
     bp.validate_alignments = parameters.validate_alignments;
+    bp.keep_filtered = parameters.output_enabled(Parameters::FILTERED_ALIGNMENTS);  // (object sites only: packed ones keep no records)
     bp.node_counts = parameters.output_enabled(Parameters::NODE_READ_COUNTS);
     bp.sequence_counts = parameters.output_enabled(Parameters::PATH_READ_COUNTS);
     return bp;
@@ -380,7 +413,7 @@ std::vector<Json> alignAndDisambiguateBatch(Parameters const& parameters, std::v
         view.reserve(sites[s].reads->size());
         for (auto const& r : *sites[s].reads)
             view.push_back(r.get());
-        documents[s] = countDocument(parameters, d, batcher.counts(s), viewsOfReads(*d.graph, view), reads_in[s], sites[s].reads);
+        documents[s] = countDocument(parameters, d, batcher.counts(s), viewsOfReads(*d.graph, view), reads_in[s], sites[s].reads, &batcher.filtered(s));
         noteSiteError(documents[s], d, batcher.error(s));
     });
     if (parameters.timings)
@@ -494,7 +527,8 @@ std::vector<Json> countGraphs(
     if (!bam_index_paths.empty() && bam_index_paths.size() != bam_paths.size())
         throw std::runtime_error("ERROR: the number of BAM index files differs from the number of BAM files");
     auto index_of = [&](size_t b) { return bam_index_paths.empty() ? std::string() : bam_index_paths[b]; };
-    const bool packed = bam_paths.size() == 1 && !parameters.output_enabled(Parameters::ALIGNMENTS) && !parameters.validate_alignments;
+    const bool packed = bam_paths.size() == 1 && !parameters.output_enabled(Parameters::ALIGNMENTS)
+        && !parameters.output_enabled(Parameters::FILTERED_ALIGNMENTS) && !parameters.validate_alignments;
     const common::FastaFile fasta(reference_path);
     std::vector<std::unique_ptr<common::BamReader>> keep_alive;  // also shares the parsed header / index with the workers
     for (size_t b = 0; b < bam_paths.size(); ++b)
@@ -626,6 +660,13 @@ namespace grmpy
 {
 namespace
 {
+// -A given and the folder is there (AlignSamples.cpp:120-121: a missing folder silently means "no")
+bool writesAlignments(Parameters const& p)
+{
+    struct stat st;
+    return !p.alignment_output_folder.empty() && stat(p.alignment_output_folder.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+
 paragraph::Parameters siteParameters(Parameters const& p)
 {
     paragraph::Parameters sp;
@@ -642,7 +683,43 @@ paragraph::Parameters siteParameters(Parameters const& p)
         | paragraph::Parameters::PATH_READ_COUNTS | paragraph::Parameters::DETAILED_READ_COUNTS;
     if (p.output_alignments)
         sp.output_options_ |= paragraph::Parameters::ALIGNMENTS;
+    if (writesAlignments(p))
+        sp.output_options_ |= paragraph::Parameters::ALIGNMENTS | paragraph::Parameters::FILTERED_ALIGNMENTS;
     return sp;
+}
+
+// writeAlignments (AlignSamples.cpp:57-109): the sample's whole count document, gzip-compressed, named after sample, graph and
+// target regions with everything outside [A-Za-z0-9.-] turned into '_'
+void writeAlignmentFile(
+    Parameters const& parameters, Json& doc, paragraph::GraphDescription const& d, std::string const& reference_path,
+    genotyping::SampleInfo const& sample)
+{
+    doc["sample"] = sample.sample_name();
+    doc["reference"] = reference_path;
+    auto safe = [](std::string text) {
+        for (char& c : text)
+            if (!(std::isalnum((unsigned char)c) || c == '.' || c == '-'))
+                c = '_';
+        return text;
+    };
+    std::string regions;
+    for (common::Region const& r : d.target_regions)
+        regions += (regions.empty() ? "" : "_") + std::string(r);
+    std::string graph_id = "00000000-0000-0000-0000-000000000000";  // (the original: a default-constructed boost uuid)
+    if (d.description.isMember("ID"))
+        graph_id = d.description["ID"].asString();
+    else if (d.description.isMember("model_name"))
+        graph_id = d.description["model_name"].asString();
+    const std::string path
+        = parameters.alignment_output_folder + "/" + safe(sample.sample_name()) + "-" + safe(graph_id) + "-" + safe(regions) + ".json.gz";
+    const std::string text = doc.dump(1) + "\n";
+    gzFile f = gzopen(path.c_str(), "wb");
+    if (!f)
+        throw std::runtime_error("ERROR: Failed to open output file '" + path + "'. Error: '" + std::strerror(errno) + "'");
+    const int n = gzwrite(f, text.data(), (unsigned)text.size());
+    const int rc = gzclose(f);
+    if (n != (int)text.size() || rc != Z_OK)
+        throw std::runtime_error("ERROR: Failed to write output file '" + path + "'");
 }
 
 // what alignSingleSample keeps of a count document (AlignSamples.cpp:160-171)
@@ -840,6 +917,9 @@ void alignSingleSample(
     common::ReadBuffer reads;
     common::extractReads(reader, d.target_regions, parameters.max_reads, (unsigned)d.longest_alt_insertion, reads);
     Json doc = paragraph::alignAndDisambiguate(siteParameters(parameters), d, reads);
+    doc["bam"] = sample.filename();
+    if (writesAlignments(parameters))
+        writeAlignmentFile(parameters, doc, d, reference_path, sample);
     finishSampleDocument(doc, sample.filename(), parameters.output_alignments);
     sample.set_alignment_data(doc);
 }
@@ -890,7 +970,7 @@ std::unique_ptr<Chunk> prepareChunk(
     chunk->load_s = t_extract - t_load;
 
     // tasks in sample-major order so a worker mostly stays on one BAM; every worker owns its readers
-    const bool packed = parameters.packed_reads && !parameters.output_alignments;
+    const bool packed = parameters.packed_reads && !parameters.output_alignments && !writesAlignments(parameters);
     if (packed)
         chunk->packed.resize(n_graphs * n_samples);
     else
@@ -1012,7 +1092,8 @@ std::vector<Json> genotypeGraphs(
         };
         paragraph::Timings mine;
         paragraph::Parameters site_parameters = siteParameters(parameters);
-        if (!parameters.output_alignments)
+        const bool write_alignments = writesAlignments(parameters);
+        if (!parameters.output_alignments && !write_alignments)
         {
             // the count documents of this workflow are read by the genotyper and dropped: only the table it reads, no copy of
             // the description (node / sequence tables and the per-family breakdown are what `paragraph` writes, not grmpy)
@@ -1051,7 +1132,14 @@ std::vector<Json> genotypeGraphs(
                     documents = paragraph::alignAndDisambiguateBatch(site_parameters, sites);
                 }
                 for (size_t i = 0; i < documents.size(); ++i)
+                {
+                    if (write_alignments)
+                    {
+                        documents[i]["bam"] = samples[i % n_samples].filename();
+                        writeAlignmentFile(parameters, documents[i], f.chunk->graphs[i / n_samples], reference_path, samples[i % n_samples]);
+                    }
                     finishSampleDocument(documents[i], samples[i % n_samples].filename(), parameters.output_alignments);
+                }
                 phase(f.c, "batch+documents");
 
                 const double t_genotype = now();

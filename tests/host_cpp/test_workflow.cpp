@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <fstream>
 #include <iostream>
+#include <map>
 
 #include "common/BamReader.hh"
 #include "common/ReadExtraction.hh"
@@ -127,9 +128,25 @@ static void testMultiparagraph(std::string const& dir)
             object_sites[i].reads = &objects[i];
         }
         const std::vector<Json> from_packed = paragraph::alignAndDisambiguateBatch(pp, packed_sites);
-        const std::vector<Json> from_objects = paragraph::alignAndDisambiguateBatch(pp, object_sites);
+        std::vector<Json> from_objects = paragraph::alignAndDisambiguateBatch(pp, object_sites);
         for (size_t i = 0; i < expected.size(); ++i)
         {
+            // FILTERED_ALIGNMENTS: the object form also lists the reads the filter chain rejected, each with the filter's message
+            // (Disambiguation.cpp:183-203) -- as many of each kind as the tallies say; the packed form keeps no records
+            {
+                const Json rejected = from_objects[i]["alignments"];
+                from_objects[i].removeMember("alignments");
+                std::map<std::string, uint64_t> by_filter;
+                for (Json const& r : rejected.elements())
+                {
+                    CHECK(r.isMember("error") && r["graphMappingStatus"].asString() == "BAD_ALIGN" && !r.isMember("graphNodesSupported"));
+                    ++by_filter["read_filter_" + r["error"].asString()];
+                }
+                Json const& st = from_objects[i]["alignment_statistics"];
+                for (const char* key : { "read_filter_bad_align", "read_filter_nonuniq" })
+                    CHECK(by_filter[key] == (st.isMember(key) ? (uint64_t)st[key].asUInt64() : 0));
+                CHECK(objects[i].size() >= rejected.size());  // (the read buffer holds the rejected reads too, as the original's does)
+            }
             CHECK(from_packed[i] == from_objects[i]);
             if (from_packed[i] != from_objects[i])
                 compareObject("packed-vs-objects[" + std::to_string(i) + "]", from_objects[i], from_packed[i]);

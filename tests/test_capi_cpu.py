@@ -122,8 +122,8 @@ def test_grmpy_command_line_parsing(tmp_path):
     assert rc == 1 and "unrecognised option '--colour'" in out
     rc, out = run("-r", fasta, "-g", graph, "-m", "x", "--path-sequence-matching", "maybe")
     assert rc == 1 and "is invalid" in out
-    rc, out = run("-r", fasta, "-g", graph, "-m", "x", "-A", "dir")
-    assert rc == 1 and "not available" in out
+    rc, out = run("-r", fasta, "-g", graph, "-m", "x", "--infer-read-haplotypes")
+    assert rc == 1 and "not available" in out  # (phasing output is outside this build; -A is taken: tests/test_gpu_workflow.py)
     manifest = tmp_path / "manifest with space.txt"
     manifest.write_text("id\tpath\tdepth\tread length\nS1\t%s\t44.2\t150\n" % os.path.join(sites, "chrX_graph_typing.bam"))
     response = tmp_path / "response.txt"

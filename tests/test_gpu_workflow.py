@@ -640,3 +640,62 @@ def test_paragraph_validate_alignments(tmp_path):
     unaligned = int(lines[1].split("\t")[-1])
     repeats = int(lines[2].split("\t")[-1])
     assert unaligned >= 0 and repeats >= 0 and unaligned + repeats + aligned >= sum(1 for d in docs) * 10
+
+
+def test_grmpy_alignment_output_folder(tmp_path):
+    """grmpy -A <folder> (lib/grmpy/AlignSamples.cpp:57-109, 120-171): one <sample>-<graph ID>-<regions>.json.gz per (sample,
+    graph) holding the sample's count document with "sample", "reference", "bam" and the per-read records -- the reads the
+    filter chain rejected first, each with the filter's message under "error", then the kept ones; the folder also switches
+    the filter tallies on; the genotypes are those of a run without -A; a folder that does not exist means "no files"."""
+    import glob
+    import gzip
+    import json
+    from paragraph_amd import build
+    if not os.path.exists(build.GRMPY_BIN) or not os.path.exists(build.PARAGRAPH_BIN):
+        build.build_host()
+    sites = os.path.join(ROOT, "tests", "golden", "sites", "chrX")
+    bam = os.path.join(sites, "chrX_graph_typing.bam")
+    fasta = os.path.join(sites, "chrX_graph_typing.fa")
+    manifest = tmp_path / "manifest.txt"
+    manifest.write_text("#id\tpath\tdepth\tread length\tdepth sd\tsex\nSAMPLE 1\t%s\t44.2\t150\t20\tmale\nSAMPLE2\t%s\t44.2\t150\t20\tfemale\n"
+                        % (bam, bam))
+    graph = os.path.join(sites, "chrX_graph_typing.2sample.json")
+    common = [build.GRMPY_BIN, "-r", fasta, "-m", str(manifest), "-g", graph, "-G", os.path.join(sites, "param.json"), "-t", "4"]
+    plain = subprocess.run(common, capture_output=True, text=True, timeout=300)
+    assert plain.returncode == 0, plain.stderr
+    folder = tmp_path / "alignments"
+    folder.mkdir()
+    r = subprocess.run(common + ["-A", str(folder)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    want, got = json.loads(plain.stdout), json.loads(r.stdout)
+    for s in ("SAMPLE 1", "SAMPLE2"):
+        assert got["samples"][s]["gt"] == want["samples"][s]["gt"]
+    description = json.load(open(graph))
+    regions = "_".join(description["target_regions"])
+    safe = lambda t: "".join(c if (c.isalnum() and c.isascii()) or c in ".-" else "_" for c in t)  # noqa: E731
+    files = sorted(os.path.basename(f) for f in glob.glob(str(folder / "*")))
+    assert files == sorted("%s-%s-%s.json.gz" % (safe(s), safe(description["ID"]), safe(regions)) for s in ("SAMPLE 1", "SAMPLE2")), files
+    # the same site through `paragraph -a -A`: the same records
+    p = subprocess.run([build.PARAGRAPH_BIN, "-r", fasta, "-b", bam, "-g", graph, "-a", "-A", "--path-sequence-matching", "0", "--threads", "2"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    pdoc = json.loads(p.stdout)
+    for f, sample in zip(files, ("SAMPLE2", "SAMPLE 1") if files[0].startswith("SAMPLE2") else ("SAMPLE 1", "SAMPLE2")):
+        doc = json.loads(gzip.open(folder / f, "rt").read())
+        assert doc["sample"] == sample and doc["reference"] == fasta and doc["bam"] == bam and doc["ID"] == description["ID"]
+        al = doc["alignments"]
+        rejected = [a for a in al if "error" in a]
+        kept = [a for a in al if "error" not in a]
+        assert rejected and kept and al[:len(rejected)] == rejected  # the rejected ones come first
+        assert all(a["error"] in ("bad_align", "nonuniq") for a in rejected)
+        assert all(a.get("graphMappingStatus") == "BAD_ALIGN" and "graphNodesSupported" not in a for a in rejected)
+        assert all(a.get("graphMappingStatus") == "MAPPED" and "graphCigar" in a for a in kept)
+        stats = doc["alignment_statistics"]
+        assert stats.get("read_filter_bad_align", 0) == sum(a["error"] == "bad_align" for a in rejected)
+        assert stats.get("read_filter_nonuniq", 0) == sum(a["error"] == "nonuniq" for a in rejected)
+        assert doc["read_counts_by_edge"] and "read_counts_by_sequence" in doc
+        assert al == pdoc["alignments"] and doc["read_counts_by_edge"] == pdoc["read_counts_by_edge"]
+    # without -A the filtered records and tallies are off
+    assert "read_filter_bad_align" not in json.dumps(want)
+    missing = subprocess.run(common + ["-A", str(tmp_path / "not_there")], capture_output=True, text=True, timeout=300)
+    assert missing.returncode == 0 and json.loads(missing.stdout) == want and not (tmp_path / "not_there").exists()

@@ -534,8 +534,34 @@ template <int MODE> static std::vector<uint32_t> rec_state(int iters)
     return h;
 }
 
+// `valu_rate occupancy [iters]`: the fill's recurrence (as pg_fill.hip has it: integer additions, program order) at EVERY
+// occupancy from 1 to 8 wavefronts per SIMD.  A workgroup is 256 threads = one wavefront per SIMD, and asks for so much LDS that
+// exactly N of them fit a CU (160 KB): N wavefronts per SIMD, evenly.  What a fifth / sixth wavefront would buy the fill's
+// arithmetic if registers and LDS let it in (-> profiles/rNN_fill_recurrence_occupancy.json).
+static void occupancy_sweep(int iters)
+{
+    printf("{\"what\": \"fill recurrence, C = 10 rows x 2 strands, 60 instructions per column (30 v_add_u32, 20 v_pk_maximum3_f16, 10 v_pk_max_u16), "
+           "N workgroups of 256 threads per CU = N wavefronts per SIMD; ns_per_wave_inst_per_simd x N x 60 = ns a SIMD spends on one column of all its wavefronts\", "
+           "\"iters\": %d,\n \"rows\": [", iters);
+    for (int n = 1; n <= 8; ++n)
+    {
+        // n blocks fit, n + 1 do not: lds in (160 KB / (n + 1), 160 KB / n]
+        const int lds = n == 1 ? 96 * 1024 : (160 * 1024 / n) & ~255;
+        const Place p = { n, 256, lds, n };
+        measure([&](int blocks, const Place& q) { hipLaunchKernelGGL((k_recurrence<3>), dim3(blocks), dim3(q.threads), q.lds, 0, g_out, g_in, iters, g_tm, (uint32_t*)nullptr); },
+                (const void*)k_recurrence<3>, "fill_recurrence_C10_integer_adds", 0, 120, iters, p);
+    }
+    printf("\n ]}\n");
+}
+
 int main(int argc, char** argv)
 {
+    const bool occupancy = argc > 1 && !strcmp(argv[1], "occupancy");
+    if (occupancy)
+    {
+        --argc;
+        ++argv;
+    }
     const int iters = argc > 1 ? atoi(argv[1]) : 3000;
     int dev = 0;
     CK(hipGetDevice(&dev));
@@ -552,6 +578,11 @@ int main(int argc, char** argv)
     for (int i = 0; i < 4096; ++i)
         h[i] = 0x3c003c00u + ((uint32_t)i * 2654435761u >> 20);
     CK(hipMemcpy(g_in, h.data(), 4096 * 4, hipMemcpyHostToDevice));
+    if (occupancy)
+    {
+        occupancy_sweep(iters / 2);
+        return 0;
+    }
     printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"compute_units\": %d, \"simds\": %d, \"clock_rate_khz_reported\": %d, "
            "\"wall_clock_rate_khz\": %d, \"iters\": %d,\n \"what\": \"per wave64 instruction: ns of one SIMD's time (host events over the launch / "
            "wave-instructions per SIMD) and s_memtime ticks of the issuing wave; chains = independent dependency chains per wavefront "

@@ -84,12 +84,12 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream-batches", type=int, default=16,
                     help="batches of the PCIe-inclusive streaming leg (0 = skip; reported beside the headline value)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_r05.json"),
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_r06.json"),
                     help="PMC-derived HBM bytes per fill launch (written by tools/pmc_traffic.py); used only when the kernel "
                          "sources it was collected on are the ones of this build (kernel_source_sha)")
-    ap.add_argument("--sq-json", default=os.path.join(ROOT, "profiles", "r05_sq_counters.json"),
+    ap.add_argument("--sq-json", default=os.path.join(ROOT, "profiles", "r06_sq_counters.json"),
                     help="SQ counters of one fill launch (tools/sq_collect.sh + tools/sq_summary.py), same rule")
-    ap.add_argument("--isa-mix-json", default=os.path.join(ROOT, "profiles", "r05_fill_isa_mix.json"),
+    ap.add_argument("--isa-mix-json", default=os.path.join(ROOT, "profiles", "r06_fill_isa_mix.json"),
                     help="static VALU mix of a step by issue class (tools/isa_mix.py), same rule")
     ap.add_argument("--valu-rate-json", default=os.path.join(ROOT, "profiles", "r04_valu_rate.json"),
                     help="measured cycles per wave64 instruction (tools/ubench/valu_rate)")
@@ -179,6 +179,23 @@ def _cpu_quota():
         return None if quota == "max" else float(quota) / float(period)
     except (OSError, ValueError):
         return None
+
+
+def _cpu_throttle():
+    """(periods, throttled periods, throttled microseconds) of this process's cgroup so far (cpu.stat of cgroup v2), or None: a
+    leg that wants more CPU than the quota in some 100 ms period is stopped for the rest of it -- the e2e leg reports how often."""
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as f:
+            kv = dict(line.split() for line in f if len(line.split()) == 2)
+        return int(kv["nr_periods"]), int(kv["nr_throttled"]), int(kv["throttled_usec"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def _throttle_delta(a, b):
+    if a is None or b is None:
+        return None
+    return {"cgroup_periods": b[0] - a[0], "throttled_periods": b[1] - a[1], "throttled_ms": (b[2] - a[2]) / 1e3}
 
 
 def _effective_cpus():
@@ -998,11 +1015,13 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
     one_pass()  # warm-up: the host library's own device context, its workspace, the file cache
     barrier()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    th0 = _cpu_throttle()
     t0 = time.perf_counter()
     for _ in range(args.e2e_steps):
         one_pass()
     barrier()
     elapsed_mine = time.perf_counter() - t0
+    th1 = _cpu_throttle()
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     elapsed = env["max_over_ranks"](elapsed_mine)
     cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
@@ -1019,6 +1038,7 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
         workflow.genotype_graphs_to_file(e2e["reference"], e2e["manifest"], graphs, out_file, **options_path)
         barrier()
         rp0 = resource.getrusage(resource.RUSAGE_SELF)
+        thp0 = _cpu_throttle()
         t0 = time.perf_counter()
         path_steps = max(2, args.e2e_steps)
         for _ in range(path_steps):
@@ -1026,6 +1046,7 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
         barrier()
         t_path = env["max_over_ranks"](time.perf_counter() - t0)
         rp1 = resource.getrusage(resource.RUSAGE_SELF)
+        thp1 = _cpu_throttle()
         cpu_path = (rp1.ru_utime - rp0.ru_utime) + (rp1.ru_stime - rp0.ru_stime)
         with open(out_file) as f:
             docs_path = json.load(f)
@@ -1034,6 +1055,7 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
         cascade = {"sites_genotyped_per_s": n * path_steps / t_path, "ms_per_step": t_path / path_steps * 1e3, "steps": path_steps,
                    "cpu_us_per_site_sample_this_rank": cpu_path / path_steps / max(1, len(mine)) * 1e6,
                    "genotypes_equal_the_gssw_only_run_on_this_rank": same_gt, "sites_on_this_rank": len(mine),
+                   "cpu_throttling_this_rank": _throttle_delta(thp0, thp1),
                    "note": "path_sequence_matching = true (the `paragraph` tool's default): reads the exact path matcher maps and the "
                            "filters accept keep that alignment, so counts may differ from the gssw-only run by design"}
     # ... and with all four stages of the cascade on (path -> k-mer -> klib -> gssw; `paragraph --kmer-sequence-matching
@@ -1106,6 +1128,7 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
            "sites_genotyped_per_s": n * steps / elapsed, "reads_in_bam_per_s": e2e["reads"] * steps / elapsed, "scaling": "strong",
            "host_threads": threads * world, "host_threads_per_rank": threads, "cpu_quota_cores": _cpu_quota(), "host_cpus": ncpu,
            "cpu_s_per_pass": cpu_all / steps, "cpu_us_per_site_sample": cpu_all / steps / n * 1e6,
+           "cpu_throttling_rank0": _throttle_delta(th0, th1),
            "cpu_note": "user + system time of the rank processes over the timed passes (getrusage): every host thread of the workflow, "
                        "the HIP runtime's threads included",
            "genotypes_equal_truth": int(table[total]), "documents_with_error": int(table[total + 1]),

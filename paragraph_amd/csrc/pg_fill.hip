@@ -290,8 +290,10 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     }
     // the H trace of a PAIR of steps (even, odd) is [TRACE_DW][64 lanes][2 steps] dwords behind a wave-uniform base that advances
     // by two steps every two steps: the dwords of the even step wait in registers for those of the odd one and leave as one
-    // global_store_dwordx2 -- half the store instructions, and the traceback, which walks diagonals (one step per cell), finds
-    // four cells of its path in one 8-byte piece, i.e. half as many 128-byte lines per read (profiles/r06_trace_pairs_ab.jsonl).
+    // global_store_dwordx2 -- half the store instructions.  At C = 10 that changes nothing (the step is bound by VALU issue:
+    // 8.93 / 8.93 ms per 200 k reads), the variants with more rows per lane gain (C = 12, 180 bp reads: +4 %; C = 16, 250 bp:
+    // +2.8 %; profiles/r06_trace_pairs_ab.jsonl, r06_trace_pairs_readlen_ab.jsonl).  The traceback reads as many lines as before
+    // (12.2 KB per read, profiles/traffic_r06.json): its diagonal leaves a dword for (step - 2, dword - 1), never for the pair's other half.
     // the stores take the scalar-base form (SGPR pair + 32-bit lane offset + immediate), no per-step vector address arithmetic
     // (readfirstlane: the base is uniform by construction; this makes it so for the compiler, which must keep it in SGPRs;
     // the builtin returns a signed int: without the casts the low half would be sign-extended over the high one)

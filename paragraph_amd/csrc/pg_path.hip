@@ -1417,10 +1417,10 @@ const char* pg_path_index_error_text(uint32_t word)
 
 pg_status pg_path_index_check(pg_ctx* ctx, const pg_graphs* G)
 {
-    if (!G || !G->path_index || !G->path_index->d_error)
-        return PG_OK;
+    // (the callers' own copies are on the copy stream: the wait is theirs too, index or no index)
     uint32_t word = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&word, G->path_index->d_error, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream_copy));
+    if (G && G->path_index && G->path_index->d_error)
+        HIP_TRY(ctx, hipMemcpyAsync(&word, G->path_index->d_error, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream_copy));
     HIP_TRY(ctx, pg_stream_wait(ctx->device, ctx->stream_copy));
     if (word)
         return pg_fail(ctx, word & 1u ? PG_ERR_UNSUPPORTED : PG_ERR_HIP, pg_path_index_error_text(word));

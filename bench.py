@@ -103,6 +103,10 @@ def parse_args():
     ap.add_argument("--sites-verify", type=int, default=500,
                     help="config3 leg: sites of rank 0's shard whose alignments, per-read outcome and count tables are compared "
                          "with the reference's code in a CPU-leg process (0 = skip); exit status 3 on a mismatch")
+    ap.add_argument("--exact-shortcut-steps", type=int, default=3,
+                    help="timed steps of the reported-only leg `exact_shortcut` (the headline workload with pg_batch_retire_exact_matches "
+                         "in front of the gssw stage: reads whose alignRead record one exact full-length match forces skip their "
+                         "fills; records and count table compared with the plain step's); 0 = leave it out")
     ap.add_argument("--e2e-steps", type=int, default=3,
                     help="timed passes of the BAM -> genotypes leg (0 = skip): every pass takes ALL sites of the e2e data set from the "
                          "BAM file to genotype documents written as JSON (with N ranks: rank r takes sites r, r + N, ...)")
@@ -1058,6 +1062,33 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
                    "cpu_throttling_this_rank": _throttle_delta(thp0, thp1),
                    "note": "path_sequence_matching = true (the `paragraph` tool's default): reads the exact path matcher maps and the "
                            "filters accept keep that alignment, so counts may differ from the gssw-only run by design"}
+    # grmpy's own cascade (gssw only) with the exact shortcut in front of it (BatchParameters::exact_match_shortcut,
+    # pg_batch_retire_exact_matches): the documents must be the gssw-only run's, byte for byte of their JSON values
+    shortcut = None
+    if args.e2e_steps > 0:
+        options_sc = dict(options, exact_match_shortcut=True)
+        workflow.genotype_graphs_to_file(e2e["reference"], e2e["manifest"], graphs, out_file, **options_sc)
+        barrier()
+        rs0 = resource.getrusage(resource.RUSAGE_SELF)
+        ths0 = _cpu_throttle()
+        t0 = time.perf_counter()
+        sc_steps = max(2, args.e2e_steps)
+        for _ in range(sc_steps):
+            workflow.genotype_graphs_to_file(e2e["reference"], e2e["manifest"], graphs, out_file, **options_sc)
+        barrier()
+        t_sc = env["max_over_ranks"](time.perf_counter() - t0)
+        rs1 = resource.getrusage(resource.RUSAGE_SELF)
+        ths1 = _cpu_throttle()
+        with open(out_file) as f:
+            docs_sc = json.load(f)
+        os.unlink(out_file)
+        shortcut = {"sites_genotyped_per_s": n * sc_steps / t_sc, "ms_per_step": t_sc / sc_steps * 1e3, "steps": sc_steps,
+                    "cpu_us_per_site_sample_this_rank": ((rs1.ru_utime - rs0.ru_utime) + (rs1.ru_stime - rs0.ru_stime)) / sc_steps / max(1, len(mine)) * 1e6,
+                    "documents_equal_the_gssw_only_run_on_this_rank": sum(1 for a, b2 in zip(docs, docs_sc) if a == b2),
+                    "sites_on_this_rank": len(mine), "cpu_throttling_this_rank": _throttle_delta(ths0, ths1),
+                    "note": "exact_match_shortcut = true: reads whose alignRead record one exact full-length match forces skip their "
+                            "four fills (pg_batch_retire_exact_matches); every document -- counts, statistics, genotypes -- must equal "
+                            "the gssw-only run's"}
     # ... and with all four stages of the cascade on (path -> k-mer -> klib -> gssw; `paragraph --kmer-sequence-matching
     # --klib-sequence-matching`, both default OFF in the reference's tools): two passes, reported only -- a failure here is written
     # into the line, it does not fail the run
@@ -1136,7 +1167,8 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
                           "reduced_equals_own_on_own_sites": bool(mine_kept),
                           "note": "one slot per edge of every site (fragment counts of the breakpoint edges), all-reduced over the ranks "
                                   "AFTER the timed passes: a site's genotype needs only its own counts, the sum only collects them"},
-           "data_make_s": e2e["make_s"], "per_rank": per_rank, "with_path_matching": cascade, "with_all_four_stages": all_four}
+           "data_make_s": e2e["make_s"], "per_rank": per_rank, "with_path_matching": cascade, "with_exact_shortcut": shortcut,
+           "with_all_four_stages": all_four}
     # what the host allows: with C usable cores and c CPU-seconds per (site, sample) no more than C / c sites per second leave the
     # node however many devices it has -- the first thing to read off an N-GPU curve of this leg
     cores = float(out["cpu_quota_cores"] or ncpu)
@@ -1365,6 +1397,9 @@ def main_rank(args):
             rc = 3
         if out.get("e2e") and out["e2e"]["mismatches"]:
             rc = 3
+        sc = out.get("exact_shortcut")
+        if sc and (sc["records_differing_from_the_plain_step"] or not sc["cigar_elements_equal"] or not sc["count_table_equal"]):
+            rc = 3
         if out.get("config5") and out["config5"].get("verified") and out["config5"]["verified"]["mismatches"]:
             rc = 3
         if out.get("sites") and out["sites"].get("reduce_equals_single") is False:
@@ -1466,6 +1501,65 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
                       "note": "`value` is measured WITH the all-reduce in every step (at N = 1 through a world-size-1 RCCL "
                               "communicator = the code path of N = 8); `without` = the same steps right after, no collective"}
         log("plain region %.3fs" % elapsed_plain)
+    # Reported only, never `value`: the same workload with the EXACT shortcut in front of the gssw stage
+    # (pg_batch_retire_exact_matches, include/paragraph_amd.h).  The path kernel runs over every read; a read whose
+    # alignRead(AF_ALL) record its one exact full-length match forces keeps that record and skips its four fills, every other
+    # read is aligned as in the plain step.  Compared with the plain step's output on every read: all fields of the reference's
+    # Read (position, score, MAPQ, uniqueness, strand, CIGAR elements) and the whole count table.
+    shortcut = None
+    if args.exact_shortcut_steps > 0 and L <= 250 and world == 1:  # (N = 1 only, like the streaming leg: `tab` is the reduced table at N > 1)
+        t0 = time.perf_counter()
+        graphs.build_path_index(32)
+        t_index = time.perf_counter() - t0
+
+        def step_shortcut():
+            k = step_no[0] & 1
+            b, t = batches[k], tables[k]
+            step_no[0] += 1
+            ctx.counts_zero(t.data_ptr(), n_counters)
+            b.set_active(None)
+            b.path_align(fetch_flags=False)
+            b.retire_exact_matches()
+            b.align(capi.AF_CIGAR | capi.AF_BOTH_STRANDS | capi.AF_REVERSE_GRAPH | capi.AF_KEEP_RESULTS)
+            b.count(remove_nonuniq=True, bad_align_frac=0.8, d_counts=t.data_ptr())
+
+        for _ in range(2):
+            step_shortcut()
+        env["barrier"]()
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.exact_shortcut_steps):
+            step_shortcut()
+        env["barrier"]()
+        t_sc = env["max_over_ranks"](time.perf_counter() - t0)
+        tim_sc = ctx.timing()
+        ctx.timing_enable(False)
+        res2, ops2 = batches[(step_no[0] - 1) & 1].download()
+        tab2 = tables[(step_no[0] - 1) & 1].cpu().numpy().view(np.uint32)
+
+        def flat_ops(r, o):  # every read's CIGAR elements, read after read (ops_off is an allocation order, not content)
+            n_ops = r["n_ops"].astype(np.int64)
+            first = np.cumsum(n_ops) - n_ops
+            idx = np.repeat(r["ops_off"].astype(np.int64) - first, n_ops) + np.arange(int(n_ops.sum()), dtype=np.int64)
+            return o[idx]
+
+        skipped = (res2["strand_score"] == -1).any(axis=1)
+        fields = ("graph_pos", "score", "mapq", "is_unique", "returned_reverse", "n_ops", "clipped", "status")
+        bad = np.zeros(len(res), dtype=bool)
+        for f in fields:
+            bad |= res[f] != res2[f]
+        bad |= ~skipped & ((res["multi_mask"] != res2["multi_mask"]) | (res["strand_score"] != res2["strand_score"]).any(axis=1))
+        same_cigars = bool(np.array_equal(flat_ops(res, ops), flat_ops(res2, ops2))) if not bad.any() else False
+        shortcut = {"reads_per_s": args.reads * world * args.exact_shortcut_steps / t_sc, "ms_per_step": t_sc / args.exact_shortcut_steps * 1e3,
+                    "steps": args.exact_shortcut_steps, "vs_value": (args.reads * world * args.exact_shortcut_steps / t_sc) / (args.reads * world * args.steps / elapsed),
+                    "reads_that_skipped_their_fills": int(skipped.sum()), "skipped_frac": float(skipped.mean()),
+                    "fill_ms_per_step": tim_sc["fill_ms"] / args.exact_shortcut_steps, "path_index_build_s": t_index,
+                    "records_differing_from_the_plain_step": int(bad.sum()), "cigar_elements_equal": same_cigars,
+                    "count_table_equal": bool(np.array_equal(tab, tab2)),
+                    "note": "reported only (`value` is the plain step: four fills for every read).  Synthetic reads carry 1 % substitutions per base: "
+                            "0.99^150 = 22 % are exact; the index build (host) is outside the timed steps, as the graph upload is"}
+        log("exact shortcut leg: %.3fs, %d reads skipped their fills, %d records differ" % (t_sc, int(skipped.sum()), int(bad.sum())))
     # every rank's own view of the timed region: a straggler GPU shows here, not in the max
     mine = {"rank": rank, "device": env["device"].index, "fill_ms_per_launch": tim["fill_ms"] / max(1, tim["fill_launches"]),
             "fill_launches": int(tim["fill_launches"]), "fill_ms": tim["fill_ms"], "trace_ms": tim["trace_ms"]}
@@ -1592,6 +1686,8 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
                            "over %d rank(s)" % world},
         "dist": dist_info,
     }
+    if shortcut:
+        out["exact_shortcut"] = shortcut
     if collective:
         out["dist"]["collective_ab"] = collective
     out["dist"]["per_rank"] = per_rank

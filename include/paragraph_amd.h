@@ -361,8 +361,29 @@ pg_status pg_graphs_build_path_index(pg_ctx* ctx, pg_graphs* graphs, uint32_t km
  * BAM strand, PathAligner.cpp:121-129) and ops.  Resets the batch's results/ops.  Asynchronous. */
 pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* batch);
 /* flags[i] of the LAST seed stage run: bit0 = MAPPED, bit1 = anchored (path stage: a unique k-mer was found),
- * bit2 = BAD_ALIGN (k-mer stage); synchronises */
+ * bit2 = BAD_ALIGN (k-mer stage), bit3 (path stage) = PG_PATH_FLAG_FWD_ABSENT: some k-mer of the read as given is in no
+ * path of the graph; synchronises */
 pg_status pg_batch_download_path_flags(pg_ctx* ctx, pg_batch* batch, uint8_t* flags);
+#define PG_PATH_FLAG_FWD_ABSENT 8u
+/* An EXACT shortcut for the gssw stage (GraphAligner::alignRead, src/c++/lib/grm/GraphAligner.cpp:308-404), for callers
+ * that run gssw WITHOUT the PathAligner stage (grmpy's default cascade): after pg_batch_path_align, a read leaves the
+ * following pg_batch_align -- with the record alignRead(AF_ALL) itself would have written -- when that record is forced:
+ *   - the path stage found exactly ONE full-length exact match over both strands (a k-mer with one path in the graph,
+ *     extended without a choice at any node end, PathOperations.cpp:117-271): every walk of the graph that spells the
+ *     read holds that k-mer's one path and leaves it the same way, so one cell of one fill reaches score L = the read's
+ *     length, all four multi-node flags of that strand are clear, and the traceback from that cell is the walk, all 'M';
+ *   - the match is on the strand as given -- then alignRead returns it whatever the other strand scores
+ *     (GraphAligner.cpp:340-356: unique beats non-unique, equal uniqueness goes to the better score, ties to the
+ *     forward strand) -- or it is on the reverse complement AND some k-mer of the read as given is in no path of the
+ *     graph (PG_PATH_FLAG_FWD_ABSENT), i.e. the forward strand scores below L;
+ *   - the read holds A / C / G / T only (an N scores 0 in gssw where the path stage compares characters) and is at most
+ *     250 bases long (beyond that gssw redoes the fill in its word mode, whose multi-node test reads bytes).
+ * Such a read's record loses PG_STATUS_PATH_ALIGNER (it IS the gssw record: graph_pos, score = L, mapq 60, unique,
+ * returned_reverse, CIGAR); multi_mask and strand_score only hold what is known (the other strand's fills never ran).
+ * Every other read stays active and is aligned by pg_batch_align(flags | PG_AF_KEEP_RESULTS) as if the path stage had not
+ * run.  On the device, queued behind the path stage, no wait; the work items of pg_batch_align are re-written like
+ * pg_batch_retire_mapped does.  tests/test_gpu_exact.py compares every field with a plain pg_batch_align. */
+pg_status pg_batch_retire_exact_matches(pg_ctx* ctx, pg_batch* batch);
 /* ---------------------------------------------------------------------------------------------------
  * k-mer seed stage (grm::KmerAligner<16>, --kmer-sequence-matching; default OFF in both CLIs)
  * ------------------------------------------------------------------------------------------------- */

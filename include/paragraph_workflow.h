@@ -22,6 +22,8 @@ extern "C" {
  *   genotyping_parameters  grmpy -G document, or NULL / "" for the defaults
  *   options_json           NULL / "" or an object with any of: "threads", "lanes", "sites_per_batch", "max_reads",
  *                          "bad_align_frac", "path_sequence_matching", "kmer_sequence_matching", "klib_sequence_matching",
+ *                          "exact_match_shortcut" (gssw-only cascade: reads whose record one exact full-length match forces skip
+ *                          their fills, pg_batch_retire_exact_matches; same documents),
  *                          "bad_align_uniq_kmer_len", "packed_reads", "devices" (array of HIP device ordinals the
  *                          lanes are spread over, lane l on devices[l % n]; default: the PG_DEVICES environment
  *                          variable -- "0,1,2,3" or "all" -- else device 0; sites are independent, the devices

@@ -49,7 +49,7 @@ EXPORTS = [
     "pg_batch_kmer_align", "pg_graphs_build_klib_index", "pg_batch_klib_align", "pg_graphs_klib_error", "pg_graphs_klib_last_kernels", "pg_graphs_build_filter_index",
     "pg_host_alloc", "pg_host_free", "pg_host_register", "pg_host_unregister", "pg_counts_zero", "pg_ctx_sync_compute",
     "pg_render_cigars", "pg_ctx_native_stream", "pg_ctx_count_record", "pg_ctx_count_wait", "pg_ctx_set_fill_streams",
-    "pg_batch_retire_mapped", "pg_batch_result_sizes", "pg_batch_download_all",
+    "pg_batch_retire_mapped", "pg_batch_result_sizes", "pg_batch_download_all", "pg_batch_retire_exact_matches",
 ]
 
 
@@ -158,6 +158,8 @@ def load_library():
     L.pg_batch_set_active.argtypes = [vp, vp, vp]
     L.pg_batch_retire_mapped.restype = C.c_int32
     L.pg_batch_retire_mapped.argtypes = [vp, vp]
+    L.pg_batch_retire_exact_matches.restype = C.c_int32
+    L.pg_batch_retire_exact_matches.argtypes = [vp, vp]
     L.pg_batch_result_sizes.restype = C.c_int32
     L.pg_batch_result_sizes.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.pg_batch_download_all.restype = C.c_int32
@@ -544,6 +546,11 @@ class Batch:
         """The cascade hand-over decided on the device: after a seed stage + count(), reads the stage mapped and the filter chain
         accepted leave the following stages (pg_batch_retire_mapped); nothing is downloaded."""
         self.ctx._chk(self.ctx.L.pg_batch_retire_mapped(self.ctx.h, self.h))
+
+    def retire_exact_matches(self):
+        """After path_align(): the reads whose gssw record the path stage's one exact full-length match forces keep that record and
+        leave the following align() (pg_batch_retire_exact_matches); nothing is downloaded."""
+        self.ctx._chk(self.ctx.L.pg_batch_retire_exact_matches(self.ctx.h, self.h))
 
     def download_all(self, want_table=True):
         """-> (results, ops, counts table or None, supports, path entries) with one wait for the batch and one for the copies

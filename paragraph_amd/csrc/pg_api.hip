@@ -1801,6 +1801,38 @@ __global__ void pg_retire_kernel(uint32_t n, const uint8_t* __restrict__ stage_f
     }
 }
 
+// pg_batch_retire_exact_matches: the reads whose gssw record the path stage's match forces (include/paragraph_amd.h)
+__global__ void pg_retire_exact_kernel(uint32_t n, const uint8_t* __restrict__ stage_flags, pg_result* results, const uint32_t* __restrict__ base_off,
+                                       const char* __restrict__ bases, uint8_t* active, uint32_t had_mask, uint32_t* group_count, uint32_t n_groups)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_groups)
+        group_count[i] = 0;
+    if (i >= n)
+        return;
+    const bool was = had_mask ? active[i] != 0 : true;
+    bool forced = false;
+    const uint8_t f = stage_flags[i];
+    if (was && (f & 1u))
+    {
+        const pg_result r = results[i];
+        const uint32_t off = base_off[i], L = base_off[i + 1] - off;
+        forced = r.is_unique != 0 && L <= 250u && (r.returned_reverse == 0 || (f & PG_PATH_FLAG_FWD_ABSENT) != 0u);
+        for (uint32_t c = 0; forced && c < L; ++c)
+        {
+            const uint32_t ch = (uint8_t)bases[off + c] & 0xDFu;  // (upper case)
+            forced = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+        }
+        if (forced)
+        {
+            // the record alignRead would have written: that of the gssw stage (the hosts treat PathAligner's differently:
+            // PathAligner.cpp:121-129 leaves the qualities as they are, GraphAligner.cpp:372-376 reverses them)
+            results[i].status = (uint16_t)(r.status & ~PG_STATUS_PATH_ALIGNER);
+        }
+    }
+    active[i] = (was && !forced) ? 1 : 0;
+}
+
 __global__ void pg_group_list_kernel(
     uint32_t n, const uint8_t* __restrict__ active, const uint32_t* __restrict__ group_of_read, const uint32_t* __restrict__ group_base,
     uint32_t* group_count, uint32_t* list)
@@ -2086,10 +2118,24 @@ static pg_status cascade_rebuild_items(pg_ctx* ctx, pg_batch* b, hipStream_t str
     return PG_OK;
 }
 
+static pg_status retire_reads(pg_ctx* ctx, pg_batch* b, bool exact);
+
 extern "C" pg_status pg_batch_retire_mapped(pg_ctx* ctx, pg_batch* b)
 {
     if (!ctx || !b || !b->graphs || !b->d_support || !b->d_path_flags)
         return fail(ctx, PG_ERR_INVALID, "pg_batch_retire_mapped: a seed stage and pg_batch_count must have run");
+    return retire_reads(ctx, b, false);
+}
+
+extern "C" pg_status pg_batch_retire_exact_matches(pg_ctx* ctx, pg_batch* b)
+{
+    if (!ctx || !b || !b->graphs || !b->d_path_flags || !b->d_results || !b->seed_chain)
+        return fail(ctx, PG_ERR_INVALID, "pg_batch_retire_exact_matches: pg_batch_path_align must have run last");
+    return retire_reads(ctx, b, true);
+}
+
+static pg_status retire_reads(pg_ctx* ctx, pg_batch* b, bool exact)
+{
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // behind the count pass, on its stream (the seed stream behind a path stage): the next stage waits for the batch's event as
     // always
@@ -2129,8 +2175,12 @@ extern "C" pg_status pg_batch_retire_mapped(pg_ctx* ctx, pg_batch* b)
             n_groups = (uint32_t)b->groups.size();
         }
         const uint32_t threads = std::max(b->n_reads, n_groups);
-        hipLaunchKernelGGL(pg_retire_kernel, dim3((threads + 255) / 256), dim3(256), 0, cs, b->n_reads, b->d_path_flags, b->d_support, b->d_active,
-                           had_mask, n_groups ? b->d_group_count : nullptr, n_groups);
+        if (exact)
+            hipLaunchKernelGGL(pg_retire_exact_kernel, dim3((threads + 255) / 256), dim3(256), 0, cs, b->n_reads, b->d_path_flags, b->d_results,
+                               b->d_base_off, b->d_bases, b->d_active, had_mask, n_groups ? b->d_group_count : nullptr, n_groups);
+        else
+            hipLaunchKernelGGL(pg_retire_kernel, dim3((threads + 255) / 256), dim3(256), 0, cs, b->n_reads, b->d_path_flags, b->d_support, b->d_active,
+                               had_mask, n_groups ? b->d_group_count : nullptr, n_groups);
         HIP_TRY(ctx, hipGetLastError());
         b->has_active = true;
         b->plan_stale = true;

@@ -425,6 +425,10 @@ __device__ __forceinline__ void path_row(const PathArgs& a, const Row& w, RowLds
     uint8_t flags = 0;
     int n_full = 0, n_matches = 0;
     const int last = L - (int)a.k;  // the last position a k-mer starts at
+    // Some k-mer of the read AS GIVEN (strand 0) is in no path of the graph (the presence filter has no false negatives): the read
+    // cannot match any walk of the graph exactly over its whole length, so a gssw fill of that strand scores below L
+    // (PG_PATH_FLAG_FWD_ABSENT, read by pg_batch_retire_exact_matches)
+    bool fwd_absent = false;
     // the first full-length match, as the walk that found it left it: seed entry, ends, nodes added (in t.rec[best])
     KmerEntry best_e{};
     uint32_t best_sp = 0, best_ep = 0, best_nl = 0, best_nr = 0;
@@ -443,6 +447,12 @@ __device__ __forceinline__ void path_row(const PathArgs& a, const Row& w, RowLds
                 win = pos;
                 wk.scan_window(win, last);
                 __threadfence_block();  // (the row reads what its other lanes wrote)
+                if (strand == 0)
+                {
+                    const int existing = min(PWIN, last - win + 1);
+                    const int present = __popcll(*(const uint64_t*)&t.mask[0]) + __popcll(*(const uint64_t*)&t.mask[8]);
+                    fwd_absent |= present < existing;
+                }
             }
             // first candidate at or behind pos
             int at = -1;
@@ -492,6 +502,8 @@ __device__ __forceinline__ void path_row(const PathArgs& a, const Row& w, RowLds
     }
     if (n_matches)
         flags |= 2;
+    if (fwd_absent)
+        flags |= PG_PATH_FLAG_FWD_ABSENT;
     if (n_full == 0)
     {
         if (w.kl == 0)

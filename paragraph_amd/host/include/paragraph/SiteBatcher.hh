@@ -60,6 +60,12 @@ struct BatchParameters
     // (CompositeAligner.cpp:105-150).  Both need the sites' paths (addSite's `paths`).
     bool kmer_sequence_matching = false;
     bool klib_sequence_matching = false;
+    // Without the path stage: an EXACT shortcut in front of gssw (pg_batch_retire_exact_matches, include/paragraph_amd.h).  The
+    // device's path kernel runs all the same, but only a read whose alignRead(AF_ALL) record its one full-length exact match
+    // forces keeps that record and skips its four fills; every other read is aligned as if the kernel had not run.  Counts,
+    // documents and genotypes are those of the plain gssw cascade (tests/test_gpu_exact.py, test_gpu_workflow.py); what it costs
+    // is the path index per graph set, what it saves is the fills of the reads without a sequencing error.
+    bool exact_match_shortcut = false;
     // which of SiteCounts' keyed tables to fill (the edge table always is): a caller that only genotypes needs neither
     bool node_counts = true, sequence_counts = true;
     // grm::ValidationAligner's bookkeeping for simulated reads (lib/grm/ValidationAligner.cpp:59-125) read by read after the

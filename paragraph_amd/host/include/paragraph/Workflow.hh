@@ -53,6 +53,7 @@ struct Parameters
     bool kmer_sequence_matching = false;   // the optional seed stages between the path stage and gssw
     bool klib_sequence_matching = false;
     bool remove_nonuniq_reads = true;
+    bool exact_match_shortcut = false;     // BatchParameters::exact_match_shortcut (only without the seed stages)
     int kmer_len = 0;
     int threads = 1;  // host threads for read extraction and document assembly
     int device = 0;   // slot of the device list (paragraph::setDevices / PG_DEVICES) the batch runs on
@@ -130,6 +131,9 @@ struct Parameters
     bool klib_sequence_matching = false;
     bool kmer_sequence_matching = false;
     int bad_align_uniq_kmer_len = 0;
+    // gssw-only cascade (the default here): reads whose alignRead record their one exact full-length match forces skip their
+    // fills (paragraph::BatchParameters::exact_match_shortcut); the documents are the same either way
+    bool exact_match_shortcut = false;
     bool output_alignments = false;  // keep "alignments" in the per-sample documents (the original writes them to a folder)
     // grmpy -A / --alignment-output-folder (lib/grmpy/AlignSamples.cpp:57-109, 120-162): when this names an existing directory,
     // every (sample, graph) pair's count document WITH the per-read records -- the reads the filters rejected included, and the

@@ -27,6 +27,7 @@ const char* kUsage = "grmpy -r <reference> -g <graphs> -m <manifest> [optional a
                      "      --path-sequence-matching BOOL (false)   --graph-sequence-matching BOOL (true)\n"
                      "      --klib-sequence-matching BOOL (false)   --kmer-sequence-matching BOOL (false)\n"
                      "      --bad-align-uniq-kmer-len N   (0)\n"
+                     "      --exact-match-shortcut [BOOL] (not in the original) reads with one exact full-length match skip their fills; same output\n"
                      "  -t, --sample-threads N            host threads (the CPUs this process may use)\n"
                      "      --devices LIST                GPUs to spread the site batches over: 0,1,2,3 or 'all' (default: PG_DEVICES, else 0)\n"
                      "      --response-file FILE          read further options from FILE\n";
@@ -73,6 +74,8 @@ int main(int argc, char** argv)
                 parameters.klib_sequence_matching = args.boolValue();
             else if (args.is(nullptr, "--kmer-sequence-matching"))
                 parameters.kmer_sequence_matching = args.boolValue();
+            else if (args.is(nullptr, "--exact-match-shortcut"))
+                parameters.exact_match_shortcut = args.optionalBool();
             else if (args.is(nullptr, "--bad-align-uniq-kmer-len"))
                 parameters.bad_align_uniq_kmer_len = std::stoi(args.value());
             else if (args.is("-t", "--sample-threads"))

@@ -1445,7 +1445,8 @@ void SiteBatcher::Impl::Run::deviceSubmit()
             path_nodes.push_back(0);
     }
     mark("graph set up");
-    if (prm.path_sequence_matching && n)
+    const bool shortcut = prm.exact_match_shortcut && !prm.path_sequence_matching && !prm.kmer_sequence_matching && !prm.klib_sequence_matching;
+    if ((prm.path_sequence_matching || shortcut) && n)
         check(ctx, pg_graphs_build_path_index(ctx, G, 32), "pg_graphs_build_path_index");
     mark("path index");
     if (prm.kmer_sequence_matching && n)
@@ -1488,6 +1489,14 @@ void SiteBatcher::Impl::Run::deviceSubmit()
     {
         check(ctx, pg_batch_path_align(ctx, batch), "pg_batch_path_align");
         hand_over();
+    }
+    else if (shortcut && n)
+    {
+        // not a stage of the cascade: no filter chain, no hand-over of MAPPED reads -- only the reads whose gssw record is
+        // forced keep it (status without PG_STATUS_PATH_ALIGNER: the record of the gssw stage)
+        check(ctx, pg_batch_path_align(ctx, batch), "pg_batch_path_align");
+        check(ctx, pg_batch_retire_exact_matches(ctx, batch), "pg_batch_retire_exact_matches");
+        keep = PG_AF_KEEP_RESULTS;
     }
     if (prm.kmer_sequence_matching && n)
     {

@@ -378,6 +378,7 @@ BatchParameters batchParameters(Parameters const& parameters)
     bp.bad_align_frac = parameters.bad_align_frac;
     bp.kmer_len = parameters.kmer_len;
     bp.path_sequence_matching = parameters.path_sequence_matching;
+    bp.exact_match_shortcut = parameters.exact_match_shortcut;
     bp.kmer_sequence_matching = parameters.kmer_sequence_matching;
     bp.klib_sequence_matching = parameters.klib_sequence_matching;
     bp.threads = parameters.threads;
@@ -673,6 +674,7 @@ paragraph::Parameters siteParameters(Parameters const& p)
     sp.max_reads = p.max_reads;
     sp.bad_align_frac = p.bad_align_frac;
     sp.path_sequence_matching = p.path_sequence_matching;
+    sp.exact_match_shortcut = p.exact_match_shortcut;
     sp.graph_sequence_matching = p.graph_sequence_matching;
     sp.kmer_sequence_matching = p.kmer_sequence_matching;
     sp.klib_sequence_matching = p.klib_sequence_matching;
@@ -1296,6 +1298,8 @@ extern "C" int pgw_genotype_graphs(
                     parameters.bad_align_frac = (float)kv.second.asDouble();
                 else if (kv.first == "path_sequence_matching")
                     parameters.path_sequence_matching = kv.second.asBool();
+                else if (kv.first == "exact_match_shortcut")
+                    parameters.exact_match_shortcut = kv.second.asBool();
                 else if (kv.first == "kmer_sequence_matching")
                     parameters.kmer_sequence_matching = kv.second.asBool();
                 else if (kv.first == "klib_sequence_matching")

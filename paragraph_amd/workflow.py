@@ -45,7 +45,7 @@ def genotype_graphs_to_file(reference_fasta, manifest, graph_paths, output_path,
 def genotype_graphs(reference_fasta, manifest, graph_paths, genotyping_parameters=None, output_path=None, **options):
     """Genotypes every graph against every sample of the manifest; returns the list of genotype documents (and leaves the
     JSON array in output_path when one is given).  Options: threads, lanes, sites_per_batch, max_reads, bad_align_frac,
-    path_sequence_matching, kmer_sequence_matching, klib_sequence_matching, bad_align_uniq_kmer_len, packed_reads,
+    path_sequence_matching, kmer_sequence_matching, klib_sequence_matching, exact_match_shortcut, bad_align_uniq_kmer_len, packed_reads,
     devices (list of HIP ordinals the lanes are spread over; default PG_DEVICES, else device 0)."""
     keep = output_path is not None
     if not keep:

@@ -164,6 +164,11 @@ def test_synthetic_sites_packed_equals_objects_and_truth(tmp_path):
         assert sum(d["samples"]["SYN"]["paired_read"] for d in packed) > len(packed)  # most mates fall off these small graphs
         if base is None:
             base = packed
+    # the exact shortcut in front of gssw (reads with one exact full-length match skip their fills): the SAME documents as the
+    # plain gssw cascade, statistics and all, from packed reads and from read objects
+    for packed_reads in (True, False):
+        assert workflow.genotype_graphs(ref, str(manifest), graphs, threads=4, lanes=2, sites_per_batch=32, packed_reads=packed_reads,
+                                        exact_match_shortcut=True) == base
     # fragment statistics see real pairs here: the running median / variance are exercised beyond the seed samples
     rich = [d["samples"]["SYN"] for d in base if d["samples"]["SYN"]["paired_read"] >= 5]
     assert rich and all(s["median_graph"] > 100 and s["variance_graph"] > 0 and s["mean_graph"] > 100 for s in rich)

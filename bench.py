@@ -107,6 +107,7 @@ def parse_args():
                     help="timed steps of the reported-only leg `exact_shortcut` (the headline workload with pg_batch_retire_exact_matches "
                          "in front of the gssw stage: reads whose alignRead record one exact full-length match forces skip their "
                          "fills; records and count table compared with the plain step's); 0 = leave it out")
+    ap.add_argument("--no-e2e-shortcut", action="store_true", help="leave the e2e leg's `with_exact_shortcut` passes out (A/B of the legs behind them)")
     ap.add_argument("--e2e-steps", type=int, default=3,
                     help="timed passes of the BAM -> genotypes leg (0 = skip): every pass takes ALL sites of the e2e data set from the "
                          "BAM file to genotype documents written as JSON (with N ranks: rank r takes sites r, r + N, ...)")
@@ -1065,7 +1066,7 @@ def run_e2e_leg(args, env, e2e, dev_index, shared, ncpu):
     # grmpy's own cascade (gssw only) with the exact shortcut in front of it (BatchParameters::exact_match_shortcut,
     # pg_batch_retire_exact_matches): the documents must be the gssw-only run's, byte for byte of their JSON values
     shortcut = None
-    if args.e2e_steps > 0:
+    if args.e2e_steps > 0 and not args.no_e2e_shortcut:
         options_sc = dict(options, exact_match_shortcut=True)
         workflow.genotype_graphs_to_file(e2e["reference"], e2e["manifest"], graphs, out_file, **options_sc)
         barrier()

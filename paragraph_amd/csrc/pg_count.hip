@@ -825,7 +825,7 @@ extern "C" pg_status pg_batch_count(pg_ctx* ctx, pg_batch* b, const pg_count_par
     }
     // (one single-thread dispatch writes both words into the page-locked block: two 8-byte copies were two dispatches)
     hipLaunchKernelGGL(pg_publish_counters_kernel, dim3(1), dim3(1), 0, cs, b->d_ops_counter, b->d_path_counter,
-                       b->graphs->path_index ? b->graphs->path_index->d_error : nullptr, b->d_h_counters);
+                       b->graphs->path_index && !b->graphs->path_index->build_pending ? b->graphs->path_index->d_error : nullptr, b->d_h_counters);
     HIP_TRY(ctx, hipGetLastError());
     b->h_counters_valid = true;
     HIP_TRY(ctx, pg_stage_end_on(ctx, b, cs));

@@ -89,6 +89,18 @@ struct PgWorkItem
     uint64_t seed_off;   // byte offset into the workspace
 };
 
+// One wavefront of the LEAN forward pass (pg_batch_align with PG_AF_LEAN): eight (read, strand) instances of one graph, one per
+// (16-lane group, 16-bit half).  An entry is the read's index, bit 31 set for its reverse complement; PG_NONE = empty.
+#define PG_INST_RC 0x80000000u
+struct PgInstItem
+{
+    uint32_t graph;
+    uint32_t pad;
+    uint32_t inst[2][PG_GROUPS];  // [half][group]
+    uint64_t trace_off;
+    uint64_t seed_off;
+};
+
 // Written by the fill kernel per (work item, group, strand).
 struct PgFillSummary
 {

@@ -94,9 +94,12 @@ __device__ __forceinline__ int sub_score(uint32_t a, uint32_t b)
 #define PG_META_AHEAD 2
 #endif
 
-template <int C, int DIR, bool WIDE, int GL = PG_GROUP_LANES>
+// INST (lean forward pass, byte variants, DIR 0): the wavefront's eight fills are eight (read, strand) instances of a PgInstItem --
+// the two halves of a register belong to two different reads -- instead of the two strands of four reads
+template <int C, int DIR, bool WIDE, int GL = PG_GROUP_LANES, bool INST = false>
 __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair, uint32_t* lds, uint32_t half = 0)
 {
+    static_assert(!INST || (DIR == 0 && !WIDE && GL == PG_GROUP_LANES), "instance items: forward graph, byte variants");
     // GL lanes per read: 16 = the four reads of a work item in one wavefront; 32 (wide variants) = two reads per wavefront,
     // wavefront `half` of the item takes reads 2 * half, 2 * half + 1 and its own half of the item's trace / seed regions
     constexpr int GROUPS = 64 / GL;
@@ -127,17 +130,20 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // items come in (forward graph, reversed graph) pairs: this instantiation takes the DIR member
     const uint32_t item_idx = a.item_begin + 2 * pair + DIR;
     const PgWorkItem* itp = a.items + item_idx;
+    const PgInstItem* inp = INST ? a.inst + (a.item_begin / 2 + pair) : nullptr;
     // an EMPTY slot of a plan re-written by the cascade's hand-over (pg_batch_retire_mapped: a group's active reads come first,
     // so the wavefront's first read says it all): nothing to fill, nothing the traceback will look at
-    if (itp->read[(int)half * GROUPS] == PG_NONE)
+    // (instance items are filled from (half 0, group 0) on)
+    if ((INST ? inp->inst[0][0] : itp->read[(int)half * GROUPS]) == PG_NONE)
         return;
-    const uint32_t graph = itp->graph;
+    const uint32_t graph = INST ? inp->graph : itp->graph;
+    const uint64_t item_seed_off = INST ? inp->seed_off : itp->seed_off, item_trace_off = INST ? inp->trace_off : itp->trace_off;
     const PgGraphDir gd = a.graphs[graph].dir[DIR];
     const uint32_t* __restrict__ smeta = a.colmeta + gd.meta_off;
     const PgNode* __restrict__ nodes = a.nodes + gd.node_off;
     const uint32_t n_nodes = gd.n_nodes;
     // (the item's seed region holds both halves' seeds: GROUPS * GL * C = 64 x the 16-lane variant's rows either way)
-    uint32_t* nodekey = (uint32_t*)(a.workspace + itp->seed_off + pg_seed_region_bytes(WIDE ? PG_VAR_WIDE + C * (GL / 16) : C, n_nodes));
+    uint32_t* nodekey = (uint32_t*)(a.workspace + item_seed_off + pg_seed_region_bytes(WIDE ? PG_VAR_WIDE + C * (GL / 16) : C, n_nodes));
     unsigned long long* nodekey64 = (unsigned long long*)nodekey;  // [n_nodes][4 reads][2 strands] 64-bit slots
 
     // ---- the moving frame ----------------------------------------------------------------------------------------------------
@@ -159,27 +165,48 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
 #pragma unroll
     for (int g = 0; g < GROUPS; ++g)
     {
-        const uint32_t ridx = itp->read[(int)half * GROUPS + g];
-        uint32_t off = 0, L = 0;
-        if (ridx != PG_NONE)
+        // half A / half B of the registers: the read's two strands, or (INST) two instances of their own
+        uint32_t eA = INST ? inp->inst[0][g] : itp->read[(int)half * GROUPS + g], eB = INST ? inp->inst[1][g] : eA;
+        const uint32_t ridxA = eA == PG_NONE ? PG_NONE : (eA & ~PG_INST_RC), ridxB = eB == PG_NONE ? PG_NONE : (eB & ~PG_INST_RC);
+        const bool rcA = INST ? eA != PG_NONE && (eA & PG_INST_RC) != 0u : false, rcB = INST ? eB != PG_NONE && (eB & PG_INST_RC) != 0u : true;
+        uint32_t offA = 0, LA = 0, offB = 0, LB = 0;
+        if (ridxA != PG_NONE)
         {
-            off = a.base_off[ridx];
-            L = a.base_off[ridx + 1] - off;
+            offA = a.base_off[ridxA];
+            LA = a.base_off[ridxA + 1] - offA;
+        }
+        if (INST)
+        {
+            if (ridxB != PG_NONE)
+            {
+                offB = a.base_off[ridxB];
+                LB = a.base_off[ridxB + 1] - offB;
+            }
+        }
+        else
+        {
+            offB = offA;
+            LB = LA;
         }
         for (int row = lane; row < ROWS; row += 64)
         {
             uint32_t cA = 5u, cB = 5u;  // 5 = padding row
-            if ((uint32_t)row < L)
+            // DIR 0: strand A = toUpper(bases), strand B = reverseComplement(bases)
+            // DIR 1: strand A = toUpper(reverse(bases)), strand B = reverseComplement(reverse(bases))
+            //        (GraphAligner.cpp:315-337)
+            if ((uint32_t)row < LA)
             {
-                const uint32_t f = (uint8_t)a.bases[off + row];
-                const uint32_t r = (uint8_t)a.bases[off + L - 1 - row];
-                // DIR 0: strand A = toUpper(bases), strand B = reverseComplement(bases)
-                // DIR 1: strand A = toUpper(reverse(bases)), strand B = reverseComplement(reverse(bases))
-                //        (GraphAligner.cpp:315-337)
-                const uint32_t chA = DIR == 0 ? upper_c(f) : upper_c(r);
-                const uint32_t chB = DIR == 0 ? comp_c(r) : comp_c(f);
-                cA = nt_code(chA);
-                cB = nt_code(chB);
+                const uint32_t f = (uint8_t)a.bases[offA + row];
+                const uint32_t r = (uint8_t)a.bases[offA + LA - 1 - row];
+                const uint32_t ch = !rcA ? (DIR == 0 ? upper_c(f) : upper_c(r)) : (DIR == 0 ? comp_c(r) : comp_c(f));
+                cA = nt_code(ch);
+            }
+            if ((uint32_t)row < LB)
+            {
+                const uint32_t f = (uint8_t)a.bases[offB + row];
+                const uint32_t r = (uint8_t)a.bases[offB + LB - 1 - row];
+                const uint32_t ch = !rcB ? (DIR == 0 ? upper_c(f) : upper_c(r)) : (DIR == 0 ? comp_c(r) : comp_c(f));
+                cB = nt_code(ch);
             }
             const int shift = (row % C) == 0 ? 2 : 1;  // a lane's first row takes its diagonal input from two steps back
 #pragma unroll
@@ -199,18 +226,27 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     __threadfence_block();
     __syncthreads();
     // rows of this lane that exist in its read (the others are padding rows)
-    uint32_t real_rows = 0;
+    uint32_t real_rows = 0, real_rows_hi = 0;  // (the two halves' reads differ in an instance item)
     {
-        const uint32_t ridx = itp->read[grp];
+        const uint32_t eA = INST ? inp->inst[0][grp] : itp->read[grp];
+        const uint32_t ridx = eA == PG_NONE ? PG_NONE : (INST ? eA & ~PG_INST_RC : eA);
         const uint32_t Lg = ridx == PG_NONE ? 0u : a.base_off[ridx + 1] - a.base_off[ridx];
         real_rows = Lg > (uint32_t)(k * C) ? Lg - (uint32_t)(k * C) : 0u;
+        real_rows_hi = real_rows;
+        if (INST)
+        {
+            const uint32_t eB = inp->inst[1][grp];
+            const uint32_t rb = eB == PG_NONE ? PG_NONE : (eB & ~PG_INST_RC);
+            const uint32_t Lb = rb == PG_NONE ? 0u : a.base_off[rb + 1] - a.base_off[rb];
+            real_rows_hi = Lb > (uint32_t)(k * C) ? Lb - (uint32_t)(k * C) : 0u;
+        }
     }
 
     const uint32_t nsteps = pg_fill_steps_lanes(gd.ncols, GL);  // even
     // [node][lane][SEED_DW] / [step / 2][TRACE_DW][lane][step & 1] (one store instruction = 512 contiguous bytes); wavefront `half` of a wide
     // item owns the second n_nodes * 64 * SEED_DW / nsteps * 64 * TRACE_DW dwords
-    uint32_t* __restrict__ seed = (uint32_t*)(a.workspace + itp->seed_off) + (size_t)half * n_nodes * 64 * SEED_DW;
-    uint32_t* __restrict__ trace = (uint32_t*)(a.workspace + itp->trace_off) + (size_t)half * nsteps * 64 * TRACE_DW;
+    uint32_t* __restrict__ seed = (uint32_t*)(a.workspace + item_seed_off) + (size_t)half * n_nodes * 64 * SEED_DW;
+    uint32_t* __restrict__ trace = (uint32_t*)(a.workspace + item_trace_off) + (size_t)half * nsteps * 64 * TRACE_DW;
 
     // H of the previous column lives in one of two register sets (HA / HB): a step reads one and writes the other, and the
     // step loop is unrolled twice with the roles swapped -- no register-to-register copies at the loop edge (the same for the
@@ -269,7 +305,10 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     auto code4_rows = [&](uint32_t (&rows)[C]) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < C; ++r)
-            rows[r] = (uint32_t)r < real_rows ? (r == 0 ? pk_delta2(2) : pk_delta2(1)) : PADPK;
+            if (INST)
+                rows[r] = pk_delta((uint32_t)r < real_rows ? (r == 0 ? 2 : 1) : PAD + 1, (uint32_t)r < real_rows_hi ? (r == 0 ? 2 : 1) : PAD + 1);
+            else
+                rows[r] = (uint32_t)r < real_rows ? (r == 0 ? pk_delta2(2) : pk_delta2(1)) : PADPK;
     };
     uint32_t sA[C], sB[C];
     {
@@ -818,6 +857,45 @@ __global__ __launch_bounds__(64) void pg_fill_kernel(PgFillArgs a)
     }
     else
         pg_fill_body<C, 0, WIDE, GL>(a, blockIdx.x / HALVES, lds, blockIdx.x % HALVES);
+}
+
+// The lean pass's two launches (byte variants): MODE 2 = the reversed-graph fill of every work-item pair (both strands of its four
+// reads), MODE 3 = the forward-graph fill of the instance items the pick kernel made from their outcome.
+template <int C, int MODE> __global__ __launch_bounds__(64) void pg_fill_lean_kernel(PgFillArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if (MODE == 2)
+        pg_fill_body<C, 1, false, PG_GROUP_LANES>(a, blockIdx.x, lds, 0);
+    else
+        pg_fill_body<C, 0, false, PG_GROUP_LANES, true>(a, blockIdx.x, lds, 0);
+}
+
+template <int C> static hipError_t launch_lean_c(PgFillArgs args, uint32_t n_pairs, int mode, hipStream_t stream)
+{
+    void (*fn)(PgFillArgs) = mode == 2 ? pg_fill_lean_kernel<C, 2> : pg_fill_lean_kernel<C, 3>;
+    const size_t lds = (size_t)(64 * 4 * C) * sizeof(uint32_t);
+    args.both_dirs = (uint32_t)mode;
+    args.n_pairs = n_pairs;
+    hipLaunchKernelGGL(fn, dim3(n_pairs), dim3(64), lds, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t pg_launch_fill_lean(int V, const PgFillArgs& args, uint32_t n_pairs, int mode, hipStream_t stream)
+{
+    if (n_pairs == 0)
+        return hipSuccess;
+    switch (V)
+    {
+    case 2: return launch_lean_c<2>(args, n_pairs, mode, stream);
+    case 4: return launch_lean_c<4>(args, n_pairs, mode, stream);
+    case 6: return launch_lean_c<6>(args, n_pairs, mode, stream);
+    case 8: return launch_lean_c<8>(args, n_pairs, mode, stream);
+    case 10: return launch_lean_c<10>(args, n_pairs, mode, stream);
+    case 12: return launch_lean_c<12>(args, n_pairs, mode, stream);
+    case 14: return launch_lean_c<14>(args, n_pairs, mode, stream);
+    case 16: return launch_lean_c<16>(args, n_pairs, mode, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 template <int C, bool WIDE = false, int GL = PG_GROUP_LANES>

@@ -10,7 +10,9 @@ struct PgFillArgs
 {
     const PgWorkItem* items;
     uint32_t item_begin;
-    uint32_t both_dirs;  // 1: forward-graph and reversed-graph workgroups alternate in runs of eight (pg_fill_kernel); 0: forward only
+    uint32_t both_dirs;  // 1: forward-graph and reversed-graph workgroups alternate in runs of eight (pg_fill_kernel); 0: forward only;
+                         // 2: reversed only (the lean pass's first launch)
+    const PgInstItem* inst;  // lean forward pass: instance item of pair p = inst[item_begin / 2 + p] (its summaries take the slots of work item item_begin + 2 p)
     uint32_t n_pairs;    // work-item pairs of this launch
     const PgGraphDev* graphs;
     const PgNode* nodes;
@@ -45,4 +47,6 @@ struct PgTraceArgs
 };
 
 hipError_t pg_launch_fill(int V, const PgFillArgs& args, uint32_t n_pairs, bool revg, bool wide32, hipStream_t stream);
+// the lean pass (byte variants only): mode 2 = the reversed-graph fills of the work items, mode 3 = forward-graph fills of args.inst
+hipError_t pg_launch_fill_lean(int V, const PgFillArgs& args, uint32_t n_pairs, int mode, hipStream_t stream);
 hipError_t pg_launch_trace(const PgTraceArgs& args, hipStream_t stream);

@@ -59,7 +59,17 @@ struct pg_path_index
     uint32_t* d_error = nullptr;     // device-built index: bit0 = two k-mers of a graph share a hash (the set must be refused), bit1 = internal
     void* staging = nullptr;         // its page-locked upload block, handed back when the index is freed (the build does not wait)
     size_t staging_cap = 0;
-    hipEvent_t ev_built = nullptr;   // behind the build's last kernel on the copy stream
+    hipEvent_t ev_built = nullptr;   // behind the build's last kernel (on the seed stream of the first path stage that uses the index)
+    // device-built index: the small tables go up on the copy stream (ev_tables behind them); the two build launches wait for the set's
+    // FIRST path stage and run on its seed stream in front of the path kernel (pg_path_index_ensure_built) -- on the copy stream they
+    // stood in front of every lane's uploads
+    hipEvent_t ev_tables = nullptr;
+    bool build_pending = false;
+    hipStream_t built_on = nullptr;
+    uint64_t build_table_entries = 0, build_filter_words = 0;
+    uint32_t build_n_chars = 0, build_n_total = 0;
+    uint32_t* d_graph_of_node = nullptr;  // (inside d_block)
+    uint32_t* d_pool_next = nullptr;      // (inside d_block)
     std::vector<uint32_t> h_k;       // per graph
 };
 
@@ -67,6 +77,8 @@ struct pg_path_index
 const char* pg_path_index_error_text(uint32_t word);
 // fetches that word for a batch whose stages are complete (synchronises the copy stream): PG_OK, or the build's failure
 pg_status pg_path_index_check(pg_ctx* ctx, const pg_graphs* G);
+// a device-built index: queues its build on `stream` if no stage has yet, otherwise makes `stream` wait for the build
+hipError_t pg_path_index_ensure_built(pg_path_index* ix, hipStream_t stream);
 
 // the tables pg_build_kmer_index makes on the host before they go up
 struct PgKmerIndexHost

@@ -651,9 +651,15 @@ void pg_path_index_free(pg_path_index* ix)
 {
     if (!ix)
         return;
+    if (ix->ev_tables)
+    {
+        (void)hipEventSynchronize(ix->ev_tables);  // (the staging block goes back below)
+        (void)hipEventDestroy(ix->ev_tables);
+    }
     if (ix->ev_built)
     {
-        (void)hipEventSynchronize(ix->ev_built);  // (long complete wherever a batch of the set has come back)
+        if (!ix->build_pending)
+            (void)hipEventSynchronize(ix->ev_built);  // (long complete wherever a batch of the set has come back)
         (void)hipEventDestroy(ix->ev_built);
     }
     pg_pinned_put(ix->staging, ix->staging_cap);
@@ -1276,10 +1282,11 @@ bool count_kmers(const pg_graphs* G, const std::vector<uint32_t>& succ_off, cons
 pg_status build_path_index_on_device(pg_ctx* ctx, pg_graphs* G, uint32_t k, pg_path_index** out)
 {
     *out = nullptr;
-    // Opt-in (PG_PATH_INDEX_DEVICE=1).  Measured on the e2e leg with `paragraph`'s default cascade (profiles/r06_path_index_device_ab.jsonl):
-    // 169 against 180 us of host CPU per (site, sample), but 77 - 79 k against 82.5 k sites/s -- the two build launches sit on
-    // the one copy stream in front of every lane's uploads.  A host with fewer cores per GPU than this box may prefer it.
-    if (k > DEV_INDEX_MAX_K || !getenv("PG_PATH_INDEX_DEVICE"))
+    // The default since the build's two launches moved from the copy stream (where they stood in front of every lane's uploads: 77 - 79 k
+    // against 82.5 k sites/s, profiles/r06_path_index_device_ab.jsonl) onto the seed stream of the set's first path stage: the e2e leg
+    // with `paragraph`'s default cascade runs as fast either way (80.6 - 81.3 k sites/s) and the host spends 164 - 166 instead of 192 - 194 us
+    // per (site, sample) (profiles/r06_path_index_seed_stream_ab.jsonl).  PG_PATH_INDEX_HOST=1: the host builder.
+    if (k > DEV_INDEX_MAX_K || getenv("PG_PATH_INDEX_HOST"))
         return PG_OK;
     static thread_local PgKmerIndexHost t;  // (kept from call to call: see pg_build_kmer_index)
     static thread_local std::vector<uint64_t> f, p;
@@ -1376,51 +1383,85 @@ pg_status build_path_index_on_device(pg_ctx* ctx, pg_graphs* G, uint32_t k, pg_p
     if (e == hipSuccess) e = pg_dev_alloc((void**)&ix->d_table, std::max<uint64_t>(table_entries, 1) * sizeof(KmerEntry));
     if (e == hipSuccess) e = pg_dev_alloc((void**)&ix->d_pool, std::max<uint64_t>(pool_entries, 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = pg_dev_alloc((void**)&ix->d_filter, (filter_words + 1) * sizeof(uint32_t));  // (+ the error word)
-    if (e == hipSuccess) e = hipMemsetAsync(ix->d_table, 0, std::max<uint64_t>(table_entries, 1) * sizeof(KmerEntry), ctx->stream_copy);
-    if (e == hipSuccess) e = hipMemsetAsync(ix->d_filter, 0, (filter_words + 1) * sizeof(uint32_t), ctx->stream_copy);
     if (e == hipSuccess)
     {
-        d_error = ix->d_filter + filter_words;
-        ix->d_error = d_error;
-        IndexBuildArgs a{};
-        a.n_chars = (uint32_t)G->h_seq_raw.size();
-        a.n_total_nodes = n_total;
-        a.k = k;
-        a.node_off = ix->d_node_off;
-        a.raw = ix->d_raw;
-        a.graph_of_node = d_graph_of_node;
-        a.graphs = ix->d_graphs;
-        a.succ_off = ix->d_succ_off;
-        a.succ = ix->d_succ;
-        a.table = ix->d_table;
-        a.pool = ix->d_pool;
-        a.pool_next = d_pool_next;
-        a.filter = ix->d_filter;
-        a.error = d_error;
-        if (a.n_chars)
-        {
-            hipLaunchKernelGGL(pg_index_build_kernel<false>, dim3((a.n_chars + 63) / 64), dim3(64), 0, ctx->stream_copy, a);
-            hipLaunchKernelGGL(pg_index_build_kernel<true>, dim3((a.n_chars + 63) / 64), dim3(64), 0, ctx->stream_copy, a);
-            e = hipGetLastError();
-        }
+        ix->d_error = ix->d_filter + filter_words;
+        ix->d_graph_of_node = d_graph_of_node;
+        ix->d_pool_next = d_pool_next;
+        ix->build_table_entries = table_entries;
+        ix->build_filter_words = filter_words;
+        ix->build_n_chars = (uint32_t)G->h_seq_raw.size();
+        ix->build_n_total = n_total;
+        ix->build_pending = true;
     }
-    // Nothing waits here: the batch's upload follows on the same stream and its event orders every stage behind the build; the
-    // error word comes back with the batch's result sizes (pg_batch_count publishes it) or with its records / flags, and the
-    // page-locked block of the upload is handed back when the index is freed.
+    // Nothing waits here and nothing is launched here: the set's first path stage queues the memsets and the two build launches on
+    // its own seed stream behind ev_tables (pg_path_index_ensure_built); the error word comes back with the batch's result sizes
+    // (pg_batch_count publishes it) or with its records / flags, and the page-locked block of the upload is handed back when the
+    // index is freed.
     ix->staging = staging;
     ix->staging_cap = staging_cap;
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_tables, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ix->ev_tables, ctx->stream_copy);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_built, pg_wait_event_flags());
-    if (e == hipSuccess) e = hipEventRecord(ix->ev_built, ctx->stream_copy);
     if (e != hipSuccess)
     {
         (void)hipStreamSynchronize(ctx->stream_copy);  // (the copy may still read the block)
+        ix->build_pending = false;
         pg_path_index_free(ix);
         return pg_fail(ctx, PG_ERR_HIP, std::string("k-mer index build: ") + hipGetErrorString(e));
     }
     *out = ix;
     return PG_OK;
 }
+
+hipError_t index_build_launch(pg_path_index* ix, hipStream_t stream)
+{
+    hipError_t e = hipStreamWaitEvent(stream, ix->ev_tables, 0);
+    if (e == hipSuccess) e = hipMemsetAsync(ix->d_table, 0, std::max<uint64_t>(ix->build_table_entries, 1) * sizeof(KmerEntry), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ix->d_filter, 0, (ix->build_filter_words + 1) * sizeof(uint32_t), stream);
+    if (e != hipSuccess)
+        return e;
+    IndexBuildArgs a{};
+    a.n_chars = ix->build_n_chars;
+    a.n_total_nodes = ix->build_n_total;
+    a.k = ix->k;
+    a.node_off = ix->d_node_off;
+    a.raw = ix->d_raw;
+    a.graph_of_node = ix->d_graph_of_node;
+    a.graphs = ix->d_graphs;
+    a.succ_off = ix->d_succ_off;
+    a.succ = ix->d_succ;
+    a.table = ix->d_table;
+    a.pool = ix->d_pool;
+    a.pool_next = ix->d_pool_next;
+    a.filter = ix->d_filter;
+    a.error = ix->d_error;
+    if (a.n_chars)
+    {
+        hipLaunchKernelGGL(pg_index_build_kernel<false>, dim3((a.n_chars + 63) / 64), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL(pg_index_build_kernel<true>, dim3((a.n_chars + 63) / 64), dim3(64), 0, stream, a);
+        e = hipGetLastError();
+    }
+    return e;
+}
 }  // namespace
+
+hipError_t pg_path_index_ensure_built(pg_path_index* ix, hipStream_t stream)
+{
+    if (!ix || !ix->ev_built)
+        return hipSuccess;  // (made on the host: resident since pg_graphs_build_path_index returned)
+    if (ix->build_pending)
+    {
+        hipError_t e = index_build_launch(ix, stream);
+        if (e == hipSuccess) e = hipEventRecord(ix->ev_built, stream);
+        if (e != hipSuccess)
+            return e;
+        ix->build_pending = false;
+        ix->built_on = stream;
+        return hipSuccess;
+    }
+    return ix->built_on == stream ? hipSuccess : hipStreamWaitEvent(stream, ix->ev_built, 0);
+}
 
 const char* pg_path_index_error_text(uint32_t word)
 {
@@ -1431,7 +1472,7 @@ pg_status pg_path_index_check(pg_ctx* ctx, const pg_graphs* G)
 {
     // (the callers' own copies are on the copy stream: the wait is theirs too, index or no index)
     uint32_t word = 0;
-    if (G && G->path_index && G->path_index->d_error)
+    if (G && G->path_index && G->path_index->d_error && !G->path_index->build_pending)  // (never built: no stage has used it)
         HIP_TRY(ctx, hipMemcpyAsync(&word, G->path_index->d_error, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream_copy));
     HIP_TRY(ctx, pg_stream_wait(ctx->device, ctx->stream_copy));
     if (word)
@@ -1509,6 +1550,7 @@ extern "C" pg_status pg_batch_path_align(pg_ctx* ctx, pg_batch* b)
             return cp;
     }
     HIP_TRY(ctx, pg_stage_begin_on(ctx, b, ps));
+    HIP_TRY(ctx, pg_path_index_ensure_built(G->path_index, ps));  // (a device-built index is MADE here, by the set's first path stage)
     // (no memsets in front of the kernel: it writes the flag of every read, and the counter is still zero from the upload when this is
     // the batch's first stage -- every dispatch of a seed chain waits for a wavefront slot beside the fills)
     if (!b->ops_counter_fresh)

@@ -68,10 +68,12 @@ def _path_reads(rng, seqs, edges, k, n):
 
 @pytest.mark.parametrize("k,index_on_device", [(8, False), (16, False), (32, False), (16, True), (32, True)])
 def test_path_stage_fuzz(gpu_ctx, k, index_on_device, monkeypatch):
-    """index_on_device: the k-mer table, node pool and presence filter made by pg_index_build_kernel (PG_PATH_INDEX_DEVICE=1)
-    instead of the host enumerator -- the same records either way."""
+    """index_on_device: the k-mer table, node pool and presence filter made by pg_index_build_kernel (the default; queued by the
+    set's first path stage on its seed stream) or by the host enumerator (PG_PATH_INDEX_HOST=1) -- the same records either way."""
     if index_on_device:
-        monkeypatch.setenv("PG_PATH_INDEX_DEVICE", "1")
+        monkeypatch.delenv("PG_PATH_INDEX_HOST", raising=False)
+    else:
+        monkeypatch.setenv("PG_PATH_INDEX_HOST", "1")
     check = path_checker()
     rng = random.Random(fuzzgen.salted(1000 + k))
     graphs, reads, gor, want = [], [], [], []

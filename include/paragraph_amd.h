@@ -119,6 +119,10 @@ typedef struct pg_result
                                  undefined downstream); 2 = internal traceback inconsistency.
                                  PG_STATUS_PATH_ALIGNER is or-ed in when the PathAligner stage produced the record */
 } pg_result;
+/* multi_mask bit 4 (lean pass, PG_AF_LEAN): the forward-graph fill of the strand that was NOT returned did not run -- its bit (0 or 1)
+ * reads 0; nothing of the reference's Read depends on it (GraphAligner.cpp:340-356: the returned strand was unique, or the other
+ * strand's reversed-graph fill already made it non-unique) */
+#define PG_MULTI_OTHER_FWD_SKIPPED 0x10u
 #define PG_STATUS_PATH_ALIGNER 0x100u
 #define PG_STATUS_KMER_ALIGNER 0x200u
 #define PG_STATUS_KLIB_ALIGNER 0x400u
@@ -168,6 +172,16 @@ const char* pg_strerror(pg_status st);
 const char* pg_last_error(const pg_ctx* ctx);
 /* bytes of HBM the ctx may use for traceback state per chunk (default 8 GiB) */
 pg_status pg_ctx_set_workspace_bytes(pg_ctx* ctx, uint64_t bytes);
+/* The LEAN gssw stage (off by default; PG_LEAN=1 in the environment turns it on for every new context): pg_batch_align with
+ * CIGAR + both strands + reversed graph -- GraphAligner::alignRead(AF_ALL), GraphAligner.cpp:308-404 -- computes the record from THREE
+ * fills per read where the fourth cannot change it: the reversed-graph fills of both strands first (a fill's best score is the same
+ * on the graph and on the reversed graph), then the forward-graph fill of the higher-scoring strand X, and that of the other strand
+ * only where X is not unique and the other strand still may be (GraphAligner.cpp:340-356).  Reads whose X turns out non-unique
+ * through its own forward fill are re-aligned by the plain four fills in the same call.  Every field of the reference's Read is what the plain
+ * stage writes; of pg_result, multi_mask's bit of a forward fill that did not run reads 0 and PG_MULTI_OTHER_FWD_SKIPPED is set.
+ * Reads of up to 250 bases; longer ones (and batches with general-path reads) run the plain stage.  tests/test_gpu_lean.py. */
+pg_status pg_ctx_set_lean(pg_ctx* ctx, int on);
+
 /* 1 (default): the fills of a batch's chunks run one after the other on the main stream, over two workspace regions.
  * 2: three regions, the fills alternate between two streams, so that the next chunk's wavefronts take the slots a draining
  * launch leaves -- for workflows whose launches are short (a 192-site batch fills for ~2 ms, 10 - 15 % of it the tail in

@@ -48,7 +48,7 @@ EXPORTS = [
     "pg_batch_path_align", "pg_batch_download_path_flags", "pg_batch_set_active", "pg_graphs_build_kmer_index",
     "pg_batch_kmer_align", "pg_graphs_build_klib_index", "pg_batch_klib_align", "pg_graphs_klib_error", "pg_graphs_klib_last_kernels", "pg_graphs_build_filter_index",
     "pg_host_alloc", "pg_host_free", "pg_host_register", "pg_host_unregister", "pg_counts_zero", "pg_ctx_sync_compute",
-    "pg_render_cigars", "pg_ctx_native_stream", "pg_ctx_count_record", "pg_ctx_count_wait", "pg_ctx_set_fill_streams",
+    "pg_render_cigars", "pg_ctx_native_stream", "pg_ctx_count_record", "pg_ctx_count_wait", "pg_ctx_set_fill_streams", "pg_ctx_set_lean",
     "pg_batch_retire_mapped", "pg_batch_result_sizes", "pg_batch_download_all", "pg_batch_retire_exact_matches",
 ]
 
@@ -102,6 +102,8 @@ def load_library():
     L.pg_ctx_set_workspace_bytes.argtypes = [vp, C.c_uint64]
     L.pg_ctx_set_fill_streams.restype = C.c_int32
     L.pg_ctx_set_fill_streams.argtypes = [vp, C.c_int]
+    L.pg_ctx_set_lean.restype = C.c_int32
+    L.pg_ctx_set_lean.argtypes = [vp, C.c_int]
     L.pg_ctx_sync.restype = C.c_int32
     L.pg_ctx_sync.argtypes = [vp]
     L.pg_ctx_timing_enable.restype = C.c_int32
@@ -295,6 +297,11 @@ class Context:
             self._chk(self.L.pg_ctx_set_workspace_bytes(self.h, workspace_bytes))
         if fill_streams:
             self.set_fill_streams(fill_streams)
+
+    def set_lean(self, on):
+        """the lean gssw stage (include/paragraph_amd.h, pg_ctx_set_lean): alignRead(AF_ALL) from three fills per read where the fourth
+        cannot change the record"""
+        self._chk(self.L.pg_ctx_set_lean(self.h, 1 if on else 0))
 
     def set_fill_streams(self, n):
         """1: fills one after the other on the main stream (two workspace regions); 2: fills alternate over two streams (three
@@ -679,6 +686,7 @@ def results_to_dicts(res, ops):
             "graph_pos": int(r["graph_pos"]), "score": int(r["score"]), "mapq": int(r["mapq"]),
             "unique": bool(r["is_unique"]), "returned_reverse": bool(r["returned_reverse"]),
             "multi": [(mm >> k) & 1 for k in range(4)],
+            "other_fwd_skipped": bool(mm & 0x10),  # lean stage: the forward-graph fill of the strand not returned did not run
             "strand_score": [int(r["strand_score"][0]), int(r["strand_score"][1])],
             "cigar": render_cigar(r, ops), "clipped": int(r["clipped"]), "status": int(r["status"]) & 0xFF,
             "by_path_aligner": bool(int(r["status"]) & STATUS_PATH_ALIGNER),

@@ -332,6 +332,10 @@ extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
     // reads of 251..512 bases: 32 lanes per read (two wavefronts per work item); PG_WIDE16=1 = the 16-lane kernels, for A/B timing
     ctx->wide32 = getenv("PG_WIDE16") == nullptr;
     {
+        const char* le = getenv("PG_LEAN");  // (the default of pg_ctx_set_lean)
+        ctx->lean = le && le[0] != '0';
+    }
+    {
         int lds = 0;
         if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
             ctx->max_lds_per_block = (uint64_t)lds;
@@ -358,6 +362,14 @@ extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
     if (const char* fs = getenv("PG_FILL_STREAMS"))  // A/B timing: overrides pg_ctx_set_fill_streams' default of this context
         ctx->fill_streams = fs[0] == '2' ? 2 : 1;
     *out = ctx;
+    return PG_OK;
+}
+
+extern "C" pg_status pg_ctx_set_lean(pg_ctx* ctx, int on)
+{
+    if (!ctx)
+        return PG_ERR_INVALID;
+    ctx->lean = on != 0;
     return PG_OK;
 }
 
@@ -1202,6 +1214,14 @@ static void batch_free_device(pg_batch* b)
     b->d_path_flags = nullptr;
     (void)pg_dev_free(b->d_active);
     b->d_active = nullptr;
+    (void)pg_dev_free(b->d_inst);
+    (void)pg_dev_free(b->d_lean_extra);
+    (void)pg_dev_free(b->d_yloc);
+    (void)pg_dev_free(b->d_lean_undecided);
+    b->d_inst = nullptr;
+    b->d_lean_extra = b->d_yloc = nullptr;
+    b->d_lean_undecided = nullptr;
+    b->cap_lean_pairs = b->cap_lean_reads = 0;
     b->has_active = false;
     (void)pg_dev_free(b->d_group_of_read2);
     (void)pg_dev_free(b->d_group_base);
@@ -1340,6 +1360,7 @@ static pg_status plan_items(pg_ctx* ctx, pg_batch* b, const uint8_t* active, hip
     if (!std::is_sorted(keys.begin(), keys.end(), key_less))  // reads of one length, site after site, arrive in order
         std::stable_sort(keys.begin(), keys.end(), key_less);
     b->plan_stale = false;
+    b->device_plan = false;
     b->plan_epoch = ctx->plan_epoch;
     if (!active)
     {
@@ -1899,7 +1920,94 @@ __global__ void pg_build_items_kernel(
     items[2 * (size_t)p] = fw;
     items[2 * (size_t)p + 1] = rv;
 }
+
+// ---- the lean gssw stage: pick behind the reversed-graph fills ---------------------------------------------------------------------
+// init: the instance items of a chunk's pair slots -- graph and workspace regions of the forward work item in the same slot (an
+// instance item of a run always takes a slot of that run: same graph, same region sizes), no instances yet
+__global__ void pg_lean_init_kernel(PgLeanBuildArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_pairs)
+        return;
+    const uint32_t p = a.pair_begin + i;
+    const PgWorkItem fw = a.items[2 * (size_t)p];
+    PgInstItem it;
+    it.graph = fw.graph;
+    it.pad = 0;
+    for (int h = 0; h < 2; ++h)
+        for (int g = 0; g < PG_GROUPS; ++g)
+            it.inst[h][g] = PG_NONE;
+    it.trace_off = fw.trace_off;
+    it.seed_off = fw.seed_off;
+    a.inst[p] = it;
+    a.extra[p] = 0;
+}
+
+// build: per read of the pair, X = the strand whose reversed-graph fill scored higher (the forward strand on a tie) goes to the instance
+// item (run start + rank / 2), half rank & 1, the read's own group; the other strand Y gets a forward fill too where the reversed-graph
+// fills already say "X is not unique, Y may be" (pg_trace.hip, LEAN) -- in the slots behind the run's X items, eight to an item.
+__global__ void pg_lean_build_kernel(PgLeanBuildArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_pairs)
+        return;
+    const uint32_t p = a.pair_begin + i;
+    uint32_t lo = 0, hi = a.n_segments;  // last segment whose pair_begin <= p
+    while (hi - lo > 1)
+    {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.segments[mid].pair_begin <= p)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const PgPlanSegment s = a.segments[lo];
+    const uint32_t rs = s.pair_begin;
+    const uint32_t count = a.group_count[s.group];
+    // pairs of this run that hold reads (a group's active reads come first)
+    uint32_t ne = 0;
+    if (count > 4u * s.first_pair)
+    {
+        ne = (count - 4u * s.first_pair + 3u) / 4u;
+        ne = ne < s.n_pairs ? ne : s.n_pairs;
+    }
+    const PgWorkItem fw = a.items[2 * (size_t)p];
+    const uint32_t q = rs + (p - rs) / 2u, h = (p - rs) & 1u;
+    for (int g = 0; g < PG_GROUPS; ++g)
+    {
+        const uint32_t ridx = fw.read[g];
+        if (ridx == PG_NONE)
+            continue;
+        const PgFillSummary* fsR = a.fillsum + ((size_t)(2 * p + 1) * PG_GROUPS + g) * 2;
+        const int SA = fsR[0].score, SB = fsR[1].score;
+        const int X = SA >= SB ? 0 : 1;
+        const int mXr = fsR[X].multi, mYr = fsR[1 - X].multi;
+        a.inst[q].inst[h][g] = ridx | (X ? PG_INST_RC : 0u);
+        uint32_t yl = PG_NONE;
+        if (mXr && !mYr)
+        {
+            const uint32_t e = atomicAdd(&a.extra[rs], 1u);
+            const uint32_t qq = rs + (ne + 1u) / 2u + e / 8u;
+            if (qq < rs + s.n_pairs)
+            {
+                const uint32_t slot = e & 7u;  // filled from (half 0, group 0) on: an item is empty iff that entry is
+                a.inst[qq].inst[slot >> 2][slot & 3u] = ridx | (X ? 0u : PG_INST_RC);
+                yl = (qq << 3) | ((slot & 3u) << 1) | (slot >> 2);
+            }
+        }
+        a.yloc[ridx] = yl;
+    }
+}
 }  // namespace
+
+hipError_t pg_launch_lean_build(const PgLeanBuildArgs& args, hipStream_t stream)
+{
+    if (!args.n_pairs)
+        return hipSuccess;
+    hipLaunchKernelGGL(pg_lean_init_kernel, dim3((args.n_pairs + 255) / 256), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(pg_lean_build_kernel, dim3((args.n_pairs + 255) / 256), dim3(256), 0, stream, args);
+    return hipGetLastError();
+}
 
 // The batch's full plan (every read active) as (group, chunk) segments on the device, and b->chunks = its chunks: made once per
 // upload, on the host, from the groups' sizes alone -- plan_items' rule: equal chunks per variant, longest graph first in a chunk.
@@ -2115,6 +2223,7 @@ static pg_status cascade_rebuild_items(pg_ctx* ctx, pg_batch* b, hipStream_t str
     b->n_pairs = b->full_pairs;
     b->max_ws = b->full_max_ws;
     b->plan_stale = false;
+    b->device_plan = true;
     return PG_OK;
 }
 
@@ -2297,8 +2406,9 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_fill2, e0, 0));
         ctx->sync_events_in_flight.push_back(e0);
     }
-    for (const Chunk& ch : b->chunks)
-    {
+    // one chunk: its fills on the fill stream, pick + traceback behind them on the second stream.  lean_chunk: the lean stage's three
+    // launches (reversed-graph fills, pick, forward-graph fills of the instances) instead of the one launch of all four fills
+    auto run_chunk = [&](const Chunk& ch, const bool lean_chunk) -> pg_status {
         const uint32_t n_pairs = ch.pair_end - ch.pair_begin;
         const unsigned h = (unsigned)(ctx->chunk_seq % regions);
         // with two fill streams consecutive chunks' fills are on different streams: the later one's wavefronts fill the slots the
@@ -2326,7 +2436,26 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             ev.kind = 0;
             HIP_TRY(ctx, hipEventRecord(ev.a, fill_stream));
         }
-        HIP_TRY(ctx, pg_launch_fill(ch.C, fa, n_pairs, revg, ctx->wide32, fill_stream));
+        if (lean_chunk)
+        {
+            fa.inst = b->d_inst;
+            HIP_TRY(ctx, pg_launch_fill_lean(ch.C, fa, n_pairs, 2, fill_stream));
+            PgLeanBuildArgs la{};
+            la.pair_begin = ch.pair_begin;
+            la.n_pairs = n_pairs;
+            la.items = b->d_items;
+            la.fillsum = b->d_fillsum;
+            la.segments = b->d_segments;
+            la.n_segments = (uint32_t)b->h_segments.size();
+            la.group_count = b->d_group_count;
+            la.inst = b->d_inst;
+            la.extra = b->d_lean_extra;
+            la.yloc = b->d_yloc;
+            HIP_TRY(ctx, pg_launch_lean_build(la, fill_stream));
+            HIP_TRY(ctx, pg_launch_fill_lean(ch.C, fa, n_pairs, 3, fill_stream));
+        }
+        else
+            HIP_TRY(ctx, pg_launch_fill(ch.C, fa, n_pairs, revg, ctx->wide32, fill_stream));
         if (ctx->timing)
         {
             HIP_TRY(ctx, hipEventRecord(ev.b, fill_stream));
@@ -2366,7 +2495,17 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             ev.kind = 1;
             HIP_TRY(ctx, hipEventRecord(ev.a, ctx->stream2));
         }
-        HIP_TRY(ctx, pg_launch_trace(ta, ctx->stream2));
+        if (lean_chunk)
+        {
+            ta.inst = b->d_inst;
+            ta.segments = b->d_segments;
+            ta.n_segments = (uint32_t)b->h_segments.size();
+            ta.yloc = b->d_yloc;
+            ta.undecided = b->d_lean_undecided;
+            HIP_TRY(ctx, pg_launch_trace_lean(ta, ctx->stream2));
+        }
+        else
+            HIP_TRY(ctx, pg_launch_trace(ta, ctx->stream2));
         if (ctx->timing)
         {
             HIP_TRY(ctx, hipEventRecord(ev.b, ctx->stream2));
@@ -2378,7 +2517,99 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         ctx->region_free[h] = td;
         ctx->sync_events_in_flight.push_back(td);
         ++ctx->chunk_seq;
+        return PG_OK;
+    };
+    // ---- the lean gssw stage (pg_ctx_set_lean) -------------------------------------------------------------------------------------
+    // alignRead(AF_ALL) asks for four fills per read and reads one record off them (GraphAligner.cpp:340-401).  A fill's best score is the
+    // same on the graph and on the reversed graph, so the reversed-graph fills of both strands (scores + their two multi flags, no
+    // trace) already say which strand X scores higher, and the record only ever needs the forward-graph fill of the OTHER strand when
+    // X turns out not to be unique while that strand still may be.  Pass 1, per chunk: reversed-graph fills of every read; a pick
+    // kernel packs the X strands -- eight reads' worth per wavefront, one per (16-lane group, register half) -- and the other strands
+    // that are already known to be needed into instance items; forward-graph fills of those; pick + traceback.  Pass 2: the reads pass
+    // 1 could not decide (X not unique because of its own forward fill; a per cent or two) through the plain four fills, on the work
+    // items re-made for them on the device.  Same records as the plain stage field by field, except multi_mask's bit of a forward fill
+    // that did not run (PG_MULTI_OTHER_FWD_SKIPPED says so).  Byte variants (reads <= 250 bases); other chunks run plain in pass 1.
+    const bool lean = ctx->lean && (flags & PG_AF_CIGAR) && (flags & PG_AF_BOTH_STRANDS) && revg && !b->has_general_reads && b->gen_idx.empty()
+        && b->n_reads && !b->groups.empty();
+    if (lean)
+    {
+        if (!b->device_plan)
+        {
+            const pg_status rp = cascade_rebuild_items(ctx, b, ctx->stream, b->has_active ? b->d_active : nullptr);
+            if (rp != PG_OK)
+                return rp;
+            const pg_status ws3 = ensure_ctx_workspace(ctx, b);
+            if (ws3 != PG_OK)
+                return ws3;
+        }
+        if (b->full_pairs > b->cap_lean_pairs || b->n_reads > b->cap_lean_reads)
+        {
+            b->park(b->d_inst);
+            b->park(b->d_lean_extra);
+            b->park(b->d_yloc);
+            b->park(b->d_lean_undecided);
+            b->d_inst = nullptr;
+            b->d_lean_extra = b->d_yloc = nullptr;
+            b->d_lean_undecided = nullptr;
+            b->cap_lean_pairs = b->full_pairs + b->full_pairs / 8 + 16;
+            b->cap_lean_reads = (size_t)b->n_reads + b->n_reads / 8 + 16;
+            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_inst, b->cap_lean_pairs * sizeof(PgInstItem)));
+            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_lean_extra, b->cap_lean_pairs * sizeof(uint32_t)));
+            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_yloc, b->cap_lean_reads * sizeof(uint32_t)));
+            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_lean_undecided, b->cap_lean_reads));
+        }
+        HIP_TRY(ctx, hipMemsetAsync(b->d_lean_undecided, 0, b->n_reads, ctx->stream));  // (reads of chunks that run plain, inactive reads)
+        {
+            // (the second stream must see the memset: the traceback writes the flags)
+            hipEvent_t e1;
+            HIP_TRY(ctx, get_sync_event(ctx, &e1));
+            HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, e1, 0));
+            ctx->sync_events_in_flight.push_back(e1);
+        }
+        for (const Chunk& ch : b->chunks)
+        {
+            const pg_status cs = run_chunk(ch, !pg_var_wide(ch.C));
+            if (cs != PG_OK)
+                return cs;
+        }
+        // pass 2: the undecided reads (the list and item kernels on the main stream, behind pass 1's last traceback)
+        {
+            hipEvent_t e2;
+            HIP_TRY(ctx, get_sync_event(ctx, &e2));
+            HIP_TRY(ctx, hipEventRecord(e2, ctx->stream2));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, e2, 0));
+            if (ctx->fill_streams == 2)
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_fill2, e2, 0));
+            ctx->sync_events_in_flight.push_back(e2);
+        }
+        const pg_status rp2 = cascade_rebuild_items(ctx, b, ctx->stream, b->d_lean_undecided);
+        if (rp2 != PG_OK)
+            return rp2;
+        {
+            hipEvent_t e3;
+            HIP_TRY(ctx, get_sync_event(ctx, &e3));
+            HIP_TRY(ctx, hipEventRecord(e3, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, e3, 0));
+            if (ctx->fill_streams == 2)
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_fill2, e3, 0));
+            ctx->sync_events_in_flight.push_back(e3);
+        }
+        for (const Chunk& ch : b->chunks)
+        {
+            const pg_status cs = run_chunk(ch, false);
+            if (cs != PG_OK)
+                return cs;
+        }
+        b->plan_stale = true;  // (the work items are those of pass 2: the next stage re-makes them for the batch's own mask)
     }
+    else
+        for (const Chunk& ch : b->chunks)
+        {
+            const pg_status cs = run_chunk(ch, false);
+            if (cs != PG_OK)
+                return cs;
+        }
     if (!b->gen_idx.empty())
     {
         const pg_status gs = run_general(ctx, b, flags);

@@ -101,6 +101,15 @@ struct PgInstItem
     uint64_t seed_off;
 };
 
+// A piece of a (variant, graph) run of reads inside one chunk of a batch's full plan (pg_api.hip, cascade_full_plan).
+struct PgPlanSegment
+{
+    uint32_t pair_begin, n_pairs;  // pair slots [pair_begin, pair_begin + n_pairs) of the batch's full plan
+    uint32_t first_pair;           // ... are pairs first_pair.. of the group (four reads per pair, active reads first)
+    uint32_t graph, list_base, group;
+    uint64_t ws_base, need, trace_bytes, seed_bytes;
+};
+
 // Written by the fill kernel per (work item, group, strand).
 struct PgFillSummary
 {

@@ -35,14 +35,6 @@ struct PgReadGroup
     uint32_t n_reads;    // reads of the group in the batch
     uint64_t sum_len;    // their bases (for the cell counts of the timing figures)
 };
-struct PgPlanSegment
-{
-    uint32_t pair_begin, n_pairs;  // pair slots [pair_begin, pair_begin + n_pairs) of the batch's full plan
-    uint32_t first_pair;           // ... are pairs first_pair.. of the group (four reads per pair, active reads first)
-    uint32_t graph, list_base, group;
-    uint64_t ws_base, need, trace_bytes, seed_bytes;
-};
-
 struct EventPair
 {
     hipEvent_t a, b;
@@ -102,6 +94,9 @@ struct pg_ctx
     uint8_t* gen_ws = nullptr;
     uint64_t gen_ws_cap = 0;
     bool wide32 = true;  // wide variants (reads of 251..512 bases) with 32 lanes per read
+    // The lean gssw stage (pg_ctx_set_lean; PG_LEAN=0 / 1 sets the default): alignRead(AF_ALL) with three fills per read where
+    // four are not needed (pg_batch_align)
+    bool lean = false;
     bool timing = false;
     std::vector<EventPair> events;
     std::vector<hipEvent_t> event_pool;
@@ -195,6 +190,14 @@ struct pg_batch
     std::vector<uint32_t> h_group_of_read;    // per read: its group, PG_NONE for empty reads and reads of the general path
     bool has_general_reads = false;           // some read of the batch takes the general path (then the host re-plans from the flags)
     bool plan_stale = false;                  // d_active changed on the device since the work items were made
+    bool device_plan = false;                 // the work items are the full plan's slots (cascade_rebuild_items), not plan_items' own
+    // ---- the lean gssw stage's tables (pg_batch_align): instance items, extra-instance counters per pair slot, where a read's
+    //      other strand was filled, the reads its pick leaves to the plain pass
+    PgInstItem* d_inst = nullptr;
+    uint32_t* d_lean_extra = nullptr;
+    uint32_t* d_yloc = nullptr;
+    uint8_t* d_lean_undecided = nullptr;
+    size_t cap_lean_pairs = 0, cap_lean_reads = 0;
     uint32_t plan_epoch = 0;                  // pg_ctx::plan_epoch when the upload-time plan was cut
     hipStream_t seed_stream = nullptr;        // the seed stream this batch's path stage ran on
     bool seed_chain = false;                  // the batch's last stage ran on the seed stream (pg_batch_path_align): its count pass and

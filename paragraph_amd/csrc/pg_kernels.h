@@ -44,7 +44,29 @@ struct PgTraceArgs
     pg_result* results;     // [read]
     pg_op* ops;             // compact output
     unsigned long long* ops_counter;
+    // ---- the lean pass (pg_launch_trace_lean): the forward fills are instance items made by pg_lean_build_kernel
+    const PgInstItem* inst;
+    const struct PgPlanSegment* segments;  // the full plan's (group, chunk) runs: the instance item of (pair, read) follows from its run
+    uint32_t n_segments;
+    const uint32_t* yloc;                  // per read: where the forward fill of its OTHER strand is (PG_NONE: not run)
+    uint8_t* undecided;                    // per read, out: 1 = the record needs that fill (the read goes on to the plain pass), 0 = written
 };
+
+// The lean pass's pick: one thread per work-item pair of a chunk, behind its reversed-graph fills (pg_api.hip)
+struct PgLeanBuildArgs
+{
+    uint32_t pair_begin, n_pairs;
+    const PgWorkItem* items;
+    const PgFillSummary* fillsum;
+    const struct PgPlanSegment* segments;
+    uint32_t n_segments;
+    const uint32_t* group_count;
+    PgInstItem* inst;
+    uint32_t* extra;  // per pair slot: instances beyond the first per read that the run starting there has been given
+    uint32_t* yloc;
+};
+hipError_t pg_launch_lean_build(const PgLeanBuildArgs& args, hipStream_t stream);
+hipError_t pg_launch_trace_lean(const PgTraceArgs& args, hipStream_t stream);
 
 hipError_t pg_launch_fill(int V, const PgFillArgs& args, uint32_t n_pairs, bool revg, bool wide32, hipStream_t stream);
 // the lean pass (byte variants only): mode 2 = the reversed-graph fills of the work items, mode 3 = forward-graph fills of args.inst

@@ -135,8 +135,19 @@ struct Emitter
 
 // GL = lanes per read in the FILL that wrote the trace (16, or 32 for the wide variants: two fill wavefronts per work item,
 // reads 0-1 / 2-3, each with its own half of the item's trace and seed regions); this kernel walks with 16 lanes per read either way
-template <int C, bool WIDE, int GL> __device__ __forceinline__ void pg_trace_pair(const PgTraceArgs& a, const uint32_t pair)
+// LEAN (pg_launch_trace_lean; byte variants): the reversed-graph fills of the pair's reads are in its reversed work item as always,
+// the forward-graph fills are INSTANCES (PgInstItem: eight (read, strand) fills per wavefront) -- every read's better strand X, and
+// its other strand Y where the reversed-graph fills already say that X is not unique and Y may be.  GraphAligner.cpp:340-356 with
+// X = the strand with the larger score (the forward strand on a tie; a fill's best score is the same on the graph and on the
+// reversed graph -- an alignment read backwards is an alignment of the reversed read to the reversed graph -- and the record is
+// marked inconsistent if the forward fill of X says otherwise):
+//   X unique                          -> X is returned whatever Y is (both unique: the larger score; Y not unique: the unique one)
+//   X not unique, Y multi on the reversed graph -> neither is unique: the larger score, X
+//   X not unique, Y not multi there   -> Y's forward fill decides (Y unique: Y, else X); not run (X's own forward fill was what made
+//                                        it non-unique): the read is left to the plain pass (a.undecided)
+template <int C, bool WIDE, int GL, bool LEAN = false> __device__ __forceinline__ void pg_trace_pair(const PgTraceArgs& a, const uint32_t pair)
 {
+    static_assert(!LEAN || (!WIDE && GL == PG_GROUP_LANES), "lean pass: byte variants");
     // No LDS and 80 VGPRs: this kernel runs on the second stream UNDER the next chunk's fill, whose 16 wavefronts per CU take
     // all 160 KB of LDS and four times 120 of the 512 VGPRs of a SIMD lane -- a traceback wavefront gets a place when a fill
     // wavefront retires and holds it for its grid-stride loop (pg_trace_blocks: how many do).
@@ -161,22 +172,97 @@ template <int C, bool WIDE, int GL> __device__ __forceinline__ void pg_trace_pai
     const bool revg = (a.flags & PG_AF_REVERSE_GRAPH) != 0;
 
     // ---- GraphAligner.cpp:340-356 ------------------------------------------------------------------
-    const int m0 = fsF[0].multi;
-    const int m1 = both ? fsF[1].multi : 0;
-    const int m2 = revg ? fsR[0].multi : 0;
-    const int m3 = (revg && both) ? fsR[1].multi : 0;
-    const bool fwd_unique = !m0 && !m2;
-    const bool rev_unique = !m1 && !m3;
+    int m0, m1, m2, m3, s;
+    bool unique;
     bool return_reverse = false;
-    if (!fwd_unique && rev_unique && both)
-        return_reverse = true;
-    else if (fwd_unique && !rev_unique)
-        return_reverse = false;
-    else if (both)
-        return_reverse = fsF[0].score < fsF[1].score;
-    const int s = return_reverse ? 1 : 0;
-    const bool unique = return_reverse ? rev_unique : fwd_unique;
-    const PgFillSummary fs = fsF[s];
+    PgFillSummary fs;
+    int score_fwd_strand, score_rc_strand;
+    uint32_t hsel = 0;           // which 16-bit half of the fill's registers (= byte pair of its trace dwords) the walked fill is
+    uint32_t inst_group = grp;   // ... and which 16-lane group of its wavefront
+    const PgInstItem* inp = nullptr;
+    bool other_skipped = false, inconsistent = false;
+    if (LEAN)
+    {
+        m2 = fsR[0].multi;
+        m3 = fsR[1].multi;
+        const int SA = fsR[0].score, SB = fsR[1].score;
+        const int X = SA >= SB ? 0 : 1, Y = 1 - X;
+        // the run of the pair (last segment whose pair_begin <= pair): instance item of X = run start + (rank in the run) / 2, half = its parity
+        uint32_t lo = 0, hi = a.n_segments;
+        while (hi - lo > 1)
+        {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.segments[mid].pair_begin <= pair)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint32_t rs = a.segments[lo].pair_begin;
+        const uint32_t qX = rs + (pair - rs) / 2u, hX = (pair - rs) & 1u;
+        const PgFillSummary fX = a.fillsum[((size_t)(2 * qX) * PG_GROUPS + grp) * 2 + hX];
+        const int mXf = fX.multi, mXr = X ? m3 : m2, mYr = X ? m2 : m3;
+        inconsistent = fX.score != (X ? SB : SA);
+        const uint32_t yl = a.yloc[ridx];
+        int mYf = 0;
+        PgFillSummary fY{};
+        uint32_t qY = 0, gY = 0, hY = 0;
+        if (yl != PG_NONE)
+        {
+            qY = yl >> 3;
+            gY = (yl >> 1) & 3u;
+            hY = yl & 1u;
+            fY = a.fillsum[((size_t)(2 * qY) * PG_GROUPS + gY) * 2 + hY];
+            mYf = fY.multi;
+            inconsistent = inconsistent || fY.score != (X ? SA : SB);
+        }
+        other_skipped = yl == PG_NONE;
+        const bool X_u = !mXf && !mXr;
+        int ret = X;
+        bool undecided = false;
+        if (!X_u && !mYr)
+        {
+            if (yl == PG_NONE)
+                undecided = true;
+            else if (!mYf)
+                ret = Y;
+        }
+        if (a.undecided && writer)
+            a.undecided[ridx] = undecided ? 1 : 0;
+        if (undecided)
+            return;
+        s = ret;
+        return_reverse = ret == 1;
+        unique = ret == X ? X_u : true;  // (Y is only ever returned as the unique one)
+        m0 = X == 0 ? mXf : mYf;
+        m1 = X == 1 ? mXf : mYf;
+        fs = ret == X ? fX : fY;
+        score_fwd_strand = X == 0 ? fX.score : (yl != PG_NONE ? fY.score : SA);
+        score_rc_strand = X == 1 ? fX.score : (yl != PG_NONE ? fY.score : SB);
+        inp = a.inst + (ret == X ? qX : qY);
+        hsel = ret == X ? hX : hY;
+        inst_group = ret == X ? grp : gY;
+    }
+    else
+    {
+        m0 = fsF[0].multi;
+        m1 = both ? fsF[1].multi : 0;
+        m2 = revg ? fsR[0].multi : 0;
+        m3 = (revg && both) ? fsR[1].multi : 0;
+        const bool fwd_unique = !m0 && !m2;
+        const bool rev_unique = !m1 && !m3;
+        if (!fwd_unique && rev_unique && both)
+            return_reverse = true;
+        else if (fwd_unique && !rev_unique)
+            return_reverse = false;
+        else if (both)
+            return_reverse = fsF[0].score < fsF[1].score;
+        s = return_reverse ? 1 : 0;
+        unique = return_reverse ? rev_unique : fwd_unique;
+        fs = fsF[s];
+        score_fwd_strand = fsF[0].score;
+        score_rc_strand = both ? fsF[1].score : -1;
+        hsel = (uint32_t)s;
+    }
 
     pg_result res;
     res.graph_pos = 0;
@@ -184,13 +270,21 @@ template <int C, bool WIDE, int GL> __device__ __forceinline__ void pg_trace_pai
     res.mapq = unique ? 60 : 0;
     res.is_unique = unique ? 1 : 0;
     res.returned_reverse = return_reverse ? 1 : 0;
-    res.multi_mask = (uint8_t)(m0 | (m1 << 1) | (m2 << 2) | (m3 << 3));
+    res.multi_mask = (uint8_t)(m0 | (m1 << 1) | (m2 << 2) | (m3 << 3) | (LEAN && other_skipped ? PG_MULTI_OTHER_FWD_SKIPPED : 0));
     res.n_ops = 0;
     res.ops_off = 0;
-    res.strand_score[0] = (int16_t)fsF[0].score;
-    res.strand_score[1] = (int16_t)(both ? fsF[1].score : -1);
+    res.strand_score[0] = (int16_t)score_fwd_strand;
+    res.strand_score[1] = (int16_t)score_rc_strand;
     res.clipped = 0;
     res.status = 0;
+    if (LEAN && inconsistent)
+    {
+        // (a forward fill whose best score is not the reversed-graph fill's: the lean pick does not hold for this read)
+        res.status = 2;
+        if (writer)
+            a.results[ridx] = res;
+        return;
+    }
 
     if (fs.score <= 0)
     {
@@ -206,10 +300,10 @@ template <int C, bool WIDE, int GL> __device__ __forceinline__ void pg_trace_pai
     const char* __restrict__ refc = a.seqchars + gdev.seq_off;
     // where this read's lanes sit in the fill wavefront's records, and which half of the item's regions that wavefront owns
     constexpr uint32_t FILL_GROUPS = 64 / GL;
-    const uint32_t half = grp / FILL_GROUPS, lane0 = (grp % FILL_GROUPS) * GL;
-    const uint8_t* __restrict__ trace = a.workspace + fw->trace_off
+    const uint32_t half = LEAN ? 0u : grp / FILL_GROUPS, lane0 = LEAN ? inst_group * GL : (grp % FILL_GROUPS) * GL;
+    const uint8_t* __restrict__ trace = a.workspace + (LEAN ? inp->trace_off : fw->trace_off)
         + (size_t)half * pg_fill_steps_lanes(gdev.dir[0].ncols, GL) * 64 * (2 * C);
-    const uint32_t* __restrict__ seed = (const uint32_t*)(a.workspace + fw->seed_off) + (size_t)half * gdev.dir[0].n_nodes * 64 * (WIDE ? 2 * C : C);
+    const uint32_t* __restrict__ seed = (const uint32_t*)(a.workspace + (LEAN ? inp->seed_off : fw->seed_off)) + (size_t)half * gdev.dir[0].n_nodes * 64 * (WIDE ? 2 * C : C);
 
     auto qchar = [&](int j) -> uint32_t {
         return s == 0 ? upper_c((uint8_t)bases[j]) : comp_c((uint8_t)bases[L - 1 - j]);
@@ -222,13 +316,13 @@ template <int C, bool WIDE, int GL> __device__ __forceinline__ void pg_trace_pai
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
         if (WIDE)
             return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * (2 * C) + 2 * r] >> (16 * s)) & 0x3FFu);
-        return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * C + r] >> (8 * s)) & 0xFFu);
+        return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * C + r] >> (8 * hsel)) & 0xFFu);
     };
     auto seedE = [&](uint32_t node, int j) -> int {
         const uint32_t kq = (uint32_t)j / C, r = (uint32_t)j % C;
         if (WIDE)
             return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * (2 * C) + 2 * r + 1] >> (16 * s)) & 0x3FFu);
-        return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * C + r] >> (16 + 8 * s)) & 0xFFu);
+        return (int)((seed[((size_t)node * 64 + (lane0 + kq)) * C + r] >> (16 + 8 * hsel)) & 0xFFu);
     };
 
     // A trace dword holds diagonal neighbours (pg_fill.hip, column()): the odd row r of the step it was written in and the even
@@ -245,7 +339,7 @@ template <int C, bool WIDE, int GL> __device__ __forceinline__ void pg_trace_pai
         const uint32_t step = col + kq + ((r & 1u) ^ 1u);
         const size_t dw = (((size_t)(step >> 1) * (C / 2) + r / 2) * 64 + (lane0 + kq)) * 2 + (step & 1u);
         // (non-temporal: a trace byte is read once, and what the walk pulls through the L2 competes with the next chunk's fill)
-        return (int)(((uint32_t)__builtin_nontemporal_load(&trace[dw * 4 + (r & 1u) + 2u * (uint32_t)s]) - tau) & 0xFFu);
+        return (int)(((uint32_t)__builtin_nontemporal_load(&trace[dw * 4 + (r & 1u) + 2u * hsel]) - tau) & 0xFFu);
     };
     // The byte is the whole score in the byte variants (reads <= 250 bases).  In the wide ones it is the score modulo 256: the
     // walk itself carries the exact score (`sc`), and every test below relates the scores of cells that are neighbours or on
@@ -625,6 +719,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_TRACE_WPE
         pg_trace_pair<C, WIDE, GL>(a, a.pair_begin + p);
 }
 
+template <int C> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_TRACE_WPE, PG_TRACE_WPE))) void pg_trace_lean_kernel(PgTraceArgs a)
+{
+    for (uint32_t p = blockIdx.x; p < a.n_pairs; p += gridDim.x)
+        pg_trace_pair<C, false, PG_GROUP_LANES, true>(a, a.pair_begin + p);
+}
+
 // Wavefronts of one traceback launch.  The walk is a chain of dependent loads that each pull a whole 128-byte line for a few
 // bytes (profiles/r03_sector_probe.json), and it runs under the next chunk's fill, which writes 3.5 TB/s the whole time.
 // Measured with stand-in kernels in the walk's place (profiles/r03_trace_tax.md): wavefronts that only sit beside the fill
@@ -651,6 +751,30 @@ template <int C, bool WIDE, int GL = PG_GROUP_LANES> static hipError_t launch_tr
 {
     hipLaunchKernelGGL((pg_trace_kernel<C, WIDE, GL>), dim3(pg_trace_blocks(args.n_pairs)), dim3(64), 0, stream, args);
     return hipGetLastError();
+}
+
+template <int C> static hipError_t launch_trace_lean_c(const PgTraceArgs& args, hipStream_t stream)
+{
+    hipLaunchKernelGGL((pg_trace_lean_kernel<C>), dim3(pg_trace_blocks(args.n_pairs)), dim3(64), 0, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t pg_launch_trace_lean(const PgTraceArgs& args, hipStream_t stream)
+{
+    if (args.n_pairs == 0)
+        return hipSuccess;
+    switch (args.C)
+    {
+    case 2: return launch_trace_lean_c<2>(args, stream);
+    case 4: return launch_trace_lean_c<4>(args, stream);
+    case 6: return launch_trace_lean_c<6>(args, stream);
+    case 8: return launch_trace_lean_c<8>(args, stream);
+    case 10: return launch_trace_lean_c<10>(args, stream);
+    case 12: return launch_trace_lean_c<12>(args, stream);
+    case 14: return launch_trace_lean_c<14>(args, stream);
+    case 16: return launch_trace_lean_c<16>(args, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t pg_launch_trace(const PgTraceArgs& args, hipStream_t stream)

@@ -107,6 +107,9 @@ def parse_args():
                     help="timed steps of the reported-only leg `exact_shortcut` (the headline workload with pg_batch_retire_exact_matches "
                          "in front of the gssw stage: reads whose alignRead record one exact full-length match forces skip their "
                          "fills; records and count table compared with the plain step's); 0 = leave it out")
+    ap.add_argument("--plain-steps", type=int, default=2,
+                    help="timed steps of the reported-only leg `plain_stage` (the headline workload through the plain gssw stage, four fills "
+                         "per read, and the lean step's records against its records); 0 = leave it out")
     ap.add_argument("--no-e2e-shortcut", action="store_true", help="leave the e2e leg's `with_exact_shortcut` passes out (A/B of the legs behind them)")
     ap.add_argument("--e2e-steps", type=int, default=3,
                     help="timed passes of the BAM -> genotypes leg (0 = skip): every pass takes ALL sites of the e2e data set from the "
@@ -1403,6 +1406,9 @@ def main_rank(args):
             rc = 3
         if out.get("e2e") and out["e2e"]["mismatches"]:
             rc = 3
+        pl = out.get("plain_stage")
+        if pl and (pl["records_differing_from_the_lean_step"] or not pl["cigar_strings_equal"]):
+            rc = 3
         sc = out.get("exact_shortcut")
         if sc and (sc["records_differing_from_the_plain_step"] or not sc["cigar_elements_equal"] or not sc["count_table_equal"]):
             rc = 3
@@ -1507,6 +1513,39 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
                       "note": "`value` is measured WITH the all-reduce in every step (at N = 1 through a world-size-1 RCCL "
                               "communicator = the code path of N = 8); `without` = the same steps right after, no collective"}
         log("plain region %.3fs" % elapsed_plain)
+    # Reported only: the same steps through the PLAIN gssw stage (pg_ctx_set_lean(0): four fills per read, all four multi flags), and
+    # the lean stage's records of the last timed step against its records -- every field of pg_result; of multi_mask the bits of the
+    # fills that ran
+    plain_stage = None
+    if args.plain_steps > 0 and tim.get("lean_rev_launches", 0) > 0:
+        ctx.set_lean(False)
+        for _ in range(min(1, args.warmup)):
+            step(red)
+        env["barrier"]()
+        elapsed_pl = timed(red, args.plain_steps)
+        res_pl, ops_pl = batches[(step_no[0] - 1) & 1].download()
+        ctx.set_lean(True)
+        differ = np.zeros(len(res), dtype=bool)
+        for f in ("graph_pos", "score", "mapq", "is_unique", "returned_reverse", "n_ops", "clipped", "status"):
+            differ |= res[f] != res_pl[f]
+        differ |= (res["strand_score"] != res_pl["strand_score"]).any(axis=1)
+        skipped = (res["multi_mask"] & 0x10) != 0
+        other_bit = np.where(res["returned_reverse"] != 0, 1, 2).astype(np.uint8)  # bit of the forward fill of the strand not returned
+        mask = np.where(skipped, 0x0F & ~other_bit, 0x0F).astype(np.uint8)
+        differ |= (res["multi_mask"] & mask) != (res_pl["multi_mask"] & mask)
+        def flat(r, o):  # every read's CIGAR elements, read after read (ops_off is an allocation order, not content)
+            n_ops = r["n_ops"].astype(np.int64)
+            first = np.cumsum(n_ops) - n_ops
+            return o[np.repeat(r["ops_off"].astype(np.int64) - first, n_ops) + np.arange(int(n_ops.sum()), dtype=np.int64)]
+
+        cig_same = bool(np.array_equal(flat(res, ops), flat(res_pl, ops_pl))) if not differ.any() else False
+        plain_stage = {"reads_per_s": args.reads * world * args.plain_steps / elapsed_pl, "ms_per_step": elapsed_pl / args.plain_steps * 1e3,
+                       "steps": args.plain_steps, "value_vs_plain": (args.reads * world * args.steps / elapsed) / (args.reads * world * args.plain_steps / elapsed_pl),
+                       "records_differing_from_the_lean_step": int(differ.sum()), "cigar_strings_equal": cig_same,  # (their elements, read after read)
+                       "forward_fills_of_the_other_strand_not_run": int(skipped.sum()),
+                       "note": "pg_ctx_set_lean(0): GraphAligner::alignRead's four fills for every read; same reads, same batches, right "
+                               "after the timed region.  Compared: every pg_result field (ops_off aside) and the rendered CIGAR strings"}
+        log("plain stage %.3fs" % elapsed_pl)
     # Reported only, never `value`: the same workload with the EXACT shortcut in front of the gssw stage
     # (pg_batch_retire_exact_matches, include/paragraph_amd.h).  The path kernel runs over every read; a read whose
     # alignRead(AF_ALL) record its one exact full-length match forces keeps that record and skips its four fills, every other
@@ -1629,7 +1668,10 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
     value = reads_total / elapsed
     b_alg = b_alg_total / args.reads  # 6*L*G + L + 64 per read
     b_alg_h = 2 * L * G + L + 64      # the same with H only (the kernel re-derives E / F in the traceback)
+    # (lean stage: a chunk's forward launch runs on a stream of its own beside the next chunk's reversed-graph launch, so the sum of
+    #  the launches' durations can exceed the wall clock; the fraction of peak is then taken against the longer of the two: conservative)
     fill_s = tim["fill_ms"] / 1e3
+    lean_on = tim.get("lean_rev_launches", 0) > 0
     reads_per_fill_leg = args.reads * args.steps  # this rank's fill launches
     achieved_gbs = reads_per_fill_leg * b_alg / fill_s / 1e9 if fill_s > 0 else 0.0
     launches = max(1, tim["fill_launches"])
@@ -1652,16 +1694,26 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
         "value_streaming": (args.reads / t_stream) if t_stream else None,
         "config": {
             "workload": "configs[1]: 1 DEL graph (200bp flanks, nodes 201/100/201), %d synthetic %dbp reads per GPU, "
-                        "GraphAligner::alignRead(AF_ALL) = 4 fills + strand pick + traceback per read, then "
+                        "GraphAligner::alignRead(AF_ALL) per read -- the lean gssw stage: the record the reference reads off its 4 fills from the 3 "
+                        "(a few per cent of the reads: 4) that can change it, strand pick + traceback -- then "
                         "filters + node/edge/sequence counts%s"
                         % (args.reads, L, " + 1 all-reduce of the counter table per step" if world > 1 else ""),
             "reads_per_gpu": args.reads, "read_len": L, "graph_len": G, "parallelism": "reads x%d" % world,
         },
-        "cell_updates_per_s": 4.0 * L * G * reads_total / elapsed,  # whole step (fill + traceback + count), all ranks
+        # whole step (fill + traceback + count), all ranks: the reference's four fills per read (what the records stand for) ...
+        "cell_updates_per_s": 4.0 * L * G * reads_total / elapsed,
+        # ... and the cells the device did update (lean stage: three fills per read; the fourth fills of a few per cent not counted)
+        "cell_updates_computed_per_s": tim["cells"] * world / elapsed,
         "roofline": {
             **roofline_head(roof_extra, achieved_gbs),
-            "kernel": "pg_fill_kernel<%d, false, 16>" % (2 * ((L + 31) // 32)),
+            "kernel": ("pg_fill_lean_kernel<%d, 2> (reversed-graph fills of both strands) + pg_fill_lean_kernel<%d, 3> (forward-graph fills of "
+                       "the instance items): the lean gssw stage's two fill launches per chunk, taken together" % ((2 * ((L + 31) // 32),) * 2))
+                      if lean_on else "pg_fill_kernel<%d, false, 16>" % (2 * ((L + 31) // 32)),
             "launches": int(tim["fill_launches"]),
+            "lean": {"rev_launches": int(tim["lean_rev_launches"]), "rev_ms": tim["lean_rev_ms"], "fwd_launches": int(tim["lean_fwd_launches"]),
+                     "fwd_ms": tim["lean_fwd_ms"],
+                     "note": "durations by HIP events on each launch's own stream; the forward launch of a chunk overlaps the reversed-graph "
+                             "launch of the next one in time"} if lean_on else None,
             "avg_launch_ms": tim["fill_ms"] / max(1, tim["fill_launches"]),
             **roof_extra,
             "alg_bytes_per_read": b_alg,
@@ -1692,6 +1744,8 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
                            "over %d rank(s)" % world},
         "dist": dist_info,
     }
+    if plain_stage:
+        out["plain_stage"] = plain_stage
     if shortcut:
         out["exact_shortcut"] = shortcut
     if collective:

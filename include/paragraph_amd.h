@@ -158,6 +158,13 @@ typedef struct pg_timing
     uint64_t fills;       /* (read, strand, graph direction) fills performed */
     uint64_t cells;       /* DP cell updates performed (useful cells, no padding) */
     uint64_t trace_bytes; /* bytes of traceback state written by the fill kernel */
+    /* the lean gssw stage's two fill launches per chunk (both are also in fill_ms; fill_launches counts the chunk once).  The forward
+     * launch runs on a stream of its own beside the next chunk's reversed-graph launch: the two durations overlap in time, their sum
+     * can exceed the wall clock */
+    double lean_rev_ms;   /* reversed-graph fills of both strands */
+    double lean_fwd_ms;   /* pick + forward-graph fills of the instance items */
+    uint64_t lean_rev_launches;
+    uint64_t lean_fwd_launches;
 } pg_timing;
 
 /* Host threads that wait for `device` (pg_batch_wait, downloads, pg_ctx_sync) sleep instead of spinning:
@@ -172,12 +179,13 @@ const char* pg_strerror(pg_status st);
 const char* pg_last_error(const pg_ctx* ctx);
 /* bytes of HBM the ctx may use for traceback state per chunk (default 8 GiB) */
 pg_status pg_ctx_set_workspace_bytes(pg_ctx* ctx, uint64_t bytes);
-/* The LEAN gssw stage (off by default; PG_LEAN=1 in the environment turns it on for every new context): pg_batch_align with
+/* The LEAN gssw stage (ON by default; pg_ctx_set_lean(ctx, 0), or PG_LEAN=0 in the environment for every new context, gives the plain
+ * four fills per read and all four multi_mask bits): pg_batch_align with
  * CIGAR + both strands + reversed graph -- GraphAligner::alignRead(AF_ALL), GraphAligner.cpp:308-404 -- computes the record from THREE
  * fills per read where the fourth cannot change it: the reversed-graph fills of both strands first (a fill's best score is the same
  * on the graph and on the reversed graph), then the forward-graph fill of the higher-scoring strand X, and that of the other strand
- * only where X is not unique and the other strand still may be (GraphAligner.cpp:340-356).  Reads whose X turns out non-unique
- * through its own forward fill are re-aligned by the plain four fills in the same call.  Every field of the reference's Read is what the plain
+ * only where X is not unique and the other strand still may be (GraphAligner.cpp:340-356) -- known from the reversed-graph fills, or
+ * found by X's own forward fill (those reads get the fourth fill in a second, small launch of the same call).  Every field of the reference's Read is what the plain
  * stage writes; of pg_result, multi_mask's bit of a forward fill that did not run reads 0 and PG_MULTI_OTHER_FWD_SKIPPED is set.
  * Reads of up to 250 bases; longer ones (and batches with general-path reads) run the plain stage.  tests/test_gpu_lean.py. */
 pg_status pg_ctx_set_lean(pg_ctx* ctx, int on);

@@ -332,8 +332,8 @@ extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
     // reads of 251..512 bases: 32 lanes per read (two wavefronts per work item); PG_WIDE16=1 = the 16-lane kernels, for A/B timing
     ctx->wide32 = getenv("PG_WIDE16") == nullptr;
     {
-        const char* le = getenv("PG_LEAN");  // (the default of pg_ctx_set_lean)
-        ctx->lean = le && le[0] != '0';
+        const char* le = getenv("PG_LEAN");  // (the default of pg_ctx_set_lean: on; PG_LEAN=0 = the plain four fills)
+        ctx->lean = !(le && le[0] == '0');
     }
     {
         int lds = 0;
@@ -385,6 +385,8 @@ extern "C" pg_status pg_ctx_set_fill_streams(pg_ctx* ctx, int n)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_fill2));
+    if (ctx->stream_lean)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_lean));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     for (auto& e : ctx->region_free)
         e = nullptr;
@@ -402,6 +404,8 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
         (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream_fill2)
         (void)hipStreamSynchronize(ctx->stream_fill2);
+    if (ctx->stream_lean)
+        (void)hipStreamSynchronize(ctx->stream_lean);
     if (ctx->stream_seed)
         (void)hipStreamSynchronize(ctx->stream_seed);
     for (hipStream_t s : ctx->stream_seed_more)
@@ -431,6 +435,8 @@ extern "C" void pg_ctx_destroy(pg_ctx* ctx)
         (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream_fill2)
         (void)hipStreamDestroy(ctx->stream_fill2);
+    if (ctx->stream_lean)
+        (void)hipStreamDestroy(ctx->stream_lean);
     if (ctx->stream_seed)
         (void)hipStreamDestroy(ctx->stream_seed);
     for (hipStream_t s : ctx->stream_seed_more)
@@ -460,6 +466,8 @@ extern "C" pg_status pg_ctx_sync(pg_ctx* ctx)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_copy));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_fill2));
+    if (ctx->stream_lean)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_lean));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_seed));
     for (hipStream_t s : ctx->stream_seed_more)
         if (s)
@@ -527,6 +535,8 @@ extern "C" pg_status pg_ctx_sync_compute(pg_ctx* ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_fill2));
+    if (ctx->stream_lean)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_lean));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_seed));
     for (hipStream_t s : ctx->stream_seed_more)
         if (s)
@@ -798,6 +808,8 @@ static pg_status drain_events(pg_ctx* ctx)
 {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_fill2));
+    if (ctx->stream_lean)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_lean));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     for (auto& e : ctx->events)
     {
@@ -807,6 +819,19 @@ static pg_status drain_events(pg_ctx* ctx)
         {
             ctx->acc.fill_ms += ms;
             ctx->acc.fill_launches++;
+        }
+        else if (e.kind == 2)
+        {
+            ctx->acc.fill_ms += ms;
+            ctx->acc.fill_launches++;
+            ctx->acc.lean_rev_ms += ms;
+            ctx->acc.lean_rev_launches++;
+        }
+        else if (e.kind == 3)
+        {
+            ctx->acc.fill_ms += ms;
+            ctx->acc.lean_fwd_ms += ms;
+            ctx->acc.lean_fwd_launches++;
         }
         else
         {
@@ -1217,10 +1242,10 @@ static void batch_free_device(pg_batch* b)
     (void)pg_dev_free(b->d_inst);
     (void)pg_dev_free(b->d_lean_extra);
     (void)pg_dev_free(b->d_yloc);
-    (void)pg_dev_free(b->d_lean_undecided);
+    (void)pg_dev_free(b->d_lean_ucount);
+    (void)pg_dev_free(b->d_lean_ulist);
     b->d_inst = nullptr;
-    b->d_lean_extra = b->d_yloc = nullptr;
-    b->d_lean_undecided = nullptr;
+    b->d_lean_extra = b->d_yloc = b->d_lean_ucount = b->d_lean_ulist = nullptr;
     b->cap_lean_pairs = b->cap_lean_reads = 0;
     b->has_active = false;
     (void)pg_dev_free(b->d_group_of_read2);
@@ -1539,6 +1564,10 @@ static pg_status ensure_ctx_workspace(pg_ctx* ctx, const pg_batch* b)
     {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_fill2));
+        if (ctx->stream_lean)
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_lean));
+    if (ctx->stream_lean)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_lean));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
         if (ctx->workspace)
             HIP_TRY(ctx, hipFree(ctx->workspace));
@@ -1941,6 +1970,8 @@ __global__ void pg_lean_init_kernel(PgLeanBuildArgs a)
     it.seed_off = fw.seed_off;
     a.inst[p] = it;
     a.extra[p] = 0;
+    if (i == 0)
+        *a.ucount = 0;
 }
 
 // build: per read of the pair, X = the strand whose reversed-graph fill scored higher (the forward strand on a tie) goes to the instance
@@ -1986,14 +2017,14 @@ __global__ void pg_lean_build_kernel(PgLeanBuildArgs a)
         uint32_t yl = PG_NONE;
         if (mXr && !mYr)
         {
+            // the run's instance slots, eight per pair slot: X of (pair rank r, group g) has 8 (r / 2) + 4 (r & 1) + g, i.e. the first
+            // 4 ne; the others follow in the order they ask (an odd ne leaves them the second half of the last X item) -- at most
+            // one per read, so they always fit; slots are handed out in order, so an item is empty iff its (half 0, group 0) is
             const uint32_t e = atomicAdd(&a.extra[rs], 1u);
-            const uint32_t qq = rs + (ne + 1u) / 2u + e / 8u;
-            if (qq < rs + s.n_pairs)
-            {
-                const uint32_t slot = e & 7u;  // filled from (half 0, group 0) on: an item is empty iff that entry is
-                a.inst[qq].inst[slot >> 2][slot & 3u] = ridx | (X ? 0u : PG_INST_RC);
-                yl = (qq << 3) | ((slot & 3u) << 1) | (slot >> 2);
-            }
+            const uint32_t t = 4u * ne + e;
+            const uint32_t qq = rs + t / 8u, within = t & 7u;
+            a.inst[qq].inst[within >> 2][within & 3u] = ridx | (X ? 0u : PG_INST_RC);
+            yl = (qq << 3) | ((within & 3u) << 1) | (within >> 2);
         }
         a.yloc[ridx] = yl;
     }
@@ -2366,8 +2397,8 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             if (done)
                 return;
             hipEvent_t e;
-            for (hipStream_t fs : { c->stream, c->stream_fill2 })
-                if (get_sync_event(c, &e) == hipSuccess)
+            for (hipStream_t fs : { c->stream, c->stream_fill2, c->stream_lean })
+                if (fs && get_sync_event(c, &e) == hipSuccess)
                 {
                     if (hipEventRecord(e, fs) == hipSuccess)
                         (void)hipStreamWaitEvent(c->stream2, e, 0);
@@ -2428,6 +2459,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         fa.bases = b->d_bases;
         fa.workspace = ws;
         fa.fillsum = b->d_fillsum;
+        hipStream_t done_stream = fill_stream;  // the stream the chunk's last fill launch is on
         EventPair ev{};
         if (ctx->timing)
         {
@@ -2440,6 +2472,12 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         {
             fa.inst = b->d_inst;
             HIP_TRY(ctx, pg_launch_fill_lean(ch.C, fa, n_pairs, 2, fill_stream));
+            if (ctx->timing)
+            {
+                ev.kind = 2;
+                HIP_TRY(ctx, hipEventRecord(ev.b, fill_stream));
+                ctx->events.push_back(ev);
+            }
             PgLeanBuildArgs la{};
             la.pair_begin = ch.pair_begin;
             la.n_pairs = n_pairs;
@@ -2451,22 +2489,50 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             la.inst = b->d_inst;
             la.extra = b->d_lean_extra;
             la.yloc = b->d_yloc;
-            HIP_TRY(ctx, pg_launch_lean_build(la, fill_stream));
-            HIP_TRY(ctx, pg_launch_fill_lean(ch.C, fa, n_pairs, 3, fill_stream));
+            la.ucount = b->d_lean_ucount + ch.pair_begin;
+            // The pick and the forward launch go to a stream of their own: the next chunk's reversed-graph fills on the fill stream
+            // do not wait for them.
+            // (one priority level up, like the second stream: the forward launch then takes the slots a draining reversed-graph launch
+            // frees before the next chunk's reversed-graph fills do, its traceback starts that much earlier, and the two kinds of
+            // wavefront -- one writes the H trace, the other nothing -- share the machine instead of taking turns at the memory:
+            // 38.9 -> 36.4 ms per million reads, profiles/r06_lean_streams_ab.jsonl.  Made by the first lean stage: an idle
+            // high-priority stream is not free, pg_internal.h.)
+            if (!ctx->stream_lean && !getenv("PG_LEAN_ONE_STREAM"))
+                HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream_lean, hipStreamNonBlocking, ctx->side_priority));
+            if (ctx->stream_lean)
+            {
+                hipEvent_t rev_done;
+                HIP_TRY(ctx, get_sync_event(ctx, &rev_done));
+                HIP_TRY(ctx, hipEventRecord(rev_done, fill_stream));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_lean, rev_done, 0));
+                ctx->sync_events_in_flight.push_back(rev_done);
+                done_stream = ctx->stream_lean;
+            }
+            if (ctx->timing)
+            {
+                HIP_TRY(ctx, get_event(ctx, &ev.a));
+                HIP_TRY(ctx, get_event(ctx, &ev.b));
+                ev.kind = 3;
+                HIP_TRY(ctx, hipEventRecord(ev.a, done_stream));
+            }
+            HIP_TRY(ctx, pg_launch_lean_build(la, done_stream));
+            HIP_TRY(ctx, pg_launch_fill_lean(ch.C, fa, n_pairs, 3, done_stream));
         }
         else
             HIP_TRY(ctx, pg_launch_fill(ch.C, fa, n_pairs, revg, ctx->wide32, fill_stream));
         if (ctx->timing)
         {
-            HIP_TRY(ctx, hipEventRecord(ev.b, fill_stream));
+            HIP_TRY(ctx, hipEventRecord(ev.b, done_stream));
             ctx->events.push_back(ev);
-            ctx->acc.fills += revg ? ch.fills : ch.fills / 2;
-            ctx->acc.cells += revg ? ch.cells : ch.cells / 2;
-            ctx->acc.trace_bytes += ch.trace_bytes;
+            // (lean: two reversed-graph fills and one forward-graph fill per read -- the fourth fills of the reads that need them, a
+            // few per cent, are not counted; the forward-graph fills of half the wavefronts write the trace)
+            ctx->acc.fills += lean_chunk ? ch.fills / 4 * 3 : revg ? ch.fills : ch.fills / 2;
+            ctx->acc.cells += lean_chunk ? ch.cells / 4 * 3 : revg ? ch.cells : ch.cells / 2;
+            ctx->acc.trace_bytes += lean_chunk ? ch.trace_bytes / 2 : ch.trace_bytes;
         }
         hipEvent_t fill_done;
         HIP_TRY(ctx, get_sync_event(ctx, &fill_done));
-        HIP_TRY(ctx, hipEventRecord(fill_done, fill_stream));
+        HIP_TRY(ctx, hipEventRecord(fill_done, done_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, fill_done, 0));
         ctx->sync_events_in_flight.push_back(fill_done);
         PgTraceArgs ta{};
@@ -2501,8 +2567,18 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             ta.segments = b->d_segments;
             ta.n_segments = (uint32_t)b->h_segments.size();
             ta.yloc = b->d_yloc;
-            ta.undecided = b->d_lean_undecided;
+            ta.inst_rw = b->d_inst;
+            ta.yloc_rw = b->d_yloc;
+            ta.extra = b->d_lean_extra;
+            ta.group_count = b->d_group_count;
+            ta.ucount = b->d_lean_ucount + ch.pair_begin;           // (one counter and 4 list entries per pair slot: a chunk's are its own)
+            ta.ulist = b->d_lean_ulist + 4 * (size_t)ch.pair_begin;
             HIP_TRY(ctx, pg_launch_trace_lean(ta, ctx->stream2));
+            // the reads whose record needs the fourth fill after all (X not unique through its own forward fill, a per cent or two):
+            // that fill -- the instances the first look queued -- and a second look at them, here on the second stream, under the
+            // next chunk's fills
+            HIP_TRY(ctx, pg_launch_fill_lean(ch.C, fa, n_pairs, 4, ctx->stream2));
+            HIP_TRY(ctx, pg_launch_trace_lean2(ta, ctx->stream2));
         }
         else
             HIP_TRY(ctx, pg_launch_trace(ta, ctx->stream2));
@@ -2525,10 +2601,11 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     // trace) already say which strand X scores higher, and the record only ever needs the forward-graph fill of the OTHER strand when
     // X turns out not to be unique while that strand still may be.  Pass 1, per chunk: reversed-graph fills of every read; a pick
     // kernel packs the X strands -- eight reads' worth per wavefront, one per (16-lane group, register half) -- and the other strands
-    // that are already known to be needed into instance items; forward-graph fills of those; pick + traceback.  Pass 2: the reads pass
-    // 1 could not decide (X not unique because of its own forward fill; a per cent or two) through the plain four fills, on the work
-    // items re-made for them on the device.  Same records as the plain stage field by field, except multi_mask's bit of a forward fill
-    // that did not run (PG_MULTI_OTHER_FWD_SKIPPED says so).  Byte variants (reads <= 250 bases); other chunks run plain in pass 1.
+    // that are already known to be needed into instance items; forward-graph fills of those; pick + traceback.  The reads this cannot
+    // decide (X not unique because of its own forward fill; a per cent or two) get the other strand's instance queued by the traceback
+    // itself; a second, small forward launch and a second look at those reads follow on the SECOND stream, under the next chunk's fills.
+    // Same records as the plain stage field by field, except multi_mask's bit of a forward fill that did not run
+    // (PG_MULTI_OTHER_FWD_SKIPPED says so).  Byte variants (reads <= 250 bases); other chunks run the plain stage.
     const bool lean = ctx->lean && (flags & PG_AF_CIGAR) && (flags & PG_AF_BOTH_STRANDS) && revg && !b->has_general_reads && b->gen_idx.empty()
         && b->n_reads && !b->groups.empty();
     if (lean)
@@ -2547,25 +2624,17 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             b->park(b->d_inst);
             b->park(b->d_lean_extra);
             b->park(b->d_yloc);
-            b->park(b->d_lean_undecided);
+            b->park(b->d_lean_ucount);
+            b->park(b->d_lean_ulist);
             b->d_inst = nullptr;
-            b->d_lean_extra = b->d_yloc = nullptr;
-            b->d_lean_undecided = nullptr;
+            b->d_lean_extra = b->d_yloc = b->d_lean_ucount = b->d_lean_ulist = nullptr;
             b->cap_lean_pairs = b->full_pairs + b->full_pairs / 8 + 16;
             b->cap_lean_reads = (size_t)b->n_reads + b->n_reads / 8 + 16;
             HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_inst, b->cap_lean_pairs * sizeof(PgInstItem)));
             HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_lean_extra, b->cap_lean_pairs * sizeof(uint32_t)));
             HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_yloc, b->cap_lean_reads * sizeof(uint32_t)));
-            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_lean_undecided, b->cap_lean_reads));
-        }
-        HIP_TRY(ctx, hipMemsetAsync(b->d_lean_undecided, 0, b->n_reads, ctx->stream));  // (reads of chunks that run plain, inactive reads)
-        {
-            // (the second stream must see the memset: the traceback writes the flags)
-            hipEvent_t e1;
-            HIP_TRY(ctx, get_sync_event(ctx, &e1));
-            HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, e1, 0));
-            ctx->sync_events_in_flight.push_back(e1);
+            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_lean_ucount, b->cap_lean_pairs * sizeof(uint32_t)));
+            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_lean_ulist, 4 * b->cap_lean_pairs * sizeof(uint32_t)));
         }
         for (const Chunk& ch : b->chunks)
         {
@@ -2573,35 +2642,6 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             if (cs != PG_OK)
                 return cs;
         }
-        // pass 2: the undecided reads (the list and item kernels on the main stream, behind pass 1's last traceback)
-        {
-            hipEvent_t e2;
-            HIP_TRY(ctx, get_sync_event(ctx, &e2));
-            HIP_TRY(ctx, hipEventRecord(e2, ctx->stream2));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, e2, 0));
-            if (ctx->fill_streams == 2)
-                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_fill2, e2, 0));
-            ctx->sync_events_in_flight.push_back(e2);
-        }
-        const pg_status rp2 = cascade_rebuild_items(ctx, b, ctx->stream, b->d_lean_undecided);
-        if (rp2 != PG_OK)
-            return rp2;
-        {
-            hipEvent_t e3;
-            HIP_TRY(ctx, get_sync_event(ctx, &e3));
-            HIP_TRY(ctx, hipEventRecord(e3, ctx->stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, e3, 0));
-            if (ctx->fill_streams == 2)
-                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_fill2, e3, 0));
-            ctx->sync_events_in_flight.push_back(e3);
-        }
-        for (const Chunk& ch : b->chunks)
-        {
-            const pg_status cs = run_chunk(ch, false);
-            if (cs != PG_OK)
-                return cs;
-        }
-        b->plan_stale = true;  // (the work items are those of pass 2: the next stage re-makes them for the batch's own mask)
     }
     else
         for (const Chunk& ch : b->chunks)

@@ -39,6 +39,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <stdlib.h>
+
 #include "pg_device.h"
 #include "pg_kernels.h"
 
@@ -136,6 +139,8 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // (instance items are filled from (half 0, group 0) on)
     if ((INST ? inp->inst[0][0] : itp->read[(int)half * GROUPS]) == PG_NONE)
         return;
+    if (INST && a.both_dirs == 4u && inp->pad == 0u)
+        return;  // (the lean stage's second forward launch: only the items the traceback's first look added instances to)
     const uint32_t graph = INST ? inp->graph : itp->graph;
     const uint64_t item_seed_off = INST ? inp->seed_off : itp->seed_off, item_trace_off = INST ? inp->trace_off : itp->trace_off;
     const PgGraphDir gd = a.graphs[graph].dir[DIR];
@@ -867,16 +872,39 @@ template <int C, int MODE> __global__ __launch_bounds__(64) void pg_fill_lean_ke
     if (MODE == 2)
         pg_fill_body<C, 1, false, PG_GROUP_LANES>(a, blockIdx.x, lds, 0);
     else
-        pg_fill_body<C, 0, false, PG_GROUP_LANES, true>(a, blockIdx.x, lds, 0);
+    {
+        // (a bounded grid walks the items: the launcher decides how many wavefronts the forward launch holds beside the next chunk's
+        // reversed-graph fills)
+        for (uint32_t p = blockIdx.x; p < a.n_pairs; p += gridDim.x)
+        {
+            pg_fill_body<C, 0, false, PG_GROUP_LANES, true>(a, p, lds, 0);
+            __syncthreads();  // (the next item's profile goes where this one's rows were read from)
+        }
+    }
 }
 
 template <int C> static hipError_t launch_lean_c(PgFillArgs args, uint32_t n_pairs, int mode, hipStream_t stream)
 {
-    void (*fn)(PgFillArgs) = mode == 2 ? pg_fill_lean_kernel<C, 2> : pg_fill_lean_kernel<C, 3>;
+    void (*fn)(PgFillArgs) = mode == 2 ? pg_fill_lean_kernel<C, 2> : pg_fill_lean_kernel<C, 3>;  // (modes 3 and 4: the same kernel)
     const size_t lds = (size_t)(64 * 4 * C) * sizeof(uint32_t);
     args.both_dirs = (uint32_t)mode;
     args.n_pairs = n_pairs;
-    hipLaunchKernelGGL(fn, dim3(n_pairs), dim3(64), lds, stream, args);
+    uint32_t grid = n_pairs;
+    if (mode != 2)
+    {
+        static const long per_cu = [] {
+            const char* e = getenv("PG_LEAN_INST_BLOCKS");
+            return e ? atol(e) : 0L;
+        }();
+        if (per_cu > 0)
+        {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess)
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            grid = std::min<uint32_t>(n_pairs, (uint32_t)(per_cu * cus));
+        }
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, args);
     return hipGetLastError();
 }
 

@@ -63,6 +63,7 @@ struct pg_ctx
     // still has its region to itself.
     uint64_t chunk_seq = 0;
     hipStream_t stream_fill2 = nullptr;
+    hipStream_t stream_lean = nullptr;  // the lean stage's pick + forward launch (side priority; made by the first lean stage)
     // The path stage and the hand-over chain behind it (its count pass, the retire kernel, the lists and counts of the next plan)
     // run on a stream of their own, one priority level up like the second stream: on the main stream they would wait behind the
     // fills of every batch queued before them, on the second stream behind tracebacks that wait for those fills.
@@ -94,9 +95,9 @@ struct pg_ctx
     uint8_t* gen_ws = nullptr;
     uint64_t gen_ws_cap = 0;
     bool wide32 = true;  // wide variants (reads of 251..512 bases) with 32 lanes per read
-    // The lean gssw stage (pg_ctx_set_lean; PG_LEAN=0 / 1 sets the default): alignRead(AF_ALL) with three fills per read where
-    // four are not needed (pg_batch_align)
-    bool lean = false;
+    // The lean gssw stage (pg_ctx_set_lean; on unless PG_LEAN=0): alignRead(AF_ALL) with three fills per read where four are not
+    // needed (pg_batch_align)
+    bool lean = true;
     bool timing = false;
     std::vector<EventPair> events;
     std::vector<hipEvent_t> event_pool;
@@ -196,7 +197,8 @@ struct pg_batch
     PgInstItem* d_inst = nullptr;
     uint32_t* d_lean_extra = nullptr;
     uint32_t* d_yloc = nullptr;
-    uint8_t* d_lean_undecided = nullptr;
+    uint32_t* d_lean_ucount = nullptr;  // per pair slot (a chunk uses the one at its first pair): reads listed for the second look
+    uint32_t* d_lean_ulist = nullptr;   // four entries per pair slot: (pair << 2 | read of the pair)
     size_t cap_lean_pairs = 0, cap_lean_reads = 0;
     uint32_t plan_epoch = 0;                  // pg_ctx::plan_epoch when the upload-time plan was cut
     hipStream_t seed_stream = nullptr;        // the seed stream this batch's path stage ran on

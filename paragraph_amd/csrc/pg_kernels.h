@@ -49,7 +49,13 @@ struct PgTraceArgs
     const struct PgPlanSegment* segments;  // the full plan's (group, chunk) runs: the instance item of (pair, read) follows from its run
     uint32_t n_segments;
     const uint32_t* yloc;                  // per read: where the forward fill of its OTHER strand is (PG_NONE: not run)
-    uint8_t* undecided;                    // per read, out: 1 = the record needs that fill (the read goes on to the plain pass), 0 = written
+    // first look only: a read whose record needs that fill after all gets it queued (an instance behind its run's others) and is listed
+    PgInstItem* inst_rw;
+    uint32_t* yloc_rw;
+    uint32_t* extra;                       // per pair slot: the run's count of such instances (pg_lean_build_kernel started it)
+    const uint32_t* group_count;
+    uint32_t* ucount;                      // the chunk's list of reads for the second look, and its length
+    uint32_t* ulist;
 };
 
 // The lean pass's pick: one thread per work-item pair of a chunk, behind its reversed-graph fills (pg_api.hip)
@@ -64,11 +70,14 @@ struct PgLeanBuildArgs
     PgInstItem* inst;
     uint32_t* extra;  // per pair slot: instances beyond the first per read that the run starting there has been given
     uint32_t* yloc;
+    uint32_t* ucount; // the chunk's second-look counter (zeroed here)
 };
 hipError_t pg_launch_lean_build(const PgLeanBuildArgs& args, hipStream_t stream);
 hipError_t pg_launch_trace_lean(const PgTraceArgs& args, hipStream_t stream);
+hipError_t pg_launch_trace_lean2(const PgTraceArgs& args, hipStream_t stream);  // the reads the first look listed
 
 hipError_t pg_launch_fill(int V, const PgFillArgs& args, uint32_t n_pairs, bool revg, bool wide32, hipStream_t stream);
-// the lean pass (byte variants only): mode 2 = the reversed-graph fills of the work items, mode 3 = forward-graph fills of args.inst
+// the lean pass (byte variants only): mode 2 = the reversed-graph fills of the work items, mode 3 = forward-graph fills of args.inst,
+// mode 4 = of those instance items only that the traceback's first look marked (PgInstItem::pad)
 hipError_t pg_launch_fill_lean(int V, const PgFillArgs& args, uint32_t n_pairs, int mode, hipStream_t stream);
 hipError_t pg_launch_trace(const PgTraceArgs& args, hipStream_t stream);

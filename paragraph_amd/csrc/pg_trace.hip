@@ -36,6 +36,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "pg_device.h"
 #include "pg_kernels.h"
 
@@ -143,20 +145,23 @@ struct Emitter
 // marked inconsistent if the forward fill of X says otherwise):
 //   X unique                          -> X is returned whatever Y is (both unique: the larger score; Y not unique: the unique one)
 //   X not unique, Y multi on the reversed graph -> neither is unique: the larger score, X
-//   X not unique, Y not multi there   -> Y's forward fill decides (Y unique: Y, else X); not run (X's own forward fill was what made
-//                                        it non-unique): the read is left to the plain pass (a.undecided)
-template <int C, bool WIDE, int GL, bool LEAN = false> __device__ __forceinline__ void pg_trace_pair(const PgTraceArgs& a, const uint32_t pair)
+//   X not unique, Y not multi there   -> Y's forward fill decides (Y unique: Y, else X); not run yet (X's own forward fill was what
+//                                        made it non-unique): it is queued here and the read comes back in pg_trace_lean2_kernel
+template <int C, bool WIDE, int GL, bool LEAN = false> __device__ __forceinline__ void pg_trace_pair(const PgTraceArgs& a, const uint32_t pair, const uint32_t slot_of_row = PG_NONE)
 {
     static_assert(!LEAN || (!WIDE && GL == PG_GROUP_LANES), "lean pass: byte variants");
     // No LDS and 80 VGPRs: this kernel runs on the second stream UNDER the next chunk's fill, whose 16 wavefronts per CU take
     // all 160 KB of LDS and four times 120 of the 512 VGPRs of a SIMD lane -- a traceback wavefront gets a place when a fill
     // wavefront retires and holds it for its grid-stride loop (pg_trace_blocks: how many do).
     const uint32_t lane = threadIdx.x;
-    const uint32_t grp = lane >> 4;  // the read of this 16-lane row
+    const uint32_t row = lane >> 4;  // this lane's 16-lane row (the row-level collectives' unit)
+    // the read of the row: read `grp` of the pair -- its own number, or (the lean stage's second look at the reads its first left
+    // open: every row has a (pair, read) of its own) the one it is given
+    const uint32_t grp = slot_of_row == PG_NONE ? row : slot_of_row;
     const uint32_t k = lane & 15u;
     // row-level collectives; the control flow below is uniform within a row, so a lane only ever talks to active lanes
-    auto row_ballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> (grp * 16u)) & 0xFFFFu; };
-    auto row_get = [&](uint32_t v, uint32_t src) -> uint32_t { return (uint32_t)__shfl((int)v, (int)(grp * 16u + src)); };
+    auto row_ballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> (row * 16u)) & 0xFFFFu; };
+    auto row_get = [&](uint32_t v, uint32_t src) -> uint32_t { return (uint32_t)__shfl((int)v, (int)(row * 16u + src)); };
     const PgWorkItem* fw = a.items + 2 * (size_t)pair;
     const uint32_t ridx = fw->read[grp];
     if (ridx == PG_NONE)
@@ -226,10 +231,33 @@ template <int C, bool WIDE, int GL, bool LEAN = false> __device__ __forceinline_
             else if (!mYf)
                 ret = Y;
         }
-        if (a.undecided && writer)
-            a.undecided[ridx] = undecided ? 1 : 0;
         if (undecided)
+        {
+            // X is not unique through its own forward fill and Y still may be: Y's forward fill is queued -- an instance behind
+            // the run's others (the pick kernel's slot space: X instances take 4 per pair, the others follow, 8 per pair slot in all) --
+            // and the read is listed for the stage's second look (pg_trace_lean2_kernel), which finds yloc set
+            if (writer)
+            {
+                const PgPlanSegment sg = a.segments[lo];
+                const uint32_t count = a.group_count[sg.group];
+                uint32_t ne = 0;
+                if (count > 4u * sg.first_pair)
+                {
+                    ne = (count - 4u * sg.first_pair + 3u) / 4u;
+                    ne = ne < sg.n_pairs ? ne : sg.n_pairs;
+                }
+                const uint32_t e = atomicAdd(&a.extra[rs], 1u);
+                const uint32_t t = 4u * ne + e;
+                const uint32_t qq = rs + t / 8u, within = t & 7u;
+                PgInstItem* it = a.inst_rw + qq;
+                it->inst[within >> 2][within & 3u] = ridx | (Y ? PG_INST_RC : 0u);
+                it->pad = 1u;  // (an item of the second forward launch)
+                a.yloc_rw[ridx] = (qq << 3) | ((within & 3u) << 1) | (within >> 2);
+                const uint32_t li = atomicAdd(a.ucount, 1u);
+                a.ulist[li] = (pair << 2) | grp;
+            }
             return;
+        }
         s = ret;
         return_reverse = ret == 1;
         unique = ret == X ? X_u : true;  // (Y is only ever returned as the unique one)
@@ -725,6 +753,21 @@ template <int C> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_pe
         pg_trace_pair<C, false, PG_GROUP_LANES, true>(a, a.pair_begin + p);
 }
 
+// the lean stage's second look: the reads its first one listed (their other strand's forward fill has run since), one per 16-lane row
+template <int C> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_TRACE_WPE, PG_TRACE_WPE))) void pg_trace_lean2_kernel(PgTraceArgs a)
+{
+    const uint32_t count = *a.ucount;
+    for (uint32_t w = blockIdx.x; w * 4u < count; w += gridDim.x)
+    {
+        const uint32_t idx = w * 4u + (threadIdx.x >> 4);
+        if (idx < count)
+        {
+            const uint32_t ent = a.ulist[idx];
+            pg_trace_pair<C, false, PG_GROUP_LANES, true>(a, ent >> 2, ent & 3u);
+        }
+    }
+}
+
 // Wavefronts of one traceback launch.  The walk is a chain of dependent loads that each pull a whole 128-byte line for a few
 // bytes (profiles/r03_sector_probe.json), and it runs under the next chunk's fill, which writes 3.5 TB/s the whole time.
 // Measured with stand-in kernels in the walk's place (profiles/r03_trace_tax.md): wavefronts that only sit beside the fill
@@ -757,6 +800,32 @@ template <int C> static hipError_t launch_trace_lean_c(const PgTraceArgs& args, 
 {
     hipLaunchKernelGGL((pg_trace_lean_kernel<C>), dim3(pg_trace_blocks(args.n_pairs)), dim3(64), 0, stream, args);
     return hipGetLastError();
+}
+
+template <int C> static hipError_t launch_trace_lean2_c(const PgTraceArgs& args, hipStream_t stream)
+{
+    // (the list is a few per cent of the chunk's reads at most: a bounded grid, the kernel strides over what the counter says)
+    const uint32_t blocks = std::min<uint32_t>(pg_trace_blocks(args.n_pairs), 4096u);
+    hipLaunchKernelGGL((pg_trace_lean2_kernel<C>), dim3(blocks ? blocks : 1u), dim3(64), 0, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t pg_launch_trace_lean2(const PgTraceArgs& args, hipStream_t stream)
+{
+    if (args.n_pairs == 0)
+        return hipSuccess;
+    switch (args.C)
+    {
+    case 2: return launch_trace_lean2_c<2>(args, stream);
+    case 4: return launch_trace_lean2_c<4>(args, stream);
+    case 6: return launch_trace_lean2_c<6>(args, stream);
+    case 8: return launch_trace_lean2_c<8>(args, stream);
+    case 10: return launch_trace_lean2_c<10>(args, stream);
+    case 12: return launch_trace_lean2_c<12>(args, stream);
+    case 14: return launch_trace_lean2_c<14>(args, stream);
+    case 16: return launch_trace_lean2_c<16>(args, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t pg_launch_trace_lean(const PgTraceArgs& args, hipStream_t stream)

@@ -115,7 +115,17 @@ def test_cpu_leg_and_verification(tmp_path):
         gres[i]["n_ops"] = len(ops) - gres[i]["ops_off"]
     ops = np.array(ops, dtype=np.uint32)
     v = bench.verify_against_reference(capi, gres, ops, res[:n], cig[:n])
-    assert v == {"reads": n, "mismatches": 0, "fields": v["fields"]}
+    assert v == {"reads": n, "mismatches": 0, "fields": v["fields"], "forward_fills_of_the_other_strand_not_run": 0}
+    # a record of the lean stage: the forward fill of the strand that was not returned did not run (bit 4), its bit reads 0
+    k = next(i for i in range(n) if res[i]["score"] > 0)
+    other = 0 if gres[k]["returned_reverse"] else 1
+    keep = int(gres[k]["multi_mask"])
+    gres[k]["multi_mask"] = (keep & ~(1 << other)) | 0x10
+    v = bench.verify_against_reference(capi, gres, ops, res[:n], cig[:n])
+    assert v["mismatches"] == 0 and v["forward_fills_of_the_other_strand_not_run"] == 1
+    gres[k]["multi_mask"] = (keep ^ (1 << (1 - other))) | 0x10  # ... but the returned strand's own flag still counts
+    assert bench.verify_against_reference(capi, gres, ops, res[:n], cig[:n])["mismatches"] == 1
+    gres[k]["multi_mask"] = keep
     gres[7]["graph_pos"] += 1
     ops[int(gres[9]["ops_off"])] ^= 1  # one CIGAR element one base longer / shorter
     v = bench.verify_against_reference(capi, gres, ops, res[:n], cig[:n])

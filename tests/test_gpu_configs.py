@@ -4,6 +4,8 @@ config 5 = long ALT nodes (kb-sized inline sequences) with 250 bp reads."""
 import numpy as np
 import pytest
 
+from tests import fuzzgen
+
 pytestmark = pytest.mark.gpu
 
 KEYS = ("graph_pos", "score", "mapq", "unique", "returned_reverse", "multi", "cigar")
@@ -51,7 +53,7 @@ def test_config3_mixed_sites_sample(gpu_ctx, checker):
             if w["score"] == 0:
                 assert g["status"] == 1
             else:
-                assert all(g[key] == w[key] for key in KEYS), (si, i, reads[i], g, w)
+                assert all(g[key] == w[key] for key in KEYS if key != "multi") and fuzzgen.multi_equal(g, w), (si, i, reads[i], g, w)
         recs = [{"pos": w["graph_pos"], "cigar": w["cigar"], "aligned": w["score"] > 0, "unique": w["unique"],
                  "graph_reverse": bool(s.is_reverse[i]) != w["returned_reverse"], "read_len": len(reads[i]),
                  "fragment": int(s.fragment[i])} for i, w in enumerate(want)]

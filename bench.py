@@ -89,6 +89,10 @@ def parse_args():
                          "sources it was collected on are the ones of this build (kernel_source_sha)")
     ap.add_argument("--sq-json", default=os.path.join(ROOT, "profiles", "r06_sq_counters.json"),
                     help="SQ counters of one fill launch (tools/sq_collect.sh + tools/sq_summary.py), same rule")
+    ap.add_argument("--traffic-json-plain", default=os.path.join(ROOT, "profiles", "traffic_r06_plain_stage.json"),
+                    help="the same for the PLAIN gssw stage's fill kernel (the `plain_stage` leg; collected with PG_LEAN=0)")
+    ap.add_argument("--sq-json-plain", default=os.path.join(ROOT, "profiles", "r06_sq_counters_plain_stage.json"),
+                    help="SQ counters of the plain stage's fill launch, same rule")
     ap.add_argument("--isa-mix-json", default=os.path.join(ROOT, "profiles", "r06_fill_isa_mix.json"),
                     help="static VALU mix of a step by issue class (tools/isa_mix.py), same rule")
     ap.add_argument("--valu-rate-json", default=os.path.join(ROOT, "profiles", "r04_valu_rate.json"),
@@ -1522,9 +1526,20 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
         for _ in range(min(1, args.warmup)):
             step(red)
         env["barrier"]()
+        ctx.timing_enable(True)
+        ctx.timing_reset()
         elapsed_pl = timed(red, args.plain_steps)
+        tim_pl = ctx.timing()
+        ctx.timing_enable(False)
         res_pl, ops_pl = batches[(step_no[0] - 1) & 1].download()
         ctx.set_lean(True)
+        # what bounds the plain stage's fill kernel, from counter files of THIS build's kernel sources collected with PG_LEAN=0
+        import copy
+        args_pl = copy.copy(args)
+        args_pl.traffic_json, args_pl.sq_json = args.traffic_json_plain, args.sq_json_plain
+        fill_pl_s = tim_pl["fill_ms"] / 1e3
+        launches_pl = max(1, tim_pl["fill_launches"])
+        bounds_pl = measured_bounds(args_pl, args.reads * args.plain_steps / launches_pl, fill_pl_s / launches_pl)
         differ = np.zeros(len(res), dtype=bool)
         for f in ("graph_pos", "score", "mapq", "is_unique", "returned_reverse", "n_ops", "clipped", "status"):
             differ |= res[f] != res_pl[f]
@@ -1543,6 +1558,12 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
                        "steps": args.plain_steps, "value_vs_plain": (args.reads * world * args.steps / elapsed) / (args.reads * world * args.plain_steps / elapsed_pl),
                        "records_differing_from_the_lean_step": int(differ.sum()), "cigar_strings_equal": cig_same,  # (their elements, read after read)
                        "forward_fills_of_the_other_strand_not_run": int(skipped.sum()),
+                       "kernel": "pg_fill_kernel<%d, false, 16>" % (2 * ((L + 31) // 32)), "launches": int(tim_pl["fill_launches"]),
+                       "avg_launch_ms": tim_pl["fill_ms"] / launches_pl,
+                       "hbm_measured_frac": bounds_pl.get("hbm_measured_frac"), "hbm_measured_gbs": bounds_pl.get("hbm_measured_gbs"),
+                       "traffic_source": bounds_pl.get("traffic_source"),
+                       "valu_issue_frac_with_measured_pairing": (bounds_pl.get("valu") or {}).get("issue_frac_with_measured_pairing"),
+                       "hbm_alg_h_only_frac": (args.reads * args.plain_steps * (2 * L * G + L + 64) / fill_pl_s / 1e9 / HBM_PEAK_GBS) if fill_pl_s > 0 else None,
                        "note": "pg_ctx_set_lean(0): GraphAligner::alignRead's four fills for every read; same reads, same batches, right "
                                "after the timed region.  Compared: every pg_result field (ops_off aside) and the rendered CIGAR strings"}
         log("plain stage %.3fs" % elapsed_pl)
@@ -1668,10 +1689,11 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
     value = reads_total / elapsed
     b_alg = b_alg_total / args.reads  # 6*L*G + L + 64 per read
     b_alg_h = 2 * L * G + L + 64      # the same with H only (the kernel re-derives E / F in the traceback)
+    b_alg_h_lean = L * G + L + 64     # ... and with ONE traced fill per read, which is all the lean stage's record needs
     # (lean stage: a chunk's forward launch runs on a stream of its own beside the next chunk's reversed-graph launch, so the sum of
     #  the launches' durations can exceed the wall clock; the fraction of peak is then taken against the longer of the two: conservative)
-    fill_s = tim["fill_ms"] / 1e3
     lean_on = tim.get("lean_rev_launches", 0) > 0
+    fill_s = min(tim["fill_ms"] / 1e3, elapsed) if lean_on else tim["fill_ms"] / 1e3
     reads_per_fill_leg = args.reads * args.steps  # this rank's fill launches
     achieved_gbs = reads_per_fill_leg * b_alg / fill_s / 1e9 if fill_s > 0 else 0.0
     launches = max(1, tim["fill_launches"])
@@ -1722,6 +1744,14 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
             "hbm_alg_h_only_bytes_per_read": b_alg_h,
             "hbm_alg_h_only_gbs": reads_per_fill_leg * b_alg_h / fill_s / 1e9 if fill_s > 0 else 0.0,
             "hbm_alg_h_only_frac": (reads_per_fill_leg * b_alg_h / fill_s / 1e9 / HBM_PEAK_GBS) if fill_s > 0 else 0.0,
+            # the lean stage traces ONE fill per read (the fourth fills of a few per cent aside): what it has to move is half of that --
+            # it is faster BECAUSE it moves fewer bytes, and its share of the HBM peak is lower for the same reason (plain_stage
+            # carries the four-fill stage's figures of the same run)
+            "hbm_alg_h_only_one_traced_fill_bytes_per_read": b_alg_h_lean if lean_on else None,
+            "hbm_alg_h_only_one_traced_fill_frac": (reads_per_fill_leg * b_alg_h_lean / fill_s / 1e9 / HBM_PEAK_GBS) if lean_on and fill_s > 0 else None,
+            "fill_time_note": ("lean stage: a chunk's forward launch overlaps the next chunk's reversed-graph launch in time; the fractions "
+                               "are taken against min(sum of the launches' durations, the timed region) = %.2f ms per step" % (fill_s / args.steps * 1e3))
+                              if lean_on else None,
             "gcups": tim["cells"] / fill_s / 1e9 if fill_s > 0 else 0.0,
             "trace_bytes_written_per_read": tim["trace_bytes"] / max(1, reads_per_fill_leg),
         },

@@ -187,7 +187,11 @@ pg_status pg_ctx_set_workspace_bytes(pg_ctx* ctx, uint64_t bytes);
  * only where X is not unique and the other strand still may be (GraphAligner.cpp:340-356) -- known from the reversed-graph fills, or
  * found by X's own forward fill (those reads get the fourth fill in a second, small launch of the same call).  Every field of the reference's Read is what the plain
  * stage writes; of pg_result, multi_mask's bit of a forward fill that did not run reads 0 and PG_MULTI_OTHER_FWD_SKIPPED is set.
- * Reads of up to 250 bases; longer ones (and batches with general-path reads) run the plain stage.  tests/test_gpu_lean.py. */
+ * Reads of up to 250 bases; longer ones (and batches with general-path reads) run the plain stage -- and so do chunks (the pieces
+ * of a batch that share the workspace) whose four fills per read come to fewer than 30 G cell updates (PG_LEAN_MIN_CELLS; 50 000
+ * reads of 150 bases on 1 kb of graph): two dependent launches of a half and a quarter of the plain launch's wavefronts only pay
+ * when each still lasts milliseconds.  on = 0: off; 1: on from that size; 2: on for every chunk (PG_LEAN=2; what the tests use).
+ * tests/test_gpu_lean.py. */
 pg_status pg_ctx_set_lean(pg_ctx* ctx, int on);
 
 /* 1 (default): the fills of a batch's chunks run one after the other on the main stream, over two workspace regions.

@@ -302,7 +302,7 @@ class Context:
     def set_lean(self, on):
         """the lean gssw stage (include/paragraph_amd.h, pg_ctx_set_lean): alignRead(AF_ALL) from three fills per read where the fourth
         cannot change the record"""
-        self._chk(self.L.pg_ctx_set_lean(self.h, 1 if on else 0))
+        self._chk(self.L.pg_ctx_set_lean(self.h, int(on)))  # (0 off, 1 on for chunks of 30 G cell updates and more, 2 on for every chunk)
 
     def set_fill_streams(self, n):
         """1: fills one after the other on the main stream (two workspace regions); 2: fills alternate over two streams (three

@@ -334,6 +334,9 @@ extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
     {
         const char* le = getenv("PG_LEAN");  // (the default of pg_ctx_set_lean: on; PG_LEAN=0 = the plain four fills)
         ctx->lean = !(le && le[0] == '0');
+        if (const char* mp = getenv("PG_LEAN_MIN_CELLS"))
+            ctx->lean_min_cells_default = (uint64_t)atof(mp);
+        ctx->lean_min_cells = (le && le[0] == '2') ? 0u : ctx->lean_min_cells_default;
     }
     {
         int lds = 0;
@@ -370,6 +373,10 @@ extern "C" pg_status pg_ctx_set_lean(pg_ctx* ctx, int on)
     if (!ctx)
         return PG_ERR_INVALID;
     ctx->lean = on != 0;
+    if (on == 1)
+        ctx->lean_min_cells = ctx->lean_min_cells_default;
+    else if (on >= 2)
+        ctx->lean_min_cells = 0;  // every chunk of byte-variant reads (tests: small batches through the lean kernels)
     return PG_OK;
 }
 
@@ -2606,8 +2613,24 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     // itself; a second, small forward launch and a second look at those reads follow on the SECOND stream, under the next chunk's fills.
     // Same records as the plain stage field by field, except multi_mask's bit of a forward fill that did not run
     // (PG_MULTI_OTHER_FWD_SKIPPED says so).  Byte variants (reads <= 250 bases); other chunks run the plain stage.
-    const bool lean = ctx->lean && (flags & PG_AF_CIGAR) && (flags & PG_AF_BOTH_STRANDS) && revg && !b->has_general_reads && b->gen_idx.empty()
+    // A chunk takes the lean route when its launches are long: the one launch of all four fills becomes two dependent ones of a half
+    // and a quarter of its wavefronts, every launch ends with a tail of one wavefront's lifetime, and a launch that does not fill the
+    // 4 096 wavefront slots a few times over lasts that lifetime whatever it holds.  A workflow batch's chunk (19 200 reads of 150
+    // bases on 600-column graphs: 7 G cell updates, a 1 ms launch) is no faster lean than plain and the BAM -> genotypes job lost a
+    // tenth with it -- a third with a path stage in front, whose seed chains wait behind the forward launch's stream
+    // (profiles/r06_lean_e2e_ab.jsonl); the headline's chunks (150 G cell updates) and those of 250-base reads on kilobase nodes
+    // (120 G in 6 000 pairs) gain a fifth and a tenth.  The bound: 30 G cell updates of the plain stage, a launch of some 5 ms
+    // (pg_ctx_set_lean(ctx, 2) / PG_LEAN_MIN_CELLS: other bounds).
+    const uint64_t lean_min_cells = ctx->lean_min_cells;
+    const auto lean_chunk_ok = [&](const Chunk& ch) { return !pg_var_wide(ch.C) && ch.cells >= lean_min_cells; };
+    bool lean = ctx->lean && (flags & PG_AF_CIGAR) && (flags & PG_AF_BOTH_STRANDS) && revg && !b->has_general_reads && b->gen_idx.empty()
         && b->n_reads && !b->groups.empty();
+    if (lean)
+    {
+        lean = false;
+        for (const Chunk& ch : b->chunks)
+            lean = lean || lean_chunk_ok(ch);
+    }
     if (lean)
     {
         if (!b->device_plan)
@@ -2638,7 +2661,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         }
         for (const Chunk& ch : b->chunks)
         {
-            const pg_status cs = run_chunk(ch, !pg_var_wide(ch.C));
+            const pg_status cs = run_chunk(ch, lean_chunk_ok(ch));
             if (cs != PG_OK)
                 return cs;
         }

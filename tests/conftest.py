@@ -50,5 +50,10 @@ def checker():
 def gpu_ctx():
     from paragraph_amd import capi
     ctx = capi.Context(0)
+    # the lean gssw stage for EVERY chunk (the library's default takes it from 30 G cell updates per chunk on: the tests' batches are smaller);
+    # PG_LEAN=0 in the environment: the plain stage (tests/test_gpu_parity.py::test_launch_settings_do_not_change_results)
+    import os
+    if os.environ.get("PG_LEAN", "") != "0":
+        ctx.set_lean(2)
     yield ctx
     ctx.close()

@@ -16,7 +16,7 @@ REF_KEYS = ("graph_pos", "score", "mapq", "unique", "returned_reverse", "cigar")
 
 def run(ctx, graphs, reads, gor, lean, flags=0xFFFFFFFF, before_align=None):
     from paragraph_amd import capi
-    ctx.set_lean(lean)
+    ctx.set_lean(2 if lean else 0)
     try:
         G = ctx.upload_graphs(graphs)
         b = ctx.new_batch()
@@ -29,7 +29,7 @@ def run(ctx, graphs, reads, gor, lean, flags=0xFFFFFFFF, before_align=None):
         b.close()
         G.close()
     finally:
-        ctx.set_lean(False)
+        ctx.set_lean(2)  # (the fixture's setting)
     return out
 
 
@@ -136,7 +136,7 @@ def test_counts_after_lean(gpu_ctx):
     site, reads = synth.config2_reads(8000, read_len=150, seed=21)
     tabs = []
     for lean in (False, True):
-        gpu_ctx.set_lean(lean)
+        gpu_ctx.set_lean(2 if lean else 0)
         try:
             G = gpu_ctx.upload_graphs([(site.seqs, site.edges)])
             G.set_labels([site.labels])
@@ -149,5 +149,5 @@ def test_counts_after_lean(gpu_ctx):
             b.close()
             G.close()
         finally:
-            gpu_ctx.set_lean(False)
+            gpu_ctx.set_lean(2)
     assert np.array_equal(tabs[0], tabs[1]) and int(tabs[0].sum()) > 0

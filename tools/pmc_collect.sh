@@ -8,7 +8,7 @@ OUT=$ROOTDIR/gpurun_out/pmc_${1:-r02}
 mkdir -p "$OUT"
 echo "${PG_HEAD:-unknown}" > "$OUT/head.txt"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOTDIR/bench.py --steps 1 --warmup 0 --reads 200000 --no-cpu-baseline --stream-batches 0 --sites-steps 0 --e2e-steps 0 --collective off"
+BENCH="python $ROOTDIR/bench.py --steps 1 --warmup 0 --reads 200000 --no-cpu-baseline --stream-batches 0 --sites-steps 0 --e2e-steps 0 --collective off --exact-shortcut-steps 0 --plain-steps 0 --config5-graphs 0"
 CAL="python $ROOTDIR/tools/pmc_calibrate.py"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/bench_$C" -o bench -- $BENCH > "$OUT/bench_$C.json" 2> "$OUT/bench_$C.err"

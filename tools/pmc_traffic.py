@@ -49,11 +49,14 @@ def main(src, dst, n_reads):
         n = max(len(ben_f.get(k, [])), len(ben_w.get(k, [])))
         out["kernels"][k] = {"launches": n, "fetch_bytes": f, "write_bytes": w,
                              "hbm_bytes_per_read": (f + w) / n_reads, "hbm_bytes_per_launch": (f + w) / max(n, 1)}
-    fill = [v for k, v in out["kernels"].items() if "pg_fill_kernel" in k][0]
-    out["hbm_bytes_per_read"] = fill["hbm_bytes_per_read"]
-    out["hbm_bytes_per_launch"] = fill["hbm_bytes_per_launch"]
-    out["fill_fetch_bytes_per_read"] = fill["fetch_bytes"] / n_reads
-    out["fill_write_bytes_per_read"] = fill["write_bytes"] / n_reads
+    # the fill kernels of the run together: pg_fill_kernel (plain stage), or the lean stage's pg_fill_lean_kernel<C, 2> (reversed-graph
+    # fills) + <C, 3> (forward-graph fills of the instance items; the second, small launch of the fourth fills included)
+    fills = {k: v for k, v in out["kernels"].items() if "pg_fill_kernel" in k or "pg_fill_lean_kernel" in k}
+    out["fill_kernels"] = sorted(fills)
+    out["hbm_bytes_per_read"] = sum(v["hbm_bytes_per_read"] for v in fills.values())
+    out["hbm_bytes_per_launch"] = sum(v["fetch_bytes"] + v["write_bytes"] for v in fills.values()) / max(1, max(v["launches"] for v in fills.values()))
+    out["fill_fetch_bytes_per_read"] = sum(v["fetch_bytes"] for v in fills.values()) / n_reads
+    out["fill_write_bytes_per_read"] = sum(v["write_bytes"] for v in fills.values()) / n_reads
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))

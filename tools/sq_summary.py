@@ -14,7 +14,7 @@ import os
 import sys
 
 
-def main(src, dst, n_reads, kernel, steps):
+def main(src, dst, n_reads, kernel, steps, waves_per_4_reads=2.0):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from paragraph_amd import build as pgbuild
     tot = collections.defaultdict(float)
@@ -28,9 +28,12 @@ def main(src, dst, n_reads, kernel, steps):
     if not tot:
         raise SystemExit("no %s rows under %s" % (kernel, src))
     n_launch = max(len(v) for v in launches.values())
-    wave_steps = (n_reads / 4.0) * 2 * steps  # forward + reversed graph wavefronts
+    # plain stage: a forward-graph and a reversed-graph wavefront per four reads; lean stage (kernel "pg_fill_lean_kernel<10"): a
+    # reversed-graph wavefront per four reads + a forward-graph one per eight (the fourth fills of a few per cent of the reads not
+    # counted: the per-wave-step figures are that much too high, the totals are what they are) = 1.5
+    wave_steps = (n_reads / 4.0) * waves_per_4_reads * steps
     head_file = os.path.join(src, "head.txt")
-    out = {"what": "SQ counters of pg_fill_kernel (%s) over %d config-2 reads in %d launch(es) = %.1f M wave-steps; separate "
+    out = {"what": "SQ counters of the fill kernel(s) (%s) over %d config-2 reads in %d launch(es) = %.1f M wave-steps; separate "
                    "rocprofv3 --pmc passes with --kernel-trace only (tools/sq_collect.sh); cycle counters in units of 4 cycles"
                    % (kernel, n_reads, n_launch, wave_steps / 1e6),
            "kernel_source_sha": pgbuild.kernel_source_sha(),
@@ -46,4 +49,5 @@ def main(src, dst, n_reads, kernel, steps):
 
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 200000,
-         sys.argv[4] if len(sys.argv) > 4 else "pg_fill_kernel<10, false", int(sys.argv[5]) if len(sys.argv) > 5 else 518)
+         sys.argv[4] if len(sys.argv) > 4 else "pg_fill_kernel<10, false", int(sys.argv[5]) if len(sys.argv) > 5 else 518,
+         float(sys.argv[6]) if len(sys.argv) > 6 else 2.0)

@@ -1717,7 +1717,7 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
         "config": {
             "workload": "configs[1]: 1 DEL graph (200bp flanks, nodes 201/100/201), %d synthetic %dbp reads per GPU, "
                         "GraphAligner::alignRead(AF_ALL) per read -- the lean gssw stage: the record the reference reads off its 4 fills from the 3 "
-                        "(a few per cent of the reads: 4) that can change it, strand pick + traceback -- then "
+                        "(4 where the better strand is not unique and the other may be: under 0.1 %% of these reads) that can change it, strand pick + traceback -- then "
                         "filters + node/edge/sequence counts%s"
                         % (args.reads, L, " + 1 all-reduce of the counter table per step" if world > 1 else ""),
             "reads_per_gpu": args.reads, "read_len": L, "graph_len": G, "parallelism": "reads x%d" % world,

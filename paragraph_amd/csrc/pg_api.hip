@@ -2584,8 +2584,12 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             // the reads whose record needs the fourth fill after all (X not unique through its own forward fill, a per cent or two):
             // that fill -- the instances the first look queued -- and a second look at them, here on the second stream, under the
             // next chunk's fills
-            HIP_TRY(ctx, pg_launch_fill_lean(ch.C, fa, n_pairs, 4, ctx->stream2));
-            HIP_TRY(ctx, pg_launch_trace_lean2(ta, ctx->stream2));
+            static const bool skip_second = getenv("PG_LEAN_TIMING_SKIP_SECOND") != nullptr;  // (timing probes only: the listed reads keep no record)
+            if (!skip_second)
+            {
+                HIP_TRY(ctx, pg_launch_fill_lean(ch.C, fa, n_pairs, 4, ctx->stream2));
+                HIP_TRY(ctx, pg_launch_trace_lean2(ta, ctx->stream2));
+            }
         }
         else
             HIP_TRY(ctx, pg_launch_trace(ta, ctx->stream2));

@@ -872,15 +872,9 @@ template <int C, int MODE> __global__ __launch_bounds__(64) void pg_fill_lean_ke
     if (MODE == 2)
         pg_fill_body<C, 1, false, PG_GROUP_LANES>(a, blockIdx.x, lds, 0);
     else
-    {
-        // (a bounded grid walks the items: the launcher decides how many wavefronts the forward launch holds beside the next chunk's
-        // reversed-graph fills)
-        for (uint32_t p = blockIdx.x; p < a.n_pairs; p += gridDim.x)
-        {
-            pg_fill_body<C, 0, false, PG_GROUP_LANES, true>(a, p, lds, 0);
-            __syncthreads();  // (the next item's profile goes where this one's rows were read from)
-        }
-    }
+        pg_fill_body<C, 0, false, PG_GROUP_LANES, true>(a, blockIdx.x, lds, 0);
+    // (one item per workgroup: a grid-stride loop over the items -- a bounded, persistent forward grid beside the next chunk's
+    // reversed-graph fills was tried, profiles/r06_lean_streams_ab.jsonl -- costs 16 registers and with them the fourth wavefront per SIMD)
 }
 
 template <int C> static hipError_t launch_lean_c(PgFillArgs args, uint32_t n_pairs, int mode, hipStream_t stream)
@@ -889,21 +883,7 @@ template <int C> static hipError_t launch_lean_c(PgFillArgs args, uint32_t n_pai
     const size_t lds = (size_t)(64 * 4 * C) * sizeof(uint32_t);
     args.both_dirs = (uint32_t)mode;
     args.n_pairs = n_pairs;
-    uint32_t grid = n_pairs;
-    if (mode != 2)
-    {
-        static const long per_cu = [] {
-            const char* e = getenv("PG_LEAN_INST_BLOCKS");
-            return e ? atol(e) : 0L;
-        }();
-        if (per_cu > 0)
-        {
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) == hipSuccess)
-                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            grid = std::min<uint32_t>(n_pairs, (uint32_t)(per_cu * cus));
-        }
-    }
+    const uint32_t grid = n_pairs;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, args);
     return hipGetLastError();
 }

@@ -151,3 +151,41 @@ def test_counts_after_lean(gpu_ctx):
         finally:
             gpu_ctx.set_lean(2)
     assert np.array_equal(tabs[0], tabs[1]) and int(tabs[0].sum()) > 0
+
+
+def test_many_chunks_two_batches_and_three_regions(checker):
+    """a workspace of 96 MiB cuts 24 000 config-2 reads + 3 000 fuzz reads into many chunks; two batch objects aligned back to back meet
+    on the regions (the lean stage's forward launch, traceback and second look of one chunk run beside the next chunk's reversed-graph
+    fills); with pg_ctx_set_fill_streams(2): three regions, the reversed-graph launches alternating between two streams.  Records equal
+    the plain stage's, and the reference's on a sample."""
+    from paragraph_amd import capi, synth
+    site, reads = synth.config2_reads(24000, read_len=150, seed=78)
+    graphs, gor = [(site.seqs, site.edges)], [0] * len(reads)
+    reads = list(reads)
+    for gi, (seqs, edges, rs) in enumerate(fuzzgen.cases(910, 300, 10)):
+        graphs.append((seqs, edges))
+        reads.extend(rs)
+        gor.extend([gi + 1] * len(rs))
+    out = {}
+    for mode, streams in (("plain", 1), ("lean", 1), ("lean3", 2)):
+        ctx = capi.Context(0, workspace_bytes=96 << 20, fill_streams=streams)
+        ctx.set_lean(0 if mode == "plain" else 2)
+        G = ctx.upload_graphs(graphs)
+        batches = [ctx.new_batch(), ctx.new_batch()]
+        for b in batches:
+            b.upload(G, reads, gor)
+        for _ in range(2):
+            for b in batches:
+                b.align(capi.AF_ALL)
+        out[mode] = [capi.results_to_dicts(*b.download()) for b in batches]
+        for b in batches:
+            b.close()
+        G.close()
+        ctx.close()
+    for mode in ("lean", "lean3"):
+        for k in (0, 1):
+            skipped = compare(out["plain"][k], out[mode][k], reads, mode)
+            assert skipped > len(reads) // 2
+    sample = list(range(0, 24000, 12))
+    want = checker.align_batch(site.seqs, site.edges, [reads[i] for i in sample], threads=8)
+    compare_ref(want, [out["lean3"][1][i] for i in sample], [reads[i] for i in sample], "three regions vs reference")

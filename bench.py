@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the read -> variant-graph realignment path on MI355X.
 
-A "step" is one pass of the hot path (4 graph fills + strand pick + traceback per read, i.e. the default
-grmpy cascade GraphAligner::alignRead(AF_ALL)) over one batch of synthetic reads that is already
+A "step" is one pass of the hot path (the default grmpy cascade GraphAligner::alignRead(AF_ALL) per read: the record the
+reference reads off four graph fills, strand pick + traceback -- computed by the library's lean gssw stage from the three fills that
+can change it, the fourth where it can; `plain_stage` runs the same steps with all four) over one batch of synthetic
+reads that is already
 resident in HBM when the timed region starts, followed by the count path (read filters, node/edge/sequence
 support, per-fragment union, per-site counters) and -- with N > 1 ranks -- the path's only collective, ONE
 all-reduce of the per-site counter table (RCCL over xGMI).
@@ -22,8 +24,11 @@ Launch: `python bench.py --gpus N` spawns its N ranks itself (torch.distributed.
 the ranks share devices and the reduce runs over gloo -- same code path, used by the tests.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- dominant kernel (pg_fill_kernel): algorithmic bytes of SURVEY.md 8(d)
-                  (B_alg = 6*L*G + L + 64 per read) / HIP-event duration of its launches / 8 TB/s
+  roofline     -- dominant kernel(s) (the lean stage's two fill launches per chunk taken together; pg_fill_kernel for the plain
+                  stage): algorithmic bytes of SURVEY.md 8(d) (B_alg = 6*L*G + L + 64 per read) / HIP-event duration of the launches /
+                  8 TB/s, and what measurably bounds them (VALU issue slots from SQ counters, HBM bytes from PMC counters)
+  plain_stage  -- the same steps through the plain gssw stage (four fills per read), its rate and bounds, and the lean step's
+                  records against its records (exit status 3 if any differ)
   cpu_baseline -- the reference's own gssw.c (oracle/_ref, kind "reference") or the plain-C port, timed on this
                   host's cores in a separate process (threads in one process AND one process per chunk; the better
                   one is `value`), N=1 only

@@ -189,3 +189,41 @@ def test_many_chunks_two_batches_and_three_regions(checker):
     sample = list(range(0, 24000, 12))
     want = checker.align_batch(site.seqs, site.edges, [reads[i] for i in sample], threads=8)
     compare_ref(want, [out["lean3"][1][i] for i in sample], [reads[i] for i in sample], "three regions vs reference")
+
+
+def test_tiny_runs_and_masks(gpu_ctx, checker):
+    """runs of one to five reads per graph on repeat-rich graphs (the instance slots of a run with one or two pairs: the other strands'
+    instances share the X strands' item), single-read batches, and a host-made active mask in front of the lean stage"""
+    import numpy as np
+    from paragraph_amd import capi
+    rng = random.Random(fuzzgen.salted(4711))
+    graphs, reads, gor, ref = [], [], [], []
+    for gi in range(400):
+        mode = rng.choice(["homo", "period", "two", None])
+        n = rng.randint(2, 5)
+        seqs = [fuzzgen.rand_seq(rng, rng.randint(3, 40), mode) for _ in range(n)]
+        edges = [(i, j) for i in range(n) for j in range(i + 1, n) if j == i + 1 or rng.random() < 0.4]
+        rs = []
+        for _ in range(rng.choice([1, 1, 2, 3, 4, 5])):
+            r = fuzzgen.rand_read(rng, seqs, edges, min_len=4, max_len=60)
+            if rng.random() < 0.3:
+                r = r[:len(r) // 2] + r[:len(r) // 2][::-1]  # (scores the same on both strands' like as not)
+            rs.append(r or "A")
+        graphs.append((seqs, edges))
+        reads.extend(rs)
+        gor.extend([gi] * len(rs))
+        ref.extend(checker.align_batch(seqs, edges, rs))
+    want = run(gpu_ctx, graphs, reads, gor, False)
+    got = run(gpu_ctx, graphs, reads, gor, True)
+    compare(want, got, reads, "tiny runs")
+    compare_ref(ref, got, reads, "tiny runs vs reference")
+    assert sum(1 for g in got if not g["other_fwd_skipped"] and g["status"] == 0) > 30
+    # one read
+    one = run(gpu_ctx, graphs[:1], reads[:1], gor[:1], True)
+    compare_ref(ref[:1], one, reads[:1], "one read")
+    # a host-made mask: every third read inactive (its record stays what the upload left), the others through the lean stage
+    mask = np.array([0 if i % 3 == 0 else 1 for i in range(len(reads))], dtype=np.uint8)
+    masked = run(gpu_ctx, graphs, reads, gor, True, flags=capi.AF_CIGAR | capi.AF_BOTH_STRANDS | capi.AF_REVERSE_GRAPH | capi.AF_KEEP_RESULTS,
+                 before_align=lambda G, b: b.set_active(mask))
+    act = [i for i in range(len(reads)) if mask[i]]
+    compare([want[i] for i in act], [masked[i] for i in act], [reads[i] for i in act], "masked")

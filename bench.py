@@ -1526,7 +1526,7 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
     # the lean stage's records of the last timed step against its records -- every field of pg_result; of multi_mask the bits of the
     # fills that ran
     plain_stage = None
-    if args.plain_steps > 0 and tim.get("lean_rev_launches", 0) > 0:
+    if args.plain_steps > 0 and (tim.get("lean_rev_launches", 0) > 0 or tim.get("lean_fused_launches", 0) > 0):
         ctx.set_lean(False)
         for _ in range(min(1, args.warmup)):
             step(red)
@@ -1697,8 +1697,9 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
     b_alg_h_lean = L * G + L + 64     # ... and with ONE traced fill per read, which is all the lean stage's record needs
     # (lean stage: a chunk's forward launch runs on a stream of its own beside the next chunk's reversed-graph launch, so the sum of
     #  the launches' durations can exceed the wall clock; the fraction of peak is then taken against the longer of the two: conservative)
-    lean_on = tim.get("lean_rev_launches", 0) > 0
-    fill_s = min(tim["fill_ms"] / 1e3, elapsed) if lean_on else tim["fill_ms"] / 1e3
+    lean_fused = tim.get("lean_fused_launches", 0) > 0
+    lean_on = tim.get("lean_rev_launches", 0) > 0 or lean_fused
+    fill_s = min(tim["fill_ms"] / 1e3, elapsed) if lean_on and not lean_fused else tim["fill_ms"] / 1e3
     reads_per_fill_leg = args.reads * args.steps  # this rank's fill launches
     achieved_gbs = reads_per_fill_leg * b_alg / fill_s / 1e9 if fill_s > 0 else 0.0
     launches = max(1, tim["fill_launches"])
@@ -1733,14 +1734,16 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
         "cell_updates_computed_per_s": tim["cells"] * world / elapsed,
         "roofline": {
             **roofline_head(roof_extra, achieved_gbs),
-            "kernel": ("pg_fill_lean_kernel<%d, 2> (reversed-graph fills of both strands) + pg_fill_lean_kernel<%d, 3> (forward-graph fills of "
-                       "the instance items): the lean gssw stage's two fill launches per chunk, taken together" % ((2 * ((L + 31) // 32),) * 2))
+            "kernel": ("pg_fill_lean_fused_kernel<%d> (the lean gssw stage in one launch: per wavefront the reversed-graph fills of two work-item "
+                       "pairs, the pick, and the forward-graph fills of their eight higher-scoring strands)" % (2 * ((L + 31) // 32))) if lean_fused
+                      else ("pg_fill_lean_kernel<%d, 2> (reversed-graph fills of both strands) + pg_fill_lean_kernel<%d, 3> (forward-graph fills of "
+                            "the instance items): the lean gssw stage's two fill launches per chunk, taken together" % ((2 * ((L + 31) // 32),) * 2))
                       if lean_on else "pg_fill_kernel<%d, false, 16>" % (2 * ((L + 31) // 32)),
             "launches": int(tim["fill_launches"]),
             "lean": {"rev_launches": int(tim["lean_rev_launches"]), "rev_ms": tim["lean_rev_ms"], "fwd_launches": int(tim["lean_fwd_launches"]),
                      "fwd_ms": tim["lean_fwd_ms"],
                      "note": "durations by HIP events on each launch's own stream; the forward launch of a chunk overlaps the reversed-graph "
-                             "launch of the next one in time"} if lean_on else None,
+                             "launch of the next one in time"} if lean_on and not lean_fused else None,
             "avg_launch_ms": tim["fill_ms"] / max(1, tim["fill_launches"]),
             **roof_extra,
             "alg_bytes_per_read": b_alg,
@@ -1756,7 +1759,7 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
             "hbm_alg_h_only_one_traced_fill_frac": (reads_per_fill_leg * b_alg_h_lean / fill_s / 1e9 / HBM_PEAK_GBS) if lean_on and fill_s > 0 else None,
             "fill_time_note": ("lean stage: a chunk's forward launch overlaps the next chunk's reversed-graph launch in time; the fractions "
                                "are taken against min(sum of the launches' durations, the timed region) = %.2f ms per step" % (fill_s / args.steps * 1e3))
-                              if lean_on else None,
+                              if lean_on and not lean_fused else None,
             "gcups": tim["cells"] / fill_s / 1e9 if fill_s > 0 else 0.0,
             "trace_bytes_written_per_read": tim["trace_bytes"] / max(1, reads_per_fill_leg),
         },

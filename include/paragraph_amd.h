@@ -165,6 +165,8 @@ typedef struct pg_timing
     double lean_fwd_ms;   /* pick + forward-graph fills of the instance items */
     uint64_t lean_rev_launches;
     uint64_t lean_fwd_launches;
+    double lean_fused_ms;          /* the lean stage as ONE launch per chunk (the default form; also in fill_ms / fill_launches) */
+    uint64_t lean_fused_launches;
 } pg_timing;
 
 /* Host threads that wait for `device` (pg_batch_wait, downloads, pg_ctx_sync) sleep instead of spinning:

@@ -57,7 +57,8 @@ class Timing(C.Structure):
     _fields_ = [("fill_ms", C.c_double), ("trace_ms", C.c_double), ("fill_launches", C.c_uint64),
                 ("trace_launches", C.c_uint64), ("fills", C.c_uint64), ("cells", C.c_uint64),
                 ("trace_bytes", C.c_uint64), ("lean_rev_ms", C.c_double), ("lean_fwd_ms", C.c_double),
-                ("lean_rev_launches", C.c_uint64), ("lean_fwd_launches", C.c_uint64)]
+                ("lean_rev_launches", C.c_uint64), ("lean_fwd_launches", C.c_uint64), ("lean_fused_ms", C.c_double),
+                ("lean_fused_launches", C.c_uint64)]
 
 
 class CountParams(C.Structure):

@@ -337,6 +337,8 @@ extern "C" pg_status pg_ctx_create(int device, pg_ctx** out)
         if (const char* mp = getenv("PG_LEAN_MIN_CELLS"))
             ctx->lean_min_cells_default = (uint64_t)atof(mp);
         ctx->lean_min_cells = (le && le[0] == '2') ? 0u : ctx->lean_min_cells_default;
+        if (const char* lf = getenv("PG_LEAN_FUSED"))
+            ctx->lean_fused = lf[0] != '0';
     }
     {
         int lds = 0;
@@ -826,6 +828,13 @@ static pg_status drain_events(pg_ctx* ctx)
         {
             ctx->acc.fill_ms += ms;
             ctx->acc.fill_launches++;
+        }
+        else if (e.kind == 4)
+        {
+            ctx->acc.fill_ms += ms;
+            ctx->acc.fill_launches++;
+            ctx->acc.lean_fused_ms += ms;
+            ctx->acc.lean_fused_launches++;
         }
         else if (e.kind == 2)
         {
@@ -2475,7 +2484,29 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             ev.kind = 0;
             HIP_TRY(ctx, hipEventRecord(ev.a, fill_stream));
         }
-        if (lean_chunk)
+        if (lean_chunk && ctx->lean_fused)
+        {
+            // ONE launch: a wavefront takes two pairs through their reversed-graph fills, the pick and the forward-graph fills (pg_fill.hip)
+            fa.inst = b->d_inst;
+            // the chunk's runs (segments are in the order of their pair slots)
+            uint32_t seg_begin = 0, n_seg = 0;
+            {
+                const std::vector<PgPlanSegment>& sv = b->h_segments;
+                const auto lb = std::lower_bound(sv.begin(), sv.end(), ch.pair_begin, [](const PgPlanSegment& x, uint32_t v) { return x.pair_begin < v; });
+                const auto ub = std::lower_bound(sv.begin(), sv.end(), ch.pair_end, [](const PgPlanSegment& x, uint32_t v) { return x.pair_begin < v; });
+                seg_begin = (uint32_t)(lb - sv.begin());
+                n_seg = (uint32_t)(ub - lb);
+            }
+            HIP_TRY(ctx, hipMemsetAsync(b->d_lean_ucount + ch.pair_begin, 0, sizeof(uint32_t), fill_stream));
+            // (every instance item of the chunk EMPTY -- entry (0, 0) = PG_NONE: the kernel writes the slots of the couples that hold
+            // reads, the second forward launch walks them all)
+            HIP_TRY(ctx, hipMemsetAsync(b->d_inst + ch.pair_begin, 0xFF, (size_t)n_pairs * sizeof(PgInstItem), fill_stream));
+            HIP_TRY(ctx, pg_launch_fill_lean_fused(ch.C, fa, b->d_segments, (uint32_t)b->h_segments.size(), b->d_group_count, b->d_inst, b->d_yloc,
+                                                   b->d_lean_ucount + ch.pair_begin, b->d_lean_ulist + 4 * (size_t)ch.pair_begin, seg_begin, n_seg, n_pairs,
+                                                   fill_stream));
+            ev.kind = 4;
+        }
+        else if (lean_chunk)
         {
             fa.inst = b->d_inst;
             HIP_TRY(ctx, pg_launch_fill_lean(ch.C, fa, n_pairs, 2, fill_stream));
@@ -2580,6 +2611,7 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
             ta.group_count = b->d_group_count;
             ta.ucount = b->d_lean_ucount + ch.pair_begin;           // (one counter and 4 list entries per pair slot: a chunk's are its own)
             ta.ulist = b->d_lean_ulist + 4 * (size_t)ch.pair_begin;
+            ta.fused = ctx->lean_fused ? 1u : 0u;
             HIP_TRY(ctx, pg_launch_trace_lean(ta, ctx->stream2));
             // the reads whose record needs the fourth fill after all (X not unique through its own forward fill, a per cent or two):
             // that fill -- the instances the first look queued -- and a second look at them, here on the second stream, under the

@@ -92,7 +92,8 @@ struct PgWorkItem
 // One wavefront of the LEAN forward pass (pg_batch_align with PG_AF_LEAN): eight (read, strand) instances of one graph, one per
 // (16-lane group, 16-bit half).  An entry is the read's index, bit 31 set for its reverse complement; PG_NONE = empty.
 #define PG_INST_RC 0x80000000u
-struct PgInstItem
+#define PG_YLOC_PENDING 0x80000000u  // yloc entry: the fill is queued for the chunk's second forward launch (the traceback's first look passes the read by)
+struct alignas(128) PgInstItem  // (a cache line of its own: the fused kernel's wavefront writes its items and reads them back at once)
 {
     uint32_t graph;
     uint32_t pad;

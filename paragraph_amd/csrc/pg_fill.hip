@@ -134,15 +134,18 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     const uint32_t item_idx = a.item_begin + 2 * pair + DIR;
     const PgWorkItem* itp = a.items + item_idx;
     const PgInstItem* inp = INST ? a.inst + (a.item_begin / 2 + pair) : nullptr;
+    // (the fused lean kernel's wavefront wrote the item itself a moment ago: device-scope loads, not the CU's vector cache)
+    auto inst_at = [&](int h, int g) -> uint32_t { return __hip_atomic_load(&inp->inst[h][g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     // an EMPTY slot of a plan re-written by the cascade's hand-over (pg_batch_retire_mapped: a group's active reads come first,
     // so the wavefront's first read says it all): nothing to fill, nothing the traceback will look at
     // (instance items are filled from (half 0, group 0) on)
-    if ((INST ? inp->inst[0][0] : itp->read[(int)half * GROUPS]) == PG_NONE)
+    if ((INST ? inst_at(0, 0) : itp->read[(int)half * GROUPS]) == PG_NONE)
         return;
-    if (INST && a.both_dirs == 4u && inp->pad == 0u)
+    if (INST && a.both_dirs == 4u && __hip_atomic_load(&inp->pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
         return;  // (the lean stage's second forward launch: only the items the traceback's first look added instances to)
-    const uint32_t graph = INST ? inp->graph : itp->graph;
-    const uint64_t item_seed_off = INST ? inp->seed_off : itp->seed_off, item_trace_off = INST ? inp->trace_off : itp->trace_off;
+    const uint32_t graph = INST ? __hip_atomic_load(&inp->graph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : itp->graph;
+    const uint64_t item_seed_off = INST ? __hip_atomic_load(&inp->seed_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : itp->seed_off;
+    const uint64_t item_trace_off = INST ? __hip_atomic_load(&inp->trace_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : itp->trace_off;
     const PgGraphDir gd = a.graphs[graph].dir[DIR];
     const uint32_t* __restrict__ smeta = a.colmeta + gd.meta_off;
     const PgNode* __restrict__ nodes = a.nodes + gd.node_off;
@@ -171,7 +174,7 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     for (int g = 0; g < GROUPS; ++g)
     {
         // half A / half B of the registers: the read's two strands, or (INST) two instances of their own
-        uint32_t eA = INST ? inp->inst[0][g] : itp->read[(int)half * GROUPS + g], eB = INST ? inp->inst[1][g] : eA;
+        uint32_t eA = INST ? inst_at(0, g) : itp->read[(int)half * GROUPS + g], eB = INST ? inst_at(1, g) : eA;
         const uint32_t ridxA = eA == PG_NONE ? PG_NONE : (eA & ~PG_INST_RC), ridxB = eB == PG_NONE ? PG_NONE : (eB & ~PG_INST_RC);
         const bool rcA = INST ? eA != PG_NONE && (eA & PG_INST_RC) != 0u : false, rcB = INST ? eB != PG_NONE && (eB & PG_INST_RC) != 0u : true;
         uint32_t offA = 0, LA = 0, offB = 0, LB = 0;
@@ -233,14 +236,14 @@ __device__ __forceinline__ void pg_fill_body(const PgFillArgs& a, uint32_t pair,
     // rows of this lane that exist in its read (the others are padding rows)
     uint32_t real_rows = 0, real_rows_hi = 0;  // (the two halves' reads differ in an instance item)
     {
-        const uint32_t eA = INST ? inp->inst[0][grp] : itp->read[grp];
+        const uint32_t eA = INST ? inst_at(0, grp) : itp->read[grp];
         const uint32_t ridx = eA == PG_NONE ? PG_NONE : (INST ? eA & ~PG_INST_RC : eA);
         const uint32_t Lg = ridx == PG_NONE ? 0u : a.base_off[ridx + 1] - a.base_off[ridx];
         real_rows = Lg > (uint32_t)(k * C) ? Lg - (uint32_t)(k * C) : 0u;
         real_rows_hi = real_rows;
         if (INST)
         {
-            const uint32_t eB = inp->inst[1][grp];
+            const uint32_t eB = inst_at(1, grp);
             const uint32_t rb = eB == PG_NONE ? PG_NONE : (eB & ~PG_INST_RC);
             const uint32_t Lb = rb == PG_NONE ? 0u : a.base_off[rb + 1] - a.base_off[rb];
             real_rows_hi = Lb > (uint32_t)(k * C) ? Lb - (uint32_t)(k * C) : 0u;
@@ -875,6 +878,231 @@ template <int C, int MODE> __global__ __launch_bounds__(64) void pg_fill_lean_ke
         pg_fill_body<C, 0, false, PG_GROUP_LANES, true>(a, blockIdx.x, lds, 0);
     // (one item per workgroup: a grid-stride loop over the items -- a bounded, persistent forward grid beside the next chunk's
     // reversed-graph fills was tried, profiles/r06_lean_streams_ab.jsonl -- costs 16 registers and with them the fourth wavefront per SIMD)
+}
+
+// The lean stage in ONE launch (pg_launch_fill_lean_fused): a wavefront takes TWO work-item pairs of one run -- eight reads -- through
+// all of it: the reversed-graph fills of both pairs (both strands each), the pick (lanes 0..7, one read each), the forward-graph
+// fill of the eight X strands as ONE instance item (which it writes into the leader pair's slot and sweeps at once).  The other
+// strands a record still needs -- those the reversed-graph fills already ask for and those X's own forward fill has just made
+// necessary (GraphAligner.cpp:340-356 by cases, pg_trace.hip) -- it queues as the instance item of the partner's slot for the chunk's
+// second, small forward launch.  No dependency between large launches: wavefronts are in their reversed-graph and forward-graph
+// sweeps at different times, so the trace stores spread over the launch by themselves.  A run's last pair without a partner runs both
+// strands of its four reads forward (half 0 = X, half 1 = the other strand): the plain forward fill, nothing left open.
+struct PgLeanFusedArgs
+{
+    const PgPlanSegment* segments;
+    uint32_t n_segments;
+    const uint32_t* group_count;
+    PgInstItem* inst;  // [pair slot]: X item in the leader's slot, the other strands' item in its partner's
+    uint32_t* yloc;    // per read, out: (slot << 3 | group << 1 | half) of the forward fill of its other strand (| PG_YLOC_PENDING: queued for
+                       // the second forward launch), PG_NONE if none runs
+    uint32_t* ucount;  // the chunk's list of reads for the traceback's second look, and its length (zeroed before the launch)
+    uint32_t* ulist;
+    uint32_t seg_begin, n_seg;  // the chunk's runs: segments[seg_begin .. seg_begin + n_seg)
+};
+
+template <int C> __global__ __launch_bounds__(64) void pg_fill_lean_fused_kernel(PgFillArgs a, PgLeanFusedArgs f)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // Every workgroup holds work.  The first ceil(n_pairs / 2): workgroup w looks at pair slots 2 w and 2 w + 1 and takes the couple one of
+    // them LEADS (a couple = slots rs + 2 k, rs + 2 k + 1 of a run starting at rs, both holding reads) -- never both: consecutive slots
+    // of a run have ranks of different parity, and a slot that ends a run leads no couple.  The last n_seg: workgroup k takes the lone
+    // last pair of the chunk's k-th run if the run has an odd number of pairs.  (One workgroup per pair slot with the partners returning
+    // at once left half of the chip idle -- workgroups are dealt to XCDs and CUs round-robin, the leaders sat on every other one: 59 ms
+    // per million reads instead of 34.)
+    const uint32_t n_couple_groups = (a.n_pairs + 1u) / 2u;
+    const uint32_t pair0 = a.item_begin / 2u;  // the chunk's first pair slot in the batch's plan
+    uint32_t p;       // the leader's pair slot
+    bool partner;
+    auto pairs_with_reads = [&](const PgPlanSegment& sgm) -> uint32_t {
+        const uint32_t count = f.group_count[sgm.group];  // (a group's active reads come first)
+        if (count <= 4u * sgm.first_pair)
+            return 0u;
+        const uint32_t n = (count - 4u * sgm.first_pair + 3u) / 4u;
+        return n < sgm.n_pairs ? n : sgm.n_pairs;
+    };
+    if (blockIdx.x < n_couple_groups)
+    {
+        const uint32_t s0 = pair0 + 2u * blockIdx.x;
+        uint32_t lo = 0, hi = f.n_segments;  // last segment whose pair_begin <= s0 (wave-uniform)
+        while (hi - lo > 1)
+        {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (f.segments[mid].pair_begin <= s0)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        PgPlanSegment sg = f.segments[lo];
+        uint32_t ne = pairs_with_reads(sg);
+        uint32_t r = s0 - sg.pair_begin;
+        p = s0;
+        if ((r & 1u) || r + 1u >= ne)
+        {
+            // not s0: its neighbour, in this run or as the first pair of the next one
+            p = s0 + 1u;
+            if (2u * blockIdx.x + 1u >= a.n_pairs)
+                return;
+            if (p >= sg.pair_begin + sg.n_pairs)
+            {
+                if (lo + 1u >= f.n_segments)
+                    return;
+                sg = f.segments[lo + 1u];
+                ne = pairs_with_reads(sg);
+            }
+            r = p - sg.pair_begin;
+            if ((r & 1u) || r + 1u >= ne)
+                return;
+        }
+        partner = true;
+    }
+    else
+    {
+        const uint32_t k = f.seg_begin + (blockIdx.x - n_couple_groups);
+        const PgPlanSegment sg = f.segments[k];
+        const uint32_t ne = pairs_with_reads(sg);
+        if (!(ne & 1u))
+            return;
+        p = sg.pair_begin + ne - 1u;
+        partner = false;
+    }
+    const uint32_t i = p - pair0;
+    // ---- reversed-graph fills, both strands, of the couple's pairs
+    for (uint32_t j = 0; j < (partner ? 2u : 1u); ++j)
+    {
+        if (a.both_dirs == 7u)
+            break;  // (timing probe 7: the forward sweep only, on stale summaries)
+        pg_fill_body<C, 1, false, PG_GROUP_LANES>(a, i + j, lds, 0);
+        __syncthreads();
+    }
+    __threadfence_block();  // (this wavefront's own stores are in the L2 once vmcnt is 0, and what it reads back it reads with device-scope loads: an agent-scope fence would write the whole L2 back, every wavefront's trace stores included)
+    // ---- the pick: lane l < 8 looks at read (pair l >> 2, group l & 3)
+    const uint32_t lane = threadIdx.x;
+    const uint32_t j = (lane >> 2) & 1u, g = lane & 3u;
+    uint32_t ridx = PG_NONE;
+    int X = 0, mXr = 0, mYr = 0, SX = 0;
+    if (lane < 8u && (j == 0u || partner))
+    {
+        ridx = a.items[2 * (size_t)(p + j)].read[g];
+        if (ridx != PG_NONE)
+        {
+            const PgFillSummary* fsR = a.fillsum + ((size_t)(2 * (p + j) + 1) * PG_GROUPS + g) * 2;
+            const int SA = __hip_atomic_load(&fsR[0].score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int SB = __hip_atomic_load(&fsR[1].score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            X = SA >= SB ? 0 : 1;
+            SX = X ? SB : SA;
+            mXr = __hip_atomic_load(&fsR[X].multi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mYr = __hip_atomic_load(&fsR[1 - X].multi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    (void)SX;
+    const PgWorkItem* fw0 = a.items + 2 * (size_t)p;
+    PgInstItem* itX = f.inst + p;
+    uint32_t yl = PG_NONE;
+    if (lane == 0u)
+    {
+        itX->graph = fw0->graph;
+        itX->pad = 0;
+        itX->trace_off = fw0->trace_off;
+        itX->seed_off = fw0->seed_off;
+    }
+    const uint32_t x_of_group = (uint32_t)__shfl((int)X, (int)g);  // X of read g of the leader pair (lanes 0..3 hold it), for every lane
+    if (lane < 8u)
+    {
+        // X of (pair j, group g) -> half j; a lone pair's other strands -> half 1 (the plain forward fill of that pair)
+        uint32_t e = ridx == PG_NONE ? PG_NONE : (ridx | (X ? PG_INST_RC : 0u));
+        if (!partner && j == 1u)
+        {
+            // (lanes 4..7 of a lone pair: the other strand of read g of pair 0)
+            const uint32_t r0 = a.items[2 * (size_t)p].read[g];
+            e = r0 == PG_NONE ? PG_NONE : (r0 | (x_of_group ? 0u : PG_INST_RC));
+        }
+        itX->inst[j][g] = e;
+        if (!partner && j == 0u && ridx != PG_NONE)
+            yl = (p << 3) | (g << 1) | 1u;
+    }
+    __threadfence_block();
+    if (a.both_dirs == 6u)
+        return;  // (timing probe PG_LEAN_FUSED_PROBE=6: the reversed-graph sweeps and the pick only)
+    // ---- forward-graph fills of the X strands (and, for a lone pair, of the other strands beside them)
+    pg_fill_body<C, 0, false, PG_GROUP_LANES, true>(a, i, lds, 0);
+    __syncthreads();
+    __threadfence_block();
+    if (partner)
+    {
+        // ---- which other strands does a record still need?  (X not unique, Y not multi on the reversed graph.)  Their forward fills
+        // are queued as the instance item of the partner's slot -- this couple's own -- for the chunk's second, small forward launch, and
+        // the reads are listed for the traceback's second look; the first look passes them by (yloc's PENDING bit).  A third sweep HERE
+        // would be a third copy of the fill body in this kernel: 106 KB of code against an instruction cache of 64 KB, and every node
+        // boundary's rare path a miss -- 59 ms per million reads instead of 34 (profiles/r06_lean_fused_ab.jsonl).
+        bool need = false;
+        if (lane < 8u && ridx != PG_NONE)
+        {
+            const int mXf = __hip_atomic_load(&a.fillsum[((size_t)(2 * p) * PG_GROUPS + g) * 2 + j].multi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            need = (mXf || mXr) && !mYr;
+        }
+        const unsigned long long needs = __ballot(need);
+        const PgWorkItem* fw1 = a.items + 2 * (size_t)(p + 1u);
+        PgInstItem* itY = f.inst + (p + 1u);
+        if (lane == 0u)
+        {
+            itY->graph = fw1->graph;
+            itY->pad = needs != 0ull ? 1u : 0u;  // (1: an item of the second forward launch)
+            itY->trace_off = fw1->trace_off;
+            itY->seed_off = fw1->seed_off;
+        }
+        if (lane < 8u)
+        {
+            // slots in the order of the lanes: (half 0, group 0) first -- an item is empty iff that entry is
+            const uint32_t rank = (uint32_t)__popcll(needs & ((1ull << lane) - 1ull));
+            const uint32_t n_need = (uint32_t)__popcll(needs);
+            if (need)
+            {
+                itY->inst[rank >> 2][rank & 3u] = ridx | (X ? 0u : PG_INST_RC);
+                yl = ((p + 1u) << 3) | ((rank & 3u) << 1) | (rank >> 2) | PG_YLOC_PENDING;
+                f.ulist[atomicAdd(f.ucount, 1u)] = ((p + j) << 2) | g;
+            }
+            if (lane >= n_need)
+                itY->inst[lane >> 2][lane & 3u] = PG_NONE;
+        }
+    }
+    if (lane < 8u && ridx != PG_NONE)
+        f.yloc[ridx] = yl;
+}
+
+template <int C> static hipError_t launch_lean_fused_c(PgFillArgs args, const PgLeanFusedArgs& f, uint32_t n_pairs, hipStream_t stream)
+{
+    void (*fn)(PgFillArgs, PgLeanFusedArgs) = pg_fill_lean_fused_kernel<C>;
+    const size_t lds = (size_t)(64 * 4 * C) * sizeof(uint32_t);
+    static const uint32_t probe = [] {
+        const char* e = getenv("PG_LEAN_FUSED_PROBE");
+        return e ? (uint32_t)atoi(e) : 5u;
+    }();
+    args.both_dirs = probe;
+    args.n_pairs = n_pairs;
+    hipLaunchKernelGGL(fn, dim3((n_pairs + 1u) / 2u + f.n_seg), dim3(64), lds, stream, args, f);
+    return hipGetLastError();
+}
+
+hipError_t pg_launch_fill_lean_fused(int V, const PgFillArgs& args, const PgPlanSegment* segments, uint32_t n_segments, const uint32_t* group_count,
+                                     PgInstItem* inst, uint32_t* yloc, uint32_t* ucount, uint32_t* ulist, uint32_t seg_begin, uint32_t n_seg,
+                                     uint32_t n_pairs, hipStream_t stream)
+{
+    if (n_pairs == 0)
+        return hipSuccess;
+    PgLeanFusedArgs f{ segments, n_segments, group_count, inst, yloc, ucount, ulist, seg_begin, n_seg };
+    switch (V)
+    {
+    case 2: return launch_lean_fused_c<2>(args, f, n_pairs, stream);
+    case 4: return launch_lean_fused_c<4>(args, f, n_pairs, stream);
+    case 6: return launch_lean_fused_c<6>(args, f, n_pairs, stream);
+    case 8: return launch_lean_fused_c<8>(args, f, n_pairs, stream);
+    case 10: return launch_lean_fused_c<10>(args, f, n_pairs, stream);
+    case 12: return launch_lean_fused_c<12>(args, f, n_pairs, stream);
+    case 14: return launch_lean_fused_c<14>(args, f, n_pairs, stream);
+    case 16: return launch_lean_fused_c<16>(args, f, n_pairs, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 template <int C> static hipError_t launch_lean_c(PgFillArgs args, uint32_t n_pairs, int mode, hipStream_t stream)

@@ -98,6 +98,7 @@ struct pg_ctx
     // The lean gssw stage (pg_ctx_set_lean; on unless PG_LEAN=0): alignRead(AF_ALL) with three fills per read where four are not
     // needed (pg_batch_align)
     bool lean = true;
+    bool lean_fused = true;  // the lean stage in one launch per chunk (pg_fill_lean_fused_kernel); PG_LEAN_FUSED=0: the three-launch form
     uint64_t lean_min_cells_default = 30000000000ull;  // a chunk goes lean from this many cell updates (of its four fills per read) on: pg_batch_align
     uint64_t lean_min_cells = 30000000000ull;
     bool timing = false;

@@ -56,6 +56,7 @@ struct PgTraceArgs
     const uint32_t* group_count;
     uint32_t* ucount;                      // the chunk's list of reads for the second look, and its length
     uint32_t* ulist;
+    uint32_t fused;                        // the forward fills were made by pg_fill_lean_fused_kernel: X of (pair, read) sits in the leader pair's slot, half = the pair's parity in its run
 };
 
 // The lean pass's pick: one thread per work-item pair of a chunk, behind its reversed-graph fills (pg_api.hip)
@@ -80,4 +81,8 @@ hipError_t pg_launch_fill(int V, const PgFillArgs& args, uint32_t n_pairs, bool 
 // the lean pass (byte variants only): mode 2 = the reversed-graph fills of the work items, mode 3 = forward-graph fills of args.inst,
 // mode 4 = of those instance items only that the traceback's first look marked (PgInstItem::pad)
 hipError_t pg_launch_fill_lean(int V, const PgFillArgs& args, uint32_t n_pairs, int mode, hipStream_t stream);
+// the lean stage in one launch: reversed-graph fills, pick and forward-graph fills of two pairs per wavefront (pg_fill.hip)
+hipError_t pg_launch_fill_lean_fused(int V, const PgFillArgs& args, const PgPlanSegment* segments, uint32_t n_segments, const uint32_t* group_count,
+                                     PgInstItem* inst, uint32_t* yloc, uint32_t* ucount, uint32_t* ulist, uint32_t seg_begin, uint32_t n_seg,
+                                     uint32_t n_pairs, hipStream_t stream);
 hipError_t pg_launch_trace(const PgTraceArgs& args, hipStream_t stream);

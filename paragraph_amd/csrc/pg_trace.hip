@@ -203,11 +203,20 @@ template <int C, bool WIDE, int GL, bool LEAN = false> __device__ __forceinline_
                 hi = mid;
         }
         const uint32_t rs = a.segments[lo].pair_begin;
-        const uint32_t qX = rs + (pair - rs) / 2u, hX = (pair - rs) & 1u;
+        // (fused kernel: the couple's X strands sit in the LEADER pair's slot; launches of their own: item rs + rank / 2)
+        const uint32_t qX = a.fused ? rs + ((pair - rs) & ~1u) : rs + (pair - rs) / 2u, hX = (pair - rs) & 1u;
         const PgFillSummary fX = a.fillsum[((size_t)(2 * qX) * PG_GROUPS + grp) * 2 + hX];
         const int mXf = fX.multi, mXr = X ? m3 : m2, mYr = X ? m2 : m3;
         inconsistent = fX.score != (X ? SB : SA);
-        const uint32_t yl = a.yloc[ridx];
+        uint32_t yl = a.yloc[ridx];
+        if (yl != PG_NONE && (yl & PG_YLOC_PENDING))
+        {
+            // the fused kernel queued the other strand's forward fill for the chunk's second forward launch and listed the read: the
+            // first look passes it by, the second (slot_of_row given) finds the fill made
+            if (slot_of_row == PG_NONE)
+                return;
+            yl &= ~PG_YLOC_PENDING;
+        }
         int mYf = 0;
         PgFillSummary fY{};
         uint32_t qY = 0, gY = 0, hY = 0;
@@ -230,6 +239,12 @@ template <int C, bool WIDE, int GL, bool LEAN = false> __device__ __forceinline_
                 undecided = true;
             else if (!mYf)
                 ret = Y;
+        }
+        if (undecided && a.fused)
+        {
+            // (the fused kernel runs every forward fill a record needs before it ends: this cannot be)
+            undecided = false;
+            inconsistent = true;
         }
         if (undecided)
         {

@@ -246,10 +246,11 @@ def test_documented_limits_fail_loudly(gpu_ctx):
 
 
 @pytest.mark.parametrize("env", [{"PG_TRACE_BLOCKS": "0"}, {"PG_TRACE_BLOCKS": "7"}, {"PG_WIDE16": "1"}, {"PG_LEAN": "0"},
-                                 {"PG_LEAN": "0", "PG_TRACE_BLOCKS": "0"}, {"PG_LEAN_ONE_STREAM": "1"}])
+                                 {"PG_LEAN": "0", "PG_TRACE_BLOCKS": "0"}, {"PG_LEAN_FUSED": "0"}, {"PG_LEAN_FUSED": "0", "PG_LEAN_ONE_STREAM": "1"}])
 def test_launch_settings_do_not_change_results(env):
     """PG_LEAN=0: the plain gssw stage (four fills per read, all four multi flags) instead of the lean one this file's contexts run
-    by default; PG_LEAN_ONE_STREAM: the lean stage's forward launch on the fill stream.
+    by default; PG_LEAN_FUSED=0: the lean stage as three launches per chunk (reversed-graph fills, pick, forward-graph fills of instance items) instead of
+    the one fused launch; with PG_LEAN_ONE_STREAM its forward launch on the fill stream.
     The traceback walks its work-item pairs in a grid-stride loop of a bounded number of wavefronts (PG_TRACE_BLOCKS; 0 = one
     wavefront per pair), and PG_WIDE16 selects the 16-lane kernels for reads of 251-512 bases: the settings are read once per
     process, so each one gets a process of its own running the read-length, word-mode and fuzz tests of this file."""

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 PG_HEAD=r06-lean bash tools/pmc_collect.sh r06 > $O/pmc.log 2>&1; echo "pmc rc=$?"
 PG_HEAD=r06-lean bash tools/sq_collect.sh > $O/sq.log 2>&1; echo "sq rc=$?"
 python tools/pmc_traffic.py gpurun_out/pmc_r06 $O/traffic_r06.json > /dev/null 2> $O/traffic.err; echo "traffic rc=$?"; tail -2 $O/traffic.err
-python tools/sq_summary.py gpurun_out/sq $O/r06_sq_counters.json 200000 "pg_fill_lean_kernel<10" 518 1.5 > /dev/null 2> $O/sqsum.err; echo "sqsum rc=$?"; tail -2 $O/sqsum.err
+python tools/sq_summary.py gpurun_out/sq $O/r06_sq_counters.json 200000 "pg_fill_lean" 518 1.5 > /dev/null 2> $O/sqsum.err; echo "sqsum rc=$?"; tail -2 $O/sqsum.err
 bash tools/stage_counters.sh 200000 > $O/stage_counters.log 2>&1; echo "stage counters rc=$?"
 python tools/stage_counters_summary.py gpurun_out/stage_counters $O/r06_stage_counters.json 200000 > $O/stage_counters_summary.txt 2> $O/stage_counters_summary.err; echo "summary rc=$?"; cat $O/stage_counters_summary.txt
 cd /tmp

@@ -50,8 +50,9 @@ def main(src, dst, n_reads):
         out["kernels"][k] = {"launches": n, "fetch_bytes": f, "write_bytes": w,
                              "hbm_bytes_per_read": (f + w) / n_reads, "hbm_bytes_per_launch": (f + w) / max(n, 1)}
     # the fill kernels of the run together: pg_fill_kernel (plain stage), or the lean stage's pg_fill_lean_kernel<C, 2> (reversed-graph
-    # fills) + <C, 3> (forward-graph fills of the instance items; the second, small launch of the fourth fills included)
-    fills = {k: v for k, v in out["kernels"].items() if "pg_fill_kernel" in k or "pg_fill_lean_kernel" in k}
+    # fills) + <C, 3> (forward-graph fills of the instance items; the second, small launch of the fourth fills included), or its fused
+    # form pg_fill_lean_fused_kernel<C> (+ <C, 3> for the second, small launch)
+    fills = {k: v for k, v in out["kernels"].items() if "pg_fill_kernel" in k or "pg_fill_lean" in k}
     out["fill_kernels"] = sorted(fills)
     out["hbm_bytes_per_read"] = sum(v["hbm_bytes_per_read"] for v in fills.values())
     out["hbm_bytes_per_launch"] = sum(v["fetch_bytes"] + v["write_bytes"] for v in fills.values()) / max(1, max(v["launches"] for v in fills.values()))

@@ -2432,6 +2432,49 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
         if (ws2 != PG_OK)
             return ws2;
     }
+    // (the lean stage's decision and its preparations -- the work items re-made as the full plan's slots, which can change the chunks and
+    //  grow the workspace -- BEFORE the regions are cut and the side streams are told to wait for the main one: a fill on the second fill
+    //  stream must not start before the list and item kernels queued here are done)
+    const bool revg_early = (flags & PG_AF_REVERSE_GRAPH) != 0;
+    const uint64_t lean_min_cells = ctx->lean_min_cells;
+    const auto lean_chunk_ok = [&](const Chunk& ch) { return !pg_var_wide(ch.C) && ch.cells >= lean_min_cells; };
+    bool lean = ctx->lean && (flags & PG_AF_CIGAR) && (flags & PG_AF_BOTH_STRANDS) && revg_early && !b->has_general_reads && b->gen_idx.empty()
+        && b->n_reads && !b->groups.empty();
+    if (lean)
+    {
+        lean = false;
+        for (const Chunk& ch : b->chunks)
+            lean = lean || lean_chunk_ok(ch);
+    }
+    if (lean)
+    {
+        if (!b->device_plan)
+        {
+            const pg_status rp = cascade_rebuild_items(ctx, b, ctx->stream, b->has_active ? b->d_active : nullptr);
+            if (rp != PG_OK)
+                return rp;
+            const pg_status ws3 = ensure_ctx_workspace(ctx, b);
+            if (ws3 != PG_OK)
+                return ws3;
+        }
+        if (b->full_pairs > b->cap_lean_pairs || b->n_reads > b->cap_lean_reads)
+        {
+            b->park(b->d_inst);
+            b->park(b->d_lean_extra);
+            b->park(b->d_yloc);
+            b->park(b->d_lean_ucount);
+            b->park(b->d_lean_ulist);
+            b->d_inst = nullptr;
+            b->d_lean_extra = b->d_yloc = b->d_lean_ucount = b->d_lean_ulist = nullptr;
+            b->cap_lean_pairs = b->full_pairs + b->full_pairs / 8 + 16;
+            b->cap_lean_reads = (size_t)b->n_reads + b->n_reads / 8 + 16;
+            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_inst, b->cap_lean_pairs * sizeof(PgInstItem)));
+            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_lean_extra, b->cap_lean_pairs * sizeof(uint32_t)));
+            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_yloc, b->cap_lean_reads * sizeof(uint32_t)));
+            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_lean_ucount, b->cap_lean_pairs * sizeof(uint32_t)));
+            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_lean_ulist, 4 * b->cap_lean_pairs * sizeof(uint32_t)));
+        }
+    }
     if ((!(flags & PG_AF_KEEP_RESULTS) || (flags == PG_AF_ALL)) && !b->ops_counter_fresh)
         HIP_TRY(ctx, hipMemsetAsync(b->d_ops_counter, 0, sizeof(unsigned long long), ctx->stream));
     b->ops_counter_fresh = false;
@@ -2657,44 +2700,8 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     // (profiles/r06_lean_e2e_ab.jsonl); the headline's chunks (150 G cell updates) and those of 250-base reads on kilobase nodes
     // (120 G in 6 000 pairs) gain a fifth and a tenth.  The bound: 30 G cell updates of the plain stage, a launch of some 5 ms
     // (pg_ctx_set_lean(ctx, 2) / PG_LEAN_MIN_CELLS: other bounds).
-    const uint64_t lean_min_cells = ctx->lean_min_cells;
-    const auto lean_chunk_ok = [&](const Chunk& ch) { return !pg_var_wide(ch.C) && ch.cells >= lean_min_cells; };
-    bool lean = ctx->lean && (flags & PG_AF_CIGAR) && (flags & PG_AF_BOTH_STRANDS) && revg && !b->has_general_reads && b->gen_idx.empty()
-        && b->n_reads && !b->groups.empty();
     if (lean)
     {
-        lean = false;
-        for (const Chunk& ch : b->chunks)
-            lean = lean || lean_chunk_ok(ch);
-    }
-    if (lean)
-    {
-        if (!b->device_plan)
-        {
-            const pg_status rp = cascade_rebuild_items(ctx, b, ctx->stream, b->has_active ? b->d_active : nullptr);
-            if (rp != PG_OK)
-                return rp;
-            const pg_status ws3 = ensure_ctx_workspace(ctx, b);
-            if (ws3 != PG_OK)
-                return ws3;
-        }
-        if (b->full_pairs > b->cap_lean_pairs || b->n_reads > b->cap_lean_reads)
-        {
-            b->park(b->d_inst);
-            b->park(b->d_lean_extra);
-            b->park(b->d_yloc);
-            b->park(b->d_lean_ucount);
-            b->park(b->d_lean_ulist);
-            b->d_inst = nullptr;
-            b->d_lean_extra = b->d_yloc = b->d_lean_ucount = b->d_lean_ulist = nullptr;
-            b->cap_lean_pairs = b->full_pairs + b->full_pairs / 8 + 16;
-            b->cap_lean_reads = (size_t)b->n_reads + b->n_reads / 8 + 16;
-            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_inst, b->cap_lean_pairs * sizeof(PgInstItem)));
-            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_lean_extra, b->cap_lean_pairs * sizeof(uint32_t)));
-            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_yloc, b->cap_lean_reads * sizeof(uint32_t)));
-            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_lean_ucount, b->cap_lean_pairs * sizeof(uint32_t)));
-            HIP_TRY(ctx, pg_dev_alloc((void**)&b->d_lean_ulist, 4 * b->cap_lean_pairs * sizeof(uint32_t)));
-        }
         for (const Chunk& ch : b->chunks)
         {
             const pg_status cs = run_chunk(ch, lean_chunk_ok(ch));

@@ -975,7 +975,8 @@ template <int C> __global__ __launch_bounds__(64) void pg_fill_lean_fused_kernel
         pg_fill_body<C, 1, false, PG_GROUP_LANES>(a, i + j, lds, 0);
         __syncthreads();
     }
-    __threadfence_block();  // (this wavefront's own stores are in the L2 once vmcnt is 0, and what it reads back it reads with device-scope loads: an agent-scope fence would write the whole L2 back, every wavefront's trace stores included)
+    __threadfence_block();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wavefront's own stores are in the L2 once vmcnt is 0, and what it reads back it reads with device-scope loads: an agent-scope fence would write the whole L2 back, every wavefront's trace stores included)
     // ---- the pick: lane l < 8 looks at read (pair l >> 2, group l & 3)
     const uint32_t lane = threadIdx.x;
     const uint32_t j = (lane >> 2) & 1u, g = lane & 3u;
@@ -1022,12 +1023,14 @@ template <int C> __global__ __launch_bounds__(64) void pg_fill_lean_fused_kernel
             yl = (p << 3) | (g << 1) | 1u;
     }
     __threadfence_block();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (a.both_dirs == 6u)
         return;  // (timing probe PG_LEAN_FUSED_PROBE=6: the reversed-graph sweeps and the pick only)
     // ---- forward-graph fills of the X strands (and, for a lone pair, of the other strands beside them)
     pg_fill_body<C, 0, false, PG_GROUP_LANES, true>(a, i, lds, 0);
     __syncthreads();
     __threadfence_block();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (partner)
     {
         // ---- which other strands does a record still need?  (X not unique, Y not multi on the reversed graph.)  Their forward fills

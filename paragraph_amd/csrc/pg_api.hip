@@ -2685,11 +2685,13 @@ extern "C" pg_status pg_batch_align(pg_ctx* ctx, pg_batch* b, uint32_t flags)
     // alignRead(AF_ALL) asks for four fills per read and reads one record off them (GraphAligner.cpp:340-401).  A fill's best score is the
     // same on the graph and on the reversed graph, so the reversed-graph fills of both strands (scores + their two multi flags, no
     // trace) already say which strand X scores higher, and the record only ever needs the forward-graph fill of the OTHER strand when
-    // X turns out not to be unique while that strand still may be.  Pass 1, per chunk: reversed-graph fills of every read; a pick
-    // kernel packs the X strands -- eight reads' worth per wavefront, one per (16-lane group, register half) -- and the other strands
-    // that are already known to be needed into instance items; forward-graph fills of those; pick + traceback.  The reads this cannot
-    // decide (X not unique because of its own forward fill; a per cent or two) get the other strand's instance queued by the traceback
-    // itself; a second, small forward launch and a second look at those reads follow on the SECOND stream, under the next chunk's fills.
+    // X turns out not to be unique while that strand still may be.  Per chunk, ONE launch (pg_fill_lean_fused_kernel, pg_fill.hip): a
+    // wavefront takes two work-item pairs of a run through their reversed-graph sweeps, the pick, and the forward-graph sweep of their
+    // eight X strands (one per (16-lane group, register half): an instance item); the other strands a record still needs -- known from
+    // the reversed-graph fills, or found by X's own forward fill -- it queues for a second, small forward launch, which follows the
+    // traceback's first look on the SECOND stream together with a second look at those reads, under the next chunk's fills.  (ctx->
+    // lean_fused off: the stage's first form, three launches per chunk -- reversed-graph fills of every work item, a pick kernel that
+    // packs the instances, the forward-graph fills of the instance items on a stream of their own.)
     // Same records as the plain stage field by field, except multi_mask's bit of a forward fill that did not run
     // (PG_MULTI_OTHER_FWD_SKIPPED says so).  Byte variants (reads <= 250 bases); other chunks run the plain stage.
     // A chunk takes the lean route when its launches are long: the one launch of all four fills becomes two dependent ones of a half

@@ -119,6 +119,7 @@ def parse_args():
     ap.add_argument("--plain-steps", type=int, default=2,
                     help="timed steps of the reported-only leg `plain_stage` (the headline workload through the plain gssw stage, four fills "
                          "per read, and the lean step's records against its records); 0 = leave it out")
+    ap.add_argument("--shortcut-in-process", action="store_true", help=argparse.SUPPRESS)  # (the child of the exact_shortcut leg)
     ap.add_argument("--no-e2e-shortcut", action="store_true", help="leave the e2e leg's `with_exact_shortcut` passes out (A/B of the legs behind them)")
     ap.add_argument("--e2e-steps", type=int, default=3,
                     help="timed passes of the BAM -> genotypes leg (0 = skip): every pass takes ALL sites of the e2e data set from the "
@@ -1578,7 +1579,28 @@ def run_config2(args, env, ctx, capi, synth, site, arr, dist_info):
     # read is aligned as in the plain step.  Compared with the plain step's output on every read: all fields of the reference's
     # Read (position, score, MAPQ, uniqueness, strand, CIGAR elements) and the whole count table.
     shortcut = None
-    if args.exact_shortcut_steps > 0 and L <= 250 and world == 1:  # (N = 1 only, like the streaming leg: `tab` is the reduced table at N > 1)
+    if args.exact_shortcut_steps > 0 and L <= 250 and world == 1 and not args.shortcut_in_process:
+        # In a process of its own: the leg's path stages make the context's second seed stream, and what that leaves with the HIP runtime
+        # of THIS process outlives the context -- the e2e leg behind it then read 72 k instead of 78 k sites/s, its all-four-stages pass
+        # 22 k instead of 30 k (profiles/r06_shortcut_leg_in_process_ab.jsonl).  The child runs the same batch (same seed) through the
+        # lean stage once, then the leg, and compares the two itself.
+        cmd = [sys.executable, os.path.abspath(__file__), "--shortcut-in-process", "--reads", str(args.reads), "--read-len", str(L), "--steps", "1",
+               "--warmup", "1", "--plain-steps", "0", "--no-cpu-baseline", "--sites-steps", "0", "--config5-graphs", "0", "--e2e-steps", "0",
+               "--stream-batches", "0", "--collective", "off", "--exact-shortcut-steps", str(args.exact_shortcut_steps), "--workspace-gib", "64"]
+        cenv = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            cenv.pop(k, None)
+        try:
+            pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=cenv, timeout=600)
+            child = json.loads([l for l in pr.stdout.decode().splitlines() if l.startswith("{")][-1])
+            shortcut = child.get("exact_shortcut")
+            if shortcut:
+                shortcut["in_a_process_of_its_own"] = True
+                shortcut["lean_step_of_that_process_reads_per_s"] = child.get("value")
+        except Exception as e:  # noqa: BLE001
+            shortcut = None
+            log("exact_shortcut child failed: %s" % e)
+    if args.exact_shortcut_steps > 0 and L <= 250 and world == 1 and args.shortcut_in_process:  # (N = 1 only, like the streaming leg: `tab` is the reduced table at N > 1)
         t0 = time.perf_counter()
         graphs.build_path_index(32)
         t_index = time.perf_counter() - t0

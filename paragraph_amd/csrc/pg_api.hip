@@ -121,19 +121,56 @@ hipError_t pg_dev_free(void* p)
     if (!p)
         return hipSuccess;
     DevCache& dc = dev_cache();
+    // A full cache makes room by letting its LARGEST idle blocks go, not by refusing the block in hand: what fills it are the blocks
+    // of large batches that are over (a million-read batch leaves gigabytes behind), what a workflow cycles through per batch are
+    // kilobytes to megabytes -- with the cache closed to them every one would go through hipFree (a device synchronisation) and
+    // hipMalloc.
+    std::vector<void*> victims;
+    bool cached = false;
     {
         std::lock_guard<std::mutex> lock(dc.m);
         auto it = dc.class_of.find(p);
-        if (it != dc.class_of.end() && dc.idle_bytes + it->second <= PG_DEV_CACHE_MAX_IDLE)
+        if (it != dc.class_of.end() && it->second <= PG_DEV_CACHE_MAX_IDLE / 2)
         {
-            dc.idle[it->second].push_back(p);
-            dc.idle_bytes += it->second;
-            return hipSuccess;
+            const size_t c = it->second;
+            while (dc.idle_bytes + c > PG_DEV_CACHE_MAX_IDLE)
+            {
+                size_t big = 0;
+                for (auto& kv : dc.idle)
+                    if (!kv.second.empty() && kv.first > big)
+                        big = kv.first;
+                if (big <= c)
+                    break;  // (nothing larger than this block left to let go)
+                std::vector<void*>& v = dc.idle[big];
+                victims.push_back(v.back());
+                dc.class_of.erase(v.back());
+                v.pop_back();
+                dc.idle_bytes -= big;
+            }
+            if (dc.idle_bytes + c <= PG_DEV_CACHE_MAX_IDLE)
+            {
+                dc.idle[c].push_back(p);
+                dc.idle_bytes += c;
+                cached = true;
+            }
         }
-        if (it != dc.class_of.end())
+        if (!cached && it != dc.class_of.end())
             dc.class_of.erase(it);
     }
-    return hipFree(p);
+    hipError_t e = hipSuccess;
+    for (void* v : victims)
+    {
+        const hipError_t ev = hipFree(v);
+        if (e == hipSuccess)
+            e = ev;
+    }
+    if (!cached)
+    {
+        const hipError_t ep = hipFree(p);
+        if (e == hipSuccess)
+            e = ep;
+    }
+    return e;
 }
 
 void pg_dev_cache_release()

@@ -461,7 +461,7 @@ def test_klib_cigar_pool_is_used_and_its_exhaustion_is_loud(gpu_ctx, monkeypatch
     nodes, ps = _site(rng, 3, 330)
     nodes = [n.replace("N", "A") for n in nodes]
     reads = []
-    for _ in range(120):
+    for _ in range(200):
         seq = "".join(nodes[x] for x in rng.choice(ps))
         st = rng.randrange(max(1, len(seq) - 300))
         r = list(seq[st:st + 300])
@@ -473,7 +473,8 @@ def test_klib_cigar_pool_is_used_and_its_exhaustion_is_loud(gpu_ctx, monkeypatch
         r = "".join(r)[:320]
         reads.append(_rc(r) if rng.random() < 0.5 else r)
     want = chk.align(nodes, ps, reads)
-    assert sum(1 for w in want if w["status"] == 1 and w["cigar"].count("I") + w["cigar"].count("D") >= 12) > 20
+    # (that the data reaches the pool at all; how many reads keep a dozen indels in their best alignment depends on the salt: 18 - 45 of 120)
+    assert sum(1 for w in want if w["status"] == 1 and w["cigar"].count("I") + w["cigar"].count("D") >= 12) > 12
     flags, got = gpu_klib(gpu_ctx, [(nodes, edges_of(ps))], [ps], reads, None, expect_packed=True)
     check(flags, got, want, reads, "klib-pool")
     monkeypatch.setenv("PG_KLIB_CIG_POOL", "0")
